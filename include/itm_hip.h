@@ -1,0 +1,275 @@
+/*
+ * itm_hip.h -- C-ABI of the MI355X-native TSDF allocate / integrate / raycast path.
+ *
+ * This is the drop-in boundary: one flat `extern "C"` surface (plain pointers, sizes and POD
+ * structs, no C++/torch types) that a fourth InfiniTAM back-end ("HIP", next to CPU/CUDA/Metal in
+ * InfiniTAM/ITMLib/Engine/DeviceSpecific/) binds to.  Every entry point names the reference
+ * method it replaces (paths relative to /root/reference/InfiniTAM/ITMLib).
+ *
+ * Conventions
+ *  - All image / map pointers are DEVICE pointers for libitmhip.so (HBM), valid on `stream`'s
+ *    device.  Nothing is synchronised implicitly except itm_get_counters / itm_download_* /
+ *    itm_stream_synchronize; every other call only enqueues work on `stream` (a hipStream_t
+ *    passed as void*; NULL = the default stream).
+ *  - Matrices are 4x4 float, column-major `m[col*4+row]` exactly as ORUtils::Matrix4
+ *    (ORUtils/Matrix.h:23-33,78); poses are world->camera.
+ *  - Intrinsics are (fx, fy, cx, cy) = ITMIntrinsics::projectionParamsSimple.all
+ *    (Objects/ITMIntrinsics.h:20-40).
+ *  - Memory layouts of ITMHashEntry, ITMVoxel_{s,f,s_rgb,f_rgb}, Vector2f/4f/4u images are
+ *    byte-identical to the reference (Utils/ITMLibDefines.h:71-199), so dumps compare 1:1.
+ *  - Return value: 0 = ok, negative = ITM_ERR_*.  The reference's engines are `void` and
+ *    exit(-1) on device errors (ORUtils/CUDADefines.h:27-36); the C++ adapter maps non-zero to
+ *    std::runtime_error.  Pool exhaustion is NOT an error: blocks are silently skipped as in
+ *    DeviceSpecific/CPU/ITMSceneReconstructionEngine_CPU.cpp:189,206.
+ *
+ * The same header is compiled with a different ITM_FN prefix by the test oracle (oracle/) so that
+ * the parity tests can drive the oracle and the product through one binding; the product library
+ * exports the `itm_` names only.
+ */
+#ifndef ITM_HIP_H_
+#define ITM_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifndef ITM_FN
+#define ITM_FN(name) itm_##name
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes -------------------------------------------------------------------------- */
+#define ITM_OK 0
+#define ITM_ERR_INVALID -1      /* bad argument / unsupported configuration            */
+#define ITM_ERR_DEVICE -2       /* HIP runtime error (message via itm_last_error)      */
+#define ITM_ERR_UNSUPPORTED -3  /* valid in the reference, not available in this build */
+
+/* ---- compile-time constants of the reference kept as defaults ---------------------------- */
+#define ITM_SDF_BLOCK_SIZE 8            /* Utils/ITMLibDefines.h:37 */
+#define ITM_SDF_BLOCK_SIZE3 512         /* :38 */
+#define ITM_DEFAULT_LOCAL_BLOCK_NUM 0x10000 /* :40  (fork value; upstream 0x40000)     */
+#define ITM_DEFAULT_BUCKET_NUM 0x100000 /* :51 */
+#define ITM_DEFAULT_EXCESS_NUM 0x20000  /* :60 */
+#define ITM_MAX_RENDERING_BLOCKS (65536 * 4) /* DeviceAgnostic/ITMVisualisationEngine.h:24 */
+
+/* TVoxel / TIndex template parameters of the reference become runtime enums. */
+enum itm_voxel_type {
+  ITM_VOXEL_S = 0,     /* ITMVoxel_s      4 B  {i16 sdf; u8 w_depth; pad}           :153-174 */
+  ITM_VOXEL_F = 1,     /* ITMVoxel_f      8 B  {f32 sdf; u8 w_depth; pad[3]}        :176-197 */
+  ITM_VOXEL_S_RGB = 2, /* ITMVoxel_s_rgb  8 B  {i16 sdf; u8 w; u8 clr[3]; u8 w_color; pad}   */
+  ITM_VOXEL_F_RGB = 3  /* ITMVoxel_f_rgb 12 B  {f32 sdf; u8 w; u8 clr[3]; u8 w_color; pad[3]} */
+};
+enum itm_index_type {
+  ITM_INDEX_HASH = 0,  /* ITMVoxelBlockHash   Objects/ITMVoxelBlockHash.h:22-100  */
+  ITM_INDEX_DENSE = 1  /* ITMPlainVoxelArray  Objects/ITMPlainVoxelArray.h:18-75  */
+};
+/* IITMVisualisationEngine::RenderImageType, Engine/ITMVisualisationEngine.h:21-26 */
+enum itm_render_type {
+  ITM_RENDER_SHADED_GREYSCALE = 0,
+  ITM_RENDER_COLOUR_FROM_VOLUME = 1,
+  ITM_RENDER_COLOUR_FROM_NORMAL = 2
+};
+
+/* ITMSceneParams, Objects/ITMSceneParams.h:14-70 (defaults Utils/ITMLibSettings.cpp:10). */
+typedef struct itm_scene_params {
+  float voxelSize;
+  float mu;
+  int32_t maxW;
+  float viewFrustum_min;
+  float viewFrustum_max;
+  int32_t stopIntegratingAtMaxW;
+} itm_scene_params;
+
+/* What `new ITMScene<TVoxel,TIndex>(params, useSwapping=false, memoryType)` fixes at compile
+ * time in the reference (Objects/ITMScene.h:37-43, ITMVoxelBlockHash.h:35-36,
+ * ITMPlainVoxelArray.h:24-37) is a runtime configuration here.  0 = reference default. */
+typedef struct itm_scene_config {
+  int32_t voxelType;      /* enum itm_voxel_type */
+  int32_t indexType;      /* enum itm_index_type */
+  int32_t bucketNum;      /* SDF_BUCKET_NUM, power of two   */
+  int32_t excessNum;      /* SDF_EXCESS_LIST_SIZE           */
+  int32_t localBlockNum;  /* SDF_LOCAL_BLOCK_NUM            */
+  int32_t denseSize[3];   /* ITMVoxelArrayInfo::size   (default 512^3)          */
+  int32_t denseOffset[3]; /* ITMVoxelArrayInfo::offset (default -256,-256,0)    */
+  int32_t denseOffsetSet; /* non-zero: use denseOffset even if it is all zero   */
+} itm_scene_config;
+
+/* The inputs an engine method takes from `const ITMView*` and `const ITMTrackingState*`:
+ * view->depth, view->rgb, view->calib->{intrinsics_d, intrinsics_rgb, trafo_rgb_to_depth} and
+ * trackingState->pose_d->GetM()  (Objects/ITMView.h:16-52, Objects/ITMTrackingState.h:18-75). */
+typedef struct itm_view {
+  const float* depth;      /* float[h*w] metres, <=0 invalid (ITMViewBuilder output)   */
+  const uint8_t* rgb;      /* uchar4[h_rgb*w_rgb] RGBA; may be NULL for colourless voxels */
+  int32_t w, h;            /* view->depth->noDims */
+  int32_t w_rgb, h_rgb;    /* view->rgb->noDims   */
+  float M_d[16];           /* trackingState->pose_d->GetM()             */
+  float intr_d[4];         /* calib->intrinsics_d.projectionParamsSimple.all   */
+  float intr_rgb[4];       /* calib->intrinsics_rgb.projectionParamsSimple.all */
+  float rgb_to_depth[16];     /* calib->trafo_rgb_to_depth.calib      (Objects/ITMExtrinsics.h) */
+  float rgb_to_depth_inv[16]; /* calib->trafo_rgb_to_depth.calib_inv                            */
+} itm_view;
+
+/* Host-visible scalars the reference keeps as members: ITMLocalVBA::lastFreeBlockId,
+ * ITMVoxelBlockHash::lastFreeExcessListId, ITMRenderState_VH::noVisibleEntries,
+ * ITMRenderState::noFwdProjMissingPoints, ITMPointCloud::noTotalPoints. */
+typedef struct itm_counters {
+  int32_t lastFreeBlockId;
+  int32_t lastFreeExcessListId;
+  int32_t noVisibleEntries;
+  int32_t noFwdProjMissingPoints;
+  int32_t noTotalPoints;
+  int32_t noRenderingBlocks;   /* numRenderingBlocks of the last CreateExpectedDepths */
+  int32_t noAllocRequests;     /* blocks requested by the last AllocateSceneFromDepth */
+  int32_t statusFlags;         /* bit0: alloc key overflow (too many ray steps)       */
+} itm_counters;
+
+/* buffers addressable by itm_download / itm_upload (parity dumps, checkpoints) */
+enum itm_buffer {
+  ITM_BUF_HASH_ENTRIES = 0,     /* ITMHashEntry[bucketNum+excessNum]   scene->index.GetEntries() */
+  ITM_BUF_EXCESS_LIST = 1,      /* int[excessNum]                      GetExcessAllocationList() */
+  ITM_BUF_VOXEL_BLOCKS = 2,     /* TVoxel[localBlockNum*512 | sx*sy*sz] localVBA.GetVoxelBlocks() */
+  ITM_BUF_ALLOCATION_LIST = 3,  /* int[localBlockNum]                  localVBA.GetAllocationList() */
+  ITM_BUF_VISIBLE_IDS = 4,      /* int[localBlockNum]   renderState_vh->GetVisibleEntryIDs()   */
+  ITM_BUF_VISIBLE_TYPE = 5,     /* uchar[noTotalEntries] renderState_vh->GetEntriesVisibleType() */
+  ITM_BUF_RANGE_IMAGE = 6,      /* Vector2f[h*w]  renderState->renderingRangeImage  */
+  ITM_BUF_RAYCAST_RESULT = 7,   /* Vector4f[h*w]  renderState->raycastResult        */
+  ITM_BUF_RAYCAST_IMAGE = 8,    /* Vector4u[h*w]  renderState->raycastImage         */
+  ITM_BUF_FORWARD_PROJECTION = 9, /* Vector4f[h*w] renderState->forwardProjection   */
+  ITM_BUF_MISSING_POINTS = 10   /* int[h*w]       renderState->fwdProjMissingPoints */
+};
+
+typedef struct itm_scene itm_scene;               /* ITMScene<TVoxel,TIndex> + engine scratch */
+typedef struct itm_render_state itm_render_state; /* ITMRenderState / ITMRenderState_VH       */
+typedef void* itm_stream;                         /* hipStream_t */
+
+/* ---- library ------------------------------------------------------------------------------ */
+const char* ITM_FN(version)(void);
+const char* ITM_FN(last_error)(void);
+/* 1 for the product (device pointers), 0 for a host-memory implementation of this ABI. */
+int ITM_FN(uses_device_memory)(void);
+size_t ITM_FN(voxel_size_bytes)(int voxelType);
+
+/* ---- device memory helpers (so a C / ctypes caller needs no other runtime) ---------------- */
+int ITM_FN(dev_malloc)(void** ptr, size_t bytes);
+int ITM_FN(dev_free)(void* ptr);
+int ITM_FN(memcpy_h2d)(void* dst_dev, const void* src_host, size_t bytes, itm_stream stream);
+int ITM_FN(memcpy_d2h)(void* dst_host, const void* src_dev, size_t bytes, itm_stream stream);
+int ITM_FN(stream_synchronize)(itm_stream stream);
+int ITM_FN(set_device)(int device);
+
+/* ---- scene -------------------------------------------------------------------------------- */
+/* new ITMScene<TVoxel,TIndex>(sceneParams,false,memType)  Objects/ITMScene.h:37-43 ; also
+ * allocates the engine scratch of ITMSceneReconstructionEngine_CPU ctor
+ * (DeviceSpecific/CPU/ITMSceneReconstructionEngine_CPU.cpp:9-15). Does NOT reset. */
+int ITM_FN(scene_create)(const itm_scene_config* cfg, const itm_scene_params* params,
+                         itm_scene** out);
+int ITM_FN(scene_destroy)(itm_scene* scene);
+int ITM_FN(scene_get_config)(const itm_scene* scene, itm_scene_config* cfg,
+                             itm_scene_params* params);
+
+/* ITMSceneReconstructionEngine::ResetScene            Engine/ITMSceneReconstructionEngine.h:35
+ * (CPU: DeviceSpecific/CPU/ITMSceneReconstructionEngine_CPU.cpp:24-45 hash, :301-312 dense) */
+int ITM_FN(reset_scene)(itm_scene* scene, itm_stream stream);
+
+/* ITMVisualisationEngine::CreateRenderState(imgSize)   Engine/ITMVisualisationEngine.h:79
+ * (CPU: DeviceSpecific/CPU/ITMVisualisationEngine_CPU.cpp:18-32; ITMRenderState ctor fills the
+ * range image with (vf_min, vf_max), Objects/ITMRenderState.h:51-75) */
+int ITM_FN(render_state_create)(const itm_scene* scene, int w, int h, itm_render_state** out);
+int ITM_FN(render_state_destroy)(itm_render_state* rs);
+
+/* ITMSceneReconstructionEngine::AllocateSceneFromDepth(scene, view, trackingState, renderState,
+ * onlyUpdateVisibleList)                               Engine/ITMSceneReconstructionEngine.h:40
+ * (CPU hash :116-291, dense :314-317 no-op) */
+int ITM_FN(allocate_scene_from_depth)(itm_scene* scene, const itm_view* view,
+                                      itm_render_state* rs, int onlyUpdateVisibleList,
+                                      itm_stream stream);
+
+/* ITMSceneReconstructionEngine::IntegrateIntoScene     Engine/ITMSceneReconstructionEngine.h:46
+ * (CPU hash :47-114, dense :319-369) */
+int ITM_FN(integrate_into_scene)(itm_scene* scene, const itm_view* view, itm_render_state* rs,
+                                 itm_stream stream);
+
+/* IITMVisualisationEngine::FindVisibleBlocks(pose, intrinsics, renderState)          :39
+ * (CPU :39-77; dense: no-op :34-37) */
+int ITM_FN(find_visible_blocks)(const itm_scene* scene, const float M[16], const float intr[4],
+                                itm_render_state* rs, itm_stream stream);
+
+/* IITMVisualisationEngine::CreateExpectedDepths(pose, intrinsics, renderState)       :45
+ * (CPU hash :93-152, dense :79-91) */
+int ITM_FN(create_expected_depths)(const itm_scene* scene, const float M[16],
+                                   const float intr[4], itm_render_state* rs, itm_stream stream);
+
+/* IITMVisualisationEngine::RenderImage(pose, intrinsics, renderState, outputImage, type) :49
+ * (CPU :190-240, :356-368).  out_rgba: uchar4[h*w] device pointer; NULL = rs->raycastImage. */
+int ITM_FN(render_image)(const itm_scene* scene, const float M[16], const float intr[4],
+                         itm_render_state* rs, uint8_t* out_rgba, int type, itm_stream stream);
+
+/* IITMVisualisationEngine::FindSurface(pose, intrinsics, renderState)               :53
+ * (CPU :370-381): raycast only, result in rs->raycastResult. */
+int ITM_FN(find_surface)(const itm_scene* scene, const float M[16], const float intr[4],
+                         itm_render_state* rs, itm_stream stream);
+
+/* IITMVisualisationEngine::CreatePointCloud(view, trackingState, renderState, skipPoints) :58
+ * (CPU :242-264, :424-462).  locations/colours: Vector4f[h*w] = trackingState->pointCloud;
+ * count is left in itm_counters::noTotalPoints. */
+int ITM_FN(create_point_cloud)(const itm_scene* scene, const itm_view* view,
+                               itm_render_state* rs, int skipPoints, float* locations,
+                               float* colours, itm_stream stream);
+
+/* IITMVisualisationEngine::CreateICPMaps(view, trackingState, renderState)          :63
+ * (CPU :266-287).  points/normals: Vector4f[h*w] = trackingState->pointCloud->locations /
+ * ->colours.  Grey rendering goes to rs->raycastImage. */
+int ITM_FN(create_icp_maps)(const itm_scene* scene, const itm_view* view, itm_render_state* rs,
+                            float* points, float* normals, itm_stream stream);
+
+/* IITMVisualisationEngine::ForwardRender(view, trackingState, renderState)          :70
+ * (CPU :289-354) */
+int ITM_FN(forward_render)(const itm_scene* scene, const itm_view* view, itm_render_state* rs,
+                           itm_stream stream);
+
+/* The per-frame call sequence of ITMMainEngine::ProcessFrame after the view is built
+ * (Engine/ITMMainEngine.cpp:123-126): ITMDenseMapper::ProcessFrame (Engine/ITMDenseMapper.cpp:
+ * 50-65: AllocateSceneFromDepth + IntegrateIntoScene) followed by
+ * ITMTrackingController::Prepare with requiresFullRendering (Engine/ITMTrackingController.cpp:
+ * 31-35: CreateExpectedDepths + CreateICPMaps).  Results are identical to issuing the four calls
+ * one after another; this entry point only removes launch overhead. */
+int ITM_FN(process_frame)(itm_scene* scene, const itm_view* view, itm_render_state* rs,
+                          float* points, float* normals, itm_stream stream);
+
+/* ---- view builder (the step before the path) -------------------------------- */
+/* convertDepthAffineToFloat  DeviceAgnostic/ITMViewBuilder.h:22-28 */
+int ITM_FN(convert_depth_affine)(const int16_t* raw, float* depth_out, int w, int h, float a,
+                                 float b, itm_stream stream);
+/* convertDisparityToDepth    DeviceAgnostic/ITMViewBuilder.h:7-20 */
+int ITM_FN(convert_disparity)(const int16_t* raw, float* depth_out, int w, int h, float c0,
+                              float c1, float fx_depth, itm_stream stream);
+
+/* ---- state access ------------------------------------------------------------------------- */
+/* Blocks until `stream` has drained, then reads the device-side counters. */
+int ITM_FN(get_counters)(const itm_scene* scene, const itm_render_state* rs, itm_counters* out,
+                         itm_stream stream);
+/* Restores counters (checkpoint / test set-up).  Only lastFreeBlockId, lastFreeExcessListId,
+ * noVisibleEntries are taken from `in`. */
+int ITM_FN(set_counters)(itm_scene* scene, itm_render_state* rs, const itm_counters* in,
+                         itm_stream stream);
+size_t ITM_FN(buffer_bytes)(const itm_scene* scene, const itm_render_state* rs, int which);
+/* Synchronous copies of whole buffers between host memory and the scene / render state. */
+int ITM_FN(download)(const itm_scene* scene, const itm_render_state* rs, int which, void* dst_host,
+                     size_t bytes, itm_stream stream);
+int ITM_FN(upload)(itm_scene* scene, itm_render_state* rs, int which, const void* src_host,
+                   size_t bytes, itm_stream stream);
+/* Device address of a buffer (zero-copy hand-off to e.g. a collective); NULL if absent. */
+void* ITM_FN(buffer_ptr)(const itm_scene* scene, const itm_render_state* rs, int which);
+
+/* Fixed-size record for the multi-stream exchange: writes
+ * {float M_d[16]; int32 noVisibleEntries; int32 ids[max_ids]} (padded with -1) to `dst`
+ * (device memory, (17+max_ids)*4 bytes) on `stream`, without a host round-trip. */
+int ITM_FN(export_visible_record)(const itm_render_state* rs, const float M_d[16], int max_ids,
+                                  void* dst, itm_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ITM_HIP_H_ */

@@ -1,0 +1,1202 @@
+// itm_oracle.cpp -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+// Single-threaded CPU restatement of the InfiniTAM allocate / integrate / raycast path, written
+// from the reference's behaviour (not its text) so that the HIP kernels can be checked against
+// something that runs everywhere (the reference itself cannot travel to the GPU box).
+// It implements the same C-ABI as include/itm_hip.h with the prefix `itmo_` and HOST pointers.
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+// The product (infinitam_amd/, libitmhip.so) never includes, links or calls anything in oracle/.
+//
+// Parity status: PINNED.  The reference ships no tests or golden vectors, so
+// this restatement is pinned against the reference's own CPU engines compiled from
+// /root/reference by oracle/Makefile (target `ref`, output oracle/_ref/libitm_ref.so) --
+// tests/test_oracle_vs_reference.py compares them bit-for-bit where /root/reference exists --
+// and against fixtures generated from that build (tests/golden/, tests/golden/make_golden.py).
+//
+// Build: g++ -O2 -ffp-contract=off (no -march=native, no fast-math, no OpenMP): float results
+// must not depend on contraction.  All arithmetic is fp32 in the operation order documented in
+// SURVEY.md Appendix A; each function cites the reference lines it follows
+// (paths relative to /root/reference/InfiniTAM/ITMLib).
+
+#define ITM_FN(name) itmo_##name
+#include "../include/itm_hip.h"
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const char* msg) { g_err = msg; return code; }
+
+// ------------------------------------------------------------------------------------------
+// POD layouts (Utils/ITMLibDefines.h:71-82, :100-199).  Padding bytes are zeroed here; the
+// reference leaves them uninitialised, so comparisons are field-wise.
+// ------------------------------------------------------------------------------------------
+struct HashEntry { int16_t px, py, pz, pad; int32_t offset; int32_t ptr; };
+static_assert(sizeof(HashEntry) == 16, "ITMHashEntry is 16 bytes");
+
+struct VoxS   { int16_t sdf; uint8_t w; uint8_t pad; };
+struct VoxF   { float sdf; uint8_t w; uint8_t pad[3]; };
+struct VoxSC  { int16_t sdf; uint8_t w; uint8_t clr[3]; uint8_t wc; uint8_t pad; };
+struct VoxFC  { float sdf; uint8_t w; uint8_t clr[3]; uint8_t wc; uint8_t pad[3]; };
+static_assert(sizeof(VoxS) == 4 && sizeof(VoxF) == 8 && sizeof(VoxSC) == 8 && sizeof(VoxFC) == 12, "voxel sizes");
+
+// voxel codec traits: SDF_valueToFloat / SDF_floatToValue / SDF_initialValue / hasColorInformation
+template <class V> struct Codec;
+template <> struct Codec<VoxS> {
+  static constexpr bool color = false;
+  static float toF(float raw) { return raw / 32767.0f; }
+  static int16_t toV(float f) { return (int16_t)(f * 32767.0f); }
+  static VoxS init() { VoxS v; std::memset(&v, 0, sizeof v); v.sdf = 32767; return v; }
+};
+template <> struct Codec<VoxSC> {
+  static constexpr bool color = true;
+  static float toF(float raw) { return raw / 32767.0f; }
+  static int16_t toV(float f) { return (int16_t)(f * 32767.0f); }
+  static VoxSC init() { VoxSC v; std::memset(&v, 0, sizeof v); v.sdf = 32767; return v; }
+};
+template <> struct Codec<VoxF> {
+  static constexpr bool color = false;
+  static float toF(float raw) { return raw; }
+  static float toV(float f) { return f; }
+  static VoxF init() { VoxF v; std::memset(&v, 0, sizeof v); v.sdf = 1.0f; return v; }
+};
+template <> struct Codec<VoxFC> {
+  static constexpr bool color = true;
+  static float toF(float raw) { return raw; }
+  static float toV(float f) { return f; }
+  static VoxFC init() { VoxFC v; std::memset(&v, 0, sizeof v); v.sdf = 1.0f; return v; }
+};
+
+struct V2f { float x, y; };
+struct V4f { float x, y, z, w; };
+struct V3f { float x, y, z; };
+struct V3i { int x, y, z; };
+
+inline float fmin_ref(float a, float b) { return (a < b) ? a : b; }   // MIN  ORUtils/MathUtils.h:5-7
+inline float fmax_ref(float a, float b) { return (a < b) ? b : a; }   // MAX  :9-11
+inline float round_ref(float x) { return (x < 0) ? (x - 0.5f) : (x + 0.5f); }  // ROUND :21-23
+
+// Matrix4 * Vector4, ORUtils/Matrix.h:115-122: left-to-right sum of four products per row.
+inline V4f mul(const float* m, const V4f& v) {
+  V4f r;
+  r.x = m[0] * v.x + m[4] * v.y + m[8] * v.z + m[12] * v.w;
+  r.y = m[1] * v.x + m[5] * v.y + m[9] * v.z + m[13] * v.w;
+  r.z = m[2] * v.x + m[6] * v.y + m[10] * v.z + m[14] * v.w;
+  r.w = m[3] * v.x + m[7] * v.y + m[11] * v.z + m[15] * v.w;
+  return r;
+}
+
+// Matrix4 * Matrix4, ORUtils/Matrix.h:102-108: r(col,row) accumulated from zero over k.
+void matmul4(const float* lhs, const float* rhs, float* out) {
+  for (int col = 0; col < 4; ++col)
+    for (int row = 0; row < 4; ++row) {
+      float acc = 0.0f;
+      for (int k = 0; k < 4; ++k) acc += lhs[k * 4 + row] * rhs[col * 4 + k];
+      out[col * 4 + row] = acc;
+    }
+}
+
+// Matrix4::inv, ORUtils/Matrix.h:162-223: cofactor expansion on the transposed matrix, every
+// element finally multiplied by 1/det.  `p3` is the left-to-right sum of three products.
+inline float p3(float a, float b, float c, float d, float e, float f) { return a * b + c * d + e * f; }
+bool invert4(const float* m, float* dst) {
+  float s[16], t[12];
+  for (int i = 0; i < 4; ++i) { s[i] = m[i * 4]; s[i + 4] = m[i * 4 + 1]; s[i + 8] = m[i * 4 + 2]; s[i + 12] = m[i * 4 + 3]; }
+  t[0] = s[10] * s[15]; t[1] = s[11] * s[14]; t[2] = s[9] * s[15];  t[3] = s[11] * s[13];
+  t[4] = s[9] * s[14];  t[5] = s[10] * s[13]; t[6] = s[8] * s[15];  t[7] = s[11] * s[12];
+  t[8] = s[8] * s[14];  t[9] = s[10] * s[12]; t[10] = s[8] * s[13]; t[11] = s[9] * s[12];
+  dst[0] = p3(t[0], s[5], t[3], s[6], t[4], s[7]) - p3(t[1], s[5], t[2], s[6], t[5], s[7]);
+  dst[1] = p3(t[1], s[4], t[6], s[6], t[9], s[7]) - p3(t[0], s[4], t[7], s[6], t[8], s[7]);
+  dst[2] = p3(t[2], s[4], t[7], s[5], t[10], s[7]) - p3(t[3], s[4], t[6], s[5], t[11], s[7]);
+  dst[3] = p3(t[5], s[4], t[8], s[5], t[11], s[6]) - p3(t[4], s[4], t[9], s[5], t[10], s[6]);
+  float det = s[0] * dst[0] + s[1] * dst[1] + s[2] * dst[2] + s[3] * dst[3];
+  if (det == 0.0f) return false;
+  dst[4] = p3(t[1], s[1], t[2], s[2], t[5], s[3]) - p3(t[0], s[1], t[3], s[2], t[4], s[3]);
+  dst[5] = p3(t[0], s[0], t[7], s[2], t[8], s[3]) - p3(t[1], s[0], t[6], s[2], t[9], s[3]);
+  dst[6] = p3(t[3], s[0], t[6], s[1], t[11], s[3]) - p3(t[2], s[0], t[7], s[1], t[10], s[3]);
+  dst[7] = p3(t[4], s[0], t[9], s[1], t[10], s[2]) - p3(t[5], s[0], t[8], s[1], t[11], s[2]);
+  t[0] = s[2] * s[7]; t[1] = s[3] * s[6]; t[2] = s[1] * s[7];  t[3] = s[3] * s[5];
+  t[4] = s[1] * s[6]; t[5] = s[2] * s[5]; t[6] = s[0] * s[7];  t[7] = s[3] * s[4];
+  t[8] = s[0] * s[6]; t[9] = s[2] * s[4]; t[10] = s[0] * s[5]; t[11] = s[1] * s[4];
+  dst[8] = p3(t[0], s[13], t[3], s[14], t[4], s[15]) - p3(t[1], s[13], t[2], s[14], t[5], s[15]);
+  dst[9] = p3(t[1], s[12], t[6], s[14], t[9], s[15]) - p3(t[0], s[12], t[7], s[14], t[8], s[15]);
+  dst[10] = p3(t[2], s[12], t[7], s[13], t[10], s[15]) - p3(t[3], s[12], t[6], s[13], t[11], s[15]);
+  dst[11] = p3(t[5], s[12], t[8], s[13], t[11], s[14]) - p3(t[4], s[12], t[9], s[13], t[10], s[14]);
+  dst[12] = p3(t[2], s[10], t[5], s[11], t[1], s[9]) - p3(t[4], s[11], t[0], s[9], t[3], s[10]);
+  dst[13] = p3(t[8], s[11], t[0], s[8], t[7], s[10]) - p3(t[6], s[10], t[9], s[11], t[1], s[8]);
+  dst[14] = p3(t[6], s[9], t[11], s[11], t[3], s[8]) - p3(t[10], s[11], t[2], s[8], t[7], s[9]);
+  dst[15] = p3(t[10], s[10], t[4], s[8], t[9], s[9]) - p3(t[8], s[9], t[11], s[10], t[5], s[8]);
+  float rdet = 1 / det;
+  for (int i = 0; i < 16; ++i) dst[i] *= rdet;
+  return true;
+}
+
+// hashIndex, DeviceAgnostic/ITMRepresentationAccess.h:8-10 (coordinates sign-extend to uint32)
+inline int hash_index(int bx, int by, int bz, uint32_t mask) {
+  return (int)((((uint32_t)bx * 73856093u) ^ ((uint32_t)by * 19349669u) ^ ((uint32_t)bz * 83492791u)) & mask);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// opaque objects
+// ------------------------------------------------------------------------------------------
+struct itm_scene {
+  itm_scene_config cfg;
+  itm_scene_params prm;
+  size_t voxBytes;
+  int noTotalEntries;
+  std::vector<HashEntry> hash;       // scene->index.GetEntries()
+  std::vector<int32_t> excessList;   // GetExcessAllocationList()
+  std::vector<uint8_t> vba;          // localVBA.GetVoxelBlocks()
+  std::vector<int32_t> allocList;    // localVBA.GetAllocationList()
+  int lastFreeBlockId = 0, lastFreeExcessListId = 0;
+  // engine scratch (ITMSceneReconstructionEngine_CPU members)
+  std::vector<uint8_t> allocType;
+  std::vector<int16_t> blockCoords;  // 4 shorts per slot
+  int noAllocRequests = 0;
+  size_t numVoxels() const {
+    return cfg.indexType == ITM_INDEX_HASH ? (size_t)cfg.localBlockNum * 512
+                                           : (size_t)cfg.denseSize[0] * cfg.denseSize[1] * cfg.denseSize[2];
+  }
+};
+
+struct itm_render_state {
+  int w, h;
+  bool hash;
+  int capIds;
+  std::vector<V2f> range;        // renderingRangeImage
+  std::vector<V4f> raycast;      // raycastResult
+  std::vector<V4f> fwdProj;      // forwardProjection
+  std::vector<int32_t> missing;  // fwdProjMissingPoints
+  std::vector<uint32_t> image;   // raycastImage (uchar4)
+  std::vector<int32_t> visibleIds;
+  std::vector<uint8_t> visibleType;
+  int noVisibleEntries = 0, noFwdProjMissingPoints = 0, noTotalPoints = 0, noRenderingBlocks = 0;
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// voxel access: readVoxel for the hash (DeviceAgnostic/ITMRepresentationAccess.h:85-119, block
+// decomposition :12-20, IndexCache Objects/ITMVoxelBlockHash.h:27-33) and for the dense array
+// (:61-77, :129-135).
+// ------------------------------------------------------------------------------------------
+struct BlockCache { int bx = 0x7fffffff, by = 0x7fffffff, bz = 0x7fffffff; int base = -1; };
+
+inline int floor_div8(int p) { return ((p < 0) ? p - 7 : p) / 8; }
+
+template <class V>
+struct Reader {
+  const itm_scene* sc;
+  const V* vox;
+  bool dense;
+  uint32_t mask;
+  explicit Reader(const itm_scene* s) : sc(s), vox((const V*)s->vba.data()), dense(s->cfg.indexType == ITM_INDEX_DENSE), mask((uint32_t)s->cfg.bucketNum - 1u) {}
+
+  V read(int px, int py, int pz, bool& found, BlockCache& cache) const {
+    if (dense) {
+      int qx = px - sc->cfg.denseOffset[0], qy = py - sc->cfg.denseOffset[1], qz = pz - sc->cfg.denseOffset[2];
+      const int* sz = sc->cfg.denseSize;
+      if (qx < 0 || qx >= sz[0] || qy < 0 || qy >= sz[1] || qz < 0 || qz >= sz[2]) { found = false; return Codec<V>::init(); }
+      found = true;
+      return vox[qx + qy * sz[0] + qz * sz[0] * sz[1]];
+    }
+    int bx = floor_div8(px), by = floor_div8(py), bz = floor_div8(pz);
+    // the reference's expression, kept in int arithmetic (equals the in-block linear index)
+    int lin = px + (py - bx) * 8 + (pz - by) * 64 - bz * 512;
+    if (bx == cache.bx && by == cache.by && bz == cache.bz) { found = true; return vox[cache.base + lin]; }
+    int idx = hash_index(bx, by, bz, mask);
+    for (;;) {
+      const HashEntry& e = sc->hash[idx];
+      if (e.px == bx && e.py == by && e.pz == bz && e.ptr >= 0) {
+        found = true;
+        cache.bx = bx; cache.by = by; cache.bz = bz; cache.base = e.ptr * 512;
+        return vox[cache.base + lin];
+      }
+      if (e.offset < 1) break;
+      idx = sc->cfg.bucketNum + e.offset - 1;
+    }
+    found = false;
+    return Codec<V>::init();
+  }
+  V read(int px, int py, int pz, bool& found) const { BlockCache c; return read(px, py, pz, found, c); }
+
+  // readFromSDF_float_uninterpolated :153-159
+  float nearest(const V3f& p, bool& found, BlockCache& cache) const {
+    V v = read((int)round_ref(p.x), (int)round_ref(p.y), (int)round_ref(p.z), found, cache);
+    return Codec<V>::toF((float)v.sdf);
+  }
+  // readFromSDF_float_interpolated :161-185 (raw values blended, then converted; found := true)
+  float trilinear(const V3f& p, bool& found, BlockCache& cache) const {
+    float fx = std::floor(p.x), fy = std::floor(p.y), fz = std::floor(p.z);
+    float cx = p.x - fx, cy = p.y - fy, cz = p.z - fz;
+    int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+    float v1, v2, r1, r2;
+    v1 = (float)read(ix, iy, iz, found, cache).sdf;
+    v2 = (float)read(ix + 1, iy, iz, found, cache).sdf;
+    r1 = (1.0f - cx) * v1 + cx * v2;
+    v1 = (float)read(ix, iy + 1, iz, found, cache).sdf;
+    v2 = (float)read(ix + 1, iy + 1, iz, found, cache).sdf;
+    r1 = (1.0f - cy) * r1 + cy * ((1.0f - cx) * v1 + cx * v2);
+    v1 = (float)read(ix, iy, iz + 1, found, cache).sdf;
+    v2 = (float)read(ix + 1, iy, iz + 1, found, cache).sdf;
+    r2 = (1.0f - cx) * v1 + cx * v2;
+    v1 = (float)read(ix, iy + 1, iz + 1, found, cache).sdf;
+    v2 = (float)read(ix + 1, iy + 1, iz + 1, found, cache).sdf;
+    r2 = (1.0f - cy) * r2 + cy * ((1.0f - cx) * v1 + cx * v2);
+    found = true;
+    return Codec<V>::toF((1.0f - cz) * r1 + cz * r2);
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// ResetScene   DeviceSpecific/CPU/ITMSceneReconstructionEngine_CPU.cpp:24-45 / :301-312
+// ------------------------------------------------------------------------------------------
+template <class V>
+void reset_scene_t(itm_scene* s) {
+  V* vox = (V*)s->vba.data();
+  V init = Codec<V>::init();
+  size_t n = s->numVoxels();
+  for (size_t i = 0; i < n; ++i) vox[i] = init;
+  int nb = (s->cfg.indexType == ITM_INDEX_HASH) ? s->cfg.localBlockNum : 1;
+  for (int i = 0; i < nb; ++i) s->allocList[i] = i;
+  s->lastFreeBlockId = nb - 1;
+  if (s->cfg.indexType == ITM_INDEX_HASH) {
+    HashEntry e; std::memset(&e, 0, sizeof e); e.ptr = -2;
+    for (int i = 0; i < s->noTotalEntries; ++i) s->hash[i] = e;
+    for (int i = 0; i < s->cfg.excessNum; ++i) s->excessList[i] = i;
+    s->lastFreeExcessListId = s->cfg.excessNum - 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// per-voxel fusion
+//   computeUpdatedVoxelDepthInfo  DeviceAgnostic/ITMSceneReconstructionEngine.h:9-56
+//   computeUpdatedVoxelColorInfo  :58-100 ; gate :121-139 ; interpolateBilinear
+//   DeviceAgnostic/ITMPixelUtils.h:11-39
+// ------------------------------------------------------------------------------------------
+struct FuseCtx {
+  float M_d[16], M_rgb[16];
+  float fx, fy, cx, cy;          // depth intrinsics
+  float fxc, fyc, cxc, cyc;      // rgb intrinsics
+  float mu; int maxW;
+  const float* depth; const uint8_t* rgb;
+  int w, h, wc, hc;
+  bool stopAtMax;
+};
+
+template <class V>
+inline float fuse_depth(V& vox, const V4f& pm, const FuseCtx& c) {
+  V4f pc = mul(c.M_d, pm);
+  if (pc.z <= 0) return -1;
+  float u = c.fx * pc.x / pc.z + c.cx;
+  float v = c.fy * pc.y / pc.z + c.cy;
+  if ((u < 1) || (u > c.w - 2) || (v < 1) || (v > c.h - 2)) return -1;
+  float dm = c.depth[(int)(u + 0.5f) + (int)(v + 0.5f) * c.w];
+  if (dm <= 0.0) return -1;
+  float eta = dm - pc.z;
+  if (eta < -c.mu) return eta;
+  float oldF = Codec<V>::toF((float)vox.sdf);
+  int oldW = vox.w;
+  float newF = fmin_ref(1.0f, eta / c.mu);
+  int newW = 1;
+  newF = oldW * oldF + newW * newF;
+  newW = oldW + newW;
+  newF /= newW;
+  newW = (newW < c.maxW) ? newW : c.maxW;
+  vox.sdf = Codec<V>::toV(newF);
+  vox.w = (uint8_t)newW;
+  return eta;
+}
+
+template <class V>
+inline void fuse_colour(V& vox, const V4f& pm, const FuseCtx& c) {
+  float oldW = (float)vox.wc;
+  float oc[3] = {(float)vox.clr[0] / 255.0f, (float)vox.clr[1] / 255.0f, (float)vox.clr[2] / 255.0f};
+  V4f pc = mul(c.M_rgb, pm);
+  float u = c.fxc * pc.x / pc.z + c.cxc;
+  float v = c.fyc * pc.y / pc.z + c.cyc;
+  if ((u < 1) || (u > c.wc - 2) || (v < 1) || (v > c.hc - 2)) return;
+  // bilinear tap pattern: b/c/d are only read when their weight can be non-zero
+  int px = (int)std::floor(u), py = (int)std::floor(v);
+  float dx = u - (float)px, dy = v - (float)py;
+  const uint8_t* A = c.rgb + 4 * ((size_t)px + (size_t)py * c.wc);
+  uint8_t zero[4] = {0, 0, 0, 0};
+  const uint8_t* B = zero; const uint8_t* C = zero; const uint8_t* D = zero;
+  if (dx != 0) B = c.rgb + 4 * ((size_t)(px + 1) + (size_t)py * c.wc);
+  if (dy != 0) C = c.rgb + 4 * ((size_t)px + (size_t)(py + 1) * c.wc);
+  if (dx != 0 && dy != 0) D = c.rgb + 4 * ((size_t)(px + 1) + (size_t)(py + 1) * c.wc);
+  float meas[3];
+  for (int k = 0; k < 3; ++k) {
+    float r = ((float)A[k] * (1.0f - dx) * (1.0f - dy) + (float)B[k] * dx * (1.0f - dy) +
+               (float)C[k] * (1.0f - dx) * dy + (float)D[k] * dx * dy);
+    meas[k] = r / 255.0f;
+  }
+  float newW = 1;
+  float nc[3];
+  for (int k = 0; k < 3; ++k) nc[k] = oc[k] * oldW + meas[k] * newW;
+  newW = oldW + newW;
+  for (int k = 0; k < 3; ++k) nc[k] /= newW;
+  uint8_t maxWu = (uint8_t)c.maxW;
+  newW = (newW < maxWu) ? newW : (float)maxWu;
+  for (int k = 0; k < 3; ++k) {
+    int vi = (int)round_ref(nc[k] * 255.0f);
+    int lo = (vi < 255) ? vi : 255;           // MIN(255, vi)
+    vox.clr[k] = (uint8_t)((0 < lo) ? lo : 0);  // MAX(0, .)
+  }
+  vox.wc = (uint8_t)newW;
+}
+
+template <class V, bool C = Codec<V>::color> struct Fuse;
+template <class V> struct Fuse<V, false> {
+  static void run(V& vox, const V4f& pm, const FuseCtx& c) { fuse_depth(vox, pm, c); }
+};
+template <class V> struct Fuse<V, true> {
+  static void run(V& vox, const V4f& pm, const FuseCtx& c) {
+    float eta = fuse_depth(vox, pm, c);
+    if ((eta > c.mu) || (std::fabs(eta / c.mu) > 0.25f)) return;
+    fuse_colour(vox, pm, c);
+  }
+};
+
+void make_fuse_ctx(const itm_scene* s, const itm_view* v, FuseCtx& c) {
+  std::memcpy(c.M_d, v->M_d, sizeof c.M_d);
+  matmul4(v->rgb_to_depth_inv, v->M_d, c.M_rgb);   // calib_inv * M_d  (_CPU.cpp:61)
+  c.fx = v->intr_d[0]; c.fy = v->intr_d[1]; c.cx = v->intr_d[2]; c.cy = v->intr_d[3];
+  c.fxc = v->intr_rgb[0]; c.fyc = v->intr_rgb[1]; c.cxc = v->intr_rgb[2]; c.cyc = v->intr_rgb[3];
+  c.mu = s->prm.mu; c.maxW = s->prm.maxW;
+  c.depth = v->depth; c.rgb = v->rgb;
+  c.w = v->w; c.h = v->h; c.wc = v->w_rgb; c.hc = v->h_rgb;
+  c.stopAtMax = s->prm.stopIntegratingAtMaxW != 0;
+}
+
+// IntegrateIntoScene  hash: _CPU.cpp:47-114 ; dense: :319-369
+template <class V>
+void integrate_t(itm_scene* s, const itm_view* view, itm_render_state* rs) {
+  FuseCtx c; make_fuse_ctx(s, view, c);
+  V* vox = (V*)s->vba.data();
+  float vs = s->prm.voxelSize;
+  if (s->cfg.indexType == ITM_INDEX_HASH) {
+    for (int e = 0; e < rs->noVisibleEntries; ++e) {
+      const HashEntry& he = s->hash[rs->visibleIds[e]];
+      if (he.ptr < 0) continue;
+      int gx = he.px * 8, gy = he.py * 8, gz = he.pz * 8;
+      V* blk = vox + (size_t)he.ptr * 512;
+      for (int z = 0; z < 8; ++z) for (int y = 0; y < 8; ++y) for (int x = 0; x < 8; ++x) {
+        int loc = x + y * 8 + z * 64;
+        if (c.stopAtMax && blk[loc].w == c.maxW) continue;
+        V4f pm = {(float)(gx + x) * vs, (float)(gy + y) * vs, (float)(gz + z) * vs, 1.0f};
+        Fuse<V>::run(blk[loc], pm, c);
+      }
+    }
+  } else {
+    const int* sz = s->cfg.denseSize; const int* off = s->cfg.denseOffset;
+    size_t n = s->numVoxels();
+    for (size_t loc = 0; loc < n; ++loc) {
+      int z = (int)(loc / ((size_t)sz[0] * sz[1]));
+      int tmp = (int)(loc - (size_t)z * sz[0] * sz[1]);
+      int y = tmp / sz[0];
+      int x = tmp - y * sz[0];
+      if (c.stopAtMax && vox[loc].w == c.maxW) continue;
+      V4f pm = {(float)(x + off[0]) * vs, (float)(y + off[1]) * vs, (float)(z + off[2]) * vs, 1.0f};
+      Fuse<V>::run(vox[loc], pm, c);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// block frustum test: checkBlockVisibility<false> / checkPointVisibility<false>
+// DeviceAgnostic/ITMSceneReconstructionEngine.h:243-342.  Corners are visited through
+// incremental +-factor updates (the accumulated rounding is part of the behaviour).
+// ------------------------------------------------------------------------------------------
+inline bool corner_visible(const V4f& p, const float* M, const float* intr, int w, int h) {
+  V4f q = mul(M, p);
+  if (q.z < 1e-10f) return false;
+  float u = intr[0] * q.x / q.z + intr[2];
+  float v = intr[1] * q.y / q.z + intr[3];
+  return (u >= 0 && u < w && v >= 0 && v < h);
+}
+bool block_visible(const HashEntry& e, const float* M, const float* intr, float voxelSize, int w, int h) {
+  float f = (float)ITM_SDF_BLOCK_SIZE * voxelSize;
+  V4f p = {(float)e.px * f, (float)e.py * f, (float)e.pz * f, 1.0f};
+  if (corner_visible(p, M, intr, w, h)) return true;   // 0 0 0
+  p.z += f; if (corner_visible(p, M, intr, w, h)) return true;   // 0 0 1
+  p.y += f; if (corner_visible(p, M, intr, w, h)) return true;   // 0 1 1
+  p.x += f; if (corner_visible(p, M, intr, w, h)) return true;   // 1 1 1
+  p.z -= f; if (corner_visible(p, M, intr, w, h)) return true;   // 1 1 0
+  p.y -= f; if (corner_visible(p, M, intr, w, h)) return true;   // 1 0 0
+  p.x -= f; p.y += f; if (corner_visible(p, M, intr, w, h)) return true;   // 0 1 0
+  p.x += f; p.y -= f; p.z += f; if (corner_visible(p, M, intr, w, h)) return true;   // 1 0 1
+  return false;
+}
+
+// ------------------------------------------------------------------------------------------
+// AllocateSceneFromDepth (hash)  _CPU.cpp:116-291 with buildHashAllocAndVisibleTypePP
+// DeviceAgnostic/ITMSceneReconstructionEngine.h:141-241 (useSwapping == false)
+// ------------------------------------------------------------------------------------------
+void allocate_hash(itm_scene* s, const itm_view* view, itm_render_state* rs, bool onlyUpdateVisibleList) {
+  const int W = view->w, H = view->h;
+  const float vs = s->prm.voxelSize, mu = s->prm.mu;
+  float invM[16];
+  invert4(view->M_d, invM);
+  const float ifx = 1.0f / view->intr_d[0], ify = 1.0f / view->intr_d[1];
+  const float cx = view->intr_d[2], cy = view->intr_d[3];
+  const float oneOverBlock = 1.0f / (vs * ITM_SDF_BLOCK_SIZE);
+  const float vfmin = s->prm.viewFrustum_min, vfmax = s->prm.viewFrustum_max;
+  const uint32_t mask = (uint32_t)s->cfg.bucketNum - 1u;
+  const int BN = s->cfg.bucketNum;
+  HashEntry* table = s->hash.data();
+  uint8_t* visT = rs->visibleType.data();
+  uint8_t* allocT = s->allocType.data();
+  int16_t* coords = s->blockCoords.data();
+
+  int lastFreeVBA = s->lastFreeBlockId, lastFreeExcess = s->lastFreeExcessListId;
+  std::memset(allocT, 0, (size_t)s->noTotalEntries);
+  for (int i = 0; i < rs->noVisibleEntries; ++i) visT[rs->visibleIds[i]] = 3;
+
+  for (int loc = 0; loc < W * H; ++loc) {
+    int y = loc / W, x = loc - y * W;
+    float d = view->depth[x + y * W];
+    if (d <= 0 || (d - mu) < 0 || (d - mu) < vfmin || (d + mu) > vfmax) continue;
+    V3f p; p.z = d; p.x = p.z * (((float)x - cx) * ifx); p.y = p.z * (((float)y - cy) * ify);
+    float norm = std::sqrt(p.x * p.x + p.y * p.y + p.z * p.z);
+    V4f a = {p.x * (1.0f - mu / norm), p.y * (1.0f - mu / norm), p.z * (1.0f - mu / norm), 1.0f};
+    V4f ta = mul(invM, a);
+    V3f pt = {ta.x * oneOverBlock, ta.y * oneOverBlock, ta.z * oneOverBlock};
+    V4f b = {p.x * (1.0f + mu / norm), p.y * (1.0f + mu / norm), p.z * (1.0f + mu / norm), 1.0f};
+    V4f tb = mul(invM, b);
+    V3f pe = {tb.x * oneOverBlock, tb.y * oneOverBlock, tb.z * oneOverBlock};
+    V3f dir = {pe.x - pt.x, pe.y - pt.y, pe.z - pt.z};
+    norm = std::sqrt(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
+    int noSteps = (int)std::ceil(2.0f * norm);
+    float div = (float)(noSteps - 1);
+    dir.x /= div; dir.y /= div; dir.z /= div;
+    for (int i = 0; i < noSteps; ++i) {
+      int16_t bx = (int16_t)std::floor(pt.x), by = (int16_t)std::floor(pt.y), bz = (int16_t)std::floor(pt.z);
+      int idx = hash_index(bx, by, bz, mask);
+      bool isFound = false;
+      HashEntry he = table[idx];
+      if (he.px == bx && he.py == by && he.pz == bz && he.ptr >= -1) {
+        visT[idx] = (he.ptr == -1) ? 2 : 1;
+        isFound = true;
+      }
+      if (!isFound) {
+        bool isExcess = false;
+        if (he.ptr >= -1) {
+          while (he.offset >= 1) {
+            idx = BN + he.offset - 1;
+            he = table[idx];
+            if (he.px == bx && he.py == by && he.pz == bz && he.ptr >= -1) {
+              visT[idx] = (he.ptr == -1) ? 2 : 1;
+              isFound = true;
+              break;
+            }
+          }
+          isExcess = true;
+        }
+        if (!isFound) {
+          allocT[idx] = isExcess ? 2 : 1;
+          if (!isExcess) visT[idx] = 1;
+          coords[idx * 4 + 0] = bx; coords[idx * 4 + 1] = by; coords[idx * 4 + 2] = bz; coords[idx * 4 + 3] = 1;
+        }
+      }
+      pt.x += dir.x; pt.y += dir.y; pt.z += dir.z;
+    }
+  }
+
+  int requests = 0;
+  if (!onlyUpdateVisibleList) {
+    for (int t = 0; t < s->noTotalEntries; ++t) {
+      uint8_t type = allocT[t];
+      if (type == 1) {
+        ++requests;
+        int vbaIdx = lastFreeVBA; lastFreeVBA--;
+        if (vbaIdx >= 0) {
+          HashEntry e; std::memset(&e, 0, sizeof e);
+          e.px = coords[t * 4]; e.py = coords[t * 4 + 1]; e.pz = coords[t * 4 + 2];
+          e.ptr = s->allocList[vbaIdx]; e.offset = 0;
+          table[t] = e;
+        }
+      } else if (type == 2) {
+        ++requests;
+        int vbaIdx = lastFreeVBA; lastFreeVBA--;
+        int exlIdx = lastFreeExcess; lastFreeExcess--;
+        if (vbaIdx >= 0 && exlIdx >= 0) {
+          HashEntry e; std::memset(&e, 0, sizeof e);
+          e.px = coords[t * 4]; e.py = coords[t * 4 + 1]; e.pz = coords[t * 4 + 2];
+          e.ptr = s->allocList[vbaIdx]; e.offset = 0;
+          int exlOffset = s->excessList[exlIdx];
+          table[t].offset = exlOffset + 1;
+          table[BN + exlOffset] = e;
+          visT[BN + exlOffset] = 1;
+        }
+      }
+    }
+  }
+  s->noAllocRequests = requests;
+
+  int nv = 0;
+  for (int t = 0; t < s->noTotalEntries; ++t) {
+    uint8_t vt = visT[t];
+    if (vt == 3) {
+      if (!block_visible(table[t], view->M_d, view->intr_d, vs, W, H)) vt = 0;
+      visT[t] = vt;
+    }
+    if (vt > 0) {
+      // the reference writes past visibleEntryIDs[SDF_LOCAL_BLOCK_NUM] here; this ABI clamps
+      if (nv < rs->capIds) rs->visibleIds[nv] = t;
+      nv++;
+    }
+  }
+  rs->noVisibleEntries = (nv < rs->capIds) ? nv : rs->capIds;
+  s->lastFreeBlockId = lastFreeVBA;
+  s->lastFreeExcessListId = lastFreeExcess;
+}
+
+// FindVisibleBlocks  DeviceSpecific/CPU/ITMVisualisationEngine_CPU.cpp:39-77
+void find_visible_hash(const itm_scene* s, const float* M, const float* intr, itm_render_state* rs) {
+  int nv = 0;
+  for (int t = 0; t < s->noTotalEntries; ++t) {
+    const HashEntry& e = s->hash[t];
+    bool vis = false;
+    if (e.ptr >= 0) vis = block_visible(e, M, intr, s->prm.voxelSize, rs->w, rs->h);
+    if (vis) { if (nv < rs->capIds) rs->visibleIds[nv] = t; nv++; }
+  }
+  rs->noVisibleEntries = (nv < rs->capIds) ? nv : rs->capIds;
+}
+
+// ------------------------------------------------------------------------------------------
+// CreateExpectedDepths  ITMVisualisationEngine_CPU.cpp:79-91 (dense) / :93-152 (hash) with
+// ProjectSingleBlock / CreateRenderingBlocks  DeviceAgnostic/ITMVisualisationEngine.h:28-90
+// ------------------------------------------------------------------------------------------
+struct RBlock { int16_t ulx, uly, lrx, lry; float z0, z1; };
+
+bool project_block(const HashEntry& e, const float* M, const float* intr, int W, int H, float voxelSize,
+                   int& ulx, int& uly, int& lrx, int& lry, float& z0, float& z1) {
+  ulx = W / 8; uly = H / 8; lrx = -1; lry = -1; z0 = 999999.9f; z1 = 0.05f;
+  for (int corner = 0; corner < 8; ++corner) {
+    int16_t tx = (int16_t)(e.px + ((corner & 1) ? 1 : 0));
+    int16_t ty = (int16_t)(e.py + ((corner & 2) ? 1 : 0));
+    int16_t tz = (int16_t)(e.pz + ((corner & 4) ? 1 : 0));
+    V4f p = {(float)tx * (float)ITM_SDF_BLOCK_SIZE * voxelSize, (float)ty * (float)ITM_SDF_BLOCK_SIZE * voxelSize,
+             (float)tz * (float)ITM_SDF_BLOCK_SIZE * voxelSize, 1.0f};
+    V4f q = mul(M, p);
+    if (q.z < 1e-6) continue;   // double literal in the reference
+    float u = (intr[0] * q.x / q.z + intr[2]) / 8;
+    float v = (intr[1] * q.y / q.z + intr[3]) / 8;
+    if (ulx > std::floor(u)) ulx = (int)std::floor(u);
+    if (lrx < std::ceil(u)) lrx = (int)std::ceil(u);
+    if (uly > std::floor(v)) uly = (int)std::floor(v);
+    if (lry < std::ceil(v)) lry = (int)std::ceil(v);
+    if (z0 > q.z) z0 = q.z;
+    if (z1 < q.z) z1 = q.z;
+  }
+  if (ulx < 0) ulx = 0;
+  if (uly < 0) uly = 0;
+  if (lrx >= W) lrx = W - 1;
+  if (lry >= H) lry = H - 1;
+  if (ulx > lrx) return false;
+  if (uly > lry) return false;
+  if (z0 < 0.05f) z0 = 0.05f;
+  if (z1 < 0.05f) return false;
+  return true;
+}
+
+void expected_depths(const itm_scene* s, const float* M, const float* intr, itm_render_state* rs) {
+  const int W = rs->w, H = rs->h;
+  if (s->cfg.indexType == ITM_INDEX_DENSE) {
+    for (int i = 0; i < W * H; ++i) { rs->range[i].x = 0.2f; rs->range[i].y = 3.0f; }
+    return;
+  }
+  for (int i = 0; i < W * H; ++i) { rs->range[i].x = 999999.9f; rs->range[i].y = 0.05f; }
+  std::vector<RBlock> blocks;
+  int count = 0;
+  for (int b = 0; b < rs->noVisibleEntries; ++b) {
+    const HashEntry& e = s->hash[rs->visibleIds[b]];
+    if (e.ptr < 0) continue;
+    int ulx, uly, lrx, lry; float z0, z1;
+    if (!project_block(e, M, intr, W, H, s->prm.voxelSize, ulx, uly, lrx, lry, z0, z1)) continue;
+    int nx = (int)std::ceil((float)(lrx - ulx + 1) / 16.0f);
+    int ny = (int)std::ceil((float)(lry - uly + 1) / 16.0f);
+    if (count + nx * ny >= ITM_MAX_RENDERING_BLOCKS) continue;
+    count += nx * ny;
+    for (int by = 0; by < ny; ++by) for (int bx = 0; bx < nx; ++bx) {
+      RBlock r;
+      r.ulx = (int16_t)(ulx + bx * 16); r.uly = (int16_t)(uly + by * 16);
+      r.lrx = (int16_t)(ulx + (bx + 1) * 16 - 1); r.lry = (int16_t)(uly + (by + 1) * 16 - 1);
+      if (r.lrx > lrx) r.lrx = (int16_t)lrx;
+      if (r.lry > lry) r.lry = (int16_t)lry;
+      r.z0 = z0; r.z1 = z1;
+      blocks.push_back(r);
+    }
+  }
+  rs->noRenderingBlocks = count;
+  for (const RBlock& r : blocks)
+    for (int y = r.uly; y <= r.lry; ++y) for (int x = r.ulx; x <= r.lrx; ++x) {
+      V2f& px = rs->range[x + y * W];
+      if (px.x > r.z0) px.x = r.z0;
+      if (px.y < r.z1) px.y = r.z1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// castRay  DeviceAgnostic/ITMVisualisationEngine.h:92-158 ; GenericRaycast  _CPU.cpp:154-188
+// ------------------------------------------------------------------------------------------
+template <class V>
+bool cast_ray(V4f& out, int x, int y, const Reader<V>& rd, const float* invM, float ifx, float ify, float cx, float cy,
+              float oneOverVoxel, float mu, const V2f& mm) {
+  float sdf = 1.0f;
+  float stepScale = mu * oneOverVoxel;
+  V4f pc;
+  pc.z = mm.x; pc.x = pc.z * (((float)x - cx) * ifx); pc.y = pc.z * (((float)y - cy) * ify); pc.w = 1.0f;
+  float acc = 0; acc += pc.x * pc.x; acc += pc.y * pc.y; acc += pc.z * pc.z;   // dot(), ORUtils/Vector.h:811-816
+  float total = std::sqrt(acc) * oneOverVoxel;
+  V4f t = mul(invM, pc);
+  V3f S = {t.x * oneOverVoxel, t.y * oneOverVoxel, t.z * oneOverVoxel};
+  pc.z = mm.y; pc.x = pc.z * (((float)x - cx) * ifx); pc.y = pc.z * (((float)y - cy) * ify); pc.w = 1.0f;
+  acc = 0; acc += pc.x * pc.x; acc += pc.y * pc.y; acc += pc.z * pc.z;
+  float totalMax = std::sqrt(acc) * oneOverVoxel;
+  t = mul(invM, pc);
+  V3f E = {t.x * oneOverVoxel, t.y * oneOverVoxel, t.z * oneOverVoxel};
+  V3f dir = {E.x - S.x, E.y - S.y, E.z - S.z};
+  float dn = 1.0f / std::sqrt(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
+  dir.x *= dn; dir.y *= dn; dir.z *= dn;
+  V3f pt = S;
+  BlockCache cache;
+  bool found;
+  float step;
+  while (total < totalMax) {
+    sdf = rd.nearest(pt, found, cache);
+    if (!found) {
+      step = (float)ITM_SDF_BLOCK_SIZE;
+    } else {
+      if ((sdf <= 0.1f) && (sdf >= -0.5f)) sdf = rd.trilinear(pt, found, cache);
+      if (sdf <= 0.0f) break;
+      step = fmax_ref(sdf * stepScale, 1.0f);
+    }
+    pt.x += step * dir.x; pt.y += step * dir.y; pt.z += step * dir.z;
+    total += step;
+  }
+  bool hit;
+  if (sdf <= 0.0f) {
+    step = sdf * stepScale;
+    pt.x += step * dir.x; pt.y += step * dir.y; pt.z += step * dir.z;
+    sdf = rd.trilinear(pt, found, cache);
+    step = sdf * stepScale;
+    pt.x += step * dir.x; pt.y += step * dir.y; pt.z += step * dir.z;
+    hit = true;
+  } else hit = false;
+  out.x = pt.x; out.y = pt.y; out.z = pt.z; out.w = hit ? 1.0f : 0.0f;
+  return hit;
+}
+
+template <class V>
+void raycast_t(const itm_scene* s, itm_render_state* rs, const float* invM, const float* intr, V4f* dst) {
+  Reader<V> rd(s);
+  const int W = rs->w, H = rs->h;
+  float ifx = 1.0f / intr[0], ify = 1.0f / intr[1];
+  float oov = 1.0f / s->prm.voxelSize;
+  for (int loc = 0; loc < W * H; ++loc) {
+    int y = loc / W, x = loc - y * W;
+    int loc2 = (int)std::floor((float)x / 8) + (int)std::floor((float)y / 8) * W;
+    cast_ray<V>(dst[loc], x, y, rd, invM, ifx, ify, intr[2], intr[3], oov, s->prm.mu, rs->range[loc2]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// shading helpers  DeviceAgnostic/ITMVisualisationEngine.h:175-279
+// ------------------------------------------------------------------------------------------
+inline uint32_t grey_px(float angle) {   // drawPixelGrey :256-260
+  float o = (0.8f * angle + 0.2f) * 255.0f;
+  uint32_t g = (uint8_t)o;
+  return g | (g << 8) | (g << 16) | (g << 24);
+}
+
+// computeNormalAndAngle<useSmoothing=true> from the ray-hit map :191-254
+bool normal_from_map(const V4f* rays, int x, int y, int W, int H, float voxelSize, const V3f& L, V3f& n, float& angle) {
+  if (y <= 2 || y >= H - 3 || x <= 2 || x >= W - 3) return false;
+  V4f xp = rays[(x + 2) + y * W], yp = rays[x + (y + 2) * W];
+  V4f xm = rays[(x - 2) + y * W], ym = rays[x + (y - 2) * W];
+  V4f dx = {0, 0, 0, 0}, dy = {0, 0, 0, 0};
+  bool plus1 = false;
+  if (xp.w <= 0 || yp.w <= 0 || xm.w <= 0 || ym.w <= 0) plus1 = true;
+  else {
+    dx = {xp.x - xm.x, xp.y - xm.y, xp.z - xm.z, xp.w - xm.w};
+    dy = {yp.x - ym.x, yp.y - ym.y, yp.z - ym.z, yp.w - ym.w};
+    float l = fmax_ref(dx.x * dx.x + dx.y * dx.y + dx.z * dx.z, dy.x * dy.x + dy.y * dy.y + dy.z * dy.z);
+    if (l * voxelSize * voxelSize > (0.15f * 0.15f)) plus1 = true;
+  }
+  if (plus1) {
+    xp = rays[(x + 1) + y * W]; yp = rays[x + (y + 1) * W];
+    xm = rays[(x - 1) + y * W]; ym = rays[x + (y - 1) * W];
+    dx = {xp.x - xm.x, xp.y - xm.y, xp.z - xm.z, xp.w - xm.w};
+    dy = {yp.x - ym.x, yp.y - ym.y, yp.z - ym.z, yp.w - ym.w};
+    if (xp.w <= 0 || yp.w <= 0 || xm.w <= 0 || ym.w <= 0) return false;
+  }
+  n.x = -(dx.y * dy.z - dx.z * dy.y);
+  n.y = -(dx.z * dy.x - dx.x * dy.z);
+  n.z = -(dx.x * dy.y - dx.y * dy.x);
+  float sc = 1.0f / std::sqrt(n.x * n.x + n.y * n.y + n.z * n.z);
+  n.x *= sc; n.y *= sc; n.z *= sc;
+  angle = n.x * L.x + n.y * L.y + n.z * L.z;
+  return angle > 0.0;
+}
+
+// computeSingleNormalFromSDF  DeviceAgnostic/ITMRepresentationAccess.h:224-337 (32 uncached reads)
+template <class V>
+V3f sdf_gradient(const Reader<V>& rd, const V3f& p) {
+  bool f;
+  float flx = std::floor(p.x), fly = std::floor(p.y), flz = std::floor(p.z);
+  float cx = p.x - flx, cy = p.y - fly, cz = p.z - flz;
+  int ix = (int)flx, iy = (int)fly, iz = (int)flz;
+  float nx = 1.0f - cx, ny = 1.0f - cy, nz = 1.0f - cz;
+  auto R = [&](int dx, int dy, int dz) { return (float)rd.read(ix + dx, iy + dy, iz + dz, f).sdf; };
+  float f000 = R(0, 0, 0), f100 = R(1, 0, 0), f010 = R(0, 1, 0), f110 = R(1, 1, 0);
+  float f001 = R(0, 0, 1), f101 = R(1, 0, 1), f011 = R(0, 1, 1), f111 = R(1, 1, 1);
+  V3f g; float p1, p2, v1, a, b, c, d;
+  // x
+  p1 = f000 * ny * nz + f010 * cy * nz + f001 * ny * cz + f011 * cy * cz;
+  a = R(-1, 0, 0); b = R(-1, 1, 0); c = R(-1, 0, 1); d = R(-1, 1, 1);
+  p2 = a * ny * nz + b * cy * nz + c * ny * cz + d * cy * cz;
+  v1 = p1 * cx + p2 * nx;
+  p1 = f100 * ny * nz + f110 * cy * nz + f101 * ny * cz + f111 * cy * cz;
+  a = R(2, 0, 0); b = R(2, 1, 0); c = R(2, 0, 1); d = R(2, 1, 1);
+  p2 = a * ny * nz + b * cy * nz + c * ny * cz + d * cy * cz;
+  g.x = Codec<V>::toF(p1 * nx + p2 * cx - v1);
+  // y
+  p1 = f000 * nx * nz + f100 * cx * nz + f001 * nx * cz + f101 * cx * cz;
+  a = R(0, -1, 0); b = R(1, -1, 0); c = R(0, -1, 1); d = R(1, -1, 1);
+  p2 = a * nx * nz + b * cx * nz + c * nx * cz + d * cx * cz;
+  v1 = p1 * cy + p2 * ny;
+  p1 = f010 * nx * nz + f110 * cx * nz + f011 * nx * cz + f111 * cx * cz;
+  a = R(0, 2, 0); b = R(1, 2, 0); c = R(0, 2, 1); d = R(1, 2, 1);
+  p2 = a * nx * nz + b * cx * nz + c * nx * cz + d * cx * cz;
+  g.y = Codec<V>::toF(p1 * ny + p2 * cy - v1);
+  // z
+  p1 = f000 * nx * ny + f100 * cx * ny + f010 * nx * cy + f110 * cx * cy;
+  a = R(0, 0, -1); b = R(1, 0, -1); c = R(0, 1, -1); d = R(1, 1, -1);
+  p2 = a * nx * ny + b * cx * ny + c * nx * cy + d * cx * cy;
+  v1 = p1 * cz + p2 * nz;
+  p1 = f001 * nx * ny + f101 * cx * ny + f011 * nx * cy + f111 * cx * cy;
+  a = R(0, 0, 2); b = R(1, 0, 2); c = R(0, 1, 2); d = R(1, 1, 2);
+  p2 = a * nx * ny + b * cx * ny + c * nx * cy + d * cx * cy;
+  g.z = Codec<V>::toF(p1 * nz + p2 * cz - v1);
+  return g;
+}
+
+// computeNormalAndAngle<TVoxel,TIndex> (SDF gradient variant) :175-189
+template <class V>
+bool normal_from_sdf(const Reader<V>& rd, const V3f& p, const V3f& L, V3f& n, float& angle) {
+  n = sdf_gradient<V>(rd, p);
+  float sc = 1.0f / std::sqrt(n.x * n.x + n.y * n.y + n.z * n.z);
+  n.x *= sc; n.y *= sc; n.z *= sc;
+  angle = n.x * L.x + n.y * L.y + n.z * L.z;
+  return angle > 0.0;
+}
+
+// readFromSDF_color4u_interpolated  DeviceAgnostic/ITMRepresentationAccess.h:187-222
+template <class V, bool C = Codec<V>::color> struct Colour;
+template <class V> struct Colour<V, false> {
+  static V4f at(const Reader<V>&, const V3f&) { return V4f{0, 0, 0, 0}; }
+};
+template <class V> struct Colour<V, true> {
+  static V4f at(const Reader<V>& rd, const V3f& p) {
+    BlockCache cache; bool f;
+    float flx = std::floor(p.x), fly = std::floor(p.y), flz = std::floor(p.z);
+    float cx = p.x - flx, cy = p.y - fly, cz = p.z - flz;
+    int ix = (int)flx, iy = (int)fly, iz = (int)flz;
+    float r[3] = {0, 0, 0};
+    auto add = [&](int dx, int dy, int dz, float wgt) {
+      V v = rd.read(ix + dx, iy + dy, iz + dz, f, cache);
+      for (int k = 0; k < 3; ++k) r[k] += wgt * (float)v.clr[k];
+    };
+    add(0, 0, 0, (1.0f - cx) * (1.0f - cy) * (1.0f - cz));
+    add(1, 0, 0, (cx) * (1.0f - cy) * (1.0f - cz));
+    add(0, 1, 0, (1.0f - cx) * (cy) * (1.0f - cz));
+    add(1, 1, 0, (cx) * (cy) * (1.0f - cz));
+    add(0, 0, 1, (1.0f - cx) * (1.0f - cy) * cz);
+    add(1, 0, 1, (cx) * (1.0f - cy) * cz);
+    add(0, 1, 1, (1.0f - cx) * (cy)*cz);
+    add(1, 1, 1, (cx) * (cy)*cz);
+    return V4f{r[0] / 255.0f, r[1] / 255.0f, r[2] / 255.0f, 255.0f / 255.0f};
+  }
+};
+
+// RenderImage_common  _CPU.cpp:190-240 with processPixelGrey/Colour/Normal :368-409
+template <class V>
+void render_image_t(const itm_scene* s, itm_render_state* rs, const float* M, const float* intr, uint32_t* out, int type) {
+  float invM[16]; invert4(M, invM);
+  raycast_t<V>(s, rs, invM, intr, rs->raycast.data());
+  V3f L = {-invM[8], -invM[9], -invM[10]};
+  Reader<V> rd(s);
+  if (type == ITM_RENDER_COLOUR_FROM_VOLUME && !Codec<V>::color) type = ITM_RENDER_SHADED_GREYSCALE;
+  for (int loc = 0; loc < rs->w * rs->h; ++loc) {
+    V4f r = rs->raycast[loc];
+    V3f p = {r.x, r.y, r.z};
+    bool found = r.w > 0;
+    V3f n; float angle = 0;
+    if (found) found = normal_from_sdf<V>(rd, p, L, n, angle);
+    if (!found) { out[loc] = 0; continue; }
+    if (type == ITM_RENDER_COLOUR_FROM_VOLUME) {
+      V4f c = Colour<V>::at(rd, p);
+      uint32_t px = (uint32_t)(uint8_t)(c.x * 255.0f) | ((uint32_t)(uint8_t)(c.y * 255.0f) << 8) |
+                    ((uint32_t)(uint8_t)(c.z * 255.0f) << 16) | (255u << 24);
+      out[loc] = px;
+    } else if (type == ITM_RENDER_COLOUR_FROM_NORMAL) {
+      // drawPixelNormal :262-267 writes r,g,b only; the alpha byte keeps its previous value
+      uint32_t prev = out[loc] & 0xff000000u;
+      uint32_t px = (uint32_t)(uint8_t)((0.3f + (-n.x + 1.0f) * 0.35f) * 255.0f) |
+                    ((uint32_t)(uint8_t)((0.3f + (-n.y + 1.0f) * 0.35f) * 255.0f) << 8) |
+                    ((uint32_t)(uint8_t)((0.3f + (-n.z + 1.0f) * 0.35f) * 255.0f) << 16) | prev;
+      out[loc] = px;
+    } else {
+      out[loc] = grey_px(angle);
+    }
+  }
+}
+
+// CreateICPMaps_common  _CPU.cpp:266-287 with processPixelICP<true> :314-349
+template <class V>
+void icp_maps_t(const itm_scene* s, const itm_view* view, itm_render_state* rs, V4f* points, V4f* normals) {
+  float invM[16]; invert4(view->M_d, invM);
+  raycast_t<V>(s, rs, invM, view->intr_d, rs->raycast.data());
+  V3f L = {-invM[8], -invM[9], -invM[10]};
+  const int W = rs->w, H = rs->h;
+  const float vs = s->prm.voxelSize;
+  const V4f* rays = rs->raycast.data();
+  for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {
+    int loc = x + y * W;
+    V4f r = rays[loc];
+    bool found = r.w > 0.0f;
+    V3f n; float angle = 0;
+    if (found) found = normal_from_map(rays, x, y, W, H, vs, L, n, angle);
+    if (found) {
+      rs->image[loc] = grey_px(angle);
+      points[loc] = V4f{r.x * vs, r.y * vs, r.z * vs, 1.0f};
+      normals[loc] = V4f{n.x, n.y, n.z, 0.0f};
+    } else {
+      points[loc] = V4f{0, 0, 0, -1.0f};
+      normals[loc] = V4f{0, 0, 0, -1.0f};
+      rs->image[loc] = 0;
+    }
+  }
+}
+
+// ForwardRender_common  _CPU.cpp:289-354 ; forwardProjectPixel  DeviceAgnostic/ITMVisualisationEngine.h:160-173
+template <class V>
+void forward_render_t(const itm_scene* s, const itm_view* view, itm_render_state* rs) {
+  const int W = rs->w, H = rs->h;
+  float invM[16]; invert4(view->M_d, invM);
+  const float* M = view->M_d; const float* ip = view->intr_d;
+  float ifx = 1.0f / ip[0], ify = 1.0f / ip[1];
+  V3f L = {-invM[8], -invM[9], -invM[10]};
+  const float vs = s->prm.voxelSize;
+  Reader<V> rd(s);
+  std::memset(rs->fwdProj.data(), 0, rs->fwdProj.size() * sizeof(V4f));
+  for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {
+    int loc = x + y * W;
+    V4f px = rs->raycast[loc];
+    V4f p = {px.x * vs, px.y * vs, px.z * vs, 1};
+    V4f q = mul(M, p);
+    float u = ip[0] * q.x / q.z + ip[2];
+    float v = ip[1] * q.y / q.z + ip[3];
+    if ((u < 0) || (u > W - 1) || (v < 0) || (v > H - 1)) continue;
+    int locNew = (int)(u + 0.5f) + (int)(v + 0.5f) * W;
+    if (locNew >= 0) rs->fwdProj[locNew] = px;
+  }
+  int nMissing = 0;
+  for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {
+    int loc = x + y * W;
+    int loc2 = (int)std::floor((float)x / 8) + (int)std::floor((float)y / 8) * W;
+    V4f fp = rs->fwdProj[loc]; V2f mm = rs->range[loc2]; float d = view->depth[loc];
+    if ((fp.w <= 0) && ((fp.x == 0 && fp.y == 0 && fp.z == 0) || (d >= 0)) && (mm.x < mm.y)) rs->missing[nMissing++] = loc;
+  }
+  rs->noFwdProjMissingPoints = nMissing;
+  float oov = 1.0f / vs;
+  for (int i = 0; i < nMissing; ++i) {
+    int loc = rs->missing[i];
+    int y = loc / W, x = loc - y * W;
+    int loc2 = (int)std::floor((float)x / 8) + (int)std::floor((float)y / 8) * W;
+    cast_ray<V>(rs->fwdProj[loc], x, y, rd, invM, ifx, ify, ip[2], ip[3], oov, s->prm.mu, rs->range[loc2]);
+  }
+  const V4f* rays = rs->fwdProj.data();
+  for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {
+    int loc = x + y * W;
+    bool found = rays[loc].w > 0.0f;
+    V3f n; float angle = 0;
+    if (found) found = normal_from_map(rays, x, y, W, H, vs, L, n, angle);
+    rs->image[loc] = found ? grey_px(angle) : 0u;
+  }
+}
+
+// CreatePointCloud_common  _CPU.cpp:242-264 ; RenderPointCloud :424-462
+template <class V>
+void point_cloud_t(const itm_scene* s, const itm_view* view, itm_render_state* rs, bool skipPoints, V4f* locations, V4f* colours) {
+  float invMd[16], invM[16];
+  invert4(view->M_d, invMd);
+  matmul4(invMd, view->rgb_to_depth, invM);   // pose_d->GetInvM() * calib
+  raycast_t<V>(s, rs, invM, view->intr_rgb, rs->raycast.data());
+  V3f L = {-invM[8], -invM[9], -invM[10]};
+  Reader<V> rd(s);
+  const int W = rs->w, H = rs->h; const float vs = s->prm.voxelSize;
+  int total = 0;
+  for (int y = 0, loc = 0; y < H; ++y) for (int x = 0; x < W; ++x, ++loc) {
+    V4f r = rs->raycast[loc];
+    V3f p = {r.x, r.y, r.z};
+    bool found = r.w > 0;
+    V3f n; float angle = 0;
+    if (found) found = normal_from_sdf<V>(rd, p, L, n, angle);
+    rs->image[loc] = found ? grey_px(angle) : 0u;
+    if (skipPoints && ((x % 2 == 0) || (y % 2 == 0))) found = false;
+    if (found) {
+      V4f c = Colour<V>::at(rd, p);
+      if (c.w > 0.0f) { c.x /= c.w; c.y /= c.w; c.z /= c.w; c.w = 1.0f; }
+      colours[total] = c;
+      locations[total] = V4f{p.x * vs, p.y * vs, p.z * vs, 1.0f};
+      total++;
+    }
+  }
+  rs->noTotalPoints = total;
+}
+
+template <class F>
+int dispatch_voxel(int voxelType, F&& f) {
+  switch (voxelType) {
+    case ITM_VOXEL_S: f((VoxS*)nullptr); return ITM_OK;
+    case ITM_VOXEL_F: f((VoxF*)nullptr); return ITM_OK;
+    case ITM_VOXEL_S_RGB: f((VoxSC*)nullptr); return ITM_OK;
+    case ITM_VOXEL_F_RGB: f((VoxFC*)nullptr); return ITM_OK;
+  }
+  return fail(ITM_ERR_INVALID, "unknown voxel type");
+}
+#define VOX_T typename std::remove_pointer<decltype(tag)>::type
+
+}  // namespace
+
+// ==========================================================================================
+// C-ABI
+// ==========================================================================================
+extern "C" {
+
+const char* itmo_version(void) { return "itm-oracle 1 (cpu restatement, test infrastructure)"; }
+const char* itmo_last_error(void) { return g_err.c_str(); }
+int itmo_uses_device_memory(void) { return 0; }
+size_t itmo_voxel_size_bytes(int t) {
+  switch (t) { case ITM_VOXEL_S: return 4; case ITM_VOXEL_F: return 8; case ITM_VOXEL_S_RGB: return 8; case ITM_VOXEL_F_RGB: return 12; }
+  return 0;
+}
+
+int itmo_dev_malloc(void** p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? ITM_OK : fail(ITM_ERR_DEVICE, "malloc"); }
+int itmo_dev_free(void* p) { std::free(p); return ITM_OK; }
+int itmo_memcpy_h2d(void* d, const void* s, size_t n, itm_stream) { std::memcpy(d, s, n); return ITM_OK; }
+int itmo_memcpy_d2h(void* d, const void* s, size_t n, itm_stream) { std::memcpy(d, s, n); return ITM_OK; }
+int itmo_stream_synchronize(itm_stream) { return ITM_OK; }
+int itmo_set_device(int) { return ITM_OK; }
+
+int itmo_scene_create(const itm_scene_config* cfg_in, const itm_scene_params* prm, itm_scene** out) {
+  if (!cfg_in || !prm || !out) return fail(ITM_ERR_INVALID, "null argument");
+  itm_scene_config cfg = *cfg_in;
+  if (cfg.bucketNum == 0) cfg.bucketNum = ITM_DEFAULT_BUCKET_NUM;
+  if (cfg.excessNum == 0) cfg.excessNum = ITM_DEFAULT_EXCESS_NUM;
+  if (cfg.localBlockNum == 0) cfg.localBlockNum = ITM_DEFAULT_LOCAL_BLOCK_NUM;
+  if (cfg.denseSize[0] == 0 && cfg.denseSize[1] == 0 && cfg.denseSize[2] == 0) {
+    cfg.denseSize[0] = cfg.denseSize[1] = cfg.denseSize[2] = 512;
+    if (!cfg.denseOffsetSet) { cfg.denseOffset[0] = -256; cfg.denseOffset[1] = -256; cfg.denseOffset[2] = 0; }
+  }
+  cfg.denseOffsetSet = 1;
+  if (cfg.bucketNum & (cfg.bucketNum - 1)) return fail(ITM_ERR_INVALID, "bucketNum must be a power of two");
+  size_t vb = itmo_voxel_size_bytes(cfg.voxelType);
+  if (!vb) return fail(ITM_ERR_INVALID, "unknown voxel type");
+  if (cfg.indexType != ITM_INDEX_HASH && cfg.indexType != ITM_INDEX_DENSE) return fail(ITM_ERR_INVALID, "unknown index type");
+  itm_scene* s = new (std::nothrow) itm_scene();
+  if (!s) return fail(ITM_ERR_DEVICE, "out of memory");
+  s->cfg = cfg; s->prm = *prm; s->voxBytes = vb;
+  s->noTotalEntries = cfg.bucketNum + cfg.excessNum;
+  s->vba.assign(s->numVoxels() * vb, 0);
+  if (cfg.indexType == ITM_INDEX_HASH) {
+    s->hash.assign(s->noTotalEntries, HashEntry{0, 0, 0, 0, 0, 0});
+    s->excessList.assign(cfg.excessNum, 0);
+    s->allocList.assign(cfg.localBlockNum, 0);
+    s->allocType.assign(s->noTotalEntries, 0);
+    s->blockCoords.assign((size_t)s->noTotalEntries * 4, 0);
+  } else {
+    s->allocList.assign(1, 0);
+  }
+  *out = s;
+  return ITM_OK;
+}
+int itmo_scene_destroy(itm_scene* s) { delete s; return ITM_OK; }
+int itmo_scene_get_config(const itm_scene* s, itm_scene_config* c, itm_scene_params* p) {
+  if (!s) return fail(ITM_ERR_INVALID, "null scene");
+  if (c) *c = s->cfg;
+  if (p) *p = s->prm;
+  return ITM_OK;
+}
+
+int itmo_reset_scene(itm_scene* s, itm_stream) {
+  if (!s) return fail(ITM_ERR_INVALID, "null scene");
+  return dispatch_voxel(s->cfg.voxelType, [&](auto tag) { reset_scene_t<VOX_T>(s); });
+}
+
+int itmo_render_state_create(const itm_scene* s, int w, int h, itm_render_state** out) {
+  if (!s || !out || w <= 0 || h <= 0) return fail(ITM_ERR_INVALID, "bad argument");
+  itm_render_state* rs = new itm_render_state();
+  rs->w = w; rs->h = h; rs->hash = s->cfg.indexType == ITM_INDEX_HASH;
+  size_t P = (size_t)w * h;
+  rs->range.assign(P, V2f{s->prm.viewFrustum_min, s->prm.viewFrustum_max});
+  rs->raycast.assign(P, V4f{0, 0, 0, 0});
+  rs->fwdProj.assign(P, V4f{0, 0, 0, 0});
+  rs->missing.assign(P, 0);
+  rs->image.assign(P, 0);
+  rs->capIds = rs->hash ? s->cfg.localBlockNum : 0;
+  if (rs->hash) {
+    rs->visibleIds.assign(s->cfg.localBlockNum, 0);
+    rs->visibleType.assign(s->noTotalEntries, 0);
+  }
+  *out = rs;
+  return ITM_OK;
+}
+int itmo_render_state_destroy(itm_render_state* rs) { delete rs; return ITM_OK; }
+
+int itmo_allocate_scene_from_depth(itm_scene* s, const itm_view* v, itm_render_state* rs, int onlyVis, itm_stream) {
+  if (!s || !v || !rs) return fail(ITM_ERR_INVALID, "null argument");
+  if (s->cfg.indexType == ITM_INDEX_DENSE) return ITM_OK;
+  if (v->w != rs->w || v->h != rs->h) return fail(ITM_ERR_INVALID, "view / render state size mismatch");
+  allocate_hash(s, v, rs, onlyVis != 0);
+  return ITM_OK;
+}
+
+int itmo_integrate_into_scene(itm_scene* s, const itm_view* v, itm_render_state* rs, itm_stream) {
+  if (!s || !v || !rs) return fail(ITM_ERR_INVALID, "null argument");
+  return dispatch_voxel(s->cfg.voxelType, [&](auto tag) { integrate_t<VOX_T>(s, v, rs); });
+}
+
+int itmo_find_visible_blocks(const itm_scene* s, const float M[16], const float intr[4], itm_render_state* rs, itm_stream) {
+  if (!s || !rs) return fail(ITM_ERR_INVALID, "null argument");
+  if (s->cfg.indexType == ITM_INDEX_HASH) find_visible_hash(s, M, intr, rs);
+  return ITM_OK;
+}
+
+int itmo_create_expected_depths(const itm_scene* s, const float M[16], const float intr[4], itm_render_state* rs, itm_stream) {
+  if (!s || !rs) return fail(ITM_ERR_INVALID, "null argument");
+  expected_depths(s, M, intr, rs);
+  return ITM_OK;
+}
+
+int itmo_render_image(const itm_scene* s, const float M[16], const float intr[4], itm_render_state* rs, uint8_t* out, int type, itm_stream) {
+  if (!s || !rs) return fail(ITM_ERR_INVALID, "null argument");
+  uint32_t* dst = out ? (uint32_t*)out : rs->image.data();
+  return dispatch_voxel(s->cfg.voxelType, [&](auto tag) { render_image_t<VOX_T>(s, rs, M, intr, dst, type); });
+}
+
+int itmo_find_surface(const itm_scene* s, const float M[16], const float intr[4], itm_render_state* rs, itm_stream) {
+  if (!s || !rs) return fail(ITM_ERR_INVALID, "null argument");
+  float invM[16]; invert4(M, invM);
+  return dispatch_voxel(s->cfg.voxelType, [&](auto tag) { raycast_t<VOX_T>(s, rs, invM, intr, rs->raycast.data()); });
+}
+
+int itmo_create_point_cloud(const itm_scene* s, const itm_view* v, itm_render_state* rs, int skip, float* loc, float* col, itm_stream) {
+  if (!s || !v || !rs || !loc || !col) return fail(ITM_ERR_INVALID, "null argument");
+  return dispatch_voxel(s->cfg.voxelType, [&](auto tag) { point_cloud_t<VOX_T>(s, v, rs, skip != 0, (V4f*)loc, (V4f*)col); });
+}
+
+int itmo_create_icp_maps(const itm_scene* s, const itm_view* v, itm_render_state* rs, float* pts, float* nrm, itm_stream) {
+  if (!s || !v || !rs || !pts || !nrm) return fail(ITM_ERR_INVALID, "null argument");
+  return dispatch_voxel(s->cfg.voxelType, [&](auto tag) { icp_maps_t<VOX_T>(s, v, rs, (V4f*)pts, (V4f*)nrm); });
+}
+
+int itmo_forward_render(const itm_scene* s, const itm_view* v, itm_render_state* rs, itm_stream) {
+  if (!s || !v || !rs) return fail(ITM_ERR_INVALID, "null argument");
+  return dispatch_voxel(s->cfg.voxelType, [&](auto tag) { forward_render_t<VOX_T>(s, v, rs); });
+}
+
+int itmo_process_frame(itm_scene* s, const itm_view* v, itm_render_state* rs, float* pts, float* nrm, itm_stream st) {
+  int r;
+  if ((r = itmo_allocate_scene_from_depth(s, v, rs, 0, st))) return r;
+  if ((r = itmo_integrate_into_scene(s, v, rs, st))) return r;
+  if ((r = itmo_create_expected_depths(s, v->M_d, v->intr_d, rs, st))) return r;
+  return itmo_create_icp_maps(s, v, rs, pts, nrm, st);
+}
+
+// convertDepthAffineToFloat / convertDisparityToDepth  DeviceAgnostic/ITMViewBuilder.h:7-28
+int itmo_convert_depth_affine(const int16_t* raw, float* out, int w, int h, float a, float b, itm_stream) {
+  for (int i = 0; i < w * h; ++i) { int16_t d = raw[i]; out[i] = ((d <= 0) || (d > 32000)) ? -1.0f : (float)d * a + b; }
+  return ITM_OK;
+}
+int itmo_convert_disparity(const int16_t* raw, float* out, int w, int h, float c0, float c1, float fx, itm_stream) {
+  for (int i = 0; i < w * h; ++i) {
+    float t = c0 - (float)raw[i];
+    float depth;
+    if (t == 0) depth = 0.0; else depth = 8.0f * c1 * fx / t;
+    out[i] = (depth > 0) ? depth : -1.0f;
+  }
+  return ITM_OK;
+}
+
+int itmo_get_counters(const itm_scene* s, const itm_render_state* rs, itm_counters* c, itm_stream) {
+  if (!c) return fail(ITM_ERR_INVALID, "null argument");
+  std::memset(c, 0, sizeof *c);
+  if (s) { c->lastFreeBlockId = s->lastFreeBlockId; c->lastFreeExcessListId = s->lastFreeExcessListId; c->noAllocRequests = s->noAllocRequests; }
+  if (rs) { c->noVisibleEntries = rs->noVisibleEntries; c->noFwdProjMissingPoints = rs->noFwdProjMissingPoints; c->noTotalPoints = rs->noTotalPoints; c->noRenderingBlocks = rs->noRenderingBlocks; }
+  return ITM_OK;
+}
+int itmo_set_counters(itm_scene* s, itm_render_state* rs, const itm_counters* c, itm_stream) {
+  if (!c) return fail(ITM_ERR_INVALID, "null argument");
+  if (s) { s->lastFreeBlockId = c->lastFreeBlockId; s->lastFreeExcessListId = c->lastFreeExcessListId; }
+  if (rs) rs->noVisibleEntries = c->noVisibleEntries;
+  return ITM_OK;
+}
+
+static void* buf_of(const itm_scene* s, const itm_render_state* rs, int which, size_t* bytes) {
+  *bytes = 0;
+  switch (which) {
+    case ITM_BUF_HASH_ENTRIES: if (s) { *bytes = s->hash.size() * sizeof(HashEntry); return (void*)s->hash.data(); } break;
+    case ITM_BUF_EXCESS_LIST: if (s) { *bytes = s->excessList.size() * 4; return (void*)s->excessList.data(); } break;
+    case ITM_BUF_VOXEL_BLOCKS: if (s) { *bytes = s->vba.size(); return (void*)s->vba.data(); } break;
+    case ITM_BUF_ALLOCATION_LIST: if (s) { *bytes = s->allocList.size() * 4; return (void*)s->allocList.data(); } break;
+    case ITM_BUF_VISIBLE_IDS: if (rs) { *bytes = rs->visibleIds.size() * 4; return (void*)rs->visibleIds.data(); } break;
+    case ITM_BUF_VISIBLE_TYPE: if (rs) { *bytes = rs->visibleType.size(); return (void*)rs->visibleType.data(); } break;
+    case ITM_BUF_RANGE_IMAGE: if (rs) { *bytes = rs->range.size() * sizeof(V2f); return (void*)rs->range.data(); } break;
+    case ITM_BUF_RAYCAST_RESULT: if (rs) { *bytes = rs->raycast.size() * sizeof(V4f); return (void*)rs->raycast.data(); } break;
+    case ITM_BUF_RAYCAST_IMAGE: if (rs) { *bytes = rs->image.size() * 4; return (void*)rs->image.data(); } break;
+    case ITM_BUF_FORWARD_PROJECTION: if (rs) { *bytes = rs->fwdProj.size() * sizeof(V4f); return (void*)rs->fwdProj.data(); } break;
+    case ITM_BUF_MISSING_POINTS: if (rs) { *bytes = rs->missing.size() * 4; return (void*)rs->missing.data(); } break;
+  }
+  return nullptr;
+}
+size_t itmo_buffer_bytes(const itm_scene* s, const itm_render_state* rs, int which) { size_t b; buf_of(s, rs, which, &b); return b; }
+void* itmo_buffer_ptr(const itm_scene* s, const itm_render_state* rs, int which) { size_t b; return buf_of(s, rs, which, &b); }
+int itmo_download(const itm_scene* s, const itm_render_state* rs, int which, void* dst, size_t bytes, itm_stream) {
+  size_t b; void* p = buf_of(s, rs, which, &b);
+  if (!p && b == 0 && bytes == 0) return ITM_OK;
+  if (!p || bytes > b) return fail(ITM_ERR_INVALID, "bad buffer / size");
+  std::memcpy(dst, p, bytes);
+  return ITM_OK;
+}
+int itmo_upload(itm_scene* s, itm_render_state* rs, int which, const void* src, size_t bytes, itm_stream) {
+  size_t b; void* p = buf_of(s, rs, which, &b);
+  if (!p || bytes > b) return fail(ITM_ERR_INVALID, "bad buffer / size");
+  std::memcpy(p, src, bytes);
+  return ITM_OK;
+}
+
+int itmo_export_visible_record(const itm_render_state* rs, const float M_d[16], int max_ids, void* dst, itm_stream) {
+  if (!rs || !dst || max_ids < 0) return fail(ITM_ERR_INVALID, "bad argument");
+  std::memcpy(dst, M_d, 64);
+  int32_t* d = (int32_t*)dst + 16;
+  d[0] = rs->noVisibleEntries;
+  for (int i = 0; i < max_ids; ++i) d[1 + i] = (i < rs->noVisibleEntries) ? rs->visibleIds[i] : -1;
+  return ITM_OK;
+}
+
+}  // extern "C"

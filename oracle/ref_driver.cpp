@@ -1,0 +1,379 @@
+// ref_driver.cpp -- TEST INFRASTRUCTURE.  Thin C-ABI shim (prefix `itmr_`, same signatures as
+// include/itm_hip.h) over the REAL reference CPU engines, compiled by oracle/Makefile target
+// `ref` straight from the sources where they lie under /root/reference (never copied into this
+// repo).  Output goes to oracle/_ref/ only (git-ignored).  It exists to pin oracle/itm_oracle.cpp
+// and to generate tests/golden/; it is absent on machines without /root/reference and nothing in
+// the product depends on it.
+//
+// The reference fixes the voxel/index types and the pool sizes at compile time
+// (Utils/ITMLibDefines.h:37-62,205,210).  This shim instantiates the reference templates for all
+// four voxel types and both index types, but can only offer the pool sizes the reference was
+// compiled with (bucket 0x100000, excess 0x20000, local blocks 0x10000); other configurations
+// return ITM_ERR_UNSUPPORTED.
+
+#define ITM_FN(name) itmr_##name
+#include "../include/itm_hip.h"
+
+#include <cstring>
+#include <string>
+
+// The two engine translation units are included so that extra <voxel, index> combinations can be
+// instantiated; each ends with an explicit instantiation for
+// <ITMVoxel_s, ITMVoxelBlockHash>.
+#include "ITMLib/Engine/DeviceSpecific/CPU/ITMSceneReconstructionEngine_CPU.cpp"
+#include "ITMLib/Engine/DeviceSpecific/CPU/ITMVisualisationEngine_CPU.cpp"
+#include "ITMLib/Engine/DeviceAgnostic/ITMViewBuilder.h"
+
+using namespace ITMLib::Engine;
+using namespace ITMLib::Objects;
+
+template class ITMLib::Engine::ITMSceneReconstructionEngine_CPU<ITMVoxel_f, ITMVoxelBlockHash>;
+template class ITMLib::Engine::ITMSceneReconstructionEngine_CPU<ITMVoxel_s_rgb, ITMVoxelBlockHash>;
+template class ITMLib::Engine::ITMSceneReconstructionEngine_CPU<ITMVoxel_f_rgb, ITMVoxelBlockHash>;
+template class ITMLib::Engine::ITMSceneReconstructionEngine_CPU<ITMVoxel_s, ITMPlainVoxelArray>;
+template class ITMLib::Engine::ITMSceneReconstructionEngine_CPU<ITMVoxel_f, ITMPlainVoxelArray>;
+template class ITMLib::Engine::ITMSceneReconstructionEngine_CPU<ITMVoxel_s_rgb, ITMPlainVoxelArray>;
+template class ITMLib::Engine::ITMSceneReconstructionEngine_CPU<ITMVoxel_f_rgb, ITMPlainVoxelArray>;
+template class ITMLib::Engine::ITMVisualisationEngine_CPU<ITMVoxel_f, ITMVoxelBlockHash>;
+template class ITMLib::Engine::ITMVisualisationEngine_CPU<ITMVoxel_s_rgb, ITMVoxelBlockHash>;
+template class ITMLib::Engine::ITMVisualisationEngine_CPU<ITMVoxel_f_rgb, ITMVoxelBlockHash>;
+template class ITMLib::Engine::ITMVisualisationEngine_CPU<ITMVoxel_s, ITMPlainVoxelArray>;
+template class ITMLib::Engine::ITMVisualisationEngine_CPU<ITMVoxel_f, ITMPlainVoxelArray>;
+template class ITMLib::Engine::ITMVisualisationEngine_CPU<ITMVoxel_s_rgb, ITMPlainVoxelArray>;
+template class ITMLib::Engine::ITMVisualisationEngine_CPU<ITMVoxel_f_rgb, ITMPlainVoxelArray>;
+
+namespace {
+thread_local std::string g_err;
+int fail(int code, const char* msg) { g_err = msg; return code; }
+
+struct RefSceneBase {
+  itm_scene_config cfg;
+  itm_scene_params prm;
+  virtual ~RefSceneBase() {}
+  virtual void reset() = 0;
+  virtual ITMRenderState* createRenderState(int w, int h) = 0;
+  virtual void allocate(const ITMView*, const ITMTrackingState*, ITMRenderState*, bool) = 0;
+  virtual void integrate(const ITMView*, const ITMTrackingState*, ITMRenderState*) = 0;
+  virtual void findVisible(const ITMPose*, const ITMIntrinsics*, ITMRenderState*) = 0;
+  virtual void expectedDepths(const ITMPose*, const ITMIntrinsics*, ITMRenderState*) = 0;
+  virtual void renderImage(const ITMPose*, const ITMIntrinsics*, ITMRenderState*, ITMUChar4Image*, int) = 0;
+  virtual void findSurface(const ITMPose*, const ITMIntrinsics*, ITMRenderState*) = 0;
+  virtual void pointCloud(const ITMView*, ITMTrackingState*, ITMRenderState*, bool) = 0;
+  virtual void icpMaps(const ITMView*, ITMTrackingState*, ITMRenderState*) = 0;
+  virtual void forwardRender(const ITMView*, ITMTrackingState*, ITMRenderState*) = 0;
+  virtual void* buffer(int which, size_t* bytes) = 0;
+  virtual int* lastFreeBlockId() = 0;
+  virtual int lastFreeExcess() = 0;
+  virtual void setLastFreeExcess(int) = 0;
+};
+
+template <class TIndex> struct IndexOps;
+template <> struct IndexOps<ITMVoxelBlockHash> {
+  static void configure(ITMVoxelBlockHash&, const itm_scene_config&) {}
+  static void* hashEntries(ITMVoxelBlockHash& i, size_t* b) { *b = (size_t)ITMVoxelBlockHash::noTotalEntries * sizeof(ITMHashEntry); return i.GetEntries(); }
+  static void* excess(ITMVoxelBlockHash& i, size_t* b) { *b = (size_t)SDF_EXCESS_LIST_SIZE * 4; return i.GetExcessAllocationList(); }
+  static int lastExcess(ITMVoxelBlockHash& i) { return i.GetLastFreeExcessListId(); }
+  static void setLastExcess(ITMVoxelBlockHash& i, int v) { i.SetLastFreeExcessListId(v); }
+  static size_t voxels(ITMVoxelBlockHash&) { return (size_t)SDF_LOCAL_BLOCK_NUM * SDF_BLOCK_SIZE3; }
+  static size_t allocEntries() { return SDF_LOCAL_BLOCK_NUM; }
+};
+template <> struct IndexOps<ITMPlainVoxelArray> {
+  // shrink / move the array inside the 512^3 allocation the reference always makes
+  static void configure(ITMPlainVoxelArray& i, const itm_scene_config& c) {
+    ITMPlainVoxelArray::IndexData* d = const_cast<ITMPlainVoxelArray::IndexData*>(i.getIndexData());
+    d->size = Vector3i(c.denseSize[0], c.denseSize[1], c.denseSize[2]);
+    d->offset = Vector3i(c.denseOffset[0], c.denseOffset[1], c.denseOffset[2]);
+  }
+  static void* hashEntries(ITMPlainVoxelArray&, size_t* b) { *b = 0; return 0; }
+  static void* excess(ITMPlainVoxelArray&, size_t* b) { *b = 0; return 0; }
+  static int lastExcess(ITMPlainVoxelArray&) { return 0; }
+  static void setLastExcess(ITMPlainVoxelArray&, int) {}
+  static size_t voxels(ITMPlainVoxelArray& i) { Vector3i s = i.getVolumeSize(); return (size_t)s.x * s.y * s.z; }
+  static size_t allocEntries() { return 1; }
+};
+
+template <class TVoxel, class TIndex>
+struct RefScene : RefSceneBase {
+  ITMSceneParams sp;
+  ITMScene<TVoxel, TIndex> scene;
+  ITMSceneReconstructionEngine_CPU<TVoxel, TIndex> reco;
+  ITMVisualisationEngine_CPU<TVoxel, TIndex> vis;
+  RefScene(const itm_scene_config& c, const itm_scene_params& p)
+      : sp(p.mu, p.maxW, p.voxelSize, p.viewFrustum_min, p.viewFrustum_max, p.stopIntegratingAtMaxW != 0),
+        scene(&sp, false, MEMORYDEVICE_CPU), vis(&scene) {
+    cfg = c; prm = p;
+    IndexOps<TIndex>::configure(scene.index, c);
+  }
+  void reset() override { reco.ResetScene(&scene); }
+  ITMRenderState* createRenderState(int w, int h) override { return vis.CreateRenderState(Vector2i(w, h)); }
+  void allocate(const ITMView* v, const ITMTrackingState* t, ITMRenderState* r, bool o) override { reco.AllocateSceneFromDepth(&scene, v, t, r, o); }
+  void integrate(const ITMView* v, const ITMTrackingState* t, ITMRenderState* r) override { reco.IntegrateIntoScene(&scene, v, t, r); }
+  void findVisible(const ITMPose* p, const ITMIntrinsics* i, ITMRenderState* r) override { vis.FindVisibleBlocks(p, i, r); }
+  void expectedDepths(const ITMPose* p, const ITMIntrinsics* i, ITMRenderState* r) override { vis.CreateExpectedDepths(p, i, r); }
+  void renderImage(const ITMPose* p, const ITMIntrinsics* i, ITMRenderState* r, ITMUChar4Image* o, int type) override {
+    vis.RenderImage(p, i, r, o, (IITMVisualisationEngine::RenderImageType)type);
+  }
+  void findSurface(const ITMPose* p, const ITMIntrinsics* i, ITMRenderState* r) override { vis.FindSurface(p, i, r); }
+  void pointCloud(const ITMView* v, ITMTrackingState* t, ITMRenderState* r, bool skip) override { vis.CreatePointCloud(v, t, r, skip); }
+  void icpMaps(const ITMView* v, ITMTrackingState* t, ITMRenderState* r) override { vis.CreateICPMaps(v, t, r); }
+  void forwardRender(const ITMView* v, ITMTrackingState* t, ITMRenderState* r) override { vis.ForwardRender(v, t, r); }
+  void* buffer(int which, size_t* bytes) override {
+    switch (which) {
+      case ITM_BUF_HASH_ENTRIES: return IndexOps<TIndex>::hashEntries(scene.index, bytes);
+      case ITM_BUF_EXCESS_LIST: return IndexOps<TIndex>::excess(scene.index, bytes);
+      case ITM_BUF_VOXEL_BLOCKS: *bytes = IndexOps<TIndex>::voxels(scene.index) * sizeof(TVoxel); return scene.localVBA.GetVoxelBlocks();
+      case ITM_BUF_ALLOCATION_LIST: *bytes = IndexOps<TIndex>::allocEntries() * 4; return scene.localVBA.GetAllocationList();
+    }
+    *bytes = 0; return 0;
+  }
+  int* lastFreeBlockId() override { return &scene.localVBA.lastFreeBlockId; }
+  int lastFreeExcess() override { return IndexOps<TIndex>::lastExcess(scene.index); }
+  void setLastFreeExcess(int v) override { IndexOps<TIndex>::setLastExcess(scene.index, v); }
+};
+
+template <class TVoxel>
+RefSceneBase* make_scene(const itm_scene_config& c, const itm_scene_params& p) {
+  if (c.indexType == ITM_INDEX_HASH) return new RefScene<TVoxel, ITMVoxelBlockHash>(c, p);
+  return new RefScene<TVoxel, ITMPlainVoxelArray>(c, p);
+}
+}  // namespace
+
+struct itm_scene { RefSceneBase* impl; };
+
+struct itm_render_state {
+  ITMRenderState* rs;
+  bool hash;
+  int w, h;
+  // the objects the reference engines read their inputs from
+  ITMRGBDCalib calib;
+  ITMView* view;
+  ITMTrackingState* ts;
+  Vector2i rgbSize;
+  int noTotalPoints;
+  itm_render_state() : rs(0), view(0), ts(0), noTotalPoints(0) {}
+};
+
+namespace {
+void set_matrix(Matrix4f& m, const float* src) { std::memcpy(m.m, src, 64); }
+
+// Fills the reference's ITMView / ITMTrackingState from the flat itm_view.
+void load_view(itm_render_state* r, const itm_view* v) {
+  Vector2i dsz(v->w, v->h), csz(v->w_rgb > 0 ? v->w_rgb : v->w, v->h_rgb > 0 ? v->h_rgb : v->h);
+  if (!r->view || r->rgbSize.x != csz.x || r->rgbSize.y != csz.y) {
+    delete r->view;
+    r->view = new ITMView(&r->calib, csz, dsz, false);
+    r->rgbSize = csz;
+  }
+  r->view->calib->intrinsics_d.SetFrom(v->intr_d[0], v->intr_d[1], v->intr_d[2], v->intr_d[3], (float)v->w, (float)v->h);
+  r->view->calib->intrinsics_rgb.SetFrom(v->intr_rgb[0], v->intr_rgb[1], v->intr_rgb[2], v->intr_rgb[3], (float)csz.x, (float)csz.y);
+  set_matrix(r->view->calib->trafo_rgb_to_depth.calib, v->rgb_to_depth);
+  set_matrix(r->view->calib->trafo_rgb_to_depth.calib_inv, v->rgb_to_depth_inv);
+  std::memcpy(r->view->depth->GetData(MEMORYDEVICE_CPU), v->depth, (size_t)v->w * v->h * sizeof(float));
+  if (v->rgb) std::memcpy(r->view->rgb->GetData(MEMORYDEVICE_CPU), v->rgb, (size_t)csz.x * csz.y * 4);
+  Matrix4f M; set_matrix(M, v->M_d);
+  r->ts->pose_d->SetM(M);
+}
+}  // namespace
+
+extern "C" {
+
+const char* itmr_version(void) { return "itm-ref 1 (reference CPU engines compiled from /root/reference)"; }
+const char* itmr_last_error(void) { return g_err.c_str(); }
+int itmr_uses_device_memory(void) { return 0; }
+size_t itmr_voxel_size_bytes(int t) {
+  switch (t) { case ITM_VOXEL_S: return sizeof(ITMVoxel_s); case ITM_VOXEL_F: return sizeof(ITMVoxel_f);
+    case ITM_VOXEL_S_RGB: return sizeof(ITMVoxel_s_rgb); case ITM_VOXEL_F_RGB: return sizeof(ITMVoxel_f_rgb); }
+  return 0;
+}
+int itmr_dev_malloc(void** p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? ITM_OK : ITM_ERR_DEVICE; }
+int itmr_dev_free(void* p) { std::free(p); return ITM_OK; }
+int itmr_memcpy_h2d(void* d, const void* s, size_t n, itm_stream) { std::memcpy(d, s, n); return ITM_OK; }
+int itmr_memcpy_d2h(void* d, const void* s, size_t n, itm_stream) { std::memcpy(d, s, n); return ITM_OK; }
+int itmr_stream_synchronize(itm_stream) { return ITM_OK; }
+int itmr_set_device(int) { return ITM_OK; }
+
+int itmr_scene_create(const itm_scene_config* cin, const itm_scene_params* prm, itm_scene** out) {
+  if (!cin || !prm || !out) return fail(ITM_ERR_INVALID, "null argument");
+  itm_scene_config c = *cin;
+  if (c.bucketNum == 0) c.bucketNum = SDF_BUCKET_NUM;
+  if (c.excessNum == 0) c.excessNum = SDF_EXCESS_LIST_SIZE;
+  if (c.localBlockNum == 0) c.localBlockNum = SDF_LOCAL_BLOCK_NUM;
+  if (c.denseSize[0] == 0 && c.denseSize[1] == 0 && c.denseSize[2] == 0) {
+    c.denseSize[0] = c.denseSize[1] = c.denseSize[2] = 512;
+    if (!c.denseOffsetSet) { c.denseOffset[0] = -256; c.denseOffset[1] = -256; c.denseOffset[2] = 0; }
+  }
+  c.denseOffsetSet = 1;
+  if (c.indexType == ITM_INDEX_HASH &&
+      (c.bucketNum != SDF_BUCKET_NUM || c.excessNum != SDF_EXCESS_LIST_SIZE || c.localBlockNum != SDF_LOCAL_BLOCK_NUM))
+    return fail(ITM_ERR_UNSUPPORTED, "reference pool sizes are compile-time constants");
+  if (c.indexType == ITM_INDEX_DENSE && (size_t)c.denseSize[0] * c.denseSize[1] * c.denseSize[2] > (size_t)512 * 512 * 512)
+    return fail(ITM_ERR_UNSUPPORTED, "dense array larger than the reference allocation");
+  RefSceneBase* impl = 0;
+  switch (c.voxelType) {
+    case ITM_VOXEL_S: impl = make_scene<ITMVoxel_s>(c, *prm); break;
+    case ITM_VOXEL_F: impl = make_scene<ITMVoxel_f>(c, *prm); break;
+    case ITM_VOXEL_S_RGB: impl = make_scene<ITMVoxel_s_rgb>(c, *prm); break;
+    case ITM_VOXEL_F_RGB: impl = make_scene<ITMVoxel_f_rgb>(c, *prm); break;
+    default: return fail(ITM_ERR_INVALID, "unknown voxel type");
+  }
+  *out = new itm_scene{impl};
+  return ITM_OK;
+}
+int itmr_scene_destroy(itm_scene* s) { if (s) { delete s->impl; delete s; } return ITM_OK; }
+int itmr_scene_get_config(const itm_scene* s, itm_scene_config* c, itm_scene_params* p) {
+  if (c) *c = s->impl->cfg;
+  if (p) *p = s->impl->prm;
+  return ITM_OK;
+}
+int itmr_reset_scene(itm_scene* s, itm_stream) { s->impl->reset(); return ITM_OK; }
+
+int itmr_render_state_create(const itm_scene* s, int w, int h, itm_render_state** out) {
+  itm_render_state* r = new itm_render_state();
+  r->rs = s->impl->createRenderState(w, h);
+  r->hash = s->impl->cfg.indexType == ITM_INDEX_HASH;
+  r->w = w; r->h = h;
+  r->ts = new ITMTrackingState(Vector2i(w, h), MEMORYDEVICE_CPU);
+  *out = r;
+  return ITM_OK;
+}
+int itmr_render_state_destroy(itm_render_state* r) {
+  if (r) { delete r->rs; delete r->view; delete r->ts; delete r; }
+  return ITM_OK;
+}
+
+int itmr_allocate_scene_from_depth(itm_scene* s, const itm_view* v, itm_render_state* r, int only, itm_stream) {
+  load_view(r, v);
+  s->impl->allocate(r->view, r->ts, r->rs, only != 0);
+  return ITM_OK;
+}
+int itmr_integrate_into_scene(itm_scene* s, const itm_view* v, itm_render_state* r, itm_stream) {
+  load_view(r, v);
+  s->impl->integrate(r->view, r->ts, r->rs);
+  return ITM_OK;
+}
+static void pose_intr(const float M[16], const float intr[4], ITMPose& pose, ITMIntrinsics& in) {
+  Matrix4f m; set_matrix(m, M); pose.SetM(m);
+  in.SetFrom(intr[0], intr[1], intr[2], intr[3], 0, 0);
+}
+int itmr_find_visible_blocks(const itm_scene* s, const float M[16], const float intr[4], itm_render_state* r, itm_stream) {
+  ITMPose pose; ITMIntrinsics in; pose_intr(M, intr, pose, in);
+  s->impl->findVisible(&pose, &in, r->rs);
+  return ITM_OK;
+}
+int itmr_create_expected_depths(const itm_scene* s, const float M[16], const float intr[4], itm_render_state* r, itm_stream) {
+  ITMPose pose; ITMIntrinsics in; pose_intr(M, intr, pose, in);
+  s->impl->expectedDepths(&pose, &in, r->rs);
+  return ITM_OK;
+}
+int itmr_render_image(const itm_scene* s, const float M[16], const float intr[4], itm_render_state* r, uint8_t* out, int type, itm_stream) {
+  ITMPose pose; ITMIntrinsics in; pose_intr(M, intr, pose, in);
+  if (!out) { s->impl->renderImage(&pose, &in, r->rs, r->rs->raycastImage, type); return ITM_OK; }
+  ITMUChar4Image img(Vector2i(r->w, r->h), true, false);
+  std::memcpy(img.GetData(MEMORYDEVICE_CPU), out, (size_t)r->w * r->h * 4);
+  s->impl->renderImage(&pose, &in, r->rs, &img, type);
+  std::memcpy(out, img.GetData(MEMORYDEVICE_CPU), (size_t)r->w * r->h * 4);
+  return ITM_OK;
+}
+int itmr_find_surface(const itm_scene* s, const float M[16], const float intr[4], itm_render_state* r, itm_stream) {
+  ITMPose pose; ITMIntrinsics in; pose_intr(M, intr, pose, in);
+  s->impl->findSurface(&pose, &in, r->rs);
+  return ITM_OK;
+}
+int itmr_create_point_cloud(const itm_scene* s, const itm_view* v, itm_render_state* r, int skip, float* loc, float* col, itm_stream) {
+  load_view(r, v);
+  s->impl->pointCloud(r->view, r->ts, r->rs, skip != 0);
+  size_t n = r->ts->pointCloud->noTotalPoints;
+  r->noTotalPoints = (int)n;
+  std::memcpy(loc, r->ts->pointCloud->locations->GetData(MEMORYDEVICE_CPU), n * 16);
+  std::memcpy(col, r->ts->pointCloud->colours->GetData(MEMORYDEVICE_CPU), n * 16);
+  return ITM_OK;
+}
+int itmr_create_icp_maps(const itm_scene* s, const itm_view* v, itm_render_state* r, float* pts, float* nrm, itm_stream) {
+  load_view(r, v);
+  s->impl->icpMaps(r->view, r->ts, r->rs);
+  size_t n = (size_t)r->w * r->h;
+  std::memcpy(pts, r->ts->pointCloud->locations->GetData(MEMORYDEVICE_CPU), n * 16);
+  std::memcpy(nrm, r->ts->pointCloud->colours->GetData(MEMORYDEVICE_CPU), n * 16);
+  return ITM_OK;
+}
+int itmr_forward_render(const itm_scene* s, const itm_view* v, itm_render_state* r, itm_stream) {
+  load_view(r, v);
+  s->impl->forwardRender(r->view, r->ts, r->rs);
+  return ITM_OK;
+}
+int itmr_process_frame(itm_scene* s, const itm_view* v, itm_render_state* r, float* pts, float* nrm, itm_stream st) {
+  // ITMDenseMapper::ProcessFrame + ITMTrackingController::Prepare (requiresFullRendering)
+  load_view(r, v);
+  s->impl->allocate(r->view, r->ts, r->rs, false);
+  s->impl->integrate(r->view, r->ts, r->rs);
+  s->impl->expectedDepths(r->ts->pose_d, &r->view->calib->intrinsics_d, r->rs);
+  return itmr_create_icp_maps(s, v, r, pts, nrm, st);
+}
+
+int itmr_convert_depth_affine(const int16_t* raw, float* out, int w, int h, float a, float b, itm_stream) {
+  for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) convertDepthAffineToFloat(out, x, y, raw, Vector2i(w, h), Vector2f(a, b));
+  return ITM_OK;
+}
+int itmr_convert_disparity(const int16_t* raw, float* out, int w, int h, float c0, float c1, float fx, itm_stream) {
+  for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) convertDisparityToDepth(out, x, y, raw, Vector2f(c0, c1), fx, Vector2i(w, h));
+  return ITM_OK;
+}
+
+int itmr_get_counters(const itm_scene* s, const itm_render_state* r, itm_counters* c, itm_stream) {
+  std::memset(c, 0, sizeof *c);
+  if (s) { c->lastFreeBlockId = *s->impl->lastFreeBlockId(); c->lastFreeExcessListId = s->impl->lastFreeExcess(); }
+  if (r) {
+    if (r->hash) c->noVisibleEntries = ((ITMRenderState_VH*)r->rs)->noVisibleEntries;
+    c->noFwdProjMissingPoints = r->rs->noFwdProjMissingPoints;
+    c->noTotalPoints = r->noTotalPoints;
+  }
+  return ITM_OK;
+}
+int itmr_set_counters(itm_scene* s, itm_render_state* r, const itm_counters* c, itm_stream) {
+  if (s) { *s->impl->lastFreeBlockId() = c->lastFreeBlockId; s->impl->setLastFreeExcess(c->lastFreeExcessListId); }
+  if (r && r->hash) ((ITMRenderState_VH*)r->rs)->noVisibleEntries = c->noVisibleEntries;
+  return ITM_OK;
+}
+
+static void* buf_of(const itm_scene* s, const itm_render_state* r, int which, size_t* bytes) {
+  *bytes = 0;
+  if (which <= ITM_BUF_ALLOCATION_LIST) return s ? s->impl->buffer(which, bytes) : 0;
+  if (!r) return 0;
+  size_t P = (size_t)r->w * r->h;
+  switch (which) {
+    case ITM_BUF_VISIBLE_IDS: if (r->hash) { *bytes = (size_t)SDF_LOCAL_BLOCK_NUM * 4; return ((ITMRenderState_VH*)r->rs)->GetVisibleEntryIDs(); } break;
+    case ITM_BUF_VISIBLE_TYPE: if (r->hash) { *bytes = ITMVoxelBlockHash::noTotalEntries; return ((ITMRenderState_VH*)r->rs)->GetEntriesVisibleType(); } break;
+    case ITM_BUF_RANGE_IMAGE: *bytes = P * 8; return r->rs->renderingRangeImage->GetData(MEMORYDEVICE_CPU);
+    case ITM_BUF_RAYCAST_RESULT: *bytes = P * 16; return r->rs->raycastResult->GetData(MEMORYDEVICE_CPU);
+    case ITM_BUF_RAYCAST_IMAGE: *bytes = P * 4; return r->rs->raycastImage->GetData(MEMORYDEVICE_CPU);
+    case ITM_BUF_FORWARD_PROJECTION: *bytes = P * 16; return r->rs->forwardProjection->GetData(MEMORYDEVICE_CPU);
+    case ITM_BUF_MISSING_POINTS: *bytes = P * 4; return r->rs->fwdProjMissingPoints->GetData(MEMORYDEVICE_CPU);
+  }
+  return 0;
+}
+size_t itmr_buffer_bytes(const itm_scene* s, const itm_render_state* r, int which) { size_t b; buf_of(s, r, which, &b); return b; }
+void* itmr_buffer_ptr(const itm_scene* s, const itm_render_state* r, int which) { size_t b; return buf_of(s, r, which, &b); }
+int itmr_download(const itm_scene* s, const itm_render_state* r, int which, void* dst, size_t bytes, itm_stream) {
+  size_t b; void* p = buf_of(s, r, which, &b);
+  if (!p && bytes == 0) return ITM_OK;
+  if (!p || bytes > b) return fail(ITM_ERR_INVALID, "bad buffer / size");
+  std::memcpy(dst, p, bytes);
+  return ITM_OK;
+}
+int itmr_upload(itm_scene* s, itm_render_state* r, int which, const void* src, size_t bytes, itm_stream) {
+  size_t b; void* p = buf_of(s, r, which, &b);
+  if (!p || bytes > b) return fail(ITM_ERR_INVALID, "bad buffer / size");
+  std::memcpy(p, src, bytes);
+  return ITM_OK;
+}
+int itmr_export_visible_record(const itm_render_state* r, const float M_d[16], int max_ids, void* dst, itm_stream) {
+  if (!r || !r->hash) return fail(ITM_ERR_INVALID, "no visible list");
+  std::memcpy(dst, M_d, 64);
+  int32_t* d = (int32_t*)dst + 16;
+  ITMRenderState_VH* vh = (ITMRenderState_VH*)r->rs;
+  d[0] = vh->noVisibleEntries;
+  for (int i = 0; i < max_ids; ++i) d[1 + i] = (i < vh->noVisibleEntries) ? vh->GetVisibleEntryIDs()[i] : -1;
+  return ITM_OK;
+}
+
+}  // extern "C"
