@@ -94,6 +94,8 @@ typedef struct itm_scene_config {
   int32_t denseSize[3];   /* ITMVoxelArrayInfo::size   (default 512^3)          */
   int32_t denseOffset[3]; /* ITMVoxelArrayInfo::offset (default -256,-256,0)    */
   int32_t denseOffsetSet; /* non-zero: use denseOffset even if it is all zero   */
+  int32_t maxRenderingBlocks; /* MAX_RENDERING_BLOCKS (DeviceAgnostic/ITMVisualisationEngine.h:24);
+                                 0 = 262144.  Runtime so that the cap path can be tested.       */
 } itm_scene_config;
 
 /* The inputs an engine method takes from `const ITMView*` and `const ITMTrackingState*`:

@@ -61,7 +61,7 @@ class SceneConfig(C.Structure):
     _fields_ = [("voxelType", C.c_int32), ("indexType", C.c_int32), ("bucketNum", C.c_int32),
                 ("excessNum", C.c_int32), ("localBlockNum", C.c_int32),
                 ("denseSize", C.c_int32 * 3), ("denseOffset", C.c_int32 * 3),
-                ("denseOffsetSet", C.c_int32)]
+                ("denseOffsetSet", C.c_int32), ("maxRenderingBlocks", C.c_int32)]
 
 
 class ViewStruct(C.Structure):
@@ -189,11 +189,13 @@ class Backend:
         self.check(self.fn["stream_synchronize"](_P(stream)), "stream_synchronize")
 
     def create_scene(self, voxelType=VOXEL_S, indexType=INDEX_HASH, params: Optional[SceneParams] = None,
-                     bucketNum=0, excessNum=0, localBlockNum=0, denseSize=(0, 0, 0), denseOffset=None) -> "Scene":
+                     bucketNum=0, excessNum=0, localBlockNum=0, denseSize=(0, 0, 0), denseOffset=None,
+                     maxRenderingBlocks=0) -> "Scene":
         cfg = SceneConfig()
         cfg.voxelType, cfg.indexType = voxelType, indexType
         cfg.bucketNum, cfg.excessNum, cfg.localBlockNum = bucketNum, excessNum, localBlockNum
         cfg.denseSize[:] = denseSize
+        cfg.maxRenderingBlocks = maxRenderingBlocks
         if denseOffset is not None:
             cfg.denseOffset[:] = denseOffset
             cfg.denseOffsetSet = 1

@@ -1,0 +1,432 @@
+// alloc.hip -- voxel-block allocation and visible-list construction for the hash index.
+//
+// Reference behaviour (sequential CPU engine = the parity target):
+//   AllocateSceneFromDepth            DeviceSpecific/CPU/ITMSceneReconstructionEngine_CPU.cpp:116-291
+//   buildHashAllocAndVisibleTypePP    DeviceAgnostic/ITMSceneReconstructionEngine.h:141-241
+//   checkBlockVisibility<false>       DeviceAgnostic/ITMSceneReconstructionEngine.h:243-342
+//   FindVisibleBlocks                 DeviceSpecific/CPU/ITMVisualisationEngine_CPU.cpp:39-77
+//
+// MI355X design (not the reference's, whose CUDA twin hands out blocks through atomicSub and is
+// therefore non-deterministic):
+//   1. mark_previous_kernel  : last frame's visible list -> type 3.
+//   2. request_kernel        : one lane per depth pixel (16x4 pixels per wave, coalesced depth
+//                              reads) walks its ray segment and probes the table.  A missing
+//                              block is requested by atomicMax of the key (pixel, step)+1 on the
+//                              target slot; the largest key is exactly the "last writer in raster
+//                              order, then step order" of the sequential loop.  The first
+//                              requester of a slot also bumps the per-chunk request counters.
+//   3. allocate_sweep_kernel : chunks of 2048 slots; ranks in ascending slot order come from the
+//                              per-chunk counters + a workgroup scan, so pointers are handed out
+//                              exactly as the sequential sweep does (vbaIdx = lastFree - rank).
+//                              Only the winning key's ray is recomputed to get the block coords.
+//   4. visible_count_kernel / visible_compact_kernel : frustum re-test of type-3 slots and an
+//                              ORDERED compaction (ascending slot ids) of the visible list.
+// No host synchronisation: all counts stay in HBM.
+#include <cstring>
+
+#include "itm_internal.h"
+#include "wave_utils.h"
+
+namespace itm {
+
+struct AllocParams {
+  Mat4 invM;     // inverse of M_d (host, ORUtils cofactor scheme)
+  Mat4 M;        // M_d
+  float ifx, ify, cx, cy;   // (1/fx, 1/fy, cx, cy)
+  float fx, fy;
+  float mu, oneOverBlock, vfmin, vfmax, voxelSize;
+  int W, H;
+  uint32_t mask;
+  int bucketNum;
+  int noTotalEntries;
+  int stepBits;
+  int capIds;
+};
+
+struct BlockRay {
+  float px, py, pz;  // current point in block units
+  float dx, dy, dz;
+  int noSteps;
+};
+
+// Ray segment [d-mu, d+mu] of one depth pixel in block coordinates; same operation order as
+// DeviceAgnostic/ITMSceneReconstructionEngine.h:155-184.  Returns false for rejected pixels.
+__device__ inline bool make_block_ray(float d, int x, int y, const AllocParams& p, BlockRay& r) {
+  if (d <= 0 || (d - p.mu) < 0 || (d - p.mu) < p.vfmin || (d + p.mu) > p.vfmax) return false;
+  float cz = d;
+  float cxp = cz * (((float)x - p.cx) * p.ifx);
+  float cyp = cz * (((float)y - p.cy) * p.ify);
+  float norm = sqrtf(cxp * cxp + cyp * cyp + cz * cz);
+  float sa = 1.0f - p.mu / norm;
+  Vec3 a = transform_point(p.invM, cxp * sa, cyp * sa, cz * sa);
+  float sx = a.x * p.oneOverBlock, sy = a.y * p.oneOverBlock, sz = a.z * p.oneOverBlock;
+  float sb = 1.0f + p.mu / norm;
+  Vec3 b = transform_point(p.invM, cxp * sb, cyp * sb, cz * sb);
+  float ex = b.x * p.oneOverBlock, ey = b.y * p.oneOverBlock, ez = b.z * p.oneOverBlock;
+  float dx = ex - sx, dy = ey - sy, dz = ez - sz;
+  norm = sqrtf(dx * dx + dy * dy + dz * dz);
+  int noSteps = (int)ceilf(2.0f * norm);
+  float div = (float)(noSteps - 1);
+  r.px = sx; r.py = sy; r.pz = sz;
+  r.dx = dx / div; r.dy = dy / div; r.dz = dz / div;
+  r.noSteps = noSteps;
+  return true;
+}
+
+__global__ void __launch_bounds__(256) mark_previous_kernel(const int32_t* __restrict__ ids, const RenderCounters* __restrict__ rc,
+                                                            uint8_t* __restrict__ visT) {
+  const int nv = rc->noVisibleEntries;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += gridDim.x * blockDim.x) visT[ids[i]] = 3;
+}
+
+// One workgroup = 16x16 pixels, one wave = 16x4 pixels.
+template <bool ONLY_VISIBLE, bool FUSE_RANGE_INIT>
+__global__ void __launch_bounds__(256) request_kernel(const float* __restrict__ depth, const uint4* __restrict__ hash,
+                                                      uint8_t* __restrict__ visT, uint32_t* __restrict__ allocKey,
+                                                      int2* __restrict__ chunkReq, SceneCounters* __restrict__ counters,
+                                                      float2* __restrict__ range, RenderCounters* __restrict__ rcnt, AllocParams p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (FUSE_RANGE_INIT && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) rcnt->noRenderingBlocks = 0;
+  const int x = blockIdx.x * 16 + (lane & 15);
+  const int y = blockIdx.y * 16 + wave * 4 + (lane >> 4);
+  if (x >= p.W || y >= p.H) return;
+  const int loc = x + y * p.W;
+  if (FUSE_RANGE_INIT) range[loc] = make_float2(999999.9f, 0.05f);  // CreateExpectedDepths init, fused
+  BlockRay r;
+  if (!make_block_ray(depth[loc], x, y, p, r)) return;
+  if (!ONLY_VISIBLE && r.noSteps > (1 << p.stepBits)) {
+    atomicOr(&counters->statusFlags, 1);
+    r.noSteps = 1 << p.stepBits;
+  }
+  for (int i = 0; i < r.noSteps; ++i) {
+    const int bx = (int)(int16_t)(int)floorf(r.px), by = (int)(int16_t)(int)floorf(r.py), bz = (int)(int16_t)(int)floorf(r.pz);
+    int idx = hash_index(bx, by, bz, p.mask);
+    HashEntry he = unpack_entry(hash[idx]);
+    bool found = false;
+    if (he.px == bx && he.py == by && he.pz == bz && he.ptr >= -1) {
+      visT[idx] = (he.ptr == -1) ? 2 : 1;
+      found = true;
+    }
+    if (!found) {
+      bool isExcess = false;
+      if (he.ptr >= -1) {
+        while (he.offset >= 1) {
+          idx = p.bucketNum + he.offset - 1;
+          he = unpack_entry(hash[idx]);
+          if (he.px == bx && he.py == by && he.pz == bz && he.ptr >= -1) {
+            visT[idx] = (he.ptr == -1) ? 2 : 1;
+            found = true;
+            break;
+          }
+        }
+        isExcess = true;
+      }
+      if (!found) {
+        if (!isExcess) visT[idx] = 1;
+        if (!ONLY_VISIBLE) {
+          const uint32_t key = (((uint32_t)loc << p.stepBits) | (uint32_t)i) + 1u;
+          const uint32_t old = atomicMax(&allocKey[idx], key);
+          if (old == 0u) {
+            atomicAdd(&chunkReq[idx / kSweepChunk].x, 1);
+            if (isExcess) atomicAdd(&chunkReq[idx / kSweepChunk].y, 1);
+          }
+        }
+      }
+    }
+    r.px += r.dx; r.py += r.dy; r.pz += r.dz;
+  }
+}
+
+// Block coordinates requested by (pixel, step): replays the winner's ray with identical arithmetic.
+__device__ inline void replay_block_pos(uint32_t key, const float* __restrict__ depth, const AllocParams& p, int& bx, int& by, int& bz) {
+  const uint32_t k = key - 1u;
+  const int loc = (int)(k >> p.stepBits);
+  const int step = (int)(k & ((1u << p.stepBits) - 1u));
+  const int y = loc / p.W, x = loc - y * p.W;
+  BlockRay r;
+  make_block_ray(depth[loc], x, y, p, r);
+  for (int i = 0; i < step; ++i) { r.px += r.dx; r.py += r.dy; r.pz += r.dz; }
+  bx = (int)(int16_t)(int)floorf(r.px); by = (int)(int16_t)(int)floorf(r.py); bz = (int)(int16_t)(int)floorf(r.pz);
+}
+
+constexpr int kSlotsPerThread = kSweepChunk / 256;  // 8
+
+// Ascending-slot allocation sweep (_CPU.cpp:175-227).  chunkReq holds, per 2048-slot chunk, the
+// number of requested slots and of excess-list requests; next-frame counters are zeroed here.
+__global__ void __launch_bounds__(256) allocate_sweep_kernel(uint32_t* __restrict__ allocKey, const int2* __restrict__ chunkReq,
+                                                             int2* __restrict__ chunkReqNext, int numChunks, uint4* __restrict__ hash,
+                                                             const int32_t* __restrict__ excessList, const int32_t* __restrict__ allocList,
+                                                             uint8_t* __restrict__ visT, const SceneCounters* __restrict__ counters,
+                                                             const float* __restrict__ depth, AllocParams p) {
+  __shared__ int lds[8];
+  const int chunk = blockIdx.x;
+  const int tid = threadIdx.x;
+  if (tid == 0) chunkReqNext[chunk] = make_int2(0, 0);
+  const int2 mine = chunkReq[chunk];
+  if (mine.x == 0) return;  // nothing requested in this chunk (uniform per workgroup)
+
+  // requests in all earlier chunks
+  int b1 = 0, b2 = 0;
+  for (int j = tid; j < chunk; j += 256) { int2 c = chunkReq[j]; b1 += c.x; b2 += c.y; }
+  const int baseReq = block_reduce_sum<4>(b1, lds);
+  const int baseExc = block_reduce_sum<4>(b2, lds + 4);
+
+  const int slot0 = chunk * kSweepChunk + tid * kSlotsPerThread;
+  uint32_t keys[kSlotsPerThread];
+  uint32_t isExcessBits = 0;
+  int n1 = 0, n2 = 0;
+#pragma unroll
+  for (int k = 0; k < kSlotsPerThread; ++k) {
+    const int slot = slot0 + k;
+    keys[k] = (slot < p.noTotalEntries) ? allocKey[slot] : 0u;
+    if (keys[k]) {
+      ++n1;
+      // target of an excess request is an occupied chain tail; of an ordered request an empty head
+      if ((int)hash[slot].w >= -1) { isExcessBits |= (1u << k); ++n2; }
+    }
+  }
+  int tot;
+  int r1 = baseReq + block_exclusive_scan<4>(n1, lds, &tot);
+  int r2 = baseExc + block_exclusive_scan<4>(n2, lds + 4, &tot);
+  if (n1 == 0) return;
+  const int lastFreeVBA = counters->lastFreeBlockId;
+  const int lastFreeExc = counters->lastFreeExcessListId;
+#pragma unroll
+  for (int k = 0; k < kSlotsPerThread; ++k) {
+    if (!keys[k]) continue;
+    const int slot = slot0 + k;
+    const int vbaIdx = lastFreeVBA - r1;
+    ++r1;
+    if (isExcessBits & (1u << k)) {
+      const int exlIdx = lastFreeExc - r2;
+      ++r2;
+      if (vbaIdx >= 0 && exlIdx >= 0) {
+        int bx, by, bz;
+        replay_block_pos(keys[k], depth, p, bx, by, bz);
+        const int off = excessList[exlIdx];
+        ((uint32_t*)&hash[slot])[2] = (uint32_t)(off + 1);                 // connect the chain tail to the child
+        hash[p.bucketNum + off] = pack_entry(bx, by, bz, 0, allocList[vbaIdx]);
+        visT[p.bucketNum + off] = 1;
+      }
+    } else if (vbaIdx >= 0) {
+      int bx, by, bz;
+      replay_block_pos(keys[k], depth, p, bx, by, bz);
+      hash[slot] = pack_entry(bx, by, bz, 0, allocList[vbaIdx]);
+    }
+    allocKey[slot] = 0u;
+  }
+}
+
+__global__ void __launch_bounds__(256) clear_keys_kernel(uint32_t* allocKey, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) allocKey[i] = 0u;
+}
+
+// checkBlockVisibility<false>: corners are reached by incremental +-f updates in a fixed order.
+__device__ inline bool corner_in_image(const Mat4& M, float fx, float fy, float cx, float cy, int W, int H, float x, float y, float z) {
+  Vec3 q = transform_point(M, x, y, z);
+  if (q.z < 1e-10f) return false;
+  float u = fx * q.x / q.z + cx;
+  float v = fy * q.y / q.z + cy;
+  return (u >= 0 && u < W && v >= 0 && v < H);
+}
+__device__ inline bool block_in_frustum(int bx, int by, int bz, const Mat4& M, float fx, float fy, float cx, float cy, float voxelSize, int W, int H) {
+  const float f = (float)kBlockSide * voxelSize;
+  float x = (float)bx * f, y = (float)by * f, z = (float)bz * f;
+  if (corner_in_image(M, fx, fy, cx, cy, W, H, x, y, z)) return true;
+  z += f; if (corner_in_image(M, fx, fy, cx, cy, W, H, x, y, z)) return true;
+  y += f; if (corner_in_image(M, fx, fy, cx, cy, W, H, x, y, z)) return true;
+  x += f; if (corner_in_image(M, fx, fy, cx, cy, W, H, x, y, z)) return true;
+  z -= f; if (corner_in_image(M, fx, fy, cx, cy, W, H, x, y, z)) return true;
+  y -= f; if (corner_in_image(M, fx, fy, cx, cy, W, H, x, y, z)) return true;
+  x -= f; y += f; if (corner_in_image(M, fx, fy, cx, cy, W, H, x, y, z)) return true;
+  x += f; y -= f; z += f; if (corner_in_image(M, fx, fy, cx, cy, W, H, x, y, z)) return true;
+  return false;
+}
+
+// Pass 1 of the visible list (_CPU.cpp:229-269): re-test type-3 slots, count visible slots per
+// chunk.  Workgroup 0 also commits the pool counters of the allocation sweep (:287-290).
+template <bool COMMIT_ALLOC>
+__global__ void __launch_bounds__(256) visible_count_kernel(uint8_t* __restrict__ visT, const uint4* __restrict__ hash,
+                                                            int32_t* __restrict__ chunkVis, const int2* __restrict__ chunkReq,
+                                                            int numChunks, SceneCounters* __restrict__ counters, AllocParams p) {
+  __shared__ int lds[8];
+  const int chunk = blockIdx.x, tid = threadIdx.x;
+  const int slot0 = chunk * kSweepChunk + tid * kSlotsPerThread;
+  int n = 0;
+  if (slot0 < p.noTotalEntries) {  // noTotalEntries is a multiple of 8 (checked on the host)
+    uint2 raw = *(const uint2*)(visT + slot0);
+    if (raw.x | raw.y) {
+      uint32_t w[2] = {raw.x, raw.y};
+      bool changed = false;
+#pragma unroll
+      for (int k = 0; k < kSlotsPerThread; ++k) {
+        uint32_t t = (w[k >> 2] >> ((k & 3) * 8)) & 0xffu;
+        if (t == 3u) {
+          HashEntry he = unpack_entry(hash[slot0 + k]);
+          if (!block_in_frustum(he.px, he.py, he.pz, p.M, p.fx, p.fy, p.cx, p.cy, p.voxelSize, p.W, p.H)) {
+            w[k >> 2] &= ~(0xffu << ((k & 3) * 8));
+            t = 0; changed = true;
+          }
+        }
+        n += (t > 0u);
+      }
+      if (changed) *(uint2*)(visT + slot0) = make_uint2(w[0], w[1]);
+    }
+  }
+  const int sum = block_reduce_sum<4>(n, lds);
+  if (tid == 0) chunkVis[chunk] = sum;
+  if (COMMIT_ALLOC && chunk == 0) {
+    int a = 0, b = 0;
+    for (int j = tid; j < numChunks; j += 256) { int2 c = chunkReq[j]; a += c.x; b += c.y; }
+    a = block_reduce_sum<4>(a, lds);
+    b = block_reduce_sum<4>(b, lds + 4);
+    if (tid == 0) {
+      counters->lastFreeBlockId -= a;
+      counters->lastFreeExcessListId -= b;
+      counters->noAllocRequests = a;
+    }
+  }
+}
+
+// Pass 2: ordered compaction of slots flagged in `flags` (non-zero byte) into ascending ids.
+__global__ void __launch_bounds__(256) visible_compact_kernel(const uint8_t* __restrict__ flags, const int32_t* __restrict__ chunkVis,
+                                                              int numChunks, int noTotalEntries, int32_t* __restrict__ ids, int capIds,
+                                                              RenderCounters* __restrict__ rc) {
+  __shared__ int lds[8];
+  const int chunk = blockIdx.x, tid = threadIdx.x;
+  const int mine = chunkVis[chunk];
+  if (chunk != 0 && mine == 0) return;
+  int b = 0, all = 0;
+  for (int j = tid; j < numChunks; j += 256) { int c = chunkVis[j]; all += c; if (j < chunk) b += c; }
+  const int base = block_reduce_sum<4>(b, lds);
+  if (chunk == 0) {
+    const int total = block_reduce_sum<4>(all, lds + 4);
+    if (tid == 0) { rc->rawVisibleCount = total; rc->noVisibleEntries = total < capIds ? total : capIds; }
+    if (mine == 0) return;
+  }
+  const int slot0 = chunk * kSweepChunk + tid * kSlotsPerThread;
+  uint32_t w[2] = {0u, 0u};
+  if (slot0 < noTotalEntries) { uint2 raw = *(const uint2*)(flags + slot0); w[0] = raw.x; w[1] = raw.y; }
+  int n = 0;
+#pragma unroll
+  for (int k = 0; k < kSlotsPerThread; ++k) n += (((w[k >> 2] >> ((k & 3) * 8)) & 0xffu) != 0u);
+  int tot;
+  int pos = base + block_exclusive_scan<4>(n, lds, &tot);
+  if (n == 0) return;
+#pragma unroll
+  for (int k = 0; k < kSlotsPerThread; ++k) {
+    if (((w[k >> 2] >> ((k & 3) * 8)) & 0xffu) != 0u) {
+      if (pos < capIds) ids[pos] = slot0 + k;
+      ++pos;
+    }
+  }
+}
+
+// FindVisibleBlocks pass 1: flag every allocated slot whose block passes the frustum test.
+__global__ void __launch_bounds__(256) freeview_flag_kernel(const uint4* __restrict__ hash, uint8_t* __restrict__ flags,
+                                                            int32_t* __restrict__ chunkVis, AllocParams p) {
+  __shared__ int lds[4];
+  const int chunk = blockIdx.x, tid = threadIdx.x;
+  const int slot0 = chunk * kSweepChunk + tid * kSlotsPerThread;
+  int n = 0;
+  if (slot0 < p.noTotalEntries) {
+    uint32_t w[2] = {0u, 0u};
+#pragma unroll
+    for (int k = 0; k < kSlotsPerThread; ++k) {
+      HashEntry he = unpack_entry(hash[slot0 + k]);
+      bool vis = false;
+      if (he.ptr >= 0) vis = block_in_frustum(he.px, he.py, he.pz, p.M, p.fx, p.fy, p.cx, p.cy, p.voxelSize, p.W, p.H);
+      if (vis) { w[k >> 2] |= 1u << ((k & 3) * 8); ++n; }
+    }
+    *(uint2*)(flags + slot0) = make_uint2(w[0], w[1]);
+  }
+  const int sum = block_reduce_sum<4>(n, lds);
+  if (tid == 0) chunkVis[chunk] = sum;
+}
+
+static int fill_params(const itm_scene* s, const float* M, const float* intr, int W, int H, int capIds, AllocParams& p) {
+  memcpy(p.M.m, M, 64);
+  if (!invert4(M, p.invM.m)) return set_error(ITM_ERR_INVALID, "pose matrix is singular");
+  p.fx = intr[0]; p.fy = intr[1]; p.cx = intr[2]; p.cy = intr[3];
+  p.ifx = 1.0f / intr[0]; p.ify = 1.0f / intr[1];
+  p.mu = s->prm.mu;
+  p.voxelSize = s->prm.voxelSize;
+  p.oneOverBlock = 1.0f / (s->prm.voxelSize * kBlockSide);
+  p.vfmin = s->prm.viewFrustum_min; p.vfmax = s->prm.viewFrustum_max;
+  p.W = W; p.H = H;
+  p.mask = (uint32_t)s->cfg.bucketNum - 1u;
+  p.bucketNum = s->cfg.bucketNum;
+  p.noTotalEntries = s->noTotalEntries;
+  p.capIds = capIds;
+  int pixBits = 1;
+  while ((1ll << pixBits) < (long long)W * H) ++pixBits;
+  p.stepBits = 31 - pixBits;
+  if (p.stepBits > 12) p.stepBits = 12;
+  return ITM_OK;
+}
+
+int launch_allocate(itm_scene* s, const itm_view* v, itm_render_state* rs, bool onlyVisible, bool fuseRangeInit, hipStream_t st) {
+  AllocParams p;
+  int rc = fill_params(s, v->M_d, v->intr_d, v->w, v->h, rs->capIds, p);
+  if (rc) return rc;
+  if (p.stepBits < 4) return set_error(ITM_ERR_INVALID, "depth image too large for the allocation key");
+  const int nChunks = s->numChunks;
+  int2* reqCur = (int2*)s->chunkReq + (size_t)(s->frameParity & 1u) * nChunks;
+  int2* reqNext = (int2*)s->chunkReq + (size_t)((s->frameParity + 1u) & 1u) * nChunks;
+
+  mark_previous_kernel<<<64, 256, 0, st>>>(rs->visibleIds, rs->counters, rs->visibleType);
+  dim3 grid((v->w + 15) / 16, (v->h + 15) / 16);
+  if (onlyVisible) {
+    if (fuseRangeInit) request_kernel<true, true><<<grid, 256, 0, st>>>(v->depth, s->hash, rs->visibleType, s->allocKey, reqCur, s->counters, rs->range, rs->counters, p);
+    else request_kernel<true, false><<<grid, 256, 0, st>>>(v->depth, s->hash, rs->visibleType, s->allocKey, reqCur, s->counters, rs->range, rs->counters, p);
+    visible_count_kernel<false><<<nChunks, 256, 0, st>>>(rs->visibleType, s->hash, s->chunkVis, reqCur, nChunks, s->counters, p);
+  } else {
+    if (fuseRangeInit) request_kernel<false, true><<<grid, 256, 0, st>>>(v->depth, s->hash, rs->visibleType, s->allocKey, reqCur, s->counters, rs->range, rs->counters, p);
+    else request_kernel<false, false><<<grid, 256, 0, st>>>(v->depth, s->hash, rs->visibleType, s->allocKey, reqCur, s->counters, rs->range, rs->counters, p);
+    allocate_sweep_kernel<<<nChunks, 256, 0, st>>>(s->allocKey, reqCur, reqNext, nChunks, s->hash, s->excessList, s->allocList,
+                                                   rs->visibleType, s->counters, v->depth, p);
+    visible_count_kernel<true><<<nChunks, 256, 0, st>>>(rs->visibleType, s->hash, s->chunkVis, reqCur, nChunks, s->counters, p);
+    s->frameParity++;
+  }
+  visible_compact_kernel<<<nChunks, 256, 0, st>>>(rs->visibleType, s->chunkVis, nChunks, s->noTotalEntries, rs->visibleIds, rs->capIds, rs->counters);
+  ITM_LAUNCH_CHECK();
+  return ITM_OK;
+}
+
+int launch_find_visible(const itm_scene* s, const float* M, const float* intr, itm_render_state* rs, hipStream_t st) {
+  AllocParams p;
+  int rc = fill_params(s, M, intr, rs->w, rs->h, rs->capIds, p);
+  if (rc) return rc;
+  const int nChunks = s->numChunks;
+  // flags live in the allocation-key scratch (4 bytes per slot available, 1 used); it is zero
+  // between frames and is re-zeroed below.
+  uint8_t* flags = (uint8_t*)s->allocKey;
+  freeview_flag_kernel<<<nChunks, 256, 0, st>>>(s->hash, flags, s->chunkVis, p);
+  visible_compact_kernel<<<nChunks, 256, 0, st>>>(flags, s->chunkVis, nChunks, s->noTotalEntries, rs->visibleIds, rs->capIds, rs->counters);
+  clear_keys_kernel<<<512, 256, 0, st>>>(s->allocKey, (s->noTotalEntries + 3) / 4);
+  ITM_LAUNCH_CHECK();
+  return ITM_OK;
+}
+
+}  // namespace itm
+
+using namespace itm;
+
+extern "C" {
+
+int itm_allocate_scene_from_depth(itm_scene* s, const itm_view* v, itm_render_state* rs, int onlyUpdateVisibleList, itm_stream stream) {
+  if (!s || !v || !rs) return set_error(ITM_ERR_INVALID, "null argument");
+  if (s->cfg.indexType == ITM_INDEX_DENSE) return ITM_OK;  // _CPU.cpp:314-317
+  if (!v->depth) return set_error(ITM_ERR_INVALID, "null depth image");
+  if (rs->scene != s || v->w != rs->w || v->h != rs->h) return set_error(ITM_ERR_INVALID, "view / render state mismatch");
+  return launch_allocate(s, v, rs, onlyUpdateVisibleList != 0, false, as_stream(stream));
+}
+
+int itm_find_visible_blocks(const itm_scene* s, const float M[16], const float intr[4], itm_render_state* rs, itm_stream stream) {
+  if (!s || !M || !intr || !rs) return set_error(ITM_ERR_INVALID, "null argument");
+  if (s->cfg.indexType == ITM_INDEX_DENSE) return ITM_OK;  // ITMVisualisationEngine_CPU.cpp:34-37
+  if (rs->scene != s) return set_error(ITM_ERR_INVALID, "render state belongs to another scene");
+  return launch_find_visible(s, M, intr, rs, as_stream(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,225 @@
+// integrate.hip -- per-voxel TSDF / weight / colour fusion.
+//
+// Reference behaviour:
+//   IntegrateIntoScene (hash)   DeviceSpecific/CPU/ITMSceneReconstructionEngine_CPU.cpp:47-114
+//   IntegrateIntoScene (dense)  DeviceSpecific/CPU/ITMSceneReconstructionEngine_CPU.cpp:319-369
+//   computeUpdatedVoxelDepthInfo / ColorInfo / ComputeUpdatedVoxelInfo
+//                               DeviceAgnostic/ITMSceneReconstructionEngine.h:9-139
+//   interpolateBilinear         DeviceAgnostic/ITMPixelUtils.h:11-39
+//
+// MI355X design: the hash kernel gives one 8x8x8 block to a 512-lane workgroup (8 waves, one z-slice
+// per wave, each wave reading/writing one contiguous 64-voxel run); the grid is a fixed number of
+// persistent workgroups striding over the device-resident visible list, so no count is read back.
+// The dense kernel streams the volume with 16-byte accesses (4 ITMVoxel_s per lane) and writes
+// only 128-bit groups that changed.  The depth map is small (1.2 MB) and stays in L2.
+#include <cstring>
+
+#include "itm_internal.h"
+
+namespace itm {
+
+struct FuseParams {
+  Mat4 M_d, M_rgb;
+  float fx, fy, cx, cy;
+  float fxc, fyc, cxc, cyc;
+  float mu, voxelSize;
+  int maxW;
+  int W, H, Wc, Hc;
+  int stopAtMax;
+};
+
+// Depth part.  Returns eta (or -1 when the voxel is not touched); `touched` tells whether the
+// register image changed.  Operation order as SURVEY.md Appendix A.5.
+template <class VX>
+__device__ inline float fuse_depth(typename VX::Reg& r, float mx, float my, float mz, const float* __restrict__ depth,
+                                   const FuseParams& p, bool& touched) {
+  Vec3 pc = transform_point(p.M_d, mx, my, mz);
+  if (pc.z <= 0) return -1;
+  const float u = p.fx * pc.x / pc.z + p.cx;
+  const float v = p.fy * pc.y / pc.z + p.cy;
+  if ((u < 1) || (u > p.W - 2) || (v < 1) || (v > p.H - 2)) return -1;
+  const float dm = depth[(int)(u + 0.5f) + (int)(v + 0.5f) * p.W];
+  if (dm <= 0.0f) return -1;
+  const float eta = dm - pc.z;
+  if (eta < -p.mu) return eta;
+  const float oldF = VX::to_float(VX::raw_sdf(r));
+  const int oldW = VX::w_depth(r);
+  float newF = eta / p.mu;
+  newF = (1.0f < newF) ? 1.0f : newF;
+  int newW = 1;
+  newF = (float)oldW * oldF + (float)newW * newF;
+  newW = oldW + newW;
+  newF /= (float)newW;
+  newW = (newW < p.maxW) ? newW : p.maxW;
+  r = VX::with_depth(r, newF, newW);
+  touched = true;
+  return eta;
+}
+
+__device__ inline float round_half_away(float x) { return (x < 0) ? (x - 0.5f) : (x + 0.5f); }
+
+template <class VX>
+__device__ inline void fuse_colour(typename VX::Reg& r, float mx, float my, float mz, const uchar4* __restrict__ rgb, const FuseParams& p) {
+  int oc[3], owc;
+  VX::get_color(r, oc, owc);
+  const float oldW = (float)owc;
+  Vec3 pc = transform_point(p.M_rgb, mx, my, mz);
+  const float u = p.fxc * pc.x / pc.z + p.cxc;
+  const float v = p.fyc * pc.y / pc.z + p.cyc;
+  if ((u < 1) || (u > p.Wc - 2) || (v < 1) || (v > p.Hc - 2)) return;
+  const int px = (int)floorf(u), py = (int)floorf(v);
+  const float dx = u - (float)px, dy = v - (float)py;
+  const uchar4 zero = make_uchar4(0, 0, 0, 0);
+  const uchar4 A = rgb[px + py * p.Wc];
+  uchar4 B = zero, C = zero, D = zero;
+  if (dx != 0) B = rgb[(px + 1) + py * p.Wc];
+  if (dy != 0) C = rgb[px + (py + 1) * p.Wc];
+  if (dx != 0 && dy != 0) D = rgb[(px + 1) + (py + 1) * p.Wc];
+  const float a4[3] = {(float)A.x, (float)A.y, (float)A.z}, b4[3] = {(float)B.x, (float)B.y, (float)B.z};
+  const float c4[3] = {(float)C.x, (float)C.y, (float)C.z}, d4[3] = {(float)D.x, (float)D.y, (float)D.z};
+  float newW = oldW + 1.0f;
+  int nc[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float m = (a4[k] * (1.0f - dx) * (1.0f - dy) + b4[k] * dx * (1.0f - dy) + c4[k] * (1.0f - dx) * dy + d4[k] * dx * dy);
+    m = m / 255.0f;
+    float c = ((float)oc[k] / 255.0f) * oldW + m * 1.0f;
+    c /= newW;
+    int vi = (int)round_half_away(c * 255.0f);
+    vi = (vi < 255) ? vi : 255;
+    nc[k] = (0 < vi) ? vi : 0;
+  }
+  const float maxWf = (float)(p.maxW & 0xff);
+  newW = (newW < maxWf) ? newW : maxWf;
+  r = VX::with_color(r, nc, (int)newW);
+}
+
+template <class VX>
+__device__ inline bool fuse_voxel(typename VX::Reg& r, float mx, float my, float mz, const float* __restrict__ depth,
+                                  const uchar4* __restrict__ rgb, const FuseParams& p) {
+  bool touched = false;
+  const float eta = fuse_depth<VX>(r, mx, my, mz, depth, p, touched);
+  if constexpr (VX::kColor) {
+    if (!((eta > p.mu) || (fabsf(eta / p.mu) > 0.25f))) {
+      fuse_colour<VX>(r, mx, my, mz, rgb, p);
+      touched = true;
+    }
+  }
+  return touched;
+}
+
+template <class VX>
+__global__ void __launch_bounds__(512) integrate_hash_kernel(const int32_t* __restrict__ visibleIds, const RenderCounters* __restrict__ rc,
+                                                             const uint4* __restrict__ hash, void* __restrict__ vba,
+                                                             const float* __restrict__ depth, const uchar4* __restrict__ rgb, FuseParams p) {
+  const int nv = rc->noVisibleEntries;
+  const int t = threadIdx.x;
+  const int x = t & 7, y = (t >> 3) & 7, z = t >> 6;
+  for (int e = blockIdx.x; e < nv; e += gridDim.x) {
+    const HashEntry he = unpack_entry(hash[visibleIds[e]]);
+    if (he.ptr < 0) continue;
+    const size_t vi = (size_t)he.ptr * kBlockVoxels + t;
+    typename VX::Reg r = VX::load(vba, vi);
+    if (p.stopAtMax && VX::w_depth(r) == p.maxW) continue;
+    const float mx = (float)(he.px * kBlockSide + x) * p.voxelSize;
+    const float my = (float)(he.py * kBlockSide + y) * p.voxelSize;
+    const float mz = (float)(he.pz * kBlockSide + z) * p.voxelSize;
+    if (fuse_voxel<VX>(r, mx, my, mz, depth, rgb, p)) VX::store(vba, vi, r);
+  }
+}
+
+// Dense volume, generic voxel type: one voxel per lane, x fastest (coalesced).
+template <class VX>
+__global__ void __launch_bounds__(256) integrate_dense_kernel(void* __restrict__ vba, const float* __restrict__ depth,
+                                                              const uchar4* __restrict__ rgb, FuseParams p, int sx, int sy, int sz,
+                                                              int ox, int oy, int oz) {
+  const size_t n = (size_t)sx * sy * sz;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t loc = (size_t)blockIdx.x * blockDim.x + threadIdx.x; loc < n; loc += stride) {
+    const int z = (int)(loc / ((size_t)sx * sy));
+    const int rem = (int)(loc - (size_t)z * sx * sy);
+    const int y = rem / sx;
+    const int x = rem - y * sx;
+    typename VX::Reg r = VX::load(vba, loc);
+    if (p.stopAtMax && VX::w_depth(r) == p.maxW) continue;
+    const float mx = (float)(x + ox) * p.voxelSize, my = (float)(y + oy) * p.voxelSize, mz = (float)(z + oz) * p.voxelSize;
+    if (fuse_voxel<VX>(r, mx, my, mz, depth, rgb, p)) VX::store(vba, loc, r);
+  }
+}
+
+// Dense volume of ITMVoxel_s with sx % 4 == 0: 4 voxels (16 B) per lane, one 1 KiB row segment per
+// wave instruction; a group is written back only if one of its voxels changed.
+__global__ void __launch_bounds__(256) integrate_dense_s_x4_kernel(uint4* __restrict__ vba, const float* __restrict__ depth, FuseParams p,
+                                                                   int sx, int sy, int sz, int ox, int oy, int oz) {
+  const int sx4 = sx >> 2;
+  const size_t n4 = (size_t)sx4 * sy * sz;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < n4; g += stride) {
+    const int z = (int)(g / ((size_t)sx4 * sy));
+    const int rem = (int)(g - (size_t)z * sx4 * sy);
+    const int y = rem / sx4;
+    const int x0 = (rem - y * sx4) * 4;
+    uint4 q = vba[g];
+    uint32_t v[4] = {q.x, q.y, q.z, q.w};
+    const float my = (float)(y + oy) * p.voxelSize, mz = (float)(z + oz) * p.voxelSize;
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (p.stopAtMax && VoxelS::w_depth(v[k]) == p.maxW) continue;
+      const float mx = (float)(x0 + k + ox) * p.voxelSize;
+      bool touched = false;
+      fuse_depth<VoxelS>(v[k], mx, my, mz, depth, p, touched);
+      any |= touched;
+    }
+    if (any) vba[g] = make_uint4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipStream_t st) {
+  FuseParams p;
+  memcpy(p.M_d.m, v->M_d, 64);
+  matmul4(v->rgb_to_depth_inv, v->M_d, p.M_rgb.m);  // calib_inv * M_d (_CPU.cpp:61)
+  p.fx = v->intr_d[0]; p.fy = v->intr_d[1]; p.cx = v->intr_d[2]; p.cy = v->intr_d[3];
+  p.fxc = v->intr_rgb[0]; p.fyc = v->intr_rgb[1]; p.cxc = v->intr_rgb[2]; p.cyc = v->intr_rgb[3];
+  p.mu = s->prm.mu; p.voxelSize = s->prm.voxelSize; p.maxW = s->prm.maxW;
+  p.W = v->w; p.H = v->h; p.Wc = v->w_rgb; p.Hc = v->h_rgb;
+  p.stopAtMax = s->prm.stopIntegratingAtMaxW;
+  const uchar4* rgb = (const uchar4*)v->rgb;
+  const bool colour = (s->cfg.voxelType == ITM_VOXEL_S_RGB || s->cfg.voxelType == ITM_VOXEL_F_RGB);
+  if (colour && (!rgb || v->w_rgb <= 0 || v->h_rgb <= 0)) return set_error(ITM_ERR_INVALID, "colour voxels need an rgb image");
+
+  if (s->cfg.indexType == ITM_INDEX_HASH) {
+    const int grid = 256 * 4;  // 4 x 512-lane workgroups per CU
+    int rc = dispatch_voxel(s->cfg.voxelType, [&](auto vx) {
+      using VX = decltype(vx);
+      integrate_hash_kernel<VX><<<grid, 512, 0, st>>>(rs->visibleIds, rs->counters, s->hash, s->vba, v->depth, rgb, p);
+      return ITM_OK;
+    });
+    if (rc) return rc;
+  } else {
+    const int* sz = s->cfg.denseSize; const int* of = s->cfg.denseOffset;
+    if (s->cfg.voxelType == ITM_VOXEL_S && (sz[0] % 4) == 0) {
+      integrate_dense_s_x4_kernel<<<256 * 32, 256, 0, st>>>((uint4*)s->vba, v->depth, p, sz[0], sz[1], sz[2], of[0], of[1], of[2]);
+    } else {
+      int rc = dispatch_voxel(s->cfg.voxelType, [&](auto vx) {
+        using VX = decltype(vx);
+        integrate_dense_kernel<VX><<<256 * 32, 256, 0, st>>>(s->vba, v->depth, rgb, p, sz[0], sz[1], sz[2], of[0], of[1], of[2]);
+        return ITM_OK;
+      });
+      if (rc) return rc;
+    }
+  }
+  ITM_LAUNCH_CHECK();
+  return ITM_OK;
+}
+
+}  // namespace itm
+
+using namespace itm;
+
+extern "C" int itm_integrate_into_scene(itm_scene* s, const itm_view* v, itm_render_state* rs, itm_stream stream) {
+  if (!s || !v || !rs) return set_error(ITM_ERR_INVALID, "null argument");
+  if (!v->depth) return set_error(ITM_ERR_INVALID, "null depth image");
+  if (rs->scene != s) return set_error(ITM_ERR_INVALID, "render state belongs to another scene");
+  return launch_integrate(s, v, rs, as_stream(stream));
+}

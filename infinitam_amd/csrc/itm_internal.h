@@ -1,0 +1,121 @@
+// itm_internal.h -- objects behind the opaque handles of include/itm_hip.h and shared helpers.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "../../include/itm_hip.h"
+#include "itm_types.h"
+
+namespace itm {
+
+// Device-resident scalars.  Nothing on the frame path reads them back to the host; grids are
+// sized from static upper bounds and kernels loop up to these counts.
+struct SceneCounters {
+  int32_t lastFreeBlockId;       // ITMLocalVBA::lastFreeBlockId
+  int32_t lastFreeExcessListId;  // ITMVoxelBlockHash::lastFreeExcessListId
+  int32_t noAllocRequests;       // requests seen by the last allocation sweep
+  int32_t statusFlags;           // bit0: allocation key overflow
+};
+struct RenderCounters {
+  int32_t noVisibleEntries;        // ITMRenderState_VH::noVisibleEntries
+  int32_t noFwdProjMissingPoints;  // ITMRenderState::noFwdProjMissingPoints
+  int32_t noTotalPoints;           // ITMPointCloud::noTotalPoints
+  int32_t noRenderingBlocks;       // numRenderingBlocks of CreateExpectedDepths
+  int32_t rawVisibleCount;         // visible slots before clamping to the list capacity
+  int32_t pad[3];
+};
+
+constexpr int kSweepChunk = 2048;  // hash slots handled by one workgroup in the ordered sweeps
+
+}  // namespace itm
+
+struct itm_scene {
+  itm_scene_config cfg;
+  itm_scene_params prm;
+  int device = 0;
+  size_t voxBytes = 0;
+  size_t numVoxels = 0;
+  int noTotalEntries = 0;
+  int numChunks = 0;             // ceil(noTotalEntries / kSweepChunk)
+  // ITMScene members, all in HBM
+  uint4* hash = nullptr;          // ITMHashEntry[noTotalEntries]
+  int32_t* excessList = nullptr;  // int[excessNum]
+  void* vba = nullptr;            // TVoxel[numVoxels]
+  int32_t* allocList = nullptr;   // int[localBlockNum]
+  itm::SceneCounters* counters = nullptr;
+  // allocation scratch (replaces entriesAllocType / blockCoords of the reference engines):
+  // per-slot winner key of this frame's block requests, zero between frames
+  uint32_t* allocKey = nullptr;   // uint32[noTotalEntries]
+  int32_t* chunkReq = nullptr;    // int2[2][numChunks]: (requests, excess requests) per sweep chunk, double-buffered
+  int32_t* chunkVis = nullptr;    // int[numChunks]: visible slots per sweep chunk
+  uint32_t frameParity = 0;
+};
+
+struct itm_render_state {
+  const itm_scene* scene = nullptr;
+  int w = 0, h = 0;
+  bool hash = false;
+  int capIds = 0;
+  float2* range = nullptr;     // renderingRangeImage  Vector2f[h*w]
+  float4* raycast = nullptr;   // raycastResult        Vector4f[h*w]
+  float4* fwdProj = nullptr;   // forwardProjection    Vector4f[h*w]
+  int32_t* missing = nullptr;  // fwdProjMissingPoints int[h*w]
+  uchar4* image = nullptr;     // raycastImage         Vector4u[h*w]
+  int32_t* visibleIds = nullptr;   // int[localBlockNum]
+  uint8_t* visibleType = nullptr;  // uchar[noTotalEntries]
+  itm::RenderCounters* counters = nullptr;
+  // scratch
+  uint4* projBuf = nullptr;    // per visible entry: projected bounding box + z range (2 x uint4)
+  int32_t* pixScratch = nullptr;  // int[h*w] (forward projection winners, ordered compaction flags)
+  int32_t* pixChunk = nullptr;    // int[ceil(h*w / kSweepChunk)]
+};
+
+namespace itm {
+
+int set_error(int code, const std::string& msg);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define ITM_HIP(call)                                                        \
+  do {                                                                       \
+    hipError_t _e = (call);                                                  \
+    if (_e != hipSuccess) return itm::hip_fail(_e, #call, __FILE__, __LINE__); \
+  } while (0)
+
+#define ITM_LAUNCH_CHECK()                                                    \
+  do {                                                                        \
+    hipError_t _e = hipGetLastError();                                        \
+    if (_e != hipSuccess) return itm::hip_fail(_e, "kernel launch", __FILE__, __LINE__); \
+  } while (0)
+
+inline hipStream_t as_stream(itm_stream s) { return (hipStream_t)s; }
+
+// host-side matrix helpers (host_math.cpp): same operation order as ORUtils/Matrix.h
+bool invert4(const float* m, float* out);
+void matmul4(const float* lhs, const float* rhs, float* out);
+
+// per-voxel-type dispatch
+template <class F>
+inline int dispatch_voxel(int voxelType, F&& f) {
+  switch (voxelType) {
+    case ITM_VOXEL_S: return f(VoxelS{});
+    case ITM_VOXEL_F: return f(VoxelF{});
+    case ITM_VOXEL_S_RGB: return f(VoxelSRgb{});
+    case ITM_VOXEL_F_RGB: return f(VoxelFRgb{});
+  }
+  return set_error(ITM_ERR_INVALID, "unknown voxel type");
+}
+
+// entry points implemented per translation unit
+int launch_allocate(itm_scene* s, const itm_view* v, itm_render_state* rs, bool onlyVisible, bool fuseRangeInit, hipStream_t st);
+int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipStream_t st);
+int launch_find_visible(const itm_scene* s, const float* M, const float* intr, itm_render_state* rs, hipStream_t st);
+int launch_expected_depths(const itm_scene* s, const float* M, const float* intr, itm_render_state* rs, bool rangeAlreadyInit, hipStream_t st);
+int launch_raycast(const itm_scene* s, const float* invM, const float* intr, itm_render_state* rs, float4* dst, hipStream_t st);
+int launch_icp_maps(const itm_scene* s, const itm_view* v, itm_render_state* rs, float4* points, float4* normals, hipStream_t st);
+int launch_render_image(const itm_scene* s, const float* M, const float* intr, itm_render_state* rs, uchar4* out, int type, hipStream_t st);
+int launch_forward_render(const itm_scene* s, const itm_view* v, itm_render_state* rs, hipStream_t st);
+int launch_point_cloud(const itm_scene* s, const itm_view* v, itm_render_state* rs, bool skip, float4* loc, float4* col, hipStream_t st);
+
+}  // namespace itm

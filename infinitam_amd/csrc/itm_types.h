@@ -1,0 +1,157 @@
+// itm_types.h -- device/host POD layouts of the TSDF path, byte-identical to the reference
+// (Utils/ITMLibDefines.h:71-82 ITMHashEntry, :100-199 ITMVoxel_*), plus the voxel codec traits
+// that replace the reference's TVoxel template parameter.  Padding bytes are always written as 0.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace itm {
+
+constexpr int kBlockSide = 8;     // SDF_BLOCK_SIZE
+constexpr int kBlockVoxels = 512; // SDF_BLOCK_SIZE3
+
+// 16-byte hash entry: {short pos[3]; (pad); int offset; int ptr}.  Loaded/stored as one uint4.
+struct __attribute__((aligned(16))) HashEntry {
+  int16_t px, py, pz, pad;
+  int32_t offset;  // 1-based index into the excess region, 0 = end of chain
+  int32_t ptr;     // >=0 voxel block, -1 swapped out, <-1 free
+};
+static_assert(sizeof(HashEntry) == 16, "hash entry layout");
+
+__host__ __device__ inline HashEntry unpack_entry(const uint4& r) {
+  HashEntry e;
+  e.px = (int16_t)(r.x & 0xffffu);
+  e.py = (int16_t)(r.x >> 16);
+  e.pz = (int16_t)(r.y & 0xffffu);
+  e.pad = 0;
+  e.offset = (int32_t)r.z;
+  e.ptr = (int32_t)r.w;
+  return e;
+}
+__host__ __device__ inline uint4 pack_entry(int bx, int by, int bz, int offset, int ptr) {
+  uint4 r;
+  r.x = ((uint32_t)(uint16_t)(int16_t)bx) | (((uint32_t)(uint16_t)(int16_t)by) << 16);
+  r.y = ((uint32_t)(uint16_t)(int16_t)bz);
+  r.z = (uint32_t)offset;
+  r.w = (uint32_t)ptr;
+  return r;
+}
+
+// hashIndex (DeviceAgnostic/ITMRepresentationAccess.h:8-10): coordinates sign-extend to uint32.
+__host__ __device__ inline int hash_index(int bx, int by, int bz, uint32_t mask) {
+  return (int)((((uint32_t)bx * 73856093u) ^ ((uint32_t)by * 19349669u) ^ ((uint32_t)bz * 83492791u)) & mask);
+}
+
+// ---- voxel codecs ---------------------------------------------------------------------------
+// Each codec describes one ITMVoxel_* layout through a register image (`Reg`) that is moved with
+// the widest aligned access the layout allows, and decoded/encoded field-wise.
+struct VoxelS {  // ITMVoxel_s: {i16 sdf @0; u8 w_depth @2; pad @3}, 4 B
+  static constexpr int kBytes = 4;
+  static constexpr bool kColor = false;
+  static constexpr bool kShort = true;
+  using Reg = uint32_t;
+  __device__ static Reg load(const void* base, size_t i) { return ((const uint32_t*)base)[i]; }
+  __device__ static void store(void* base, size_t i, Reg r) { ((uint32_t*)base)[i] = r; }
+  __device__ static float raw_sdf(Reg r) { return (float)(int16_t)(r & 0xffffu); }
+  __device__ static int w_depth(Reg r) { return (int)((r >> 16) & 0xffu); }
+  __device__ static float to_float(float raw) { return raw / 32767.0f; }
+  __device__ static Reg with_depth(Reg, float f, int w) {
+    int16_t s = (int16_t)(f * 32767.0f);
+    return ((uint32_t)(uint16_t)s) | ((uint32_t)(w & 0xff) << 16);
+  }
+  __device__ static Reg init() { return 32767u; }
+  // nearest/trilinear reads only need the sdf: a 2-byte load
+  __device__ static float load_raw_sdf(const void* base, size_t i) { return (float)((const int16_t*)base)[i * 2]; }
+};
+
+struct VoxelF {  // ITMVoxel_f: {f32 sdf @0; u8 w_depth @4; pad}, 8 B
+  static constexpr int kBytes = 8;
+  static constexpr bool kColor = false;
+  static constexpr bool kShort = false;
+  using Reg = uint2;
+  __device__ static Reg load(const void* base, size_t i) { return ((const uint2*)base)[i]; }
+  __device__ static void store(void* base, size_t i, Reg r) { ((uint2*)base)[i] = r; }
+  __device__ static float raw_sdf(Reg r) { return __uint_as_float(r.x); }
+  __device__ static int w_depth(Reg r) { return (int)(r.y & 0xffu); }
+  __device__ static float to_float(float raw) { return raw; }
+  __device__ static Reg with_depth(Reg, float f, int w) { return make_uint2(__float_as_uint(f), (uint32_t)(w & 0xff)); }
+  __device__ static Reg init() { return make_uint2(__float_as_uint(1.0f), 0u); }
+  __device__ static float load_raw_sdf(const void* base, size_t i) { return ((const float*)base)[i * 2]; }
+};
+
+struct VoxelSRgb {  // ITMVoxel_s_rgb: {i16 sdf @0; u8 w_depth @2; u8 clr[3] @3; u8 w_color @6; pad @7}, 8 B
+  static constexpr int kBytes = 8;
+  static constexpr bool kColor = true;
+  static constexpr bool kShort = true;
+  using Reg = uint2;
+  __device__ static Reg load(const void* base, size_t i) { return ((const uint2*)base)[i]; }
+  __device__ static void store(void* base, size_t i, Reg r) { ((uint2*)base)[i] = r; }
+  __device__ static float raw_sdf(Reg r) { return (float)(int16_t)(r.x & 0xffffu); }
+  __device__ static int w_depth(Reg r) { return (int)((r.x >> 16) & 0xffu); }
+  __device__ static float to_float(float raw) { return raw / 32767.0f; }
+  __device__ static Reg with_depth(Reg r, float f, int w) {
+    int16_t s = (int16_t)(f * 32767.0f);
+    r.x = (r.x & 0xff000000u) | ((uint32_t)(uint16_t)s) | ((uint32_t)(w & 0xff) << 16);
+    return r;
+  }
+  __device__ static void get_color(Reg r, int c[3], int& wc) {
+    c[0] = (int)(r.x >> 24); c[1] = (int)(r.y & 0xffu); c[2] = (int)((r.y >> 8) & 0xffu); wc = (int)((r.y >> 16) & 0xffu);
+  }
+  __device__ static Reg with_color(Reg r, const int c[3], int wc) {
+    r.x = (r.x & 0x00ffffffu) | ((uint32_t)(c[0] & 0xff) << 24);
+    r.y = (uint32_t)(c[1] & 0xff) | ((uint32_t)(c[2] & 0xff) << 8) | ((uint32_t)(wc & 0xff) << 16);
+    return r;
+  }
+  __device__ static Reg init() { return make_uint2(32767u, 0u); }
+  __device__ static float load_raw_sdf(const void* base, size_t i) { return (float)((const int16_t*)base)[i * 4]; }
+};
+
+struct VoxelFRgb {  // ITMVoxel_f_rgb: {f32 sdf @0; u8 w_depth @4; u8 clr[3] @5; u8 w_color @8; pad}, 12 B
+  static constexpr int kBytes = 12;
+  static constexpr bool kColor = true;
+  static constexpr bool kShort = false;
+  struct Reg { uint32_t a, b, c; };
+  __device__ static Reg load(const void* base, size_t i) {
+    const uint32_t* p = (const uint32_t*)base + i * 3;
+    Reg r; r.a = p[0]; r.b = p[1]; r.c = p[2]; return r;
+  }
+  __device__ static void store(void* base, size_t i, Reg r) {
+    uint32_t* p = (uint32_t*)base + i * 3;
+    p[0] = r.a; p[1] = r.b; p[2] = r.c;
+  }
+  __device__ static float raw_sdf(Reg r) { return __uint_as_float(r.a); }
+  __device__ static int w_depth(Reg r) { return (int)(r.b & 0xffu); }
+  __device__ static float to_float(float raw) { return raw; }
+  __device__ static Reg with_depth(Reg r, float f, int w) {
+    r.a = __float_as_uint(f);
+    r.b = (r.b & 0xffffff00u) | (uint32_t)(w & 0xff);
+    return r;
+  }
+  __device__ static void get_color(Reg r, int c[3], int& wc) {
+    c[0] = (int)((r.b >> 8) & 0xffu); c[1] = (int)((r.b >> 16) & 0xffu); c[2] = (int)(r.b >> 24); wc = (int)(r.c & 0xffu);
+  }
+  __device__ static Reg with_color(Reg r, const int c[3], int wc) {
+    r.b = (r.b & 0xffu) | ((uint32_t)(c[0] & 0xff) << 8) | ((uint32_t)(c[1] & 0xff) << 16) | ((uint32_t)(c[2] & 0xff) << 24);
+    r.c = (uint32_t)(wc & 0xff);
+    return r;
+  }
+  __device__ static Reg init() { Reg r; r.a = __float_as_uint(1.0f); r.b = 0; r.c = 0; return r; }
+  __device__ static float load_raw_sdf(const void* base, size_t i) { return ((const float*)base)[i * 3]; }
+};
+
+// 4x4 column-major matrix passed to kernels by value
+struct Mat4 { float m[16]; };
+
+// Matrix4 * (x,y,z,1): per row ((m0*x + m4*y) + m8*z) + m12*1, as ORUtils/Matrix.h:115-122.
+// Compiled with -ffp-contract=off, so every product and sum is rounded on its own.
+struct Vec3 { float x, y, z; };
+__host__ __device__ inline Vec3 transform_point(const Mat4& M, float x, float y, float z) {
+  Vec3 r;
+  r.x = M.m[0] * x + M.m[4] * y + M.m[8] * z + M.m[12] * 1.0f;
+  r.y = M.m[1] * x + M.m[5] * y + M.m[9] * z + M.m[13] * 1.0f;
+  r.z = M.m[2] * x + M.m[6] * y + M.m[10] * z + M.m[14] * 1.0f;
+  return r;
+}
+
+}  // namespace itm

@@ -1,0 +1,444 @@
+// scene.hip -- scene / render-state lifetime, ResetScene, state transfer and the small helpers of
+// the C-ABI (include/itm_hip.h).  Reference behaviour restated:
+//   ResetScene               DeviceSpecific/CPU/ITMSceneReconstructionEngine_CPU.cpp:24-45, :301-312
+//   ITMScene / ITMLocalVBA   Objects/ITMScene.h:37-43, Objects/ITMLocalVBA.h:40-48
+//   ITMRenderState(_VH)      Objects/ITMRenderState.h:51-75, Objects/ITMRenderState_VH.h:38-47
+//   view builder conversions DeviceAgnostic/ITMViewBuilder.h:7-28
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "itm_internal.h"
+
+namespace itm {
+
+static thread_local std::string g_last_error;
+
+int set_error(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+  char buf[512];
+  snprintf(buf, sizeof buf, "%s: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+  g_last_error = buf;
+  return ITM_ERR_DEVICE;
+}
+
+// ---- host matrix helpers ---------------------------------------------------------------------
+// Matrix4::inv (ORUtils/Matrix.h:162-223): cofactors of the transposed matrix, then every element
+// times 1/det.  Host code in this file is compiled with -ffp-contract=off as well.
+static inline float tri(float a, float b, float c, float d, float e, float f) { return a * b + c * d + e * f; }
+
+bool invert4(const float* m, float* o) {
+  float s[16], t[12];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) s[i + 4 * j] = m[i * 4 + j];
+  t[0] = s[10] * s[15]; t[1] = s[11] * s[14]; t[2] = s[9] * s[15];  t[3] = s[11] * s[13];
+  t[4] = s[9] * s[14];  t[5] = s[10] * s[13]; t[6] = s[8] * s[15];  t[7] = s[11] * s[12];
+  t[8] = s[8] * s[14];  t[9] = s[10] * s[12]; t[10] = s[8] * s[13]; t[11] = s[9] * s[12];
+  o[0] = tri(t[0], s[5], t[3], s[6], t[4], s[7]) - tri(t[1], s[5], t[2], s[6], t[5], s[7]);
+  o[1] = tri(t[1], s[4], t[6], s[6], t[9], s[7]) - tri(t[0], s[4], t[7], s[6], t[8], s[7]);
+  o[2] = tri(t[2], s[4], t[7], s[5], t[10], s[7]) - tri(t[3], s[4], t[6], s[5], t[11], s[7]);
+  o[3] = tri(t[5], s[4], t[8], s[5], t[11], s[6]) - tri(t[4], s[4], t[9], s[5], t[10], s[6]);
+  float det = s[0] * o[0] + s[1] * o[1] + s[2] * o[2] + s[3] * o[3];
+  if (det == 0.0f) return false;
+  o[4] = tri(t[1], s[1], t[2], s[2], t[5], s[3]) - tri(t[0], s[1], t[3], s[2], t[4], s[3]);
+  o[5] = tri(t[0], s[0], t[7], s[2], t[8], s[3]) - tri(t[1], s[0], t[6], s[2], t[9], s[3]);
+  o[6] = tri(t[3], s[0], t[6], s[1], t[11], s[3]) - tri(t[2], s[0], t[7], s[1], t[10], s[3]);
+  o[7] = tri(t[4], s[0], t[9], s[1], t[10], s[2]) - tri(t[5], s[0], t[8], s[1], t[11], s[2]);
+  t[0] = s[2] * s[7]; t[1] = s[3] * s[6]; t[2] = s[1] * s[7];  t[3] = s[3] * s[5];
+  t[4] = s[1] * s[6]; t[5] = s[2] * s[5]; t[6] = s[0] * s[7];  t[7] = s[3] * s[4];
+  t[8] = s[0] * s[6]; t[9] = s[2] * s[4]; t[10] = s[0] * s[5]; t[11] = s[1] * s[4];
+  o[8] = tri(t[0], s[13], t[3], s[14], t[4], s[15]) - tri(t[1], s[13], t[2], s[14], t[5], s[15]);
+  o[9] = tri(t[1], s[12], t[6], s[14], t[9], s[15]) - tri(t[0], s[12], t[7], s[14], t[8], s[15]);
+  o[10] = tri(t[2], s[12], t[7], s[13], t[10], s[15]) - tri(t[3], s[12], t[6], s[13], t[11], s[15]);
+  o[11] = tri(t[5], s[12], t[8], s[13], t[11], s[14]) - tri(t[4], s[12], t[9], s[13], t[10], s[14]);
+  o[12] = tri(t[2], s[10], t[5], s[11], t[1], s[9]) - tri(t[4], s[11], t[0], s[9], t[3], s[10]);
+  o[13] = tri(t[8], s[11], t[0], s[8], t[7], s[10]) - tri(t[6], s[10], t[9], s[11], t[1], s[8]);
+  o[14] = tri(t[6], s[9], t[11], s[11], t[3], s[8]) - tri(t[10], s[11], t[2], s[8], t[7], s[9]);
+  o[15] = tri(t[10], s[10], t[4], s[8], t[9], s[9]) - tri(t[8], s[9], t[11], s[10], t[5], s[8]);
+  float rdet = 1 / det;
+  for (int i = 0; i < 16; ++i) o[i] *= rdet;
+  return true;
+}
+
+// Matrix4 * Matrix4 (ORUtils/Matrix.h:102-108): element (col,row) accumulated from zero over k.
+void matmul4(const float* lhs, const float* rhs, float* out) {
+  for (int col = 0; col < 4; ++col)
+    for (int row = 0; row < 4; ++row) {
+      float acc = 0.0f;
+      for (int k = 0; k < 4; ++k) acc += lhs[k * 4 + row] * rhs[col * 4 + k];
+      out[col * 4 + row] = acc;
+    }
+}
+
+// ---- fill kernels ----------------------------------------------------------------------------
+template <class VX>
+__global__ void __launch_bounds__(256) reset_voxels_kernel(void* vba, size_t n) {
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  typename VX::Reg init = VX::init();
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) VX::store(vba, i, init);
+}
+
+// VoxelS volumes are the large ones (dense 512^3): write 16 bytes per lane.
+__global__ void __launch_bounds__(256) reset_voxels_s_x4_kernel(uint4* vba, size_t n4) {
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  const uint4 v = make_uint4(32767u, 32767u, 32767u, 32767u);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) vba[i] = v;
+}
+
+__global__ void __launch_bounds__(256) reset_hash_kernel(uint4* hash, int nEntries, int32_t* excessList, int nExcess,
+                                                         int32_t* allocList, int nBlocks, uint32_t* allocKey,
+                                                         int32_t* chunkReq, int nChunkReq, SceneCounters* counters) {
+  int stride = gridDim.x * blockDim.x;
+  int i0 = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint4 empty = pack_entry(0, 0, 0, 0, -2);
+  for (int i = i0; i < nEntries; i += stride) { hash[i] = empty; allocKey[i] = 0u; }
+  for (int i = i0; i < nExcess; i += stride) excessList[i] = i;
+  for (int i = i0; i < nBlocks; i += stride) allocList[i] = i;
+  for (int i = i0; i < nChunkReq; i += stride) chunkReq[i] = 0;
+  if (i0 == 0) {
+    counters->lastFreeBlockId = nBlocks - 1;
+    counters->lastFreeExcessListId = nExcess - 1;
+    counters->noAllocRequests = 0;
+    counters->statusFlags = 0;
+  }
+}
+
+__global__ void reset_dense_kernel(int32_t* allocList, SceneCounters* counters) {
+  allocList[0] = 0;
+  counters->lastFreeBlockId = 0;
+  counters->lastFreeExcessListId = 0;
+  counters->noAllocRequests = 0;
+  counters->statusFlags = 0;
+}
+
+__global__ void __launch_bounds__(256) fill_range_kernel(float2* img, int n, float a, float b) {
+  int stride = gridDim.x * blockDim.x;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) img[i] = make_float2(a, b);
+}
+
+// convertDepthAffineToFloat (DeviceAgnostic/ITMViewBuilder.h:22-28)
+__global__ void __launch_bounds__(256) depth_affine_kernel(const int16_t* raw, float* out, int n, float a, float b) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int16_t d = raw[i];
+  out[i] = ((d <= 0) || (d > 32000)) ? -1.0f : (float)d * a + b;
+}
+// convertDisparityToDepth (DeviceAgnostic/ITMViewBuilder.h:7-20)
+__global__ void __launch_bounds__(256) depth_disparity_kernel(const int16_t* raw, float* out, int n, float c0, float c1, float fx) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float t = c0 - (float)raw[i];
+  float depth;
+  if (t == 0) depth = 0.0f; else depth = 8.0f * c1 * fx / t;
+  out[i] = (depth > 0) ? depth : -1.0f;
+}
+
+__global__ void __launch_bounds__(256) export_record_kernel(const int32_t* ids, const RenderCounters* rc, Mat4 M, int maxIds, int32_t* dst) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int nv = rc->noVisibleEntries;
+  if (i < 16) dst[i] = __float_as_int(M.m[i]);
+  if (i == 16) dst[16] = nv;
+  if (i < maxIds) dst[17 + i] = (i < nv) ? ids[i] : -1;
+}
+
+static void* buffer_of(const itm_scene* s, const itm_render_state* rs, int which, size_t* bytes) {
+  *bytes = 0;
+  bool hashScene = s && s->cfg.indexType == ITM_INDEX_HASH;
+  switch (which) {
+    case ITM_BUF_HASH_ENTRIES: if (hashScene) { *bytes = (size_t)s->noTotalEntries * 16; return s->hash; } break;
+    case ITM_BUF_EXCESS_LIST: if (hashScene) { *bytes = (size_t)s->cfg.excessNum * 4; return s->excessList; } break;
+    case ITM_BUF_VOXEL_BLOCKS: if (s) { *bytes = s->numVoxels * s->voxBytes; return s->vba; } break;
+    case ITM_BUF_ALLOCATION_LIST: if (s) { *bytes = (hashScene ? (size_t)s->cfg.localBlockNum : 1) * 4; return s->allocList; } break;
+    default: break;
+  }
+  if (!rs) return nullptr;
+  size_t P = (size_t)rs->w * rs->h;
+  switch (which) {
+    case ITM_BUF_VISIBLE_IDS: if (rs->hash) { *bytes = (size_t)rs->capIds * 4; return rs->visibleIds; } break;
+    case ITM_BUF_VISIBLE_TYPE: if (rs->hash) { *bytes = (size_t)rs->scene->noTotalEntries; return rs->visibleType; } break;
+    case ITM_BUF_RANGE_IMAGE: *bytes = P * 8; return rs->range;
+    case ITM_BUF_RAYCAST_RESULT: *bytes = P * 16; return rs->raycast;
+    case ITM_BUF_RAYCAST_IMAGE: *bytes = P * 4; return rs->image;
+    case ITM_BUF_FORWARD_PROJECTION: *bytes = P * 16; return rs->fwdProj;
+    case ITM_BUF_MISSING_POINTS: *bytes = P * 4; return rs->missing;
+    default: break;
+  }
+  return nullptr;
+}
+
+static void free_scene(itm_scene* s) {
+  if (!s) return;
+  (void)hipFree(s->hash); (void)hipFree(s->excessList); (void)hipFree(s->vba); (void)hipFree(s->allocList);
+  (void)hipFree(s->counters); (void)hipFree(s->allocKey); (void)hipFree(s->chunkReq); (void)hipFree(s->chunkVis);
+  delete s;
+}
+static void free_rs(itm_render_state* r) {
+  if (!r) return;
+  (void)hipFree(r->range); (void)hipFree(r->raycast); (void)hipFree(r->fwdProj); (void)hipFree(r->missing);
+  (void)hipFree(r->image); (void)hipFree(r->visibleIds); (void)hipFree(r->visibleType); (void)hipFree(r->counters);
+  (void)hipFree(r->projBuf); (void)hipFree(r->pixScratch); (void)hipFree(r->pixChunk);
+  delete r;
+}
+
+}  // namespace itm
+
+using namespace itm;
+
+extern "C" {
+
+const char* itm_version(void) { return "itm-hip 0.1 (gfx950)"; }
+const char* itm_last_error(void) { return g_last_error.c_str(); }
+int itm_uses_device_memory(void) { return 1; }
+size_t itm_voxel_size_bytes(int t) {
+  switch (t) {
+    case ITM_VOXEL_S: return VoxelS::kBytes;
+    case ITM_VOXEL_F: return VoxelF::kBytes;
+    case ITM_VOXEL_S_RGB: return VoxelSRgb::kBytes;
+    case ITM_VOXEL_F_RGB: return VoxelFRgb::kBytes;
+  }
+  return 0;
+}
+
+int itm_dev_malloc(void** p, size_t n) {
+  if (!p) return set_error(ITM_ERR_INVALID, "null pointer");
+  ITM_HIP(hipMalloc(p, n ? n : 1));
+  return ITM_OK;
+}
+int itm_dev_free(void* p) { ITM_HIP(hipFree(p)); return ITM_OK; }
+int itm_memcpy_h2d(void* d, const void* s, size_t n, itm_stream st) {
+  ITM_HIP(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, as_stream(st)));
+  return ITM_OK;
+}
+int itm_memcpy_d2h(void* d, const void* s, size_t n, itm_stream st) {
+  ITM_HIP(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, as_stream(st)));
+  return ITM_OK;
+}
+int itm_stream_synchronize(itm_stream st) { ITM_HIP(hipStreamSynchronize(as_stream(st))); return ITM_OK; }
+int itm_set_device(int d) { ITM_HIP(hipSetDevice(d)); return ITM_OK; }
+
+int itm_scene_create(const itm_scene_config* cfg_in, const itm_scene_params* prm, itm_scene** out) {
+  if (!cfg_in || !prm || !out) return set_error(ITM_ERR_INVALID, "null argument");
+  itm_scene_config cfg = *cfg_in;
+  if (cfg.bucketNum == 0) cfg.bucketNum = ITM_DEFAULT_BUCKET_NUM;
+  if (cfg.excessNum == 0) cfg.excessNum = ITM_DEFAULT_EXCESS_NUM;
+  if (cfg.localBlockNum == 0) cfg.localBlockNum = ITM_DEFAULT_LOCAL_BLOCK_NUM;
+  if (cfg.denseSize[0] == 0 && cfg.denseSize[1] == 0 && cfg.denseSize[2] == 0) {
+    cfg.denseSize[0] = cfg.denseSize[1] = cfg.denseSize[2] = 512;
+    if (!cfg.denseOffsetSet) { cfg.denseOffset[0] = -256; cfg.denseOffset[1] = -256; cfg.denseOffset[2] = 0; }
+  }
+  cfg.denseOffsetSet = 1;
+  if (cfg.maxRenderingBlocks == 0) cfg.maxRenderingBlocks = ITM_MAX_RENDERING_BLOCKS;
+  if (cfg.maxRenderingBlocks < 0) return set_error(ITM_ERR_INVALID, "maxRenderingBlocks must be positive");
+  size_t vb = itm_voxel_size_bytes(cfg.voxelType);
+  if (!vb) return set_error(ITM_ERR_INVALID, "unknown voxel type");
+  if (cfg.indexType != ITM_INDEX_HASH && cfg.indexType != ITM_INDEX_DENSE) return set_error(ITM_ERR_INVALID, "unknown index type");
+  if (cfg.indexType == ITM_INDEX_HASH) {
+    if (cfg.bucketNum <= 0 || (cfg.bucketNum & (cfg.bucketNum - 1))) return set_error(ITM_ERR_INVALID, "bucketNum must be a power of two");
+    if (cfg.excessNum <= 0 || cfg.localBlockNum <= 0) return set_error(ITM_ERR_INVALID, "pool sizes must be positive");
+    if ((cfg.bucketNum + cfg.excessNum) % 8 != 0) return set_error(ITM_ERR_INVALID, "bucketNum + excessNum must be a multiple of 8");
+  } else {
+    if (cfg.denseSize[0] <= 0 || cfg.denseSize[1] <= 0 || cfg.denseSize[2] <= 0) return set_error(ITM_ERR_INVALID, "dense size must be positive");
+  }
+  if (prm->voxelSize <= 0 || prm->mu <= 0 || prm->maxW <= 0 || prm->maxW > 255) return set_error(ITM_ERR_INVALID, "bad scene parameters");
+
+  itm_scene* s = new (std::nothrow) itm_scene();
+  if (!s) return set_error(ITM_ERR_DEVICE, "out of host memory");
+  s->cfg = cfg; s->prm = *prm; s->voxBytes = vb;
+  (void)hipGetDevice(&s->device);
+  hipError_t e = hipSuccess;
+  auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes ? bytes : 16); };
+  if (cfg.indexType == ITM_INDEX_HASH) {
+    s->noTotalEntries = cfg.bucketNum + cfg.excessNum;
+    s->numChunks = (s->noTotalEntries + kSweepChunk - 1) / kSweepChunk;
+    s->numVoxels = (size_t)cfg.localBlockNum * kBlockVoxels;
+    alloc((void**)&s->hash, (size_t)s->noTotalEntries * 16);
+    alloc((void**)&s->excessList, (size_t)cfg.excessNum * 4);
+    alloc((void**)&s->allocList, (size_t)cfg.localBlockNum * 4);
+    alloc((void**)&s->allocKey, (size_t)s->noTotalEntries * 4);
+    alloc((void**)&s->chunkReq, (size_t)s->numChunks * 2 * 2 * 4);
+    alloc((void**)&s->chunkVis, (size_t)s->numChunks * 4);
+  } else {
+    s->numVoxels = (size_t)cfg.denseSize[0] * cfg.denseSize[1] * cfg.denseSize[2];
+    alloc((void**)&s->allocList, 4);
+  }
+  alloc(&s->vba, s->numVoxels * vb + 16);
+  alloc((void**)&s->counters, sizeof(SceneCounters));
+  if (e != hipSuccess) { free_scene(s); return hip_fail(e, "hipMalloc(scene)", __FILE__, __LINE__); }
+  e = hipMemset(s->counters, 0, sizeof(SceneCounters));
+  if (e == hipSuccess && s->allocKey) e = hipMemset(s->allocKey, 0, (size_t)s->noTotalEntries * 4);
+  if (e == hipSuccess && s->chunkReq) e = hipMemset(s->chunkReq, 0, (size_t)s->numChunks * 16);
+  if (e != hipSuccess) { free_scene(s); return hip_fail(e, "hipMemset(scene)", __FILE__, __LINE__); }
+  *out = s;
+  return ITM_OK;
+}
+
+int itm_scene_destroy(itm_scene* s) { free_scene(s); return ITM_OK; }
+
+int itm_scene_get_config(const itm_scene* s, itm_scene_config* c, itm_scene_params* p) {
+  if (!s) return set_error(ITM_ERR_INVALID, "null scene");
+  if (c) *c = s->cfg;
+  if (p) *p = s->prm;
+  return ITM_OK;
+}
+
+int itm_reset_scene(itm_scene* s, itm_stream stream) {
+  if (!s) return set_error(ITM_ERR_INVALID, "null scene");
+  hipStream_t st = as_stream(stream);
+  const int grid = 2048;
+  if (s->cfg.voxelType == ITM_VOXEL_S && (s->numVoxels % 4) == 0) {
+    reset_voxels_s_x4_kernel<<<grid, 256, 0, st>>>((uint4*)s->vba, s->numVoxels / 4);
+  } else {
+    int rc = dispatch_voxel(s->cfg.voxelType, [&](auto vx) {
+      using VX = decltype(vx);
+      reset_voxels_kernel<VX><<<grid, 256, 0, st>>>(s->vba, s->numVoxels);
+      return ITM_OK;
+    });
+    if (rc) return rc;
+  }
+  ITM_LAUNCH_CHECK();
+  if (s->cfg.indexType == ITM_INDEX_HASH) {
+    reset_hash_kernel<<<1024, 256, 0, st>>>(s->hash, s->noTotalEntries, s->excessList, s->cfg.excessNum, s->allocList,
+                                            s->cfg.localBlockNum, s->allocKey, s->chunkReq, s->numChunks * 4, s->counters);
+  } else {
+    reset_dense_kernel<<<1, 1, 0, st>>>(s->allocList, s->counters);
+  }
+  ITM_LAUNCH_CHECK();
+  return ITM_OK;
+}
+
+int itm_render_state_create(const itm_scene* s, int w, int h, itm_render_state** out) {
+  if (!s || !out || w <= 0 || h <= 0) return set_error(ITM_ERR_INVALID, "bad argument");
+  if ((long long)w * h >= (1ll << 24)) return set_error(ITM_ERR_INVALID, "image too large");
+  itm_render_state* r = new (std::nothrow) itm_render_state();
+  if (!r) return set_error(ITM_ERR_DEVICE, "out of host memory");
+  r->scene = s; r->w = w; r->h = h;
+  r->hash = s->cfg.indexType == ITM_INDEX_HASH;
+  r->capIds = r->hash ? s->cfg.localBlockNum : 0;
+  size_t P = (size_t)w * h;
+  hipError_t e = hipSuccess;
+  auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes ? bytes : 16); };
+  alloc((void**)&r->range, P * 8);
+  alloc((void**)&r->raycast, P * 16);
+  alloc((void**)&r->fwdProj, P * 16);
+  alloc((void**)&r->missing, P * 4);
+  alloc((void**)&r->image, P * 4);
+  alloc((void**)&r->counters, sizeof(RenderCounters));
+  alloc((void**)&r->pixScratch, P * 4);
+  alloc((void**)&r->pixChunk, ((P + kSweepChunk - 1) / kSweepChunk) * 4 + 16);
+  if (r->hash) {
+    alloc((void**)&r->visibleIds, (size_t)r->capIds * 4);
+    alloc((void**)&r->visibleType, (size_t)s->noTotalEntries);
+    alloc((void**)&r->projBuf, (size_t)r->capIds * 32);
+  }
+  if (e != hipSuccess) { free_rs(r); return hip_fail(e, "hipMalloc(render state)", __FILE__, __LINE__); }
+  // MemoryBlock<T> storage is zero-initialised in the reference (ORUtils/MemoryBlock.h Clear on allocate)
+  e = hipMemset(r->counters, 0, sizeof(RenderCounters));
+  if (e == hipSuccess) e = hipMemset(r->raycast, 0, P * 16);
+  if (e == hipSuccess) e = hipMemset(r->fwdProj, 0, P * 16);
+  if (e == hipSuccess) e = hipMemset(r->missing, 0, P * 4);
+  if (e == hipSuccess) e = hipMemset(r->image, 0, P * 4);
+  if (e == hipSuccess && r->hash) e = hipMemset(r->visibleIds, 0, (size_t)r->capIds * 4);
+  if (e == hipSuccess && r->hash) e = hipMemset(r->visibleType, 0, (size_t)s->noTotalEntries);
+  if (e != hipSuccess) { free_rs(r); return hip_fail(e, "hipMemset(render state)", __FILE__, __LINE__); }
+  fill_range_kernel<<<256, 256, 0, 0>>>(r->range, (int)P, s->prm.viewFrustum_min, s->prm.viewFrustum_max);
+  e = hipDeviceSynchronize();
+  if (e != hipSuccess) { free_rs(r); return hip_fail(e, "init range image", __FILE__, __LINE__); }
+  *out = r;
+  return ITM_OK;
+}
+int itm_render_state_destroy(itm_render_state* r) { free_rs(r); return ITM_OK; }
+
+int itm_convert_depth_affine(const int16_t* raw, float* out, int w, int h, float a, float b, itm_stream st) {
+  if (!raw || !out || w <= 0 || h <= 0) return set_error(ITM_ERR_INVALID, "bad argument");
+  int n = w * h;
+  depth_affine_kernel<<<(n + 255) / 256, 256, 0, as_stream(st)>>>(raw, out, n, a, b);
+  ITM_LAUNCH_CHECK();
+  return ITM_OK;
+}
+int itm_convert_disparity(const int16_t* raw, float* out, int w, int h, float c0, float c1, float fx, itm_stream st) {
+  if (!raw || !out || w <= 0 || h <= 0) return set_error(ITM_ERR_INVALID, "bad argument");
+  int n = w * h;
+  depth_disparity_kernel<<<(n + 255) / 256, 256, 0, as_stream(st)>>>(raw, out, n, c0, c1, fx);
+  ITM_LAUNCH_CHECK();
+  return ITM_OK;
+}
+
+int itm_get_counters(const itm_scene* s, const itm_render_state* rs, itm_counters* out, itm_stream stream) {
+  if (!out) return set_error(ITM_ERR_INVALID, "null argument");
+  memset(out, 0, sizeof *out);
+  hipStream_t st = as_stream(stream);
+  SceneCounters sc{}; RenderCounters rc{};
+  if (s) ITM_HIP(hipMemcpyAsync(&sc, s->counters, sizeof sc, hipMemcpyDeviceToHost, st));
+  if (rs) ITM_HIP(hipMemcpyAsync(&rc, rs->counters, sizeof rc, hipMemcpyDeviceToHost, st));
+  ITM_HIP(hipStreamSynchronize(st));
+  out->lastFreeBlockId = sc.lastFreeBlockId;
+  out->lastFreeExcessListId = sc.lastFreeExcessListId;
+  out->noAllocRequests = sc.noAllocRequests;
+  out->statusFlags = sc.statusFlags;
+  out->noVisibleEntries = rc.noVisibleEntries;
+  out->noFwdProjMissingPoints = rc.noFwdProjMissingPoints;
+  out->noTotalPoints = rc.noTotalPoints;
+  out->noRenderingBlocks = rc.noRenderingBlocks;
+  return ITM_OK;
+}
+
+int itm_set_counters(itm_scene* s, itm_render_state* rs, const itm_counters* in, itm_stream stream) {
+  if (!in) return set_error(ITM_ERR_INVALID, "null argument");
+  hipStream_t st = as_stream(stream);
+  if (s) {
+    SceneCounters sc{};
+    ITM_HIP(hipMemcpyAsync(&sc, s->counters, sizeof sc, hipMemcpyDeviceToHost, st));
+    ITM_HIP(hipStreamSynchronize(st));
+    sc.lastFreeBlockId = in->lastFreeBlockId;
+    sc.lastFreeExcessListId = in->lastFreeExcessListId;
+    ITM_HIP(hipMemcpyAsync(s->counters, &sc, sizeof sc, hipMemcpyHostToDevice, st));
+    ITM_HIP(hipStreamSynchronize(st));
+  }
+  if (rs) {
+    RenderCounters rc{};
+    ITM_HIP(hipMemcpyAsync(&rc, rs->counters, sizeof rc, hipMemcpyDeviceToHost, st));
+    ITM_HIP(hipStreamSynchronize(st));
+    rc.noVisibleEntries = in->noVisibleEntries;
+    ITM_HIP(hipMemcpyAsync(rs->counters, &rc, sizeof rc, hipMemcpyHostToDevice, st));
+    ITM_HIP(hipStreamSynchronize(st));
+  }
+  return ITM_OK;
+}
+
+size_t itm_buffer_bytes(const itm_scene* s, const itm_render_state* rs, int which) {
+  size_t b; buffer_of(s, rs, which, &b); return b;
+}
+void* itm_buffer_ptr(const itm_scene* s, const itm_render_state* rs, int which) {
+  size_t b; return buffer_of(s, rs, which, &b);
+}
+int itm_download(const itm_scene* s, const itm_render_state* rs, int which, void* dst, size_t bytes, itm_stream stream) {
+  size_t b; void* p = buffer_of(s, rs, which, &b);
+  if (!p && bytes == 0) return ITM_OK;
+  if (!p || !dst || bytes > b) return set_error(ITM_ERR_INVALID, "bad buffer / size");
+  hipStream_t st = as_stream(stream);
+  ITM_HIP(hipMemcpyAsync(dst, p, bytes, hipMemcpyDeviceToHost, st));
+  ITM_HIP(hipStreamSynchronize(st));
+  return ITM_OK;
+}
+int itm_upload(itm_scene* s, itm_render_state* rs, int which, const void* src, size_t bytes, itm_stream stream) {
+  size_t b; void* p = buffer_of(s, rs, which, &b);
+  if (!p || !src || bytes > b) return set_error(ITM_ERR_INVALID, "bad buffer / size");
+  hipStream_t st = as_stream(stream);
+  ITM_HIP(hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, st));
+  ITM_HIP(hipStreamSynchronize(st));
+  return ITM_OK;
+}
+
+int itm_export_visible_record(const itm_render_state* rs, const float M_d[16], int max_ids, void* dst, itm_stream stream) {
+  if (!rs || !rs->hash || !dst || !M_d || max_ids < 0) return set_error(ITM_ERR_INVALID, "bad argument");
+  Mat4 M; memcpy(M.m, M_d, 64);
+  int n = (max_ids > 17 ? max_ids : 17);
+  export_record_kernel<<<(n + 255) / 256, 256, 0, as_stream(stream)>>>(rs->visibleIds, rs->counters, M, max_ids, (int32_t*)dst);
+  ITM_LAUNCH_CHECK();
+  return ITM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,329 @@
+// visualise.hip -- expected-depth range image, ray casting, ICP maps and free-view rendering.
+//
+// Reference behaviour:
+//   CreateExpectedDepths   DeviceSpecific/CPU/ITMVisualisationEngine_CPU.cpp:79-91 (dense), :93-152 (hash)
+//   ProjectSingleBlock / CreateRenderingBlocks   DeviceAgnostic/ITMVisualisationEngine.h:28-90
+//   GenericRaycast         ITMVisualisationEngine_CPU.cpp:154-188
+//   CreateICPMaps_common   :266-287, processPixelICP<true>  DeviceAgnostic/ITMVisualisationEngine.h:314-349
+//   RenderImage_common     :190-240, processPixelGrey/Colour/Normal  :368-409
+//   computeSingleNormalFromSDF / readFromSDF_color4u_interpolated  DeviceAgnostic/ITMRepresentationAccess.h:187-337
+//
+// MI355X design:
+//   * range image: one lane per visible block projects its 8 corners and min/max-merges its
+//     bounding box straight into the range image with integer atomics on the float bit patterns
+//     (all values are positive, so uint ordering == float ordering).  The intermediate list of
+//     16x16 "rendering blocks" of the reference only matters through its cap
+//     (MAX_RENDERING_BLOCKS); the cap is honoured exactly by an overflow pass that replays the
+//     sequential accept/skip decisions only when the total reaches the cap.
+//   * ray casting: one lane per pixel, 16x4 pixels per wave (two 8x8 range cells per wave), a
+//     per-lane block cache as in the reference; 2-byte sdf gathers from HBM/L2.
+//   * ICP maps: one lane per pixel over the ray-hit map.
+#include <cstring>
+
+#include "itm_internal.h"
+#include "shading_device.h"
+
+namespace itm {
+
+// ---------------------------------------------------------------------------------------------
+// expected depth range
+// ---------------------------------------------------------------------------------------------
+struct ProjParams {
+  Mat4 M;
+  float fx, fy, cx, cy;
+  float voxelSize;
+  int W, H;
+  int maxBlocks;
+};
+
+__global__ void __launch_bounds__(256) range_init_kernel(float2* __restrict__ img, int n, float a, float b, RenderCounters* rc) {
+  const int stride = gridDim.x * blockDim.x;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) img[i] = make_float2(a, b);
+  if (blockIdx.x == 0 && threadIdx.x == 0) rc->noRenderingBlocks = 0;
+}
+
+struct Projected { int ulx, uly, lrx, lry; float z0, z1; int n; };
+
+// ProjectSingleBlock + the tile count of CreateExpectedDepths (:128-131)
+__device__ inline Projected project_block(const HashEntry& e, const ProjParams& p) {
+  Projected r;
+  r.ulx = p.W / 8; r.uly = p.H / 8; r.lrx = -1; r.lry = -1; r.z0 = 999999.9f; r.z1 = 0.05f; r.n = 0;
+  if (e.ptr < 0) return r;
+#pragma unroll
+  for (int corner = 0; corner < 8; ++corner) {
+    const int16_t tx = (int16_t)(e.px + ((corner & 1) ? 1 : 0));
+    const int16_t ty = (int16_t)(e.py + ((corner & 2) ? 1 : 0));
+    const int16_t tz = (int16_t)(e.pz + ((corner & 4) ? 1 : 0));
+    const float x = (float)tx * (float)kBlockSide * p.voxelSize;
+    const float y = (float)ty * (float)kBlockSide * p.voxelSize;
+    const float z = (float)tz * (float)kBlockSide * p.voxelSize;
+    const Vec3 q = transform_point(p.M, x, y, z);
+    if ((double)q.z < 1e-6) continue;  // double literal in the reference
+    const float u = (p.fx * q.x / q.z + p.cx) / 8;
+    const float v = (p.fy * q.y / q.z + p.cy) / 8;
+    if ((float)r.ulx > floorf(u)) r.ulx = (int)floorf(u);
+    if ((float)r.lrx < ceilf(u)) r.lrx = (int)ceilf(u);
+    if ((float)r.uly > floorf(v)) r.uly = (int)floorf(v);
+    if ((float)r.lry < ceilf(v)) r.lry = (int)ceilf(v);
+    if (r.z0 > q.z) r.z0 = q.z;
+    if (r.z1 < q.z) r.z1 = q.z;
+  }
+  if (r.ulx < 0) r.ulx = 0;
+  if (r.uly < 0) r.uly = 0;
+  if (r.lrx >= p.W) r.lrx = p.W - 1;
+  if (r.lry >= p.H) r.lry = p.H - 1;
+  if (r.ulx > r.lrx) return r;
+  if (r.uly > r.lry) return r;
+  if (r.z0 < 0.05f) r.z0 = 0.05f;
+  if (r.z1 < 0.05f) return r;
+  const int nx = (int)ceilf((float)(r.lrx - r.ulx + 1) / 16.0f);
+  const int ny = (int)ceilf((float)(r.lry - r.uly + 1) / 16.0f);
+  r.n = nx * ny;
+  return r;
+}
+
+__device__ inline void merge_box(float2* __restrict__ range, int W, const Projected& r) {
+  const uint32_t z0 = __float_as_uint(r.z0), z1 = __float_as_uint(r.z1);
+  for (int y = r.uly; y <= r.lry; ++y)
+    for (int x = r.ulx; x <= r.lrx; ++x) {
+      uint32_t* px = (uint32_t*)&range[x + y * W];
+      atomicMin(px, z0);
+      atomicMax(px + 1, z1);
+    }
+}
+
+__global__ void __launch_bounds__(256) project_fill_kernel(const int32_t* __restrict__ ids, RenderCounters* __restrict__ rc,
+                                                           const uint4* __restrict__ hash, float2* __restrict__ range,
+                                                           uint4* __restrict__ projBuf, ProjParams p) {
+  const int nv = rc->noVisibleEntries;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nv; e += gridDim.x * blockDim.x) {
+    const HashEntry he = unpack_entry(hash[ids[e]]);
+    const Projected r = project_block(he, p);
+    projBuf[2 * e] = make_uint4((uint32_t)r.ulx, (uint32_t)r.uly, (uint32_t)r.lrx, (uint32_t)r.lry);
+    projBuf[2 * e + 1] = make_uint4(__float_as_uint(r.z0), __float_as_uint(r.z1), (uint32_t)r.n, 0u);
+    if (r.n > 0) {
+      atomicAdd(&rc->noRenderingBlocks, r.n);
+      merge_box(range, p.W, r);  // optimistic: undone by range_overflow_kernel if the cap is reached
+    }
+  }
+}
+
+// Only does work when the cap of the reference's rendering-block list would have been hit:
+// "if (numRenderingBlocks + required >= MAX) skip this block" is order dependent, so it is replayed
+// sequentially over the (ascending) visible list and the range image is rebuilt.
+__global__ void __launch_bounds__(256) range_overflow_kernel(RenderCounters* __restrict__ rc, float2* __restrict__ range,
+                                                             uint4* __restrict__ projBuf, ProjParams p) {
+  if (rc->noRenderingBlocks < p.maxBlocks) return;
+  const int nv = rc->noVisibleEntries;
+  const int n = p.W * p.H;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) range[i] = make_float2(999999.9f, 0.05f);
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int count = 0;
+    for (int e = 0; e < nv; ++e) {
+      uint4 b = projBuf[2 * e + 1];
+      const int need = (int)b.z;
+      if (need == 0) continue;
+      if (count + need >= p.maxBlocks) { b.w = 0u; } else { b.w = 1u; count += need; }
+      projBuf[2 * e + 1] = b;
+    }
+    rc->noRenderingBlocks = count;
+  }
+  __threadfence();
+  __syncthreads();
+  for (int e = threadIdx.x; e < nv; e += blockDim.x) {
+    const uint4 a = projBuf[2 * e], b = projBuf[2 * e + 1];
+    if (b.z == 0u || b.w == 0u) continue;
+    Projected r;
+    r.ulx = (int)a.x; r.uly = (int)a.y; r.lrx = (int)a.z; r.lry = (int)a.w;
+    r.z0 = __uint_as_float(b.x); r.z1 = __uint_as_float(b.y); r.n = (int)b.z;
+    merge_box(range, p.W, r);
+  }
+}
+
+int launch_expected_depths(const itm_scene* s, const float* M, const float* intr, itm_render_state* rs, bool rangeAlreadyInit, hipStream_t st) {
+  const int P = rs->w * rs->h;
+  if (s->cfg.indexType == ITM_INDEX_DENSE) {
+    range_init_kernel<<<512, 256, 0, st>>>(rs->range, P, 0.2f, 3.0f, rs->counters);
+    ITM_LAUNCH_CHECK();
+    return ITM_OK;
+  }
+  ProjParams p;
+  memcpy(p.M.m, M, 64);
+  p.fx = intr[0]; p.fy = intr[1]; p.cx = intr[2]; p.cy = intr[3];
+  p.voxelSize = s->prm.voxelSize;
+  p.W = rs->w; p.H = rs->h;
+  p.maxBlocks = s->cfg.maxRenderingBlocks;
+  if (!rangeAlreadyInit) range_init_kernel<<<512, 256, 0, st>>>(rs->range, P, 999999.9f, 0.05f, rs->counters);
+  project_fill_kernel<<<128, 256, 0, st>>>(rs->visibleIds, rs->counters, s->hash, rs->range, rs->projBuf, p);
+  range_overflow_kernel<<<1, 256, 0, st>>>(rs->counters, rs->range, rs->projBuf, p);
+  ITM_LAUNCH_CHECK();
+  return ITM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ray casting
+// ---------------------------------------------------------------------------------------------
+// One workgroup = 16x16 pixels; wave w covers rows 4w..4w+3 (16x4 pixels, two 8x8 range cells).
+template <class VX, bool DENSE>
+__global__ void __launch_bounds__(256) raycast_kernel(VolumeView vol, const float2* __restrict__ range, float4* __restrict__ out, RayParams p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int x = blockIdx.x * 16 + (lane & 15);
+  const int y = blockIdx.y * 16 + wave * 4 + (lane >> 4);
+  if (x >= p.W || y >= p.H) return;
+  const float2 mm = range[(x >> 3) + (y >> 3) * p.W];  // floor(x/8) + floor(y/8)*W  (_CPU.cpp:174)
+  out[x + y * p.W] = cast_ray<VX, DENSE>(x, y, vol, p, mm);
+}
+
+int launch_raycast(const itm_scene* s, const float* invM, const float* intr, itm_render_state* rs, float4* dst, hipStream_t st) {
+  RayParams p; make_ray_params(s, invM, intr, rs->w, rs->h, p);
+  const VolumeView vol = make_volume(s);
+  const dim3 grid((rs->w + 15) / 16, (rs->h + 15) / 16);
+  const bool dense = s->cfg.indexType == ITM_INDEX_DENSE;
+  int rc = dispatch_voxel(s->cfg.voxelType, [&](auto vx) {
+    using VX = decltype(vx);
+    if (dense) raycast_kernel<VX, true><<<grid, 256, 0, st>>>(vol, rs->range, dst, p);
+    else raycast_kernel<VX, false><<<grid, 256, 0, st>>>(vol, rs->range, dst, p);
+    return ITM_OK;
+  });
+  if (rc) return rc;
+  ITM_LAUNCH_CHECK();
+  return ITM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ICP maps (normals from the ray-hit map)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) icp_maps_kernel(const float4* __restrict__ rays, float4* __restrict__ points,
+                                                       float4* __restrict__ normals, uchar4* __restrict__ image, RayParams p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int x = blockIdx.x * 16 + (lane & 15);
+  const int y = blockIdx.y * 16 + wave * 4 + (lane >> 4);
+  if (x >= p.W || y >= p.H) return;
+  const int loc = x + y * p.W;
+  const float4 r = rays[loc];
+  bool found = r.w > 0.0f;
+  float nx = 0, ny = 0, nz = 0, angle = 0;
+  if (found) found = normal_from_hits(rays, x, y, p.W, p.H, p.voxelSize, p.lx, p.ly, p.lz, nx, ny, nz, angle);
+  if (found) {
+    image[loc] = grey_pixel(angle);
+    points[loc] = make_float4(r.x * p.voxelSize, r.y * p.voxelSize, r.z * p.voxelSize, 1.0f);
+    normals[loc] = make_float4(nx, ny, nz, 0.0f);
+  } else {
+    const float4 inv = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+    points[loc] = inv; normals[loc] = inv; image[loc] = make_uchar4(0, 0, 0, 0);
+  }
+}
+
+int launch_icp_maps(const itm_scene* s, const itm_view* v, itm_render_state* rs, float4* points, float4* normals, hipStream_t st) {
+  float invM[16];
+  if (!invert4(v->M_d, invM)) return set_error(ITM_ERR_INVALID, "pose matrix is singular");
+  int rc = launch_raycast(s, invM, v->intr_d, rs, rs->raycast, st);
+  if (rc) return rc;
+  RayParams p; make_ray_params(s, invM, v->intr_d, rs->w, rs->h, p);
+  const dim3 grid((rs->w + 15) / 16, (rs->h + 15) / 16);
+  icp_maps_kernel<<<grid, 256, 0, st>>>(rs->raycast, points, normals, rs->image, p);
+  ITM_LAUNCH_CHECK();
+  return ITM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// free-view rendering: SDF-gradient normals, colour lookup
+// ---------------------------------------------------------------------------------------------
+template <class VX, bool DENSE>
+__global__ void __launch_bounds__(256) render_image_kernel(VolumeView vol, const float4* __restrict__ rays, uchar4* __restrict__ out, int type, RayParams p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int x = blockIdx.x * 16 + (lane & 15);
+  const int y = blockIdx.y * 16 + wave * 4 + (lane >> 4);
+  if (x >= p.W || y >= p.H) return;
+  const int loc = x + y * p.W;
+  const float4 r = rays[loc];
+  bool found = r.w > 0;
+  float nx = 0, ny = 0, nz = 0, angle = 0;
+  if (found) found = normal_from_sdf<VX, DENSE>(vol, r.x, r.y, r.z, p, nx, ny, nz, angle);
+  if (!found) { out[loc] = make_uchar4(0, 0, 0, 0); return; }
+  if (type == ITM_RENDER_COLOUR_FROM_VOLUME) {
+    const float4 c = colour_at<VX, DENSE>(vol, r.x, r.y, r.z);
+    out[loc] = make_uchar4((unsigned char)(c.x * 255.0f), (unsigned char)(c.y * 255.0f), (unsigned char)(c.z * 255.0f), 255);
+  } else if (type == ITM_RENDER_COLOUR_FROM_NORMAL) {
+    // drawPixelNormal writes r,g,b only; the alpha byte keeps its previous value
+    unsigned char* o = (unsigned char*)&out[loc];
+    o[0] = (unsigned char)((0.3f + (-nx + 1.0f) * 0.35f) * 255.0f);
+    o[1] = (unsigned char)((0.3f + (-ny + 1.0f) * 0.35f) * 255.0f);
+    o[2] = (unsigned char)((0.3f + (-nz + 1.0f) * 0.35f) * 255.0f);
+  } else {
+    out[loc] = grey_pixel(angle);
+  }
+}
+
+int launch_render_image(const itm_scene* s, const float* M, const float* intr, itm_render_state* rs, uchar4* out, int type, hipStream_t st) {
+  float invM[16];
+  if (!invert4(M, invM)) return set_error(ITM_ERR_INVALID, "pose matrix is singular");
+  int rc = launch_raycast(s, invM, intr, rs, rs->raycast, st);
+  if (rc) return rc;
+  RayParams p; make_ray_params(s, invM, intr, rs->w, rs->h, p);
+  const VolumeView vol = make_volume(s);
+  const dim3 grid((rs->w + 15) / 16, (rs->h + 15) / 16);
+  const bool dense = s->cfg.indexType == ITM_INDEX_DENSE;
+  const bool colour = (s->cfg.voxelType == ITM_VOXEL_S_RGB || s->cfg.voxelType == ITM_VOXEL_F_RGB);
+  if (type == ITM_RENDER_COLOUR_FROM_VOLUME && !colour) type = ITM_RENDER_SHADED_GREYSCALE;  // _CPU.cpp:205-206
+  if (type != ITM_RENDER_COLOUR_FROM_VOLUME && type != ITM_RENDER_COLOUR_FROM_NORMAL) type = ITM_RENDER_SHADED_GREYSCALE;
+  rc = dispatch_voxel(s->cfg.voxelType, [&](auto vx) {
+    using VX = decltype(vx);
+    if (dense) render_image_kernel<VX, true><<<grid, 256, 0, st>>>(vol, rs->raycast, out, type, p);
+    else render_image_kernel<VX, false><<<grid, 256, 0, st>>>(vol, rs->raycast, out, type, p);
+    return ITM_OK;
+  });
+  if (rc) return rc;
+  ITM_LAUNCH_CHECK();
+  return ITM_OK;
+}
+
+}  // namespace itm
+
+using namespace itm;
+
+extern "C" {
+
+int itm_create_expected_depths(const itm_scene* s, const float M[16], const float intr[4], itm_render_state* rs, itm_stream stream) {
+  if (!s || !M || !intr || !rs) return set_error(ITM_ERR_INVALID, "null argument");
+  if (rs->scene != s) return set_error(ITM_ERR_INVALID, "render state belongs to another scene");
+  return launch_expected_depths(s, M, intr, rs, false, as_stream(stream));
+}
+
+int itm_find_surface(const itm_scene* s, const float M[16], const float intr[4], itm_render_state* rs, itm_stream stream) {
+  if (!s || !M || !intr || !rs) return set_error(ITM_ERR_INVALID, "null argument");
+  if (rs->scene != s) return set_error(ITM_ERR_INVALID, "render state belongs to another scene");
+  float invM[16];
+  if (!invert4(M, invM)) return set_error(ITM_ERR_INVALID, "pose matrix is singular");
+  return launch_raycast(s, invM, intr, rs, rs->raycast, as_stream(stream));
+}
+
+int itm_create_icp_maps(const itm_scene* s, const itm_view* v, itm_render_state* rs, float* points, float* normals, itm_stream stream) {
+  if (!s || !v || !rs || !points || !normals) return set_error(ITM_ERR_INVALID, "null argument");
+  if (rs->scene != s) return set_error(ITM_ERR_INVALID, "render state belongs to another scene");
+  return launch_icp_maps(s, v, rs, (float4*)points, (float4*)normals, as_stream(stream));
+}
+
+int itm_render_image(const itm_scene* s, const float M[16], const float intr[4], itm_render_state* rs, uint8_t* out, int type, itm_stream stream) {
+  if (!s || !M || !intr || !rs) return set_error(ITM_ERR_INVALID, "null argument");
+  if (rs->scene != s) return set_error(ITM_ERR_INVALID, "render state belongs to another scene");
+  return launch_render_image(s, M, intr, rs, out ? (uchar4*)out : rs->image, type, as_stream(stream));
+}
+
+// ITMDenseMapper::ProcessFrame + ITMTrackingController::Prepare (Engine/ITMMainEngine.cpp:123-126)
+int itm_process_frame(itm_scene* s, const itm_view* v, itm_render_state* rs, float* points, float* normals, itm_stream stream) {
+  if (!s || !v || !rs || !points || !normals) return set_error(ITM_ERR_INVALID, "null argument");
+  if (!v->depth) return set_error(ITM_ERR_INVALID, "null depth image");
+  if (rs->scene != s || v->w != rs->w || v->h != rs->h) return set_error(ITM_ERR_INVALID, "view / render state mismatch");
+  hipStream_t st = as_stream(stream);
+  int rc;
+  const bool hashScene = s->cfg.indexType == ITM_INDEX_HASH;
+  if (hashScene && (rc = launch_allocate(s, v, rs, false, true, st))) return rc;
+  if ((rc = launch_integrate(s, v, rs, st))) return rc;
+  if ((rc = launch_expected_depths(s, v->M_d, v->intr_d, rs, hashScene, st))) return rc;
+  return launch_icp_maps(s, v, rs, (float4*)points, (float4*)normals, st);
+}
+
+}  // extern "C"

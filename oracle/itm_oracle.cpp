@@ -628,7 +628,7 @@ void expected_depths(const itm_scene* s, const float* M, const float* intr, itm_
     if (!project_block(e, M, intr, W, H, s->prm.voxelSize, ulx, uly, lrx, lry, z0, z1)) continue;
     int nx = (int)std::ceil((float)(lrx - ulx + 1) / 16.0f);
     int ny = (int)std::ceil((float)(lry - uly + 1) / 16.0f);
-    if (count + nx * ny >= ITM_MAX_RENDERING_BLOCKS) continue;
+    if (count + nx * ny >= s->cfg.maxRenderingBlocks) continue;
     count += nx * ny;
     for (int by = 0; by < ny; ++by) for (int bx = 0; bx < nx; ++bx) {
       RBlock r;
@@ -1014,6 +1014,8 @@ int itmo_scene_create(const itm_scene_config* cfg_in, const itm_scene_params* pr
     if (!cfg.denseOffsetSet) { cfg.denseOffset[0] = -256; cfg.denseOffset[1] = -256; cfg.denseOffset[2] = 0; }
   }
   cfg.denseOffsetSet = 1;
+  if (cfg.maxRenderingBlocks == 0) cfg.maxRenderingBlocks = ITM_MAX_RENDERING_BLOCKS;
+  if (cfg.indexType == ITM_INDEX_HASH && (cfg.bucketNum + cfg.excessNum) % 8 != 0) return fail(ITM_ERR_INVALID, "bucketNum + excessNum must be a multiple of 8");
   if (cfg.bucketNum & (cfg.bucketNum - 1)) return fail(ITM_ERR_INVALID, "bucketNum must be a power of two");
   size_t vb = itmo_voxel_size_bytes(cfg.voxelType);
   if (!vb) return fail(ITM_ERR_INVALID, "unknown voxel type");

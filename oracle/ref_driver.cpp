@@ -203,6 +203,8 @@ int itmr_scene_create(const itm_scene_config* cin, const itm_scene_params* prm, 
     if (!c.denseOffsetSet) { c.denseOffset[0] = -256; c.denseOffset[1] = -256; c.denseOffset[2] = 0; }
   }
   c.denseOffsetSet = 1;
+  if (c.maxRenderingBlocks == 0) c.maxRenderingBlocks = MAX_RENDERING_BLOCKS;
+  if (c.maxRenderingBlocks != MAX_RENDERING_BLOCKS) return fail(ITM_ERR_UNSUPPORTED, "MAX_RENDERING_BLOCKS is a compile-time constant of the reference");
   if (c.indexType == ITM_INDEX_HASH &&
       (c.bucketNum != SDF_BUCKET_NUM || c.excessNum != SDF_EXCESS_LIST_SIZE || c.localBlockNum != SDF_LOCAL_BLOCK_NUM))
     return fail(ITM_ERR_UNSUPPORTED, "reference pool sizes are compile-time constants");

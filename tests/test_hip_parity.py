@@ -1,0 +1,47 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle on identical inputs.
+
+Bar: hash table, free lists, counters, visible set, weights bit-exact; sdf, range
+image, raycast result, ICP maps bit-exact as well because both sides are built without FP
+contraction (tolerances in itm_testlib.compare_results document the fallback bar).
+"""
+import numpy as np
+import pytest
+
+import itm_testlib as T
+from itm_testlib import Scenario
+
+pytestmark = pytest.mark.gpu
+
+SCENARIOS = [
+    Scenario(name="micro_hash_s", w=160, h=120, voxelSize=0.01, frames=3),
+    Scenario(name="hash_s_5mm", frames=3),
+    Scenario(name="hash_s_4mm", voxelSize=0.004, frames=3),
+    Scenario(name="hash_s_4mm_bench_traj", voxelSize=0.004, frames=4, trajectory="bench"),
+    Scenario(name="hash_s_yaw", voxelSize=0.005, frames=3, trajectory="yaw"),
+    Scenario(name="hash_f", voxelType=T.VOXEL_F, frames=2),
+    Scenario(name="hash_s_rgb", voxelType=T.VOXEL_S_RGB, frames=2, colour=True),
+    Scenario(name="hash_f_rgb", voxelType=T.VOXEL_F_RGB, frames=2, colour=True),
+    Scenario(name="hash_s_noise", frames=2, noise_seed=12345, w=160, h=120, voxelSize=0.01),
+    Scenario(name="hash_small_pool", frames=3, localBlockNum=4096),          # pool exhaustion
+    Scenario(name="hash_tiny_table", frames=3, bucketNum=0x1000, excessNum=0x400, w=320, h=240, voxelSize=0.01),  # many collisions + excess exhaustion
+    Scenario(name="dense_s_128", indexType=T.INDEX_DENSE, denseSize=(128, 128, 128), denseOffset=(-64, -64, 100),
+             voxelSize=0.01, frames=2, w=320, h=240),
+    Scenario(name="dense_f_rgb_64", indexType=T.INDEX_DENSE, voxelType=T.VOXEL_F_RGB, denseSize=(64, 64, 64),
+             denseOffset=(-32, -32, 118), voxelSize=0.01, frames=2, w=160, h=120, colour=True),
+    Scenario(name="dense_s_stopmax", indexType=T.INDEX_DENSE, denseSize=(64, 64, 64), denseOffset=(-32, -32, 118),
+             voxelSize=0.01, frames=4, w=160, h=120, maxW=2, stopIntegratingAtMaxW=True),
+]
+
+
+@pytest.mark.parametrize("sc", SCENARIOS, ids=lambda s: s.name)
+def test_engine_calls_match_oracle(hip, oracle, sc):
+    a = T.run_scenario(hip, sc)
+    b = T.run_scenario(oracle, sc)
+    T.compare_results(a, b, sc)
+
+
+@pytest.mark.parametrize("sc", [SCENARIOS[0], SCENARIOS[2], SCENARIOS[7]], ids=lambda s: s.name)
+def test_fused_process_frame_matches_oracle(hip, oracle, sc):
+    a = T.run_scenario(hip, sc, fused=True)
+    b = T.run_scenario(oracle, sc)
+    T.compare_results(a, b, sc, what=sc.name + "/fused")
