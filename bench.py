@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- fused depth frames/s of the TSDF hot path on MI355X (BASELINE.json metric).
+
+One "step" = one 640x480 depth frame through the per-frame call sequence of
+ITMMainEngine::ProcessFrame after the view is built (reference Engine/ITMMainEngine.cpp:123-126):
+AllocateSceneFromDepth + IntegrateIntoScene + CreateExpectedDepths + CreateICPMaps, issued through
+the C-ABI (itm_process_frame) with the float depth frames already resident in HBM.
+
+Workload (config.workload): BASELINE.json configs[1] -- synthetic 640x480 depth (sphere + wall,
+SURVEY.md section 8d benchmark trajectory), hash TSDF, ITMVoxel_s, 4 mm voxels, mu 0.02,
+512^3-equivalent pool (0x40000 blocks).  Multi-GPU (config 4): one independent stream per rank
+(stream g offset 0.05*g m), weak scaling, with an RCCL all-gather of the per-stream
+{pose, visible-block list} record every frame on a side stream.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H = 640, 480
+VOXEL_SIZE, MU = 0.004, 0.02
+LOCAL_BLOCKS = 0x40000
+PERIOD = 100                 # the benchmark trajectory repeats every 100 frames
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MAX_IDS = 16384              # ids per exchanged visible-block record
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=40)
+    ap.add_argument("--no-exchange", action="store_true", help="skip the visible-list all-gather at N>1")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import infinitam_amd as itm
+    from infinitam_amd import capi, synth
+    be = itm.load()
+    be.check(be.fn["set_device"](local_rank), "set_device")
+
+    # ---- scene + inputs resident in HBM -------------------------------------------------------
+    params = capi.default_params(voxelSize=VOXEL_SIZE, mu=MU)
+    scene = be.create_scene(capi.VOXEL_S, capi.INDEX_HASH, params, localBlockNum=LOCAL_BLOCKS)
+    scene.reco.ResetScene()
+    rs = scene.vis.CreateRenderState((W, H))
+    intr = synth.intrinsics_for(W, H)
+    frames = np.stack([synth.depth_frame(W, H, synth.bench_position(k, rank), intr) for k in range(PERIOD)])
+    depth_dev = torch.from_numpy(frames).cuda()
+    points = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+    normals = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+    poses = [synth.pose_matrix(synth.bench_position(k, rank)) for k in range(PERIOD)]
+    views = []
+    for k in range(PERIOD):
+        v = capi.View(depth_dev[k].data_ptr(), W, H, M_d=poses[k], intr_d=intr).struct()
+        views.append(v)
+    stream = torch.cuda.current_stream()
+    sp = C.c_void_p(stream.cuda_stream)
+    fn = be.fn["process_frame"]
+    sh, rh = C.c_void_p(scene.h), C.c_void_p(rs.h)
+    pp, np_ = C.c_void_p(points.data_ptr()), C.c_void_p(normals.data_ptr())
+
+    exchange = world > 1 and not args.no_exchange
+    if exchange:
+        side = torch.cuda.Stream()
+        rec = torch.empty(17 + MAX_IDS, dtype=torch.int32, device="cuda")
+        gathered = torch.empty(world * (17 + MAX_IDS), dtype=torch.int32, device="cuda")
+        export = be.fn["export_visible_record"]
+        recp = C.c_void_p(rec.data_ptr())
+
+    def step(k):
+        v = views[k % PERIOD]
+        rc = fn(sh, C.byref(v), rh, pp, np_, sp)
+        if rc:
+            be.check(rc, "process_frame")
+        if exchange:
+            # the record is produced on the frame stream, the collective runs on a side stream and
+            # overlaps the next frame (it is not on the critical path of fusion)
+            Ma = (C.c_float * 16)(*[float(x) for x in poses[k % PERIOD]])
+            side.wait_stream(stream)
+            with torch.cuda.stream(side):
+                export(rh, Ma, MAX_IDS, recp, C.c_void_p(side.cuda_stream))
+                dist.all_gather_into_tensor(gathered, rec)
+            stream.wait_stream(side)
+
+    prof = be.fn.get("profile_enable")
+    for k in range(args.warmup):
+        step(k)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if prof:
+        prof(sh, 1)
+    t0 = time.perf_counter()
+    for k in range(args.warmup, args.warmup + args.steps):
+        step(k)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    counters = scene.counters(rs)
+    roofline = None
+    if prof:
+        roofline = read_roofline(be, scene, rs, args.steps, counters)
+        prof(sh, 0)
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_baseline = run_cpu_baseline(args.cpu_frames)
+
+    if rank == 0:
+        fps = world * args.steps / elapsed
+        out = {
+            "metric": "fused depth frames/sec (640x480, hash TSDF)",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: synthetic 640x480 depth (sphere+wall, bench trajectory), "
+                                   "hash TSDF ITMVoxel_s, 4 mm voxels, mu 0.02, 0x40000-block pool; "
+                                   "allocate+integrate+expected-depths+ICP raycast per frame",
+                       "streams": world, "exchange": "rccl all_gather of visible-block records" if exchange else "none",
+                       "visible_blocks_last_frame": counters["noVisibleEntries"]},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def read_roofline(be, scene, rs, steps, counters):
+    """Filled in once the library exports its stage timers (itm_profile_*)."""
+    return None
+
+
+def run_cpu_baseline(nframes):
+    """The CPU oracle (a port of the reference CPU engines, bit-equal to them) timed on ONE host
+    core on the first `nframes` frames of the same workload.  Checker code, used only here."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import itm_testlib as T
+    ob = T.oracle_backend()
+    sc = T.Scenario(name="bench_cpu", voxelSize=VOXEL_SIZE, mu=MU, localBlockNum=LOCAL_BLOCKS, trajectory="bench", frames=nframes)
+    ses = T.Session(ob, sc)
+    views = [ses.view(k) for k in range(min(nframes, 4))]  # warm page cache of the generator
+    del views
+    ses.close()
+    ses = T.Session(ob, sc)
+    depth = [ob.to_backend(sc.depth(k)) for k in range(nframes)]
+    t0 = time.perf_counter()
+    for k in range(nframes):
+        v = T.View(depth[k], sc.w, sc.h, M_d=sc.pose(k), intr_d=sc.intr())
+        ses.scene.process_frame(v, ses.rs, ses.points, ses.normals)
+    dt = time.perf_counter() - t0
+    ses.close()
+    return {"value": round(nframes / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"first {nframes} frames of the same workload, oracle/libitm_oracle.so single thread"}
+
+
+if __name__ == "__main__":
+    main()
