@@ -161,6 +161,10 @@ int ITM_FN(memcpy_d2h)(void* dst_host, const void* src_dev, size_t bytes, itm_st
 int ITM_FN(stream_synchronize)(itm_stream stream);
 int ITM_FN(set_device)(int device);
 
+/* Test hooks (no effect on results): select alternative code paths so that they can be covered. */
+#define ITM_DEBUG_FORCE_GLOBAL_RANGE_ATOMICS 1 /* range image via global atomics even if it fits LDS */
+int ITM_FN(debug_set)(int key, int value);
+
 /* ---- scene -------------------------------------------------------------------------------- */
 /* new ITMScene<TVoxel,TIndex>(sceneParams,false,memType)  Objects/ITMScene.h:37-43 ; also
  * allocates the engine scratch of ITMSceneReconstructionEngine_CPU ctor

@@ -142,6 +142,7 @@ _SIGS = {
     "download": (C.c_int, [_P, _P, C.c_int, _P, C.c_size_t, _P]),
     "upload": (C.c_int, [_P, _P, C.c_int, _P, C.c_size_t, _P]),
     "buffer_ptr": (_P, [_P, _P, C.c_int]),
+    "debug_set": (C.c_int, [C.c_int, C.c_int]),
     "export_visible_record": (C.c_int, [_P, C.POINTER(C.c_float), C.c_int, _P, _P]),
 }
 

@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(256) allocate_sweep_kernel(uint32_t* __restric
                                                              int2* __restrict__ chunkReqNext, int numChunks, uint4* __restrict__ hash,
                                                              const int32_t* __restrict__ excessList, const int32_t* __restrict__ allocList,
                                                              uint8_t* __restrict__ visT, const SceneCounters* __restrict__ counters,
-                                                             const float* __restrict__ depth, AllocParams p) {
+                                                             uint32_t* __restrict__ headBits, const float* __restrict__ depth, AllocParams p) {
   __shared__ int lds[8];
   const int chunk = blockIdx.x;
   const int tid = threadIdx.x;
@@ -212,6 +212,7 @@ __global__ void __launch_bounds__(256) allocate_sweep_kernel(uint32_t* __restric
       int bx, by, bz;
       replay_block_pos(keys[k], depth, p, bx, by, bz);
       hash[slot] = pack_entry(bx, by, bz, 0, allocList[vbaIdx]);
+      atomicOr(&headBits[slot >> 5], 1u << (slot & 31));
     }
     allocKey[slot] = 0u;
   }
@@ -384,7 +385,7 @@ int launch_allocate(itm_scene* s, const itm_view* v, itm_render_state* rs, bool 
     if (fuseRangeInit) request_kernel<false, true><<<grid, 256, 0, st>>>(v->depth, s->hash, rs->visibleType, s->allocKey, reqCur, s->counters, rs->range, rs->counters, p);
     else request_kernel<false, false><<<grid, 256, 0, st>>>(v->depth, s->hash, rs->visibleType, s->allocKey, reqCur, s->counters, rs->range, rs->counters, p);
     allocate_sweep_kernel<<<nChunks, 256, 0, st>>>(s->allocKey, reqCur, reqNext, nChunks, s->hash, s->excessList, s->allocList,
-                                                   rs->visibleType, s->counters, v->depth, p);
+                                                   rs->visibleType, s->counters, s->headBits, v->depth, p);
     visible_count_kernel<true><<<nChunks, 256, 0, st>>>(rs->visibleType, s->hash, s->chunkVis, reqCur, nChunks, s->counters, p);
     s->frameParity++;
   }

@@ -50,6 +50,10 @@ struct itm_scene {
   uint32_t* allocKey = nullptr;   // uint32[noTotalEntries]
   int32_t* chunkReq = nullptr;    // int2[2][numChunks]: (requests, excess requests) per sweep chunk, double-buffered
   int32_t* chunkVis = nullptr;    // int[numChunks]: visible slots per sweep chunk
+  // occupancy bitmap of the ordered part of the table: bit b set <=> hash[b].ptr >= 0.  A clear bit
+  // proves that no block hashing to bucket b is allocated (excess entries hang off occupied heads),
+  // which lets the ray caster skip empty space without touching the 16-byte entries.
+  uint32_t* headBits = nullptr;   // uint32[bucketNum / 32]
   uint32_t frameParity = 0;
 };
 
@@ -68,6 +72,7 @@ struct itm_render_state {
   itm::RenderCounters* counters = nullptr;
   // scratch
   uint4* projBuf = nullptr;    // per visible entry: projected bounding box + z range (2 x uint4)
+  uint2* rangePartials = nullptr;  // [32][ceil(w/8)*ceil(h/8)] partial range images (LDS path)
   int32_t* pixScratch = nullptr;  // int[h*w] (forward projection winners, ordered compaction flags)
   int32_t* pixChunk = nullptr;    // int[ceil(h*w / kSweepChunk)]
 };
@@ -108,6 +113,7 @@ inline int dispatch_voxel(int voxelType, F&& f) {
 }
 
 // entry points implemented per translation unit
+int rebuild_head_bits(itm_scene* s, hipStream_t st);
 int launch_allocate(itm_scene* s, const itm_view* v, itm_render_state* rs, bool onlyVisible, bool fuseRangeInit, hipStream_t st);
 int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipStream_t st);
 int launch_find_visible(const itm_scene* s, const float* M, const float* intr, itm_render_state* rs, hipStream_t st);

@@ -13,6 +13,7 @@ namespace itm {
 struct VolumeView {
   const uint4* hash;   // hash entries (hash index only)
   const void* vba;     // voxel storage
+  const uint32_t* headBits;  // occupancy bitmap of the ordered buckets (hash index only)
   uint32_t mask;       // bucketNum - 1
   int bucketNum;
   int sx, sy, sz;      // dense size
@@ -41,14 +42,17 @@ __device__ inline long long locate_voxel(const VolumeView& vol, int px, int py, 
     const int lin = (px - bx * 8) + (py - by * 8) * 8 + (pz - bz * 8) * 64;
     if (bx == cache.bx && by == cache.by && bz == cache.bz) return (long long)cache.base + lin;
     int idx = hash_index(bx, by, bz, vol.mask);
+    // both loads are issued together; the 16-byte entry is only consumed when the bucket is occupied
+    const uint32_t word = vol.headBits[idx >> 5];
+    HashEntry e = unpack_entry(vol.hash[idx]);
+    if (!((word >> (idx & 31)) & 1u)) return -1;
     for (;;) {
-      const HashEntry e = unpack_entry(vol.hash[idx]);
       if (e.px == bx && e.py == by && e.pz == bz && e.ptr >= 0) {
         cache.bx = bx; cache.by = by; cache.bz = bz; cache.base = e.ptr * kBlockVoxels;
         return (long long)cache.base + lin;
       }
       if (e.offset < 1) break;
-      idx = vol.bucketNum + e.offset - 1;
+      e = unpack_entry(vol.hash[vol.bucketNum + e.offset - 1]);
     }
     return -1;
   }
@@ -68,24 +72,64 @@ __device__ inline float sdf_nearest(const VolumeView& vol, float x, float y, flo
   return VX::to_float(read_raw_sdf<VX, DENSE>(vol, (int)round_ref(x), (int)round_ref(y), (int)round_ref(z), found, cache));
 }
 
+// Walks the excess chain starting from an already loaded head entry; block base or -1.
+__device__ inline int resolve_block(const VolumeView& vol, HashEntry e, int bx, int by, int bz) {
+  for (;;) {
+    if (e.px == bx && e.py == by && e.pz == bz && e.ptr >= 0) return e.ptr * kBlockVoxels;
+    if (e.offset < 1) return -1;
+    e = unpack_entry(vol.hash[vol.bucketNum + e.offset - 1]);
+  }
+}
+
+// Trilinear read (reference: eight readVoxel calls in the order 000 100 | 010 110 | 001 101 | 011 111,
+// blended on the raw values).  The voxel values do not depend on the order in which blocks are
+// looked up (the reference's IndexCache only short-cuts the probe), so for the hash index the
+// lookups are restructured for memory-level parallelism: the up-to-8 distinct blocks touched by
+// the 2x2x2 neighbourhood are probed with independent loads issued back to back, then the eight
+// voxel loads are issued back to back.  The arithmetic on the values is unchanged.
 template <class VX, bool DENSE>
 __device__ inline float sdf_trilinear(const VolumeView& vol, float x, float y, float z, bool& found, BlockCache& cache) {
   const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
   const float cx = x - fx, cy = y - fy, cz = z - fz;
   const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
-  float v1, v2, r1, r2;
-  v1 = read_raw_sdf<VX, DENSE>(vol, ix, iy, iz, found, cache);
-  v2 = read_raw_sdf<VX, DENSE>(vol, ix + 1, iy, iz, found, cache);
-  r1 = (1.0f - cx) * v1 + cx * v2;
-  v1 = read_raw_sdf<VX, DENSE>(vol, ix, iy + 1, iz, found, cache);
-  v2 = read_raw_sdf<VX, DENSE>(vol, ix + 1, iy + 1, iz, found, cache);
-  r1 = (1.0f - cy) * r1 + cy * ((1.0f - cx) * v1 + cx * v2);
-  v1 = read_raw_sdf<VX, DENSE>(vol, ix, iy, iz + 1, found, cache);
-  v2 = read_raw_sdf<VX, DENSE>(vol, ix + 1, iy, iz + 1, found, cache);
-  r2 = (1.0f - cx) * v1 + cx * v2;
-  v1 = read_raw_sdf<VX, DENSE>(vol, ix, iy + 1, iz + 1, found, cache);
-  v2 = read_raw_sdf<VX, DENSE>(vol, ix + 1, iy + 1, iz + 1, found, cache);
-  r2 = (1.0f - cy) * r2 + cy * ((1.0f - cx) * v1 + cx * v2);
+  float v[8];
+  if (DENSE) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = read_raw_sdf<VX, DENSE>(vol, ix + (c & 1), iy + ((c >> 1) & 1), iz + (c >> 2), found, cache);
+  } else {
+    const int bx = floor_div8(ix), by = floor_div8(iy), bz = floor_div8(iz);
+    const int lx = ix - bx * 8, ly = iy - by * 8, lz = iz - bz * 8;
+    // bit k set: the +1 neighbour along axis k lies in the next block
+    const int cross = (lx == 7 ? 1 : 0) | (ly == 7 ? 2 : 0) | (lz == 7 ? 4 : 0);
+    const bool cached = (bx == cache.bx && by == cache.by && bz == cache.bz);
+    HashEntry head[8];
+    bool need[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      need[s] = ((s & ~cross) == 0) && !(s == 0 && cached);
+      if (need[s]) head[s] = unpack_entry(vol.hash[hash_index(bx + (s & 1), by + ((s >> 1) & 1), bz + (s >> 2), vol.mask)]);
+    }
+    int base[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      base[s] = -1;
+      if (need[s]) base[s] = resolve_block(vol, head[s], bx + (s & 1), by + ((s >> 1) & 1), bz + (s >> 2));
+    }
+    if (cached) base[0] = cache.base;
+    else if (base[0] >= 0) { cache.bx = bx; cache.by = by; cache.bz = bz; cache.base = base[0]; }
+    const float dflt = VX::kShort ? 32767.0f : 1.0f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int b = base[c & cross];
+      const int off = ((lx + (c & 1)) & 7) + ((ly + ((c >> 1) & 1)) & 7) * 8 + ((lz + (c >> 2)) & 7) * 64;
+      v[c] = (b >= 0) ? VX::load_raw_sdf(vol.vba, (size_t)(b + off)) : dflt;
+    }
+  }
+  float r1, r2;
+  r1 = (1.0f - cx) * v[0] + cx * v[1];
+  r1 = (1.0f - cy) * r1 + cy * ((1.0f - cx) * v[2] + cx * v[3]);
+  r2 = (1.0f - cx) * v[4] + cx * v[5];
+  r2 = (1.0f - cy) * r2 + cy * ((1.0f - cx) * v[6] + cx * v[7]);
   found = true;
   return VX::to_float((1.0f - cz) * r1 + cz * r2);
 }
@@ -126,6 +170,34 @@ __device__ inline float4 cast_ray(int x, int y, const VolumeView& vol, const Ray
     sdf = sdf_nearest<VX, DENSE>(vol, px, py, pz, found, cache);
     if (!found) {
       step = (float)kBlockSide;
+      if (!DENSE) {
+        // Empty-space skipping.  While blocks are missing the march is pure arithmetic
+        // (pt += 8*dir, total += 8, exactly as the reference computes it), so the next kLook
+        // positions are known in advance: their occupancy bits are fetched with independent loads
+        // and every leading position whose bucket is provably empty is stepped over at once.
+        px += step * dx; py += step * dy; pz += step * dz;
+        total += step;
+        constexpr int kLook = 4;
+        float qx[kLook + 1], qy[kLook + 1], qz[kLook + 1], qt[kLook + 1];
+        bool empty[kLook];
+        qx[0] = px; qy[0] = py; qz[0] = pz; qt[0] = total;
+#pragma unroll
+        for (int j = 0; j < kLook; ++j) {
+          const int vx = (int)round_ref(qx[j]), vy = (int)round_ref(qy[j]), vz = (int)round_ref(qz[j]);
+          const int h = hash_index(floor_div8(vx), floor_div8(vy), floor_div8(vz), vol.mask);
+          empty[j] = !((vol.headBits[h >> 5] >> (h & 31)) & 1u);
+          qx[j + 1] = qx[j] + step * dx; qy[j + 1] = qy[j] + step * dy; qz[j + 1] = qz[j] + step * dz;
+          qt[j + 1] = qt[j] + step;
+        }
+        int adv = 0;
+#pragma unroll
+        for (int j = 0; j < kLook; ++j) {
+          if (adv == j && qt[j] < totalMax && empty[j]) adv = j + 1;
+        }
+#pragma unroll
+        for (int j = 1; j <= kLook; ++j) if (adv == j) { px = qx[j]; py = qy[j]; pz = qz[j]; total = qt[j]; }
+        continue;
+      }
     } else {
       if ((sdf <= 0.1f) && (sdf >= -0.5f)) sdf = sdf_trilinear<VX, DENSE>(vol, px, py, pz, found, cache);
       if (sdf <= 0.0f) break;

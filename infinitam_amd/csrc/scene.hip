@@ -89,12 +89,13 @@ __global__ void __launch_bounds__(256) reset_voxels_s_x4_kernel(uint4* vba, size
 }
 
 __global__ void __launch_bounds__(256) reset_hash_kernel(uint4* hash, int nEntries, int32_t* excessList, int nExcess,
-                                                         int32_t* allocList, int nBlocks, uint32_t* allocKey,
+                                                         int32_t* allocList, int nBlocks, uint32_t* allocKey, uint32_t* headBits, int nHeadWords,
                                                          int32_t* chunkReq, int nChunkReq, SceneCounters* counters) {
   int stride = gridDim.x * blockDim.x;
   int i0 = blockIdx.x * blockDim.x + threadIdx.x;
   const uint4 empty = pack_entry(0, 0, 0, 0, -2);
   for (int i = i0; i < nEntries; i += stride) { hash[i] = empty; allocKey[i] = 0u; }
+  for (int i = i0; i < nHeadWords; i += stride) headBits[i] = 0u;
   for (int i = i0; i < nExcess; i += stride) excessList[i] = i;
   for (int i = i0; i < nBlocks; i += stride) allocList[i] = i;
   for (int i = i0; i < nChunkReq; i += stride) chunkReq[i] = 0;
@@ -104,6 +105,26 @@ __global__ void __launch_bounds__(256) reset_hash_kernel(uint4* hash, int nEntri
     counters->noAllocRequests = 0;
     counters->statusFlags = 0;
   }
+}
+
+// rebuilds the occupancy bitmap from the table (after an upload of hash entries)
+__global__ void __launch_bounds__(256) head_bits_kernel(const uint4* __restrict__ hash, uint32_t* __restrict__ headBits, int nWords, int bucketNum) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= nWords) return;
+  uint32_t bits = 0;
+  for (int k = 0; k < 32; ++k) {
+    const int slot = w * 32 + k;
+    if (slot < bucketNum && (int)hash[slot].w >= 0) bits |= 1u << k;
+  }
+  headBits[w] = bits;
+}
+
+int rebuild_head_bits(itm_scene* s, hipStream_t st) {
+  if (!s->headBits) return ITM_OK;
+  const int nWords = (s->cfg.bucketNum + 31) / 32;
+  head_bits_kernel<<<(nWords + 255) / 256, 256, 0, st>>>(s->hash, s->headBits, nWords, s->cfg.bucketNum);
+  ITM_LAUNCH_CHECK();
+  return ITM_OK;
 }
 
 __global__ void reset_dense_kernel(int32_t* allocList, SceneCounters* counters) {
@@ -172,14 +193,14 @@ static void* buffer_of(const itm_scene* s, const itm_render_state* rs, int which
 static void free_scene(itm_scene* s) {
   if (!s) return;
   (void)hipFree(s->hash); (void)hipFree(s->excessList); (void)hipFree(s->vba); (void)hipFree(s->allocList);
-  (void)hipFree(s->counters); (void)hipFree(s->allocKey); (void)hipFree(s->chunkReq); (void)hipFree(s->chunkVis);
+  (void)hipFree(s->counters); (void)hipFree(s->headBits); (void)hipFree(s->allocKey); (void)hipFree(s->chunkReq); (void)hipFree(s->chunkVis);
   delete s;
 }
 static void free_rs(itm_render_state* r) {
   if (!r) return;
   (void)hipFree(r->range); (void)hipFree(r->raycast); (void)hipFree(r->fwdProj); (void)hipFree(r->missing);
   (void)hipFree(r->image); (void)hipFree(r->visibleIds); (void)hipFree(r->visibleType); (void)hipFree(r->counters);
-  (void)hipFree(r->projBuf); (void)hipFree(r->pixScratch); (void)hipFree(r->pixChunk);
+  (void)hipFree(r->projBuf); (void)hipFree(r->rangePartials); (void)hipFree(r->pixScratch); (void)hipFree(r->pixChunk);
   delete r;
 }
 
@@ -258,6 +279,7 @@ int itm_scene_create(const itm_scene_config* cfg_in, const itm_scene_params* prm
     alloc((void**)&s->excessList, (size_t)cfg.excessNum * 4);
     alloc((void**)&s->allocList, (size_t)cfg.localBlockNum * 4);
     alloc((void**)&s->allocKey, (size_t)s->noTotalEntries * 4);
+    alloc((void**)&s->headBits, (size_t)(cfg.bucketNum + 31) / 32 * 4);
     alloc((void**)&s->chunkReq, (size_t)s->numChunks * 2 * 2 * 4);
     alloc((void**)&s->chunkVis, (size_t)s->numChunks * 4);
   } else {
@@ -269,6 +291,8 @@ int itm_scene_create(const itm_scene_config* cfg_in, const itm_scene_params* prm
   if (e != hipSuccess) { free_scene(s); return hip_fail(e, "hipMalloc(scene)", __FILE__, __LINE__); }
   e = hipMemset(s->counters, 0, sizeof(SceneCounters));
   if (e == hipSuccess && s->allocKey) e = hipMemset(s->allocKey, 0, (size_t)s->noTotalEntries * 4);
+  if (e == hipSuccess && s->headBits) e = hipMemset(s->headBits, 0, (size_t)(cfg.bucketNum + 31) / 32 * 4);
+  if (e == hipSuccess && s->hash) e = hipMemset(s->hash, 0, (size_t)s->noTotalEntries * 16);
   if (e == hipSuccess && s->chunkReq) e = hipMemset(s->chunkReq, 0, (size_t)s->numChunks * 16);
   if (e != hipSuccess) { free_scene(s); return hip_fail(e, "hipMemset(scene)", __FILE__, __LINE__); }
   *out = s;
@@ -301,7 +325,7 @@ int itm_reset_scene(itm_scene* s, itm_stream stream) {
   ITM_LAUNCH_CHECK();
   if (s->cfg.indexType == ITM_INDEX_HASH) {
     reset_hash_kernel<<<1024, 256, 0, st>>>(s->hash, s->noTotalEntries, s->excessList, s->cfg.excessNum, s->allocList,
-                                            s->cfg.localBlockNum, s->allocKey, s->chunkReq, s->numChunks * 4, s->counters);
+                                            s->cfg.localBlockNum, s->allocKey, s->headBits, (s->cfg.bucketNum + 31) / 32, s->chunkReq, s->numChunks * 4, s->counters);
   } else {
     reset_dense_kernel<<<1, 1, 0, st>>>(s->allocList, s->counters);
   }
@@ -332,6 +356,7 @@ int itm_render_state_create(const itm_scene* s, int w, int h, itm_render_state**
     alloc((void**)&r->visibleIds, (size_t)r->capIds * 4);
     alloc((void**)&r->visibleType, (size_t)s->noTotalEntries);
     alloc((void**)&r->projBuf, (size_t)r->capIds * 32);
+    if ((size_t)((w + 7) / 8) * ((h + 7) / 8) * 8 <= 150 * 1024) alloc((void**)&r->rangePartials, (size_t)32 * ((w + 7) / 8) * ((h + 7) / 8) * 8);
   }
   if (e != hipSuccess) { free_rs(r); return hip_fail(e, "hipMalloc(render state)", __FILE__, __LINE__); }
   // MemoryBlock<T> storage is zero-initialised in the reference (ORUtils/MemoryBlock.h Clear on allocate)
@@ -428,6 +453,7 @@ int itm_upload(itm_scene* s, itm_render_state* rs, int which, const void* src, s
   if (!p || !src || bytes > b) return set_error(ITM_ERR_INVALID, "bad buffer / size");
   hipStream_t st = as_stream(stream);
   ITM_HIP(hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, st));
+  if (which == ITM_BUF_HASH_ENTRIES) { int rc = rebuild_head_bits(s, st); if (rc) return rc; }
   ITM_HIP(hipStreamSynchronize(st));
   return ITM_OK;
 }

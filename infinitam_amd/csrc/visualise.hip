@@ -18,12 +18,16 @@
 //   * ray casting: one lane per pixel, 16x4 pixels per wave (two 8x8 range cells per wave), a
 //     per-lane block cache as in the reference; 2-byte sdf gathers from HBM/L2.
 //   * ICP maps: one lane per pixel over the ray-hit map.
+#include <cstdlib>
 #include <cstring>
 
 #include "itm_internal.h"
 #include "shading_device.h"
+#include "wave_utils.h"
 
 namespace itm {
+
+int g_debug_force_global_range = 0;
 
 // ---------------------------------------------------------------------------------------------
 // expected depth range
@@ -142,6 +146,122 @@ __global__ void __launch_bounds__(256) range_overflow_kernel(RenderCounters* __r
   }
 }
 
+// LDS variant, used whenever the sub-sampled range image fits in LDS (160 KiB per CU: up to ~19k
+// cells, i.e. 1280x960 frames).  Global atomics on the 4800-cell image are contention bound
+// (~29 us for 10k blocks) and a single workgroup is ALU bound on one CU (~77 us), so the work is
+// split in two launches:
+//   project_partial_kernel : kRangeParts workgroups, each projects a slice of the visible list and
+//       min/max-merges the boxes into its own LDS copy of the [0,W/8)x[0,H/8) region with LDS
+//       atomics, then writes that partial image to HBM.  Cells outside the region (the reference
+//       clamps boxes to the FULL image size, a quirk that only touches cells no ray ever reads) go
+//       through global atomics.
+//   range_reduce_kernel    : one workgroup reduces the partial images into the range image; if the
+//       rendering-block cap of the reference was reached it instead replays the sequential
+//       accept / skip decisions and rebuilds the image from the accepted boxes.
+constexpr int kRangeParts = 32;
+
+__global__ void __launch_bounds__(512) project_partial_kernel(const int32_t* __restrict__ ids, RenderCounters* __restrict__ rc,
+                                                              const uint4* __restrict__ hash, float2* __restrict__ range,
+                                                              uint4* __restrict__ projBuf, uint2* __restrict__ partials,
+                                                              ProjParams p, int RW, int RH) {
+  extern __shared__ uint2 cells[];
+  __shared__ int lds[8];
+  const int tid = threadIdx.x;
+  const int nCells = RW * RH;
+  const uint2 initCell = make_uint2(__float_as_uint(999999.9f), __float_as_uint(0.05f));
+  for (int i = tid; i < nCells; i += 512) cells[i] = initCell;
+  __syncthreads();
+  const int nv = rc->noVisibleEntries;
+  int need = 0;
+  for (int e = blockIdx.x * 512 + tid; e < nv; e += kRangeParts * 512) {
+    const HashEntry he = unpack_entry(hash[ids[e]]);
+    const Projected r = project_block(he, p);
+    projBuf[2 * e] = make_uint4((uint32_t)r.ulx, (uint32_t)r.uly, (uint32_t)r.lrx, (uint32_t)r.lry);
+    projBuf[2 * e + 1] = make_uint4(__float_as_uint(r.z0), __float_as_uint(r.z1), (uint32_t)r.n, 1u);
+    if (r.n == 0) continue;
+    need += r.n;
+    const uint32_t z0 = __float_as_uint(r.z0), z1 = __float_as_uint(r.z1);
+    for (int y = r.uly; y <= r.lry; ++y)
+      for (int x = r.ulx; x <= r.lrx; ++x) {
+        if (x < RW && y < RH) {
+          atomicMin(&cells[x + y * RW].x, z0);
+          atomicMax(&cells[x + y * RW].y, z1);
+        } else {
+          uint32_t* px = (uint32_t*)&range[x + y * p.W];
+          atomicMin(px, z0);
+          atomicMax(px + 1, z1);
+        }
+      }
+  }
+  const int sum = block_reduce_sum<8>(need, lds);
+  if (tid == 0 && sum) atomicAdd(&rc->noRenderingBlocks, sum);
+  __syncthreads();
+  uint2* mine = partials + (size_t)blockIdx.x * nCells;
+  for (int i = tid; i < nCells; i += 512) mine[i] = cells[i];
+}
+
+__global__ void __launch_bounds__(256) range_reduce_kernel(RenderCounters* __restrict__ rc, float2* __restrict__ range,
+                                                            uint4* __restrict__ projBuf, const uint2* __restrict__ partials,
+                                                            ProjParams p, int RW, int RH) {
+  extern __shared__ uint2 cells[];
+  const int tid = threadIdx.x;
+  const int nCells = RW * RH;
+  if (rc->noRenderingBlocks < p.maxBlocks) {
+    const int i = blockIdx.x * 256 + tid;   // one cell per lane, kRangeParts independent loads
+    if (i < nCells) {
+      uint2 c[kRangeParts];
+#pragma unroll
+      for (int g = 0; g < kRangeParts; ++g) c[g] = partials[(size_t)g * nCells + i];
+      uint32_t lo = 0xffffffffu, hi = 0u;
+#pragma unroll
+      for (int g = 0; g < kRangeParts; ++g) { lo = c[g].x < lo ? c[g].x : lo; hi = c[g].y > hi ? c[g].y : hi; }
+      const int y = i / RW, x = i - y * RW;
+      range[x + y * p.W] = make_float2(__uint_as_float(lo), __uint_as_float(hi));
+    }
+    return;
+  }
+  if (blockIdx.x != 0) return;
+  // cap reached (uniform branch): sequential replay, then rebuild the whole image
+  const int nv = rc->noVisibleEntries;
+  const uint2 initCell = make_uint2(__float_as_uint(999999.9f), __float_as_uint(0.05f));
+  for (int i = tid; i < nCells; i += 256) cells[i] = initCell;
+  for (int i = tid; i < p.W * p.H; i += 256) range[i] = make_float2(999999.9f, 0.05f);
+  if (tid == 0) {
+    int count = 0;
+    for (int e = 0; e < nv; ++e) {
+      uint4 b = projBuf[2 * e + 1];
+      const int n = (int)b.z;
+      if (n == 0) continue;
+      if (count + n >= p.maxBlocks) b.w = 0u; else { b.w = 1u; count += n; }
+      projBuf[2 * e + 1] = b;
+    }
+    rc->noRenderingBlocks = count;
+  }
+  __threadfence();
+  __syncthreads();
+  for (int e = tid; e < nv; e += 256) {
+    const uint4 a = projBuf[2 * e], b = projBuf[2 * e + 1];
+    if (b.z == 0u || b.w == 0u) continue;
+    for (int y = (int)a.y; y <= (int)a.w; ++y)
+      for (int x = (int)a.x; x <= (int)a.z; ++x) {
+        if (x < RW && y < RH) {
+          atomicMin(&cells[x + y * RW].x, b.x);
+          atomicMax(&cells[x + y * RW].y, b.y);
+        } else {
+          uint32_t* px = (uint32_t*)&range[x + y * p.W];
+          atomicMin(px, b.x);
+          atomicMax(px + 1, b.y);
+        }
+      }
+  }
+  __syncthreads();
+  for (int i = tid; i < nCells; i += 256) {
+    const int y = i / RW, x = i - y * RW;
+    const uint2 c = cells[i];
+    range[x + y * p.W] = make_float2(__uint_as_float(c.x), __uint_as_float(c.y));
+  }
+}
+
 int launch_expected_depths(const itm_scene* s, const float* M, const float* intr, itm_render_state* rs, bool rangeAlreadyInit, hipStream_t st) {
   const int P = rs->w * rs->h;
   if (s->cfg.indexType == ITM_INDEX_DENSE) {
@@ -156,8 +276,22 @@ int launch_expected_depths(const itm_scene* s, const float* M, const float* intr
   p.W = rs->w; p.H = rs->h;
   p.maxBlocks = s->cfg.maxRenderingBlocks;
   if (!rangeAlreadyInit) range_init_kernel<<<512, 256, 0, st>>>(rs->range, P, 999999.9f, 0.05f, rs->counters);
-  project_fill_kernel<<<128, 256, 0, st>>>(rs->visibleIds, rs->counters, s->hash, rs->range, rs->projBuf, p);
-  range_overflow_kernel<<<1, 256, 0, st>>>(rs->counters, rs->range, rs->projBuf, p);
+  const int RW = (rs->w + 7) / 8, RH = (rs->h + 7) / 8;
+  const size_t ldsBytes = (size_t)RW * RH * sizeof(uint2);
+  const bool forceGlobal = g_debug_force_global_range != 0;  // test hook for the fallback path
+  if (ldsBytes <= 150 * 1024 && !forceGlobal && rs->rangePartials) {
+    static bool attrSet = false;
+    if (!attrSet) {
+      ITM_HIP(hipFuncSetAttribute((const void*)project_partial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      ITM_HIP(hipFuncSetAttribute((const void*)range_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      attrSet = true;
+    }
+    project_partial_kernel<<<kRangeParts, 512, ldsBytes, st>>>(rs->visibleIds, rs->counters, s->hash, rs->range, rs->projBuf, rs->rangePartials, p, RW, RH);
+    range_reduce_kernel<<<(RW * RH + 255) / 256, 256, ldsBytes, st>>>(rs->counters, rs->range, rs->projBuf, rs->rangePartials, p, RW, RH);
+  } else {
+    project_fill_kernel<<<128, 256, 0, st>>>(rs->visibleIds, rs->counters, s->hash, rs->range, rs->projBuf, p);
+    range_overflow_kernel<<<1, 256, 0, st>>>(rs->counters, rs->range, rs->projBuf, p);
+  }
   ITM_LAUNCH_CHECK();
   return ITM_OK;
 }
@@ -285,6 +419,11 @@ int launch_render_image(const itm_scene* s, const float* M, const float* intr, i
 using namespace itm;
 
 extern "C" {
+
+int itm_debug_set(int key, int value) {
+  if (key == ITM_DEBUG_FORCE_GLOBAL_RANGE_ATOMICS) { g_debug_force_global_range = value; return ITM_OK; }
+  return set_error(ITM_ERR_INVALID, "unknown debug key");
+}
 
 int itm_create_expected_depths(const itm_scene* s, const float M[16], const float intr[4], itm_render_state* rs, itm_stream stream) {
   if (!s || !M || !intr || !rs) return set_error(ITM_ERR_INVALID, "null argument");

@@ -193,6 +193,16 @@ namespace {
 // ------------------------------------------------------------------------------------------
 struct BlockCache { int bx = 0x7fffffff, by = 0x7fffffff, bz = 0x7fffffff; int base = -1; };
 
+// Work counters (the "algorithmic bytes" of DESIGN.md are priced from these); read through
+// itmo_debug_stats, which is not part of the shared ABI.
+struct Stats {
+  long long rays, ray_hits, ray_steps, max_ray_steps;
+  long long nearest_reads, nearest_misses, trilinear_reads, voxel_reads, hash_probes;
+  long long alloc_pixels, alloc_steps, alloc_probes;
+  long long fuse_blocks, fuse_voxels_visited, fuse_voxels_updated;
+};
+Stats g_stats;
+
 inline int floor_div8(int p) { return ((p < 0) ? p - 7 : p) / 8; }
 
 template <class V>
@@ -218,6 +228,7 @@ struct Reader {
     int idx = hash_index(bx, by, bz, mask);
     for (;;) {
       const HashEntry& e = sc->hash[idx];
+      ++g_stats.hash_probes;
       if (e.px == bx && e.py == by && e.pz == bz && e.ptr >= 0) {
         found = true;
         cache.bx = bx; cache.by = by; cache.bz = bz; cache.base = e.ptr * 512;
@@ -234,6 +245,7 @@ struct Reader {
   // readFromSDF_float_uninterpolated :153-159
   float nearest(const V3f& p, bool& found, BlockCache& cache) const {
     V v = read((int)round_ref(p.x), (int)round_ref(p.y), (int)round_ref(p.z), found, cache);
+    ++g_stats.nearest_reads; if (!found) ++g_stats.nearest_misses; else ++g_stats.voxel_reads;
     return Codec<V>::toF((float)v.sdf);
   }
   // readFromSDF_float_interpolated :161-185 (raw values blended, then converted; found := true)
@@ -255,6 +267,7 @@ struct Reader {
     v2 = (float)read(ix + 1, iy + 1, iz + 1, found, cache).sdf;
     r2 = (1.0f - cy) * r2 + cy * ((1.0f - cx) * v1 + cx * v2);
     found = true;
+    ++g_stats.trilinear_reads; g_stats.voxel_reads += 8;
     return Codec<V>::toF((1.0f - cz) * r1 + cz * r2);
   }
 };
@@ -316,6 +329,7 @@ inline float fuse_depth(V& vox, const V4f& pm, const FuseCtx& c) {
   newW = (newW < c.maxW) ? newW : c.maxW;
   vox.sdf = Codec<V>::toV(newF);
   vox.w = (uint8_t)newW;
+  ++g_stats.fuse_voxels_updated;
   return eta;
 }
 
@@ -392,6 +406,7 @@ void integrate_t(itm_scene* s, const itm_view* view, itm_render_state* rs) {
       if (he.ptr < 0) continue;
       int gx = he.px * 8, gy = he.py * 8, gz = he.pz * 8;
       V* blk = vox + (size_t)he.ptr * 512;
+      ++g_stats.fuse_blocks; g_stats.fuse_voxels_visited += 512;
       for (int z = 0; z < 8; ++z) for (int y = 0; y < 8; ++y) for (int x = 0; x < 8; ++x) {
         int loc = x + y * 8 + z * 64;
         if (c.stopAtMax && blk[loc].w == c.maxW) continue;
@@ -481,11 +496,13 @@ void allocate_hash(itm_scene* s, const itm_view* view, itm_render_state* rs, boo
     int noSteps = (int)std::ceil(2.0f * norm);
     float div = (float)(noSteps - 1);
     dir.x /= div; dir.y /= div; dir.z /= div;
+    ++g_stats.alloc_pixels; g_stats.alloc_steps += noSteps;
     for (int i = 0; i < noSteps; ++i) {
       int16_t bx = (int16_t)std::floor(pt.x), by = (int16_t)std::floor(pt.y), bz = (int16_t)std::floor(pt.z);
       int idx = hash_index(bx, by, bz, mask);
       bool isFound = false;
       HashEntry he = table[idx];
+      ++g_stats.alloc_probes;
       if (he.px == bx && he.py == by && he.pz == bz && he.ptr >= -1) {
         visT[idx] = (he.ptr == -1) ? 2 : 1;
         isFound = true;
@@ -496,6 +513,7 @@ void allocate_hash(itm_scene* s, const itm_view* view, itm_render_state* rs, boo
           while (he.offset >= 1) {
             idx = BN + he.offset - 1;
             he = table[idx];
+            ++g_stats.alloc_probes;
             if (he.px == bx && he.py == by && he.pz == bz && he.ptr >= -1) {
               visT[idx] = (he.ptr == -1) ? 2 : 1;
               isFound = true;
@@ -675,7 +693,9 @@ bool cast_ray(V4f& out, int x, int y, const Reader<V>& rd, const float* invM, fl
   BlockCache cache;
   bool found;
   float step;
+  long long steps = 0;
   while (total < totalMax) {
+    ++steps;
     sdf = rd.nearest(pt, found, cache);
     if (!found) {
       step = (float)ITM_SDF_BLOCK_SIZE;
@@ -687,8 +707,11 @@ bool cast_ray(V4f& out, int x, int y, const Reader<V>& rd, const float* invM, fl
     pt.x += step * dir.x; pt.y += step * dir.y; pt.z += step * dir.z;
     total += step;
   }
+  ++g_stats.rays; g_stats.ray_steps += steps;
+  if (steps > g_stats.max_ray_steps) g_stats.max_ray_steps = steps;
   bool hit;
   if (sdf <= 0.0f) {
+    ++g_stats.ray_hits;
     step = sdf * stepScale;
     pt.x += step * dir.x; pt.y += step * dir.y; pt.z += step * dir.z;
     sdf = rd.trilinear(pt, found, cache);
@@ -1002,6 +1025,7 @@ int itmo_memcpy_h2d(void* d, const void* s, size_t n, itm_stream) { std::memcpy(
 int itmo_memcpy_d2h(void* d, const void* s, size_t n, itm_stream) { std::memcpy(d, s, n); return ITM_OK; }
 int itmo_stream_synchronize(itm_stream) { return ITM_OK; }
 int itmo_set_device(int) { return ITM_OK; }
+int itmo_debug_set(int, int) { return ITM_OK; }
 
 int itmo_scene_create(const itm_scene_config* cfg_in, const itm_scene_params* prm, itm_scene** out) {
   if (!cfg_in || !prm || !out) return fail(ITM_ERR_INVALID, "null argument");
@@ -1190,6 +1214,13 @@ int itmo_upload(itm_scene* s, itm_render_state* rs, int which, const void* src, 
   if (!p || bytes > b) return fail(ITM_ERR_INVALID, "bad buffer / size");
   std::memcpy(p, src, bytes);
   return ITM_OK;
+}
+
+// test-only: read (and optionally clear) the work counters; 15 int64 values
+int itmo_debug_stats(long long* out, int clear) {
+  if (out) std::memcpy(out, &g_stats, sizeof g_stats);
+  if (clear) std::memset(&g_stats, 0, sizeof g_stats);
+  return (int)(sizeof g_stats / sizeof(long long));
 }
 
 int itmo_export_visible_record(const itm_render_state* rs, const float M_d[16], int max_ids, void* dst, itm_stream) {

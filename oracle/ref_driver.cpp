@@ -191,6 +191,7 @@ int itmr_memcpy_h2d(void* d, const void* s, size_t n, itm_stream) { std::memcpy(
 int itmr_memcpy_d2h(void* d, const void* s, size_t n, itm_stream) { std::memcpy(d, s, n); return ITM_OK; }
 int itmr_stream_synchronize(itm_stream) { return ITM_OK; }
 int itmr_set_device(int) { return ITM_OK; }
+int itmr_debug_set(int, int) { return ITM_OK; }
 
 int itmr_scene_create(const itm_scene_config* cin, const itm_scene_params* prm, itm_scene** out) {
   if (!cin || !prm || !out) return fail(ITM_ERR_INVALID, "null argument");

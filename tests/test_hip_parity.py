@@ -30,6 +30,7 @@ SCENARIOS = [
              denseOffset=(-32, -32, 118), voxelSize=0.01, frames=2, w=160, h=120, colour=True),
     Scenario(name="dense_s_stopmax", indexType=T.INDEX_DENSE, denseSize=(64, 64, 64), denseOffset=(-32, -32, 118),
              voxelSize=0.01, frames=4, w=160, h=120, maxW=2, stopIntegratingAtMaxW=True),
+    Scenario(name="hash_render_block_cap", w=320, h=240, voxelSize=0.01, frames=3, maxRenderingBlocks=700),
 ]
 
 
@@ -45,3 +46,15 @@ def test_fused_process_frame_matches_oracle(hip, oracle, sc):
     a = T.run_scenario(hip, sc, fused=True)
     b = T.run_scenario(oracle, sc)
     T.compare_results(a, b, sc, what=sc.name + "/fused")
+
+
+@pytest.mark.parametrize("sc", [SCENARIOS[0], SCENARIOS[-1]], ids=lambda s: s.name)
+def test_range_image_global_atomic_path(hip, oracle, sc):
+    """The fallback used when the range image does not fit LDS (and its cap replay)."""
+    hip.check(hip.fn["debug_set"](1, 1), "debug_set")
+    try:
+        a = T.run_scenario(hip, sc)
+    finally:
+        hip.check(hip.fn["debug_set"](1, 0), "debug_set")
+    b = T.run_scenario(oracle, sc)
+    T.compare_results(a, b, sc, what=sc.name + "/global-atomics")
