@@ -111,15 +111,16 @@ def main():
                 dist.all_gather_into_tensor(gathered, rec)
             stream.wait_stream(side)
 
-    prof = be.fn.get("profile_enable")
+    TK_RAYCAST = 5
     for k in range(args.warmup):
         step(k)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    if prof:
-        prof(sh, 1)
+    if rank == 0:
+        scene.profile_read(reset=True)
+        scene.profile_enable(1 << TK_RAYCAST)   # two hipEventRecord per frame around the dominant kernel
     t0 = time.perf_counter()
     for k in range(args.warmup, args.warmup + args.steps):
         step(k)
@@ -136,9 +137,9 @@ def main():
 
     counters = scene.counters(rs)
     roofline = None
-    if prof:
+    if rank == 0:
         roofline = read_roofline(be, scene, rs, args.steps, counters)
-        prof(sh, 0)
+        scene.profile_enable(0)
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -164,9 +165,39 @@ def main():
         dist.destroy_process_group()
 
 
+def algorithmic_bytes():
+    """Algorithmic bytes per launch of the kernels on the path (DESIGN.md 'Algorithmic bytes',
+    SURVEY.md section 8d), priced from the oracle's work counters on frames 20..59 of this workload
+    (tests/golden/algbytes_config2.json, regenerated by tests/golden/make_algbytes.py)."""
+    with open(os.path.join(ROOT, "tests", "golden", "algbytes_config2.json")) as f:
+        c = json.load(f)
+    P, V, E = W * H, 4, 16
+    found_nearest = c["nearest_reads"] - c["nearest_misses"]
+    raycast = 8 * (P / 64) + V * (found_nearest + 8 * c["trilinear_reads"]) + E * c["hash_probes"] + 16 * P
+    integrate = c["visible_blocks"] * (512 * V * 2 + E + 4) + 4 * P
+    return {"raycast": raycast, "integrate": integrate}, c
+
+
 def read_roofline(be, scene, rs, steps, counters):
-    """Filled in once the library exports its stage timers (itm_profile_*)."""
-    return None
+    """Dominant kernel = the ray-cast kernel (rocprofv3: 45-55 % of the frame, profiles/).  Its average
+    duration is measured with hipEvents recorded around every launch inside the timed region, on the
+    stream the kernel runs on (itm_profile_enable / itm_profile_read)."""
+    prof = scene.profile_read(reset=True)
+    alg, _ = algorithmic_bytes()
+    r = prof["raycast"]
+    if not r["calls"]:
+        return None
+    avg_s = r["total_ms"] * 1e-3 / r["calls"]
+    achieved = alg["raycast"] / avg_s / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "raycast_traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            traffic = json.load(f).get("hbm_bytes_per_launch")
+    return {"bound": "hbm", "kernel": "raycast_kernel<VoxelS,hash>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "algorithmic_bytes_per_launch": round(alg["raycast"]), "avg_kernel_us": round(avg_s * 1e6, 2),
+            "launches_timed": r["calls"]}
 
 
 def run_cpu_baseline(nframes):

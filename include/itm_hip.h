@@ -269,6 +269,28 @@ int ITM_FN(upload)(itm_scene* scene, itm_render_state* rs, int which, const void
 /* Device address of a buffer (zero-copy hand-off to e.g. a collective); NULL if absent. */
 void* ITM_FN(buffer_ptr)(const itm_scene* scene, const itm_render_state* rs, int which);
 
+/* ---- per-kernel timers (the reference wraps ProcessFrame in a stopwatch: Engine/CLIEngine.cpp:44-86,
+ * Utils/NVTimer.h; here hipEvents bracket individual kernels on their stream) ------------------- */
+enum itm_timed_kernel {
+  ITM_TK_REQUEST = 0,       /* per-pixel block requests (buildHashAllocAndVisibleTypePP)   */
+  ITM_TK_ALLOC_SWEEP = 1,   /* ordered allocation sweep                                    */
+  ITM_TK_VISIBLE_LIST = 2,  /* frustum re-test + ordered compaction (2 launches)           */
+  ITM_TK_INTEGRATE = 3,     /* IntegrateIntoScene kernel                                   */
+  ITM_TK_RANGE = 4,         /* CreateExpectedDepths kernels                                */
+  ITM_TK_RAYCAST = 5,       /* GenericRaycast kernel                                       */
+  ITM_TK_ICP_MAPS = 6,      /* processPixelICP kernel                                      */
+  ITM_TK_COUNT = 7
+};
+typedef struct itm_profile {
+  int32_t calls[8];
+  double total_ms[8];
+} itm_profile;
+/* kernel_mask: bit i enables timing of kernel i (0 disables everything).  Each timed launch costs
+ * two hipEventRecord calls on the frame stream. */
+int ITM_FN(profile_enable)(itm_scene* scene, uint32_t kernel_mask);
+/* Waits for the recorded events, accumulates and returns the totals; reset != 0 clears them. */
+int ITM_FN(profile_read)(itm_scene* scene, itm_profile* out, int reset);
+
 /* Fixed-size record for the multi-stream exchange: writes
  * {float M_d[16]; int32 noVisibleEntries; int32 ids[max_ids]} (padded with -1) to `dst`
  * (device memory, (17+max_ids)*4 bytes) on `stream`, without a host round-trip. */

@@ -71,6 +71,13 @@ class ViewStruct(C.Structure):
                 ("rgb_to_depth", C.c_float * 16), ("rgb_to_depth_inv", C.c_float * 16)]
 
 
+class Profile(C.Structure):
+    _fields_ = [("calls", C.c_int32 * 8), ("total_ms", C.c_double * 8)]
+
+
+TIMED_KERNELS = ["request", "alloc_sweep", "visible_list", "integrate", "range", "raycast", "icp_maps"]
+
+
 class Counters(C.Structure):
     _fields_ = [("lastFreeBlockId", C.c_int32), ("lastFreeExcessListId", C.c_int32),
                 ("noVisibleEntries", C.c_int32), ("noFwdProjMissingPoints", C.c_int32),
@@ -143,6 +150,8 @@ _SIGS = {
     "upload": (C.c_int, [_P, _P, C.c_int, _P, C.c_size_t, _P]),
     "buffer_ptr": (_P, [_P, _P, C.c_int]),
     "debug_set": (C.c_int, [C.c_int, C.c_int]),
+    "profile_enable": (C.c_int, [_P, C.c_uint32]),
+    "profile_read": (C.c_int, [_P, C.POINTER(Profile), C.c_int]),
     "export_visible_record": (C.c_int, [_P, C.POINTER(C.c_float), C.c_int, _P, _P]),
 }
 
@@ -302,6 +311,14 @@ class Scene:
                 BUF_RANGE_IMAGE: np.dtype("<f4"), BUF_RAYCAST_RESULT: np.dtype("<f4"),
                 BUF_RAYCAST_IMAGE: np.dtype("u1"), BUF_FORWARD_PROJECTION: np.dtype("<f4"),
                 BUF_MISSING_POINTS: np.dtype("<i4")}[which]
+
+    def profile_enable(self, mask: int):
+        self.be.check(self.be.fn["profile_enable"](_P(self.h), mask), "profile_enable")
+
+    def profile_read(self, reset=True) -> dict:
+        p = Profile()
+        self.be.check(self.be.fn["profile_read"](_P(self.h), C.byref(p), int(reset)), "profile_read")
+        return {n: {"calls": int(p.calls[i]), "total_ms": float(p.total_ms[i])} for i, n in enumerate(TIMED_KERNELS)}
 
     def download(self, which: int, rs: Optional["RenderState"] = None, stream=None) -> np.ndarray:
         rsh = _P(rs.h if rs else None)

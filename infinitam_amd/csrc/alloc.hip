@@ -378,17 +378,21 @@ int launch_allocate(itm_scene* s, const itm_view* v, itm_render_state* rs, bool 
   mark_previous_kernel<<<64, 256, 0, st>>>(rs->visibleIds, rs->counters, rs->visibleType);
   dim3 grid((v->w + 15) / 16, (v->h + 15) / 16);
   if (onlyVisible) {
+    KernelTimer tq(s, ITM_TK_REQUEST, st);
     if (fuseRangeInit) request_kernel<true, true><<<grid, 256, 0, st>>>(v->depth, s->hash, rs->visibleType, s->allocKey, reqCur, s->counters, rs->range, rs->counters, p);
     else request_kernel<true, false><<<grid, 256, 0, st>>>(v->depth, s->hash, rs->visibleType, s->allocKey, reqCur, s->counters, rs->range, rs->counters, p);
-    visible_count_kernel<false><<<nChunks, 256, 0, st>>>(rs->visibleType, s->hash, s->chunkVis, reqCur, nChunks, s->counters, p);
   } else {
+    { KernelTimer tq(s, ITM_TK_REQUEST, st);
     if (fuseRangeInit) request_kernel<false, true><<<grid, 256, 0, st>>>(v->depth, s->hash, rs->visibleType, s->allocKey, reqCur, s->counters, rs->range, rs->counters, p);
-    else request_kernel<false, false><<<grid, 256, 0, st>>>(v->depth, s->hash, rs->visibleType, s->allocKey, reqCur, s->counters, rs->range, rs->counters, p);
+    else request_kernel<false, false><<<grid, 256, 0, st>>>(v->depth, s->hash, rs->visibleType, s->allocKey, reqCur, s->counters, rs->range, rs->counters, p); }
+    { KernelTimer ts(s, ITM_TK_ALLOC_SWEEP, st);
     allocate_sweep_kernel<<<nChunks, 256, 0, st>>>(s->allocKey, reqCur, reqNext, nChunks, s->hash, s->excessList, s->allocList,
-                                                   rs->visibleType, s->counters, s->headBits, v->depth, p);
-    visible_count_kernel<true><<<nChunks, 256, 0, st>>>(rs->visibleType, s->hash, s->chunkVis, reqCur, nChunks, s->counters, p);
+                                                   rs->visibleType, s->counters, s->headBits, v->depth, p); }
     s->frameParity++;
   }
+  KernelTimer tv(s, ITM_TK_VISIBLE_LIST, st);
+  if (onlyVisible) visible_count_kernel<false><<<nChunks, 256, 0, st>>>(rs->visibleType, s->hash, s->chunkVis, reqCur, nChunks, s->counters, p);
+  else visible_count_kernel<true><<<nChunks, 256, 0, st>>>(rs->visibleType, s->hash, s->chunkVis, reqCur, nChunks, s->counters, p);
   visible_compact_kernel<<<nChunks, 256, 0, st>>>(rs->visibleType, s->chunkVis, nChunks, s->noTotalEntries, rs->visibleIds, rs->capIds, rs->counters);
   ITM_LAUNCH_CHECK();
   return ITM_OK;

@@ -188,6 +188,7 @@ int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipS
   const bool colour = (s->cfg.voxelType == ITM_VOXEL_S_RGB || s->cfg.voxelType == ITM_VOXEL_F_RGB);
   if (colour && (!rgb || v->w_rgb <= 0 || v->h_rgb <= 0)) return set_error(ITM_ERR_INVALID, "colour voxels need an rgb image");
 
+  KernelTimer tk(s, ITM_TK_INTEGRATE, st);
   if (s->cfg.indexType == ITM_INDEX_HASH) {
     const int grid = 256 * 4;  // 4 x 512-lane workgroups per CU
     int rc = dispatch_voxel(s->cfg.voxelType, [&](auto vx) {

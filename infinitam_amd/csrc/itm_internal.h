@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <vector>
 
 #include "../../include/itm_hip.h"
 #include "itm_types.h"
@@ -25,6 +26,18 @@ struct RenderCounters {
   int32_t noRenderingBlocks;       // numRenderingBlocks of CreateExpectedDepths
   int32_t rawVisibleCount;         // visible slots before clamping to the list capacity
   int32_t pad[3];
+};
+
+// hipEvent pairs around selected kernels (itm_profile_enable / itm_profile_read)
+struct Profiler {
+  uint32_t mask = 0;
+  struct Rec { int id; hipEvent_t a, b; };
+  std::vector<Rec> pending;
+  std::vector<hipEvent_t> pool;
+  double total_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int32_t calls[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  hipEvent_t get();
+  void flush();
 };
 
 constexpr int kSweepChunk = 2048;  // hash slots handled by one workgroup in the ordered sweeps
@@ -55,6 +68,7 @@ struct itm_scene {
   // which lets the ray caster skip empty space without touching the 16-byte entries.
   uint32_t* headBits = nullptr;   // uint32[bucketNum / 32]
   uint32_t frameParity = 0;
+  itm::Profiler* prof = nullptr;
 };
 
 struct itm_render_state {
@@ -95,6 +109,17 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
   } while (0)
 
 inline hipStream_t as_stream(itm_stream s) { return (hipStream_t)s; }
+
+// RAII bracket: records an event before and after the launches in its scope when kernel `id` is timed
+struct KernelTimer {
+  Profiler* p; hipStream_t st; int id; hipEvent_t a;
+  KernelTimer(const itm_scene* s, int id_, hipStream_t st_) : p(s->prof), st(st_), id(id_), a(nullptr) {
+    if (p && (p->mask >> id) & 1u) { a = p->get(); (void)hipEventRecord(a, st); } else p = nullptr;
+  }
+  ~KernelTimer() {
+    if (p) { hipEvent_t b = p->get(); (void)hipEventRecord(b, st); p->pending.push_back({id, a, b}); }
+  }
+};
 
 // host-side matrix helpers (host_math.cpp): same operation order as ORUtils/Matrix.h
 bool invert4(const float* m, float* out);

@@ -8,6 +8,13 @@
 
 #include "itm_types.h"
 
+#ifndef ITM_RAY_FUSED_FETCH
+#define ITM_RAY_FUSED_FETCH 0
+#endif
+#ifndef ITM_RAY_BITMAP_GUARD
+#define ITM_RAY_BITMAP_GUARD 1  // consult the occupancy bitmap before fetching a hash entry (single-voxel lookups)
+#endif
+
 namespace itm {
 
 struct VolumeView {
@@ -42,10 +49,11 @@ __device__ inline long long locate_voxel(const VolumeView& vol, int px, int py, 
     const int lin = (px - bx * 8) + (py - by * 8) * 8 + (pz - bz * 8) * 64;
     if (bx == cache.bx && by == cache.by && bz == cache.bz) return (long long)cache.base + lin;
     int idx = hash_index(bx, by, bz, vol.mask);
-    // both loads are issued together; the 16-byte entry is only consumed when the bucket is occupied
-    const uint32_t word = vol.headBits[idx >> 5];
+#if ITM_RAY_BITMAP_GUARD
+    // the 16-byte entry is only fetched when the occupancy bit says the bucket is in use
+    if (!((vol.headBits[idx >> 5] >> (idx & 31)) & 1u)) return -1;
+#endif
     HashEntry e = unpack_entry(vol.hash[idx]);
-    if (!((word >> (idx & 31)) & 1u)) return -1;
     for (;;) {
       if (e.px == bx && e.py == by && e.pz == bz && e.ptr >= 0) {
         cache.bx = bx; cache.by = by; cache.bz = bz; cache.base = e.ptr * kBlockVoxels;
@@ -81,57 +89,93 @@ __device__ inline int resolve_block(const VolumeView& vol, HashEntry e, int bx, 
   }
 }
 
-// Trilinear read (reference: eight readVoxel calls in the order 000 100 | 010 110 | 001 101 | 011 111,
-// blended on the raw values).  The voxel values do not depend on the order in which blocks are
-// looked up (the reference's IndexCache only short-cuts the probe), so for the hash index the
-// lookups are restructured for memory-level parallelism: the up-to-8 distinct blocks touched by
-// the 2x2x2 neighbourhood are probed with independent loads issued back to back, then the eight
-// voxel loads are issued back to back.  The arithmetic on the values is unchanged.
+// The 2x2x2 voxel neighbourhood of floor(p): raw sdf values in the reference's read order
+// 000 100 | 010 110 | 001 101 | 011 111 (default value where no block is allocated).
+//
+// The values of a trilinear read do not depend on the order in which blocks are looked up (the
+// reference's IndexCache only short-cuts the probe), so for the hash index the lookups are
+// restructured for memory-level parallelism: the up-to-8 distinct blocks the neighbourhood touches
+// are probed with independent loads issued back to back, then the eight voxel loads are issued
+// back to back.  The nearest voxel of p (ROUND per axis) is always one of these eight corners, so
+// one fetch serves both the nearest-neighbour read and the trilinear read of a ray step.
 template <class VX, bool DENSE>
-__device__ inline float sdf_trilinear(const VolumeView& vol, float x, float y, float z, bool& found, BlockCache& cache) {
-  const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
-  const float cx = x - fx, cy = y - fy, cz = z - fz;
-  const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
-  float v[8];
-  if (DENSE) {
-#pragma unroll
-    for (int c = 0; c < 8; ++c) v[c] = read_raw_sdf<VX, DENSE>(vol, ix + (c & 1), iy + ((c >> 1) & 1), iz + (c >> 2), found, cache);
-  } else {
-    const int bx = floor_div8(ix), by = floor_div8(iy), bz = floor_div8(iz);
-    const int lx = ix - bx * 8, ly = iy - by * 8, lz = iz - bz * 8;
-    // bit k set: the +1 neighbour along axis k lies in the next block
-    const int cross = (lx == 7 ? 1 : 0) | (ly == 7 ? 2 : 0) | (lz == 7 ? 4 : 0);
-    const bool cached = (bx == cache.bx && by == cache.by && bz == cache.bz);
-    HashEntry head[8];
-    bool need[8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      need[s] = ((s & ~cross) == 0) && !(s == 0 && cached);
-      if (need[s]) head[s] = unpack_entry(vol.hash[hash_index(bx + (s & 1), by + ((s >> 1) & 1), bz + (s >> 2), vol.mask)]);
-    }
-    int base[8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      base[s] = -1;
-      if (need[s]) base[s] = resolve_block(vol, head[s], bx + (s & 1), by + ((s >> 1) & 1), bz + (s >> 2));
-    }
-    if (cached) base[0] = cache.base;
-    else if (base[0] >= 0) { cache.bx = bx; cache.by = by; cache.bz = bz; cache.base = base[0]; }
+struct Corners {
+  float v[8];      // raw sdf per corner
+  bool present[8]; // block allocated / inside the dense volume
+  float cx, cy, cz;  // fractional position
+  int ix, iy, iz;    // floor(p)
+
+  __device__ inline void fetch(const VolumeView& vol, float x, float y, float z, BlockCache& cache) {
+    const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
+    cx = x - fx; cy = y - fy; cz = z - fz;
+    ix = (int)fx; iy = (int)fy; iz = (int)fz;
     const float dflt = VX::kShort ? 32767.0f : 1.0f;
+    if (DENSE) {
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const int b = base[c & cross];
-      const int off = ((lx + (c & 1)) & 7) + ((ly + ((c >> 1) & 1)) & 7) * 8 + ((lz + (c >> 2)) & 7) * 64;
-      v[c] = (b >= 0) ? VX::load_raw_sdf(vol.vba, (size_t)(b + off)) : dflt;
+      for (int c = 0; c < 8; ++c) {
+        const long long a = locate_voxel<true>(vol, ix + (c & 1), iy + ((c >> 1) & 1), iz + (c >> 2), cache);
+        present[c] = a >= 0;
+        v[c] = present[c] ? VX::load_raw_sdf(vol.vba, (size_t)a) : dflt;
+      }
+    } else {
+      const int bx = floor_div8(ix), by = floor_div8(iy), bz = floor_div8(iz);
+      const int lx = ix - bx * 8, ly = iy - by * 8, lz = iz - bz * 8;
+      // bit k set: the +1 neighbour along axis k lies in the next block
+      const int cross = (lx == 7 ? 1 : 0) | (ly == 7 ? 2 : 0) | (lz == 7 ? 4 : 0);
+      const bool cached = (bx == cache.bx && by == cache.by && bz == cache.bz);
+      HashEntry head[8];
+      bool need[8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        need[s] = ((s & ~cross) == 0) && !(s == 0 && cached);
+        if (need[s]) head[s] = unpack_entry(vol.hash[hash_index(bx + (s & 1), by + ((s >> 1) & 1), bz + (s >> 2), vol.mask)]);
+      }
+      int base[8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        base[s] = -1;
+        if (need[s]) base[s] = resolve_block(vol, head[s], bx + (s & 1), by + ((s >> 1) & 1), bz + (s >> 2));
+      }
+      if (cached) base[0] = cache.base;
+      else if (base[0] >= 0) { cache.bx = bx; cache.by = by; cache.bz = bz; cache.base = base[0]; }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int b = base[c & cross];
+        const int off = ((lx + (c & 1)) & 7) + ((ly + ((c >> 1) & 1)) & 7) * 8 + ((lz + (c >> 2)) & 7) * 64;
+        present[c] = b >= 0;
+        v[c] = present[c] ? VX::load_raw_sdf(vol.vba, (size_t)(b + off)) : dflt;
+      }
     }
   }
-  float r1, r2;
-  r1 = (1.0f - cx) * v[0] + cx * v[1];
-  r1 = (1.0f - cy) * r1 + cy * ((1.0f - cx) * v[2] + cx * v[3]);
-  r2 = (1.0f - cx) * v[4] + cx * v[5];
-  r2 = (1.0f - cy) * r2 + cy * ((1.0f - cx) * v[6] + cx * v[7]);
+
+  // readFromSDF_float_interpolated on the fetched values (blend on raw values, then convert)
+  __device__ inline float trilinear() const {
+    float r1, r2;
+    r1 = (1.0f - cx) * v[0] + cx * v[1];
+    r1 = (1.0f - cy) * r1 + cy * ((1.0f - cx) * v[2] + cx * v[3]);
+    r2 = (1.0f - cx) * v[4] + cx * v[5];
+    r2 = (1.0f - cy) * r2 + cy * ((1.0f - cx) * v[6] + cx * v[7]);
+    return VX::to_float((1.0f - cz) * r1 + cz * r2);
+  }
+
+  // readFromSDF_float_uninterpolated at the same point: the voxel at ROUND(p) is corner
+  // (ROUND(p) - floor(p)) in {0,1}^3
+  __device__ inline float nearest(float x, float y, float z, bool& found) const {
+    const int c = ((int)round_ref(x) - ix) | (((int)round_ref(y) - iy) << 1) | (((int)round_ref(z) - iz) << 2);
+    float val = v[0]; bool pr = present[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) if (c == k) { val = v[k]; pr = present[k]; }
+    found = pr;
+    return VX::to_float(val);
+  }
+};
+
+template <class VX, bool DENSE>
+__device__ inline float sdf_trilinear(const VolumeView& vol, float x, float y, float z, bool& found, BlockCache& cache) {
+  Corners<VX, DENSE> cn;
+  cn.fetch(vol, x, y, z, cache);
   found = true;
-  return VX::to_float((1.0f - cz) * r1 + cz * r2);
+  return cn.trilinear();
 }
 
 struct RayParams {
@@ -167,39 +211,21 @@ __device__ inline float4 cast_ray(int x, int y, const VolumeView& vol, const Ray
   bool found;
   float step;
   while (total < totalMax) {
+#if ITM_RAY_FUSED_FETCH
+    // one fetch of the 2x2x2 neighbourhood serves the nearest read and the trilinear re-read
+    // (measured slower on MI355X: 155 us vs 72 us -- the extra probes/ALU of every step outweigh
+    // the saved round trip; kept for experiments)
+    Corners<VX, DENSE> cn;
+    cn.fetch(vol, px, py, pz, cache);
+    sdf = cn.nearest(px, py, pz, found);
+    if (found && (sdf <= 0.1f) && (sdf >= -0.5f)) sdf = cn.trilinear();
+#else
     sdf = sdf_nearest<VX, DENSE>(vol, px, py, pz, found, cache);
+    if (found && (sdf <= 0.1f) && (sdf >= -0.5f)) sdf = sdf_trilinear<VX, DENSE>(vol, px, py, pz, found, cache);
+#endif
     if (!found) {
       step = (float)kBlockSide;
-      if (!DENSE) {
-        // Empty-space skipping.  While blocks are missing the march is pure arithmetic
-        // (pt += 8*dir, total += 8, exactly as the reference computes it), so the next kLook
-        // positions are known in advance: their occupancy bits are fetched with independent loads
-        // and every leading position whose bucket is provably empty is stepped over at once.
-        px += step * dx; py += step * dy; pz += step * dz;
-        total += step;
-        constexpr int kLook = 4;
-        float qx[kLook + 1], qy[kLook + 1], qz[kLook + 1], qt[kLook + 1];
-        bool empty[kLook];
-        qx[0] = px; qy[0] = py; qz[0] = pz; qt[0] = total;
-#pragma unroll
-        for (int j = 0; j < kLook; ++j) {
-          const int vx = (int)round_ref(qx[j]), vy = (int)round_ref(qy[j]), vz = (int)round_ref(qz[j]);
-          const int h = hash_index(floor_div8(vx), floor_div8(vy), floor_div8(vz), vol.mask);
-          empty[j] = !((vol.headBits[h >> 5] >> (h & 31)) & 1u);
-          qx[j + 1] = qx[j] + step * dx; qy[j + 1] = qy[j] + step * dy; qz[j + 1] = qz[j] + step * dz;
-          qt[j + 1] = qt[j] + step;
-        }
-        int adv = 0;
-#pragma unroll
-        for (int j = 0; j < kLook; ++j) {
-          if (adv == j && qt[j] < totalMax && empty[j]) adv = j + 1;
-        }
-#pragma unroll
-        for (int j = 1; j <= kLook; ++j) if (adv == j) { px = qx[j]; py = qy[j]; pz = qz[j]; total = qt[j]; }
-        continue;
-      }
     } else {
-      if ((sdf <= 0.1f) && (sdf >= -0.5f)) sdf = sdf_trilinear<VX, DENSE>(vol, px, py, pz, found, cache);
       if (sdf <= 0.0f) break;
       const float s = sdf * stepScale;
       step = (s < 1.0f) ? 1.0f : s;

@@ -25,6 +25,22 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
   return ITM_ERR_DEVICE;
 }
 
+hipEvent_t Profiler::get() {
+  if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+void Profiler::flush() {
+  for (const Rec& r : pending) {
+    (void)hipEventSynchronize(r.b);
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { total_ms[r.id] += ms; calls[r.id] += 1; }
+    pool.push_back(r.a); pool.push_back(r.b);
+  }
+  pending.clear();
+}
+
 // ---- host matrix helpers ---------------------------------------------------------------------
 // Matrix4::inv (ORUtils/Matrix.h:162-223): cofactors of the transposed matrix, then every element
 // times 1/det.  Host code in this file is compiled with -ffp-contract=off as well.
@@ -192,6 +208,7 @@ static void* buffer_of(const itm_scene* s, const itm_render_state* rs, int which
 
 static void free_scene(itm_scene* s) {
   if (!s) return;
+  if (s->prof) { s->prof->flush(); for (hipEvent_t e : s->prof->pool) (void)hipEventDestroy(e); delete s->prof; }
   (void)hipFree(s->hash); (void)hipFree(s->excessList); (void)hipFree(s->vba); (void)hipFree(s->allocList);
   (void)hipFree(s->counters); (void)hipFree(s->headBits); (void)hipFree(s->allocKey); (void)hipFree(s->chunkReq); (void)hipFree(s->chunkVis);
   delete s;
@@ -388,6 +405,22 @@ int itm_convert_disparity(const int16_t* raw, float* out, int w, int h, float c0
   int n = w * h;
   depth_disparity_kernel<<<(n + 255) / 256, 256, 0, as_stream(st)>>>(raw, out, n, c0, c1, fx);
   ITM_LAUNCH_CHECK();
+  return ITM_OK;
+}
+
+int itm_profile_enable(itm_scene* s, uint32_t mask) {
+  if (!s) return set_error(ITM_ERR_INVALID, "null scene");
+  if (!s->prof) s->prof = new Profiler();
+  s->prof->mask = mask;
+  return ITM_OK;
+}
+int itm_profile_read(itm_scene* s, itm_profile* out, int reset) {
+  if (!s || !out) return set_error(ITM_ERR_INVALID, "null argument");
+  memset(out, 0, sizeof *out);
+  if (!s->prof) return ITM_OK;
+  s->prof->flush();
+  for (int i = 0; i < 8; ++i) { out->calls[i] = s->prof->calls[i]; out->total_ms[i] = s->prof->total_ms[i]; }
+  if (reset) for (int i = 0; i < 8; ++i) { s->prof->calls[i] = 0; s->prof->total_ms[i] = 0; }
   return ITM_OK;
 }
 

@@ -25,6 +25,10 @@
 #include "shading_device.h"
 #include "wave_utils.h"
 
+#ifndef ITM_RAY_XCD_SWIZZLE
+#define ITM_RAY_XCD_SWIZZLE 0   // measured: no gain (L2 is cold at every kernel start), see DESIGN.md
+#endif
+
 namespace itm {
 
 int g_debug_force_global_range = 0;
@@ -264,6 +268,7 @@ __global__ void __launch_bounds__(256) range_reduce_kernel(RenderCounters* __res
 
 int launch_expected_depths(const itm_scene* s, const float* M, const float* intr, itm_render_state* rs, bool rangeAlreadyInit, hipStream_t st) {
   const int P = rs->w * rs->h;
+  KernelTimer tk(s, ITM_TK_RANGE, st);
   if (s->cfg.indexType == ITM_INDEX_DENSE) {
     range_init_kernel<<<512, 256, 0, st>>>(rs->range, P, 0.2f, 3.0f, rs->counters);
     ITM_LAUNCH_CHECK();
@@ -303,8 +308,20 @@ int launch_expected_depths(const itm_scene* s, const float* M, const float* intr
 template <class VX, bool DENSE>
 __global__ void __launch_bounds__(256) raycast_kernel(VolumeView vol, const float2* __restrict__ range, float4* __restrict__ out, RayParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int x = blockIdx.x * 16 + (lane & 15);
-  const int y = blockIdx.y * 16 + wave * 4 + (lane >> 4);
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so workgroup L runs
+  // on XCD (L % 8).  Tiles are renumbered so that each XCD gets a contiguous band of the image:
+  // its rays then share voxel blocks and hash lines inside that XCD's private 4 MiB L2.
+#if ITM_RAY_XCD_SWIZZLE
+  const int tilesX = (p.W + 15) / 16;
+  const int perXcd = gridDim.x / 8;                       // grid is padded to a multiple of 8
+  const int tile = (blockIdx.x % 8) * perXcd + blockIdx.x / 8;
+  const int tx = tile % tilesX, ty = tile / tilesX;
+#else
+  const int tilesX = (p.W + 15) / 16;
+  const int tx = blockIdx.x % tilesX, ty = blockIdx.x / tilesX;
+#endif
+  const int x = tx * 16 + (lane & 15);
+  const int y = ty * 16 + wave * 4 + (lane >> 4);
   if (x >= p.W || y >= p.H) return;
   const float2 mm = range[(x >> 3) + (y >> 3) * p.W];  // floor(x/8) + floor(y/8)*W  (_CPU.cpp:174)
   out[x + y * p.W] = cast_ray<VX, DENSE>(x, y, vol, p, mm);
@@ -313,8 +330,10 @@ __global__ void __launch_bounds__(256) raycast_kernel(VolumeView vol, const floa
 int launch_raycast(const itm_scene* s, const float* invM, const float* intr, itm_render_state* rs, float4* dst, hipStream_t st) {
   RayParams p; make_ray_params(s, invM, intr, rs->w, rs->h, p);
   const VolumeView vol = make_volume(s);
-  const dim3 grid((rs->w + 15) / 16, (rs->h + 15) / 16);
+  const int nTiles = ((rs->w + 15) / 16) * ((rs->h + 15) / 16);
+  const dim3 grid((nTiles + 7) / 8 * 8);
   const bool dense = s->cfg.indexType == ITM_INDEX_DENSE;
+  KernelTimer tk(s, ITM_TK_RAYCAST, st);
   int rc = dispatch_voxel(s->cfg.voxelType, [&](auto vx) {
     using VX = decltype(vx);
     if (dense) raycast_kernel<VX, true><<<grid, 256, 0, st>>>(vol, rs->range, dst, p);
@@ -357,6 +376,7 @@ int launch_icp_maps(const itm_scene* s, const itm_view* v, itm_render_state* rs,
   if (rc) return rc;
   RayParams p; make_ray_params(s, invM, v->intr_d, rs->w, rs->h, p);
   const dim3 grid((rs->w + 15) / 16, (rs->h + 15) / 16);
+  KernelTimer tk(s, ITM_TK_ICP_MAPS, st);
   icp_maps_kernel<<<grid, 256, 0, st>>>(rs->raycast, points, normals, rs->image, p);
   ITM_LAUNCH_CHECK();
   return ITM_OK;
