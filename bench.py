@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=40)
     ap.add_argument("--no-exchange", action="store_true", help="skip the visible-list all-gather at N>1")
+    ap.add_argument("--force-exchange", action="store_true", help="run the all-gather path even with one rank (self-test)")
     return ap.parse_args()
 
 
@@ -58,8 +59,9 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or args.force_exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import infinitam_amd as itm
@@ -88,13 +90,11 @@ def main():
     sh, rh = C.c_void_p(scene.h), C.c_void_p(rs.h)
     pp, np_ = C.c_void_p(points.data_ptr()), C.c_void_p(normals.data_ptr())
 
-    exchange = world > 1 and not args.no_exchange
+    exchange = (world > 1 and not args.no_exchange) or args.force_exchange
     if exchange:
+        from infinitam_amd.streams import VisibleListExchange
         side = torch.cuda.Stream()
-        rec = torch.empty(17 + MAX_IDS, dtype=torch.int32, device="cuda")
-        gathered = torch.empty(world * (17 + MAX_IDS), dtype=torch.int32, device="cuda")
-        export = be.fn["export_visible_record"]
-        recp = C.c_void_p(rec.data_ptr())
+        ex = VisibleListExchange(be, world, rank, MAX_IDS, device="cuda")
 
     def step(k):
         v = views[k % PERIOD]
@@ -102,14 +102,16 @@ def main():
         if rc:
             be.check(rc, "process_frame")
         if exchange:
-            # the record is produced on the frame stream, the collective runs on a side stream and
-            # overlaps the next frame (it is not on the critical path of fusion)
-            Ma = (C.c_float * 16)(*[float(x) for x in poses[k % PERIOD]])
+            # The record is produced from the device-resident visible list and all-gathered on a side
+            # stream; it overlaps the next frame's allocation/integration and is only re-joined with
+            # the frame stream before the list is rebuilt (not on the critical path).
             side.wait_stream(stream)
             with torch.cuda.stream(side):
-                export(rh, Ma, MAX_IDS, recp, C.c_void_p(side.cuda_stream))
-                dist.all_gather_into_tensor(gathered, rec)
-            stream.wait_stream(side)
+                ex.publish(rs.h, poses[k % PERIOD], side.cuda_stream)
+                copied = torch.cuda.Event()
+                copied.record(side)
+                ex.all_gather()
+            stream.wait_event(copied)   # the frame stream only waits for the 64 KB record copy
 
     TK_RAYCAST = 5
     for k in range(args.warmup):
@@ -161,7 +163,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or args.force_exchange:
         dist.destroy_process_group()
 
 

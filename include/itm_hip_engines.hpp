@@ -1,0 +1,240 @@
+// itm_hip_engines.hpp -- C++ host side above the C-ABI (include/itm_hip.h).
+//
+// Header-only adapter classes with the method names, argument meaning and (void / throwing) error
+// behaviour of the reference's engine interfaces, so that code written against
+//   ITMLib::Engine::ITMSceneReconstructionEngine<TVoxel,TIndex>   (Engine/ITMSceneReconstructionEngine.h:28-52)
+//   ITMLib::Engine::ITMVisualisationEngine<TVoxel,TIndex>         (Engine/ITMVisualisationEngine.h:18-107)
+// reads the same against the HIP back-end.  The reference's own object headers are NOT included:
+// the few host-side value types the methods take (pose, intrinsics, view, tracking state, scene
+// shell, render-state shell) are re-declared here as thin shells over device handles.  A maintainer
+// of the reference instead derives two classes from the reference's abstract engines and forwards
+// to the same C functions -- see INTEGRATION.md for that stub.
+//
+// Everything lives in HBM and is owned by the C library; the shells only carry handles.  Device
+// errors become std::runtime_error (the reference prints and exit(-1)s: ORUtils/CUDADefines.h:27-36).
+#pragma once
+
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+#include "itm_hip.h"
+
+namespace itmhip {
+
+inline void check(int rc, const char* what) {
+  if (rc != ITM_OK) throw std::runtime_error(std::string(what) + ": " + itm_last_error());
+}
+
+// voxel / index tags replacing the reference's TVoxel / TIndex template arguments
+struct ITMVoxel_s { static constexpr int kType = ITM_VOXEL_S; };
+struct ITMVoxel_f { static constexpr int kType = ITM_VOXEL_F; };
+struct ITMVoxel_s_rgb { static constexpr int kType = ITM_VOXEL_S_RGB; };
+struct ITMVoxel_f_rgb { static constexpr int kType = ITM_VOXEL_F_RGB; };
+struct ITMVoxelBlockHash { static constexpr int kType = ITM_INDEX_HASH; };
+struct ITMPlainVoxelArray { static constexpr int kType = ITM_INDEX_DENSE; };
+
+struct Vector2i { int x, y; };
+
+// ITMPose: only the model-view matrix is needed by the path (Objects/ITMPose.h GetM()).
+struct ITMPose {
+  float M[16];
+  ITMPose() { std::memset(M, 0, sizeof M); M[0] = M[5] = M[10] = M[15] = 1.0f; }
+  void SetM(const float* m) { std::memcpy(M, m, sizeof M); }
+  const float* GetM() const { return M; }
+};
+
+// ITMIntrinsics::projectionParamsSimple.all (Objects/ITMIntrinsics.h)
+struct ITMIntrinsics {
+  float all[4];
+  ITMIntrinsics() { SetFrom(580, 580, 320, 240); }
+  void SetFrom(float fx, float fy, float cx, float cy) { all[0] = fx; all[1] = fy; all[2] = cx; all[3] = cy; }
+};
+
+// ITMRGBDCalib (Objects/ITMRGBDCalib.h): intrinsics + rgb->depth extrinsics
+struct ITMRGBDCalib {
+  ITMIntrinsics intrinsics_rgb, intrinsics_d;
+  float trafo_rgb_to_depth_calib[16], trafo_rgb_to_depth_calib_inv[16];
+  ITMRGBDCalib() {
+    std::memset(trafo_rgb_to_depth_calib, 0, 64);
+    trafo_rgb_to_depth_calib[0] = trafo_rgb_to_depth_calib[5] = trafo_rgb_to_depth_calib[10] = trafo_rgb_to_depth_calib[15] = 1.0f;
+    std::memcpy(trafo_rgb_to_depth_calib_inv, trafo_rgb_to_depth_calib, 64);
+  }
+};
+
+// ITMView (Objects/ITMView.h): device images + calibration
+struct ITMView {
+  ITMRGBDCalib calib;
+  const float* depth = nullptr;  // device float[h*w]
+  const uint8_t* rgb = nullptr;  // device uchar4[h_rgb*w_rgb]
+  Vector2i depthSize{0, 0}, rgbSize{0, 0};
+};
+
+// ITMTrackingState (Objects/ITMTrackingState.h): pose + the ICP maps written by CreateICPMaps
+struct ITMTrackingState {
+  ITMPose pose_d, pose_pointCloud;
+  float* pointCloud_locations = nullptr;  // device Vector4f[h*w]
+  float* pointCloud_colours = nullptr;    // device Vector4f[h*w] (normals for the ICP tracker)
+  int age_pointCloud = -1;
+  bool requiresFullRendering = true;
+};
+
+struct ITMSceneParams : itm_scene_params {
+  ITMSceneParams(float mu_, int maxW_, float voxelSize_, float vfMin, float vfMax, bool stopAtMax) {
+    mu = mu_; maxW = maxW_; voxelSize = voxelSize_; viewFrustum_min = vfMin; viewFrustum_max = vfMax;
+    stopIntegratingAtMaxW = stopAtMax ? 1 : 0;
+  }
+};
+
+// ITMScene<TVoxel,TIndex> (Objects/ITMScene.h:37-43): owns the device scene
+template <class TVoxel, class TIndex>
+class ITMScene {
+ public:
+  itm_scene* handle = nullptr;
+  const ITMSceneParams* sceneParams;
+  explicit ITMScene(const ITMSceneParams* params, int localBlockNum = 0, int bucketNum = 0, int excessNum = 0) : sceneParams(params) {
+    itm_scene_config cfg;
+    std::memset(&cfg, 0, sizeof cfg);
+    cfg.voxelType = TVoxel::kType; cfg.indexType = TIndex::kType;
+    cfg.localBlockNum = localBlockNum; cfg.bucketNum = bucketNum; cfg.excessNum = excessNum;
+    check(itm_scene_create(&cfg, params, &handle), "itm_scene_create");
+  }
+  ~ITMScene() { itm_scene_destroy(handle); }
+  ITMScene(const ITMScene&) = delete;
+  ITMScene& operator=(const ITMScene&) = delete;
+};
+
+// ITMRenderState / ITMRenderState_VH (Objects/ITMRenderState.h, ITMRenderState_VH.h)
+class ITMRenderState {
+ public:
+  itm_render_state* handle = nullptr;
+  Vector2i imgSize;
+  ITMRenderState(itm_render_state* h, Vector2i s) : handle(h), imgSize(s) {}
+  ~ITMRenderState() { itm_render_state_destroy(handle); }
+  ITMRenderState(const ITMRenderState&) = delete;
+  ITMRenderState& operator=(const ITMRenderState&) = delete;
+};
+
+inline itm_view make_view(const ITMView* view, const ITMTrackingState* ts) {
+  itm_view v;
+  std::memset(&v, 0, sizeof v);
+  v.depth = view->depth; v.rgb = view->rgb;
+  v.w = view->depthSize.x; v.h = view->depthSize.y; v.w_rgb = view->rgbSize.x; v.h_rgb = view->rgbSize.y;
+  std::memcpy(v.M_d, ts->pose_d.GetM(), 64);
+  std::memcpy(v.intr_d, view->calib.intrinsics_d.all, 16);
+  std::memcpy(v.intr_rgb, view->calib.intrinsics_rgb.all, 16);
+  std::memcpy(v.rgb_to_depth, view->calib.trafo_rgb_to_depth_calib, 64);
+  std::memcpy(v.rgb_to_depth_inv, view->calib.trafo_rgb_to_depth_calib_inv, 64);
+  return v;
+}
+
+// ITMSceneReconstructionEngine_HIP: same three methods as the reference interface
+template <class TVoxel, class TIndex>
+class ITMSceneReconstructionEngine_HIP {
+ public:
+  itm_stream stream = nullptr;
+  void ResetScene(ITMScene<TVoxel, TIndex>* scene) { check(itm_reset_scene(scene->handle, stream), "ResetScene"); }
+  void AllocateSceneFromDepth(ITMScene<TVoxel, TIndex>* scene, const ITMView* view, const ITMTrackingState* trackingState,
+                              const ITMRenderState* renderState, bool onlyUpdateVisibleList = false) {
+    itm_view v = make_view(view, trackingState);
+    check(itm_allocate_scene_from_depth(scene->handle, &v, renderState->handle, onlyUpdateVisibleList ? 1 : 0, stream), "AllocateSceneFromDepth");
+  }
+  void IntegrateIntoScene(ITMScene<TVoxel, TIndex>* scene, const ITMView* view, const ITMTrackingState* trackingState,
+                          const ITMRenderState* renderState) {
+    itm_view v = make_view(view, trackingState);
+    check(itm_integrate_into_scene(scene->handle, &v, renderState->handle, stream), "IntegrateIntoScene");
+  }
+};
+
+// ITMVisualisationEngine_HIP: the IITMVisualisationEngine methods
+template <class TVoxel, class TIndex>
+class ITMVisualisationEngine_HIP {
+  const ITMScene<TVoxel, TIndex>* scene;
+
+ public:
+  enum RenderImageType { RENDER_SHADED_GREYSCALE, RENDER_COLOUR_FROM_VOLUME, RENDER_COLOUR_FROM_NORMAL };
+  itm_stream stream = nullptr;
+  explicit ITMVisualisationEngine_HIP(const ITMScene<TVoxel, TIndex>* s) : scene(s) {}
+
+  ITMRenderState* CreateRenderState(const Vector2i& imgSize) const {
+    itm_render_state* h = nullptr;
+    check(itm_render_state_create(scene->handle, imgSize.x, imgSize.y, &h), "CreateRenderState");
+    return new ITMRenderState(h, imgSize);
+  }
+  void FindVisibleBlocks(const ITMPose* pose, const ITMIntrinsics* intrinsics, ITMRenderState* renderState) const {
+    check(itm_find_visible_blocks(scene->handle, pose->GetM(), intrinsics->all, renderState->handle, stream), "FindVisibleBlocks");
+  }
+  void CreateExpectedDepths(const ITMPose* pose, const ITMIntrinsics* intrinsics, ITMRenderState* renderState) const {
+    check(itm_create_expected_depths(scene->handle, pose->GetM(), intrinsics->all, renderState->handle, stream), "CreateExpectedDepths");
+  }
+  // outputImage: device uchar4[h*w]; nullptr renders into renderState->raycastImage
+  void RenderImage(const ITMPose* pose, const ITMIntrinsics* intrinsics, const ITMRenderState* renderState, uint8_t* outputImage,
+                   RenderImageType type = RENDER_SHADED_GREYSCALE) const {
+    check(itm_render_image(scene->handle, pose->GetM(), intrinsics->all, renderState->handle, outputImage, (int)type, stream), "RenderImage");
+  }
+  void FindSurface(const ITMPose* pose, const ITMIntrinsics* intrinsics, const ITMRenderState* renderState) const {
+    check(itm_find_surface(scene->handle, pose->GetM(), intrinsics->all, renderState->handle, stream), "FindSurface");
+  }
+  void CreatePointCloud(const ITMView* view, ITMTrackingState* trackingState, ITMRenderState* renderState, bool skipPoints) const {
+    itm_view v = make_view(view, trackingState);
+    check(itm_create_point_cloud(scene->handle, &v, renderState->handle, skipPoints ? 1 : 0, trackingState->pointCloud_locations,
+                                 trackingState->pointCloud_colours, stream), "CreatePointCloud");
+    trackingState->pose_pointCloud = trackingState->pose_d;
+  }
+  void CreateICPMaps(const ITMView* view, ITMTrackingState* trackingState, ITMRenderState* renderState) const {
+    itm_view v = make_view(view, trackingState);
+    check(itm_create_icp_maps(scene->handle, &v, renderState->handle, trackingState->pointCloud_locations,
+                              trackingState->pointCloud_colours, stream), "CreateICPMaps");
+    trackingState->pose_pointCloud = trackingState->pose_d;   // ITMVisualisationEngine_CPU.cpp:272
+  }
+  void ForwardRender(const ITMView* view, ITMTrackingState* trackingState, ITMRenderState* renderState) const {
+    itm_view v = make_view(view, trackingState);
+    check(itm_forward_render(scene->handle, &v, renderState->handle, stream), "ForwardRender");
+  }
+};
+
+// The callers of the path, same call order and state machine as
+// ITMDenseMapper::ProcessFrame / UpdateVisibleList (Engine/ITMDenseMapper.cpp:50-71) and
+// ITMTrackingController::Prepare (Engine/ITMTrackingController.cpp:18-46, non-colour trackers).
+template <class TVoxel, class TIndex>
+class ITMDenseMapper_HIP {
+  ITMSceneReconstructionEngine_HIP<TVoxel, TIndex> reco;
+
+ public:
+  void SetStream(itm_stream s) { reco.stream = s; }
+  void ResetScene(ITMScene<TVoxel, TIndex>* scene) { reco.ResetScene(scene); }
+  void ProcessFrame(const ITMView* view, const ITMTrackingState* ts, ITMScene<TVoxel, TIndex>* scene, ITMRenderState* rs) {
+    reco.AllocateSceneFromDepth(scene, view, ts, rs);
+    reco.IntegrateIntoScene(scene, view, ts, rs);
+  }
+  void UpdateVisibleList(const ITMView* view, const ITMTrackingState* ts, ITMScene<TVoxel, TIndex>* scene, ITMRenderState* rs) {
+    reco.AllocateSceneFromDepth(scene, view, ts, rs, true);
+  }
+};
+
+template <class TVoxel, class TIndex>
+class ITMTrackingController_HIP {
+  const ITMVisualisationEngine_HIP<TVoxel, TIndex>* vis;
+  bool useApproximateRaycast;
+
+ public:
+  ITMTrackingController_HIP(const ITMVisualisationEngine_HIP<TVoxel, TIndex>* v, bool approximate = false) : vis(v), useApproximateRaycast(approximate) {}
+  // ITMTrackingController::Track with the external (no-op) tracker of this fork
+  void Track(ITMTrackingState* ts, const ITMView*) {
+    const bool far = ts->age_pointCloud < 0 || ts->age_pointCloud > 5;   // TrackerFarFromPointCloud, pose test omitted for external poses
+    ts->requiresFullRendering = far || !useApproximateRaycast;
+  }
+  void Prepare(ITMTrackingState* ts, const ITMView* view, ITMRenderState* rs) {
+    vis->CreateExpectedDepths(&ts->pose_d, &view->calib.intrinsics_d, rs);
+    if (ts->requiresFullRendering) {
+      vis->CreateICPMaps(view, ts, rs);
+      ts->pose_pointCloud = ts->pose_d;
+      if (ts->age_pointCloud == -1) ts->age_pointCloud = -2; else ts->age_pointCloud = 0;
+    } else {
+      vis->ForwardRender(view, ts, rs);
+      ts->age_pointCloud++;
+    }
+  }
+};
+
+}  // namespace itmhip
