@@ -8,6 +8,15 @@
 
 #include "itm_types.h"
 
+#ifndef ITM_RAY_SAMEBLOCK_FAST
+#define ITM_RAY_SAMEBLOCK_FAST 0
+#endif
+#ifndef ITM_EXP_SIMPLE_TRILINEAR
+#define ITM_EXP_SIMPLE_TRILINEAR 0
+#endif
+#ifndef ITM_EXP_MAXITER
+#define ITM_EXP_MAXITER 0
+#endif
 #ifndef ITM_RAY_FUSED_FETCH
 #define ITM_RAY_FUSED_FETCH 0
 #endif
@@ -35,7 +44,9 @@ struct BlockCache {
 };
 
 __device__ inline int floor_div8(int p) { return ((p < 0) ? p - 7 : p) / 8; }
-__device__ inline float round_ref(float x) { return (x < 0) ? (x - 0.5f) : (x + 0.5f); }
+// ROUND(x) = x<0 ? x-0.5 : x+0.5 (ORUtils/MathUtils.h:21-23); after the (int) truncation this equals
+// x + copysign(0.5, x) for every x (they only differ for x = -0.0: -0.5 vs +0.5, both truncate to 0).
+__device__ inline float round_ref(float x) { return x + __builtin_copysignf(0.5f, x); }
 
 // Linear voxel index of integer point (px,py,pz), or -1 when no voxel is stored there.
 template <bool DENSE>
@@ -172,6 +183,28 @@ struct Corners {
 
 template <class VX, bool DENSE>
 __device__ inline float sdf_trilinear(const VolumeView& vol, float x, float y, float z, bool& found, BlockCache& cache) {
+#if ITM_EXP_SIMPLE_TRILINEAR
+  // timing experiment only (wrong at block borders): every corner is read from the block of floor(p)
+  if (!DENSE) {
+    const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
+    const float cx = x - fx, cy = y - fy, cz = z - fz;
+    const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+    const long long a0 = locate_voxel<false>(vol, ix, iy, iz, cache);
+    const int lx = ix & 7, ly = iy & 7, lz = iz & 7;
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int off = ((lx + (c & 1)) & 7) + ((ly + ((c >> 1) & 1)) & 7) * 8 + ((lz + (c >> 2)) & 7) * 64;
+      v[c] = (a0 >= 0) ? VX::load_raw_sdf(vol.vba, (size_t)(cache.base + off)) : 32767.0f;
+    }
+    float r1 = (1.0f - cx) * v[0] + cx * v[1];
+    r1 = (1.0f - cy) * r1 + cy * ((1.0f - cx) * v[2] + cx * v[3]);
+    float r2 = (1.0f - cx) * v[4] + cx * v[5];
+    r2 = (1.0f - cy) * r2 + cy * ((1.0f - cx) * v[6] + cx * v[7]);
+    found = true;
+    return VX::to_float((1.0f - cz) * r1 + cz * r2);
+  }
+#endif
   Corners<VX, DENSE> cn;
   cn.fetch(vol, x, y, z, cache);
   found = true;
@@ -210,6 +243,8 @@ __device__ inline float4 cast_ray(int x, int y, const VolumeView& vol, const Ray
   BlockCache cache;
   bool found;
   float step;
+  int iters = 0; (void)iters;
+  bool expectBand = false;  // the previous step was inside the band: expect a trilinear read again
   while (total < totalMax) {
 #if ITM_RAY_FUSED_FETCH
     // one fetch of the 2x2x2 neighbourhood serves the nearest read and the trilinear re-read
@@ -220,8 +255,49 @@ __device__ inline float4 cast_ray(int x, int y, const VolumeView& vol, const Ray
     sdf = cn.nearest(px, py, pz, found);
     if (found && (sdf <= 0.1f) && (sdf >= -0.5f)) sdf = cn.trilinear();
 #else
-    sdf = sdf_nearest<VX, DENSE>(vol, px, py, pz, found, cache);
-    if (found && (sdf <= 0.1f) && (sdf >= -0.5f)) sdf = sdf_trilinear<VX, DENSE>(vol, px, py, pz, found, cache);
+    bool fast = false;
+#if ITM_RAY_SAMEBLOCK_FAST
+    if (!DENSE) {
+      // Fast path: the whole 2x2x2 neighbourhood of floor(p) lies in the block this ray already
+      // holds in its cache -> no probe is needed and the nearest voxel is one of the 8 corners, so
+      // all 8 values are fetched with independent loads in ONE round trip and serve both the
+      // nearest read and (if the value is inside the band) the trilinear re-read.
+      const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+      const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+      const int bx = floor_div8(ix), by = floor_div8(iy), bz = floor_div8(iz);
+      const int lx = ix - bx * 8, ly = iy - by * 8, lz = iz - bz * 8;
+      fast = expectBand && (bx == cache.bx && by == cache.by && bz == cache.bz && lx < 7 && ly < 7 && lz < 7);
+      if (fast) {
+        const size_t a = (size_t)(cache.base + lx + ly * 8 + lz * 64);
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = VX::load_raw_sdf(vol.vba, a + (size_t)((c & 1) + ((c >> 1) & 1) * 8 + (c >> 2) * 64));
+        const int cn = ((int)round_ref(px) - ix) | (((int)round_ref(py) - iy) << 1) | (((int)round_ref(pz) - iz) << 2);
+        float vn = v[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) if (cn == k) vn = v[k];
+        found = true;
+        sdf = VX::to_float(vn);
+        expectBand = (sdf <= 0.1f) && (sdf >= -0.5f);
+        if (expectBand) {
+          const float cx = px - fx, cy = py - fy, cz = pz - fz;
+          float r1 = (1.0f - cx) * v[0] + cx * v[1];
+          r1 = (1.0f - cy) * r1 + cy * ((1.0f - cx) * v[2] + cx * v[3]);
+          float r2 = (1.0f - cx) * v[4] + cx * v[5];
+          r2 = (1.0f - cy) * r2 + cy * ((1.0f - cx) * v[6] + cx * v[7]);
+          sdf = VX::to_float((1.0f - cz) * r1 + cz * r2);
+        }
+      }
+    }
+#endif
+    if (!fast) {
+      sdf = sdf_nearest<VX, DENSE>(vol, px, py, pz, found, cache);
+      expectBand = found && (sdf <= 0.1f) && (sdf >= -0.5f);
+      if (expectBand) sdf = sdf_trilinear<VX, DENSE>(vol, px, py, pz, found, cache);
+    }
+#endif
+#if ITM_EXP_MAXITER
+    if (++iters >= ITM_EXP_MAXITER) break;   // timing experiment only: results are wrong
 #endif
     if (!found) {
       step = (float)kBlockSide;

@@ -173,6 +173,11 @@ __global__ void __launch_bounds__(256) depth_disparity_kernel(const int16_t* raw
   out[i] = (depth > 0) ? depth : -1.0f;
 }
 
+__global__ void __launch_bounds__(256) div32767_kernel(const float* __restrict__ in, float* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = VoxelS::to_float(in[i]);
+}
+
 __global__ void __launch_bounds__(256) export_record_kernel(const int32_t* ids, const RenderCounters* rc, Mat4 M, int maxIds, int32_t* dst) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int nv = rc->noVisibleEntries;
@@ -392,6 +397,13 @@ int itm_render_state_create(const itm_scene* s, int w, int h, itm_render_state**
   return ITM_OK;
 }
 int itm_render_state_destroy(itm_render_state* r) { free_rs(r); return ITM_OK; }
+
+int itm_debug_div32767(const float* in, float* out, int n, itm_stream st) {
+  if (!in || !out || n < 0) return set_error(ITM_ERR_INVALID, "bad argument");
+  div32767_kernel<<<(n + 255) / 256, 256, 0, as_stream(st)>>>(in, out, n);
+  ITM_LAUNCH_CHECK();
+  return ITM_OK;
+}
 
 int itm_convert_depth_affine(const int16_t* raw, float* out, int w, int h, float a, float b, itm_stream st) {
   if (!raw || !out || w <= 0 || h <= 0) return set_error(ITM_ERR_INVALID, "bad argument");

@@ -9,6 +9,7 @@
 
 #include "itm_internal.h"
 #include "raycast_device.h"
+#include "raycast_sm.h"
 
 namespace itm {
 

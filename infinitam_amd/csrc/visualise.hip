@@ -25,6 +25,9 @@
 #include "shading_device.h"
 #include "wave_utils.h"
 
+#ifndef ITM_RAY_WAVE_8X8
+#define ITM_RAY_WAVE_8X8 0
+#endif
 #ifndef ITM_RAY_XCD_SWIZZLE
 #define ITM_RAY_XCD_SWIZZLE 0   // measured: no gain (L2 is cold at every kernel start), see DESIGN.md
 #endif
@@ -320,11 +323,17 @@ __global__ void __launch_bounds__(256) raycast_kernel(VolumeView vol, const floa
   const int tilesX = (p.W + 15) / 16;
   const int tx = blockIdx.x % tilesX, ty = blockIdx.x / tilesX;
 #endif
+#if ITM_RAY_WAVE_8X8
+  // one wave = one 8x8 range cell: all 64 rays share [zmin, zmax] and start at the same depth
+  const int x = tx * 16 + (wave & 1) * 8 + (lane & 7);
+  const int y = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
+#else
   const int x = tx * 16 + (lane & 15);
   const int y = ty * 16 + wave * 4 + (lane >> 4);
+#endif
   if (x >= p.W || y >= p.H) return;
   const float2 mm = range[(x >> 3) + (y >> 3) * p.W];  // floor(x/8) + floor(y/8)*W  (_CPU.cpp:174)
-  out[x + y * p.W] = cast_ray<VX, DENSE>(x, y, vol, p, mm);
+  out[x + y * p.W] = cast_ray_any<VX, DENSE>(x, y, vol, p, mm);
 }
 
 int launch_raycast(const itm_scene* s, const float* invM, const float* intr, itm_render_state* rs, float4* dst, hipStream_t st) {

@@ -58,3 +58,24 @@ def test_range_image_global_atomic_path(hip, oracle, sc):
         hip.check(hip.fn["debug_set"](1, 0), "debug_set")
     b = T.run_scenario(oracle, sc)
     T.compare_results(a, b, sc, what=sc.name + "/global-atomics")
+
+
+def test_div_by_32767_is_ieee(hip):
+    """SDF_valueToFloat of the short voxels is computed with a 3-instruction reciprocal sequence; it must
+    equal the IEEE division for every value the path can produce."""
+    rng = np.random.default_rng(3)
+    xs = np.concatenate([
+        np.arange(-32768, 32768, dtype=np.float32),                                   # every raw short
+        rng.uniform(-40000, 40000, 1 << 22).astype(np.float32),                       # trilinear blends
+        (rng.uniform(-1, 1, 1 << 20) * np.float32(2.0) ** rng.integers(-60, 20, 1 << 20)).astype(np.float32),
+        # -0.0 and +-inf are excluded: they cannot occur (raw values are shorts or convex blends of shorts) and
+        # the sequence returns +0.0 / NaN for them where the division returns -0.0 / +-inf
+        np.array([0.0, 1e-30, -1e-30, 32767.0, -32767.0, 3.4e38], np.float32),
+    ])
+    src = hip.to_backend(xs)
+    dst = T.DevBuffer(hip, xs.nbytes, np.float32, xs.shape)
+    hip.check(hip.fn["debug_div32767"](src.ptr, dst.ptr, len(xs), None), "debug_div32767")
+    got = dst.numpy()
+    want = xs / np.float32(32767.0)
+    finite = np.isfinite(want)
+    assert np.array_equal(got[finite].view(np.uint32), want[finite].view(np.uint32))
