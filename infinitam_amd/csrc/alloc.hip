@@ -73,9 +73,10 @@ __device__ inline bool make_block_ray(float d, int x, int y, const AllocParams& 
   return true;
 }
 
-__global__ void __launch_bounds__(256) mark_previous_kernel(const int32_t* __restrict__ ids, const RenderCounters* __restrict__ rc,
+__global__ void __launch_bounds__(256) mark_previous_kernel(const int32_t* __restrict__ ids, RenderCounters* __restrict__ rc,
                                                             uint8_t* __restrict__ visT) {
   const int nv = rc->noVisibleEntries;
+  if (blockIdx.x == 0 && threadIdx.x == 0) rc->noRenderingBlocks = 0;   // the range stage accumulates into it
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += gridDim.x * blockDim.x) visT[ids[i]] = 3;
 }
 
@@ -366,28 +367,41 @@ static int fill_params(const itm_scene* s, const float* M, const float* intr, in
   return ITM_OK;
 }
 
-int launch_allocate(itm_scene* s, const itm_view* v, itm_render_state* rs, bool onlyVisible, bool fuseRangeInit, hipStream_t st) {
+// Stage 1 (reads the table, writes the request keys / visible types): can overlap the previous
+// frame's integration and ray casting, which do not touch these buffers.
+int launch_request_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, bool onlyVisible, bool fuseRangeInit, hipStream_t st) {
   AllocParams p;
   int rc = fill_params(s, v->M_d, v->intr_d, v->w, v->h, rs->capIds, p);
   if (rc) return rc;
   if (p.stepBits < 4) return set_error(ITM_ERR_INVALID, "depth image too large for the allocation key");
   const int nChunks = s->numChunks;
   int2* reqCur = (int2*)s->chunkReq + (size_t)(s->frameParity & 1u) * nChunks;
-  int2* reqNext = (int2*)s->chunkReq + (size_t)((s->frameParity + 1u) & 1u) * nChunks;
-
   mark_previous_kernel<<<64, 256, 0, st>>>(rs->visibleIds, rs->counters, rs->visibleType);
   dim3 grid((v->w + 15) / 16, (v->h + 15) / 16);
+  KernelTimer tq(s, ITM_TK_REQUEST, st);
   if (onlyVisible) {
-    KernelTimer tq(s, ITM_TK_REQUEST, st);
     if (fuseRangeInit) request_kernel<true, true><<<grid, 256, 0, st>>>(v->depth, s->hash, rs->visibleType, s->allocKey, reqCur, s->counters, rs->range, rs->counters, p);
     else request_kernel<true, false><<<grid, 256, 0, st>>>(v->depth, s->hash, rs->visibleType, s->allocKey, reqCur, s->counters, rs->range, rs->counters, p);
   } else {
-    { KernelTimer tq(s, ITM_TK_REQUEST, st);
     if (fuseRangeInit) request_kernel<false, true><<<grid, 256, 0, st>>>(v->depth, s->hash, rs->visibleType, s->allocKey, reqCur, s->counters, rs->range, rs->counters, p);
-    else request_kernel<false, false><<<grid, 256, 0, st>>>(v->depth, s->hash, rs->visibleType, s->allocKey, reqCur, s->counters, rs->range, rs->counters, p); }
-    { KernelTimer ts(s, ITM_TK_ALLOC_SWEEP, st);
+    else request_kernel<false, false><<<grid, 256, 0, st>>>(v->depth, s->hash, rs->visibleType, s->allocKey, reqCur, s->counters, rs->range, rs->counters, p);
+  }
+  ITM_LAUNCH_CHECK();
+  return ITM_OK;
+}
+
+// Stage 2 (writes the table and the visible list): ordered allocation sweep + visible list.
+int launch_sweep_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, bool onlyVisible, hipStream_t st) {
+  AllocParams p;
+  int rc = fill_params(s, v->M_d, v->intr_d, v->w, v->h, rs->capIds, p);
+  if (rc) return rc;
+  const int nChunks = s->numChunks;
+  int2* reqCur = (int2*)s->chunkReq + (size_t)(s->frameParity & 1u) * nChunks;
+  int2* reqNext = (int2*)s->chunkReq + (size_t)((s->frameParity + 1u) & 1u) * nChunks;
+  if (!onlyVisible) {
+    KernelTimer ts(s, ITM_TK_ALLOC_SWEEP, st);
     allocate_sweep_kernel<<<nChunks, 256, 0, st>>>(s->allocKey, reqCur, reqNext, nChunks, s->hash, s->excessList, s->allocList,
-                                                   rs->visibleType, s->counters, s->headBits, v->depth, p); }
+                                                   rs->visibleType, s->counters, s->headBits, v->depth, p);
     s->frameParity++;
   }
   KernelTimer tv(s, ITM_TK_VISIBLE_LIST, st);
@@ -396,6 +410,12 @@ int launch_allocate(itm_scene* s, const itm_view* v, itm_render_state* rs, bool 
   visible_compact_kernel<<<nChunks, 256, 0, st>>>(rs->visibleType, s->chunkVis, nChunks, s->noTotalEntries, rs->visibleIds, rs->capIds, rs->counters);
   ITM_LAUNCH_CHECK();
   return ITM_OK;
+}
+
+int launch_allocate(itm_scene* s, const itm_view* v, itm_render_state* rs, bool onlyVisible, bool fuseRangeInit, hipStream_t st) {
+  int rc = launch_request_stage(s, v, rs, onlyVisible, fuseRangeInit, st);
+  if (rc) return rc;
+  return launch_sweep_stage(s, v, rs, onlyVisible, st);
 }
 
 int launch_find_visible(const itm_scene* s, const float* M, const float* intr, itm_render_state* rs, hipStream_t st) {

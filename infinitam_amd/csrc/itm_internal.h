@@ -139,6 +139,8 @@ inline int dispatch_voxel(int voxelType, F&& f) {
 
 // entry points implemented per translation unit
 int rebuild_head_bits(itm_scene* s, hipStream_t st);
+int launch_request_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, bool onlyVisible, bool fuseRangeInit, hipStream_t st);
+int launch_sweep_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, bool onlyVisible, hipStream_t st);
 int launch_allocate(itm_scene* s, const itm_view* v, itm_render_state* rs, bool onlyVisible, bool fuseRangeInit, hipStream_t st);
 int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipStream_t st);
 int launch_find_visible(const itm_scene* s, const float* M, const float* intr, itm_render_state* rs, hipStream_t st);

@@ -79,3 +79,17 @@ def test_div_by_32767_is_ieee(hip):
     want = xs / np.float32(32767.0)
     finite = np.isfinite(want)
     assert np.array_equal(got[finite].view(np.uint32), want[finite].view(np.uint32))
+
+
+def test_fused_and_separate_calls_interleave(hip, oracle):
+    """itm_process_frame and the four separate engine calls can be mixed on one scene."""
+    sc = Scenario(name="mix", voxelSize=0.005, frames=6, trajectory="bench")
+    ses = T.Session(hip, sc)
+    ref = T.Session(oracle, sc)
+    for k in range(6):
+        ses.frame(k, fused=(k % 2 == 0))
+        ref.frame(k, fused=False)
+    x, y = ses.snapshot(), ref.snapshot()
+    x.counters = [ses.scene.counters(ses.rs)]
+    y.counters = [ref.scene.counters(ref.rs)]
+    T.compare_results(x, y, sc, what="interleaved")
