@@ -34,6 +34,7 @@ LOCAL_BLOCKS = 0x40000
 PERIOD = 100                 # the benchmark trajectory repeats every 100 frames
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MAX_IDS = 16384              # ids per exchanged visible-block record
+EXCHANGE_BATCH = 8           # frames per all-gather (8 x 64 KB records per rank and collective)
 
 
 def parse():
@@ -93,8 +94,7 @@ def main():
     exchange = (world > 1 and not args.no_exchange) or args.force_exchange
     if exchange:
         from infinitam_amd.streams import VisibleListExchange
-        side = torch.cuda.Stream()
-        ex = VisibleListExchange(be, world, rank, MAX_IDS, device="cuda")
+        ex = VisibleListExchange(be, world, rank, MAX_IDS, device="cuda", batch=EXCHANGE_BATCH)
 
     def step(k):
         v = views[k % PERIOD]
@@ -102,16 +102,8 @@ def main():
         if rc:
             be.check(rc, "process_frame")
         if exchange:
-            # The record is produced from the device-resident visible list and all-gathered on a side
-            # stream; it overlaps the next frame's allocation/integration and is only re-joined with
-            # the frame stream before the list is rebuilt (not on the critical path).
-            side.wait_stream(stream)
-            with torch.cuda.stream(side):
-                ex.publish(rs.h, poses[k % PERIOD], side.cuda_stream)
-                copied = torch.cuda.Event()
-                copied.record(side)
-                ex.all_gather()
-            stream.wait_event(copied)   # the frame stream only waits for the 64 KB record copy
+            # record copy on the frame stream, RCCL all-gather on a side stream (off the critical path)
+            ex.step(rs.h, poses[k % PERIOD], stream)
 
     TK_RAYCAST = 5
     for k in range(args.warmup):
@@ -158,7 +150,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: synthetic 640x480 depth (sphere+wall, bench trajectory), "
                                    "hash TSDF ITMVoxel_s, 4 mm voxels, mu 0.02, 0x40000-block pool; "
                                    "allocate+integrate+expected-depths+ICP raycast per frame",
-                       "streams": world, "exchange": "rccl all_gather of visible-block records" if exchange else "none",
+                       "streams": world, "exchange": f"rccl all_gather of visible-block records, {EXCHANGE_BATCH} frames per collective" if exchange else "none",
                        "visible_blocks_last_frame": counters["noVisibleEntries"]},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }

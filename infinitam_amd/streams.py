@@ -29,14 +29,31 @@ def stream_of_rank(rank: int, world: int) -> int:
 
 
 class VisibleListExchange:
-    def __init__(self, backend, world: int, rank: int, max_ids: int = 16384, device=None):
+    """Owns two batch buffers (ping-pong) of `batch` records each and the gathered table.
+
+    GPU protocol (`step`): each frame's record is written on the FRAME stream right behind the frame's
+    kernels (a 3 us copy kernel, no cross-stream wait on the critical path).  Every `batch` frames one
+    collective moves the whole batch (fewer, larger collectives: the per-call host cost of the
+    collective, ~40 us through torch.distributed, would otherwise bound a 150 us frame) on a side
+    stream that waits for the last copy; the frame stream only ever waits for the collective that used
+    the same batch buffer two batches earlier, which has long finished."""
+
+    def __init__(self, backend, world: int, rank: int, max_ids: int = 16384, device=None, batch: int = 1):
         import torch
         self.torch = torch
-        self.be, self.world, self.rank, self.max_ids = backend, world, rank, max_ids
+        self.be, self.world, self.rank, self.max_ids, self.batch = backend, world, rank, max_ids, batch
         self.words = RECORD_HEADER + max_ids
         dev = device if device is not None else ("cuda" if backend.on_device else "cpu")
-        self.record = torch.full((self.words,), -1, dtype=torch.int32, device=dev)
-        self.gathered = torch.full((world * self.words,), -1, dtype=torch.int32, device=dev)
+        self.buffers = [torch.full((batch * self.words,), -1, dtype=torch.int32, device=dev) for _ in range(2)]
+        self.record = self.buffers[0][: self.words]
+        self.gathered = torch.full((world * batch * self.words,), -1, dtype=torch.int32, device=dev)
+        self.frame = 0
+        self._cuda = str(dev).startswith("cuda")
+        if self._cuda:
+            self.side = torch.cuda.Stream()
+            self.copied = [torch.cuda.Event(), torch.cuda.Event()]
+            self.released = [torch.cuda.Event(), torch.cuda.Event()]
+            self.in_flight = [False, False]
 
     def publish(self, render_state_handle: int, M_d, stream_ptr=None):
         """Writes this stream's record into self.record on `stream_ptr` (device side, no host sync)."""
@@ -45,16 +62,42 @@ class VisibleListExchange:
                                                  C.c_void_p(self.record.data_ptr()), C.c_void_p(stream_ptr))
         self.be.check(rc, "export_visible_record")
 
-    def all_gather(self, group=None):
+    def all_gather(self, group=None, source=None):
         import torch.distributed as dist
-        if self.world == 1:
-            self.gathered.copy_(self.record)
+        src = source if source is not None else self.buffers[0]
+        if self.world == 1 and not dist.is_initialized():
+            self.gathered.copy_(src)
         else:
-            dist.all_gather_into_tensor(self.gathered, self.record, group=group)
+            dist.all_gather_into_tensor(self.gathered, src, group=group)
+
+    def step(self, render_state_handle: int, M_d, frame_stream, group=None):
+        """One frame of the GPU protocol described above; `frame_stream` is the torch stream the frame ran on."""
+        torch = self.torch
+        slot = self.frame % self.batch
+        b = (self.frame // self.batch) & 1
+        if not self._cuda:                                   # host-memory backends (CPU tests): same schedule, synchronous
+            self.record = self.buffers[b][slot * self.words:(slot + 1) * self.words]
+            self.publish(render_state_handle, M_d, None)
+            if slot == self.batch - 1:
+                self.all_gather(group, self.buffers[b])
+            self.frame += 1
+            return
+        if slot == 0 and self.in_flight[b]:
+            frame_stream.wait_event(self.released[b])      # the collective two batches ago released this buffer
+        self.record = self.buffers[b][slot * self.words:(slot + 1) * self.words]
+        self.publish(render_state_handle, M_d, frame_stream.cuda_stream)
+        if slot == self.batch - 1:
+            self.copied[b].record(frame_stream)
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(self.copied[b])
+                self.all_gather(group, self.buffers[b])
+                self.released[b].record(self.side)
+            self.in_flight[b] = True
+        self.frame += 1
 
     def table(self) -> List[Tuple[np.ndarray, np.ndarray]]:
         """Host view of the gathered records: per stream (M_d[16] float32, visible ids int32[nv])."""
-        g = self.gathered.cpu().numpy().reshape(self.world, self.words)
+        g = self.gathered.cpu().numpy().reshape(self.world, self.batch, self.words)[:, -1, :]   # newest record of each stream
         out = []
         for r in range(self.world):
             M = g[r, :16].view(np.float32).copy()

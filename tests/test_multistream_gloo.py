@@ -30,13 +30,13 @@ def _worker(rank, world, port, q):
         ob = T.oracle_backend()
         sc = T.Scenario(name="ms", w=160, h=120, voxelSize=0.01, frames=2, stream=stream_of_rank(rank, world))
         ses = T.Session(ob, sc)
-        ex = VisibleListExchange(ob, world, rank, max_ids=2048, device="cpu")
+        ex = VisibleListExchange(ob, world, rank, max_ids=2048, device="cpu", batch=2)   # 2 frames per collective
         tables = []
         for k in range(sc.frames):
             v = ses.frame(k, fused=True)
-            ex.publish(ses.rs.h, v.M_d)
-            ex.all_gather()
-            tables.append(ex.table())
+            ex.step(ses.rs.h, v.M_d, None)
+            if k % 2 == 1:
+                tables.append(ex.table())
         nv = ses.scene.counters(ses.rs)["noVisibleEntries"]
         ids = ses.scene.download(T.BUF_VISIBLE_IDS, ses.rs)[:nv]
         q.put((rank, np.asarray(v.M_d, np.float32), ids, tables[-1]))
