@@ -29,6 +29,8 @@
 
 namespace itm {
 
+int g_debug_explicit_mark = 0;   // test hook: always run the explicit mark-previous launch
+
 struct AllocParams {
   Mat4 invM;     // inverse of M_d (host, ORUtils cofactor scheme)
   Mat4 M;        // M_d
@@ -76,16 +78,18 @@ __device__ inline bool make_block_ray(float d, int x, int y, const AllocParams& 
 __global__ void __launch_bounds__(256) mark_previous_kernel(const int32_t* __restrict__ ids, RenderCounters* __restrict__ rc,
                                                             uint8_t* __restrict__ visT) {
   const int nv = rc->noVisibleEntries;
-  if (blockIdx.x == 0 && threadIdx.x == 0) rc->noRenderingBlocks = 0;   // the range stage accumulates into it
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += gridDim.x * blockDim.x) visT[ids[i]] = 3;
 }
 
 // One workgroup = 16x16 pixels, one wave = 16x4 pixels.
-template <bool ONLY_VISIBLE, bool FUSE_RANGE_INIT>
+template <bool ONLY_VISIBLE, bool FUSE_RANGE_INIT, bool LAZY>
 __global__ void __launch_bounds__(256) request_kernel(const float* __restrict__ depth, const uint4* __restrict__ hash,
                                                       uint8_t* __restrict__ visT, uint32_t* __restrict__ allocKey,
                                                       int2* __restrict__ chunkReq, SceneCounters* __restrict__ counters,
                                                       float2* __restrict__ range, RenderCounters* __restrict__ rcnt, AllocParams p) {
+  // LAZY: instead of first marking last frame's list as type 3 (a separate launch), this frame's
+  // touches carry bit 7; visible_count_kernel then reads every other non-zero type as "3".
+  constexpr uint8_t kTouched = LAZY ? 0x80 : 0x00;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (FUSE_RANGE_INIT && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) rcnt->noRenderingBlocks = 0;
   const int x = blockIdx.x * 16 + (lane & 15);
@@ -105,7 +109,7 @@ __global__ void __launch_bounds__(256) request_kernel(const float* __restrict__ 
     HashEntry he = unpack_entry(hash[idx]);
     bool found = false;
     if (he.px == bx && he.py == by && he.pz == bz && he.ptr >= -1) {
-      visT[idx] = (he.ptr == -1) ? 2 : 1;
+      visT[idx] = ((he.ptr == -1) ? 2 : 1) | kTouched;
       found = true;
     }
     if (!found) {
@@ -115,7 +119,7 @@ __global__ void __launch_bounds__(256) request_kernel(const float* __restrict__ 
           idx = p.bucketNum + he.offset - 1;
           he = unpack_entry(hash[idx]);
           if (he.px == bx && he.py == by && he.pz == bz && he.ptr >= -1) {
-            visT[idx] = (he.ptr == -1) ? 2 : 1;
+            visT[idx] = ((he.ptr == -1) ? 2 : 1) | kTouched;
             found = true;
             break;
           }
@@ -123,7 +127,7 @@ __global__ void __launch_bounds__(256) request_kernel(const float* __restrict__ 
         isExcess = true;
       }
       if (!found) {
-        if (!isExcess) visT[idx] = 1;
+        if (!isExcess) visT[idx] = 1 | kTouched;
         if (!ONLY_VISIBLE) {
           const uint32_t key = (((uint32_t)loc << p.stepBits) | (uint32_t)i) + 1u;
           const uint32_t old = atomicMax(&allocKey[idx], key);
@@ -158,7 +162,7 @@ __global__ void __launch_bounds__(256) allocate_sweep_kernel(uint32_t* __restric
                                                              int2* __restrict__ chunkReqNext, int numChunks, uint4* __restrict__ hash,
                                                              const int32_t* __restrict__ excessList, const int32_t* __restrict__ allocList,
                                                              uint8_t* __restrict__ visT, const SceneCounters* __restrict__ counters,
-                                                             uint32_t* __restrict__ headBits, const float* __restrict__ depth, AllocParams p) {
+                                                             uint32_t* __restrict__ headBits, const float* __restrict__ depth, int lazy, AllocParams p) {
   __shared__ int lds[8];
   const int chunk = blockIdx.x;
   const int tid = threadIdx.x;
@@ -207,7 +211,7 @@ __global__ void __launch_bounds__(256) allocate_sweep_kernel(uint32_t* __restric
         const int off = excessList[exlIdx];
         ((uint32_t*)&hash[slot])[2] = (uint32_t)(off + 1);                 // connect the chain tail to the child
         hash[p.bucketNum + off] = pack_entry(bx, by, bz, 0, allocList[vbaIdx]);
-        visT[p.bucketNum + off] = 1;
+        visT[p.bucketNum + off] = lazy ? 0x81 : 1;
       }
     } else if (vbaIdx >= 0) {
       int bx, by, bz;
@@ -247,7 +251,7 @@ __device__ inline bool block_in_frustum(int bx, int by, int bz, const Mat4& M, f
 
 // Pass 1 of the visible list (_CPU.cpp:229-269): re-test type-3 slots, count visible slots per
 // chunk.  Workgroup 0 also commits the pool counters of the allocation sweep (:287-290).
-template <bool COMMIT_ALLOC>
+template <bool COMMIT_ALLOC, bool LAZY>
 __global__ void __launch_bounds__(256) visible_count_kernel(uint8_t* __restrict__ visT, const uint4* __restrict__ hash,
                                                             int32_t* __restrict__ chunkVis, const int2* __restrict__ chunkReq,
                                                             int numChunks, SceneCounters* __restrict__ counters, AllocParams p) {
@@ -263,13 +267,15 @@ __global__ void __launch_bounds__(256) visible_count_kernel(uint8_t* __restrict_
 #pragma unroll
       for (int k = 0; k < kSlotsPerThread; ++k) {
         uint32_t t = (w[k >> 2] >> ((k & 3) * 8)) & 0xffu;
-        if (t == 3u) {
+        const uint32_t t0 = t;
+        if (LAZY && (t & 0x80u)) {
+          t &= 0x7fu;                         // touched this frame: type 1 / 2
+        } else if (LAZY ? (t != 0u) : (t == 3u)) {
+          // visible in the previous frame and not seen again: keep only if still in the frustum
           HashEntry he = unpack_entry(hash[slot0 + k]);
-          if (!block_in_frustum(he.px, he.py, he.pz, p.M, p.fx, p.fy, p.cx, p.cy, p.voxelSize, p.W, p.H)) {
-            w[k >> 2] &= ~(0xffu << ((k & 3) * 8));
-            t = 0; changed = true;
-          }
+          t = block_in_frustum(he.px, he.py, he.pz, p.M, p.fx, p.fy, p.cx, p.cy, p.voxelSize, p.W, p.H) ? 3u : 0u;
         }
+        if (t != t0) { w[k >> 2] = (w[k >> 2] & ~(0xffu << ((k & 3) * 8))) | (t << ((k & 3) * 8)); changed = true; }
         n += (t > 0u);
       }
       if (changed) *(uint2*)(visT + slot0) = make_uint2(w[0], w[1]);
@@ -369,6 +375,9 @@ static int fill_params(const itm_scene* s, const float* M, const float* intr, in
 
 // Stage 1 (reads the table, writes the request keys / visible types): can overlap the previous
 // frame's integration and ray casting, which do not touch these buffers.
+// Stage 1: per-pixel block requests.  When the visible list and the visible types are known to be
+// coherent (always, unless the caller rewrote one of them) the "mark previous list as type 3" launch is
+// skipped and folded into the type encoding (LAZY, see request_kernel).
 int launch_request_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, bool onlyVisible, bool fuseRangeInit, hipStream_t st) {
   AllocParams p;
   int rc = fill_params(s, v->M_d, v->intr_d, v->w, v->h, rs->capIds, p);
@@ -376,16 +385,20 @@ int launch_request_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, 
   if (p.stepBits < 4) return set_error(ITM_ERR_INVALID, "depth image too large for the allocation key");
   const int nChunks = s->numChunks;
   int2* reqCur = (int2*)s->chunkReq + (size_t)(s->frameParity & 1u) * nChunks;
-  mark_previous_kernel<<<64, 256, 0, st>>>(rs->visibleIds, rs->counters, rs->visibleType);
+  const bool lazy = rs->listCoherent && !g_debug_explicit_mark;
+  rs->lazyThisFrame = lazy;
+  if (!lazy) mark_previous_kernel<<<64, 256, 0, st>>>(rs->visibleIds, rs->counters, rs->visibleType);
   dim3 grid((v->w + 15) / 16, (v->h + 15) / 16);
   KernelTimer tq(s, ITM_TK_REQUEST, st);
+#define ITM_REQ(OV, FU, LZ) request_kernel<OV, FU, LZ><<<grid, 256, 0, st>>>(v->depth, s->hash, rs->visibleType, s->allocKey, reqCur, s->counters, rs->range, rs->counters, p)
   if (onlyVisible) {
-    if (fuseRangeInit) request_kernel<true, true><<<grid, 256, 0, st>>>(v->depth, s->hash, rs->visibleType, s->allocKey, reqCur, s->counters, rs->range, rs->counters, p);
-    else request_kernel<true, false><<<grid, 256, 0, st>>>(v->depth, s->hash, rs->visibleType, s->allocKey, reqCur, s->counters, rs->range, rs->counters, p);
+    if (fuseRangeInit) { if (lazy) ITM_REQ(true, true, true); else ITM_REQ(true, true, false); }
+    else { if (lazy) ITM_REQ(true, false, true); else ITM_REQ(true, false, false); }
   } else {
-    if (fuseRangeInit) request_kernel<false, true><<<grid, 256, 0, st>>>(v->depth, s->hash, rs->visibleType, s->allocKey, reqCur, s->counters, rs->range, rs->counters, p);
-    else request_kernel<false, false><<<grid, 256, 0, st>>>(v->depth, s->hash, rs->visibleType, s->allocKey, reqCur, s->counters, rs->range, rs->counters, p);
+    if (fuseRangeInit) { if (lazy) ITM_REQ(false, true, true); else ITM_REQ(false, true, false); }
+    else { if (lazy) ITM_REQ(false, false, true); else ITM_REQ(false, false, false); }
   }
+#undef ITM_REQ
   ITM_LAUNCH_CHECK();
   return ITM_OK;
 }
@@ -398,17 +411,21 @@ int launch_sweep_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, bo
   const int nChunks = s->numChunks;
   int2* reqCur = (int2*)s->chunkReq + (size_t)(s->frameParity & 1u) * nChunks;
   int2* reqNext = (int2*)s->chunkReq + (size_t)((s->frameParity + 1u) & 1u) * nChunks;
+  const bool lazy = rs->lazyThisFrame;
   if (!onlyVisible) {
     KernelTimer ts(s, ITM_TK_ALLOC_SWEEP, st);
     allocate_sweep_kernel<<<nChunks, 256, 0, st>>>(s->allocKey, reqCur, reqNext, nChunks, s->hash, s->excessList, s->allocList,
-                                                   rs->visibleType, s->counters, s->headBits, v->depth, p);
+                                                   rs->visibleType, s->counters, s->headBits, v->depth, lazy ? 1 : 0, p);
     s->frameParity++;
   }
   KernelTimer tv(s, ITM_TK_VISIBLE_LIST, st);
-  if (onlyVisible) visible_count_kernel<false><<<nChunks, 256, 0, st>>>(rs->visibleType, s->hash, s->chunkVis, reqCur, nChunks, s->counters, p);
-  else visible_count_kernel<true><<<nChunks, 256, 0, st>>>(rs->visibleType, s->hash, s->chunkVis, reqCur, nChunks, s->counters, p);
+#define ITM_CNT(CM, LZ) visible_count_kernel<CM, LZ><<<nChunks, 256, 0, st>>>(rs->visibleType, s->hash, s->chunkVis, reqCur, nChunks, s->counters, p)
+  if (onlyVisible) { if (lazy) ITM_CNT(false, true); else ITM_CNT(false, false); }
+  else { if (lazy) ITM_CNT(true, true); else ITM_CNT(true, false); }
+#undef ITM_CNT
   visible_compact_kernel<<<nChunks, 256, 0, st>>>(rs->visibleType, s->chunkVis, nChunks, s->noTotalEntries, rs->visibleIds, rs->capIds, rs->counters);
   ITM_LAUNCH_CHECK();
+  rs->listCoherent = true;   // list == non-zero visible types again
   return ITM_OK;
 }
 
@@ -430,6 +447,7 @@ int launch_find_visible(const itm_scene* s, const float* M, const float* intr, i
   visible_compact_kernel<<<nChunks, 256, 0, st>>>(flags, s->chunkVis, nChunks, s->noTotalEntries, rs->visibleIds, rs->capIds, rs->counters);
   clear_keys_kernel<<<512, 256, 0, st>>>(s->allocKey, (s->noTotalEntries + 3) / 4);
   ITM_LAUNCH_CHECK();
+  rs->listCoherent = false;   // the list no longer mirrors entriesVisibleType
   return ITM_OK;
 }
 

@@ -76,6 +76,10 @@ struct itm_render_state {
   int w = 0, h = 0;
   bool hash = false;
   int capIds = 0;
+  // true while visibleEntryIDs holds exactly the slots with a non-zero entriesVisibleType (the state
+  // AllocateSceneFromDepth leaves behind); lets the next allocation skip the mark-previous launch
+  bool listCoherent = true;
+  bool lazyThisFrame = false;
   float2* range = nullptr;     // renderingRangeImage  Vector2f[h*w]
   float4* raycast = nullptr;   // raycastResult        Vector4f[h*w]
   float4* fwdProj = nullptr;   // forwardProjection    Vector4f[h*w]
@@ -138,6 +142,7 @@ inline int dispatch_voxel(int voxelType, F&& f) {
 }
 
 // entry points implemented per translation unit
+extern int g_debug_explicit_mark;
 int rebuild_head_bits(itm_scene* s, hipStream_t st);
 int launch_request_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, bool onlyVisible, bool fuseRangeInit, hipStream_t st);
 int launch_sweep_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, bool onlyVisible, hipStream_t st);

@@ -472,6 +472,7 @@ int itm_set_counters(itm_scene* s, itm_render_state* rs, const itm_counters* in,
     ITM_HIP(hipMemcpyAsync(&rc, rs->counters, sizeof rc, hipMemcpyDeviceToHost, st));
     ITM_HIP(hipStreamSynchronize(st));
     rc.noVisibleEntries = in->noVisibleEntries;
+    rs->listCoherent = false;
     ITM_HIP(hipMemcpyAsync(rs->counters, &rc, sizeof rc, hipMemcpyHostToDevice, st));
     ITM_HIP(hipStreamSynchronize(st));
   }
@@ -499,6 +500,7 @@ int itm_upload(itm_scene* s, itm_render_state* rs, int which, const void* src, s
   hipStream_t st = as_stream(stream);
   ITM_HIP(hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, st));
   if (which == ITM_BUF_HASH_ENTRIES) { int rc = rebuild_head_bits(s, st); if (rc) return rc; }
+  if (rs && (which == ITM_BUF_VISIBLE_IDS || which == ITM_BUF_VISIBLE_TYPE)) rs->listCoherent = false;
   ITM_HIP(hipStreamSynchronize(st));
   return ITM_OK;
 }

@@ -451,6 +451,7 @@ extern "C" {
 
 int itm_debug_set(int key, int value) {
   if (key == ITM_DEBUG_FORCE_GLOBAL_RANGE_ATOMICS) { g_debug_force_global_range = value; return ITM_OK; }
+  if (key == ITM_DEBUG_EXPLICIT_MARK_PREVIOUS) { g_debug_explicit_mark = value; return ITM_OK; }
   return set_error(ITM_ERR_INVALID, "unknown debug key");
 }
 

@@ -93,3 +93,36 @@ def test_fused_and_separate_calls_interleave(hip, oracle):
     x.counters = [ses.scene.counters(ses.rs)]
     y.counters = [ref.scene.counters(ref.rs)]
     T.compare_results(x, y, sc, what="interleaved")
+
+
+def test_explicit_mark_previous_path(hip, oracle):
+    """The allocation normally folds "mark last frame's list as type 3" into the type encoding; the explicit
+    launch (used after FindVisibleBlocks / uploads on the same render state) must give the same scene."""
+    sc = Scenario(name="explicit_mark", voxelSize=0.005, frames=4, trajectory="bench")
+    hip.check(hip.fn["debug_set"](2, 1), "debug_set")
+    try:
+        a = T.run_scenario(hip, sc)
+    finally:
+        hip.check(hip.fn["debug_set"](2, 0), "debug_set")
+    T.compare_results(a, T.run_scenario(oracle, sc), sc, what="explicit mark")
+
+
+def test_find_visible_blocks_then_allocate_on_same_render_state(hip, oracle):
+    """FindVisibleBlocks rewrites the list but not the types (reference behaviour); the next allocation on
+    that render state must still match the oracle."""
+    sc = Scenario(name="fvb_then_alloc", w=160, h=120, voxelSize=0.01, frames=2)
+    res = []
+    for be in (hip, oracle):
+        ses = T.Session(be, sc)
+        ses.frame(0)
+        v1 = ses.view(1)
+        ses.scene.vis.FindVisibleBlocks(T.synth.pose_matrix((0.2, 0.0, 0.0)), sc.intr(), ses.rs)
+        ses.scene.reco.AllocateSceneFromDepth(v1, ses.rs)
+        ses.scene.reco.IntegrateIntoScene(v1, ses.rs)
+        ses.scene.vis.CreateExpectedDepths(v1.M_d, v1.intr_d, ses.rs)
+        ses.scene.vis.CreateICPMaps(v1, ses.rs, ses.points, ses.normals)
+        snap = ses.snapshot()
+        snap.counters = [ses.scene.counters(ses.rs)]
+        res.append(snap)
+        ses.close()
+    T.compare_results(res[0], res[1], sc, what="find-visible then allocate")
