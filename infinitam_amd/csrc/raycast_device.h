@@ -11,6 +11,9 @@
 #ifndef ITM_RAY_SAMEBLOCK_FAST
 #define ITM_RAY_SAMEBLOCK_FAST 0
 #endif
+#ifndef ITM_RAY_PREDICT_BAND
+#define ITM_RAY_PREDICT_BAND 0
+#endif
 #ifndef ITM_EXP_SIMPLE_TRILINEAR
 #define ITM_EXP_SIMPLE_TRILINEAR 0
 #endif
@@ -290,11 +293,36 @@ __device__ inline float4 cast_ray(int x, int y, const VolumeView& vol, const Ray
       }
     }
 #endif
+#if ITM_RAY_PREDICT_BAND
+    if (!fast) {
+      // A step inside the band is usually followed by another one: then fetch the 2x2x2 neighbourhood
+      // straight away (the nearest voxel is one of its corners) instead of nearest -> trilinear, which
+      // saves one dependent round trip per step for rays that graze the surface (the tail of the kernel).
+      bool corners = expectBand;
+      bool inBand = false;
+      if (!corners) {
+        sdf = sdf_nearest<VX, DENSE>(vol, px, py, pz, found, cache);
+        inBand = found && (sdf <= 0.1f) && (sdf >= -0.5f);
+        corners = inBand;
+      }
+      if (corners) {
+        Corners<VX, DENSE> cn;
+        cn.fetch(vol, px, py, pz, cache);
+        if (expectBand) {
+          sdf = cn.nearest(px, py, pz, found);
+          inBand = found && (sdf <= 0.1f) && (sdf >= -0.5f);
+        }
+        if (inBand) sdf = cn.trilinear();
+      }
+      expectBand = inBand;
+    }
+#else
     if (!fast) {
       sdf = sdf_nearest<VX, DENSE>(vol, px, py, pz, found, cache);
       expectBand = found && (sdf <= 0.1f) && (sdf >= -0.5f);
       if (expectBand) sdf = sdf_trilinear<VX, DENSE>(vol, px, py, pz, found, cache);
     }
+#endif
 #endif
 #if ITM_EXP_MAXITER
     if (++iters >= ITM_EXP_MAXITER) break;   // timing experiment only: results are wrong

@@ -34,6 +34,22 @@ SCENARIOS = [
 ]
 
 
+# BASELINE.json configurations at full size (oracle: seconds per frame)
+FULL_SIZE = [
+    Scenario(name="config2_hash_4mm_pool40000", voxelSize=0.004, frames=3, trajectory="bench", localBlockNum=0x40000),
+    Scenario(name="config5_1280x960_f_rgb_2mm", w=1280, h=960, voxelType=T.VOXEL_F_RGB, colour=True, voxelSize=0.002,
+             frames=2, localBlockNum=0x40000),
+]
+
+
+@pytest.mark.parametrize("sc", FULL_SIZE, ids=lambda s: s.name)
+def test_baseline_configs_full_size(hip, oracle, sc):
+    a = T.run_scenario(hip, sc, fused=True)
+    b = T.run_scenario(oracle, sc)
+    T.compare_results(a, b, sc)
+    assert a.counters[-1]["statusFlags"] == 0
+
+
 @pytest.mark.parametrize("sc", SCENARIOS, ids=lambda s: s.name)
 def test_engine_calls_match_oracle(hip, oracle, sc):
     a = T.run_scenario(hip, sc)
