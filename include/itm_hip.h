@@ -168,6 +168,9 @@ int ITM_FN(debug_set)(int key, int value);
 /* out[i] = SDF_valueToFloat(in[i]) of the short voxel types, i.e. in[i] / 32767.0f, through the same
  * device routine the kernels use (a 3-instruction correctly rounded division; test hook). */
 int ITM_FN(debug_div32767)(const float* in, float* out, int n, itm_stream stream);
+/* out[i] = a[i] / b[i] through the reduced division sequences of the integration kernel (mode 1: shared
+ * refined reciprocal; 2: small-integer divisor; 3: the refined reciprocal of b; 4: reciprocal given in r). */
+int ITM_FN(debug_divide)(int mode, const float* a, const float* b, const float* r, float* out, int n, itm_stream stream);
 
 /* ---- scene -------------------------------------------------------------------------------- */
 /* new ITMScene<TVoxel,TIndex>(sceneParams,false,memType)  Objects/ITMScene.h:37-43 ; also

@@ -151,6 +151,7 @@ _SIGS = {
     "buffer_ptr": (_P, [_P, _P, C.c_int]),
     "debug_set": (C.c_int, [C.c_int, C.c_int]),
     "debug_div32767": (C.c_int, [_P, _P, C.c_int, _P]),
+    "debug_divide": (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_int, _P]),
     "profile_enable": (C.c_int, [_P, C.c_uint32]),
     "profile_read": (C.c_int, [_P, C.POINTER(Profile), C.c_int]),
     "export_visible_record": (C.c_int, [_P, C.POINTER(C.c_float), C.c_int, _P, _P]),

@@ -23,6 +23,8 @@ struct FuseParams {
   float fx, fy, cx, cy;
   float fxc, fyc, cxc, cyc;
   float mu, voxelSize;
+  float rcpMu;      // RN(1/mu), computed on the host
+  int muFast;       // 1: eta/mu may use the 3-instruction reciprocal division (host-checked)
   int maxW;
   int W, H, Wc, Hc;
   int stopAtMax;
@@ -35,8 +37,26 @@ __device__ inline float fuse_depth(typename VX::Reg& r, float mx, float my, floa
                                    const FuseParams& p, bool& touched) {
   Vec3 pc = transform_point(p.M_d, mx, my, mz);
   if (pc.z <= 0) return -1;
-  const float u = p.fx * pc.x / pc.z + p.cx;
-  const float v = p.fy * pc.y / pc.z + p.cy;
+  const float tx = p.fx * pc.x, ty = p.fy * pc.y;
+#if ITM_FAST_DIVISIONS
+  // Conservative early-out before the two divisions: the voxel is rejected below when
+  // u = tx/z + cx is outside [1, W-2]; half a pixel of margin dwarfs every rounding error, so this
+  // never rejects a voxel the exact test would keep (most voxels of a dense volume leave here).
+  if (tx < (0.5f - p.cx) * pc.z || tx > ((float)(p.W - 2) + 0.5f - p.cx) * pc.z ||
+      ty < (0.5f - p.cy) * pc.z || ty > ((float)(p.H - 2) + 0.5f - p.cy) * pc.z) return -1;
+  float u, v;
+  if (pc.z >= 1e-4f && pc.z <= 1e4f) {       // normal range: shared refined reciprocal, exact quotients
+    const float rz = refined_rcp(pc.z);
+    u = div_by_rcp(tx, pc.z, rz) + p.cx;
+    v = div_by_rcp(ty, pc.z, rz) + p.cy;
+  } else {
+    u = tx / pc.z + p.cx;
+    v = ty / pc.z + p.cy;
+  }
+#else
+  const float u = tx / pc.z + p.cx;
+  const float v = ty / pc.z + p.cy;
+#endif
   if ((u < 1) || (u > p.W - 2) || (v < 1) || (v > p.H - 2)) return -1;
   const float dm = depth[(int)(u + 0.5f) + (int)(v + 0.5f) * p.W];
   if (dm <= 0.0f) return -1;
@@ -44,12 +64,25 @@ __device__ inline float fuse_depth(typename VX::Reg& r, float mx, float my, floa
   if (eta < -p.mu) return eta;
   const float oldF = VX::to_float(VX::raw_sdf(r));
   const int oldW = VX::w_depth(r);
+#if ITM_FAST_DIVISIONS
+  float newF = p.muFast ? div_markstein(eta, p.mu, p.rcpMu) : eta / p.mu;
+#else
   float newF = eta / p.mu;
+#endif
   newF = (1.0f < newF) ? 1.0f : newF;
   int newW = 1;
   newF = (float)oldW * oldF + (float)newW * newF;
   newW = oldW + newW;
+#if ITM_FAST_DIVISIONS
+  {
+    // newW is an integer in [1, 256]: the refined reciprocal equals RN(1/newW) for all of them (tested),
+    // its significand is never all ones, so the 3-instruction quotient is the correctly rounded one
+    const float w = (float)newW;
+    newF = div_markstein(newF, w, refined_rcp(w));
+  }
+#else
   newF /= (float)newW;
+#endif
   newW = (newW < p.maxW) ? newW : p.maxW;
   r = VX::with_depth(r, newF, newW);
   touched = true;
@@ -148,20 +181,23 @@ __global__ void __launch_bounds__(256) integrate_dense_kernel(void* __restrict__
 }
 
 // Dense volume of ITMVoxel_s with sx % 4 == 0: 4 voxels (16 B) per lane, one 1 KiB row segment per
-// wave instruction; a group is written back only if one of its voxels changed.
+// wave instruction; a group is written back only if one of its voxels changed.  blockIdx.y = z slice,
+// blockIdx.x splits the (y, x/4) plane; no 64-bit index division in the loop, two 16-byte loads in
+// flight per lane.
+template <bool POW2>
 __global__ void __launch_bounds__(256) integrate_dense_s_x4_kernel(uint4* __restrict__ vba, const float* __restrict__ depth, FuseParams p,
-                                                                   int sx, int sy, int sz, int ox, int oy, int oz) {
+                                                                   int sx, int sy, int sz, int ox, int oy, int oz, int log2sx4) {
   const int sx4 = sx >> 2;
-  const size_t n4 = (size_t)sx4 * sy * sz;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < n4; g += stride) {
-    const int z = (int)(g / ((size_t)sx4 * sy));
-    const int rem = (int)(g - (size_t)z * sx4 * sy);
-    const int y = rem / sx4;
-    const int x0 = (rem - y * sx4) * 4;
-    uint4 q = vba[g];
+  const int z = blockIdx.y;
+  const int plane = sx4 * sy;                       // groups per z slice
+  uint4* __restrict__ slice = vba + (size_t)z * plane;
+  const float mz = (float)(z + oz) * p.voxelSize;
+  const int stride = gridDim.x * 256;
+  auto process = [&](int idx, uint4 q) {
+    const int y = POW2 ? (idx >> log2sx4) : (idx / sx4);
+    const int x0 = (POW2 ? (idx & (sx4 - 1)) : (idx - y * sx4)) * 4;
     uint32_t v[4] = {q.x, q.y, q.z, q.w};
-    const float my = (float)(y + oy) * p.voxelSize, mz = (float)(z + oz) * p.voxelSize;
+    const float my = (float)(y + oy) * p.voxelSize;
     bool any = false;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -171,8 +207,38 @@ __global__ void __launch_bounds__(256) integrate_dense_s_x4_kernel(uint4* __rest
       fuse_depth<VoxelS>(v[k], mx, my, mz, depth, p, touched);
       any |= touched;
     }
-    if (any) vba[g] = make_uint4(v[0], v[1], v[2], v[3]);
+    if (any) slice[idx] = make_uint4(v[0], v[1], v[2], v[3]);
+  };
+  // Conservative cull of a whole 4-voxel group BEFORE its 16 bytes are fetched: camera-space
+  // coordinates are affine along x, so if both end voxels of the group lie outside the same frustum
+  // plane (with half a pixel of margin, as in fuse_depth) every voxel of the group is rejected by the
+  // exact per-voxel test as well.  ~70 % of a 512^3 volume around the camera is culled this way.
+  auto culled = [&](int idx) {
+    const int y = POW2 ? (idx >> log2sx4) : (idx / sx4);
+    const int x0 = (POW2 ? (idx & (sx4 - 1)) : (idx - y * sx4)) * 4;
+    const float my = (float)(y + oy) * p.voxelSize;
+    const Vec3 a = transform_point(p.M_d, (float)(x0 + ox) * p.voxelSize, my, mz);
+    const Vec3 b = transform_point(p.M_d, (float)(x0 + 3 + ox) * p.voxelSize, my, mz);
+    const float lox = 0.5f - p.cx, hix = (float)(p.W - 2) + 0.5f - p.cx;
+    const float loy = 0.5f - p.cy, hiy = (float)(p.H - 2) + 0.5f - p.cy;
+    const float eps = 1e-3f * p.voxelSize;                 // margin on the z <= 0 plane
+    const float atx = p.fx * a.x, aty = p.fy * a.y, btx = p.fx * b.x, bty = p.fy * b.y;
+    // the four side planes are only meaningful for points in front of the camera
+    const bool front = (a.z > eps) && (b.z > eps);
+    return ((a.z < -eps) && (b.z < -eps)) ||
+           (front && (((atx < lox * a.z) && (btx < lox * b.z)) || ((atx > hix * a.z) && (btx > hix * b.z)) ||
+                      ((aty < loy * a.z) && (bty < loy * b.z)) || ((aty > hiy * a.z) && (bty > hiy * b.z))));
+  };
+  int idx = blockIdx.x * 256 + threadIdx.x;
+  for (; idx + stride < plane; idx += 2 * stride) {
+    const bool c0 = culled(idx), c1 = culled(idx + stride);
+    uint4 q0, q1;
+    if (!c0) q0 = slice[idx];
+    if (!c1) q1 = slice[idx + stride];
+    if (!c0) process(idx, q0);
+    if (!c1) process(idx + stride, q1);
   }
+  if (idx < plane && !culled(idx)) process(idx, slice[idx]);
 }
 
 int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipStream_t st) {
@@ -182,6 +248,13 @@ int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipS
   p.fx = v->intr_d[0]; p.fy = v->intr_d[1]; p.cx = v->intr_d[2]; p.cy = v->intr_d[3];
   p.fxc = v->intr_rgb[0]; p.fyc = v->intr_rgb[1]; p.cxc = v->intr_rgb[2]; p.cyc = v->intr_rgb[3];
   p.mu = s->prm.mu; p.voxelSize = s->prm.voxelSize; p.maxW = s->prm.maxW;
+  {
+    // 1/mu correctly rounded (host division); the fast quotient needs a normal mu whose significand is
+    // not all ones and a magnitude that keeps eta/mu far from overflow/underflow
+    p.rcpMu = 1.0f / p.mu;
+    uint32_t bits; memcpy(&bits, &p.mu, 4);
+    p.muFast = ((bits & 0x7fffffu) != 0x7fffffu) && p.mu >= 1e-6f && p.mu <= 1e6f;
+  }
   p.W = v->w; p.H = v->h; p.Wc = v->w_rgb; p.Hc = v->h_rgb;
   p.stopAtMax = s->prm.stopIntegratingAtMaxW;
   const uchar4* rgb = (const uchar4*)v->rgb;
@@ -200,7 +273,16 @@ int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipS
   } else {
     const int* sz = s->cfg.denseSize; const int* of = s->cfg.denseOffset;
     if (s->cfg.voxelType == ITM_VOXEL_S && (sz[0] % 4) == 0) {
-      integrate_dense_s_x4_kernel<<<256 * 32, 256, 0, st>>>((uint4*)s->vba, v->depth, p, sz[0], sz[1], sz[2], of[0], of[1], of[2]);
+      const int sx4 = sz[0] / 4;
+      int lg = 0; while ((1 << lg) < sx4) ++lg;
+      const bool pow2 = (1 << lg) == sx4;
+      const int plane = sx4 * sz[1];
+      int splits = (plane + 2 * 256 - 1) / (2 * 256);        // every lane gets ~2 groups per pass
+      if (splits > 64) splits = 64;
+      if (splits < 1) splits = 1;
+      const dim3 grid(splits, sz[2]);
+      if (pow2) integrate_dense_s_x4_kernel<true><<<grid, 256, 0, st>>>((uint4*)s->vba, v->depth, p, sz[0], sz[1], sz[2], of[0], of[1], of[2], lg);
+      else integrate_dense_s_x4_kernel<false><<<grid, 256, 0, st>>>((uint4*)s->vba, v->depth, p, sz[0], sz[1], sz[2], of[0], of[1], of[2], lg);
     } else {
       int rc = dispatch_voxel(s->cfg.voxelType, [&](auto vx) {
         using VX = decltype(vx);

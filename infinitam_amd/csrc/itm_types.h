@@ -65,6 +65,37 @@ __device__ inline float div_by_32767(float x) {
 #endif
 }
 
+// ---- correctly rounded divisions without the IEEE division macro ---------------------------------
+// hipcc lowers a/b (f32, IEEE) to v_div_scale x2, v_rcp, five FMAs, v_div_fmas, v_div_fixup.  The scale /
+// fixup steps only act on denormal, huge or special operands; for operands in a normal range the result is
+// exactly the FMA chain below, so replaying that chain gives bit-identical quotients with fewer
+// instructions, and a refined reciprocal can be shared by several divisions by the same denominator.
+//   r  = rcp(b);  r = r + r*(1 - b*r)                      (refined reciprocal, 3 instructions)
+//   q  = a*r;  q = q + r*(a - b*q);  q = q + r*(a - b*q)   (5 instructions per quotient)
+// Callers guarantee b is a normal number well inside the exponent range (guards at the call sites);
+// tests/test_hip_parity.py::test_fast_divisions_are_ieee compares all helpers with the true division.
+#ifndef ITM_FAST_DIVISIONS
+#define ITM_FAST_DIVISIONS 1
+#endif
+__device__ inline float refined_rcp(float b) {
+  const float r = __builtin_amdgcn_rcpf(b);
+  const float e = __builtin_fmaf(-b, r, 1.0f);
+  return __builtin_fmaf(e, r, r);
+}
+__device__ inline float div_by_rcp(float a, float b, float r) {
+  float q = a * r;
+  float e = __builtin_fmaf(-b, q, a);
+  q = __builtin_fmaf(e, r, q);
+  e = __builtin_fmaf(-b, q, a);
+  return __builtin_fmaf(e, r, q);
+}
+// a / b when r == RN(1/b) exactly and the significand of b is not all ones (Markstein): 3 instructions
+__device__ inline float div_markstein(float a, float b, float r) {
+  const float q = a * r;
+  const float e = __builtin_fmaf(-q, b, a);
+  return __builtin_fmaf(e, r, q);
+}
+
 // ---- voxel codecs ---------------------------------------------------------------------------
 // Each codec describes one ITMVoxel_* layout through a register image (`Reg`) that is moved with
 // the widest aligned access the layout allows, and decoded/encoded field-wise.

@@ -177,6 +177,18 @@ __global__ void __launch_bounds__(256) div32767_kernel(const float* __restrict__
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = VoxelS::to_float(in[i]);
 }
+// mode 1: a/b through the shared-reciprocal chain; mode 2: a/b with b a small integer through the
+// refined reciprocal + 3-instruction quotient; mode 3: the refined reciprocal itself; mode 4: a/b with a
+// host-rounded reciprocal in r (division by a constant)
+__global__ void __launch_bounds__(256) divide_kernel(int mode, const float* __restrict__ a, const float* __restrict__ b,
+                                                     const float* __restrict__ r, float* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (mode == 1) out[i] = div_by_rcp(a[i], b[i], refined_rcp(b[i]));
+  else if (mode == 2) out[i] = div_markstein(a[i], b[i], refined_rcp(b[i]));
+  else if (mode == 3) out[i] = refined_rcp(b[i]);
+  else out[i] = div_markstein(a[i], b[i], r[i]);
+}
 
 __global__ void __launch_bounds__(256) export_record_kernel(const int32_t* ids, const RenderCounters* rc, Mat4 M, int maxIds, int32_t* dst) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -401,6 +413,13 @@ int itm_render_state_destroy(itm_render_state* r) { free_rs(r); return ITM_OK; }
 int itm_debug_div32767(const float* in, float* out, int n, itm_stream st) {
   if (!in || !out || n < 0) return set_error(ITM_ERR_INVALID, "bad argument");
   div32767_kernel<<<(n + 255) / 256, 256, 0, as_stream(st)>>>(in, out, n);
+  ITM_LAUNCH_CHECK();
+  return ITM_OK;
+}
+
+int itm_debug_divide(int mode, const float* a, const float* b, const float* r, float* out, int n, itm_stream st) {
+  if (!a || !b || !out || n < 0 || mode < 1 || mode > 4 || (mode == 4 && !r)) return set_error(ITM_ERR_INVALID, "bad argument");
+  divide_kernel<<<(n + 255) / 256, 256, 0, as_stream(st)>>>(mode, a, b, r, out, n);
   ITM_LAUNCH_CHECK();
   return ITM_OK;
 }

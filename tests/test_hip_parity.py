@@ -142,3 +142,40 @@ def test_find_visible_blocks_then_allocate_on_same_render_state(hip, oracle):
         res.append(snap)
         ses.close()
     T.compare_results(res[0], res[1], sc, what="find-visible then allocate")
+
+
+def _divide(hip, mode, a, b, r=None):
+    da, db = hip.to_backend(a), hip.to_backend(b)
+    dr = hip.to_backend(r) if r is not None else None
+    out = T.DevBuffer(hip, a.nbytes, np.float32, a.shape)
+    hip.check(hip.fn["debug_divide"](mode, da.ptr, db.ptr, dr.ptr if dr else None, out.ptr, len(a), None), "debug_divide")
+    return out.numpy()
+
+
+def test_fast_divisions_are_ieee(hip):
+    """The integration kernel replaces the IEEE division macro by shorter FMA chains; they must return the
+    correctly rounded quotient (== numpy float32 division) over the operand ranges the kernel guards."""
+    rng = np.random.default_rng(11)
+    n = 1 << 22
+    # (1) projection u = fx*x/z: z in [1e-4, 1e4], numerators up to +-1e6, plus log-uniform magnitudes
+    z = (10.0 ** rng.uniform(-4, 4, n)).astype(np.float32)
+    num = (rng.uniform(-1, 1, n) * 10.0 ** rng.uniform(-6, 6, n)).astype(np.float32)
+    got = _divide(hip, 1, num, z)
+    assert np.array_equal(got.view(np.uint32), (num / z).view(np.uint32))
+    # typical values: pixels*depth over depth
+    z2 = rng.uniform(0.3, 4.0, n).astype(np.float32)
+    num2 = (rng.uniform(-700, 700, n).astype(np.float32) * z2).astype(np.float32)
+    assert np.array_equal(_divide(hip, 1, num2, z2).view(np.uint32), (num2 / z2).view(np.uint32))
+    # (2)+(3) weights: every integer divisor 1..256, its refined reciprocal and quotients of running sums
+    w = np.arange(1, 257, dtype=np.float32)
+    assert np.array_equal(_divide(hip, 3, w, w).view(np.uint32), (np.float32(1.0) / w).view(np.uint32))
+    ww = rng.integers(1, 257, n).astype(np.float32)
+    acc = (rng.uniform(-1.0, 1.0, n) * ww).astype(np.float32)
+    assert np.array_equal(_divide(hip, 2, acc, ww).view(np.uint32), (acc / ww).view(np.uint32))
+    # (4) eta / mu with the host-rounded reciprocal, several band widths
+    for mu in (0.02, 0.01, 0.005, 0.04, 0.1, 0.03125):
+        mu32 = np.float32(mu)
+        eta = rng.uniform(-3 * mu, 4.0, n).astype(np.float32)
+        b = np.full(n, mu32, np.float32)
+        r = np.full(n, np.float32(1.0) / mu32, np.float32)
+        assert np.array_equal(_divide(hip, 4, eta, b, r).view(np.uint32), (eta / b).view(np.uint32)), mu
