@@ -259,6 +259,48 @@ int ITM_FN(convert_depth_affine)(const int16_t* raw, float* depth_out, int w, in
 int ITM_FN(convert_disparity)(const int16_t* raw, float* depth_out, int w, int h, float c0,
                               float c1, float fx_depth, itm_stream stream);
 
+/* ---- ICP depth tracker (the step after the path) -------------------------------------
+ * Consumes the points / normals maps CreateICPMaps writes.  Device-specific half of the reference tracker:
+ *   ITMLowLevelEngine::FilterSubsampleWithHoles (float)  DeviceAgnostic/ITMLowLevelEngine.h:26-47,
+ *                                                         DeviceSpecific/CPU/ITMLowLevelEngine_CPU.cpp:50-62
+ *   ITMDepthTracker_CPU::ComputeGandH                     DeviceSpecific/CPU/ITMDepthTracker_CPU.cpp:15-79,
+ *                                                         DeviceAgnostic/ITMDepthTracker.h:8-106
+ * and the host Levenberg-Marquardt loop around it:
+ *   ITMDepthTracker::TrackCamera                          Engine/ITMDepthTracker.cpp:149-200 (+ :79-147, ITMPose::Coerce) */
+enum itm_tracker_iteration {               /* TrackerIterationType, Utils/ITMLibDefines.h:277-283 */
+  ITM_TRACKER_ITERATION_ROTATION = 1,
+  ITM_TRACKER_ITERATION_TRANSLATION = 2,
+  ITM_TRACKER_ITERATION_BOTH = 3,
+  ITM_TRACKER_ITERATION_NONE = 4
+};
+typedef struct itm_tracker_config {        /* ITMLibSettings fields the tracker factory passes on */
+  int32_t noHierarchyLevels;               /* <= 8; default 5                                  */
+  int32_t trackingRegime[8];               /* per level, level 0 = full resolution; default B B R R R */
+  int32_t noICPRunTillLevel;               /* default 0                                        */
+  float distThresh;                        /* depthTrackerICPThreshold, default 0.1*0.1        */
+  float terminationThreshold;              /* depthTrackerTerminationThreshold, default 1e-3   */
+} itm_tracker_config;
+typedef struct itm_tracker_gh {
+  float f;                                 /* sqrt(sum b^2)/n, or 1e5 when n <= 100            */
+  float nabla[6];
+  float hessian[36];                       /* r + c*6; entries outside the active block are 0  */
+  int32_t noValidPoints;
+} itm_tracker_gh;
+/* out: float[(h_in/2)*(w_in/2)] */
+int ITM_FN(filter_subsample_with_holes)(const float* in, int w_in, int h_in, float* out, itm_stream stream);
+/* Synchronises `stream` (the host loop needs the sums).  Sums are accumulated by a fixed-order reduction
+ * tree in double precision: deterministic, and within float rounding of the reference's sequential sum. */
+int ITM_FN(tracker_compute_g_and_h)(const float* depth, int w, int h, const float viewIntr[4],
+                                    const float* pointsMap, const float* normalsMap, int sceneW, int sceneH,
+                                    const float sceneIntr[4], const float approxInvPose[16],
+                                    const float scenePose[16], float distThresh, int iterationType,
+                                    itm_tracker_gh* out, itm_stream stream);
+/* ITMDepthTracker::TrackCamera: view->depth / intr_d / M_d (initial pose_d), the ICP maps of the previous
+ * frame and the pose they were rendered from (pose_pointCloud); writes the refined pose_d to M_d_out. */
+int ITM_FN(track_camera)(const itm_tracker_config* cfg, const itm_view* view, const float* pointsMap,
+                         const float* normalsMap, const float scenePose[16], float M_d_out[16],
+                         itm_stream stream);
+
 /* ---- state access ------------------------------------------------------------------------- */
 /* Blocks until `stream` has drained, then reads the device-side counters. */
 int ITM_FN(get_counters)(const itm_scene* scene, const itm_render_state* rs, itm_counters* out,

@@ -237,4 +237,26 @@ class ITMTrackingController_HIP {
   }
 };
 
+// ITMDepthTracker (Engine/ITMDepthTracker.h): TrackCamera refines trackingState->pose_d against the ICP maps
+// of the previous frame; the gradient / Hessian reduction and the depth pyramid run on the GPU.
+class ITMDepthTracker_HIP {
+  itm_tracker_config cfg;
+
+ public:
+  itm_stream stream = nullptr;
+  ITMDepthTracker_HIP(const int* trackingRegime, int noHierarchyLevels, int noICPRunTillLevel, float distThresh, float terminationThreshold) {
+    std::memset(&cfg, 0, sizeof cfg);
+    cfg.noHierarchyLevels = noHierarchyLevels;
+    for (int i = 0; i < noHierarchyLevels && i < 8; ++i) cfg.trackingRegime[i] = trackingRegime[i];
+    cfg.noICPRunTillLevel = noICPRunTillLevel; cfg.distThresh = distThresh; cfg.terminationThreshold = terminationThreshold;
+  }
+  void TrackCamera(ITMTrackingState* trackingState, const ITMView* view) {
+    itm_view v = make_view(view, trackingState);
+    float M[16];
+    check(itm_track_camera(&cfg, &v, trackingState->pointCloud_locations, trackingState->pointCloud_colours,
+                           trackingState->pose_pointCloud.GetM(), M, stream), "TrackCamera");
+    trackingState->pose_d.SetM(M);
+  }
+};
+
 }  // namespace itmhip

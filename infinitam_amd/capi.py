@@ -78,6 +78,26 @@ class Profile(C.Structure):
 TIMED_KERNELS = ["request", "alloc_sweep", "visible_list", "integrate", "range", "raycast", "icp_maps"]
 
 
+class TrackerConfig(C.Structure):
+    """itm_tracker_config; defaults of ITMLibSettings (Utils/ITMLibSettings.cpp:12-13,62-71)."""
+    _fields_ = [("noHierarchyLevels", C.c_int32), ("trackingRegime", C.c_int32 * 8), ("noICPRunTillLevel", C.c_int32),
+                ("distThresh", C.c_float), ("terminationThreshold", C.c_float)]
+
+    @staticmethod
+    def default():
+        t = TrackerConfig()
+        t.noHierarchyLevels = 5
+        t.trackingRegime[:5] = [3, 3, 1, 1, 1]
+        t.noICPRunTillLevel = 0
+        t.distThresh = 0.1 * 0.1
+        t.terminationThreshold = 1e-3
+        return t
+
+
+class TrackerGH(C.Structure):
+    _fields_ = [("f", C.c_float), ("nabla", C.c_float * 6), ("hessian", C.c_float * 36), ("noValidPoints", C.c_int32)]
+
+
 class Counters(C.Structure):
     _fields_ = [("lastFreeBlockId", C.c_int32), ("lastFreeExcessListId", C.c_int32),
                 ("noVisibleEntries", C.c_int32), ("noFwdProjMissingPoints", C.c_int32),
@@ -143,6 +163,10 @@ _SIGS = {
     "process_frame": (C.c_int, [_P, C.POINTER(ViewStruct), _P, _P, _P, _P]),
     "convert_depth_affine": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_float, C.c_float, _P]),
     "convert_disparity": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, _P]),
+    "filter_subsample_with_holes": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
+    "tracker_compute_g_and_h": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_float), _P, _P, C.c_int, C.c_int, C.POINTER(C.c_float),
+                                          C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_int, C.POINTER(TrackerGH), _P]),
+    "track_camera": (C.c_int, [C.POINTER(TrackerConfig), C.POINTER(ViewStruct), _P, _P, C.POINTER(C.c_float), C.POINTER(C.c_float), _P]),
     "get_counters": (C.c_int, [_P, _P, C.POINTER(Counters), _P]),
     "set_counters": (C.c_int, [_P, _P, C.POINTER(Counters), _P]),
     "buffer_bytes": (C.c_size_t, [_P, _P, C.c_int]),

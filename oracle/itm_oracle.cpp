@@ -1237,3 +1237,239 @@ int itmo_export_visible_record(const itm_render_state* rs, const float M_d[16], 
 }
 
 }  // extern "C"
+
+// ==========================================================================================
+// ICP depth tracker: sequential restatement
+//   filterSubsampleWithHoles          DeviceAgnostic/ITMLowLevelEngine.h:26-47
+//   computePerPointGH_Depth(_Ab)      DeviceAgnostic/ITMDepthTracker.h:8-106
+//   ITMDepthTracker_CPU::ComputeGandH DeviceSpecific/CPU/ITMDepthTracker_CPU.cpp:15-79
+//   ITMDepthTracker::TrackCamera      Engine/ITMDepthTracker.cpp:79-200
+//   ITMPose parameter conversions     Objects/ITMPose.cpp:84-236,305-326 ; ORUtils/Cholesky.h
+// ==========================================================================================
+namespace {
+
+bool bilerp_holes(const V4f* src, float px, float py, int W, V4f& r) {
+  int16_t ix = (int16_t)std::floor(px), iy = (int16_t)std::floor(py);
+  float dx = px - (float)ix, dy = py - (float)iy;
+  const V4f &a = src[ix + iy * W], &b = src[(ix + 1) + iy * W], &c = src[ix + (iy + 1) * W], &d = src[(ix + 1) + (iy + 1) * W];
+  if (a.w < 0 || b.w < 0 || c.w < 0 || d.w < 0) { r = V4f{0, 0, 0, -1.0f}; return false; }
+  r.x = (a.x * (1.0f - dx) * (1.0f - dy) + b.x * dx * (1.0f - dy) + c.x * (1.0f - dx) * dy + d.x * dx * dy);
+  r.y = (a.y * (1.0f - dx) * (1.0f - dy) + b.y * dx * (1.0f - dy) + c.y * (1.0f - dx) * dy + d.y * dx * dy);
+  r.z = (a.z * (1.0f - dx) * (1.0f - dy) + b.z * dx * (1.0f - dy) + c.z * (1.0f - dx) * dy + d.z * dx * dy);
+  r.w = (a.w * (1.0f - dx) * (1.0f - dy) + b.w * dx * (1.0f - dy) + c.w * (1.0f - dx) * dy + d.w * dx * dy);
+  return true;
+}
+
+void subsample_holes(const float* in, int wIn, int hIn, float* out) {
+  int w = wIn / 2, h = hIn / 2;
+  for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) {
+    int sx = x * 2, sy = y * 2;
+    float acc = 0.0f, good = 0.0f, v;
+    v = in[sx + sy * wIn]; if (v > 0.0f) { acc += v; good++; }
+    v = in[(sx + 1) + sy * wIn]; if (v > 0.0f) { acc += v; good++; }
+    v = in[sx + (sy + 1) * wIn]; if (v > 0.0f) { acc += v; good++; }
+    v = in[(sx + 1) + (sy + 1) * wIn]; if (v > 0.0f) { acc += v; good++; }
+    if (good > 0) acc /= good;
+    out[x + y * w] = acc;
+  }
+}
+
+int g_and_h(const float* depth, int w, int h, const float* vi, const V4f* pts, const V4f* nrm, int sW, int sH, const float* si,
+            const float* invPose, const float* scenePose, float distThresh, int type, itm_tracker_gh* out) {
+  std::memset(out, 0, sizeof *out);
+  if (type == ITM_TRACKER_ITERATION_NONE) return 0;
+  const bool shortIt = type != ITM_TRACKER_ITERATION_BOTH;
+  const int np = shortIt ? 3 : 6, nh = np * (np + 1) / 2;
+  float sumH[21], sumN[6], sumF = 0.0f; int n = 0;
+  for (int i = 0; i < 21; ++i) sumH[i] = 0; for (int i = 0; i < 6; ++i) sumN[i] = 0;
+  for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) {
+    float d = depth[x + y * w];
+    if (d <= 1e-8f) continue;
+    V4f p3 = {d * (((float)x - vi[2]) / vi[0]), d * (((float)y - vi[3]) / vi[1]), d, 1.0f};
+    V4f q = mul(invPose, p3); q.w = 1.0f;
+    V4f rp = mul(scenePose, q);
+    if (rp.z <= 0.0f) continue;
+    float u = si[0] * rp.x / rp.z + si[2], v = si[1] * rp.y / rp.z + si[3];
+    if (!((u >= 0.0f) && (u <= sW - 2) && (v >= 0.0f) && (v <= sH - 2))) continue;
+    V4f cp; bilerp_holes(pts, u, v, sW, cp);
+    if (cp.w < 0.0f) continue;
+    float ex = cp.x - q.x, ey = cp.y - q.y, ez = cp.z - q.z;
+    float dist = ex * ex + ey * ey + ez * ez;
+    if (dist > distThresh) continue;
+    V4f nn; bilerp_holes(nrm, u, v, sW, nn);
+    float b = nn.x * ex + nn.y * ey + nn.z * ez;
+    float A[6];
+    if (type == ITM_TRACKER_ITERATION_TRANSLATION) { A[0] = nn.x; A[1] = nn.y; A[2] = nn.z; }
+    else {
+      A[0] = +q.z * nn.y - q.y * nn.z;
+      A[1] = -q.z * nn.x + q.x * nn.z;
+      A[2] = +q.y * nn.x - q.x * nn.y;
+      if (!shortIt) { A[3] = nn.x; A[4] = nn.y; A[5] = nn.z; }
+    }
+    n++; sumF += b * b;
+    for (int r = 0, k = 0; r < np; ++r) {
+      sumN[r] += b * A[r];
+      for (int c = 0; c <= r; ++c, ++k) sumH[k] += A[r] * A[c];
+    }
+  }
+  for (int r = 0, k = 0; r < np; ++r) for (int c = 0; c <= r; ++c, ++k) out->hessian[r + c * 6] = sumH[k];
+  for (int r = 0; r < np; ++r) for (int c = r + 1; c < np; ++c) out->hessian[r + c * 6] = out->hessian[c + r * 6];
+  for (int r = 0; r < np; ++r) out->nabla[r] = sumN[r];
+  out->noValidPoints = n;
+  out->f = (n > 100) ? std::sqrt(sumF) / n : 1e5f;
+  (void)nh;
+  return n;
+}
+
+struct OPose {
+  float t[3], r[3], M[16];
+  static float dot(const float* a, const float* b) { float s = 0; for (int i = 0; i < 3; ++i) s += a[i] * b[i]; return s; }
+  static void cross(const float* a, const float* b, float* o) { o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0]; }
+  static void fromParams(const float* w, const float* t, float* R, float* T) {
+    float one_6th = 1.0f / 6.0f, one_20th = 1.0f / 20.0f;
+    float theta_sq = dot(w, w), theta = std::sqrt(theta_sq), A, B, cv[3];
+    cross(w, t, cv);
+    if (theta_sq < 1e-8f) { A = 1.0f - one_6th * theta_sq; B = 0.5f; for (int i = 0; i < 3; ++i) T[i] = t[i] + 0.5f * cv[i]; }
+    else {
+      float C;
+      if (theta_sq < 1e-6f) { C = one_6th * (1.0f - one_20th * theta_sq); A = 1.0f - theta_sq * C; B = 0.5f - 0.25f * one_6th * theta_sq; }
+      else { float it = 1.0f / theta; A = sinf(theta) * it; B = (1.0f - cosf(theta)) * (it * it); C = (1.0f - A) * (it * it); }
+      float c2[3]; cross(w, cv, c2);
+      for (int i = 0; i < 3; ++i) T[i] = t[i] + B * cv[i] + C * c2[i];
+    }
+    float wx2 = w[0] * w[0], wy2 = w[1] * w[1], wz2 = w[2] * w[2], a, b;
+    R[0] = 1.0f - B * (wy2 + wz2); R[4] = 1.0f - B * (wx2 + wz2); R[8] = 1.0f - B * (wx2 + wy2);
+    a = A * w[2]; b = B * (w[0] * w[1]); R[0 + 3 * 1] = b - a; R[1 + 3 * 0] = b + a;
+    a = A * w[1]; b = B * (w[0] * w[2]); R[0 + 3 * 2] = b + a; R[2 + 3 * 0] = b - a;
+    a = A * w[0]; b = B * (w[1] * w[2]); R[1 + 3 * 2] = b - a; R[2 + 3 * 1] = b + a;
+  }
+  void modelViewFromParams() {
+    float R[9], T[3]; fromParams(r, t, R, T);
+    for (int c = 0; c < 3; ++c) for (int rr = 0; rr < 3; ++rr) M[rr + 4 * c] = R[rr + 3 * c];
+    M[12] = T[0]; M[13] = T[1]; M[14] = T[2]; M[3] = M[7] = M[11] = 0.0f; M[15] = 1.0f;
+  }
+  void paramsFromModelView() {
+    float R[9], T[3] = {M[12], M[13], M[14]}, rot[3];
+    for (int c = 0; c < 3; ++c) for (int rr = 0; rr < 3; ++rr) R[rr + 3 * c] = M[rr + 4 * c];
+    float cos_angle = (R[0] + R[4] + R[8] - 1.0f) * 0.5f;
+    rot[0] = (R[2 + 3 * 1] - R[1 + 3 * 2]) * 0.5f; rot[1] = (R[0 + 3 * 2] - R[2 + 3 * 0]) * 0.5f; rot[2] = (R[1 + 3 * 0] - R[0 + 3 * 1]) * 0.5f;
+    float sin_abs = std::sqrt(dot(rot, rot));
+    if (cos_angle > M_SQRT1_2) { if (sin_abs) { float s = asinf(sin_abs) / sin_abs; rot[0] *= s; rot[1] *= s; rot[2] *= s; } }
+    else if (cos_angle > -M_SQRT1_2) { float s = acosf(cos_angle) / sin_abs; rot[0] *= s; rot[1] *= s; rot[2] *= s; }
+    else {
+      float angle = (float)M_PI - asinf(sin_abs);
+      float d0 = R[0] - cos_angle, d1 = R[4] - cos_angle, d2 = R[8] - cos_angle, r2[3];
+      if (fabsf(d0) > fabsf(d1) && fabsf(d0) > fabsf(d2)) { r2[0] = d0; r2[1] = (R[1] + R[3]) * 0.5f; r2[2] = (R[6] + R[2]) * 0.5f; }
+      else if (fabsf(d1) > fabsf(d2)) { r2[0] = (R[1] + R[3]) * 0.5f; r2[1] = d1; r2[2] = (R[5] + R[7]) * 0.5f; }
+      else { r2[0] = (R[6] + R[2]) * 0.5f; r2[1] = (R[5] + R[7]) * 0.5f; r2[2] = d2; }
+      if (dot(r2, rot) < 0.0f) { r2[0] *= -1.0f; r2[1] *= -1.0f; r2[2] *= -1.0f; }
+      float len = std::sqrt(dot(r2, r2));
+      if (len == 0) { r2[0] = r2[1] = r2[2] = 0; } else { r2[0] /= len; r2[1] /= len; r2[2] /= len; }
+      rot[0] = angle * r2[0]; rot[1] = angle * r2[1]; rot[2] = angle * r2[2];
+    }
+    float shtot = 0.5f, theta = std::sqrt(dot(rot, rot));
+    if (theta > 0.00001f) shtot = sinf(theta * 0.5f) / theta;
+    float hw[3] = {rot[0] * -0.5f, rot[1] * -0.5f, rot[2] * -0.5f}, z[3] = {0, 0, 0}, HR[9], HT[3], rt[3];
+    fromParams(hw, z, HR, HT);
+    for (int i = 0; i < 3; ++i) rt[i] = HR[i] * T[0] + HR[i + 3] * T[1] + HR[i + 6] * T[2];
+    if (theta > 0.001f) { float denom = dot(rot, rot); float prm = dot(T, rot) * (1 - 2 * shtot) / denom; for (int i = 0; i < 3; ++i) rt[i] -= rot[i] * prm; }
+    else { float prm = dot(T, rot) / 24; for (int i = 0; i < 3; ++i) rt[i] -= rot[i] * prm; }
+    for (int i = 0; i < 3; ++i) rt[i] /= 2 * shtot;
+    for (int i = 0; i < 3; ++i) { r[i] = rot[i]; t[i] = rt[i]; }
+  }
+};
+
+void chol_solve(const float* mat, int n, const float* v, float* result) {
+  std::vector<float> ch(mat, mat + n * n), y(n);
+  for (int c = 0; c < n; ++c) {
+    float inv_diag = 1;
+    for (int r = c; r < n; ++r) {
+      float val = ch[c + r * n];
+      for (int c2 = 0; c2 < c; ++c2) val -= ch[c + c2 * n] * ch[c2 + r * n];
+      if (r == c) { ch[c + r * n] = val; inv_diag = 1.0f / val; } else { ch[r + c * n] = val; ch[c + r * n] = val * inv_diag; }
+    }
+  }
+  for (int i = 0; i < n; ++i) { float val = v[i]; for (int j = 0; j < i; ++j) val -= ch[j + i * n] * y[j]; y[i] = val; }
+  for (int i = 0; i < n; ++i) y[i] /= ch[i + i * n];
+  for (int i = n - 1; i >= 0; --i) { float val = y[i]; for (int j = i + 1; j < n; ++j) val -= ch[i + j * n] * result[j]; result[i] = val; }
+}
+
+}  // namespace
+
+extern "C" {
+
+int itmo_filter_subsample_with_holes(const float* in, int w_in, int h_in, float* out, itm_stream) {
+  if (!in || !out || w_in < 2 || h_in < 2) return fail(ITM_ERR_INVALID, "bad argument");
+  subsample_holes(in, w_in, h_in, out);
+  return ITM_OK;
+}
+
+int itmo_tracker_compute_g_and_h(const float* depth, int w, int h, const float vi[4], const float* pts, const float* nrm, int sW, int sH,
+                                 const float si[4], const float invPose[16], const float scenePose[16], float distThresh, int type,
+                                 itm_tracker_gh* out, itm_stream) {
+  if (!depth || !pts || !nrm || !out) return fail(ITM_ERR_INVALID, "bad argument");
+  g_and_h(depth, w, h, vi, (const V4f*)pts, (const V4f*)nrm, sW, sH, si, invPose, scenePose, distThresh, type, out);
+  return ITM_OK;
+}
+
+int itmo_track_camera(const itm_tracker_config* cfg, const itm_view* view, const float* pts, const float* nrm, const float scenePose[16],
+                      float M_out[16], itm_stream) {
+  if (!cfg || !view || !pts || !nrm || !scenePose || !M_out) return fail(ITM_ERR_INVALID, "null argument");
+  const int L = cfg->noHierarchyLevels;
+  if (L < 1 || L > 8) return fail(ITM_ERR_INVALID, "noHierarchyLevels must be 1..8");
+  std::vector<std::vector<float>> pyr(L);
+  std::vector<const float*> dl(L); std::vector<int> wl(L), hl(L); std::vector<float> il(4 * L), dt(L); std::vector<int> its(L);
+  dl[0] = view->depth; wl[0] = view->w; hl[0] = view->h;
+  for (int k = 0; k < 4; ++k) il[k] = view->intr_d[k];
+  for (int i = 1; i < L; ++i) {
+    wl[i] = wl[i - 1] / 2; hl[i] = hl[i - 1] / 2;
+    if (wl[i] < 1 || hl[i] < 1) return fail(ITM_ERR_INVALID, "image too small for the hierarchy");
+    pyr[i].resize((size_t)wl[i] * hl[i]);
+    subsample_holes(dl[i - 1], wl[i - 1], hl[i - 1], pyr[i].data());
+    dl[i] = pyr[i].data();
+    for (int k = 0; k < 4; ++k) il[4 * i + k] = il[4 * (i - 1) + k] * 0.5f;
+  }
+  its[0] = 2; for (int i = 1; i < L; ++i) its[i] = its[i - 1] + 2;
+  float stepT = cfg->distThresh / L; dt[L - 1] = cfg->distThresh;
+  for (int i = L - 2; i >= 0; --i) dt[i] = dt[i + 1] - stepT;
+  OPose pose; std::memcpy(pose.M, view->M_d, 64); pose.paramsFromModelView();
+  float Hg[36], Ng[6], A[36], step[6];
+  std::memset(Hg, 0, sizeof Hg); std::memset(Ng, 0, sizeof Ng);
+  for (int lev = L - 1; lev >= cfg->noICPRunTillLevel; --lev) {
+    int type = cfg->trackingRegime[lev];
+    if (type == ITM_TRACKER_ITERATION_NONE) continue;
+    float inv[16]; invert4(pose.M, inv);
+    OPose good = pose; float f_old = 1e20f, lambda = 1.0f;
+    for (int it = 0; it < its[lev]; ++it) {
+      itm_tracker_gh gh;
+      int n = g_and_h(dl[lev], wl[lev], hl[lev], &il[4 * lev], (const V4f*)pts, (const V4f*)nrm, view->w, view->h, &il[0], inv, scenePose, dt[lev], type, &gh);
+      if ((n <= 0) || (gh.f > f_old)) { pose = good; invert4(pose.M, inv); lambda *= 10.0f; }
+      else {
+        good = pose; f_old = gh.f;
+        for (int i = 0; i < 36; ++i) Hg[i] = gh.hessian[i] / n;
+        for (int i = 0; i < 6; ++i) Ng[i] = gh.nabla[i] / n;
+        lambda /= 10.0f;
+      }
+      for (int i = 0; i < 36; ++i) A[i] = Hg[i];
+      for (int i = 0; i < 6; ++i) A[i + i * 6] *= 1.0f + lambda;
+      for (int i = 0; i < 6; ++i) step[i] = 0;
+      if (type != ITM_TRACKER_ITERATION_BOTH) { float sm[9]; for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) sm[r + c * 3] = A[r + c * 6]; chol_solve(sm, 3, Ng, step); }
+      else chol_solve(A, 6, Ng, step);
+      float s[6] = {0, 0, 0, 0, 0, 0};
+      if (type == ITM_TRACKER_ITERATION_ROTATION) { s[0] = step[0]; s[1] = step[1]; s[2] = step[2]; }
+      else if (type == ITM_TRACKER_ITERATION_TRANSLATION) { s[3] = step[0]; s[4] = step[1]; s[5] = step[2]; }
+      else for (int i = 0; i < 6; ++i) s[i] = step[i];
+      float Ti[16] = {1.0f, -s[2], s[1], 0.0f,  s[2], 1.0f, -s[0], 0.0f,  -s[1], s[0], 1.0f, 0.0f,  s[3], s[4], s[5], 1.0f};
+      float ninv[16]; matmul4(Ti, inv, ninv);
+      invert4(ninv, pose.M); pose.paramsFromModelView();
+      pose.paramsFromModelView(); pose.modelViewFromParams();
+      invert4(pose.M, inv);
+      float len = 0.0f; for (int i = 0; i < 6; ++i) len += step[i] * step[i];
+      if (std::sqrt(len) / 6 < cfg->terminationThreshold) break;
+    }
+  }
+  std::memcpy(M_out, pose.M, 64);
+  return ITM_OK;
+}
+
+}  // extern "C"

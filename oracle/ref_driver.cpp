@@ -23,6 +23,8 @@
 #include "ITMLib/Engine/DeviceSpecific/CPU/ITMSceneReconstructionEngine_CPU.cpp"
 #include "ITMLib/Engine/DeviceSpecific/CPU/ITMVisualisationEngine_CPU.cpp"
 #include "ITMLib/Engine/DeviceAgnostic/ITMViewBuilder.h"
+#include "ITMLib/Engine/DeviceSpecific/CPU/ITMDepthTracker_CPU.h"
+#include "ITMLib/Engine/DeviceSpecific/CPU/ITMLowLevelEngine_CPU.h"
 
 using namespace ITMLib::Engine;
 using namespace ITMLib::Objects;
@@ -380,6 +382,81 @@ int itmr_export_visible_record(const itm_render_state* r, const float M_d[16], i
   ITMRenderState_VH* vh = (ITMRenderState_VH*)r->rs;
   d[0] = vh->noVisibleEntries;
   for (int i = 0; i < max_ids; ++i) d[1 + i] = (i < vh->noVisibleEntries) ? vh->GetVisibleEntryIDs()[i] : -1;
+  return ITM_OK;
+}
+
+}  // extern "C"
+
+// ---- ICP depth tracker: the reference's own ITMDepthTracker_CPU / ITMLowLevelEngine_CPU -----------------
+namespace {
+// exposes the protected evaluation state of ITMDepthTracker so that ComputeGandH can be called for one level
+struct TrackerProbe : ITMDepthTracker_CPU {
+  TrackerProbe(Vector2i sz, TrackerIterationType* regime, const ITMLowLevelEngine* ll)
+      : ITMDepthTracker_CPU(sz, regime, 1, 0, 0.01f, 1e-3f, ll) {}
+  int eval(ITMTemplatedHierarchyLevel<ITMFloatImage>* vl, ITMSceneHierarchyLevel* sl, const Matrix4f& sp, TrackerIterationType it,
+           float dth, Matrix4f inv, float& f, float* nabla, float* hessian) {
+    this->viewHierarchyLevel = vl; this->sceneHierarchyLevel = sl; this->scenePose = sp; this->iterationType = it;
+    this->levelId = 0; this->distThresh[0] = dth;
+    return this->ComputeGandH(f, nabla, hessian, inv);
+  }
+};
+}  // namespace
+
+extern "C" {
+
+int itmr_filter_subsample_with_holes(const float* in, int w_in, int h_in, float* out, itm_stream) {
+  ITMLowLevelEngine_CPU ll;
+  ITMFloatImage src(Vector2i(w_in, h_in), true, false), dst(Vector2i(w_in, h_in), true, false);
+  std::memcpy(src.GetData(MEMORYDEVICE_CPU), in, (size_t)w_in * h_in * 4);
+  ll.FilterSubsampleWithHoles(&dst, &src);
+  std::memcpy(out, dst.GetData(MEMORYDEVICE_CPU), (size_t)(w_in / 2) * (h_in / 2) * 4);
+  return ITM_OK;
+}
+
+int itmr_tracker_compute_g_and_h(const float* depth, int w, int h, const float vi[4], const float* pts, const float* nrm, int sW, int sH,
+                                 const float si[4], const float invPose[16], const float scenePose[16], float distThresh, int type,
+                                 itm_tracker_gh* out, itm_stream) {
+  std::memset(out, 0, sizeof *out);
+  ITMLowLevelEngine_CPU ll;
+  TrackerIterationType regime[1] = {(TrackerIterationType)type};
+  TrackerProbe probe(Vector2i(w, h), regime, &ll);
+  ITMTemplatedHierarchyLevel<ITMFloatImage> vl(Vector2i(w, h), 0, regime[0], MEMORYDEVICE_CPU, false);
+  std::memcpy(vl.depth->GetData(MEMORYDEVICE_CPU), depth, (size_t)w * h * 4);
+  vl.intrinsics = Vector4f(vi[0], vi[1], vi[2], vi[3]);
+  ITMSceneHierarchyLevel sl(Vector2i(sW, sH), 0, regime[0], MEMORYDEVICE_CPU, false);
+  std::memcpy(sl.pointsMap->GetData(MEMORYDEVICE_CPU), pts, (size_t)sW * sH * 16);
+  std::memcpy(sl.normalsMap->GetData(MEMORYDEVICE_CPU), nrm, (size_t)sW * sH * 16);
+  sl.intrinsics = Vector4f(si[0], si[1], si[2], si[3]);
+  Matrix4f sp, inv; set_matrix(sp, scenePose); set_matrix(inv, invPose);
+  float hessian[36]; for (int i = 0; i < 36; ++i) hessian[i] = 0;
+  float nabla[6] = {0, 0, 0, 0, 0, 0}, f = 0;
+  int n = probe.eval(&vl, &sl, sp, regime[0], distThresh, inv, f, nabla, hessian);
+  out->noValidPoints = n; out->f = f;
+  for (int i = 0; i < 6; ++i) out->nabla[i] = nabla[i];
+  for (int i = 0; i < 36; ++i) out->hessian[i] = hessian[i];
+  return ITM_OK;
+}
+
+int itmr_track_camera(const itm_tracker_config* cfg, const itm_view* view, const float* pts, const float* nrm, const float scenePose[16],
+                      float M_out[16], itm_stream) {
+  const int L = cfg->noHierarchyLevels;
+  ITMLowLevelEngine_CPU ll;
+  TrackerIterationType regime[8];
+  for (int i = 0; i < L; ++i) regime[i] = (TrackerIterationType)cfg->trackingRegime[i];
+  Vector2i sz(view->w, view->h);
+  ITMDepthTracker_CPU tracker(sz, regime, L, cfg->noICPRunTillLevel, cfg->distThresh, cfg->terminationThreshold, &ll);
+  ITMRGBDCalib calib;
+  calib.intrinsics_d.SetFrom(view->intr_d[0], view->intr_d[1], view->intr_d[2], view->intr_d[3], (float)view->w, (float)view->h);
+  ITMView v(&calib, sz, sz, false);
+  std::memcpy(v.depth->GetData(MEMORYDEVICE_CPU), view->depth, (size_t)view->w * view->h * 4);
+  ITMTrackingState ts(sz, MEMORYDEVICE_CPU);
+  std::memcpy(ts.pointCloud->locations->GetData(MEMORYDEVICE_CPU), pts, (size_t)view->w * view->h * 16);
+  std::memcpy(ts.pointCloud->colours->GetData(MEMORYDEVICE_CPU), nrm, (size_t)view->w * view->h * 16);
+  Matrix4f M, sp; set_matrix(M, view->M_d); set_matrix(sp, scenePose);
+  ts.pose_d->SetM(M);
+  ts.pose_pointCloud->SetM(sp);
+  tracker.TrackCamera(&ts, &v);
+  std::memcpy(M_out, ts.pose_d->GetM().m, 64);
   return ITM_OK;
 }
 
