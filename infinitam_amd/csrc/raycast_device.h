@@ -23,11 +23,33 @@
 #ifndef ITM_RAY_FUSED_FETCH
 #define ITM_RAY_FUSED_FETCH 0
 #endif
+#ifndef ITM_RAY_MISS_LOOKAHEAD
+#define ITM_RAY_MISS_LOOKAHEAD 0  // K > 0: after a miss, probe the occupancy bits of the next K 8-voxel steps at once
+#endif
+#ifndef ITM_EXP_WAVE_TIMING
+#define ITM_EXP_WAVE_TIMING 0  // experiment: per-wave cycle accounting of cast_ray into g_waveStats (read with itm_debug_read_wave_stats)
+#endif
+#ifndef ITM_RAY_PREFETCH_COLUMN
+#define ITM_RAY_PREFETCH_COLUMN 0  // on entering a block, touch the ray's (x,y) column in all 8 z-slices of the block (LDS-DMA loads into a junk buffer)
+#endif
 #ifndef ITM_RAY_BITMAP_GUARD
 #define ITM_RAY_BITMAP_GUARD 1  // consult the occupancy bitmap before fetching a hash entry (single-voxel lookups)
 #endif
 
 namespace itm {
+
+#if ITM_EXP_WAVE_TIMING
+static __device__ unsigned long long g_waveStats[8192 * 12];
+static __device__ unsigned long long g_waveTrace[160 * 64 * 4];  // waves with index % 32 == 1: per iteration (t0-start, near end, tri end, iteration end | lanes<<48)
+#define ITM_WT(...) __VA_ARGS__
+__device__ inline unsigned long long wt_wave_max(unsigned long long v) {
+  for (int o = 32; o > 0; o >>= 1) { const unsigned long long u = __shfl_xor(v, o, 64); v = u > v ? u : v; }
+  return v;
+}
+__device__ inline unsigned long long wt_clock() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t = clock64(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); return t; }
+#else
+#define ITM_WT(...)
+#endif
 
 struct VolumeView {
   const uint4* hash;   // hash entries (hash index only)
@@ -83,10 +105,26 @@ __device__ inline long long locate_voxel(const VolumeView& vol, int px, int py, 
 // raw (unconverted) sdf of the voxel at an integer point; the default voxel when absent
 template <class VX, bool DENSE>
 __device__ inline float read_raw_sdf(const VolumeView& vol, int px, int py, int pz, bool& found, BlockCache& cache) {
+#if ITM_RAY_PREFETCH_COLUMN
+  const int prevBase = cache.base;
+#endif
   const long long a = locate_voxel<DENSE>(vol, px, py, pz, cache);
   found = a >= 0;
   if (!found) return VX::kShort ? 32767.0f : 1.0f;
-  return VX::load_raw_sdf(vol.vba, (size_t)a);
+  const float v = VX::load_raw_sdf(vol.vba, (size_t)a);
+#if ITM_RAY_PREFETCH_COLUMN
+  if (!DENSE && cache.base != prevBase) {
+    // first read in this block: a z-step is a new 128-byte line every time (x + 8y + 64z layout), cold in this
+    // XCD's L2.  Request the ray's column of all 8 z-slices now, so the following steps inside the block hit.
+    __shared__ int junk[64];
+    const char* col = (const char*)vol.vba + ((size_t)cache.base + (size_t)((int)a & 63)) * VX::kBytes;
+#pragma unroll
+    for (int zz = 0; zz < 8; ++zz)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(col + zz * 64 * VX::kBytes),
+                                       (__attribute__((address_space(3))) void*)junk, 4, 0, 0);
+  }
+#endif
+  return v;
 }
 
 template <class VX, bool DENSE>
@@ -224,6 +262,7 @@ struct RayParams {
 
 template <class VX, bool DENSE>
 __device__ inline float4 cast_ray(int x, int y, const VolumeView& vol, const RayParams& p, float2 mm) {
+  ITM_WT(const unsigned long long wtEntry = wt_clock();)
   float sdf = 1.0f;
   const float stepScale = p.mu * p.oneOverVoxel;
   float pcz = mm.x;
@@ -248,7 +287,9 @@ __device__ inline float4 cast_ray(int x, int y, const VolumeView& vol, const Ray
   float step;
   int iters = 0; (void)iters;
   bool expectBand = false;  // the previous step was inside the band: expect a trilinear read again
+  ITM_WT(unsigned long long wtStart = wt_clock(); unsigned long long wtNear = 0, wtTri = 0; unsigned long long wtMaxIter = 0; unsigned wtMaxIdx = 0; unsigned wtIters = 0, wtTriIters = 0, wtLanesIter = 0, wtLanesTri = 0;)
   while (total < totalMax) {
+    ITM_WT(const unsigned long long wt0 = wt_clock(); ++wtIters; const unsigned wtLanesNow = __popcll(__ballot(1)); wtLanesIter += wtLanesNow; unsigned long long wtT1 = wt0, wtT2 = wt0;)
 #if ITM_RAY_FUSED_FETCH
     // one fetch of the 2x2x2 neighbourhood serves the nearest read and the trilinear re-read
     // (measured slower on MI355X: 155 us vs 72 us -- the extra probes/ALU of every step outweigh
@@ -320,23 +361,61 @@ __device__ inline float4 cast_ray(int x, int y, const VolumeView& vol, const Ray
     if (!fast) {
       sdf = sdf_nearest<VX, DENSE>(vol, px, py, pz, found, cache);
       expectBand = found && (sdf <= 0.1f) && (sdf >= -0.5f);
+      ITM_WT(const unsigned long long anyBand = __ballot(expectBand); const unsigned long long wt1 = wt_clock(); wtNear += wt1 - wt0; wtT1 = wt1; wtT2 = wt1;)
       if (expectBand) sdf = sdf_trilinear<VX, DENSE>(vol, px, py, pz, found, cache);
+      ITM_WT(if (anyBand) { const float keep = sdf; asm volatile("" :: "v"(keep)); wtT2 = wt_clock(); wtTri += wtT2 - wt1; ++wtTriIters; wtLanesTri += __popcll(anyBand); })
     }
 #endif
 #endif
 #if ITM_EXP_MAXITER
     if (++iters >= ITM_EXP_MAXITER) break;   // timing experiment only: results are wrong
 #endif
-    if (!found) {
-      step = (float)kBlockSide;
-    } else {
-      if (sdf <= 0.0f) break;
-      const float s = sdf * stepScale;
-      step = (s < 1.0f) ? 1.0f : s;
+#if ITM_RAY_MISS_LOOKAHEAD > 0
+    if (!DENSE && !found) {
+      // A miss advances the ray by exactly one block side, and so does every following miss: the positions
+      // p + k*(8*dir) (accumulated one add at a time, as the sequential loop does) are known in advance.
+      // Their occupancy bits are loaded together (one round trip instead of K dependent ones); the ray
+      // jumps over the leading run of positions whose bucket is provably empty.  A set bit (or the end of
+      // the range) stops the run and the position is examined by the normal path of the next iteration.
+      constexpr int K = ITM_RAY_MISS_LOOKAHEAD;
+      const float ex = (float)kBlockSide * dx, ey = (float)kBlockSide * dy, ez = (float)kBlockSide * dz;
+      float qx[K + 1], qy[K + 1], qz[K + 1], qt[K + 1];
+      uint32_t occ[K];
+      float ax = px, ay = py, az = pz, at = total;
+#pragma unroll
+      for (int k = 0; k <= K; ++k) {
+        ax += ex; ay += ey; az += ez; at += (float)kBlockSide;
+        qx[k] = ax; qy[k] = ay; qz[k] = az; qt[k] = at;
+        if (k < K) {
+          const int idx = hash_index(floor_div8((int)round_ref(ax)), floor_div8((int)round_ref(ay)), floor_div8((int)round_ref(az)), vol.mask);
+          occ[k] = (vol.headBits[idx >> 5] >> (idx & 31)) & 1u;
+        }
+      }
+      px = qx[0]; py = qy[0]; pz = qz[0]; total = qt[0];
+      bool go = true;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        go = go && (qt[k] < totalMax) && (occ[k] == 0u);
+        if (go) { px = qx[k + 1]; py = qy[k + 1]; pz = qz[k + 1]; total = qt[k + 1]; }
+      }
+    } else
+#endif
+    {
+      if (!found) {
+        step = (float)kBlockSide;
+      } else {
+        if (sdf <= 0.0f) break;
+        const float s = sdf * stepScale;
+        step = (s < 1.0f) ? 1.0f : s;
+      }
+      px += step * dx; py += step * dy; pz += step * dz;
+      total += step;
     }
-    px += step * dx; py += step * dy; pz += step * dz;
-    total += step;
+    ITM_WT({ const float keep2 = total + px; asm volatile("" :: "v"(keep2)); const unsigned long long te = wt_clock(); const unsigned long long d = te - wt0; if (d > wtMaxIter) { wtMaxIter = d; wtMaxIdx = wtIters; }
+      const unsigned wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+      if ((wv & 31) == 1 && (wv >> 5) < 160 && wtIters <= 64) { unsigned long long* tr = g_waveTrace + ((size_t)(wv >> 5) * 64 + (wtIters - 1)) * 4; tr[0] = wt0 - wtStart; tr[1] = wtT1 - wtStart; tr[2] = wtT2 - wtStart; tr[3] = (te - wtStart) | ((unsigned long long)wtLanesNow << 48); } })
   }
+  ITM_WT(const unsigned long long wtLoopEnd = wt_clock();)
   float w = 0.0f;
   if (sdf <= 0.0f) {
     step = sdf * stepScale;
@@ -346,6 +425,161 @@ __device__ inline float4 cast_ray(int x, int y, const VolumeView& vol, const Ray
     px += step * dx; py += step * dy; pz += step * dz;
     w = 1.0f;
   }
+#if ITM_EXP_WAVE_TIMING
+  {
+    const float keepw = px + w; asm volatile("" :: "v"(keepw));
+    const unsigned long long wtEnd = wt_clock();
+    const unsigned wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // the accumulators are per lane (a lane only counts while it is active): the lane that stayed longest has the wave's totals
+    const unsigned long long mIters = wt_wave_max(wtIters), mTriIters = wt_wave_max(wtTriIters), mNear = wt_wave_max(wtNear), mTri = wt_wave_max(wtTri),
+                             mLanesIter = wt_wave_max(wtLanesIter), mLanesTri = wt_wave_max(wtLanesTri);
+    wtMaxIter = wt_wave_max(wtMaxIter);
+    if ((threadIdx.x & 63) == 0 && wv < 8192) {
+      unsigned long long* o = g_waveStats + (size_t)wv * 12;
+      o[8] = wtStart - wtEntry; o[9] = wtLoopEnd - wtStart; o[10] = wtEnd - wtLoopEnd; o[11] = wtMaxIter; o[7] = wtMaxIdx;
+      o[0] = wtEnd - wtStart; o[1] = mIters; o[2] = mTriIters; o[3] = mNear; o[4] = mTri; o[5] = mLanesIter; o[6] = mLanesTri;
+    }
+  }
+#endif
+  return make_float4(px, py, pz, w);
+}
+
+#ifndef ITM_RAY_WHILE_WHILE
+#define ITM_RAY_WHILE_WHILE 1
+#endif
+#ifndef ITM_RAY_MARCH_BURST
+#define ITM_RAY_MARCH_BURST 4   // cheap steps a lane may take before the wave serves the lanes waiting for a trilinear read
+#endif
+
+// castRay restructured as two nested loops ("while-while"): the inner loop only does the cheap part of a
+// step (nearest-voxel read, empty-space / far-field advance) and a lane leaves it as soon as its value lies
+// inside the truncation band; the expensive trilinear read (band steps and the post-hit refinement alike)
+// sits after the inner loop.  SIMT reconvergence then does the scheduling: lanes that need a trilinear
+// read wait while the other lanes of the wave take up to ITM_RAY_MARCH_BURST cheap steps, then the
+// trilinear code runs once for all of them -- instead of once per iteration in which ANY lane happens to
+// be in the band.  Per ray the sequence of positions, reads and float operations is exactly that of
+// cast_ray (and of the reference), so results are bit-identical.
+//
+// Measured on MI355X (config 2, tools/wave_stats.py per-wave cycle traces): the kernel lasts as long as its
+// slowest wave (rays that pass the sphere and run ~45 empty-space steps to the wall); a cold voxel/hash
+// line costs ~2 000 cycles per dependent round trip, a trilinear step ~4 500.  Burst 1 (= the plain loop)
+// 69 us, 2: 65, 3: 64, 4: 62, 8: 66, unbounded: 95 (lanes then serialise each other's empty-space runs).
+// Neither a leaner trilinear (upper bound tried with ITM_EXP_SIMPLE_TRILINEAR: no change), nor the
+// empty-space look-ahead (ITM_RAY_MISS_LOOKAHEAD, desynchronises the lanes' arrival at the surface: +5 us),
+// nor a z-column prefetch at block entry (ITM_RAY_PREFETCH_COLUMN: +12 us) help on top of it.
+template <class VX, bool DENSE>
+__device__ inline float4 cast_ray_ww(int x, int y, const VolumeView& vol, const RayParams& p, float2 mm) {
+  enum : int { MARCH = 0, TRI = 1, REFINE = 2, DONE = 3 };
+  const float stepScale = p.mu * p.oneOverVoxel;
+  float pcz = mm.x;
+  float pcx = pcz * (((float)x - p.cx) * p.ifx);
+  float pcy = pcz * (((float)y - p.cy) * p.ify);
+  float acc = 0.0f; acc += pcx * pcx; acc += pcy * pcy; acc += pcz * pcz;
+  float total = sqrtf(acc) * p.oneOverVoxel;
+  Vec3 t = transform_point(p.invM, pcx, pcy, pcz);
+  const float sx = t.x * p.oneOverVoxel, sy = t.y * p.oneOverVoxel, sz = t.z * p.oneOverVoxel;
+  pcz = mm.y;
+  pcx = pcz * (((float)x - p.cx) * p.ifx);
+  pcy = pcz * (((float)y - p.cy) * p.ify);
+  acc = 0.0f; acc += pcx * pcx; acc += pcy * pcy; acc += pcz * pcz;
+  const float totalMax = sqrtf(acc) * p.oneOverVoxel;
+  t = transform_point(p.invM, pcx, pcy, pcz);
+  float dx = t.x * p.oneOverVoxel - sx, dy = t.y * p.oneOverVoxel - sy, dz = t.z * p.oneOverVoxel - sz;
+  const float dn = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+  dx *= dn; dy *= dn; dz *= dn;
+  float px = sx, py = sy, pz = sz;
+  BlockCache cache;
+  bool found;
+  float w = 0.0f;
+  int st = (total < totalMax) ? MARCH : DONE;
+  ITM_WT(const unsigned long long wtStart = wt_clock(); unsigned wtOuter = 0;)
+  while (st != DONE) {
+    ITM_WT(const unsigned long long wt0 = wt_clock(); unsigned wtInner = 0; const unsigned wtLanes0 = __popcll(__ballot(1)); const unsigned wtMarch0 = __popcll(__ballot(st == MARCH));)
+    // ---- cheap phase: at most ITM_RAY_MARCH_BURST steps, so that waiting lanes are served regularly ----
+    int budget = ITM_RAY_MARCH_BURST;
+    while (st == MARCH && budget > 0) {
+      --budget;
+      ITM_WT(++wtInner;)
+      const float sdf = sdf_nearest<VX, DENSE>(vol, px, py, pz, found, cache);
+      if (!found) {
+        const float ex = (float)kBlockSide * dx, ey = (float)kBlockSide * dy, ez = (float)kBlockSide * dz;
+        px += ex; py += ey; pz += ez; total += (float)kBlockSide;
+#if ITM_RAY_MISS_LOOKAHEAD > 0
+        if (!DENSE) {
+          // A miss advances the ray by exactly one block side, and so does every following miss: the next
+          // positions (accumulated one add at a time, as the sequential loop does) are known in advance.
+          // Their occupancy bits are loaded together (one round trip instead of K dependent ones) and the
+          // ray jumps over the leading run of provably empty buckets.  A set bit or the end of the range
+          // stops the run; that position is examined by the normal path.
+          constexpr int K = ITM_RAY_MISS_LOOKAHEAD;
+          float qx[K], qy[K], qz[K], qt[K];
+          uint32_t occ[K];
+          float ax = px, ay = py, az = pz, at = total;
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            const int idx = hash_index((int)round_ref(ax) >> 3, (int)round_ref(ay) >> 3, (int)round_ref(az) >> 3, vol.mask);
+            occ[k] = (vol.headBits[idx >> 5] >> (idx & 31)) & 1u;
+            if (!(at < totalMax)) occ[k] = 1u;
+            ax += ex; ay += ey; az += ez; at += (float)kBlockSide;
+            qx[k] = ax; qy[k] = ay; qz[k] = az; qt[k] = at;
+          }
+          bool go = true;
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            go = go && (occ[k] == 0u);
+            if (go) { px = qx[k]; py = qy[k]; pz = qz[k]; total = qt[k]; }
+          }
+        }
+#endif
+        if (!(total < totalMax)) st = DONE;
+      } else if ((sdf <= 0.1f) && (sdf >= -0.5f)) {
+        st = TRI;                        // the position is kept for the trilinear read
+      } else if (sdf <= 0.0f) {
+        // surface crossed on the nearest value (below the band): first refinement move
+        const float step = sdf * stepScale;
+        px += step * dx; py += step * dy; pz += step * dz;
+        st = REFINE;
+      } else {
+        const float s = sdf * stepScale;
+        const float step = (s < 1.0f) ? 1.0f : s;
+        px += step * dx; py += step * dy; pz += step * dz;
+        total += step;
+        if (!(total < totalMax)) st = DONE;
+      }
+    }
+    // ---- expensive phase: one trilinear read for every lane that waits for one ------------------------
+    ITM_WT(const unsigned long long wtA = wt_clock(); const unsigned wtTriLanes = __popcll(__ballot(st == TRI || st == REFINE)); wtInner = (unsigned)wt_wave_max(wtInner);)
+    if (st == TRI || st == REFINE) {
+      const float sdf = sdf_trilinear<VX, DENSE>(vol, px, py, pz, found, cache);
+      if (st == REFINE) {
+        const float step = sdf * stepScale;
+        px += step * dx; py += step * dy; pz += step * dz;
+        w = 1.0f; st = DONE;
+      } else if (sdf <= 0.0f) {
+        const float step = sdf * stepScale;
+        px += step * dx; py += step * dy; pz += step * dz;
+        st = REFINE;
+      } else {
+        const float s = sdf * stepScale;
+        const float step = (s < 1.0f) ? 1.0f : s;
+        px += step * dx; py += step * dy; pz += step * dz;
+        total += step;
+        st = (total < totalMax) ? MARCH : DONE;
+      }
+    }
+    ITM_WT({ const float keep2 = total + px; asm volatile("" :: "v"(keep2)); const unsigned long long tB = wt_clock();
+      const unsigned wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+      if ((wv & 31) == 1 && (wv >> 5) < 160 && wtOuter < 64) { unsigned long long* tr = g_waveTrace + ((size_t)(wv >> 5) * 64 + wtOuter) * 4; tr[0] = wt0 - wtStart; tr[1] = wtA - wtStart; tr[2] = tB - wtStart; tr[3] = wtLanes0 | (wtMarch0 << 8) | (wtTriLanes << 16) | (wtInner << 24); }
+      ++wtOuter; })
+  }
+#if ITM_EXP_WAVE_TIMING
+  {
+    const unsigned long long wtEnd = wt_clock();
+    const unsigned wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const unsigned long long mOuter = wt_wave_max(wtOuter);
+    if ((threadIdx.x & 63) == 0 && wv < 8192) { unsigned long long* o = g_waveStats + (size_t)wv * 12; o[0] = wtEnd - wtStart; o[1] = mOuter; }
+  }
+#endif
   return make_float4(px, py, pz, w);
 }
 

@@ -227,6 +227,8 @@ __device__ inline float4 cast_ray_any(int x, int y, const VolumeView& vol, const
 #if ITM_RAY_STATE_MACHINE
   if constexpr (!DENSE) return cast_ray_sm<VX>(x, y, vol, p, mm);
   else return cast_ray<VX, DENSE>(x, y, vol, p, mm);
+#elif ITM_RAY_WHILE_WHILE
+  return cast_ray_ww<VX, DENSE>(x, y, vol, p, mm);
 #else
   return cast_ray<VX, DENSE>(x, y, vol, p, mm);
 #endif

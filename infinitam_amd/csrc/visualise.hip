@@ -500,3 +500,12 @@ int itm_process_frame(itm_scene* s, const itm_view* v, itm_render_state* rs, flo
 }
 
 }  // extern "C"
+
+#if ITM_EXP_WAVE_TIMING
+extern "C" int itm_debug_read_wave_stats(unsigned long long* dst, int n) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(itm::g_waveStats), (size_t)n * 8);
+}
+extern "C" int itm_debug_read_wave_trace(unsigned long long* dst, int n) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(itm::g_waveTrace), (size_t)n * 8);
+}
+#endif

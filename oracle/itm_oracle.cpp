@@ -202,6 +202,8 @@ struct Stats {
   long long fuse_blocks, fuse_voxels_visited, fuse_voxels_updated;
 };
 Stats g_stats;
+int* g_rayTrace = nullptr;  // optional per-ray (steps, band steps, not-found steps) dump, width in g_rayTraceW
+int g_rayTraceW = 0;
 
 inline int floor_div8(int p) { return ((p < 0) ? p - 7 : p) / 8; }
 
@@ -694,13 +696,14 @@ bool cast_ray(V4f& out, int x, int y, const Reader<V>& rd, const float* invM, fl
   bool found;
   float step;
   long long steps = 0;
+  int bandSteps = 0, missSteps = 0;
   while (total < totalMax) {
     ++steps;
     sdf = rd.nearest(pt, found, cache);
     if (!found) {
-      step = (float)ITM_SDF_BLOCK_SIZE;
+      step = (float)ITM_SDF_BLOCK_SIZE; ++missSteps;
     } else {
-      if ((sdf <= 0.1f) && (sdf >= -0.5f)) sdf = rd.trilinear(pt, found, cache);
+      if ((sdf <= 0.1f) && (sdf >= -0.5f)) { sdf = rd.trilinear(pt, found, cache); ++bandSteps; }
       if (sdf <= 0.0f) break;
       step = fmax_ref(sdf * stepScale, 1.0f);
     }
@@ -708,6 +711,7 @@ bool cast_ray(V4f& out, int x, int y, const Reader<V>& rd, const float* invM, fl
     total += step;
   }
   ++g_stats.rays; g_stats.ray_steps += steps;
+  if (g_rayTrace) { int* r = g_rayTrace + 3 * (x + y * g_rayTraceW); r[0] = (int)steps; r[1] = bandSteps; r[2] = missSteps; }
   if (steps > g_stats.max_ray_steps) g_stats.max_ray_steps = steps;
   bool hit;
   if (sdf <= 0.0f) {
@@ -1221,6 +1225,7 @@ int itmo_upload(itm_scene* s, itm_render_state* rs, int which, const void* src, 
 }
 
 // test-only: read (and optionally clear) the work counters; 15 int64 values
+int itmo_debug_ray_trace(int* buf, int width) { g_rayTrace = buf; g_rayTraceW = width; return 0; }
 int itmo_debug_stats(long long* out, int clear) {
   if (out) std::memcpy(out, &g_stats, sizeof g_stats);
   if (clear) std::memset(&g_stats, 0, sizeof g_stats);
