@@ -74,8 +74,10 @@ __device__ inline int floor_div8(int p) { return ((p < 0) ? p - 7 : p) / 8; }
 __device__ inline float round_ref(float x) { return x + __builtin_copysignf(0.5f, x); }
 
 // Linear voxel index of integer point (px,py,pz), or -1 when no voxel is stored there.
+// `guard`: consult the occupancy bitmap first (one extra dependent round trip when the block exists, but an absent
+// block is then proven by a 4-byte L2-resident read instead of a 16-byte entry fetch from a 19 MB table).
 template <bool DENSE>
-__device__ inline long long locate_voxel(const VolumeView& vol, int px, int py, int pz, BlockCache& cache) {
+__device__ inline long long locate_voxel(const VolumeView& vol, int px, int py, int pz, BlockCache& cache, bool guard = true) {
   if (DENSE) {
     const int qx = px - vol.ox, qy = py - vol.oy, qz = pz - vol.oz;
     if (qx < 0 || qx >= vol.sx || qy < 0 || qy >= vol.sy || qz < 0 || qz >= vol.sz) return -1;
@@ -87,7 +89,7 @@ __device__ inline long long locate_voxel(const VolumeView& vol, int px, int py, 
     int idx = hash_index(bx, by, bz, vol.mask);
 #if ITM_RAY_BITMAP_GUARD
     // the 16-byte entry is only fetched when the occupancy bit says the bucket is in use
-    if (!((vol.headBits[idx >> 5] >> (idx & 31)) & 1u)) return -1;
+    if (guard && !((vol.headBits[idx >> 5] >> (idx & 31)) & 1u)) return -1;
 #endif
     HashEntry e = unpack_entry(vol.hash[idx]);
     for (;;) {
@@ -104,11 +106,11 @@ __device__ inline long long locate_voxel(const VolumeView& vol, int px, int py, 
 
 // raw (unconverted) sdf of the voxel at an integer point; the default voxel when absent
 template <class VX, bool DENSE>
-__device__ inline float read_raw_sdf(const VolumeView& vol, int px, int py, int pz, bool& found, BlockCache& cache) {
+__device__ inline float read_raw_sdf(const VolumeView& vol, int px, int py, int pz, bool& found, BlockCache& cache, bool guard = true) {
 #if ITM_RAY_PREFETCH_COLUMN
   const int prevBase = cache.base;
 #endif
-  const long long a = locate_voxel<DENSE>(vol, px, py, pz, cache);
+  const long long a = locate_voxel<DENSE>(vol, px, py, pz, cache, guard);
   found = a >= 0;
   if (!found) return VX::kShort ? 32767.0f : 1.0f;
   const float v = VX::load_raw_sdf(vol.vba, (size_t)a);
@@ -128,8 +130,8 @@ __device__ inline float read_raw_sdf(const VolumeView& vol, int px, int py, int 
 }
 
 template <class VX, bool DENSE>
-__device__ inline float sdf_nearest(const VolumeView& vol, float x, float y, float z, bool& found, BlockCache& cache) {
-  return VX::to_float(read_raw_sdf<VX, DENSE>(vol, (int)round_ref(x), (int)round_ref(y), (int)round_ref(z), found, cache));
+__device__ inline float sdf_nearest(const VolumeView& vol, float x, float y, float z, bool& found, BlockCache& cache, bool guard = true) {
+  return VX::to_float(read_raw_sdf<VX, DENSE>(vol, (int)round_ref(x), (int)round_ref(y), (int)round_ref(z), found, cache, guard));
 }
 
 // Walks the excess chain starting from an already loaded head entry; block base or -1.
@@ -213,12 +215,15 @@ struct Corners {
   // readFromSDF_float_uninterpolated at the same point: the voxel at ROUND(p) is corner
   // (ROUND(p) - floor(p)) in {0,1}^3
   __device__ inline float nearest(float x, float y, float z, bool& found) const {
-    const int c = ((int)round_ref(x) - ix) | (((int)round_ref(y) - iy) << 1) | (((int)round_ref(z) - iz) << 2);
-    float val = v[0]; bool pr = present[0];
-#pragma unroll
-    for (int k = 1; k < 8; ++k) if (c == k) { val = v[k]; pr = present[k]; }
-    found = pr;
-    return VX::to_float(val);
+    // a tree of selects on the three offset bits (a chain of `if (c == k)` gets turned into a dynamically indexed
+    // array by the optimiser, which then moves v[] to LDS: +30 us on the kernel)
+    const bool bx = ((int)round_ref(x) - ix) != 0, by = ((int)round_ref(y) - iy) != 0, bz = ((int)round_ref(z) - iz) != 0;
+    const float x0 = bx ? v[1] : v[0], x1 = bx ? v[3] : v[2], x2 = bx ? v[5] : v[4], x3 = bx ? v[7] : v[6];
+    const bool p0 = bx ? present[1] : present[0], p1 = bx ? present[3] : present[2], p2 = bx ? present[5] : present[4], p3 = bx ? present[7] : present[6];
+    const float y0 = by ? x1 : x0, y1 = by ? x3 : x2;
+    const bool q0 = by ? p1 : p0, q1 = by ? p3 : p2;
+    found = bz ? q1 : q0;
+    return VX::to_float(bz ? y1 : y0);
   }
 };
 
@@ -447,6 +452,12 @@ __device__ inline float4 cast_ray(int x, int y, const VolumeView& vol, const Ray
 #ifndef ITM_RAY_WHILE_WHILE
 #define ITM_RAY_WHILE_WHILE 1
 #endif
+#ifndef ITM_RAY_ADAPTIVE_GUARD
+#define ITM_RAY_ADAPTIVE_GUARD 0  // skip the occupancy-bitmap round trip while the ray is in allocated territory; measured 63.0 vs 61.5 us: off
+#endif
+#ifndef ITM_RAY_PREDICT_TRI
+#define ITM_RAY_PREDICT_TRI 0     // after a band step, fetch the 2x2x2 neighbourhood at the next position directly; measured 72 vs 61.5 us: off
+#endif
 #ifndef ITM_RAY_MARCH_BURST
 #define ITM_RAY_MARCH_BURST 4   // cheap steps a lane may take before the wave serves the lanes waiting for a trilinear read
 #endif
@@ -469,7 +480,7 @@ __device__ inline float4 cast_ray(int x, int y, const VolumeView& vol, const Ray
 // nor a z-column prefetch at block entry (ITM_RAY_PREFETCH_COLUMN: +12 us) help on top of it.
 template <class VX, bool DENSE>
 __device__ inline float4 cast_ray_ww(int x, int y, const VolumeView& vol, const RayParams& p, float2 mm) {
-  enum : int { MARCH = 0, TRI = 1, REFINE = 2, DONE = 3 };
+  enum : int { MARCH = 0, TRI = 1, REFINE = 2, DONE = 3, TRIP = 4 };
   const float stepScale = p.mu * p.oneOverVoxel;
   float pcz = mm.x;
   float pcx = pcz * (((float)x - p.cx) * p.ifx);
@@ -492,6 +503,7 @@ __device__ inline float4 cast_ray_ww(int x, int y, const VolumeView& vol, const 
   bool found;
   float w = 0.0f;
   int st = (total < totalMax) ? MARCH : DONE;
+  bool inAllocated = true;   // rays start at the near face of the visible blocks' bounding range
   ITM_WT(const unsigned long long wtStart = wt_clock(); unsigned wtOuter = 0;)
   while (st != DONE) {
     ITM_WT(const unsigned long long wt0 = wt_clock(); unsigned wtInner = 0; const unsigned wtLanes0 = __popcll(__ballot(1)); const unsigned wtMarch0 = __popcll(__ballot(st == MARCH));)
@@ -500,7 +512,8 @@ __device__ inline float4 cast_ray_ww(int x, int y, const VolumeView& vol, const 
     while (st == MARCH && budget > 0) {
       --budget;
       ITM_WT(++wtInner;)
-      const float sdf = sdf_nearest<VX, DENSE>(vol, px, py, pz, found, cache);
+      const float sdf = sdf_nearest<VX, DENSE>(vol, px, py, pz, found, cache, !(ITM_RAY_ADAPTIVE_GUARD && inAllocated));
+      inAllocated = found;
       if (!found) {
         const float ex = (float)kBlockSide * dx, ey = (float)kBlockSide * dy, ez = (float)kBlockSide * dz;
         px += ex; py += ey; pz += ez; total += (float)kBlockSide;
@@ -548,23 +561,44 @@ __device__ inline float4 cast_ray_ww(int x, int y, const VolumeView& vol, const 
       }
     }
     // ---- expensive phase: one trilinear read for every lane that waits for one ------------------------
-    ITM_WT(const unsigned long long wtA = wt_clock(); const unsigned wtTriLanes = __popcll(__ballot(st == TRI || st == REFINE)); wtInner = (unsigned)wt_wave_max(wtInner);)
-    if (st == TRI || st == REFINE) {
-      const float sdf = sdf_trilinear<VX, DENSE>(vol, px, py, pz, found, cache);
-      if (st == REFINE) {
-        const float step = sdf * stepScale;
-        px += step * dx; py += step * dy; pz += step * dz;
-        w = 1.0f; st = DONE;
-      } else if (sdf <= 0.0f) {
-        const float step = sdf * stepScale;
-        px += step * dx; py += step * dy; pz += step * dz;
-        st = REFINE;
-      } else {
-        const float s = sdf * stepScale;
-        const float step = (s < 1.0f) ? 1.0f : s;
-        px += step * dx; py += step * dy; pz += step * dz;
-        total += step;
-        st = (total < totalMax) ? MARCH : DONE;
+    ITM_WT(const unsigned long long wtA = wt_clock(); const unsigned wtTriLanes = __popcll(__ballot(st == TRI || st == REFINE || st == TRIP)); wtInner = (unsigned)wt_wave_max(wtInner);)
+    if (st == TRI || st == REFINE || st == TRIP) {
+      Corners<VX, DENSE> cn;
+      cn.fetch(vol, px, py, pz, cache);
+      float sdf;
+      bool band = true;
+      if (st == TRIP) {
+        // predicted band step: the nearest voxel is one of the fetched corners; redo the decision of the cheap
+        // phase on it (same value, same tests) and fall back to its outcome when the ray has left the band
+        sdf = cn.nearest(px, py, pz, found);
+        inAllocated = found;
+        band = found && (sdf <= 0.1f) && (sdf >= -0.5f);
+        if (!band) {
+          float step;
+          if (!found) { step = (float)kBlockSide; st = MARCH; }
+          else if (sdf <= 0.0f) { step = sdf * stepScale; st = REFINE; }
+          else { const float s = sdf * stepScale; step = (s < 1.0f) ? 1.0f : s; st = MARCH; }
+          px += step * dx; py += step * dy; pz += step * dz;
+          if (st == MARCH) { total += step; if (!(total < totalMax)) st = DONE; }
+        }
+      }
+      if (band) {
+        sdf = cn.trilinear();
+        if (st == REFINE) {
+          const float step = sdf * stepScale;
+          px += step * dx; py += step * dy; pz += step * dz;
+          w = 1.0f; st = DONE;
+        } else if (sdf <= 0.0f) {
+          const float step = sdf * stepScale;
+          px += step * dx; py += step * dy; pz += step * dz;
+          st = REFINE;
+        } else {
+          const float s = sdf * stepScale;
+          const float step = (s < 1.0f) ? 1.0f : s;
+          px += step * dx; py += step * dy; pz += step * dz;
+          total += step;
+          st = (total < totalMax) ? (ITM_RAY_PREDICT_TRI ? TRIP : MARCH) : DONE;
+        }
       }
     }
     ITM_WT({ const float keep2 = total + px; asm volatile("" :: "v"(keep2)); const unsigned long long tB = wt_clock();
