@@ -15,8 +15,12 @@
 #include <cstring>
 
 #include "itm_internal.h"
+#include "range_device.h"
 
 namespace itm {
+
+int g_debug_integrate_wgs = 0;
+int g_debug_no_fused_projection = 0;
 
 struct FuseParams {
   Mat4 M_d, M_rgb;
@@ -159,17 +163,18 @@ __device__ inline int block_band(int bx, int by, int bz, const FuseParams& p) {
   return b < 7 ? b : 7;
 }
 
+// One 8x8x8 block per 512-lane workgroup iteration; workgroup `wgIdx` of `wgCount` persistent workgroups.
 template <class VX>
-__global__ void __launch_bounds__(512) integrate_hash_kernel(const int32_t* __restrict__ visibleIds, const RenderCounters* __restrict__ rc,
-                                                             const uint4* __restrict__ hash, void* __restrict__ vba,
-                                                             const float* __restrict__ depth, const uchar4* __restrict__ rgb, FuseParams p) {
+__device__ inline void integrate_hash_body(int wgIdx, int wgCount, const int32_t* __restrict__ visibleIds, const RenderCounters* __restrict__ rc,
+                                           const uint4* __restrict__ hash, void* __restrict__ vba,
+                                           const float* __restrict__ depth, const uchar4* __restrict__ rgb, const FuseParams& p) {
   const int nv = rc->noVisibleEntries;
   const int t = threadIdx.x;
   const int x = t & 7, y = (t >> 3) & 7, z = t >> 6;
 #if ITM_XCD_AFFINITY
   // The workgroups of XCD k (blockIdx % 8 == k) filter the visible list for the blocks of image band k: every
   // wave tests the same 64 entries (one per lane) and the workgroup then integrates the matching blocks.
-  const int lane = t & 63, xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, nWg = gridDim.x >> 3;
+  const int lane = t & 63, xcd = wgIdx & 7, wg = wgIdx >> 3, nWg = wgCount >> 3;
   for (int c0 = wg * 64; c0 < nv; c0 += nWg * 64) {
     const int e = c0 + lane;
     HashEntry he; he.px = he.py = he.pz = 0; he.ptr = -1; he.offset = 0;
@@ -193,7 +198,7 @@ __global__ void __launch_bounds__(512) integrate_hash_kernel(const int32_t* __re
     }
   }
 #else
-  for (int e = blockIdx.x; e < nv; e += gridDim.x) {
+  for (int e = wgIdx; e < nv; e += wgCount) {
     const HashEntry he = unpack_entry(hash[visibleIds[e]]);
     if (he.ptr < 0) continue;
     const size_t vi = (size_t)he.ptr * kBlockVoxels + t;
@@ -205,6 +210,31 @@ __global__ void __launch_bounds__(512) integrate_hash_kernel(const int32_t* __re
     if (fuse_voxel<VX>(r, mx, my, mz, depth, rgb, p)) VX::store(vba, vi, r);
   }
 #endif
+}
+
+template <class VX>
+__global__ void __launch_bounds__(512) integrate_hash_kernel(const int32_t* __restrict__ visibleIds, const RenderCounters* __restrict__ rc,
+                                                             const uint4* __restrict__ hash, void* __restrict__ vba,
+                                                             const float* __restrict__ depth, const uchar4* __restrict__ rgb, FuseParams p) {
+  integrate_hash_body<VX>(blockIdx.x, gridDim.x, visibleIds, rc, hash, vba, depth, rgb, p);
+}
+
+// IntegrateIntoScene and the projection half of CreateExpectedDepths in ONE launch: both only depend on the
+// visible list, integration is ALU bound on every CU while the kRangeParts projection workgroups are bound by
+// LDS atomics on 32 CUs, so they overlap almost perfectly (17 + 11.5 us as two launches -> ~19 us).  The first
+// kRangeParts workgroups project, the others are the persistent integration workgroups.
+template <class VX>
+__global__ void __launch_bounds__(512) integrate_project_kernel(const int32_t* __restrict__ visibleIds, RenderCounters* __restrict__ rc,
+                                                                const uint4* __restrict__ hash, void* __restrict__ vba,
+                                                                const float* __restrict__ depth, const uchar4* __restrict__ rgb, FuseParams p,
+                                                                float2* __restrict__ range, uint4* __restrict__ projBuf, uint2* __restrict__ partials,
+                                                                ProjParams pp, int RW, int RH) {
+  extern __shared__ uint2 cells[];
+  if (blockIdx.x < kRangeParts) {
+    project_partial_body(blockIdx.x, cells, visibleIds, rc, hash, range, projBuf, partials, pp, RW, RH);
+    return;
+  }
+  integrate_hash_body<VX>(blockIdx.x - kRangeParts, gridDim.x - kRangeParts, visibleIds, rc, hash, vba, depth, rgb, p);
 }
 
 // Dense volume, generic voxel type: one voxel per lane, x fastest (coalesced).
@@ -287,7 +317,9 @@ __global__ void __launch_bounds__(256) integrate_dense_s_x4_kernel(uint4* __rest
   if (idx < plane && !culled(idx)) process(idx, slice[idx]);
 }
 
-int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipStream_t st) {
+// `fuseProjection`: also run the projection half of CreateExpectedDepths (hash scenes whose sub-sampled range image
+// fits four times in LDS; the caller checked can_fuse_projection and launches range_reduce afterwards).
+int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipStream_t st, bool fuseProjection) {
   FuseParams p;
   memcpy(p.M_d.m, v->M_d, 64);
   matmul4(v->rgb_to_depth_inv, v->M_d, p.M_rgb.m);  // calib_inv * M_d (_CPU.cpp:61)
@@ -309,10 +341,22 @@ int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipS
 
   KernelTimer tk(s, ITM_TK_INTEGRATE, st);
   if (s->cfg.indexType == ITM_INDEX_HASH) {
-    const int grid = 256 * 4;  // 4 x 512-lane workgroups per CU
+    // 4 x 512-lane workgroups per CU; with the projection fused in, the 38 KB LDS image limits residency to 3 per CU
+    const int grid = g_debug_integrate_wgs > 0 ? g_debug_integrate_wgs : (fuseProjection ? 256 * 3 : 256 * 4);
+    ProjParams pp;
+    const int RW = (rs->w + 7) / 8, RH = (rs->h + 7) / 8;
+    if (fuseProjection) {
+      memcpy(pp.M.m, v->M_d, 64);
+      pp.fx = v->intr_d[0]; pp.fy = v->intr_d[1]; pp.cx = v->intr_d[2]; pp.cy = v->intr_d[3];
+      pp.voxelSize = s->prm.voxelSize; pp.W = rs->w; pp.H = rs->h; pp.maxBlocks = s->cfg.maxRenderingBlocks;
+    }
     int rc = dispatch_voxel(s->cfg.voxelType, [&](auto vx) {
       using VX = decltype(vx);
-      integrate_hash_kernel<VX><<<grid, 512, 0, st>>>(rs->visibleIds, rs->counters, s->hash, s->vba, v->depth, rgb, p);
+      if (fuseProjection)
+        integrate_project_kernel<VX><<<grid, 512, (size_t)RW * RH * sizeof(uint2), st>>>(rs->visibleIds, rs->counters, s->hash, s->vba, v->depth, rgb, p,
+                                                                                       rs->range, rs->projBuf, rs->rangePartials, pp, RW, RH);
+      else
+        integrate_hash_kernel<VX><<<grid, 512, 0, st>>>(rs->visibleIds, rs->counters, s->hash, s->vba, v->depth, rgb, p);
       return ITM_OK;
     });
     if (rc) return rc;
@@ -350,5 +394,5 @@ extern "C" int itm_integrate_into_scene(itm_scene* s, const itm_view* v, itm_ren
   if (!s || !v || !rs) return set_error(ITM_ERR_INVALID, "null argument");
   if (!v->depth) return set_error(ITM_ERR_INVALID, "null depth image");
   if (rs->scene != s) return set_error(ITM_ERR_INVALID, "render state belongs to another scene");
-  return launch_integrate(s, v, rs, as_stream(stream));
+  return launch_integrate(s, v, rs, as_stream(stream), false);
 }

@@ -143,13 +143,16 @@ inline int dispatch_voxel(int voxelType, F&& f) {
 
 // entry points implemented per translation unit
 extern int g_debug_explicit_mark;
+extern int g_debug_integrate_wgs;
+extern int g_debug_no_fused_projection;
 int rebuild_head_bits(itm_scene* s, hipStream_t st);
 int launch_request_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, bool onlyVisible, bool fuseRangeInit, hipStream_t st);
 int launch_sweep_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, bool onlyVisible, hipStream_t st);
 int launch_allocate(itm_scene* s, const itm_view* v, itm_render_state* rs, bool onlyVisible, bool fuseRangeInit, hipStream_t st);
-int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipStream_t st);
+int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipStream_t st, bool fuseProjection = false);
+bool can_fuse_projection(const itm_scene* s, const itm_render_state* rs);
 int launch_find_visible(const itm_scene* s, const float* M, const float* intr, itm_render_state* rs, hipStream_t st);
-int launch_expected_depths(const itm_scene* s, const float* M, const float* intr, itm_render_state* rs, bool rangeAlreadyInit, hipStream_t st);
+int launch_expected_depths(const itm_scene* s, const float* M, const float* intr, itm_render_state* rs, bool rangeAlreadyInit, hipStream_t st, bool projected = false);
 int launch_raycast(const itm_scene* s, const float* invM, const float* intr, itm_render_state* rs, float4* dst, hipStream_t st);
 int launch_icp_maps(const itm_scene* s, const itm_view* v, itm_render_state* rs, float4* points, float4* normals, hipStream_t st);
 int launch_render_image(const itm_scene* s, const float* M, const float* intr, itm_render_state* rs, uchar4* out, int type, hipStream_t st);

@@ -23,6 +23,7 @@
 
 #include "itm_internal.h"
 #include "shading_device.h"
+#include "range_device.h"
 #include "wave_utils.h"
 
 #ifndef ITM_RAY_WAVE_8X8
@@ -39,58 +40,10 @@ int g_debug_force_global_range = 0;
 // ---------------------------------------------------------------------------------------------
 // expected depth range
 // ---------------------------------------------------------------------------------------------
-struct ProjParams {
-  Mat4 M;
-  float fx, fy, cx, cy;
-  float voxelSize;
-  int W, H;
-  int maxBlocks;
-};
-
 __global__ void __launch_bounds__(256) range_init_kernel(float2* __restrict__ img, int n, float a, float b, RenderCounters* rc) {
   const int stride = gridDim.x * blockDim.x;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) img[i] = make_float2(a, b);
   if (blockIdx.x == 0 && threadIdx.x == 0) rc->noRenderingBlocks = 0;
-}
-
-struct Projected { int ulx, uly, lrx, lry; float z0, z1; int n; };
-
-// ProjectSingleBlock + the tile count of CreateExpectedDepths (:128-131)
-__device__ inline Projected project_block(const HashEntry& e, const ProjParams& p) {
-  Projected r;
-  r.ulx = p.W / 8; r.uly = p.H / 8; r.lrx = -1; r.lry = -1; r.z0 = 999999.9f; r.z1 = 0.05f; r.n = 0;
-  if (e.ptr < 0) return r;
-#pragma unroll
-  for (int corner = 0; corner < 8; ++corner) {
-    const int16_t tx = (int16_t)(e.px + ((corner & 1) ? 1 : 0));
-    const int16_t ty = (int16_t)(e.py + ((corner & 2) ? 1 : 0));
-    const int16_t tz = (int16_t)(e.pz + ((corner & 4) ? 1 : 0));
-    const float x = (float)tx * (float)kBlockSide * p.voxelSize;
-    const float y = (float)ty * (float)kBlockSide * p.voxelSize;
-    const float z = (float)tz * (float)kBlockSide * p.voxelSize;
-    const Vec3 q = transform_point(p.M, x, y, z);
-    if ((double)q.z < 1e-6) continue;  // double literal in the reference
-    const float u = (p.fx * q.x / q.z + p.cx) / 8;
-    const float v = (p.fy * q.y / q.z + p.cy) / 8;
-    if ((float)r.ulx > floorf(u)) r.ulx = (int)floorf(u);
-    if ((float)r.lrx < ceilf(u)) r.lrx = (int)ceilf(u);
-    if ((float)r.uly > floorf(v)) r.uly = (int)floorf(v);
-    if ((float)r.lry < ceilf(v)) r.lry = (int)ceilf(v);
-    if (r.z0 > q.z) r.z0 = q.z;
-    if (r.z1 < q.z) r.z1 = q.z;
-  }
-  if (r.ulx < 0) r.ulx = 0;
-  if (r.uly < 0) r.uly = 0;
-  if (r.lrx >= p.W) r.lrx = p.W - 1;
-  if (r.lry >= p.H) r.lry = p.H - 1;
-  if (r.ulx > r.lrx) return r;
-  if (r.uly > r.lry) return r;
-  if (r.z0 < 0.05f) r.z0 = 0.05f;
-  if (r.z1 < 0.05f) return r;
-  const int nx = (int)ceilf((float)(r.lrx - r.ulx + 1) / 16.0f);
-  const int ny = (int)ceilf((float)(r.lry - r.uly + 1) / 16.0f);
-  r.n = nx * ny;
-  return r;
 }
 
 __device__ inline void merge_box(float2* __restrict__ range, int W, const Projected& r) {
@@ -165,46 +118,12 @@ __global__ void __launch_bounds__(256) range_overflow_kernel(RenderCounters* __r
 //   range_reduce_kernel    : one workgroup reduces the partial images into the range image; if the
 //       rendering-block cap of the reference was reached it instead replays the sequential
 //       accept / skip decisions and rebuilds the image from the accepted boxes.
-constexpr int kRangeParts = 32;
-
 __global__ void __launch_bounds__(512) project_partial_kernel(const int32_t* __restrict__ ids, RenderCounters* __restrict__ rc,
                                                               const uint4* __restrict__ hash, float2* __restrict__ range,
                                                               uint4* __restrict__ projBuf, uint2* __restrict__ partials,
                                                               ProjParams p, int RW, int RH) {
   extern __shared__ uint2 cells[];
-  __shared__ int lds[8];
-  const int tid = threadIdx.x;
-  const int nCells = RW * RH;
-  const uint2 initCell = make_uint2(__float_as_uint(999999.9f), __float_as_uint(0.05f));
-  for (int i = tid; i < nCells; i += 512) cells[i] = initCell;
-  __syncthreads();
-  const int nv = rc->noVisibleEntries;
-  int need = 0;
-  for (int e = blockIdx.x * 512 + tid; e < nv; e += kRangeParts * 512) {
-    const HashEntry he = unpack_entry(hash[ids[e]]);
-    const Projected r = project_block(he, p);
-    projBuf[2 * e] = make_uint4((uint32_t)r.ulx, (uint32_t)r.uly, (uint32_t)r.lrx, (uint32_t)r.lry);
-    projBuf[2 * e + 1] = make_uint4(__float_as_uint(r.z0), __float_as_uint(r.z1), (uint32_t)r.n, 1u);
-    if (r.n == 0) continue;
-    need += r.n;
-    const uint32_t z0 = __float_as_uint(r.z0), z1 = __float_as_uint(r.z1);
-    for (int y = r.uly; y <= r.lry; ++y)
-      for (int x = r.ulx; x <= r.lrx; ++x) {
-        if (x < RW && y < RH) {
-          atomicMin(&cells[x + y * RW].x, z0);
-          atomicMax(&cells[x + y * RW].y, z1);
-        } else {
-          uint32_t* px = (uint32_t*)&range[x + y * p.W];
-          atomicMin(px, z0);
-          atomicMax(px + 1, z1);
-        }
-      }
-  }
-  const int sum = block_reduce_sum<8>(need, lds);
-  if (tid == 0 && sum) atomicAdd(&rc->noRenderingBlocks, sum);
-  __syncthreads();
-  uint2* mine = partials + (size_t)blockIdx.x * nCells;
-  for (int i = tid; i < nCells; i += 512) mine[i] = cells[i];
+  project_partial_body(blockIdx.x, cells, ids, rc, hash, range, projBuf, partials, p, RW, RH);
 }
 
 __global__ void __launch_bounds__(256) range_reduce_kernel(RenderCounters* __restrict__ rc, float2* __restrict__ range,
@@ -269,7 +188,15 @@ __global__ void __launch_bounds__(256) range_reduce_kernel(RenderCounters* __res
   }
 }
 
-int launch_expected_depths(const itm_scene* s, const float* M, const float* intr, itm_render_state* rs, bool rangeAlreadyInit, hipStream_t st) {
+// true when the projection can ride in the integration launch (integrate.hip): four workgroups per CU must keep
+// their LDS copy of the sub-sampled range image
+bool can_fuse_projection(const itm_scene* s, const itm_render_state* rs) {
+  const size_t ldsBytes = (size_t)((rs->w + 7) / 8) * ((rs->h + 7) / 8) * sizeof(uint2);
+  return !g_debug_no_fused_projection && s->cfg.indexType == ITM_INDEX_HASH && ldsBytes <= 39 * 1024 && rs->rangePartials && !g_debug_force_global_range;
+}
+
+// `projected`: project_partial already ran inside the integration launch, only the reduction is left
+int launch_expected_depths(const itm_scene* s, const float* M, const float* intr, itm_render_state* rs, bool rangeAlreadyInit, hipStream_t st, bool projected) {
   const int P = rs->w * rs->h;
   KernelTimer tk(s, ITM_TK_RANGE, st);
   if (s->cfg.indexType == ITM_INDEX_DENSE) {
@@ -294,7 +221,7 @@ int launch_expected_depths(const itm_scene* s, const float* M, const float* intr
       ITM_HIP(hipFuncSetAttribute((const void*)range_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
       attrSet = true;
     }
-    project_partial_kernel<<<kRangeParts, 512, ldsBytes, st>>>(rs->visibleIds, rs->counters, s->hash, rs->range, rs->projBuf, rs->rangePartials, p, RW, RH);
+    if (!projected) project_partial_kernel<<<kRangeParts, 512, ldsBytes, st>>>(rs->visibleIds, rs->counters, s->hash, rs->range, rs->projBuf, rs->rangePartials, p, RW, RH);
     range_reduce_kernel<<<(RW * RH + 255) / 256, 256, ldsBytes, st>>>(rs->counters, rs->range, rs->projBuf, rs->rangePartials, p, RW, RH);
   } else {
     project_fill_kernel<<<128, 256, 0, st>>>(rs->visibleIds, rs->counters, s->hash, rs->range, rs->projBuf, p);
@@ -455,13 +382,15 @@ extern "C" {
 int itm_debug_set(int key, int value) {
   if (key == ITM_DEBUG_FORCE_GLOBAL_RANGE_ATOMICS) { g_debug_force_global_range = value; return ITM_OK; }
   if (key == ITM_DEBUG_EXPLICIT_MARK_PREVIOUS) { g_debug_explicit_mark = value; return ITM_OK; }
+  if (key == ITM_DEBUG_INTEGRATE_WORKGROUPS) { g_debug_integrate_wgs = value; return ITM_OK; }
+  if (key == ITM_DEBUG_NO_FUSED_PROJECTION) { g_debug_no_fused_projection = value; return ITM_OK; }
   return set_error(ITM_ERR_INVALID, "unknown debug key");
 }
 
 int itm_create_expected_depths(const itm_scene* s, const float M[16], const float intr[4], itm_render_state* rs, itm_stream stream) {
   if (!s || !M || !intr || !rs) return set_error(ITM_ERR_INVALID, "null argument");
   if (rs->scene != s) return set_error(ITM_ERR_INVALID, "render state belongs to another scene");
-  return launch_expected_depths(s, M, intr, rs, false, as_stream(stream));
+  return launch_expected_depths(s, M, intr, rs, false, as_stream(stream), false);
 }
 
 int itm_find_surface(const itm_scene* s, const float M[16], const float intr[4], itm_render_state* rs, itm_stream stream) {
@@ -497,8 +426,9 @@ int itm_process_frame(itm_scene* s, const itm_view* v, itm_render_state* rs, flo
   int rc;
   const bool hashScene = s->cfg.indexType == ITM_INDEX_HASH;
   if (hashScene && (rc = launch_allocate(s, v, rs, false, true, st))) return rc;
-  if ((rc = launch_integrate(s, v, rs, st))) return rc;
-  if ((rc = launch_expected_depths(s, v->M_d, v->intr_d, rs, hashScene, st))) return rc;
+  const bool fuse = hashScene && can_fuse_projection(s, rs);
+  if ((rc = launch_integrate(s, v, rs, st, fuse))) return rc;
+  if ((rc = launch_expected_depths(s, v->M_d, v->intr_d, rs, hashScene, st, fuse))) return rc;
   return launch_icp_maps(s, v, rs, (float4*)points, (float4*)normals, st);
 }
 
