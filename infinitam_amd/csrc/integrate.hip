@@ -34,12 +34,11 @@ struct FuseParams {
   int stopAtMax;
 };
 
-// Depth part.  Returns eta (or -1 when the voxel is not touched); `touched` tells whether the
-// register image changed.  Operation order as SURVEY.md Appendix A.5.
-template <class VX>
-__device__ inline float fuse_depth(typename VX::Reg& r, float mx, float my, float mz, const float* __restrict__ depth,
-                                   const FuseParams& p, bool& touched) {
+// Depth part, stage 1: project the voxel; returns the index of the depth pixel it falls on, or -1 when the voxel
+// cannot be touched (behind the camera / outside the image).  Operation order as SURVEY.md Appendix A.5.
+__device__ inline int fuse_depth_project(float mx, float my, float mz, const FuseParams& p, float& pcz) {
   Vec3 pc = transform_point(p.M_d, mx, my, mz);
+  pcz = pc.z;
   if (pc.z <= 0) return -1;
   const float tx = p.fx * pc.x, ty = p.fy * pc.y;
 #if ITM_FAST_DIVISIONS
@@ -62,9 +61,15 @@ __device__ inline float fuse_depth(typename VX::Reg& r, float mx, float my, floa
   const float v = ty / pc.z + p.cy;
 #endif
   if ((u < 1) || (u > p.W - 2) || (v < 1) || (v > p.H - 2)) return -1;
-  const float dm = depth[(int)(u + 0.5f) + (int)(v + 0.5f) * p.W];
+  return (int)(u + 0.5f) + (int)(v + 0.5f) * p.W;
+}
+
+// Stage 2: the running average with the measured depth dm of that pixel.  Returns eta (or -1 when the voxel is not
+// touched); `touched` tells whether the register image changed.
+template <class VX>
+__device__ inline float fuse_depth_update(typename VX::Reg& r, float dm, float pcz, const FuseParams& p, bool& touched) {
   if (dm <= 0.0f) return -1;
-  const float eta = dm - pc.z;
+  const float eta = dm - pcz;
   if (eta < -p.mu) return eta;
   const float oldF = VX::to_float(VX::raw_sdf(r));
   const int oldW = VX::w_depth(r);
@@ -91,6 +96,15 @@ __device__ inline float fuse_depth(typename VX::Reg& r, float mx, float my, floa
   r = VX::with_depth(r, newF, newW);
   touched = true;
   return eta;
+}
+
+template <class VX>
+__device__ inline float fuse_depth(typename VX::Reg& r, float mx, float my, float mz, const float* __restrict__ depth,
+                                   const FuseParams& p, bool& touched) {
+  float pcz;
+  const int pix = fuse_depth_project(mx, my, mz, p, pcz);
+  if (pix < 0) return -1;
+  return fuse_depth_update<VX>(r, depth[pix], pcz, p, touched);
 }
 
 __device__ inline float round_half_away(float x) { return (x < 0) ? (x - 0.5f) : (x + 0.5f); }
@@ -198,6 +212,9 @@ __device__ inline void integrate_hash_body(int wgIdx, int wgCount, const int32_t
     }
   }
 #else
+  // (A software-pipelined variant -- visible id three blocks ahead, hash entry two, voxels one -- was measured: no
+  // gain for ITMVoxel_s, config 5 253 -> 280 us.  The loop is not bound by its read chain: with colour voxels nearly
+  // every wave has a lane inside the colour band and pays the whole colour path, i.e. it is ALU bound.)
   for (int e = wgIdx; e < nv; e += wgCount) {
     const HashEntry he = unpack_entry(hash[visibleIds[e]]);
     if (he.ptr < 0) continue;
@@ -274,13 +291,21 @@ __global__ void __launch_bounds__(256) integrate_dense_s_x4_kernel(uint4* __rest
     const int x0 = (POW2 ? (idx & (sx4 - 1)) : (idx - y * sx4)) * 4;
     uint32_t v[4] = {q.x, q.y, q.z, q.w};
     const float my = (float)(y + oy) * p.voxelSize;
+    // project the four voxels, gather their depth pixels together (four independent loads in flight), then update
+    int pix[4]; float pcz[4], dm[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      pix[k] = -1;
+      if (p.stopAtMax && VoxelS::w_depth(v[k]) == p.maxW) continue;
+      pix[k] = fuse_depth_project((float)(x0 + k + ox) * p.voxelSize, my, mz, p, pcz[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dm[k] = (pix[k] >= 0) ? depth[pix[k]] : 0.0f;
     bool any = false;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      if (p.stopAtMax && VoxelS::w_depth(v[k]) == p.maxW) continue;
-      const float mx = (float)(x0 + k + ox) * p.voxelSize;
       bool touched = false;
-      fuse_depth<VoxelS>(v[k], mx, my, mz, depth, p, touched);
+      if (pix[k] >= 0) fuse_depth_update<VoxelS>(v[k], dm[k], pcz[k], p, touched);
       any |= touched;
     }
     if (any) slice[idx] = make_uint4(v[0], v[1], v[2], v[3]);

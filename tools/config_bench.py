@@ -20,7 +20,7 @@ from infinitam_amd import capi, synth  # noqa: E402
 
 
 def run(cfg: int, frames: int):
-    be = itm.load()
+    be = capi.Backend(os.environ['ITM_LIB'], 'itm_') if os.environ.get('ITM_LIB') else itm.load()
     if cfg == 3:
         W, H, vox, idx, vs = 640, 480, capi.VOXEL_S, capi.INDEX_DENSE, 0.004
         prm = capi.default_params(voxelSize=vs, stopIntegratingAtMaxW=True)
