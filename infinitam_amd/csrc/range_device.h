@@ -65,6 +65,66 @@ __device__ inline Projected project_block(const HashEntry& e, const ProjParams& 
 // through global atomics.
 constexpr int kRangeParts = 32;
 
+// Rendering-block cap of the reference reached (numRenderingBlocks >= MAX_RENDERING_BLOCKS): replays the sequential
+// accept / skip decisions and rebuilds the whole image from the accepted boxes.  One workgroup of `nthreads` lanes.
+__device__ inline void range_replay_capped(int tid, int nthreads, uint2* cells, RenderCounters* __restrict__ rc, float2* __restrict__ range,
+                                           uint4* __restrict__ projBuf, const ProjParams& p, int RW, int RH) {
+  const int nCells = RW * RH;
+  const int nv = rc->noVisibleEntries;
+  const uint2 initCell = make_uint2(__float_as_uint(999999.9f), __float_as_uint(0.05f));
+  for (int i = tid; i < nCells; i += nthreads) cells[i] = initCell;
+  for (int i = tid; i < p.W * p.H; i += nthreads) range[i] = make_float2(999999.9f, 0.05f);
+  if (tid == 0) {
+    int count = 0;
+    for (int e = 0; e < nv; ++e) {
+      uint4 b = projBuf[2 * e + 1];
+      const int n = (int)b.z;
+      if (n == 0) continue;
+      if (count + n >= p.maxBlocks) b.w = 0u; else { b.w = 1u; count += n; }
+      projBuf[2 * e + 1] = b;
+    }
+    rc->noRenderingBlocks = count;
+  }
+  __threadfence();
+  __syncthreads();
+  for (int e = tid; e < nv; e += nthreads) {
+    const uint4 a = projBuf[2 * e], b = projBuf[2 * e + 1];
+    if (b.z == 0u || b.w == 0u) continue;
+    for (int y = (int)a.y; y <= (int)a.w; ++y)
+      for (int x = (int)a.x; x <= (int)a.z; ++x) {
+        if (x < RW && y < RH) {
+          atomicMin(&cells[x + y * RW].x, b.x);
+          atomicMax(&cells[x + y * RW].y, b.y);
+        } else {
+          uint32_t* px = (uint32_t*)&range[x + y * p.W];
+          atomicMin(px, b.x);
+          atomicMax(px + 1, b.y);
+        }
+      }
+  }
+  __syncthreads();
+  for (int i = tid; i < nCells; i += nthreads) {
+    const int y = i / RW, x = i - y * RW;
+    const uint2 c = cells[i];
+    range[x + y * p.W] = make_float2(__uint_as_float(c.x), __uint_as_float(c.y));
+  }
+}
+
+// min / max over the kRangeParts partial images for one cell
+__device__ inline void range_reduce_cell(int i, const uint2* __restrict__ partials, float2* __restrict__ range, int nCells, int RW, int W) {
+  uint2 c[kRangeParts];
+#pragma unroll
+  for (int g = 0; g < kRangeParts; ++g) c[g] = partials[(size_t)g * nCells + i];
+  uint32_t lo = 0xffffffffu, hi = 0u;
+#pragma unroll
+  for (int g = 0; g < kRangeParts; ++g) { lo = c[g].x < lo ? c[g].x : lo; hi = c[g].y > hi ? c[g].y : hi; }
+  const int y = i / RW, x = i - y * RW;
+  range[x + y * W] = make_float2(__uint_as_float(lo), __uint_as_float(hi));
+}
+
+// (Letting the kRangeParts workgroups meet at an in-kernel counter and reduce the partial images themselves, to
+// save the reduction launch, was measured slower: the agent-scope fences write back / invalidate the L2s the
+// integration workgroups are using -- fused launch 26.7 -> 41.4 us for 6.7 us saved.)
 __device__ inline void project_partial_body(int part, uint2* cells, const int32_t* __restrict__ ids, RenderCounters* __restrict__ rc,
                                             const uint4* __restrict__ hash, float2* __restrict__ range, uint4* __restrict__ projBuf,
                                             uint2* __restrict__ partials, const ProjParams& p, int RW, int RH) {

@@ -134,58 +134,12 @@ __global__ void __launch_bounds__(256) range_reduce_kernel(RenderCounters* __res
   const int nCells = RW * RH;
   if (rc->noRenderingBlocks < p.maxBlocks) {
     const int i = blockIdx.x * 256 + tid;   // one cell per lane, kRangeParts independent loads
-    if (i < nCells) {
-      uint2 c[kRangeParts];
-#pragma unroll
-      for (int g = 0; g < kRangeParts; ++g) c[g] = partials[(size_t)g * nCells + i];
-      uint32_t lo = 0xffffffffu, hi = 0u;
-#pragma unroll
-      for (int g = 0; g < kRangeParts; ++g) { lo = c[g].x < lo ? c[g].x : lo; hi = c[g].y > hi ? c[g].y : hi; }
-      const int y = i / RW, x = i - y * RW;
-      range[x + y * p.W] = make_float2(__uint_as_float(lo), __uint_as_float(hi));
-    }
+    if (i < nCells) range_reduce_cell(i, partials, range, nCells, RW, p.W);
     return;
   }
   if (blockIdx.x != 0) return;
   // cap reached (uniform branch): sequential replay, then rebuild the whole image
-  const int nv = rc->noVisibleEntries;
-  const uint2 initCell = make_uint2(__float_as_uint(999999.9f), __float_as_uint(0.05f));
-  for (int i = tid; i < nCells; i += 256) cells[i] = initCell;
-  for (int i = tid; i < p.W * p.H; i += 256) range[i] = make_float2(999999.9f, 0.05f);
-  if (tid == 0) {
-    int count = 0;
-    for (int e = 0; e < nv; ++e) {
-      uint4 b = projBuf[2 * e + 1];
-      const int n = (int)b.z;
-      if (n == 0) continue;
-      if (count + n >= p.maxBlocks) b.w = 0u; else { b.w = 1u; count += n; }
-      projBuf[2 * e + 1] = b;
-    }
-    rc->noRenderingBlocks = count;
-  }
-  __threadfence();
-  __syncthreads();
-  for (int e = tid; e < nv; e += 256) {
-    const uint4 a = projBuf[2 * e], b = projBuf[2 * e + 1];
-    if (b.z == 0u || b.w == 0u) continue;
-    for (int y = (int)a.y; y <= (int)a.w; ++y)
-      for (int x = (int)a.x; x <= (int)a.z; ++x) {
-        if (x < RW && y < RH) {
-          atomicMin(&cells[x + y * RW].x, b.x);
-          atomicMax(&cells[x + y * RW].y, b.y);
-        } else {
-          uint32_t* px = (uint32_t*)&range[x + y * p.W];
-          atomicMin(px, b.x);
-          atomicMax(px + 1, b.y);
-        }
-      }
-  }
-  __syncthreads();
-  for (int i = tid; i < nCells; i += 256) {
-    const int y = i / RW, x = i - y * RW;
-    const uint2 c = cells[i];
-    range[x + y * p.W] = make_float2(__uint_as_float(c.x), __uint_as_float(c.y));
-  }
+  range_replay_capped(tid, 256, cells, rc, range, projBuf, p, RW, RH);
 }
 
 // true when the projection can ride in the integration launch (integrate.hip): four workgroups per CU must keep
