@@ -261,6 +261,23 @@ int ITM_FN(convert_depth_affine)(const int16_t* raw, float* depth_out, int w, in
 int ITM_FN(convert_disparity)(const int16_t* raw, float* depth_out, int w, int h, float c0,
                               float c1, float fx_depth, itm_stream stream);
 
+/* ITMViewBuilder::DepthFiltering  Engine/ITMViewBuilder.h:32, DeviceSpecific/CPU/ITMViewBuilder_CPU.cpp:119-130,
+ * filterDepth DeviceAgnostic/ITMViewBuilder.h:30-52: one 5x5 bilateral pass; `out` is cleared, then pixels
+ * 2 <= x < w-2, 2 <= y < h-2 are written (invalid input pixel -> -1).  in != out. */
+int ITM_FN(filter_depth)(const float* in, float* out, int w, int h, itm_stream stream);
+/* ITMViewBuilder::ComputeNormalAndWeights  Engine/ITMViewBuilder.h:33, ..._CPU.cpp:132-145, computeNormalAndWeight
+ * DeviceAgnostic/ITMViewBuilder.h:55-117.  normals: float4[h*w], sigmaZ: float[h*w]; only the interior
+ * (2-pixel border excluded) is written, as in the reference.  `intr` = projectionParamsSimple.all (fx,fy,cx,cy). */
+int ITM_FN(compute_normal_and_weights)(const float* depth, float* normals, float* sigmaZ, int w, int h,
+                                       const float intr[4], itm_stream stream);
+/* ITMViewBuilder::UpdateView(view, rgb, rawDepth, useBilateralFilter, modelSensorNoise)  ..._CPU.cpp:14-63, for a raw
+ * depth frame already in device memory: conversion by calibration type (0 = TRAFO_KINECT disparity, 1 = TRAFO_AFFINE,
+ * Objects/ITMDisparityCalib.h:24-29), optionally the five bilateral passes (ping-pong with `scratch`, float[h*w]) and
+ * the normal / uncertainty images (normals, sigmaZ may be NULL when modelSensorNoise == 0). */
+int ITM_FN(update_view)(const int16_t* raw, int w, int h, int calibType, float c0, float c1, const float intr_d[4],
+                        int useBilateralFilter, int modelSensorNoise, float* depth_out, float* scratch,
+                        float* normals, float* sigmaZ, itm_stream stream);
+
 /* ---- ICP depth tracker (the step after the path) -------------------------------------
  * Consumes the points / normals maps CreateICPMaps writes.  Device-specific half of the reference tracker:
  *   ITMLowLevelEngine::FilterSubsampleWithHoles (float)  DeviceAgnostic/ITMLowLevelEngine.h:26-47,

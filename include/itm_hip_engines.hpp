@@ -237,6 +237,37 @@ class ITMTrackingController_HIP {
   }
 };
 
+// ITMViewBuilder (Engine/ITMViewBuilder.h:17-60): raw depth frame (device short image) -> ITMView::depth in metres,
+// optional 5-pass bilateral filter and normal / uncertainty images.  The caller owns the device images.
+class ITMViewBuilder_HIP {
+  const ITMRGBDCalib* calib;
+  int calibType; float c0, c1;
+
+ public:
+  itm_stream stream = nullptr;
+  // calibType: 0 = ITMDisparityCalib::TRAFO_KINECT (params c0, c1), 1 = TRAFO_AFFINE (depth = raw * c0 + c1)
+  ITMViewBuilder_HIP(const ITMRGBDCalib* calib_, int calibType_, float c0_, float c1_) : calib(calib_), calibType(calibType_), c0(c0_), c1(c1_) {}
+  void ConvertDisparityToDepth(float* depth_out, const int16_t* disp_in, Vector2i size) {
+    check(itm_convert_disparity(disp_in, depth_out, size.x, size.y, c0, c1, calib->intrinsics_d.all[0], stream), "ConvertDisparityToDepth");
+  }
+  void ConvertDepthAffineToFloat(float* depth_out, const int16_t* depth_in, Vector2i size) {
+    check(itm_convert_depth_affine(depth_in, depth_out, size.x, size.y, c0, c1, stream), "ConvertDepthAffineToFloat");
+  }
+  void DepthFiltering(float* image_out, const float* image_in, Vector2i size) {
+    check(itm_filter_depth(image_in, image_out, size.x, size.y, stream), "DepthFiltering");
+  }
+  void ComputeNormalAndWeights(float* normal_out, float* sigmaZ_out, const float* depth_in, Vector2i size) {
+    check(itm_compute_normal_and_weights(depth_in, normal_out, sigmaZ_out, size.x, size.y, calib->intrinsics_d.all, stream), "ComputeNormalAndWeights");
+  }
+  // UpdateView(view, rgb, rawDepth, useBilateralFilter, modelSensorNoise): fills view->depth (and the optional images)
+  void UpdateView(ITMView* view, const int16_t* rawDepth, float* depth, float* scratch, bool useBilateralFilter,
+                  bool modelSensorNoise = false, float* depthNormal = nullptr, float* depthUncertainty = nullptr) {
+    check(itm_update_view(rawDepth, view->depthSize.x, view->depthSize.y, calibType, c0, c1, calib->intrinsics_d.all, useBilateralFilter ? 1 : 0,
+                          modelSensorNoise ? 1 : 0, depth, scratch, depthNormal, depthUncertainty, stream), "UpdateView");
+    view->depth = depth;
+  }
+};
+
 // ITMDepthTracker (Engine/ITMDepthTracker.h): TrackCamera refines trackingState->pose_d against the ICP maps
 // of the previous frame; the gradient / Hessian reduction and the depth pyramid run on the GPU.
 class ITMDepthTracker_HIP {

@@ -163,6 +163,9 @@ _SIGS = {
     "process_frame": (C.c_int, [_P, C.POINTER(ViewStruct), _P, _P, _P, _P]),
     "convert_depth_affine": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_float, C.c_float, _P]),
     "convert_disparity": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, _P]),
+    "filter_depth": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    "compute_normal_and_weights": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P]),
+    "update_view": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "filter_subsample_with_holes": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
     "tracker_compute_g_and_h": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_float), _P, _P, C.c_int, C.c_int, C.POINTER(C.c_float),
                                           C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_int, C.POINTER(TrackerGH), _P]),

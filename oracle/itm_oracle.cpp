@@ -1177,6 +1177,69 @@ int itmo_convert_disparity(const int16_t* raw, float* out, int w, int h, float c
   return ITM_OK;
 }
 
+// filterDepth / computeNormalAndWeight  DeviceAgnostic/ITMViewBuilder.h:30-117 ; DepthFiltering / ComputeNormalAndWeights /
+// UpdateView  DeviceSpecific/CPU/ITMViewBuilder_CPU.cpp:14-63,119-145
+int itmo_filter_depth(const float* in, float* out, int w, int h, itm_stream) {
+  std::memset(out, 0, (size_t)w * h * 4);
+  for (int y = 2; y < h - 2; ++y) for (int x = 2; x < w - 2; ++x) {
+    float z = in[x + y * w];
+    if (z < 0.0f) { out[x + y * w] = -1.0f; continue; }
+    float sigma_z = 1.0f / (0.0012f + 0.0019f * (z - 0.4f) * (z - 0.4f) + 0.0001f / std::sqrt(z) * 0.25f);
+    float final_depth = 0.0f, w_sum = 0.0f;
+    for (int i = -2; i <= 2; ++i) for (int j = -2; j <= 2; ++j) {
+      float tmpz = in[(x + j) + (y + i) * w];
+      if (tmpz < 0.0f) continue;
+      float dz = (tmpz - z); dz *= dz;
+      float wgt = std::exp(-0.5f * ((std::abs(i) + std::abs(j)) * 1.2232f * 1.2232f + dz * sigma_z * sigma_z));
+      w_sum += wgt;
+      final_depth += wgt * tmpz;
+    }
+    final_depth /= w_sum;
+    out[x + y * w] = final_depth;
+  }
+  return ITM_OK;
+}
+int itmo_compute_normal_and_weights(const float* depth, float* normals, float* sigmaZ, int w, int h, const float intr[4], itm_stream) {
+  const float PIf = float(3.1415926535897932384626433832795);
+  for (int y = 2; y < h - 2; ++y) for (int x = 2; x < w - 2; ++x) {
+    const int idx = x + y * w;
+    float* n = normals + 4 * (size_t)idx;
+    float z = depth[idx];
+    if (z < 0.0f) { n[3] = -1.0f; sigmaZ[idx] = -1; continue; }
+    float zxp = depth[(x + 1) + y * w], zyp = depth[x + (y + 1) * w], zxm = depth[(x - 1) + y * w], zym = depth[x + (y - 1) * w];
+    if (zxp <= 0 || zyp <= 0 || zxm <= 0 || zym <= 0) { n[3] = -1.0f; sigmaZ[idx] = -1; continue; }
+    float xp1x = zxp * ((x + 1.0f) - intr[2]) * intr[0], xp1y = zxp * (y - intr[3]) * intr[1];
+    float xm1x = zxm * ((x - 1.0f) - intr[2]) * intr[0], xm1y = zxm * (y - intr[3]) * intr[1];
+    float yp1x = zyp * (x - intr[2]) * intr[0], yp1y = zyp * ((y + 1.0f) - intr[3]) * intr[1];
+    float ym1x = zym * (x - intr[2]) * intr[0], ym1y = zym * ((y - 1.0f) - intr[3]) * intr[1];
+    float dxx = xp1x - xm1x, dxy = xp1y - xm1y, dxz = zxp - zxm;
+    float dyx = yp1x - ym1x, dyy = yp1y - ym1y, dyz = zyp - zym;
+    float nx = (dxy * dyz - dxz * dyy), ny = (dxz * dyx - dxx * dyz), nz = (dxx * dyy - dxy * dyx);
+    if (nx == 0.0f && ny == 0 && nz == 0) { n[3] = -1.0f; sigmaZ[idx] = -1; continue; }
+    float norm = 1.0f / std::sqrt(nx * nx + ny * ny + nz * nz);
+    nx *= norm; ny *= norm; nz *= norm;
+    n[0] = nx; n[1] = ny; n[2] = nz; n[3] = 1.0f;
+    float theta = std::acos(nz);
+    float theta_diff = theta / (PIf * 0.5f - theta);
+    sigmaZ[idx] = (0.0012f + 0.0019f * (z - 0.4f) * (z - 0.4f) + 0.0001f / std::sqrt(z) * theta_diff * theta_diff);
+  }
+  return ITM_OK;
+}
+int itmo_update_view(const int16_t* raw, int w, int h, int calibType, float c0, float c1, const float intr_d[4], int useBilateralFilter,
+                     int modelSensorNoise, float* depth_out, float* scratch, float* normals, float* sigmaZ, itm_stream st) {
+  if (calibType == 0) itmo_convert_disparity(raw, depth_out, w, h, c0, c1, intr_d[0], st);
+  else if (calibType == 1) itmo_convert_depth_affine(raw, depth_out, w, h, c0, c1, st);
+  else return ITM_ERR_INVALID;
+  if (useBilateralFilter) {
+    itmo_filter_depth(depth_out, scratch, w, h, st); itmo_filter_depth(scratch, depth_out, w, h, st);
+    itmo_filter_depth(depth_out, scratch, w, h, st); itmo_filter_depth(scratch, depth_out, w, h, st);
+    itmo_filter_depth(depth_out, scratch, w, h, st);
+    std::memcpy(depth_out, scratch, (size_t)w * h * 4);
+  }
+  if (modelSensorNoise) itmo_compute_normal_and_weights(depth_out, normals, sigmaZ, w, h, intr_d, st);
+  return ITM_OK;
+}
+
 int itmo_get_counters(const itm_scene* s, const itm_render_state* rs, itm_counters* c, itm_stream) {
   if (!c) return fail(ITM_ERR_INVALID, "null argument");
   std::memset(c, 0, sizeof *c);

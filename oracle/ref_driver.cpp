@@ -25,6 +25,7 @@
 #include "ITMLib/Engine/DeviceAgnostic/ITMViewBuilder.h"
 #include "ITMLib/Engine/DeviceSpecific/CPU/ITMDepthTracker_CPU.h"
 #include "ITMLib/Engine/DeviceSpecific/CPU/ITMLowLevelEngine_CPU.h"
+#include "ITMLib/Engine/DeviceSpecific/CPU/ITMViewBuilder_CPU.h"
 
 using namespace ITMLib::Engine;
 using namespace ITMLib::Objects;
@@ -325,6 +326,49 @@ int itmr_convert_depth_affine(const int16_t* raw, float* out, int w, int h, floa
 }
 int itmr_convert_disparity(const int16_t* raw, float* out, int w, int h, float c0, float c1, float fx, itm_stream) {
   for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) convertDisparityToDepth(out, x, y, raw, Vector2f(c0, c1), fx, Vector2i(w, h));
+  return ITM_OK;
+}
+
+// the reference's own view builder (ITMViewBuilder_CPU) on host images
+int itmr_filter_depth(const float* in, float* out, int w, int h, itm_stream) {
+  ITMRGBDCalib calib; ITMViewBuilder_CPU vb(&calib);
+  ITMFloatImage a(Vector2i(w, h), true, false), b(Vector2i(w, h), true, false);
+  std::memcpy(a.GetData(MEMORYDEVICE_CPU), in, (size_t)w * h * 4);
+  vb.DepthFiltering(&b, &a);
+  std::memcpy(out, b.GetData(MEMORYDEVICE_CPU), (size_t)w * h * 4);
+  return ITM_OK;
+}
+int itmr_compute_normal_and_weights(const float* depth, float* normals, float* sigmaZ, int w, int h, const float intr[4], itm_stream) {
+  ITMRGBDCalib calib; ITMViewBuilder_CPU vb(&calib);
+  ITMFloatImage d(Vector2i(w, h), true, false), sz(Vector2i(w, h), true, false);
+  ITMFloat4Image n(Vector2i(w, h), true, false);
+  std::memcpy(d.GetData(MEMORYDEVICE_CPU), depth, (size_t)w * h * 4);
+  std::memcpy(n.GetData(MEMORYDEVICE_CPU), normals, (size_t)w * h * 16);   // rejected pixels keep old components
+  std::memcpy(sz.GetData(MEMORYDEVICE_CPU), sigmaZ, (size_t)w * h * 4);
+  vb.ComputeNormalAndWeights(&n, &sz, &d, Vector4f(intr[0], intr[1], intr[2], intr[3]));
+  std::memcpy(normals, n.GetData(MEMORYDEVICE_CPU), (size_t)w * h * 16);
+  std::memcpy(sigmaZ, sz.GetData(MEMORYDEVICE_CPU), (size_t)w * h * 4);
+  return ITM_OK;
+}
+int itmr_update_view(const int16_t* raw, int w, int h, int calibType, float c0, float c1, const float intr_d[4], int useBilateralFilter,
+                     int modelSensorNoise, float* depth_out, float* scratch, float* normals, float* sigmaZ, itm_stream) {
+  ITMRGBDCalib calib;
+  calib.intrinsics_d.SetFrom(intr_d[0], intr_d[1], intr_d[2], intr_d[3], w, h);
+  calib.disparityCalib.params = Vector2f(c0, c1);
+  calib.disparityCalib.type = calibType == 0 ? ITMDisparityCalib::TRAFO_KINECT : ITMDisparityCalib::TRAFO_AFFINE;
+  ITMViewBuilder_CPU vb(&calib);
+  ITMUChar4Image rgb(Vector2i(w, h), true, false);
+  ITMShortImage rawImg(Vector2i(w, h), true, false);
+  std::memcpy(rawImg.GetData(MEMORYDEVICE_CPU), raw, (size_t)w * h * 2);
+  ITMView* view = NULL;
+  vb.UpdateView(&view, &rgb, &rawImg, useBilateralFilter != 0, modelSensorNoise != 0);
+  std::memcpy(depth_out, view->depth->GetData(MEMORYDEVICE_CPU), (size_t)w * h * 4);
+  if (modelSensorNoise) {
+    std::memcpy(normals, view->depthNormal->GetData(MEMORYDEVICE_CPU), (size_t)w * h * 16);
+    std::memcpy(sigmaZ, view->depthUncertainty->GetData(MEMORYDEVICE_CPU), (size_t)w * h * 4);
+  }
+  (void)scratch;
+  delete view;
   return ITM_OK;
 }
 
