@@ -278,6 +278,27 @@ int ITM_FN(update_view)(const int16_t* raw, int w, int h, int calibType, float c
                         int useBilateralFilter, int modelSensorNoise, float* depth_out, float* scratch,
                         float* normals, float* sigmaZ, itm_stream stream);
 
+/* ---- on-disk input formats of the view builder's sources (host memory, no device work) -------------------------
+ * Depth: PGM "P5" (or ASCII "P2") with maxval > 256: 16-bit samples stored BIG-endian, swapped on load
+ * (Utils/FileUtils.cpp:377-421); colour: PPM "P6" / "P3" -> RGBA with alpha 255 (:324-375); writers :251-322
+ * (the float writer stores millimetres WITHOUT the byte swap, as the reference does).  Calibration text:
+ * ITMLib/Utils/ITMCalibIO.cpp:10-101 (rgb intrinsics, depth intrinsics, 3x4 rgb->depth extrinsics, disparity calib;
+ * "0 0" selects affine 1/1000).  All pointers are host pointers.  Return ITM_OK or ITM_ERR_INVALID. */
+typedef struct itm_rgbd_calib {
+  float size_rgb[2], intr_rgb[4];          /* sizeX sizeY ; fx fy cx cy                                  */
+  float size_d[2], intr_d[4];
+  float rgb_to_depth[16];                  /* trafo_rgb_to_depth.calib, column-major                    */
+  float rgb_to_depth_inv[16];              /* .calib_inv (transpose / -R^T t, Objects/ITMExtrinsics.h:32-42) */
+  int32_t disparityType;                   /* 0 = TRAFO_KINECT, 1 = TRAFO_AFFINE                        */
+  float disparityParams[2];
+} itm_rgbd_calib;
+int ITM_FN(read_depth_image)(const char* path, int16_t* dst, int capacityPixels, int* w, int* h);
+int ITM_FN(read_rgb_image)(const char* path, uint8_t* dst_rgba, int capacityPixels, int* w, int* h);
+int ITM_FN(write_depth_image)(const char* path, const int16_t* src, int w, int h);
+int ITM_FN(write_rgb_image)(const char* path, const uint8_t* src_rgba, int w, int h);
+int ITM_FN(write_float_depth_image)(const char* path, const float* src, int w, int h);
+int ITM_FN(read_rgbd_calib)(const char* path, itm_rgbd_calib* out);
+
 /* ---- ICP depth tracker (the step after the path) -------------------------------------
  * Consumes the points / normals maps CreateICPMaps writes.  Device-specific half of the reference tracker:
  *   ITMLowLevelEngine::FilterSubsampleWithHoles (float)  DeviceAgnostic/ITMLowLevelEngine.h:26-47,
@@ -334,6 +355,13 @@ int ITM_FN(download)(const itm_scene* scene, const itm_render_state* rs, int whi
                      size_t bytes, itm_stream stream);
 int ITM_FN(upload)(itm_scene* scene, itm_render_state* rs, int which, const void* src_host,
                    size_t bytes, itm_stream stream);
+/* Scene checkpoint: one file per memory block in the layout of ORUtils/MemoryBlockPersister.h:17-130
+ * (int32 element count, then the raw elements): hash.dat (ITMHashEntry), excess.dat (int), alloc.dat (int),
+ * voxel.dat (TVoxel), counters.dat (itm_counters as 8 ints), config.dat (itm_scene_config + itm_scene_params as bytes,
+ * checked on load), and for a render state visible_ids.dat (int) / visible_type.dat (uchar).  Loading into a scene of
+ * the same configuration and continuing gives bit-identical results to the uninterrupted run.  `dir` must exist. */
+int ITM_FN(scene_save)(const itm_scene* scene, const itm_render_state* rs, const char* dir, itm_stream stream);
+int ITM_FN(scene_load)(itm_scene* scene, itm_render_state* rs, const char* dir, itm_stream stream);
 /* Device address of a buffer (zero-copy hand-off to e.g. a collective); NULL if absent. */
 void* ITM_FN(buffer_ptr)(const itm_scene* scene, const itm_render_state* rs, int which);
 

@@ -94,6 +94,13 @@ class TrackerConfig(C.Structure):
         return t
 
 
+class RGBDCalib(C.Structure):
+    """itm_rgbd_calib: calibration text of the reference (ITMLib/Utils/ITMCalibIO.cpp)."""
+    _fields_ = [("size_rgb", C.c_float * 2), ("intr_rgb", C.c_float * 4), ("size_d", C.c_float * 2), ("intr_d", C.c_float * 4),
+                ("rgb_to_depth", C.c_float * 16), ("rgb_to_depth_inv", C.c_float * 16), ("disparityType", C.c_int32),
+                ("disparityParams", C.c_float * 2)]
+
+
 class TrackerGH(C.Structure):
     _fields_ = [("f", C.c_float), ("nabla", C.c_float * 6), ("hessian", C.c_float * 36), ("noValidPoints", C.c_int32)]
 
@@ -185,6 +192,19 @@ _SIGS = {
 }
 
 
+# host-side file formats: exported by the product and by the reference shim; the CPU oracle has no need for them
+_HOST_IO_SIGS = {
+    "read_depth_image": (C.c_int, [C.c_char_p, _P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "read_rgb_image": (C.c_int, [C.c_char_p, _P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "write_depth_image": (C.c_int, [C.c_char_p, _P, C.c_int, C.c_int]),
+    "write_rgb_image": (C.c_int, [C.c_char_p, _P, C.c_int, C.c_int]),
+    "write_float_depth_image": (C.c_int, [C.c_char_p, _P, C.c_int, C.c_int]),
+    "read_rgbd_calib": (C.c_int, [C.c_char_p, _P]),
+    "scene_save": (C.c_int, [_P, _P, C.c_char_p, _P]),
+    "scene_load": (C.c_int, [_P, _P, C.c_char_p, _P]),
+}
+
+
 class Backend:
     """One loaded implementation of the C-ABI."""
 
@@ -198,7 +218,39 @@ class Backend:
             f = getattr(self.lib, prefix + name)   # AttributeError => missing symbol, fail loudly
             f.restype, f.argtypes = res, args
             self.fn[name] = f
+        for name, (res, args) in _HOST_IO_SIGS.items():
+            f = getattr(self.lib, prefix + name, None)
+            if f is None:
+                if prefix == "itm_":
+                    raise ItmError(f"product library lacks {prefix}{name}")
+                continue
+            f.restype, f.argtypes = res, args
+            self.fn[name] = f
         self.on_device = bool(self.fn["uses_device_memory"]())
+
+    # ---- host-side file formats (numpy in / out) -----------------------------------------------
+    def read_depth_image(self, path: str) -> np.ndarray:
+        cap = 4096 * 4096
+        buf = np.empty(cap, np.int16); w, h = C.c_int(), C.c_int()
+        self.check(self.fn["read_depth_image"](path.encode(), buf.ctypes.data_as(_P), cap, C.byref(w), C.byref(h)), "read_depth_image")
+        return buf[: w.value * h.value].reshape(h.value, w.value).copy()
+
+    def read_rgb_image(self, path: str) -> np.ndarray:
+        cap = 4096 * 4096
+        buf = np.empty(cap * 4, np.uint8); w, h = C.c_int(), C.c_int()
+        self.check(self.fn["read_rgb_image"](path.encode(), buf.ctypes.data_as(_P), cap, C.byref(w), C.byref(h)), "read_rgb_image")
+        return buf[: w.value * h.value * 4].reshape(h.value, w.value, 4).copy()
+
+    def write_image(self, path: str, img: np.ndarray):
+        img = np.ascontiguousarray(img)
+        h, w = img.shape[:2]
+        kind = {np.dtype(np.int16): "write_depth_image", np.dtype(np.uint8): "write_rgb_image", np.dtype(np.float32): "write_float_depth_image"}[img.dtype]
+        self.check(self.fn[kind](path.encode(), img.ctypes.data_as(_P), w, h), kind)
+
+    def read_rgbd_calib(self, path: str) -> "RGBDCalib":
+        out = RGBDCalib()
+        self.check(self.fn["read_rgbd_calib"](path.encode(), C.byref(out)), "read_rgbd_calib")
+        return out
 
     def check(self, rc: int, what: str = ""):
         if rc != 0:
@@ -327,6 +379,13 @@ class Scene:
         c = Counters()
         self.be.check(self.be.fn["get_counters"](_P(self.h), _P(rs.h if rs else None), C.byref(c), _P(stream)), "get_counters")
         return c.as_dict()
+
+    def save(self, directory: str, rs: Optional["RenderState"] = None, stream=None):
+        """Scene checkpoint (itm_scene_save): MemoryBlockPersister-style files in an existing directory."""
+        self.be.check(self.be.fn["scene_save"](_P(self.h), _P(rs.h if rs else None), directory.encode(), _P(stream)), "scene_save")
+
+    def load(self, directory: str, rs: Optional["RenderState"] = None, stream=None):
+        self.be.check(self.be.fn["scene_load"](_P(self.h), _P(rs.h if rs else None), directory.encode(), _P(stream)), "scene_load")
 
     def set_counters(self, rs, lastFreeBlockId, lastFreeExcessListId, noVisibleEntries, stream=None):
         c = Counters()

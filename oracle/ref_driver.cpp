@@ -26,6 +26,10 @@
 #include "ITMLib/Engine/DeviceSpecific/CPU/ITMDepthTracker_CPU.h"
 #include "ITMLib/Engine/DeviceSpecific/CPU/ITMLowLevelEngine_CPU.h"
 #include "ITMLib/Engine/DeviceSpecific/CPU/ITMViewBuilder_CPU.h"
+#include "ITMLib/Utils/ITMCalibIO.h"
+#include "Utils/FileUtils.h"
+#include "ORUtils/MemoryBlockPersister.h"
+#include <stdexcept>
 
 using namespace ITMLib::Engine;
 using namespace ITMLib::Objects;
@@ -327,6 +331,66 @@ int itmr_convert_depth_affine(const int16_t* raw, float* out, int w, int h, floa
 int itmr_convert_disparity(const int16_t* raw, float* out, int w, int h, float c0, float c1, float fx, itm_stream) {
   for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) convertDisparityToDepth(out, x, y, raw, Vector2f(c0, c1), fx, Vector2i(w, h));
   return ITM_OK;
+}
+
+// the reference's own file readers / writers (Utils/FileUtils.cpp, ITMLib/Utils/ITMCalibIO.cpp)
+int itmr_read_depth_image(const char* path, int16_t* dst, int cap, int* w, int* h) {
+  ITMShortImage img(Vector2i(2, 2), true, false);
+  if (!ReadImageFromFile(&img, path)) return ITM_ERR_INVALID;
+  if (img.noDims.x * img.noDims.y > cap) return ITM_ERR_INVALID;
+  *w = img.noDims.x; *h = img.noDims.y;
+  std::memcpy(dst, img.GetData(MEMORYDEVICE_CPU), (size_t)*w * *h * 2);
+  return ITM_OK;
+}
+int itmr_read_rgb_image(const char* path, uint8_t* dst, int cap, int* w, int* h) {
+  ITMUChar4Image img(Vector2i(2, 2), true, false);
+  if (!ReadImageFromFile(&img, path)) return ITM_ERR_INVALID;
+  if (img.noDims.x * img.noDims.y > cap) return ITM_ERR_INVALID;
+  *w = img.noDims.x; *h = img.noDims.y;
+  std::memcpy(dst, img.GetData(MEMORYDEVICE_CPU), (size_t)*w * *h * 4);
+  return ITM_OK;
+}
+int itmr_write_depth_image(const char* path, const int16_t* src, int w, int h) {
+  ITMShortImage img(Vector2i(w, h), true, false);
+  std::memcpy(img.GetData(MEMORYDEVICE_CPU), src, (size_t)w * h * 2);
+  SaveImageToFile(&img, path);
+  return ITM_OK;
+}
+int itmr_write_rgb_image(const char* path, const uint8_t* src, int w, int h) {
+  ITMUChar4Image img(Vector2i(w, h), true, false);
+  std::memcpy(img.GetData(MEMORYDEVICE_CPU), src, (size_t)w * h * 4);
+  SaveImageToFile(&img, path, false);
+  return ITM_OK;
+}
+int itmr_write_float_depth_image(const char* path, const float* src, int w, int h) {
+  ITMFloatImage img(Vector2i(w, h), true, false);
+  std::memcpy(img.GetData(MEMORYDEVICE_CPU), src, (size_t)w * h * 4);
+  SaveImageToFile(&img, path);
+  return ITM_OK;
+}
+int itmr_read_rgbd_calib(const char* path, itm_rgbd_calib* out) {
+  ITMRGBDCalib c;
+  std::memset(out, 0, sizeof *out);
+  if (!readRGBDCalib(path, c)) return ITM_ERR_INVALID;
+  std::memcpy(out->intr_rgb, &c.intrinsics_rgb.projectionParamsSimple.all, 16);
+  std::memcpy(out->intr_d, &c.intrinsics_d.projectionParamsSimple.all, 16);
+  std::memcpy(out->rgb_to_depth, c.trafo_rgb_to_depth.calib.m, 64);
+  std::memcpy(out->rgb_to_depth_inv, c.trafo_rgb_to_depth.calib_inv.m, 64);
+  out->disparityType = c.disparityCalib.type == ITMDisparityCalib::TRAFO_KINECT ? 0 : 1;
+  out->disparityParams[0] = c.disparityCalib.params.x; out->disparityParams[1] = c.disparityCalib.params.y;
+  return ITM_OK;
+}
+
+// ORUtils::MemoryBlockPersister reads a block file written by the product's checkpoint
+int itmr_debug_load_hash_block(const char* path, void* dst, int maxEntries) {
+  try {
+    ORUtils::MemoryBlock<ITMHashEntry>* b = ORUtils::MemoryBlockPersister::LoadMemoryBlock<ITMHashEntry>(std::string(path));
+    const int n = (int)b->dataSize;
+    if (n > maxEntries) { delete b; return -1; }
+    std::memcpy(dst, b->GetData(MEMORYDEVICE_CPU), (size_t)n * sizeof(ITMHashEntry));
+    delete b;
+    return n;
+  } catch (...) { return -1; }
 }
 
 // the reference's own view builder (ITMViewBuilder_CPU) on host images

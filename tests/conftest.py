@@ -32,3 +32,10 @@ def reference():
 def hip():
     import itm_testlib
     return itm_testlib.hip_backend()
+
+
+@pytest.fixture(scope="session")
+def hip_host():
+    """The product library for its host-only entry points (file formats); loads without a GPU."""
+    import itm_testlib
+    return itm_testlib.hip_backend()

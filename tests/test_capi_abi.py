@@ -31,21 +31,21 @@ def test_library_exports_every_declared_symbol(libpath):
     assert not missing, f"libitmhip.so does not export: {missing}"
     be = capi.Backend(libpath, "itm_")          # binds every symbol with its signature; no compute calls
     assert be.on_device and "gfx950" in be.version()
-    assert set(declared) == set(capi._SIGS), "ctypes binding and header disagree on the function set"
+    assert set(declared) == set(capi._SIGS) | set(capi._HOST_IO_SIGS), "ctypes binding and header disagree on the function set"
     for t, nbytes in ((capi.VOXEL_S, 4), (capi.VOXEL_F, 8), (capi.VOXEL_S_RGB, 8), (capi.VOXEL_F_RGB, 12)):
         assert be.fn["voxel_size_bytes"](t) == nbytes == capi.VOXEL_DTYPES[t].itemsize
 
 
 def test_struct_layouts_match_the_header(tmp_path):
     src = tmp_path / "sizes.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "itm_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu\\n",'
-                   'sizeof(itm_scene_params), sizeof(itm_scene_config), sizeof(itm_view), sizeof(itm_counters), sizeof(itm_profile),'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "itm_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+                   'sizeof(itm_scene_params), sizeof(itm_scene_config), sizeof(itm_view), sizeof(itm_counters), sizeof(itm_profile), sizeof(itm_rgbd_calib),'
                    'offsetof(itm_view, M_d), offsetof(itm_view, rgb_to_depth_inv)); return 0;}\n')
     exe = tmp_path / "sizes"
     subprocess.run(["gcc", "-std=c99", "-I", os.path.join(T.ROOT, "include"), str(src), "-o", str(exe)], check=True)
     got = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
     want = [C.sizeof(capi.SceneParams), C.sizeof(capi.SceneConfig), C.sizeof(capi.ViewStruct), C.sizeof(capi.Counters),
-            C.sizeof(capi.Profile), capi.ViewStruct.M_d.offset, capi.ViewStruct.rgb_to_depth_inv.offset]
+            C.sizeof(capi.Profile), C.sizeof(capi.RGBDCalib), capi.ViewStruct.M_d.offset, capi.ViewStruct.rgb_to_depth_inv.offset]
     assert got == want
 
 
