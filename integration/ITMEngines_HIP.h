@@ -1,0 +1,285 @@
+// ITMEngines_HIP.h -- the binding a maintainer of the reference adds: two classes derived from the reference's OWN
+// abstract engines (ITMLib/Engine/ITMSceneReconstructionEngine.h:28-52, ITMLib/Engine/ITMVisualisationEngine.h:18-107)
+// that forward every virtual to the C-ABI of include/itm_hip.h.  Compiled only where the reference tree is on the
+// include path (oracle/Makefile target `hipdemo`, tests/test_reference_integration.py); nothing of the reference is
+// copied here -- the classes below are new code against its public interfaces.
+//
+// Memory model.  The scene lives in HBM inside libitmhip.so ("device twin" of an ITMScene object, created on first
+// use).  This adapter is written for a reference build WITHOUT CUDA, whose images only have host storage: the depth /
+// colour image of a view is staged into HBM on every call and the results the rest of InfiniTAM reads on the host
+// (visible list, range image, ray-cast result, ICP maps, renders, counters) are mirrored back after each call.  A
+// build whose MemoryBlocks have a device slot passes those pointers instead and drops the staging.
+// SyncSceneToHost() copies table + voxels into the reference's host scene on demand (saving, meshing, tests).
+#pragma once
+
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <string>
+
+#include "ITMLib/Engine/ITMSceneReconstructionEngine.h"
+#include "ITMLib/Engine/ITMVisualisationEngine.h"
+#include "itm_hip.h"
+
+namespace ITMLib {
+namespace Engine {
+
+inline void HipCheck(int rc, const char* what) {
+  if (rc != ITM_OK) throw std::runtime_error(std::string(what) + ": " + itm_last_error());
+}
+
+template <class TVoxel> struct HipVoxelTag;
+template <> struct HipVoxelTag<ITMVoxel_s> { enum { value = ITM_VOXEL_S }; };
+template <> struct HipVoxelTag<ITMVoxel_f> { enum { value = ITM_VOXEL_F }; };
+template <> struct HipVoxelTag<ITMVoxel_s_rgb> { enum { value = ITM_VOXEL_S_RGB }; };
+template <> struct HipVoxelTag<ITMVoxel_f_rgb> { enum { value = ITM_VOXEL_F_RGB }; };
+
+// render-state shells that own their device twin (the reference deletes render states through the virtual destructor)
+struct HipRenderStateTwin {
+  itm_render_state* dev = nullptr;
+  virtual ~HipRenderStateTwin() { itm_render_state_destroy(dev); }
+};
+struct ITMRenderState_VH_HIP : public ITMRenderState_VH, public HipRenderStateTwin {
+  ITMRenderState_VH_HIP(int noTotalEntries, const Vector2i& s, float vfMin, float vfMax) : ITMRenderState_VH(noTotalEntries, s, vfMin, vfMax, MEMORYDEVICE_CPU) {}
+};
+struct ITMRenderState_HIP : public ITMRenderState, public HipRenderStateTwin {
+  ITMRenderState_HIP(const Vector2i& s, float vfMin, float vfMax) : ITMRenderState(s, vfMin, vfMax, MEMORYDEVICE_CPU) {}
+};
+
+template <class TIndex> struct HipIndexTraits;
+template <> struct HipIndexTraits<ITMVoxelBlockHash> {
+  enum { value = ITM_INDEX_HASH };
+  static void Configure(const ITMVoxelBlockHash&, itm_scene_config& c) {
+    c.bucketNum = SDF_BUCKET_NUM; c.excessNum = SDF_EXCESS_LIST_SIZE; c.localBlockNum = SDF_LOCAL_BLOCK_NUM;
+  }
+  static ITMRenderState_VH_HIP* NewRenderState(const Vector2i& s, float vfMin, float vfMax) {
+    return new ITMRenderState_VH_HIP(ITMVoxelBlockHash::noTotalEntries, s, vfMin, vfMax);
+  }
+};
+template <> struct HipIndexTraits<ITMPlainVoxelArray> {
+  enum { value = ITM_INDEX_DENSE };
+  static void Configure(const ITMPlainVoxelArray& index, itm_scene_config& c) {
+    const ITMPlainVoxelArray::IndexData* d = index.getIndexData();
+    c.denseSize[0] = d->size.x; c.denseSize[1] = d->size.y; c.denseSize[2] = d->size.z;
+    c.denseOffset[0] = d->offset.x; c.denseOffset[1] = d->offset.y; c.denseOffset[2] = d->offset.z;
+    c.denseOffsetSet = 1;
+  }
+  static ITMRenderState_HIP* NewRenderState(const Vector2i& s, float vfMin, float vfMax) { return new ITMRenderState_HIP(s, vfMin, vfMax); }
+};
+
+// ---- device twins, keyed by the address of the reference object they shadow ------------------------------------
+struct HipRegistry {
+  std::map<const void*, itm_scene*> scenes;
+  struct Stage { void* depth = nullptr; void* rgb = nullptr; void* points = nullptr; void* normals = nullptr; size_t pixels = 0, rgbPixels = 0; };
+  std::map<const void*, Stage> views;
+  static HipRegistry& Get() { static HipRegistry r; return r; }
+  ~HipRegistry() {
+    for (auto& kv : scenes) itm_scene_destroy(kv.second);
+    for (auto& kv : views) { itm_dev_free(kv.second.depth); itm_dev_free(kv.second.rgb); itm_dev_free(kv.second.points); itm_dev_free(kv.second.normals); }
+  }
+};
+
+template <class TVoxel, class TIndex>
+itm_scene* HipSceneOf(const ITMScene<TVoxel, TIndex>* scene) {
+  HipRegistry& r = HipRegistry::Get();
+  auto it = r.scenes.find(scene);
+  if (it != r.scenes.end()) return it->second;
+  itm_scene_config c; std::memset(&c, 0, sizeof c);
+  c.voxelType = HipVoxelTag<TVoxel>::value; c.indexType = HipIndexTraits<TIndex>::value;
+  HipIndexTraits<TIndex>::Configure(scene->index, c);
+  c.maxRenderingBlocks = MAX_RENDERING_BLOCKS;
+  const ITMSceneParams* sp = scene->sceneParams;
+  itm_scene_params p; std::memset(&p, 0, sizeof p);
+  p.mu = sp->mu; p.maxW = sp->maxW; p.voxelSize = sp->voxelSize; p.viewFrustum_min = sp->viewFrustum_min; p.viewFrustum_max = sp->viewFrustum_max;
+  p.stopIntegratingAtMaxW = sp->stopIntegratingAtMaxW ? 1 : 0;
+  itm_scene* dev = nullptr;
+  HipCheck(itm_scene_create(&c, &p, &dev), "itm_scene_create");
+  r.scenes[scene] = dev;
+  return dev;
+}
+
+// the scene twin is released by the visualisation engine bound to that scene (render states must be deleted first,
+// as the reference does: ITMMainEngine::~ITMMainEngine deletes renderState_live before the engines)
+inline void HipReleaseScene(const void* scene) {
+  auto it = HipRegistry::Get().scenes.find(scene);
+  if (it != HipRegistry::Get().scenes.end()) { itm_scene_destroy(it->second); HipRegistry::Get().scenes.erase(it); }
+}
+inline void HipReleaseView(const void* view) {
+  auto it = HipRegistry::Get().views.find(view);
+  if (it == HipRegistry::Get().views.end()) return;
+  itm_dev_free(it->second.depth); itm_dev_free(it->second.rgb); itm_dev_free(it->second.points); itm_dev_free(it->second.normals);
+  HipRegistry::Get().views.erase(it);
+}
+
+inline itm_render_state* HipRenderStateOf(const ITMRenderState* rs) {
+  const HipRenderStateTwin* t = dynamic_cast<const HipRenderStateTwin*>(rs);
+  if (!t || !t->dev) throw std::runtime_error("render state was not created by the HIP visualisation engine");
+  return t->dev;
+}
+
+// stages the host images of a view in HBM and fills the POD view of the C-ABI
+inline itm_view HipStageView(const ITMView* view, const ITMPose* pose_d, bool withRgb) {
+  HipRegistry::Stage& st = HipRegistry::Get().views[view];
+  const Vector2i ds = view->depth->noDims, cs = view->rgb->noDims;
+  const size_t px = (size_t)ds.x * ds.y, cpx = (size_t)cs.x * cs.y;
+  if (st.pixels != px) {
+    itm_dev_free(st.depth); itm_dev_free(st.points); itm_dev_free(st.normals);
+    HipCheck(itm_dev_malloc(&st.depth, px * 4), "dev_malloc"); HipCheck(itm_dev_malloc(&st.points, px * 16), "dev_malloc"); HipCheck(itm_dev_malloc(&st.normals, px * 16), "dev_malloc");
+    st.pixels = px;
+  }
+  if (st.rgbPixels != cpx) { itm_dev_free(st.rgb); HipCheck(itm_dev_malloc(&st.rgb, cpx * 4), "dev_malloc"); st.rgbPixels = cpx; }
+  HipCheck(itm_memcpy_h2d(st.depth, view->depth->GetData(MEMORYDEVICE_CPU), px * 4, 0), "memcpy_h2d");
+  if (withRgb) HipCheck(itm_memcpy_h2d(st.rgb, view->rgb->GetData(MEMORYDEVICE_CPU), cpx * 4, 0), "memcpy_h2d");
+  itm_view v; std::memset(&v, 0, sizeof v);
+  v.depth = (const float*)st.depth; v.rgb = (const uint8_t*)st.rgb;
+  v.w = ds.x; v.h = ds.y; v.w_rgb = cs.x; v.h_rgb = cs.y;
+  std::memcpy(v.M_d, pose_d->GetM().m, 64);
+  std::memcpy(v.intr_d, &view->calib->intrinsics_d.projectionParamsSimple.all, 16);
+  std::memcpy(v.intr_rgb, &view->calib->intrinsics_rgb.projectionParamsSimple.all, 16);
+  std::memcpy(v.rgb_to_depth, view->calib->trafo_rgb_to_depth.calib.m, 64);
+  std::memcpy(v.rgb_to_depth_inv, view->calib->trafo_rgb_to_depth.calib_inv.m, 64);
+  return v;
+}
+
+template <class TIndex> struct HipMirror;   // copies the index-specific part of a render state back to the host shell
+template <> struct HipMirror<ITMVoxelBlockHash> {
+  static void VisibleList(const itm_scene* dev, ITMRenderState* rs) {
+    ITMRenderState_VH* vh = (ITMRenderState_VH*)rs;
+    itm_render_state* d = HipRenderStateOf(rs);
+    itm_counters c; HipCheck(itm_get_counters(dev, d, &c, 0), "get_counters");
+    vh->noVisibleEntries = c.noVisibleEntries;
+    HipCheck(itm_download(dev, d, ITM_BUF_VISIBLE_IDS, vh->GetVisibleEntryIDs(), itm_buffer_bytes(dev, d, ITM_BUF_VISIBLE_IDS), 0), "download ids");
+    HipCheck(itm_download(dev, d, ITM_BUF_VISIBLE_TYPE, vh->GetEntriesVisibleType(), itm_buffer_bytes(dev, d, ITM_BUF_VISIBLE_TYPE), 0), "download types");
+  }
+};
+template <> struct HipMirror<ITMPlainVoxelArray> { static void VisibleList(const itm_scene*, ITMRenderState*) {} };
+
+// ---- ITMSceneReconstructionEngine ---------------------------------------------------------------------------
+template <class TVoxel, class TIndex>
+class ITMSceneReconstructionEngine_HIP : public ITMSceneReconstructionEngine<TVoxel, TIndex> {
+  static bool Colour() { return HipVoxelTag<TVoxel>::value == ITM_VOXEL_S_RGB || HipVoxelTag<TVoxel>::value == ITM_VOXEL_F_RGB; }
+
+ public:
+  void ResetScene(ITMScene<TVoxel, TIndex>* scene) { HipCheck(itm_reset_scene(HipSceneOf(scene), 0), "ResetScene"); }
+
+  void AllocateSceneFromDepth(ITMScene<TVoxel, TIndex>* scene, const ITMView* view, const ITMTrackingState* trackingState,
+                              const ITMRenderState* renderState, bool onlyUpdateVisibleList = false) {
+    itm_scene* dev = HipSceneOf(scene);
+    itm_view v = HipStageView(view, trackingState->pose_d, false);
+    HipCheck(itm_allocate_scene_from_depth(dev, &v, HipRenderStateOf(renderState), onlyUpdateVisibleList ? 1 : 0, 0), "AllocateSceneFromDepth");
+    HipMirror<TIndex>::VisibleList(dev, const_cast<ITMRenderState*>(renderState));
+  }
+
+  void IntegrateIntoScene(ITMScene<TVoxel, TIndex>* scene, const ITMView* view, const ITMTrackingState* trackingState,
+                          const ITMRenderState* renderState) {
+    itm_view v = HipStageView(view, trackingState->pose_d, Colour());
+    HipCheck(itm_integrate_into_scene(HipSceneOf(scene), &v, HipRenderStateOf(renderState), 0), "IntegrateIntoScene");
+  }
+
+  // table, free lists, voxels and pool counters -> the host arrays of the reference's scene object
+  static void SyncSceneToHost(ITMScene<TVoxel, TIndex>* scene);
+};
+
+template <class TVoxel, class TIndex> struct HipSceneSync;
+template <class TVoxel> struct HipSceneSync<TVoxel, ITMVoxelBlockHash> {
+  static void Run(ITMScene<TVoxel, ITMVoxelBlockHash>* scene, itm_scene* dev) {
+    HipCheck(itm_download(dev, 0, ITM_BUF_HASH_ENTRIES, scene->index.GetEntries(), itm_buffer_bytes(dev, 0, ITM_BUF_HASH_ENTRIES), 0), "download table");
+    HipCheck(itm_download(dev, 0, ITM_BUF_EXCESS_LIST, scene->index.GetExcessAllocationList(), itm_buffer_bytes(dev, 0, ITM_BUF_EXCESS_LIST), 0), "download excess list");
+    itm_counters c; HipCheck(itm_get_counters(dev, 0, &c, 0), "get_counters");
+    scene->index.SetLastFreeExcessListId(c.lastFreeExcessListId);
+  }
+};
+template <class TVoxel> struct HipSceneSync<TVoxel, ITMPlainVoxelArray> { static void Run(ITMScene<TVoxel, ITMPlainVoxelArray>*, itm_scene*) {} };
+
+template <class TVoxel, class TIndex>
+void ITMSceneReconstructionEngine_HIP<TVoxel, TIndex>::SyncSceneToHost(ITMScene<TVoxel, TIndex>* scene) {
+  itm_scene* dev = HipSceneOf(scene);
+  HipSceneSync<TVoxel, TIndex>::Run(scene, dev);
+  itm_counters c; HipCheck(itm_get_counters(dev, 0, &c, 0), "get_counters");
+  scene->localVBA.lastFreeBlockId = c.lastFreeBlockId;
+  HipCheck(itm_download(dev, 0, ITM_BUF_VOXEL_BLOCKS, scene->localVBA.GetVoxelBlocks(), itm_buffer_bytes(dev, 0, ITM_BUF_VOXEL_BLOCKS), 0), "download voxels");
+  HipCheck(itm_download(dev, 0, ITM_BUF_ALLOCATION_LIST, scene->localVBA.GetAllocationList(), itm_buffer_bytes(dev, 0, ITM_BUF_ALLOCATION_LIST), 0), "download allocation list");
+}
+
+// ---- ITMVisualisationEngine ---------------------------------------------------------------------------------
+template <class TVoxel, class TIndex>
+class ITMVisualisationEngine_HIP : public ITMVisualisationEngine<TVoxel, TIndex> {
+  itm_scene* Dev() const { return HipSceneOf(this->scene); }
+  void MirrorImages(ITMRenderState* rs, bool range, bool rays, bool image) const {
+    itm_render_state* d = HipRenderStateOf(rs);
+    const size_t px = (size_t)rs->raycastResult->noDims.x * rs->raycastResult->noDims.y;
+    if (range) HipCheck(itm_download(Dev(), d, ITM_BUF_RANGE_IMAGE, rs->renderingRangeImage->GetData(MEMORYDEVICE_CPU), px * 8, 0), "download range image");
+    if (rays) HipCheck(itm_download(Dev(), d, ITM_BUF_RAYCAST_RESULT, rs->raycastResult->GetData(MEMORYDEVICE_CPU), px * 16, 0), "download raycast result");
+    if (image) HipCheck(itm_download(Dev(), d, ITM_BUF_RAYCAST_IMAGE, rs->raycastImage->GetData(MEMORYDEVICE_CPU), px * 4, 0), "download raycast image");
+  }
+
+ public:
+  explicit ITMVisualisationEngine_HIP(const ITMScene<TVoxel, TIndex>* scene) : ITMVisualisationEngine<TVoxel, TIndex>(scene) {}
+  ~ITMVisualisationEngine_HIP() { HipReleaseScene(this->scene); }
+
+  typename IndexToRenderState<TIndex>::type* CreateRenderState(const Vector2i& imgSize) const {
+    auto* rs =
+        HipIndexTraits<TIndex>::NewRenderState(imgSize, this->scene->sceneParams->viewFrustum_min, this->scene->sceneParams->viewFrustum_max);
+    HipCheck(itm_render_state_create(Dev(), imgSize.x, imgSize.y, &rs->dev), "CreateRenderState");
+    return rs;
+  }
+
+  void FindVisibleBlocks(const ITMPose* pose, const ITMIntrinsics* intrinsics, ITMRenderState* renderState) const {
+    HipCheck(itm_find_visible_blocks(Dev(), pose->GetM().m, &intrinsics->projectionParamsSimple.all.x, HipRenderStateOf(renderState), 0), "FindVisibleBlocks");
+    HipMirror<TIndex>::VisibleList(Dev(), renderState);
+  }
+  void CreateExpectedDepths(const ITMPose* pose, const ITMIntrinsics* intrinsics, ITMRenderState* renderState) const {
+    HipCheck(itm_create_expected_depths(Dev(), pose->GetM().m, &intrinsics->projectionParamsSimple.all.x, HipRenderStateOf(renderState), 0), "CreateExpectedDepths");
+    MirrorImages(renderState, true, false, false);
+  }
+  void RenderImage(const ITMPose* pose, const ITMIntrinsics* intrinsics, const ITMRenderState* renderState, ITMUChar4Image* outputImage,
+                   IITMVisualisationEngine::RenderImageType type = IITMVisualisationEngine::RENDER_SHADED_GREYSCALE) const {
+    const size_t px = (size_t)outputImage->noDims.x * outputImage->noDims.y;
+    void* out = nullptr; HipCheck(itm_dev_malloc(&out, px * 4), "dev_malloc");
+    // pixels the render does not touch keep their previous content, as on the host
+    HipCheck(itm_memcpy_h2d(out, outputImage->GetData(MEMORYDEVICE_CPU), px * 4, 0), "memcpy_h2d");
+    const int t = type == IITMVisualisationEngine::RENDER_COLOUR_FROM_VOLUME ? ITM_RENDER_COLOUR_FROM_VOLUME
+                  : type == IITMVisualisationEngine::RENDER_COLOUR_FROM_NORMAL ? ITM_RENDER_COLOUR_FROM_NORMAL : ITM_RENDER_SHADED_GREYSCALE;
+    int rc = itm_render_image(Dev(), pose->GetM().m, &intrinsics->projectionParamsSimple.all.x, HipRenderStateOf(renderState), (uint8_t*)out, t, 0);
+    if (rc == ITM_OK) rc = itm_memcpy_d2h(outputImage->GetData(MEMORYDEVICE_CPU), out, px * 4, 0);
+    itm_dev_free(out);
+    HipCheck(rc, "RenderImage");
+    MirrorImages(const_cast<ITMRenderState*>(renderState), false, true, false);
+  }
+  void FindSurface(const ITMPose* pose, const ITMIntrinsics* intrinsics, const ITMRenderState* renderState) const {
+    HipCheck(itm_find_surface(Dev(), pose->GetM().m, &intrinsics->projectionParamsSimple.all.x, HipRenderStateOf(renderState), 0), "FindSurface");
+    MirrorImages(const_cast<ITMRenderState*>(renderState), false, true, false);
+  }
+  void CreatePointCloud(const ITMView* view, ITMTrackingState* trackingState, ITMRenderState* renderState, bool skipPoints) const {
+    itm_view v = HipStageView(view, trackingState->pose_d, false);
+    HipRegistry::Stage& st = HipRegistry::Get().views[view];
+    HipCheck(itm_create_point_cloud(Dev(), &v, HipRenderStateOf(renderState), skipPoints ? 1 : 0, (float*)st.points, (float*)st.normals, 0), "CreatePointCloud");
+    itm_counters c; HipCheck(itm_get_counters(Dev(), HipRenderStateOf(renderState), &c, 0), "get_counters");
+    trackingState->pointCloud->noTotalPoints = c.noTotalPoints;
+    HipCheck(itm_memcpy_d2h(trackingState->pointCloud->locations->GetData(MEMORYDEVICE_CPU), st.points, (size_t)c.noTotalPoints * 16, 0), "memcpy_d2h");
+    HipCheck(itm_memcpy_d2h(trackingState->pointCloud->colours->GetData(MEMORYDEVICE_CPU), st.normals, (size_t)c.noTotalPoints * 16, 0), "memcpy_d2h");
+    trackingState->pose_pointCloud->SetFrom(trackingState->pose_d);
+  }
+  void CreateICPMaps(const ITMView* view, ITMTrackingState* trackingState, ITMRenderState* renderState) const {
+    itm_view v = HipStageView(view, trackingState->pose_d, false);
+    HipRegistry::Stage& st = HipRegistry::Get().views[view];
+    HipCheck(itm_create_icp_maps(Dev(), &v, HipRenderStateOf(renderState), (float*)st.points, (float*)st.normals, 0), "CreateICPMaps");
+    HipCheck(itm_memcpy_d2h(trackingState->pointCloud->locations->GetData(MEMORYDEVICE_CPU), st.points, st.pixels * 16, 0), "memcpy_d2h");
+    HipCheck(itm_memcpy_d2h(trackingState->pointCloud->colours->GetData(MEMORYDEVICE_CPU), st.normals, st.pixels * 16, 0), "memcpy_d2h");
+    trackingState->pose_pointCloud->SetFrom(trackingState->pose_d);   // ITMVisualisationEngine_CPU.cpp CreateICPMaps
+    MirrorImages(renderState, false, true, true);
+  }
+  void ForwardRender(const ITMView* view, ITMTrackingState* trackingState, ITMRenderState* renderState) const {
+    itm_view v = HipStageView(view, trackingState->pose_d, false);
+    itm_render_state* d = HipRenderStateOf(renderState);
+    HipCheck(itm_forward_render(Dev(), &v, d, 0), "ForwardRender");
+    const size_t px = (size_t)renderState->forwardProjection->noDims.x * renderState->forwardProjection->noDims.y;
+    HipCheck(itm_download(Dev(), d, ITM_BUF_FORWARD_PROJECTION, renderState->forwardProjection->GetData(MEMORYDEVICE_CPU), px * 16, 0), "download");
+    HipCheck(itm_download(Dev(), d, ITM_BUF_MISSING_POINTS, renderState->fwdProjMissingPoints->GetData(MEMORYDEVICE_CPU), px * 4, 0), "download");
+    itm_counters c; HipCheck(itm_get_counters(Dev(), d, &c, 0), "get_counters");
+    renderState->noFwdProjMissingPoints = c.noFwdProjMissingPoints;
+  }
+};
+
+}  // namespace Engine
+}  // namespace ITMLib

@@ -1,0 +1,141 @@
+// ref_hip_demo.cpp -- drives the REFERENCE's own abstract engine interfaces twice, side by side: once with the
+// reference's CPU engines, once with the HIP adapters of ITMEngines_HIP.h (libitmhip.so behind them), on the same
+// synthetic frames, and compares everything the rest of InfiniTAM would read -- bit for bit.
+//
+// Built only where the reference tree exists (oracle/Makefile target `hipdemo` -> oracle/_ref/ref_hip_demo, g++ only;
+// the binary travels to the GPU box).  Prints one JSON line per configuration; exit code 0 iff all are equal.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ITMLib/Engine/DeviceSpecific/CPU/ITMSceneReconstructionEngine_CPU.cpp"
+#include "ITMLib/Engine/DeviceSpecific/CPU/ITMVisualisationEngine_CPU.cpp"
+#include "ITMEngines_HIP.h"
+
+using namespace ITMLib::Engine;
+using namespace ITMLib::Objects;
+
+template class ITMLib::Engine::ITMSceneReconstructionEngine_CPU<ITMVoxel_f_rgb, ITMVoxelBlockHash>;
+template class ITMLib::Engine::ITMVisualisationEngine_CPU<ITMVoxel_f_rgb, ITMVoxelBlockHash>;
+template class ITMLib::Engine::ITMSceneReconstructionEngine_CPU<ITMVoxel_s, ITMPlainVoxelArray>;
+template class ITMLib::Engine::ITMVisualisationEngine_CPU<ITMVoxel_s, ITMPlainVoxelArray>;
+
+static const int W = 160, H = 120;
+
+// sphere (r 0.5 m at z 1.5 m) in front of a wall at 2.5 m, camera at t, fp32 without contraction
+static void make_depth(float* d, float tx, float ty) {
+  const float fx = 145.0f, fy = 145.0f, cx = 80.0f, cy = 60.0f;
+  for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {
+    const float dx = ((float)x - cx) / fx, dy = ((float)y - cy) / fy;
+    const float ox = tx, oy = ty, oz = 0.0f - 1.5f;
+    const float A = dx * dx + dy * dy + 1.0f, B = 2.0f * (ox * dx + oy * dy + oz), C = ox * ox + oy * oy + oz * oz - 0.25f;
+    const float disc = B * B - 4.0f * A * C;
+    float z = 2.5f;
+    if (disc > 0) { const float t = (-B - std::sqrt(disc)) / (2.0f * A); if (t > 0) z = t; }
+    d[x + y * W] = z;
+  }
+}
+
+template <class T> static bool same(const T* a, const T* b, size_t n) { return std::memcmp(a, b, n * sizeof(T)) == 0; }
+
+template <class TIndex> struct VisibleCmp;
+template <> struct VisibleCmp<ITMVoxelBlockHash> {
+  static bool Equal(const ITMRenderState* a, const ITMRenderState* b, std::string& why) {
+    const ITMRenderState_VH* x = (const ITMRenderState_VH*)a; const ITMRenderState_VH* y = (const ITMRenderState_VH*)b;
+    if (x->noVisibleEntries != y->noVisibleEntries) { why = "noVisibleEntries"; return false; }
+    if (!same(x->GetVisibleEntryIDs(), y->GetVisibleEntryIDs(), (size_t)x->noVisibleEntries)) { why = "visibleEntryIDs"; return false; }
+    if (!same(const_cast<ITMRenderState_VH*>(x)->GetEntriesVisibleType(), const_cast<ITMRenderState_VH*>(y)->GetEntriesVisibleType(), (size_t)ITMVoxelBlockHash::noTotalEntries)) { why = "entriesVisibleType"; return false; }
+    return true;
+  }
+  static bool SceneEqual(ITMVoxelBlockHash& a, ITMVoxelBlockHash& b, std::string& why) {
+    if (!same(a.GetEntries(), b.GetEntries(), (size_t)ITMVoxelBlockHash::noTotalEntries)) { why = "hash entries"; return false; }
+    if (!same(a.GetExcessAllocationList(), b.GetExcessAllocationList(), (size_t)SDF_EXCESS_LIST_SIZE)) { why = "excess list"; return false; }
+    if (a.GetLastFreeExcessListId() != b.GetLastFreeExcessListId()) { why = "lastFreeExcessListId"; return false; }
+    return true;
+  }
+  static size_t Voxels(ITMVoxelBlockHash&) { return (size_t)SDF_LOCAL_BLOCK_NUM * SDF_BLOCK_SIZE3; }
+  static void Configure(ITMVoxelBlockHash&) {}
+};
+template <> struct VisibleCmp<ITMPlainVoxelArray> {
+  static bool Equal(const ITMRenderState*, const ITMRenderState*, std::string&) { return true; }
+  static bool SceneEqual(ITMPlainVoxelArray&, ITMPlainVoxelArray&, std::string&) { return true; }
+  static size_t Voxels(ITMPlainVoxelArray& i) { Vector3i s = i.getVolumeSize(); return (size_t)s.x * s.y * s.z; }
+  static void Configure(ITMPlainVoxelArray& i) {   // a 128^3 window of the 512^3 allocation keeps the CPU side quick
+    ITMPlainVoxelArray::IndexData* d = const_cast<ITMPlainVoxelArray::IndexData*>(i.getIndexData());
+    d->size = Vector3i(128, 128, 128); d->offset = Vector3i(-64, -64, 100);
+  }
+};
+
+template <class TVoxel, class TIndex>
+static bool run(const char* name, float voxelSize, int frames) {
+  ITMSceneParams sp(0.02f, 100, voxelSize, 0.2f, 3.0f, false);
+  ITMScene<TVoxel, TIndex> sceneA(&sp, false, MEMORYDEVICE_CPU), sceneB(&sp, false, MEMORYDEVICE_CPU);
+  VisibleCmp<TIndex>::Configure(sceneA.index); VisibleCmp<TIndex>::Configure(sceneB.index);
+  // everything below goes through the reference's abstract interfaces
+  ITMSceneReconstructionEngine<TVoxel, TIndex>* reco[2] = {new ITMSceneReconstructionEngine_CPU<TVoxel, TIndex>(), new ITMSceneReconstructionEngine_HIP<TVoxel, TIndex>()};
+  ITMVisualisationEngine<TVoxel, TIndex>* vis[2] = {new ITMVisualisationEngine_CPU<TVoxel, TIndex>(&sceneA), new ITMVisualisationEngine_HIP<TVoxel, TIndex>(&sceneB)};
+  ITMScene<TVoxel, TIndex>* scene[2] = {&sceneA, &sceneB};
+  ITMRGBDCalib calib;
+  calib.intrinsics_d.SetFrom(145, 145, 80, 60, W, H); calib.intrinsics_rgb.SetFrom(145, 145, 80, 60, W, H);
+  ITMRenderState* rs[2]; ITMView* view[2]; ITMTrackingState* ts[2];
+  for (int e = 0; e < 2; ++e) {
+    reco[e]->ResetScene(scene[e]);
+    rs[e] = vis[e]->CreateRenderState(Vector2i(W, H));
+    view[e] = new ITMView(&calib, Vector2i(W, H), Vector2i(W, H), false);
+    ts[e] = new ITMTrackingState(Vector2i(W, H), MEMORYDEVICE_CPU);
+  }
+  std::string why; bool ok = true;
+  ITMUChar4Image img[2] = {ITMUChar4Image(Vector2i(W, H), true, false), ITMUChar4Image(Vector2i(W, H), true, false)};
+  for (int k = 0; k < frames && ok; ++k) {
+    const float tx = 0.01f * (float)k;
+    Matrix4f M; M.setIdentity(); M.m[12] = -tx;
+    for (int e = 0; e < 2; ++e) {
+      make_depth(view[e]->depth->GetData(MEMORYDEVICE_CPU), tx, 0.0f);
+      Vector4u* c = view[e]->rgb->GetData(MEMORYDEVICE_CPU);
+      for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) c[x + y * W] = Vector4u((uchar)(x & 255), (uchar)(y & 255), (uchar)((x ^ y) & 255), 255);
+      ts[e]->pose_d->SetM(M);
+      // ITMDenseMapper::ProcessFrame + ITMTrackingController::Prepare, then a free-view render
+      reco[e]->AllocateSceneFromDepth(scene[e], view[e], ts[e], rs[e]);
+      reco[e]->IntegrateIntoScene(scene[e], view[e], ts[e], rs[e]);
+      vis[e]->CreateExpectedDepths(ts[e]->pose_d, &view[e]->calib->intrinsics_d, rs[e]);
+      vis[e]->CreateICPMaps(view[e], ts[e], rs[e]);
+      vis[e]->RenderImage(ts[e]->pose_d, &view[e]->calib->intrinsics_d, rs[e], &img[e], IITMVisualisationEngine::RENDER_COLOUR_FROM_NORMAL);
+    }
+    const size_t px = (size_t)W * H;
+    if (!VisibleCmp<TIndex>::Equal(rs[0], rs[1], why)) ok = false;
+    // the range image is only defined on the sub-sampled region the rays read
+    for (int y = 0; y < (H + 7) / 8 && ok; ++y)
+      if (!same(rs[0]->renderingRangeImage->GetData(MEMORYDEVICE_CPU) + y * W, rs[1]->renderingRangeImage->GetData(MEMORYDEVICE_CPU) + y * W, (size_t)((W + 7) / 8))) { ok = false; why = "range image"; }
+    if (ok && !same(ts[0]->pointCloud->locations->GetData(MEMORYDEVICE_CPU), ts[1]->pointCloud->locations->GetData(MEMORYDEVICE_CPU), px)) { ok = false; why = "ICP points"; }
+    if (ok && !same(ts[0]->pointCloud->colours->GetData(MEMORYDEVICE_CPU), ts[1]->pointCloud->colours->GetData(MEMORYDEVICE_CPU), px)) { ok = false; why = "ICP normals"; }
+    if (ok && !same(rs[0]->raycastImage->GetData(MEMORYDEVICE_CPU), rs[1]->raycastImage->GetData(MEMORYDEVICE_CPU), px)) { ok = false; why = "raycast image"; }
+    if (ok && !same(img[0].GetData(MEMORYDEVICE_CPU), img[1].GetData(MEMORYDEVICE_CPU), px)) { ok = false; why = "free-view render"; }
+    if (ok && !same(ts[0]->pose_pointCloud->GetM().m, ts[1]->pose_pointCloud->GetM().m, 16)) { ok = false; why = "pose_pointCloud"; }
+    if (!ok) why += " (frame " + std::to_string(k) + ")";
+  }
+  long long hits = 0;
+  if (ok) {
+    ITMSceneReconstructionEngine_HIP<TVoxel, TIndex>::SyncSceneToHost(&sceneB);
+    if (!VisibleCmp<TIndex>::SceneEqual(sceneA.index, sceneB.index, why)) ok = false;
+    else if (!same(sceneA.localVBA.GetVoxelBlocks(), sceneB.localVBA.GetVoxelBlocks(), VisibleCmp<TIndex>::Voxels(sceneA.index))) { ok = false; why = "voxel blocks"; }
+    else if (sceneA.localVBA.lastFreeBlockId != sceneB.localVBA.lastFreeBlockId) { ok = false; why = "lastFreeBlockId"; }
+    const Vector4f* p = ts[1]->pointCloud->locations->GetData(MEMORYDEVICE_CPU);
+    for (int i = 0; i < W * H; ++i) hits += p[i].w > 0;
+  }
+  std::printf("{\"config\": \"%s\", \"frames\": %d, \"equal\": %s, \"icp_points\": %lld, \"lastFreeBlockId\": %d, \"mismatch\": \"%s\"}\n", name, frames,
+              ok ? "true" : "false", hits, sceneB.localVBA.lastFreeBlockId, why.c_str());
+  // teardown in the reference's order: render states, then engines (the HIP visualisation engine releases the scene twin)
+  for (int e = 0; e < 2; ++e) { HipReleaseView(view[e]); delete rs[e]; delete view[e]; delete ts[e]; delete reco[e]; delete vis[e]; }
+  return ok;
+}
+
+int main() {
+  std::printf("{\"library\": \"%s\"}\n", itm_version());
+  bool ok = true;
+  ok &= run<ITMVoxel_s, ITMVoxelBlockHash>("hash ITMVoxel_s 10 mm", 0.01f, 4);
+  ok &= run<ITMVoxel_f_rgb, ITMVoxelBlockHash>("hash ITMVoxel_f_rgb 10 mm", 0.01f, 3);
+  ok &= run<ITMVoxel_s, ITMPlainVoxelArray>("dense 128^3 ITMVoxel_s 10 mm", 0.01f, 3);
+  return ok ? 0 : 1;
+}

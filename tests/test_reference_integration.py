@@ -1,0 +1,45 @@
+"""The binding a maintainer of the reference adds (integration/ITMEngines_HIP.h: classes derived from the reference's
+own abstract engines, forwarding to the C-ABI), exercised through those abstract interfaces side by side with the
+reference's CPU engines (integration/ref_hip_demo.cpp).
+
+  * here (reference tree present): the adapter + demo compile and link against the reference headers and libitmhip.so;
+  * on the GPU box: the prebuilt binary (oracle/_ref/ref_hip_demo, travels with the snapshot) must report bit-equal
+    visible lists, range images, ICP maps, renders, hash tables, free lists and voxels for a hash, a colour hash and a
+    dense scene.
+"""
+import json
+import os
+import subprocess
+
+import pytest
+
+import itm_testlib as T
+
+DEMO = os.path.join(T.ORACLE_DIR, "_ref", "ref_hip_demo")
+
+
+def test_adapter_compiles_against_the_reference():
+    if not os.path.isdir(T.REFERENCE_TREE):
+        pytest.skip("reference tree not on this machine")
+    import infinitam_amd
+    if not os.path.exists(infinitam_amd.lib_path()):
+        infinitam_amd.build()
+    subprocess.run(["make", "-C", T.ORACLE_DIR, "hipdemo"], check=True, capture_output=True)
+    assert os.path.exists(DEMO)
+    out = subprocess.run(["nm", "-C", "--undefined-only", DEMO], capture_output=True, text=True, check=True).stdout
+    for sym in ("itm_allocate_scene_from_depth", "itm_integrate_into_scene", "itm_create_expected_depths", "itm_create_icp_maps", "itm_render_image"):
+        assert sym in out, sym            # the virtuals really forward to the C-ABI
+
+
+@pytest.mark.gpu
+def test_reference_interfaces_drive_the_hip_engines_bit_exactly():
+    if not os.path.exists(DEMO):
+        pytest.skip("oracle/_ref/ref_hip_demo was not built (needs the reference tree at build time)")
+    res = subprocess.run([DEMO], capture_output=True, text=True, timeout=600)
+    lines = [json.loads(l) for l in res.stdout.strip().splitlines() if l.startswith("{")]
+    configs = [l for l in lines if "config" in l]
+    assert len(configs) == 3, res.stdout + res.stderr
+    for c in configs:
+        assert c["equal"], c
+        assert c["icp_points"] > 3000
+    assert res.returncode == 0
