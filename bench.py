@@ -154,9 +154,15 @@ def main():
                        "visible_blocks_last_frame": counters["noVisibleEntries"]},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
-        print(json.dumps(out))
     if world > 1 or args.force_exchange:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints its version banner through C stdio, which a pipe only delivers at exit: flush it first so that the
+        # JSON line is the last line on stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 def algorithmic_bytes():
