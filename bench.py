@@ -200,27 +200,36 @@ def read_roofline(be, scene, rs, steps, counters):
             "launches_timed": r["calls"]}
 
 
-def run_cpu_baseline(nframes):
-    """The CPU oracle (a port of the reference CPU engines, bit-equal to them) timed on ONE host
-    core on the first `nframes` frames of the same workload.  Checker code, used only here."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import itm_testlib as T
-    ob = T.oracle_backend()
-    sc = T.Scenario(name="bench_cpu", voxelSize=VOXEL_SIZE, mu=MU, localBlockNum=LOCAL_BLOCKS, trajectory="bench", frames=nframes)
-    ses = T.Session(ob, sc)
-    views = [ses.view(k) for k in range(min(nframes, 4))]  # warm page cache of the generator
-    del views
-    ses.close()
-    ses = T.Session(ob, sc)
-    depth = [ob.to_backend(sc.depth(k)) for k in range(nframes)]
+def _time_cpu(be, sc, nframes, T):
+    ses = T.Session(be, sc)
+    depth = [be.to_backend(sc.depth(k)) for k in range(nframes)]
     t0 = time.perf_counter()
     for k in range(nframes):
         v = T.View(depth[k], sc.w, sc.h, M_d=sc.pose(k), intr_d=sc.intr())
         ses.scene.process_frame(v, ses.rs, ses.points, ses.normals)
     dt = time.perf_counter() - t0
     ses.close()
-    return {"value": round(nframes / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"first {nframes} frames of the same workload, oracle/libitm_oracle.so single thread"}
+    return nframes / dt
+
+
+def run_cpu_baseline(nframes):
+    """The CPU oracle (a port of the reference CPU engines, bit-equal to them) timed on ONE host
+    core on the first `nframes` frames of the same workload; beside it, where the prebuilt oracle/_ref library
+    travelled along, the reference's OWN CPU engines on the same frames (their voxel pool is the fork's compile-time
+    0x10000 blocks instead of 0x40000, which this workload never exhausts).  Checker code, used only here."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import itm_testlib as T
+    ob = T.oracle_backend()
+    sc = T.Scenario(name="bench_cpu", voxelSize=VOXEL_SIZE, mu=MU, localBlockNum=LOCAL_BLOCKS, trajectory="bench", frames=nframes)
+    _time_cpu(ob, T.Scenario(name="warm", voxelSize=VOXEL_SIZE, mu=MU, localBlockNum=LOCAL_BLOCKS, trajectory="bench", frames=2), 2, T)
+    out = {"value": round(_time_cpu(ob, sc, nframes, T), 3), "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": f"first {nframes} frames of the same workload, oracle/libitm_oracle.so single thread"}
+    if os.path.exists(T.REF_LIB):
+        rb = T.Backend(T.REF_LIB, "itmr_")
+        sc_ref = T.Scenario(name="bench_ref", voxelSize=VOXEL_SIZE, mu=MU, trajectory="bench", frames=nframes)
+        out["reference_engines"] = {"value": round(_time_cpu(rb, sc_ref, nframes, T), 3), "unit": "frames/s", "cores": 1,
+                                    "note": "ITMSceneReconstructionEngine_CPU / ITMVisualisationEngine_CPU compiled from the reference sources (oracle/_ref), same frames"}
+    return out
 
 
 if __name__ == "__main__":
