@@ -159,25 +159,6 @@ __device__ inline bool fuse_voxel(typename VX::Reg& r, float mx, float my, float
   return touched;
 }
 
-#ifndef ITM_XCD_AFFINITY
-#define ITM_XCD_AFFINITY 0   // measured: ray cast 82 -> 76 us but integrate 18 -> 28 us (static band partition is unbalanced); see DESIGN.md
-#endif
-
-// Image band (0..7) a voxel block projects into: the XCD that ray-casts that band (visualise.hip) also integrates
-// the block, so the lines it writes are still in that XCD's L2 when the rays read them.  Only placement depends
-// on this value, never a result, so the approximate division is fine.
-__device__ inline int block_band(int bx, int by, int bz, const FuseParams& p) {
-  const float c = ((float)kBlockSide * 0.5f);
-  const Vec3 q = transform_point(p.M_d, ((float)(bx * kBlockSide) + c) * p.voxelSize, ((float)(by * kBlockSide) + c) * p.voxelSize,
-                                 ((float)(bz * kBlockSide) + c) * p.voxelSize);
-  float u = (q.z > 1e-6f) ? __fdividef(p.fx * q.x, q.z) + p.cx : 0.0f;
-  u = fminf(fmaxf(u, 0.0f), (float)(p.W - 1));
-  const int tilesPerBand = ((p.W + 15) / 16 + 7) / 8;
-  const int b = (int)u / (16 * tilesPerBand);
-  return b < 7 ? b : 7;
-}
-
-// One 8x8x8 block per 512-lane workgroup iteration; workgroup `wgIdx` of `wgCount` persistent workgroups.
 template <class VX>
 __device__ inline void integrate_hash_body(int wgIdx, int wgCount, const int32_t* __restrict__ visibleIds, const RenderCounters* __restrict__ rc,
                                            const uint4* __restrict__ hash, void* __restrict__ vba,
@@ -185,33 +166,6 @@ __device__ inline void integrate_hash_body(int wgIdx, int wgCount, const int32_t
   const int nv = rc->noVisibleEntries;
   const int t = threadIdx.x;
   const int x = t & 7, y = (t >> 3) & 7, z = t >> 6;
-#if ITM_XCD_AFFINITY
-  // The workgroups of XCD k (blockIdx % 8 == k) filter the visible list for the blocks of image band k: every
-  // wave tests the same 64 entries (one per lane) and the workgroup then integrates the matching blocks.
-  const int lane = t & 63, xcd = wgIdx & 7, wg = wgIdx >> 3, nWg = wgCount >> 3;
-  for (int c0 = wg * 64; c0 < nv; c0 += nWg * 64) {
-    const int e = c0 + lane;
-    HashEntry he; he.px = he.py = he.pz = 0; he.ptr = -1; he.offset = 0;
-    int band = -1;
-    if (e < nv) {
-      he = unpack_entry(hash[visibleIds[e]]);
-      if (he.ptr >= 0) band = block_band(he.px, he.py, he.pz, p);
-    }
-    unsigned long long m = __ballot(band == xcd);
-    while (m) {
-      const int j = __ffsll((long long)m) - 1;
-      m &= m - 1;
-      const int bpx = __shfl((int)he.px, j, 64), bpy = __shfl((int)he.py, j, 64), bpz = __shfl((int)he.pz, j, 64), ptr = __shfl(he.ptr, j, 64);
-      const size_t vi = (size_t)ptr * kBlockVoxels + t;
-      typename VX::Reg r = VX::load(vba, vi);
-      if (p.stopAtMax && VX::w_depth(r) == p.maxW) continue;
-      const float mx = (float)(bpx * kBlockSide + x) * p.voxelSize;
-      const float my = (float)(bpy * kBlockSide + y) * p.voxelSize;
-      const float mz = (float)(bpz * kBlockSide + z) * p.voxelSize;
-      if (fuse_voxel<VX>(r, mx, my, mz, depth, rgb, p)) VX::store(vba, vi, r);
-    }
-  }
-#else
   // (A software-pipelined variant -- visible id three blocks ahead, hash entry two, voxels one -- was measured: no
   // gain for ITMVoxel_s, config 5 253 -> 280 us.  The loop is not bound by its read chain: with colour voxels nearly
   // every wave has a lane inside the colour band and pays the whole colour path, i.e. it is ALU bound.)
@@ -226,7 +180,6 @@ __device__ inline void integrate_hash_body(int wgIdx, int wgCount, const int32_t
     const float mz = (float)(he.pz * kBlockSide + z) * p.voxelSize;
     if (fuse_voxel<VX>(r, mx, my, mz, depth, rgb, p)) VX::store(vba, vi, r);
   }
-#endif
 }
 
 template <class VX>

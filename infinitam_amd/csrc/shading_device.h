@@ -9,7 +9,6 @@
 
 #include "itm_internal.h"
 #include "raycast_device.h"
-#include "raycast_sm.h"
 
 namespace itm {
 

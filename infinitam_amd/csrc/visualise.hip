@@ -26,12 +26,6 @@
 #include "range_device.h"
 #include "wave_utils.h"
 
-#ifndef ITM_RAY_WAVE_8X8
-#define ITM_RAY_WAVE_8X8 0
-#endif
-#ifndef ITM_XCD_AFFINITY
-#define ITM_XCD_AFFINITY 0   // measured: ray cast 82 -> 76 us but integrate 18 -> 28 us (static band partition is unbalanced); see DESIGN.md
-#endif
 
 namespace itm {
 
@@ -192,39 +186,22 @@ int launch_expected_depths(const itm_scene* s, const float* M, const float* intr
 template <class VX, bool DENSE>
 __global__ void __launch_bounds__(256) raycast_kernel(VolumeView vol, const float2* __restrict__ range, float4* __restrict__ out, RayParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // XCD-affine tile order.  Workgroups are dealt round-robin over the 8 XCDs (workgroup L runs on XCD L % 8,
-  // measured: tools/microbench/l2_affinity.hip) and every XCD has a private 4 MiB L2 in which lines written by
-  // the previous kernel stay valid.  The image is cut into 8 vertical bands; band b is ray-cast by XCD b and the
-  // integration kernel updates the voxel blocks that project into band b on XCD b as well (integrate.hip), so
-  // most hash-entry and voxel lines a ray touches are L2 hits (~300 cycles) instead of Infinity-Cache round trips
-  // (~1 300 idle, ~2 000 loaded).
+  // (An XCD-affine order -- image band b ray-cast by XCD b, with integration placing the blocks of band b on XCD b --
+  // recovers 5 of the ~17 us the rays lose to voxel lines written on other XCDs, but costs integration 10 us; and 8x8
+  // pixel waves change nothing.  Both measured)
   const int tilesX = (p.W + 15) / 16;
-  const int tilesPerBand = (tilesX + 7) / 8;
-  const int band = blockIdx.x & 7, inBand = blockIdx.x >> 3;
-#if ITM_XCD_AFFINITY
-  const int tx = band * tilesPerBand + inBand % tilesPerBand, ty = inBand / tilesPerBand;
-#else
-  const int lin = inBand * 8 + band; const int tx = lin % (tilesPerBand * 8), ty = lin / (tilesPerBand * 8);
-#endif
-  if (tx >= tilesX) return;
-#if ITM_RAY_WAVE_8X8
-  // one wave = one 8x8 range cell: all 64 rays share [zmin, zmax] and start at the same depth
-  const int x = tx * 16 + (wave & 1) * 8 + (lane & 7);
-  const int y = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
-#else
+  const int tx = blockIdx.x % tilesX, ty = blockIdx.x / tilesX;
   const int x = tx * 16 + (lane & 15);
   const int y = ty * 16 + wave * 4 + (lane >> 4);
-#endif
   if (x >= p.W || y >= p.H) return;
   const float2 mm = range[(x >> 3) + (y >> 3) * p.W];  // floor(x/8) + floor(y/8)*W  (_CPU.cpp:174)
-  out[x + y * p.W] = cast_ray_any<VX, DENSE>(x, y, vol, p, mm);
+  out[x + y * p.W] = cast_ray<VX, DENSE>(x, y, vol, p, mm);
 }
 
 int launch_raycast(const itm_scene* s, const float* invM, const float* intr, itm_render_state* rs, float4* dst, hipStream_t st) {
   RayParams p; make_ray_params(s, invM, intr, rs->w, rs->h, p);
   const VolumeView vol = make_volume(s);
-  const int tilesPerBand = ((rs->w + 15) / 16 + 7) / 8;
-  const dim3 grid(8 * tilesPerBand * ((rs->h + 15) / 16));
+  const dim3 grid(((rs->w + 15) / 16) * ((rs->h + 15) / 16));
   const bool dense = s->cfg.indexType == ITM_INDEX_DENSE;
   KernelTimer tk(s, ITM_TK_RAYCAST, st);
   int rc = dispatch_voxel(s->cfg.voxelType, [&](auto vx) {

@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(256) fwd_raycast_missing_kernel(VolumeView vol
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int loc = missing[i];
     const int y = loc / p.W, x = loc - y * p.W;
-    fwd[loc] = cast_ray_any<VX, DENSE>(x, y, vol, p, range[(x >> 3) + (y >> 3) * p.W]);
+    fwd[loc] = cast_ray<VX, DENSE>(x, y, vol, p, range[(x >> 3) + (y >> 3) * p.W]);
   }
 }
 
