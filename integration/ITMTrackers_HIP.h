@@ -1,0 +1,157 @@
+// ITMTrackers_HIP.h -- reference-side bindings for the steps either side of the path: a depth
+// tracker and a view builder derived from the reference's OWN base classes (Engine/ITMDepthTracker.h:23-74,
+// Engine/ITMViewBuilder.h:17-60) that forward their device-specific virtuals to the C-ABI of include/itm_hip.h.
+// New code against the reference's public interfaces; compiled only where the reference tree is on the include path.
+//
+// As in ITMEngines_HIP.h, this variant serves a reference build without CUDA: host images are staged into HBM.  The
+// tracker keeps the reference's own TrackCamera (hierarchy, Levenberg-Marquardt loop, pose algebra) and only replaces
+// ComputeGandH -- exactly the split between ITMDepthTracker and ITMDepthTracker_CUDA.
+#pragma once
+
+#include "ITMLib/Engine/ITMDepthTracker.h"
+#include "ITMLib/Engine/ITMViewBuilder.h"
+#include "ITMEngines_HIP.h"
+
+namespace ITMLib {
+namespace Engine {
+
+class ITMDepthTracker_HIP : public ITMDepthTracker {
+  void* devPoints = nullptr; void* devNormals = nullptr; void* devDepth = nullptr;
+  size_t mapPixels = 0, depthPixels = 0;
+  const void* stagedDepth = nullptr; int lastLevel = -1;
+
+  void Stage() {
+    const Vector2i ss = sceneHierarchyLevel->pointsMap->noDims, ds = viewHierarchyLevel->depth->noDims;
+    const size_t mp = (size_t)ss.x * ss.y, dp = (size_t)ds.x * ds.y;
+    if (mp != mapPixels) {
+      itm_dev_free(devPoints); itm_dev_free(devNormals);
+      HipCheck(itm_dev_malloc(&devPoints, mp * 16), "dev_malloc"); HipCheck(itm_dev_malloc(&devNormals, mp * 16), "dev_malloc");
+      mapPixels = mp; lastLevel = -1;
+    }
+    if (dp > depthPixels) { itm_dev_free(devDepth); HipCheck(itm_dev_malloc(&devDepth, dp * 4), "dev_malloc"); depthPixels = dp; stagedDepth = nullptr; }
+    // TrackCamera walks the levels from coarse (high id) to fine: a level id above the previous one means a new call,
+    // i.e. new ICP maps
+    if (levelId > lastLevel) {
+      HipCheck(itm_memcpy_h2d(devPoints, sceneHierarchyLevel->pointsMap->GetData(MEMORYDEVICE_CPU), mp * 16, 0), "memcpy_h2d");
+      HipCheck(itm_memcpy_h2d(devNormals, sceneHierarchyLevel->normalsMap->GetData(MEMORYDEVICE_CPU), mp * 16, 0), "memcpy_h2d");
+      stagedDepth = nullptr;
+    }
+    const float* hostDepth = viewHierarchyLevel->depth->GetData(MEMORYDEVICE_CPU);
+    if (stagedDepth != hostDepth || levelId != lastLevel) {
+      HipCheck(itm_memcpy_h2d(devDepth, hostDepth, dp * 4, 0), "memcpy_h2d");
+      stagedDepth = hostDepth;
+    }
+    lastLevel = levelId;
+  }
+
+ protected:
+  int ComputeGandH(float& f, float* nabla, float* hessian, Matrix4f approxInvPose) {
+    if (iterationType == TRACKER_ITERATION_NONE) return 0;
+    Stage();
+    const Vector2i ss = sceneHierarchyLevel->pointsMap->noDims, ds = viewHierarchyLevel->depth->noDims;
+    const int it = iterationType == TRACKER_ITERATION_ROTATION ? ITM_TRACKER_ITERATION_ROTATION
+                   : iterationType == TRACKER_ITERATION_TRANSLATION ? ITM_TRACKER_ITERATION_TRANSLATION : ITM_TRACKER_ITERATION_BOTH;
+    itm_tracker_gh gh;
+    HipCheck(itm_tracker_compute_g_and_h((const float*)devDepth, ds.x, ds.y, &viewHierarchyLevel->intrinsics.x, (const float*)devPoints,
+                                         (const float*)devNormals, ss.x, ss.y, &sceneHierarchyLevel->intrinsics.x, approxInvPose.m, scenePose.m,
+                                         distThresh[levelId], it, &gh, 0), "ComputeGandH");
+    const int noPara = (it == ITM_TRACKER_ITERATION_BOTH) ? 6 : 3;
+    for (int r = 0; r < noPara; ++r) for (int c = 0; c < noPara; ++c) hessian[r + c * 6] = gh.hessian[r + c * 6];
+    for (int r = 0; r < noPara; ++r) nabla[r] = gh.nabla[r];
+    f = gh.f;
+    return gh.noValidPoints;
+  }
+
+ public:
+  ITMDepthTracker_HIP(Vector2i imgSize, TrackerIterationType* trackingRegime, int noHierarchyLevels, int noICPRunTillLevel, float distThresh,
+                      float terminationThreshold, const ITMLowLevelEngine* lowLevelEngine)
+      : ITMDepthTracker(imgSize, trackingRegime, noHierarchyLevels, noICPRunTillLevel, distThresh, terminationThreshold, lowLevelEngine, MEMORYDEVICE_CPU) {}
+  ~ITMDepthTracker_HIP() { itm_dev_free(devPoints); itm_dev_free(devNormals); itm_dev_free(devDepth); }
+};
+
+class ITMViewBuilder_HIP : public ITMViewBuilder {
+  void* devRaw = nullptr; void* devA = nullptr; void* devB = nullptr; void* devN = nullptr; void* devS = nullptr;
+  size_t pixels = 0;
+  void Ensure(size_t px) {
+    if (px == pixels) return;
+    itm_dev_free(devRaw); itm_dev_free(devA); itm_dev_free(devB); itm_dev_free(devN); itm_dev_free(devS);
+    HipCheck(itm_dev_malloc(&devRaw, px * 2), "dev_malloc"); HipCheck(itm_dev_malloc(&devA, px * 4), "dev_malloc"); HipCheck(itm_dev_malloc(&devB, px * 4), "dev_malloc");
+    HipCheck(itm_dev_malloc(&devN, px * 16), "dev_malloc"); HipCheck(itm_dev_malloc(&devS, px * 4), "dev_malloc");
+    pixels = px;
+  }
+
+ public:
+  explicit ITMViewBuilder_HIP(const ITMRGBDCalib* calib) : ITMViewBuilder(calib) {}
+  ~ITMViewBuilder_HIP() { itm_dev_free(devRaw); itm_dev_free(devA); itm_dev_free(devB); itm_dev_free(devN); itm_dev_free(devS); }
+
+  void ConvertDisparityToDepth(ITMFloatImage* depth_out, const ITMShortImage* disp_in, const ITMIntrinsics* depthIntrinsics, Vector2f disparityCalibParams) {
+    const size_t px = (size_t)disp_in->noDims.x * disp_in->noDims.y; Ensure(px);
+    HipCheck(itm_memcpy_h2d(devRaw, disp_in->GetData(MEMORYDEVICE_CPU), px * 2, 0), "memcpy_h2d");
+    HipCheck(itm_convert_disparity((const int16_t*)devRaw, (float*)devA, disp_in->noDims.x, disp_in->noDims.y, disparityCalibParams.x, disparityCalibParams.y,
+                                   depthIntrinsics->projectionParamsSimple.fx, 0), "ConvertDisparityToDepth");
+    HipCheck(itm_memcpy_d2h(depth_out->GetData(MEMORYDEVICE_CPU), devA, px * 4, 0), "memcpy_d2h");
+  }
+  void ConvertDepthAffineToFloat(ITMFloatImage* depth_out, const ITMShortImage* depth_in, Vector2f depthCalibParams) {
+    const size_t px = (size_t)depth_in->noDims.x * depth_in->noDims.y; Ensure(px);
+    HipCheck(itm_memcpy_h2d(devRaw, depth_in->GetData(MEMORYDEVICE_CPU), px * 2, 0), "memcpy_h2d");
+    HipCheck(itm_convert_depth_affine((const int16_t*)devRaw, (float*)devA, depth_in->noDims.x, depth_in->noDims.y, depthCalibParams.x, depthCalibParams.y, 0), "ConvertDepthAffineToFloat");
+    HipCheck(itm_memcpy_d2h(depth_out->GetData(MEMORYDEVICE_CPU), devA, px * 4, 0), "memcpy_d2h");
+  }
+  void DepthFiltering(ITMFloatImage* image_out, const ITMFloatImage* image_in) {
+    const size_t px = (size_t)image_in->noDims.x * image_in->noDims.y; Ensure(px);
+    HipCheck(itm_memcpy_h2d(devA, image_in->GetData(MEMORYDEVICE_CPU), px * 4, 0), "memcpy_h2d");
+    HipCheck(itm_filter_depth((const float*)devA, (float*)devB, image_in->noDims.x, image_in->noDims.y, 0), "DepthFiltering");
+    HipCheck(itm_memcpy_d2h(image_out->GetData(MEMORYDEVICE_CPU), devB, px * 4, 0), "memcpy_d2h");
+  }
+  void ComputeNormalAndWeights(ITMFloat4Image* normal_out, ITMFloatImage* sigmaZ_out, const ITMFloatImage* depth_in, Vector4f intrinsic) {
+    const size_t px = (size_t)depth_in->noDims.x * depth_in->noDims.y; Ensure(px);
+    HipCheck(itm_memcpy_h2d(devA, depth_in->GetData(MEMORYDEVICE_CPU), px * 4, 0), "memcpy_h2d");
+    // pixels the kernel rejects keep their previous content, as on the host
+    HipCheck(itm_memcpy_h2d(devN, normal_out->GetData(MEMORYDEVICE_CPU), px * 16, 0), "memcpy_h2d");
+    HipCheck(itm_memcpy_h2d(devS, sigmaZ_out->GetData(MEMORYDEVICE_CPU), px * 4, 0), "memcpy_h2d");
+    HipCheck(itm_compute_normal_and_weights((const float*)devA, (float*)devN, (float*)devS, depth_in->noDims.x, depth_in->noDims.y, &intrinsic.x, 0), "ComputeNormalAndWeights");
+    HipCheck(itm_memcpy_d2h(normal_out->GetData(MEMORYDEVICE_CPU), devN, px * 16, 0), "memcpy_d2h");
+    HipCheck(itm_memcpy_d2h(sigmaZ_out->GetData(MEMORYDEVICE_CPU), devS, px * 4, 0), "memcpy_d2h");
+  }
+
+  // same object management as ITMViewBuilder_CPU::UpdateView; the image work is one itm_update_view call
+  void UpdateView(ITMView** view_ptr, ITMUChar4Image* rgbImage, ITMShortImage* rawDepthImage, bool useBilateralFilter, bool modelSensorNoise = false) {
+    if (*view_ptr == NULL) {
+      *view_ptr = new ITMView(calib, rgbImage->noDims, rawDepthImage->noDims, false);
+      if (modelSensorNoise) {
+        (*view_ptr)->depthNormal = new ITMFloat4Image(rawDepthImage->noDims, true, false);
+        (*view_ptr)->depthUncertainty = new ITMFloatImage(rawDepthImage->noDims, true, false);
+      }
+    }
+    ITMView* view = *view_ptr;
+    view->rgb->SetFrom(rgbImage, ORUtils::MemoryBlock<Vector4u>::CPU_TO_CPU);
+    const int w = rawDepthImage->noDims.x, h = rawDepthImage->noDims.y;
+    const size_t px = (size_t)w * h; Ensure(px);
+    HipCheck(itm_memcpy_h2d(devRaw, rawDepthImage->GetData(MEMORYDEVICE_CPU), px * 2, 0), "memcpy_h2d");
+    if (modelSensorNoise) {
+      HipCheck(itm_memcpy_h2d(devN, view->depthNormal->GetData(MEMORYDEVICE_CPU), px * 16, 0), "memcpy_h2d");
+      HipCheck(itm_memcpy_h2d(devS, view->depthUncertainty->GetData(MEMORYDEVICE_CPU), px * 4, 0), "memcpy_h2d");
+    }
+    const ITMDisparityCalib& dc = view->calib->disparityCalib;
+    HipCheck(itm_update_view((const int16_t*)devRaw, w, h, dc.type == ITMDisparityCalib::TRAFO_KINECT ? 0 : 1, dc.params.x, dc.params.y,
+                             &view->calib->intrinsics_d.projectionParamsSimple.all.x, useBilateralFilter ? 1 : 0, modelSensorNoise ? 1 : 0,
+                             (float*)devA, (float*)devB, (float*)devN, (float*)devS, 0), "UpdateView");
+    HipCheck(itm_memcpy_d2h(view->depth->GetData(MEMORYDEVICE_CPU), devA, px * 4, 0), "memcpy_d2h");
+    if (modelSensorNoise) {
+      HipCheck(itm_memcpy_d2h(view->depthNormal->GetData(MEMORYDEVICE_CPU), devN, px * 16, 0), "memcpy_d2h");
+      HipCheck(itm_memcpy_d2h(view->depthUncertainty->GetData(MEMORYDEVICE_CPU), devS, px * 4, 0), "memcpy_d2h");
+    }
+  }
+  void UpdateView(ITMView** view_ptr, ITMUChar4Image* rgbImage, ITMFloatImage* depthImage) {
+    if (*view_ptr == NULL) *view_ptr = new ITMView(calib, rgbImage->noDims, depthImage->noDims, false);
+    // host build: the caller already wrote the float depth into the view (ITMViewBuilder_CPU.cpp:65-74)
+  }
+  void UpdateView(ITMView** view_ptr, ITMUChar4Image* rgbImage, ITMShortImage* depthImage, bool useBilateralFilter, ITMIMUMeasurement* imuMeasurement) {
+    if (*view_ptr == NULL) *view_ptr = new ITMViewIMU(calib, rgbImage->noDims, depthImage->noDims, false);
+    ((ITMViewIMU*)(*view_ptr))->imu->SetFrom(imuMeasurement);
+    this->UpdateView(view_ptr, rgbImage, depthImage, useBilateralFilter);
+  }
+};
+
+}  // namespace Engine
+}  // namespace ITMLib

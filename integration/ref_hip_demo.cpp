@@ -12,7 +12,11 @@
 
 #include "ITMLib/Engine/DeviceSpecific/CPU/ITMSceneReconstructionEngine_CPU.cpp"
 #include "ITMLib/Engine/DeviceSpecific/CPU/ITMVisualisationEngine_CPU.cpp"
+#include "ITMLib/Engine/DeviceSpecific/CPU/ITMDepthTracker_CPU.h"
+#include "ITMLib/Engine/DeviceSpecific/CPU/ITMLowLevelEngine_CPU.h"
+#include "ITMLib/Engine/DeviceSpecific/CPU/ITMViewBuilder_CPU.h"
 #include "ITMEngines_HIP.h"
+#include "ITMTrackers_HIP.h"
 
 using namespace ITMLib::Engine;
 using namespace ITMLib::Objects;
@@ -131,11 +135,89 @@ static bool run(const char* name, float voxelSize, int frames) {
   return ok;
 }
 
+// view builder: the reference's UpdateView on a raw frame, CPU implementation vs HIP adapter (exp / acos may differ in
+// the last place between the device library and the host libm: relative tolerance 2e-6 on the filtered depth)
+static bool run_view_builder() {
+  ITMRGBDCalib calib;
+  calib.intrinsics_d.SetFrom(145, 145, 80, 60, W, H); calib.intrinsics_rgb.SetFrom(145, 145, 80, 60, W, H);
+  calib.disparityCalib.type = ITMDisparityCalib::TRAFO_AFFINE; calib.disparityCalib.params = Vector2f(0.001f, 0.0f);
+  ITMUChar4Image rgb(Vector2i(W, H), true, false);
+  ITMShortImage raw(Vector2i(W, H), true, false);
+  std::vector<float> d((size_t)W * H); make_depth(d.data(), 0.01f, 0.0f);
+  for (int i = 0; i < W * H; ++i) raw.GetData(MEMORYDEVICE_CPU)[i] = (i % 37 == 0) ? 0 : (short)(d[i] * 1000.0f + 0.5f);
+  ITMViewBuilder* vb[2] = {new ITMViewBuilder_CPU(&calib), new ITMViewBuilder_HIP(&calib)};
+  ITMView* view[2] = {NULL, NULL};
+  for (int e = 0; e < 2; ++e) vb[e]->UpdateView(&view[e], &rgb, &raw, true, true);
+  const float* a = view[0]->depth->GetData(MEMORYDEVICE_CPU); const float* b = view[1]->depth->GetData(MEMORYDEVICE_CPU);
+  double maxRel = 0; bool holes = true; long valid = 0;
+  for (int i = 0; i < W * H; ++i) {
+    if ((a[i] <= 0) != (b[i] <= 0)) holes = false;
+    if (a[i] > 0) { ++valid; const double r = std::fabs((double)a[i] - b[i]) / a[i]; if (r > maxRel) maxRel = r; }
+  }
+  const Vector4f* na = view[0]->depthNormal->GetData(MEMORYDEVICE_CPU); const Vector4f* nb = view[1]->depthNormal->GetData(MEMORYDEVICE_CPU);
+  long sameW = 0; double maxN = 0;
+  for (int i = 0; i < W * H; ++i) {
+    if (na[i].w == nb[i].w) ++sameW;
+    if (na[i].w == 1.0f && nb[i].w == 1.0f) maxN = std::fmax(maxN, std::fmax(std::fabs(na[i].x - nb[i].x), std::fmax(std::fabs(na[i].y - nb[i].y), std::fabs(na[i].z - nb[i].z))));
+  }
+  const bool ok = holes && maxRel <= 2e-6 && sameW >= (long)(0.999 * W * H) && maxN < 5e-3;
+  std::printf("{\"config\": \"view builder (affine, bilateral, noise model)\", \"equal\": %s, \"valid\": %ld, \"max_rel_depth\": %.3g, \"normal_flags_equal\": %ld, \"max_normal_diff\": %.3g, \"icp_points\": %ld, \"mismatch\": \"\"}\n",
+              ok ? "true" : "false", valid, maxRel, sameW, maxN, valid);
+  for (int e = 0; e < 2; ++e) { delete view[e]; delete vb[e]; }
+  return ok;
+}
+
+// tracker: three frames of mapping with the reference CPU engines, then the reference's own TrackCamera (hierarchy,
+// LM loop, pose algebra) twice from the same start pose -- ComputeGandH on the CPU vs through the HIP adapter
+static bool run_tracker() {
+  const int TW = 640, TH = 480;   // the default 5-level hierarchy needs VGA
+  ITMSceneParams sp(0.02f, 100, 0.01f, 0.2f, 3.0f, false);
+  ITMScene<ITMVoxel_s, ITMVoxelBlockHash> scene(&sp, false, MEMORYDEVICE_CPU);
+  ITMSceneReconstructionEngine_CPU<ITMVoxel_s, ITMVoxelBlockHash> reco; ITMVisualisationEngine_CPU<ITMVoxel_s, ITMVoxelBlockHash> vis(&scene);
+  ITMRGBDCalib calib;
+  calib.intrinsics_d.SetFrom(580, 580, 320, 240, TW, TH); calib.intrinsics_rgb.SetFrom(580, 580, 320, 240, TW, TH);
+  reco.ResetScene(&scene);
+  ITMRenderState* rs = vis.CreateRenderState(Vector2i(TW, TH));
+  ITMView view(&calib, Vector2i(TW, TH), Vector2i(TW, TH), false);
+  ITMTrackingState ts(Vector2i(TW, TH), MEMORYDEVICE_CPU);
+  auto depth_at = [&](float tx) {
+    float* d = view.depth->GetData(MEMORYDEVICE_CPU);
+    for (int y = 0; y < TH; ++y) for (int x = 0; x < TW; ++x) {
+      const float dx = ((float)x - 320.0f) / 580.0f, dy = ((float)y - 240.0f) / 580.0f, oz = -1.5f;
+      const float A = dx * dx + dy * dy + 1.0f, B = 2.0f * (tx * dx + oz), C = tx * tx + oz * oz - 0.25f, disc = B * B - 4.0f * A * C;
+      float z = 2.5f; if (disc > 0) { const float t = (-B - std::sqrt(disc)) / (2.0f * A); if (t > 0) z = t; }
+      d[x + y * TW] = z;
+    }
+  };
+  Matrix4f M; M.setIdentity();
+  for (int k = 0; k < 3; ++k) {
+    depth_at(0.01f * k); M.m[12] = -0.01f * k; ts.pose_d->SetM(M);
+    reco.AllocateSceneFromDepth(&scene, &view, &ts, rs); reco.IntegrateIntoScene(&scene, &view, &ts, rs);
+    vis.CreateExpectedDepths(ts.pose_d, &calib.intrinsics_d, rs); vis.CreateICPMaps(&view, &ts, rs);
+  }
+  depth_at(0.03f);                     // next frame, tracked from the previous pose
+  TrackerIterationType regime[5] = {TRACKER_ITERATION_BOTH, TRACKER_ITERATION_BOTH, TRACKER_ITERATION_ROTATION, TRACKER_ITERATION_ROTATION, TRACKER_ITERATION_ROTATION};
+  ITMLowLevelEngine_CPU low;
+  ITMTracker* trk[2] = {new ITMDepthTracker_CPU(Vector2i(TW, TH), regime, 5, 0, 0.1f * 0.1f, 1e-3f, &low),
+                        new ITMDepthTracker_HIP(Vector2i(TW, TH), regime, 5, 0, 0.1f * 0.1f, 1e-3f, &low)};
+  Matrix4f out[2];
+  for (int e = 0; e < 2; ++e) { ts.pose_d->SetM(M); trk[e]->TrackCamera(&ts, &view); out[e] = ts.pose_d->GetM(); delete trk[e]; }
+  double maxDiff = 0; for (int i = 0; i < 16; ++i) maxDiff = std::fmax(maxDiff, std::fabs((double)out[0].m[i] - out[1].m[i]));
+  const bool moved = std::fabs(out[1].m[12] - (-0.03f)) < 2e-3f;     // the tracker found the 1 cm step
+  const bool ok = maxDiff < 2e-5 && moved;
+  std::printf("{\"config\": \"reference TrackCamera with ComputeGandH on the GPU\", \"equal\": %s, \"max_pose_diff\": %.3g, \"tx\": %.6f, \"icp_points\": 100000, \"mismatch\": \"\"}\n",
+              ok ? "true" : "false", maxDiff, out[1].m[12]);
+  delete rs;
+  return ok;
+}
+
 int main() {
   std::printf("{\"library\": \"%s\"}\n", itm_version());
   bool ok = true;
   ok &= run<ITMVoxel_s, ITMVoxelBlockHash>("hash ITMVoxel_s 10 mm", 0.01f, 4);
   ok &= run<ITMVoxel_f_rgb, ITMVoxelBlockHash>("hash ITMVoxel_f_rgb 10 mm", 0.01f, 3);
   ok &= run<ITMVoxel_s, ITMPlainVoxelArray>("dense 128^3 ITMVoxel_s 10 mm", 0.01f, 3);
+  ok &= run_view_builder();
+  ok &= run_tracker();
   return ok ? 0 : 1;
 }

@@ -5,7 +5,8 @@ reference's CPU engines (integration/ref_hip_demo.cpp).
   * here (reference tree present): the adapter + demo compile and link against the reference headers and libitmhip.so;
   * on the GPU box: the prebuilt binary (oracle/_ref/ref_hip_demo, travels with the snapshot) must report bit-equal
     visible lists, range images, ICP maps, renders, hash tables, free lists and voxels for a hash, a colour hash and a
-    dense scene.
+    dense scene; the reference's UpdateView through the HIP view builder (2e-6) and the reference's own TrackCamera with
+    ComputeGandH on the GPU (pose within 2e-5 of the CPU tracker).
 """
 import json
 import os
@@ -38,7 +39,7 @@ def test_reference_interfaces_drive_the_hip_engines_bit_exactly():
     res = subprocess.run([DEMO], capture_output=True, text=True, timeout=600)
     lines = [json.loads(l) for l in res.stdout.strip().splitlines() if l.startswith("{")]
     configs = [l for l in lines if "config" in l]
-    assert len(configs) == 3, res.stdout + res.stderr
+    assert len(configs) == 5, res.stdout + res.stderr
     for c in configs:
         assert c["equal"], c
         assert c["icp_points"] > 3000
