@@ -115,8 +115,18 @@ __device__ inline void fuse_colour(typename VX::Reg& r, float mx, float my, floa
   VX::get_color(r, oc, owc);
   const float oldW = (float)owc;
   Vec3 pc = transform_point(p.M_rgb, mx, my, mz);
-  const float u = p.fxc * pc.x / pc.z + p.cxc;
-  const float v = p.fyc * pc.y / pc.z + p.cyc;
+  float u, v;
+#if ITM_FAST_DIVISIONS
+  if (pc.z >= 1e-4f && pc.z <= 1e4f) {       // normal range: shared refined reciprocal, exact quotients (as in fuse_depth)
+    const float rz = refined_rcp(pc.z);
+    u = div_by_rcp(p.fxc * pc.x, pc.z, rz) + p.cxc;
+    v = div_by_rcp(p.fyc * pc.y, pc.z, rz) + p.cyc;
+  } else
+#endif
+  {
+    u = p.fxc * pc.x / pc.z + p.cxc;
+    v = p.fyc * pc.y / pc.z + p.cyc;
+  }
   if ((u < 1) || (u > p.Wc - 2) || (v < 1) || (v > p.Hc - 2)) return;
   const int px = (int)floorf(u), py = (int)floorf(v);
   const float dx = u - (float)px, dy = v - (float)py;
@@ -130,12 +140,25 @@ __device__ inline void fuse_colour(typename VX::Reg& r, float mx, float my, floa
   const float c4[3] = {(float)C.x, (float)C.y, (float)C.z}, d4[3] = {(float)D.x, (float)D.y, (float)D.z};
   float newW = oldW + 1.0f;
   int nc[3];
+#if ITM_FAST_DIVISIONS
+  // x / 255 and c / newW (newW an integer in [1, 256]) as Markstein quotients: RN(1/255) is a compile-time constant,
+  // the refined reciprocal equals RN(1/newW) for every such weight, neither significand is all ones
+  // (tests/test_hip_parity.py::test_fast_divisions_are_ieee, cases 5 and 6)
+  const float r255 = 1.0f / 255.0f;
+  const float rW = refined_rcp(newW);
+#endif
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     float m = (a4[k] * (1.0f - dx) * (1.0f - dy) + b4[k] * dx * (1.0f - dy) + c4[k] * (1.0f - dx) * dy + d4[k] * dx * dy);
+#if ITM_FAST_DIVISIONS
+    m = div_markstein(m, 255.0f, r255);
+    float c = div_markstein((float)oc[k], 255.0f, r255) * oldW + m * 1.0f;
+    c = div_markstein(c, newW, rW);
+#else
     m = m / 255.0f;
     float c = ((float)oc[k] / 255.0f) * oldW + m * 1.0f;
     c /= newW;
+#endif
     int vi = (int)round_half_away(c * 255.0f);
     vi = (vi < 255) ? vi : 255;
     nc[k] = (0 < vi) ? vi : 0;

@@ -179,3 +179,11 @@ def test_fast_divisions_are_ieee(hip):
         b = np.full(n, mu32, np.float32)
         r = np.full(n, np.float32(1.0) / mu32, np.float32)
         assert np.array_equal(_divide(hip, 4, eta, b, r).view(np.uint32), (eta / b).view(np.uint32)), mu
+    # (5) colour path: x / 255 with the compile-time reciprocal -- every stored colour, and bilinear blends of colours
+    d255 = np.full(n, np.float32(255.0), np.float32)
+    r255 = np.full(n, np.float32(1.0) / np.float32(255.0), np.float32)
+    xs = np.concatenate([np.arange(0, 256, dtype=np.float32), rng.uniform(0, 255.0, n - 256).astype(np.float32)])
+    assert np.array_equal(_divide(hip, 4, xs, d255, r255).view(np.uint32), (xs / d255).view(np.uint32))
+    # (6) colour running average c / newW: c = old*oldW + new in [0, 256], integer weights 1..256
+    c = (rng.uniform(0, 1.0, n) * ww + rng.uniform(0, 1.0, n)).astype(np.float32)
+    assert np.array_equal(_divide(hip, 2, c, ww).view(np.uint32), (c / ww).view(np.uint32))
