@@ -47,6 +47,8 @@ struct GHParams {
 
 constexpr int kGHValues = 1 + 6 + 21;   // f, nabla, packed lower-triangular hessian
 
+struct GHBlockRecord { double sums[kGHValues]; int count; volatile unsigned int seq; };   // one per workgroup, in pinned host memory
+
 // interpolateBilinear_withHoles for a Vector4f map; returns false when any tap is a hole (w < 0)
 __device__ inline bool bilinear_holes(const float4* __restrict__ src, float px, float py, int W, float4& r) {
   const int ix = (int)(int16_t)(int)floorf(px), iy = (int)(int16_t)(int)floorf(py);   // (short)floor(...)
@@ -64,7 +66,7 @@ __device__ inline bool bilinear_holes(const float4* __restrict__ src, float px, 
 template <int MODE>
 __global__ void __launch_bounds__(256) gh_partial_kernel(const float* __restrict__ depth, const float4* __restrict__ pointsMap,
                                                         const float4* __restrict__ normalsMap, double* __restrict__ partial,
-                                                        int* __restrict__ partialCount, GHParams p) {
+                                                        int* __restrict__ partialCount, GHParams p, GHBlockRecord* __restrict__ hostRec, unsigned int seq) {
   constexpr int NP = (MODE == 3) ? 6 : 3;
   constexpr int NH = NP * (NP + 1) / 2;
   __shared__ double lds[4][kGHValues];
@@ -135,30 +137,28 @@ __global__ void __launch_bounds__(256) gh_partial_kernel(const float* __restrict
   if (lane == 0) ldsCount[wave] = c;
   __syncthreads();
   const int blk = blockIdx.x + blockIdx.y * gridDim.x;
-  if (threadIdx.x < kGHValues) partial[(size_t)blk * kGHValues + threadIdx.x] = ((lds[0][threadIdx.x] + lds[1][threadIdx.x]) + lds[2][threadIdx.x]) + lds[3][threadIdx.x];
-  if (threadIdx.x == 0) partialCount[blk] = ((ldsCount[0] + ldsCount[1]) + ldsCount[2]) + ldsCount[3];
+  const double mine = (threadIdx.x < kGHValues) ? ((lds[0][threadIdx.x] + lds[1][threadIdx.x]) + lds[2][threadIdx.x]) + lds[3][threadIdx.x] : 0.0;
+  const int cnt = ((ldsCount[0] + ldsCount[1]) + ldsCount[2]) + ldsCount[3];
+  if (threadIdx.x < kGHValues) partial[(size_t)blk * kGHValues + threadIdx.x] = mine;
+  if (threadIdx.x == 0) partialCount[blk] = cnt;
+  if (hostRec) {
+    // the same partial goes to a record in pinned host memory, stamped with the call's sequence number: the host adds
+    // the records in block order itself (one launch per Levenberg-Marquardt iteration, no reduction launch, no copy)
+    GHBlockRecord* r = hostRec + blk;
+    if (threadIdx.x < kGHValues) r->sums[threadIdx.x] = mine;
+    if (threadIdx.x == 0) r->count = cnt;
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) { r->seq = seq; __threadfence_system(); }
+  }
 }
 
 // adds the per-workgroup partials in index order (fixed order => deterministic)
-__global__ void __launch_bounds__(64) gh_final_kernel(const double* __restrict__ partial, const int* __restrict__ partialCount, int nBlocks,
-                                                     int nValues, double* __restrict__ out, int* __restrict__ outCount) {
-  const int t = threadIdx.x;
-  if (t < nValues) {
-    double s = 0.0;
-    for (int b = 0; b < nBlocks; ++b) s += partial[(size_t)b * kGHValues + t];
-    out[t] = s;
-  }
-  if (t == 63) {
-    int c = 0;
-    for (int b = 0; b < nBlocks; ++b) c += partialCount[b];
-    *outCount = c;
-  }
-}
-
 // ---- scratch (one per process and device; calls synchronise anyway) ------------------------------
 struct TrackerScratch {
   int device = -1;
-  double* partial = nullptr; int* partialCount = nullptr; double* sums = nullptr; int* count = nullptr;
+  double* partial = nullptr; int* partialCount = nullptr;
+  GHBlockRecord* rec = nullptr; GHBlockRecord* recDev = nullptr; size_t recBlocks = 0; unsigned int seq = 0;   // pinned host records + device address
   size_t blocks = 0;
   std::vector<float*> pyramid; std::vector<size_t> pyramidBytes;
 };
@@ -168,12 +168,17 @@ static int ensure_scratch(size_t blocks) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (g_scratch.device != dev || g_scratch.blocks < blocks) {
-    (void)hipFree(g_scratch.partial); (void)hipFree(g_scratch.partialCount); (void)hipFree(g_scratch.sums); (void)hipFree(g_scratch.count);
-    g_scratch.partial = nullptr; g_scratch.partialCount = nullptr; g_scratch.sums = nullptr; g_scratch.count = nullptr;
+    (void)hipFree(g_scratch.partial); (void)hipFree(g_scratch.partialCount);
+    g_scratch.partial = nullptr; g_scratch.partialCount = nullptr;
     ITM_HIP(hipMalloc((void**)&g_scratch.partial, blocks * kGHValues * sizeof(double)));
     ITM_HIP(hipMalloc((void**)&g_scratch.partialCount, blocks * sizeof(int)));
-    ITM_HIP(hipMalloc((void**)&g_scratch.sums, kGHValues * sizeof(double)));
-    ITM_HIP(hipMalloc((void**)&g_scratch.count, sizeof(int)));
+    if (g_scratch.rec && (g_scratch.device != dev || g_scratch.recBlocks < blocks)) { (void)hipHostFree(g_scratch.rec); g_scratch.rec = nullptr; }
+    if (!g_scratch.rec) {
+      ITM_HIP(hipHostMalloc((void**)&g_scratch.rec, blocks * sizeof(GHBlockRecord), hipHostMallocMapped));
+      memset(g_scratch.rec, 0, blocks * sizeof(GHBlockRecord));
+      ITM_HIP(hipHostGetDevicePointer((void**)&g_scratch.recDev, g_scratch.rec, 0));
+      g_scratch.recBlocks = blocks;
+    }
     if (g_scratch.device != dev) { g_scratch.pyramid.clear(); g_scratch.pyramidBytes.clear(); }
     g_scratch.device = dev; g_scratch.blocks = blocks;
   }
@@ -198,15 +203,31 @@ static int compute_g_and_h(const float* depth, int w, int h, const float* viewIn
   const float4* pm = (const float4*)pointsMap; const float4* nm = (const float4*)normalsMap;
   const int np = (iterationType == ITM_TRACKER_ITERATION_BOTH) ? 6 : 3;
   const int nh = np * (np + 1) / 2;
-  if (iterationType == 1) gh_partial_kernel<1><<<grid, 256, 0, st>>>(depth, pm, nm, g_scratch.partial, g_scratch.partialCount, p);
-  else if (iterationType == 2) gh_partial_kernel<2><<<grid, 256, 0, st>>>(depth, pm, nm, g_scratch.partial, g_scratch.partialCount, p);
-  else gh_partial_kernel<3><<<grid, 256, 0, st>>>(depth, pm, nm, g_scratch.partial, g_scratch.partialCount, p);
-  gh_final_kernel<<<1, 64, 0, st>>>(g_scratch.partial, g_scratch.partialCount, (int)blocks, kGHValues, g_scratch.sums, g_scratch.count);
+  const unsigned int seq = ++g_scratch.seq;
+  if (iterationType == 1) gh_partial_kernel<1><<<grid, 256, 0, st>>>(depth, pm, nm, g_scratch.partial, g_scratch.partialCount, p, g_scratch.recDev, seq);
+  else if (iterationType == 2) gh_partial_kernel<2><<<grid, 256, 0, st>>>(depth, pm, nm, g_scratch.partial, g_scratch.partialCount, p, g_scratch.recDev, seq);
+  else gh_partial_kernel<3><<<grid, 256, 0, st>>>(depth, pm, nm, g_scratch.partial, g_scratch.partialCount, p, g_scratch.recDev, seq);
   ITM_LAUNCH_CHECK();
-  double sums[kGHValues]; int n = 0;
-  ITM_HIP(hipMemcpyAsync(sums, g_scratch.sums, sizeof sums, hipMemcpyDeviceToHost, st));
-  ITM_HIP(hipMemcpyAsync(&n, g_scratch.count, sizeof n, hipMemcpyDeviceToHost, st));
-  ITM_HIP(hipStreamSynchronize(st));
+  // wait for every workgroup's record (bounded poll, then a stream synchronisation, which also surfaces device errors)
+  // and add them in block order: fixed order => deterministic, in double precision
+  double sums[kGHValues];
+  for (int i = 0; i < kGHValues; ++i) sums[i] = 0.0;
+  int n = 0;
+  bool synced = false;
+  for (size_t b = 0; b < blocks; ++b) {
+    const GHBlockRecord* r = g_scratch.rec + b;
+    int spin = 0;
+    while (r->seq != seq) {
+      __builtin_ia32_pause();
+      if (++spin > 4000000) {
+        if (synced) return set_error(ITM_ERR_DEVICE, "tracker reduction did not complete");
+        ITM_HIP(hipStreamSynchronize(st)); synced = true; spin = 0;
+      }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    for (int i = 0; i < kGHValues; ++i) sums[i] += r->sums[i];
+    n += r->count;
+  }
   for (int r = 0, k = 0; r < np; ++r)
     for (int c = 0; c <= r; ++c, ++k) out->hessian[r + c * 6] = (float)sums[7 + k];
   for (int r = 0; r < np; ++r)
