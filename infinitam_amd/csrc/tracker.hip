@@ -11,8 +11,8 @@
 //
 // Device part: one lane per depth pixel computes its residual row (A, b) with the reference's float
 // operations; the 1 + 6 + 21 sums and the valid count are reduced with wave shuffles, one partial per
-// workgroup, and a second single-workgroup pass adds the partials in a fixed order in double precision
-// (deterministic; the reference adds floats in raster order, so sums agree to float rounding, the count
+// workgroup, written to a stamped record in pinned host memory; the host adds the records in block order in double
+// precision (deterministic; the reference adds floats in raster order, so sums agree to float rounding, the count
 // exactly).  Host part: the Levenberg-Marquardt loop, 3x3 / 6x6 Cholesky and the SE(3) re-projection of
 // the pose, restated from the reference (plain C++ on the host, as in the reference's CUDA back-end).
 #include <cmath>
