@@ -59,11 +59,19 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    # self-test hook (never set by the driver): ITM_BENCH_SHARED_GPU=1 lets several ranks share GPU 0 with the gloo
+    # backend, to exercise the multi-rank control flow on a one-GPU box; RCCL needs one GPU per rank
+    shared = os.environ.get("ITM_BENCH_SHARED_GPU") == "1"
+    if shared:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1 or args.force_exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if shared:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import infinitam_amd as itm
     from infinitam_amd import capi, synth
