@@ -1,0 +1,55 @@
+"""The widening rows against reference-generated vectors (tests/golden/g_widening.npz, made by make_golden_widening.py
+from the reference's ITMViewBuilder_CPU / ITMDepthTracker_CPU / ITMLowLevelEngine_CPU): these pin the oracle and the HIP
+path on machines without the reference tree (the GPU box).  Oracle: bit-exact (same host libm as the generator);
+HIP: exact where only IEEE operations are involved, stated tolerances where exp / acos or the summation order enter."""
+import os
+
+import numpy as np
+import pytest
+
+import itm_testlib as T
+import test_tracker as tt
+import test_viewbuilder as tv
+
+G = np.load(os.path.join(T.GOLDEN_DIR, "g_widening.npz"))
+
+
+def view_builder_outputs(be):
+    img = tv.noisy_depth()
+    n, s = tv.run_normals(be, img)
+    d, un, us = tv.run_update(be, tv.raw_depth(), 1, 0.001, 0.0, True, True)
+    return {"vb_filter": tv.run_filter(be, img), "vb_normals": n, "vb_sigma": s, "vb_update_depth": d, "vb_update_normals": un, "vb_update_sigma": us}
+
+
+def test_oracle_view_builder_equals_reference_vectors(oracle):
+    for k, a in view_builder_outputs(oracle).items():
+        assert np.array_equal(a, G[k]), k
+
+
+def test_oracle_tracker_equals_reference_vectors(oracle):
+    assert np.array_equal(tt.subsample(oracle, tt.holes_image()), G["trk_subsample"])
+    ses, v, nxt = tt.build_maps_vga(oracle)
+    assert np.array_equal(tt.track(oracle, ses, v, nxt), G["trk_pose"])
+
+
+@pytest.mark.gpu
+def test_hip_view_builder_against_reference_vectors(hip):
+    o = view_builder_outputs(hip)
+    for k in ("vb_filter", "vb_update_depth"):
+        a, b = o[k], G[k]
+        assert np.array_equal(a <= 0, b <= 0), k
+        m = b > 0
+        assert np.abs(a[m] - b[m]).max() <= 2e-6 * np.abs(b[m]).max(), k
+    assert np.array_equal(o["vb_normals"], G["vb_normals"])               # IEEE operations only
+    m = G["vb_sigma"] > 0
+    assert np.array_equal(o["vb_sigma"] < 0, G["vb_sigma"] < 0)
+    assert np.abs(o["vb_sigma"][m] - G["vb_sigma"][m]).max() <= 1e-5 * G["vb_sigma"][m].max()
+    same = (o["vb_update_normals"][..., 3] == G["vb_update_normals"][..., 3])
+    assert same.mean() > 0.999
+
+
+@pytest.mark.gpu
+def test_hip_tracker_against_reference_vectors(hip):
+    assert np.array_equal(tt.subsample(hip, tt.holes_image()), G["trk_subsample"])
+    ses, v, nxt = tt.build_maps_vga(hip)
+    assert np.abs(tt.track(hip, ses, v, nxt) - G["trk_pose"]).max() < 2e-5
