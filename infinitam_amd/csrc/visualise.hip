@@ -29,6 +29,10 @@
 
 namespace itm {
 
+#ifndef ITM_NT_STORES
+#define ITM_NT_STORES 1
+#endif
+
 int g_debug_force_global_range = 0;
 
 // ---------------------------------------------------------------------------------------------
@@ -218,6 +222,15 @@ int launch_raycast(const itm_scene* s, const float* invM, const float* intr, itm
 // ---------------------------------------------------------------------------------------------
 // ICP maps (normals from the ray-hit map)
 // ---------------------------------------------------------------------------------------------
+// Streaming outputs (11 MB per frame that nothing on the GPU re-reads soon) are stored with the non-temporal hint so that
+// they do not wash the hash lines, occupancy words and voxel lines of the next kernels out of the 4 MB L2s.
+#if ITM_NT_STORES
+__device__ inline void nt_store(float4* p, float4 v) { __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y); __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w); }
+__device__ inline void nt_store(uchar4* p, uchar4 v) { __builtin_nontemporal_store(*(unsigned int*)&v, (unsigned int*)p); }
+#else
+template <class T> __device__ inline void nt_store(T* p, T v) { *p = v; }
+#endif
+
 __global__ void __launch_bounds__(256) icp_maps_kernel(const float4* __restrict__ rays, float4* __restrict__ points,
                                                        float4* __restrict__ normals, uchar4* __restrict__ image, RayParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -230,12 +243,12 @@ __global__ void __launch_bounds__(256) icp_maps_kernel(const float4* __restrict_
   float nx = 0, ny = 0, nz = 0, angle = 0;
   if (found) found = normal_from_hits(rays, x, y, p.W, p.H, p.voxelSize, p.lx, p.ly, p.lz, nx, ny, nz, angle);
   if (found) {
-    image[loc] = grey_pixel(angle);
-    points[loc] = make_float4(r.x * p.voxelSize, r.y * p.voxelSize, r.z * p.voxelSize, 1.0f);
-    normals[loc] = make_float4(nx, ny, nz, 0.0f);
+    nt_store(&image[loc], grey_pixel(angle));
+    nt_store(&points[loc], make_float4(r.x * p.voxelSize, r.y * p.voxelSize, r.z * p.voxelSize, 1.0f));
+    nt_store(&normals[loc], make_float4(nx, ny, nz, 0.0f));
   } else {
     const float4 inv = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
-    points[loc] = inv; normals[loc] = inv; image[loc] = make_uchar4(0, 0, 0, 0);
+    nt_store(&points[loc], inv); nt_store(&normals[loc], inv); nt_store(&image[loc], make_uchar4(0, 0, 0, 0));
   }
 }
 
