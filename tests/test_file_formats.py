@@ -60,17 +60,17 @@ def test_float_depth_writer_quirk(hip_host, tmp_path):
 
 
 def test_calib_values(hip_host):
-    c = hip_host.read_rgbd_calib(os.path.join(T.GOLDEN_DIR, "calib_teddy_like.txt"))
-    assert list(c.intr_d) == [np.float32(573.71), np.float32(574.394), np.float32(346.471), np.float32(249.031)]
-    assert c.disparityType == 0 and list(c.disparityParams) == [np.float32(1135.09), np.float32(0.0819141)]
+    c = hip_host.read_rgbd_calib(os.path.join(T.GOLDEN_DIR, "calib_synthetic.txt"))
+    assert list(c.intr_d) == [np.float32(580.5), np.float32(581.25), np.float32(318.75), np.float32(242.5)]
+    assert c.disparityType == 0 and list(c.disparityParams) == [np.float32(1090.25), np.float32(0.0778125)]
     m = np.array(c.rgb_to_depth[:], np.float32).reshape(4, 4).T     # column-major -> rows
-    assert m[0, 3] == np.float32(0.0243073) and m[3].tolist() == [0, 0, 0, 1]
+    assert m[0, 3] == np.float32(0.0251) and m[3].tolist() == [0, 0, 0, 1]
     inv = np.array(c.rgb_to_depth_inv[:], np.float32).reshape(4, 4).T
     assert np.abs(m.astype(np.float64) @ inv.astype(np.float64) - np.eye(4)).max() < 1e-4   # calibration matrix is only ~orthonormal
 
 
 def test_calib_variants(hip_host, tmp_path):
-    base = open(os.path.join(T.GOLDEN_DIR, "calib_teddy_like.txt")).read().rsplit("\n\n", 1)[0]
+    base = open(os.path.join(T.GOLDEN_DIR, "calib_synthetic.txt")).read().rsplit("\n\n", 1)[0]
     for tail, want in (("affine 0.0002 0.01", (1, 0.0002, 0.01)), ("kinect 1090 0.08", (0, 1090.0, 0.08)), ("0 0", (1, 1.0 / 1000.0, 0.0))):
         p = str(tmp_path / "c.txt")
         open(p, "w").write(base + "\n\n" + tail + "\n")
@@ -94,8 +94,8 @@ def test_against_reference_both_directions(hip_host, reference, tmp_path):
     assert open(a, "rb").read() == open(b, "rb").read()
     hip_host.write_image(a, depth); reference.write_image(b, depth)
     assert open(a, "rb").read() == open(b, "rb").read()
-    ca = hip_host.read_rgbd_calib(os.path.join(T.GOLDEN_DIR, "calib_teddy_like.txt"))
-    cb = reference.read_rgbd_calib(os.path.join(T.GOLDEN_DIR, "calib_teddy_like.txt"))
+    ca = hip_host.read_rgbd_calib(os.path.join(T.GOLDEN_DIR, "calib_synthetic.txt"))
+    cb = reference.read_rgbd_calib(os.path.join(T.GOLDEN_DIR, "calib_synthetic.txt"))
     for f_ in ("intr_rgb", "intr_d", "rgb_to_depth", "rgb_to_depth_inv", "disparityParams"):
         assert list(getattr(ca, f_)) == list(getattr(cb, f_)), f_
     assert ca.disparityType == cb.disparityType
