@@ -1,17 +1,22 @@
 #!/usr/bin/env python3
 """bench.py -- fused depth frames/s of the TSDF hot path on MI355X (BASELINE.json metric).
 
-One "step" = one 640x480 depth frame through the per-frame call sequence of
-ITMMainEngine::ProcessFrame after the view is built (reference Engine/ITMMainEngine.cpp:123-126):
-AllocateSceneFromDepth + IntegrateIntoScene + CreateExpectedDepths + CreateICPMaps, issued through
-the C-ABI (itm_process_frame) with the float depth frames already resident in HBM.
+One "step" = one depth frame through the per-frame call sequence of ITMMainEngine::ProcessFrame after the
+view is built (reference Engine/ITMMainEngine.cpp:123-126): AllocateSceneFromDepth + IntegrateIntoScene +
+CreateExpectedDepths + CreateICPMaps, issued through the C-ABI (itm_process_frame) with the float depth
+frames already resident in HBM.
 
-Workload (config.workload): BASELINE.json configs[1] -- synthetic 640x480 depth (sphere + wall,
-SURVEY.md section 8d benchmark trajectory), hash TSDF, ITMVoxel_s, 4 mm voxels, mu 0.02,
-512^3-equivalent pool (0x40000 blocks).  Multi-GPU (config 4): one independent stream per rank
-(stream g offset 0.05*g m), weak scaling, with an RCCL all-gather of the per-stream
-{pose, visible-block list} record every frame on a side stream.
+Workloads (--config, names in config.workload):
+  2 (default, the headline): BASELINE configs[1] -- synthetic 640x480 depth (sphere + wall, SURVEY 8d bench
+     trajectory), hash TSDF, ITMVoxel_s, 4 mm voxels, mu 0.02, 0x40000-block pool.  roofline = ray cast.
+  3: BASELINE configs[2] -- dense ITMPlainVoxelArray 512^3, ITMVoxel_s, 4 mm, stopIntegratingAtMaxW.
+     roofline = dense integrate (the pure HBM-bound kernel).
+  5: BASELINE configs[4] -- 1280x960, ITMVoxel_f_rgb, 2 mm, hash pool 0x40000.  roofline = hash integrate.
+Multi-GPU (BASELINE configs[3]): one independent stream per rank (stream g offset 0.05*g m in y), weak
+scaling, with an RCCL all-gather of the per-stream {pose, visible-block list} record on a side stream.
 
+Launching:  `python bench.py --gpus N` spawns N rank processes itself (before anything touches the GPU);
+under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (WORLD_SIZE set) it is one rank.
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -20,21 +25,33 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-W, H = 640, 480
-VOXEL_SIZE, MU = 0.004, 0.02
-LOCAL_BLOCKS = 0x40000
-PERIOD = 100                 # the benchmark trajectory repeats every 100 frames
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MAX_IDS = 16384              # ids per exchanged visible-block record
-EXCHANGE_BATCH = 8           # frames per all-gather (8 x 64 KB records per rank and collective)
+PERIOD = 100                 # the benchmark trajectory repeats every 100 frames
+TK = {"request": 0, "alloc_sweep": 1, "visible_list": 2, "integrate": 3, "range": 4, "raycast": 5, "icp_maps": 6}
+
+WORKLOADS = {
+    2: dict(w=640, h=480, voxel="s", index="hash", voxelSize=0.004, mu=0.02, blocks=0x40000, stopAtMax=False, colour=False,
+            kernel="raycast", distinct=PERIOD,
+            name="BASELINE configs[1]: synthetic 640x480 depth (sphere+wall, bench trajectory), hash TSDF ITMVoxel_s, "
+                 "4 mm voxels, mu 0.02, 0x40000-block pool; allocate+integrate+expected-depths+ICP raycast per frame"),
+    3: dict(w=640, h=480, voxel="s", index="dense", voxelSize=0.004, mu=0.02, blocks=0, stopAtMax=True, colour=False,
+            kernel="integrate", distinct=PERIOD,
+            name="BASELINE configs[2]: synthetic 640x480 depth (bench trajectory), dense ITMPlainVoxelArray 512^3 ITMVoxel_s, "
+                 "4 mm voxels, stopIntegratingAtMaxW; integrate+expected-depths+ICP raycast per frame"),
+    5: dict(w=1280, h=960, voxel="f_rgb", index="hash", voxelSize=0.002, mu=0.02, blocks=0x40000, stopAtMax=False, colour=True,
+            kernel="integrate", distinct=25,
+            name="BASELINE configs[4]: synthetic 1280x960 depth+rgb (bench trajectory), hash TSDF ITMVoxel_f_rgb, 2 mm voxels, "
+                 "mu 0.02, 0x40000-block pool; allocate+integrate(colour)+expected-depths+ICP raycast per frame"),
+}
 
 
 def parse():
@@ -42,203 +59,350 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=40)
+    ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU baseline sample (0 = per-config default)")
     ap.add_argument("--no-exchange", action="store_true", help="skip the visible-list all-gather at N>1")
     ap.add_argument("--force-exchange", action="store_true", help="run the all-gather path even with one rank (self-test)")
+    ap.add_argument("--exchange-batch", type=int, default=1, help="frames per all-gather (1 = every frame, as BASELINE configs[3] asks)")
+    ap.add_argument("--streams-per-gpu", type=int, default=1,
+                    help="independent scenes co-scheduled on one GPU, each on its own HIP stream (separate figure; headline is 1)")
+    ap.add_argument("--lib", default=None, help="alternative shared library exporting the same C-ABI (tests: a host-memory backend)")
+    ap.add_argument("--lib-prefix", default="itm_")
     return ap.parse_args()
 
 
-def main():
-    args = parse()
+# -------------------------------------------------------------------------------------------------------------
+# parent: spawn one process per GPU.  Nothing here imports torch or touches the GPU.
+# -------------------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args) -> int:
+    n = args.gpus
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "ITM_BENCH_SPAWNED": "1"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        out = subprocess.PIPE if r == 0 else subprocess.DEVNULL
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
+    text = procs[0].communicate()[0].decode(errors="replace")
+    codes = [procs[0].returncode]
+    deadline = time.time() + 120
+    for p in procs[1:]:
+        try:
+            codes.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            p.kill()                       # exact child, never a pattern
+            codes.append(-9)
+    lines = [ln for ln in text.splitlines() if ln.strip()]
+    for ln in lines[:-1]:
+        print(ln, file=sys.stderr)
+    if any(codes) or not lines:
+        print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
+        if lines:
+            print(lines[-1], file=sys.stderr)
+        return 1
+    print(lines[-1], flush=True)
+    return 0
+
+
+# -------------------------------------------------------------------------------------------------------------
+# one rank
+# -------------------------------------------------------------------------------------------------------------
+class Stream:
+    """One depth stream: scene + render state + its frames resident in the backend's memory."""
+
+    def __init__(self, be, capi, synth, torch, wl, stream_id, device, hip_stream):
+        import numpy as np
+        w, h = wl["w"], wl["h"]
+        vox = {"s": capi.VOXEL_S, "f_rgb": capi.VOXEL_F_RGB}[wl["voxel"]]
+        idx = capi.INDEX_HASH if wl["index"] == "hash" else capi.INDEX_DENSE
+        params = capi.default_params(voxelSize=wl["voxelSize"], mu=wl["mu"], stopIntegratingAtMaxW=wl["stopAtMax"])
+        self.scene = be.create_scene(vox, idx, params, localBlockNum=wl["blocks"])
+        self.scene.reco.ResetScene()
+        self.rs = self.scene.vis.CreateRenderState((w, h))
+        intr = synth.intrinsics_for(w, h)
+        nd = wl["distinct"]
+        # the trajectory has period 100; with fewer resident frames (config 5) every 100/nd-th pose is kept
+        ks = [k * (PERIOD // nd) for k in range(nd)]
+        frames = np.stack([synth.depth_frame(w, h, synth.bench_position(k, stream_id), intr) for k in ks])
+        self.depth = torch.from_numpy(frames).to(device)
+        self.points = torch.empty((h, w, 4), dtype=torch.float32, device=device)
+        self.normals = torch.empty((h, w, 4), dtype=torch.float32, device=device)
+        self.rgb = torch.from_numpy(synth.rgb_frame(w, h)).to(device) if wl["colour"] else None
+        self.poses = [synth.pose_matrix(synth.bench_position(k, stream_id)) for k in ks]
+        self.views = [capi.View(self.depth[i].data_ptr(), w, h, M_d=self.poses[i], intr_d=intr,
+                                rgb=(self.rgb.data_ptr() if self.rgb is not None else None), w_rgb=w, h_rgb=h, intr_rgb=intr).struct()
+                      for i in range(nd)]
+        self.poses_c = [(C.c_float * 16)(*[float(x) for x in m]) for m in self.poses]   # built once, not per frame
+        self.nd = nd
+        self.hip_stream = hip_stream
+        self.sp = C.c_void_p(hip_stream.cuda_stream if hip_stream is not None else None)
+        self.sh, self.rh = C.c_void_p(self.scene.h), C.c_void_p(self.rs.h)
+        self.pp, self.np_ = C.c_void_p(self.points.data_ptr()), C.c_void_p(self.normals.data_ptr())
+
+
+def worker(args) -> int:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with matching values", file=sys.stderr)
+        return 2
+    import numpy as np  # noqa: F401
     import torch
     import torch.distributed as dist
 
-    if not torch.cuda.is_available():
+    import infinitam_amd as itm
+    from infinitam_amd import capi, synth
+    be = capi.Backend(args.lib, args.lib_prefix) if args.lib else itm.load()
+    product = args.lib is None
+    on_gpu = be.on_device
+    if on_gpu and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     # self-test hook (never set by the driver): ITM_BENCH_SHARED_GPU=1 lets several ranks share GPU 0 with the gloo
     # backend, to exercise the multi-rank control flow on a one-GPU box; RCCL needs one GPU per rank
     shared = os.environ.get("ITM_BENCH_SHARED_GPU") == "1"
     if shared:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
+    device = "cpu"
+    if on_gpu:
+        torch.cuda.set_device(local_rank)
+        device = "cuda"
+    backend_name = "none"
     if world > 1 or args.force_exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        if shared:
+        if shared or not on_gpu:
+            backend_name = "gloo"
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
+            backend_name = "nccl (RCCL)"
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if on_gpu:
+        be.check(be.fn["set_device"](local_rank), "set_device")
 
-    import infinitam_amd as itm
-    from infinitam_amd import capi, synth
-    be = itm.load()
-    be.check(be.fn["set_device"](local_rank), "set_device")
-
-    # ---- scene + inputs resident in HBM -------------------------------------------------------
-    params = capi.default_params(voxelSize=VOXEL_SIZE, mu=MU)
-    scene = be.create_scene(capi.VOXEL_S, capi.INDEX_HASH, params, localBlockNum=LOCAL_BLOCKS)
-    scene.reco.ResetScene()
-    rs = scene.vis.CreateRenderState((W, H))
-    intr = synth.intrinsics_for(W, H)
-    frames = np.stack([synth.depth_frame(W, H, synth.bench_position(k, rank), intr) for k in range(PERIOD)])
-    depth_dev = torch.from_numpy(frames).cuda()
-    points = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
-    normals = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
-    poses = [synth.pose_matrix(synth.bench_position(k, rank)) for k in range(PERIOD)]
-    views = []
-    for k in range(PERIOD):
-        v = capi.View(depth_dev[k].data_ptr(), W, H, M_d=poses[k], intr_d=intr).struct()
-        views.append(v)
-    stream = torch.cuda.current_stream()
-    sp = C.c_void_p(stream.cuda_stream)
+    wl = WORKLOADS[args.config]
+    k_streams = max(1, args.streams_per_gpu)
+    streams = []
+    for j in range(k_streams):
+        hs = None
+        if on_gpu:
+            hs = torch.cuda.current_stream() if k_streams == 1 else torch.cuda.Stream()
+        streams.append(Stream(be, capi, synth, torch, wl, rank * k_streams + j, device, hs))
     fn = be.fn["process_frame"]
-    sh, rh = C.c_void_p(scene.h), C.c_void_p(rs.h)
-    pp, np_ = C.c_void_p(points.data_ptr()), C.c_void_p(normals.data_ptr())
 
     exchange = (world > 1 and not args.no_exchange) or args.force_exchange
+    exs = []
     if exchange:
         from infinitam_amd.streams import VisibleListExchange
-        ex = VisibleListExchange(be, world, rank, MAX_IDS, device="cuda", batch=EXCHANGE_BATCH)
+        exs = [VisibleListExchange(be, world, rank, MAX_IDS, device=device, batch=max(1, args.exchange_batch)) for _ in streams]
 
     def step(k):
-        v = views[k % PERIOD]
-        rc = fn(sh, C.byref(v), rh, pp, np_, sp)
-        if rc:
-            be.check(rc, "process_frame")
-        if exchange:
-            # record copy on the frame stream, RCCL all-gather on a side stream (off the critical path)
-            ex.step(rs.h, poses[k % PERIOD], stream)
+        for j, s in enumerate(streams):
+            i = k % s.nd
+            rc = fn(s.sh, C.byref(s.views[i]), s.rh, s.pp, s.np_, s.sp)
+            if rc:
+                be.check(rc, "process_frame")
+            if exchange:
+                # record copy on the frame stream, all-gather on a side stream (off the critical path)
+                exs[j].step(s.rs.h, s.poses_c[i], s.hip_stream)
 
-    TK_RAYCAST = 5
+    def sync():
+        if on_gpu:
+            torch.cuda.synchronize()
+
+    def barrier():
+        sync()
+        if world > 1:
+            dist.barrier()
+        sync()
+
+    sync()
     for k in range(args.warmup):
         step(k)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    if rank == 0:
-        scene.profile_read(reset=True)
-        scene.profile_enable(1 << TK_RAYCAST)   # two hipEventRecord per frame around the dominant kernel
+    barrier()
+    timed_kernel = TK[wl["kernel"]]
+    if rank == 0 and product:
+        streams[0].scene.profile_read(reset=True)
+        streams[0].scene.profile_enable(1 << timed_kernel)   # two hipEventRecord per frame around the roofline kernel
     t0 = time.perf_counter()
     for k in range(args.warmup, args.warmup + args.steps):
         step(k)
-    torch.cuda.synchronize()
+    barrier()
+    elapsed_local = time.perf_counter() - t0
+    elapsed = elapsed_local
+    fps_minmax = None
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed_local], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        tn = torch.tensor([elapsed_local], dtype=torch.float64, device=device)
+        dist.all_reduce(tn, op=dist.ReduceOp.MIN)
+        per = k_streams * args.steps
+        fps_minmax = [round(per / elapsed, 1), round(per / float(tn.item()), 1)]
 
-    counters = scene.counters(rs)
+    counters = streams[0].scene.counters(streams[0].rs)
     roofline = None
-    if rank == 0:
-        roofline = read_roofline(be, scene, rs, args.steps, counters)
-        scene.profile_enable(0)
+    if rank == 0 and product:
+        roofline = read_roofline(args.config, wl, streams[0].scene, counters)
+        streams[0].scene.profile_enable(0)
 
     cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_baseline = run_cpu_baseline(args.cpu_frames)
+    if rank == 0 and world == 1 and product and k_streams == 1 and not args.no_cpu_baseline:
+        cpu_baseline = run_cpu_baseline(args.config, wl, args.cpu_frames)
 
+    out = None
     if rank == 0:
-        fps = world * args.steps / elapsed
+        total_frames = world * k_streams * args.steps
+        fps = total_frames / elapsed
         out = {
-            "metric": "fused depth frames/sec (640x480, hash TSDF)",
+            "metric": "fused depth frames/sec (640x480, hash TSDF)" if args.config == 2 else f"fused depth frames/sec (config {args.config})",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: synthetic 640x480 depth (sphere+wall, bench trajectory), "
-                                   "hash TSDF ITMVoxel_s, 4 mm voxels, mu 0.02, 0x40000-block pool; "
-                                   "allocate+integrate+expected-depths+ICP raycast per frame",
-                       "streams": world, "exchange": f"rccl all_gather of visible-block records, {EXCHANGE_BATCH} frames per collective" if exchange else "none",
-                       "visible_blocks_last_frame": counters["noVisibleEntries"]},
+            "data": "synthetic" if product else "synthetic; ALTERNATIVE BACKEND (--lib) -- control-flow check, not a measurement of the product",
+            "config": {"workload": wl["name"], "streams": world * k_streams, "streams_per_gpu": k_streams,
+                       "world_size_seen": (dist.get_world_size() if dist.is_initialized() else 1), "collective_backend": backend_name,
+                       "exchange": (f"all_gather of {17 + MAX_IDS}-word visible-block records, {max(1, args.exchange_batch)} frame(s) per collective, side stream"
+                                    if exchange else "none"),
+                       "per_rank_fps_min_max": fps_minmax,
+                       "visible_blocks_last_frame": counters["noVisibleEntries"],
+                       "timing_note": "value includes two hipEventRecord per frame around the roofline kernel on rank 0",
+                       "backend": be.version()},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
-    if world > 1 or args.force_exchange:
+    if dist.is_initialized():
         dist.destroy_process_group()
     if rank == 0:
         # RCCL prints its version banner through C stdio, which a pipe only delivers at exit: flush it first so that the
         # JSON line is the last line on stdout
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
+        C.CDLL(None).fflush(None)
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
+    return 0
 
 
-def algorithmic_bytes():
-    """Algorithmic bytes per launch of the kernels on the path (DESIGN.md 'Algorithmic bytes',
-    SURVEY.md section 8d), priced from the oracle's work counters on frames 20..59 of this workload
-    (tests/golden/algbytes_config2.json, regenerated by tests/golden/make_algbytes.py)."""
-    with open(os.path.join(ROOT, "tests", "golden", "algbytes_config2.json")) as f:
-        c = json.load(f)
-    P, V, E = W * H, 4, 16
-    found_nearest = c["nearest_reads"] - c["nearest_misses"]
-    raycast = 8 * (P / 64) + V * (found_nearest + 8 * c["trilinear_reads"]) + E * c["hash_probes"] + 16 * P
-    integrate = c["visible_blocks"] * (512 * V * 2 + E + 4) + 4 * P
-    return {"raycast": raycast, "integrate": integrate}, c
+# -------------------------------------------------------------------------------------------------------------
+# roofline of the dominant kernel
+# -------------------------------------------------------------------------------------------------------------
+def algorithmic_bytes(config, wl, counters):
+    """Algorithmic bytes per launch (DESIGN.md 'Algorithmic bytes', SURVEY.md section 8d formulas).
+
+    config 2, ray cast: 8*P/64 + V*(R_found + 8*R_t) + E*H + 16*P with the counts of the reference algorithm on this
+      workload taken from the CPU oracle's work counters (tests/golden/algbytes_config2.json, frames 20..59):
+      R_found = nearest reads that find a voxel, R_t = trilinear reads, H = 16-byte hash entries the reference's
+      readVoxel dereferences (every cache-miss probe incl. chain links and the misses of empty-space steps).
+    config 5, hash integrate: Nv*(512*V*2 + E + 4) + 4*P (+ 4*P rgb), Nv live from the device counters.
+    config 3, dense integrate: 512^3*V read + 4*P (the writes of updated voxels, U*V <= 3 %, are NOT counted)."""
+    P = wl["w"] * wl["h"]
+    E = 16
+    if config == 2:
+        with open(os.path.join(ROOT, "tests", "golden", "algbytes_config2.json")) as f:
+            c = json.load(f)
+        V = 4
+        found_nearest = c["nearest_reads"] - c["nearest_misses"]
+        return 8 * (P / 64) + V * (found_nearest + 8 * c["trilinear_reads"]) + E * c["hash_probes"] + 16 * P
+    if config == 5:
+        V = 12
+        return counters["noVisibleEntries"] * (512 * V * 2 + E + 4) + 4 * P + 4 * P
+    return 512 ** 3 * 4 + 4 * P
 
 
-def read_roofline(be, scene, rs, steps, counters):
-    """Dominant kernel = the ray-cast kernel (rocprofv3: 45-55 % of the frame, profiles/).  Its average
-    duration is measured with hipEvents recorded around every launch inside the timed region, on the
-    stream the kernel runs on (itm_profile_enable / itm_profile_read)."""
+def read_roofline(config, wl, scene, counters):
+    """Average duration of the roofline kernel from hipEvents recorded around every launch inside the timed region, on the
+    stream the kernel runs on (itm_profile_enable / itm_profile_read).  `traffic` = HBM bytes per launch from the PMC
+    counters of a separate rocprofv3 pass (profiles/traffic_r02.json, stamped with the commit it was collected on)."""
     prof = scene.profile_read(reset=True)
-    alg, _ = algorithmic_bytes()
-    r = prof["raycast"]
+    r = prof[wl["kernel"]]
     if not r["calls"]:
         return None
     avg_s = r["total_ms"] * 1e-3 / r["calls"]
-    achieved = alg["raycast"] / avg_s / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "raycast_traffic.json")
+    alg = algorithmic_bytes(config, wl, counters)
+    achieved = alg / avg_s / 1e9
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "traffic_r02.json")
     if os.path.exists(tpath):
         with open(tpath) as f:
-            traffic = json.load(f).get("hbm_bytes_per_launch")
-    return {"bound": "hbm", "kernel": "raycast_kernel<VoxelS,hash>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "algorithmic_bytes_per_launch": round(alg["raycast"]), "avg_kernel_us": round(avg_s * 1e6, 2),
+            t = json.load(f).get(f"config{config}")
+        if t:
+            traffic, traffic_src = t.get("hbm_bytes_per_launch"), t.get("source")
+    kname = {2: "raycast_kernel<VoxelS,hash>", 3: "integrate_dense_s_x4_kernel", 5: "integrate_project_kernel<VoxelFRgb>"}[config]
+    return {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": round(alg), "avg_kernel_us": round(avg_s * 1e6, 2),
             "launches_timed": r["calls"]}
 
 
+# -------------------------------------------------------------------------------------------------------------
+# CPU baseline (checker code: the only place outside tests/ and smoke() that loads anything from oracle/)
+# -------------------------------------------------------------------------------------------------------------
 def _time_cpu(be, sc, nframes, T):
     ses = T.Session(be, sc)
     depth = [be.to_backend(sc.depth(k)) for k in range(nframes)]
+    rgb = ses.rgb
     t0 = time.perf_counter()
     for k in range(nframes):
-        v = T.View(depth[k], sc.w, sc.h, M_d=sc.pose(k), intr_d=sc.intr())
+        v = T.View(depth[k], sc.w, sc.h, M_d=sc.pose(k), intr_d=sc.intr(), rgb=rgb, w_rgb=sc.w, h_rgb=sc.h, intr_rgb=sc.intr())
         ses.scene.process_frame(v, ses.rs, ses.points, ses.normals)
     dt = time.perf_counter() - t0
     ses.close()
     return nframes / dt
 
 
-def run_cpu_baseline(nframes):
-    """The CPU oracle (a port of the reference CPU engines, bit-equal to them) timed on ONE host
-    core on the first `nframes` frames of the same workload; beside it, where the prebuilt oracle/_ref library
-    travelled along, the reference's OWN CPU engines on the same frames (their voxel pool is the fork's compile-time
-    0x10000 blocks instead of 0x40000, which this workload never exhausts).  Checker code, used only here."""
+def run_cpu_baseline(config, wl, nframes):
+    """The CPU oracle (a port of the reference CPU engines, bit-equal to them) on the first `nframes` frames of the same
+    workload: single thread, and with OpenMP on all host cores over the loops the reference parallelises
+    (ITMSceneReconstructionEngine_CPU.cpp:80,164,348; ITMVisualisationEngine_CPU.cpp:168,211,283).  Beside it, where
+    the prebuilt oracle/_ref libraries travelled along, the reference's OWN CPU engines on the same frames (their voxel
+    pool is the fork's compile-time 0x10000 blocks, which config 2 never exhausts; configs 3/5 need other template
+    instantiations and are timed on the port only)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import itm_testlib as T
+    from infinitam_amd import capi
+    cores = os.cpu_count() or 1
+    if not nframes:
+        nframes = {2: 40, 3: 3, 5: 8}[config]
+    vox = {"s": capi.VOXEL_S, "f_rgb": capi.VOXEL_F_RGB}[wl["voxel"]]
+    idx = capi.INDEX_HASH if wl["index"] == "hash" else capi.INDEX_DENSE
+    mk = lambda name, n, **kw: T.Scenario(name=name, w=wl["w"], h=wl["h"], voxelType=vox, indexType=idx, voxelSize=wl["voxelSize"], mu=wl["mu"],  # noqa: E731
+                                          stopIntegratingAtMaxW=wl["stopAtMax"], colour=wl["colour"], trajectory="bench", frames=n, **kw)
     ob = T.oracle_backend()
-    sc = T.Scenario(name="bench_cpu", voxelSize=VOXEL_SIZE, mu=MU, localBlockNum=LOCAL_BLOCKS, trajectory="bench", frames=nframes)
-    _time_cpu(ob, T.Scenario(name="warm", voxelSize=VOXEL_SIZE, mu=MU, localBlockNum=LOCAL_BLOCKS, trajectory="bench", frames=2), 2, T)
-    out = {"value": round(_time_cpu(ob, sc, nframes, T), 3), "unit": "frames/s", "cores": 1, "kind": "port",
+    _time_cpu(ob, mk("warm", 1, localBlockNum=wl["blocks"]), 1, T)
+    one = _time_cpu(ob, mk("bench_cpu", nframes, localBlockNum=wl["blocks"]), nframes, T)
+    out = {"value": round(one, 3), "unit": "frames/s", "cores": 1, "kind": "port",
            "sample": f"first {nframes} frames of the same workload, oracle/libitm_oracle.so single thread"}
-    if os.path.exists(T.REF_LIB):
+    omp = T.oracle_omp_backend()
+    if omp is not None:
+        n2 = nframes * 2
+        _time_cpu(omp, mk("warm", 1, localBlockNum=wl["blocks"]), 1, T)
+        out["all_cores"] = {"value": round(_time_cpu(omp, mk("bench_cpu_omp", n2, localBlockNum=wl["blocks"]), n2, T), 3), "unit": "frames/s",
+                            "cores": cores, "kind": "port", "sample": f"first {n2} frames, oracle/libitm_oracle_omp.so (OpenMP, {cores} threads; timing only)"}
+    if config == 2 and os.path.exists(T.REF_LIB):
         rb = T.Backend(T.REF_LIB, "itmr_")
-        sc_ref = T.Scenario(name="bench_ref", voxelSize=VOXEL_SIZE, mu=MU, trajectory="bench", frames=nframes)
-        out["reference_engines"] = {"value": round(_time_cpu(rb, sc_ref, nframes, T), 3), "unit": "frames/s", "cores": 1,
+        out["reference_engines"] = {"value": round(_time_cpu(rb, mk("bench_ref", nframes), nframes, T), 3), "unit": "frames/s", "cores": 1, "kind": "reference",
                                     "note": "ITMSceneReconstructionEngine_CPU / ITMVisualisationEngine_CPU compiled from the reference sources (oracle/_ref), same frames"}
+        if os.path.exists(T.REF_OMP_LIB):
+            ro = T.Backend(T.REF_OMP_LIB, "itmr_")
+            n2 = nframes * 2
+            out["reference_engines_all_cores"] = {"value": round(_time_cpu(ro, mk("bench_ref_omp", n2), n2, T), 3), "unit": "frames/s", "cores": cores,
+                                                  "kind": "reference", "note": "the same engines built with -fopenmp -DWITH_OPENMP (timing only: the reference's OpenMP allocation loop is racy)"}
     return out
 
 
+def main() -> int:
+    args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args)
+    return worker(args)
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -45,7 +45,9 @@ class VisibleListExchange:
         self.words = RECORD_HEADER + max_ids
         dev = device if device is not None else ("cuda" if backend.on_device else "cpu")
         self.buffers = [torch.full((batch * self.words,), -1, dtype=torch.int32, device=dev) for _ in range(2)]
-        self.record = self.buffers[0][: self.words]
+        self.slots = [[buf[i * self.words:(i + 1) * self.words] for i in range(batch)] for buf in self.buffers]
+        self.slot_ptr = [[C.c_void_p(v.data_ptr()) for v in views] for views in self.slots]
+        self.record, self.record_ptr = self.slots[0][0], self.slot_ptr[0][0]
         self.gathered = torch.full((world * batch * self.words,), -1, dtype=torch.int32, device=dev)
         self.frame = 0
         self._cuda = str(dev).startswith("cuda")
@@ -55,11 +57,16 @@ class VisibleListExchange:
             self.released = [torch.cuda.Event(), torch.cuda.Event()]
             self.in_flight = [False, False]
 
+    @staticmethod
+    def pose_array(M_d):
+        """ctypes form of a pose; callers on a per-frame path build it once per pose, not once per frame."""
+        return (C.c_float * 16)(*[float(x) for x in np.asarray(M_d, np.float32).reshape(16)])
+
     def publish(self, render_state_handle: int, M_d, stream_ptr=None):
         """Writes this stream's record into self.record on `stream_ptr` (device side, no host sync)."""
-        Ma = (C.c_float * 16)(*[float(x) for x in np.asarray(M_d, np.float32).reshape(16)])
+        Ma = M_d if isinstance(M_d, C.Array) else self.pose_array(M_d)
         rc = self.be.fn["export_visible_record"](C.c_void_p(render_state_handle), Ma, self.max_ids,
-                                                 C.c_void_p(self.record.data_ptr()), C.c_void_p(stream_ptr))
+                                                 self.record_ptr, C.c_void_p(stream_ptr))
         self.be.check(rc, "export_visible_record")
 
     def all_gather(self, group=None, source=None):
@@ -76,7 +83,7 @@ class VisibleListExchange:
         slot = self.frame % self.batch
         b = (self.frame // self.batch) & 1
         if not self._cuda:                                   # host-memory backends (CPU tests): same schedule, synchronous
-            self.record = self.buffers[b][slot * self.words:(slot + 1) * self.words]
+            self.record, self.record_ptr = self.slots[b][slot], self.slot_ptr[b][slot]
             self.publish(render_state_handle, M_d, None)
             if slot == self.batch - 1:
                 self.all_gather(group, self.buffers[b])
@@ -84,7 +91,7 @@ class VisibleListExchange:
             return
         if slot == 0 and self.in_flight[b]:
             frame_stream.wait_event(self.released[b])      # the collective two batches ago released this buffer
-        self.record = self.buffers[b][slot * self.words:(slot + 1) * self.words]
+        self.record, self.record_ptr = self.slots[b][slot], self.slot_ptr[b][slot]
         self.publish(render_state_handle, M_d, frame_stream.cuda_stream)
         if slot == self.batch - 1:
             self.copied[b].record(frame_stream)
@@ -97,6 +104,8 @@ class VisibleListExchange:
 
     def table(self) -> List[Tuple[np.ndarray, np.ndarray]]:
         """Host view of the gathered records: per stream (M_d[16] float32, visible ids int32[nv])."""
+        if self._cuda:
+            self.side.synchronize()      # the gathered table is written by collectives on the side stream
         g = self.gathered.cpu().numpy().reshape(self.world, self.batch, self.words)[:, -1, :]   # newest record of each stream
         out = []
         for r in range(self.world):

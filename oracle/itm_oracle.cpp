@@ -202,6 +202,19 @@ struct Stats {
   long long fuse_blocks, fuse_voxels_visited, fuse_voxels_updated;
 };
 Stats g_stats;
+// The OpenMP build (libitm_oracle_omp.so, TIMING ONLY: bench.py's all-cores CPU baseline) parallelises the loops the
+// reference parallelises under WITH_OPENMP (ITMSceneReconstructionEngine_CPU.cpp:80,164,348; ITMVisualisationEngine_CPU.cpp:
+// 168,211,283); its work counters are compiled out (shared counters would serialise the threads) and, like the
+// reference's OpenMP allocation loop, its request pass is racy -- parity tests always use the single-thread build.
+#ifdef _OPENMP
+#define ITMO_STAT(x) ((void)0)
+#define ITMO_PARALLEL_FOR _Pragma("omp parallel for schedule(dynamic, 64)")
+#define ITMO_PARALLEL_FOR_STATIC _Pragma("omp parallel for schedule(static)")
+#else
+#define ITMO_STAT(x) (x)
+#define ITMO_PARALLEL_FOR
+#define ITMO_PARALLEL_FOR_STATIC
+#endif
 int* g_rayTrace = nullptr;  // optional per-ray (steps, band steps, not-found steps) dump, width in g_rayTraceW
 int g_rayTraceW = 0;
 
@@ -230,7 +243,7 @@ struct Reader {
     int idx = hash_index(bx, by, bz, mask);
     for (;;) {
       const HashEntry& e = sc->hash[idx];
-      ++g_stats.hash_probes;
+      ITMO_STAT(++g_stats.hash_probes);
       if (e.px == bx && e.py == by && e.pz == bz && e.ptr >= 0) {
         found = true;
         cache.bx = bx; cache.by = by; cache.bz = bz; cache.base = e.ptr * 512;
@@ -247,7 +260,7 @@ struct Reader {
   // readFromSDF_float_uninterpolated :153-159
   float nearest(const V3f& p, bool& found, BlockCache& cache) const {
     V v = read((int)round_ref(p.x), (int)round_ref(p.y), (int)round_ref(p.z), found, cache);
-    ++g_stats.nearest_reads; if (!found) ++g_stats.nearest_misses; else ++g_stats.voxel_reads;
+    ITMO_STAT(++g_stats.nearest_reads); if (!found) ITMO_STAT(++g_stats.nearest_misses); else ITMO_STAT(++g_stats.voxel_reads);
     return Codec<V>::toF((float)v.sdf);
   }
   // readFromSDF_float_interpolated :161-185 (raw values blended, then converted; found := true)
@@ -269,7 +282,7 @@ struct Reader {
     v2 = (float)read(ix + 1, iy + 1, iz + 1, found, cache).sdf;
     r2 = (1.0f - cy) * r2 + cy * ((1.0f - cx) * v1 + cx * v2);
     found = true;
-    ++g_stats.trilinear_reads; g_stats.voxel_reads += 8;
+    ITMO_STAT(++g_stats.trilinear_reads); ITMO_STAT(g_stats.voxel_reads += 8);
     return Codec<V>::toF((1.0f - cz) * r1 + cz * r2);
   }
 };
@@ -331,7 +344,7 @@ inline float fuse_depth(V& vox, const V4f& pm, const FuseCtx& c) {
   newW = (newW < c.maxW) ? newW : c.maxW;
   vox.sdf = Codec<V>::toV(newF);
   vox.w = (uint8_t)newW;
-  ++g_stats.fuse_voxels_updated;
+  ITMO_STAT(++g_stats.fuse_voxels_updated);
   return eta;
 }
 
@@ -403,12 +416,13 @@ void integrate_t(itm_scene* s, const itm_view* view, itm_render_state* rs) {
   V* vox = (V*)s->vba.data();
   float vs = s->prm.voxelSize;
   if (s->cfg.indexType == ITM_INDEX_HASH) {
+    ITMO_PARALLEL_FOR
     for (int e = 0; e < rs->noVisibleEntries; ++e) {
       const HashEntry& he = s->hash[rs->visibleIds[e]];
       if (he.ptr < 0) continue;
       int gx = he.px * 8, gy = he.py * 8, gz = he.pz * 8;
       V* blk = vox + (size_t)he.ptr * 512;
-      ++g_stats.fuse_blocks; g_stats.fuse_voxels_visited += 512;
+      ITMO_STAT(++g_stats.fuse_blocks); ITMO_STAT(g_stats.fuse_voxels_visited += 512);
       for (int z = 0; z < 8; ++z) for (int y = 0; y < 8; ++y) for (int x = 0; x < 8; ++x) {
         int loc = x + y * 8 + z * 64;
         if (c.stopAtMax && blk[loc].w == c.maxW) continue;
@@ -419,6 +433,7 @@ void integrate_t(itm_scene* s, const itm_view* view, itm_render_state* rs) {
   } else {
     const int* sz = s->cfg.denseSize; const int* off = s->cfg.denseOffset;
     size_t n = s->numVoxels();
+    ITMO_PARALLEL_FOR_STATIC
     for (size_t loc = 0; loc < n; ++loc) {
       int z = (int)(loc / ((size_t)sz[0] * sz[1]));
       int tmp = (int)(loc - (size_t)z * sz[0] * sz[1]);
@@ -481,6 +496,7 @@ void allocate_hash(itm_scene* s, const itm_view* view, itm_render_state* rs, boo
   std::memset(allocT, 0, (size_t)s->noTotalEntries);
   for (int i = 0; i < rs->noVisibleEntries; ++i) visT[rs->visibleIds[i]] = 3;
 
+  ITMO_PARALLEL_FOR
   for (int loc = 0; loc < W * H; ++loc) {
     int y = loc / W, x = loc - y * W;
     float d = view->depth[x + y * W];
@@ -498,13 +514,13 @@ void allocate_hash(itm_scene* s, const itm_view* view, itm_render_state* rs, boo
     int noSteps = (int)std::ceil(2.0f * norm);
     float div = (float)(noSteps - 1);
     dir.x /= div; dir.y /= div; dir.z /= div;
-    ++g_stats.alloc_pixels; g_stats.alloc_steps += noSteps;
+    ITMO_STAT(++g_stats.alloc_pixels); ITMO_STAT(g_stats.alloc_steps += noSteps);
     for (int i = 0; i < noSteps; ++i) {
       int16_t bx = (int16_t)std::floor(pt.x), by = (int16_t)std::floor(pt.y), bz = (int16_t)std::floor(pt.z);
       int idx = hash_index(bx, by, bz, mask);
       bool isFound = false;
       HashEntry he = table[idx];
-      ++g_stats.alloc_probes;
+      ITMO_STAT(++g_stats.alloc_probes);
       if (he.px == bx && he.py == by && he.pz == bz && he.ptr >= -1) {
         visT[idx] = (he.ptr == -1) ? 2 : 1;
         isFound = true;
@@ -515,7 +531,7 @@ void allocate_hash(itm_scene* s, const itm_view* view, itm_render_state* rs, boo
           while (he.offset >= 1) {
             idx = BN + he.offset - 1;
             he = table[idx];
-            ++g_stats.alloc_probes;
+            ITMO_STAT(++g_stats.alloc_probes);
             if (he.px == bx && he.py == by && he.pz == bz && he.ptr >= -1) {
               visT[idx] = (he.ptr == -1) ? 2 : 1;
               isFound = true;
@@ -710,12 +726,12 @@ bool cast_ray(V4f& out, int x, int y, const Reader<V>& rd, const float* invM, fl
     pt.x += step * dir.x; pt.y += step * dir.y; pt.z += step * dir.z;
     total += step;
   }
-  ++g_stats.rays; g_stats.ray_steps += steps;
+  ITMO_STAT(++g_stats.rays); ITMO_STAT(g_stats.ray_steps += steps);
   if (g_rayTrace) { int* r = g_rayTrace + 3 * (x + y * g_rayTraceW); r[0] = (int)steps; r[1] = bandSteps; r[2] = missSteps; }
-  if (steps > g_stats.max_ray_steps) g_stats.max_ray_steps = steps;
+  ITMO_STAT(g_stats.max_ray_steps = (steps > g_stats.max_ray_steps) ? steps : g_stats.max_ray_steps);
   bool hit;
   if (sdf <= 0.0f) {
-    ++g_stats.ray_hits;
+    ITMO_STAT(++g_stats.ray_hits);
     step = sdf * stepScale;
     pt.x += step * dir.x; pt.y += step * dir.y; pt.z += step * dir.z;
     sdf = rd.trilinear(pt, found, cache);
@@ -733,6 +749,7 @@ void raycast_t(const itm_scene* s, itm_render_state* rs, const float* invM, cons
   const int W = rs->w, H = rs->h;
   float ifx = 1.0f / intr[0], ify = 1.0f / intr[1];
   float oov = 1.0f / s->prm.voxelSize;
+  ITMO_PARALLEL_FOR
   for (int loc = 0; loc < W * H; ++loc) {
     int y = loc / W, x = loc - y * W;
     int loc2 = (int)std::floor((float)x / 8) + (int)std::floor((float)y / 8) * W;
@@ -867,6 +884,7 @@ void render_image_t(const itm_scene* s, itm_render_state* rs, const float* M, co
   V3f L = {-invM[8], -invM[9], -invM[10]};
   Reader<V> rd(s);
   if (type == ITM_RENDER_COLOUR_FROM_VOLUME && !Codec<V>::color) type = ITM_RENDER_SHADED_GREYSCALE;
+  ITMO_PARALLEL_FOR
   for (int loc = 0; loc < rs->w * rs->h; ++loc) {
     V4f r = rs->raycast[loc];
     V3f p = {r.x, r.y, r.z};
@@ -901,6 +919,7 @@ void icp_maps_t(const itm_scene* s, const itm_view* view, itm_render_state* rs, 
   const int W = rs->w, H = rs->h;
   const float vs = s->prm.voxelSize;
   const V4f* rays = rs->raycast.data();
+  ITMO_PARALLEL_FOR
   for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {
     int loc = x + y * W;
     V4f r = rays[loc];

@@ -27,6 +27,8 @@ from infinitam_amd.capi import (BUF_ALLOCATION_LIST, BUF_EXCESS_LIST, BUF_HASH_E
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_LIB = os.path.join(ORACLE_DIR, "libitm_oracle.so")
 REF_LIB = os.path.join(ORACLE_DIR, "_ref", "libitm_ref.so")
+ORACLE_OMP_LIB = os.path.join(ORACLE_DIR, "libitm_oracle_omp.so")      # timing only (bench.py all-cores baseline)
+REF_OMP_LIB = os.path.join(ORACLE_DIR, "_ref", "libitm_ref_omp.so")    # timing only
 REFERENCE_TREE = "/root/reference/InfiniTAM"
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
@@ -39,6 +41,15 @@ def oracle_backend() -> Backend:
             subprocess.run(["make", "-C", ORACLE_DIR], check=True, capture_output=True)
         _cache["oracle"] = Backend(ORACLE_LIB, "itmo_")
     return _cache["oracle"]
+
+
+def oracle_omp_backend() -> Optional[Backend]:
+    """The OpenMP build of the oracle (timing only, never a parity checker); None if it cannot be built."""
+    if "oracle_omp" not in _cache:
+        if not os.path.exists(ORACLE_OMP_LIB):
+            subprocess.run(["make", "-C", ORACLE_DIR, "libitm_oracle_omp.so"], capture_output=True)
+        _cache["oracle_omp"] = Backend(ORACLE_OMP_LIB, "itmo_") if os.path.exists(ORACLE_OMP_LIB) else None
+    return _cache["oracle_omp"]
 
 
 def reference_backend() -> Optional[Backend]:
