@@ -166,6 +166,7 @@ int ITM_FN(set_device)(int device);
 #define ITM_DEBUG_EXPLICIT_MARK_PREVIOUS 2     /* always run the separate mark-previous-list launch   */
 #define ITM_DEBUG_INTEGRATE_WORKGROUPS 3      /* tuning: persistent workgroups of the hash integration (0 = default) */
 #define ITM_DEBUG_NO_FUSED_PROJECTION 4       /* process_frame: keep integration and projection as two launches */
+#define ITM_DEBUG_NO_DIRECTORY 5              /* ray casting / free-view reads walk the hash table instead of the block directory */
 int ITM_FN(debug_set)(int key, int value);
 /* out[i] = SDF_valueToFloat(in[i]) of the short voxel types, i.e. in[i] / 32767.0f, through the same
  * device routine the kernels use (a 3-instruction correctly rounded division; test hook). */

@@ -67,6 +67,12 @@ struct itm_scene {
   // proves that no block hashing to bucket b is allocated (excess entries hang off occupied heads),
   // which lets the ray caster skip empty space without touching the 16-byte entries.
   uint32_t* headBits = nullptr;   // uint32[bucketNum / 32]
+  // Block directory (raycast_device.h): dirPtr[cell] = voxel-block index of the block at that position or -1, cells in
+  // brick-major order (4x4x4 blocks = 256 contiguous bytes); superMask[s] = 64-bit occupancy of the 4x4x4 bricks of
+  // super-brick s (bit set <=> some block of that brick is allocated).  Maintained by the allocation sweep, rebuilt
+  // after uploads; exact mirrors of the table, so lookups through them return what the table walk returns.
+  int32_t* dirPtr = nullptr;      // int32[kDirCells]  (512 MB)
+  uint2* superMask = nullptr;     // uint2[kSuperWords] (256 KB)
   uint32_t frameParity = 0;
   itm::Profiler* prof = nullptr;
 };
@@ -145,7 +151,8 @@ inline int dispatch_voxel(int voxelType, F&& f) {
 extern int g_debug_explicit_mark;
 extern int g_debug_integrate_wgs;
 extern int g_debug_no_fused_projection;
-int rebuild_head_bits(itm_scene* s, hipStream_t st);
+int rebuild_head_bits(itm_scene* s, hipStream_t st);   // occupancy bitmap AND block directory, from the table
+extern int g_debug_no_directory;
 int launch_request_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, bool onlyVisible, bool fuseRangeInit, hipStream_t st);
 int launch_sweep_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, bool onlyVisible, hipStream_t st);
 int launch_allocate(itm_scene* s, const itm_view* v, itm_render_state* rs, bool onlyVisible, bool fuseRangeInit, hipStream_t st);

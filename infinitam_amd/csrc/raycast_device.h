@@ -42,6 +42,8 @@ struct VolumeView {
   const uint32_t* headBits;  // occupancy bitmap of the ordered buckets (hash index only)
   uint32_t mask;       // bucketNum - 1
   int bucketNum;
+  const int32_t* dirPtr;    // block directory (itm_types.h); nullptr = walk the table (hash index only)
+  const uint2* superMask;   // brick occupancy per super-brick
   int sx, sy, sz;      // dense size
   int ox, oy, oz;      // dense offset
 };
@@ -69,6 +71,17 @@ __device__ inline long long locate_voxel(const VolumeView& vol, int px, int py, 
     const int bx = floor_div8(px), by = floor_div8(py), bz = floor_div8(pz);
     const int lin = (px - bx * 8) + (py - by * 8) * 8 + (pz - bz * 8) * 64;
     if (bx == cache.bx && by == cache.by && bz == cache.bz) return (long long)cache.base + lin;
+    {
+      // covered by the block directory: one load instead of the table walk (same answer: the directory holds exactly
+      // the entries with ptr >= 0)
+      const uint32_t ux = (uint32_t)(bx + kDirHalf), uy = (uint32_t)(by + kDirHalf), uz = (uint32_t)(bz + kDirHalf);
+      if (vol.dirPtr && dir_covers(ux, uy, uz)) {
+        const int ptr = vol.dirPtr[dir_cell(ux, uy, uz)];
+        if (ptr < 0) return -1;
+        cache.bx = bx; cache.by = by; cache.bz = bz; cache.base = ptr * kBlockVoxels;
+        return (long long)cache.base + lin;
+      }
+    }
     int idx = hash_index(bx, by, bz, vol.mask);
 #if ITM_RAY_BITMAP_GUARD
     // the 16-byte entry is only fetched when the occupancy bit says the bucket is in use
@@ -126,47 +139,83 @@ struct Corners {
   float cx, cy, cz;  // fractional position
   int ix, iy, iz;    // floor(p)
 
+  // Every load below is issued unconditionally from an address that is always valid (a lane that has nothing to fetch
+  // reads voxel 0 / its own cell again and drops the value): a load inside an exec-masked branch forces the compiler to
+  // wait for it inside that branch, which turned the eight voxel reads of a trilinear sample into eight serial round
+  // trips (round 1's "4 500 cycles per trilinear step").  Unconditional, they are in flight together.
   __device__ inline void fetch(const VolumeView& vol, float x, float y, float z, BlockCache& cache) {
     const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
     cx = x - fx; cy = y - fy; cz = z - fz;
     ix = (int)fx; iy = (int)fy; iz = (int)fz;
     const float dflt = VX::kShort ? 32767.0f : 1.0f;
+    size_t addr[8];
     if (DENSE) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const long long a = locate_voxel<true>(vol, ix + (c & 1), iy + ((c >> 1) & 1), iz + (c >> 2), cache);
         present[c] = a >= 0;
-        v[c] = present[c] ? VX::load_raw_sdf(vol.vba, (size_t)a) : dflt;
+        addr[c] = present[c] ? (size_t)a : (size_t)0;
       }
     } else {
-      const int bx = floor_div8(ix), by = floor_div8(iy), bz = floor_div8(iz);
-      const int lx = ix - bx * 8, ly = iy - by * 8, lz = iz - bz * 8;
+      const int bx = ix >> 3, by = iy >> 3, bz = iz >> 3;            // floor division by 8
+      const int lx = ix & 7, ly = iy & 7, lz = iz & 7;
       // bit k set: the +1 neighbour along axis k lies in the next block
       const int cross = (lx == 7 ? 1 : 0) | (ly == 7 ? 2 : 0) | (lz == 7 ? 4 : 0);
       const bool cached = (bx == cache.bx && by == cache.by && bz == cache.bz);
-      HashEntry head[8];
-      bool need[8];
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        need[s] = ((s & ~cross) == 0) && !(s == 0 && cached);
-        if (need[s]) head[s] = unpack_entry(vol.hash[hash_index(bx + (s & 1), by + ((s >> 1) & 1), bz + (s >> 2), vol.mask)]);
-      }
       int base[8];
+      const uint32_t ux = (uint32_t)(bx + kDirHalf), uy = (uint32_t)(by + kDirHalf), uz = (uint32_t)(bz + kDirHalf);
+      const bool viaDir = vol.dirPtr && dir_covers(ux, uy, uz) && dir_covers(ux + 1u, uy + 1u, uz + 1u);
+      // block directory: the blocks of the 2x2x2 neighbourhood are eight 4-byte cells, mostly of one 256-byte brick.  A wave
+      // whose lanes all sit inside their cached block and away from its upper faces skips the round altogether.
+      if (__any(viaDir && !(cached && cross == 0))) {
+        int ptr[8];
 #pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        base[s] = -1;
-        if (need[s]) base[s] = resolve_block(vol, head[s], bx + (s & 1), by + ((s >> 1) & 1), bz + (s >> 2));
+        for (int s = 0; s < 8; ++s) {
+          const int t = s & cross;                                     // block of corner pattern s (s itself when it crosses)
+          const uint32_t cell = viaDir ? dir_cell(ux + (uint32_t)(t & 1), uy + (uint32_t)((t >> 1) & 1), uz + (uint32_t)(t >> 2)) : 0u;
+          ptr[s] = vol.dirPtr[cell];
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) base[s] = (ptr[s] < 0) ? -1 : ptr[s] * kBlockVoxels;
+      } else {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) base[s] = cache.base;             // every lane: cached && cross == 0 (or no lane uses the directory)
       }
-      if (cached) base[0] = cache.base;
-      else if (base[0] >= 0) { cache.bx = bx; cache.by = by; cache.bz = bz; cache.base = base[0]; }
+      if (!viaDir) {
+        // outside the directory (or directory disabled): table walk; entries are fetched for the blocks actually needed, the
+        // other loads re-read the first entry
+        const int idx0 = hash_index(bx, by, bz, vol.mask);
+        HashEntry head[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const bool need = ((s & ~cross) == 0) && !(s == 0 && cached);
+          head[s] = unpack_entry(vol.hash[need ? hash_index(bx + (s & 1), by + ((s >> 1) & 1), bz + (s >> 2), vol.mask) : idx0]);
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const bool need = ((s & ~cross) == 0) && !(s == 0 && cached);
+          base[s] = need ? resolve_block(vol, head[s], bx + (s & 1), by + ((s >> 1) & 1), bz + (s >> 2)) : -1;
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) base[s] = base[s & cross];
+      }
+      if (cached) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) if ((s & cross) == 0) base[s] = cache.base;
+      } else if (base[0] >= 0) { cache.bx = bx; cache.by = by; cache.bz = bz; cache.base = base[0]; }
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        const int b = base[c & cross];
+        const int b = base[c];
         const int off = ((lx + (c & 1)) & 7) + ((ly + ((c >> 1) & 1)) & 7) * 8 + ((lz + (c >> 2)) & 7) * 64;
         present[c] = b >= 0;
-        v[c] = present[c] ? VX::load_raw_sdf(vol.vba, (size_t)(b + off)) : dflt;
+        addr[c] = present[c] ? (size_t)(b + off) : (size_t)0;
       }
     }
+    float raw[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) raw[c] = VX::load_raw_sdf(vol.vba, addr[c]);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = present[c] ? raw[c] : dflt;
   }
 
   // readFromSDF_float_interpolated on the fetched values (blend on raw values, then convert)
@@ -354,6 +403,135 @@ __device__ inline float4 cast_ray(int x, int y, const VolumeView& vol, const Ray
 #endif
   return make_float4(px, py, pz, w);
 #endif
+}
+
+// castRay over the block directory (hash index).  Same per-ray sequence of positions, reads and float operations as
+// cast_ray / the reference; what changes is how "is there a block here" is answered:
+//   * a ray keeps the 64-bit brick-occupancy word of its current super-brick (16^3 blocks) in registers.  While the
+//     bricks it steps into are empty according to that word it advances by the reference's 8-voxel "no block" step on
+//     register arithmetic alone -- no memory access, so the lanes of a wave that cross empty space (silhouette rays that
+//     run ~45 such steps from the sphere to the wall) do not wait for the lanes that are entering blocks, and
+//     vice versa: the run is an inner loop of its own, the other lanes wait at its exit for a few hundred cycles
+//     instead of pacing every one of those steps with a memory round trip (round 1: 59 wave iterations of ~2 600
+//     cycles on 16 % of the waves = the kernel time);
+//   * entering a block is dirPtr -> voxel (two dependent loads) instead of occupancy bit -> hash entry -> voxel.
+#ifndef ITM_RAY_EMPTY_RUN
+#define ITM_RAY_EMPTY_RUN (1 << 30)   // cap on consecutive register-only steps before the wave looks at its other lanes
+#endif
+template <class VX>
+__device__ inline float4 cast_ray_dir(int x, int y, const VolumeView& vol, const RayParams& p, float2 mm) {
+  enum : int { MARCH = 0, TRI = 1, REFINE = 2, DONE = 3 };
+  const float stepScale = p.mu * p.oneOverVoxel;
+  const RaySetup r = ray_setup(x, y, p, mm);
+  float px = r.px, py = r.py, pz = r.pz, total = r.total;
+  const float dx = r.dx, dy = r.dy, dz = r.dz, totalMax = r.totalMax;
+  BlockCache cache;
+  uint32_t superKey = 0xffffffffu;
+  uint2 superWord = make_uint2(0u, 0u);
+  bool found;
+  float w = 0.0f;
+  int st = (total < totalMax) ? MARCH : DONE;
+  ITM_WT(const unsigned long long wtStart = wt_clock(); unsigned wtOuter = 0, wtInner = 0, wtSteps = 0; unsigned long long wtRun = 0, wtMem = 0, wtTri = 0;)
+  while (st != DONE) {
+    int budget = ITM_RAY_MARCH_BURST;
+    while (st == MARCH && budget > 0) {
+      int vx, vy, vz, bx, by, bz;
+      uint32_t ux, uy, uz;
+      bool inCache, covered;
+      // ---- (1) empty-space run: register arithmetic only ----------------------------------------------------
+      int run = ITM_RAY_EMPTY_RUN;
+      ITM_WT(const unsigned long long wtA = wt_clock(); ++wtInner;)
+      for (;;) {
+        ITM_WT(++wtSteps;)
+        vx = (int)round_ref(px); vy = (int)round_ref(py); vz = (int)round_ref(pz);
+        bx = vx >> 3; by = vy >> 3; bz = vz >> 3;                        // floor division by 8
+        inCache = (bx == cache.bx && by == cache.by && bz == cache.bz);
+        ux = (uint32_t)(bx + kDirHalf); uy = (uint32_t)(by + kDirHalf); uz = (uint32_t)(bz + kDirHalf);
+        covered = dir_covers(ux, uy, uz);
+        if (inCache || !covered || dir_super(ux, uy, uz) != superKey) break;
+        const uint32_t bit = dir_brick_bit(ux, uy, uz);
+        if ((((bit & 32u) ? superWord.y : superWord.x) >> (bit & 31u)) & 1u) break;
+        if (--run < 0) break;
+        // the brick is empty: the reference's "block not found" step
+        px += (float)kBlockSide * dx; py += (float)kBlockSide * dy; pz += (float)kBlockSide * dz;
+        total += (float)kBlockSide;
+        if (!(total < totalMax)) { st = DONE; break; }
+      }
+      ITM_WT(const unsigned long long wtB = wt_clock(); wtRun += wtB - wtA;)
+      if (st != MARCH) break;
+      --budget;
+      // ---- (2) this position needs memory -----------------------------------------------------------------------
+      const int lin = (vx & 7) + ((vy & 7) << 3) + ((vz & 7) << 6);
+      // directory cell and super-brick word are fetched together and unconditionally (lanes that do not need them read
+      // cell / word 0 and drop the value): one round trip, then the voxel
+      const uint32_t sk = covered ? dir_super(ux, uy, uz) : 0u;
+      const int ptr = vol.dirPtr[covered ? dir_cell(ux, uy, uz) : 0u];
+      const uint2 sw = vol.superMask[sk];
+      if (covered) { superWord = sw; superKey = sk; }
+      long long a = -1;
+      if (inCache) {
+        a = (long long)cache.base + lin;
+      } else if (covered) {
+        if (ptr >= 0) {
+          cache.bx = bx; cache.by = by; cache.bz = bz; cache.base = ptr * kBlockVoxels;
+          a = (long long)cache.base + lin;
+        }
+      } else {
+        a = locate_voxel<false>(vol, vx, vy, vz, cache);   // outside the directory: the table walk
+      }
+      found = a >= 0;
+      const float raw = VX::load_raw_sdf(vol.vba, found ? (size_t)a : (size_t)0);
+      const float sdf = found ? VX::to_float(raw) : 1.0f;
+      if (found && (sdf <= 0.1f) && (sdf >= -0.5f)) {
+        st = TRI;                        // the position is kept for the trilinear read
+      } else {
+        float step;
+        if (!found) step = (float)kBlockSide;
+        else if (sdf <= 0.0f) { step = sdf * stepScale; st = REFINE; }   // surface crossed below the band: first refinement move
+        else { const float s = sdf * stepScale; step = (s < 1.0f) ? 1.0f : s; }
+        px += step * dx; py += step * dy; pz += step * dz;
+        if (st == MARCH) { total += step; if (!(total < totalMax)) st = DONE; }
+      }
+      ITM_WT({ const float keep3 = total + px; asm volatile("" :: "v"(keep3)); wtMem += wt_clock() - wtB; })
+    }
+    // ---- expensive phase: one trilinear read for every lane that waits for one ------------------------
+    ITM_WT(const unsigned long long wtC = wt_clock();)
+    if (st == TRI || st == REFINE) {
+      const float sdf = sdf_trilinear<VX, false>(vol, px, py, pz, found, cache);
+      if (st == REFINE) {
+        const float step = sdf * stepScale;
+        px += step * dx; py += step * dy; pz += step * dz;
+        w = 1.0f; st = DONE;
+      } else if (sdf <= 0.0f) {
+        const float step = sdf * stepScale;
+        px += step * dx; py += step * dy; pz += step * dz;
+        st = REFINE;
+      } else {
+        const float s = sdf * stepScale;
+        const float step = (s < 1.0f) ? 1.0f : s;
+        px += step * dx; py += step * dy; pz += step * dz;
+        total += step;
+        st = (total < totalMax) ? MARCH : DONE;
+      }
+    }
+    ITM_WT({ const float keep4 = total + px; asm volatile("" :: "v"(keep4)); wtTri += wt_clock() - wtC; ++wtOuter; })
+  }
+#if ITM_EXP_WAVE_TIMING
+  {
+    const float keep2 = total + px; asm volatile("" :: "v"(keep2));
+    const unsigned long long wtEnd = wt_clock();
+    const unsigned wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // per wave: total cycles, outer iterations, inner (memory-step) iterations, register-only steps, cycles in the empty runs,
+    // in the memory steps and in the trilinear phase (each the maximum over the lanes: the lane that stayed longest)
+    const unsigned long long mOuter = wt_wave_max(wtOuter), mInner = wt_wave_max(wtInner), mSteps = wt_wave_max(wtSteps);
+    const unsigned long long mRun = wt_wave_max(wtRun), mMem = wt_wave_max(wtMem), mTri = wt_wave_max(wtTri);
+    if ((threadIdx.x & 63) == 0 && wv < 8192) {
+      unsigned long long* o = g_waveStats + (size_t)wv * 12;
+      o[0] = wtEnd - wtStart; o[1] = mOuter; o[2] = mInner; o[3] = mSteps; o[4] = mRun; o[5] = mMem; o[6] = mTri;
+    }
+  }
+#endif
+  return make_float4(px, py, pz, w);
 }
 
 }  // namespace itm

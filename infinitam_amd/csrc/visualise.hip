@@ -34,6 +34,7 @@ namespace itm {
 #endif
 
 int g_debug_force_global_range = 0;
+int g_debug_no_directory = 0;
 
 // ---------------------------------------------------------------------------------------------
 // expected depth range
@@ -187,7 +188,7 @@ int launch_expected_depths(const itm_scene* s, const float* M, const float* intr
 // ray casting
 // ---------------------------------------------------------------------------------------------
 // One workgroup = 16x16 pixels; wave w covers rows 4w..4w+3 (16x4 pixels, two 8x8 range cells).
-template <class VX, bool DENSE>
+template <class VX, bool DENSE, bool DIR>
 __global__ void __launch_bounds__(256) raycast_kernel(VolumeView vol, const float2* __restrict__ range, float4* __restrict__ out, RayParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // (An XCD-affine order -- image band b ray-cast by XCD b, with integration placing the blocks of band b on XCD b --
@@ -199,7 +200,8 @@ __global__ void __launch_bounds__(256) raycast_kernel(VolumeView vol, const floa
   const int y = ty * 16 + wave * 4 + (lane >> 4);
   if (x >= p.W || y >= p.H) return;
   const float2 mm = range[(x >> 3) + (y >> 3) * p.W];  // floor(x/8) + floor(y/8)*W  (_CPU.cpp:174)
-  out[x + y * p.W] = cast_ray<VX, DENSE>(x, y, vol, p, mm);
+  if constexpr (DIR) out[x + y * p.W] = cast_ray_dir<VX>(x, y, vol, p, mm);
+  else out[x + y * p.W] = cast_ray<VX, DENSE>(x, y, vol, p, mm);
 }
 
 int launch_raycast(const itm_scene* s, const float* invM, const float* intr, itm_render_state* rs, float4* dst, hipStream_t st) {
@@ -210,8 +212,9 @@ int launch_raycast(const itm_scene* s, const float* invM, const float* intr, itm
   KernelTimer tk(s, ITM_TK_RAYCAST, st);
   int rc = dispatch_voxel(s->cfg.voxelType, [&](auto vx) {
     using VX = decltype(vx);
-    if (dense) raycast_kernel<VX, true><<<grid, 256, 0, st>>>(vol, rs->range, dst, p);
-    else raycast_kernel<VX, false><<<grid, 256, 0, st>>>(vol, rs->range, dst, p);
+    if (dense) raycast_kernel<VX, true, false><<<grid, 256, 0, st>>>(vol, rs->range, dst, p);
+    else if (vol.dirPtr) raycast_kernel<VX, false, true><<<grid, 256, 0, st>>>(vol, rs->range, dst, p);
+    else raycast_kernel<VX, false, false><<<grid, 256, 0, st>>>(vol, rs->range, dst, p);
     return ITM_OK;
   });
   if (rc) return rc;
@@ -328,6 +331,7 @@ int itm_debug_set(int key, int value) {
   if (key == ITM_DEBUG_EXPLICIT_MARK_PREVIOUS) { g_debug_explicit_mark = value; return ITM_OK; }
   if (key == ITM_DEBUG_INTEGRATE_WORKGROUPS) { g_debug_integrate_wgs = value; return ITM_OK; }
   if (key == ITM_DEBUG_NO_FUSED_PROJECTION) { g_debug_no_fused_projection = value; return ITM_OK; }
+  if (key == ITM_DEBUG_NO_DIRECTORY) { g_debug_no_directory = value; return ITM_OK; }
   return set_error(ITM_ERR_INVALID, "unknown debug key");
 }
 

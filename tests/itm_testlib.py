@@ -28,6 +28,7 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_LIB = os.path.join(ORACLE_DIR, "libitm_oracle.so")
 REF_LIB = os.path.join(ORACLE_DIR, "_ref", "libitm_ref.so")
 ORACLE_OMP_LIB = os.path.join(ORACLE_DIR, "libitm_oracle_omp.so")      # timing only (bench.py all-cores baseline)
+REF_POOL40000_LIB = os.path.join(ORACLE_DIR, "_ref", "libitm_ref_pool40000.so")   # reference built with SDF_LOCAL_BLOCK_NUM=0x40000
 REF_OMP_LIB = os.path.join(ORACLE_DIR, "_ref", "libitm_ref_omp.so")    # timing only
 REFERENCE_TREE = "/root/reference/InfiniTAM"
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
@@ -60,6 +61,15 @@ def reference_backend() -> Optional[Backend]:
             subprocess.run(["make", "-C", ORACLE_DIR, "ref"], check=True, capture_output=True)
         _cache["ref"] = Backend(REF_LIB, "itmr_") if os.path.exists(REF_LIB) else None
     return _cache["ref"]
+
+
+def reference_pool40000_backend() -> Optional[Backend]:
+    """The reference's CPU engines compiled with the upstream pool size 0x40000 (oracle/Makefile target ref40000)."""
+    if "ref40000" not in _cache:
+        if not os.path.exists(REF_POOL40000_LIB) and os.path.isdir(REFERENCE_TREE):
+            subprocess.run(["make", "-C", ORACLE_DIR, "ref40000"], check=True, capture_output=True)
+        _cache["ref40000"] = Backend(REF_POOL40000_LIB, "itmr_") if os.path.exists(REF_POOL40000_LIB) else None
+    return _cache["ref40000"]
 
 
 def hip_backend() -> Backend:

@@ -32,7 +32,7 @@ def test_bench_spawns_two_ranks_and_reports_them():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["streams"] == 2 and out["config"]["world_size_seen"] == 2
     assert out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
-    assert out["config"]["collective_backend"] == "gloo" and "1 frame(s) per collective" in out["config"]["exchange"]
+    assert out["config"]["collective_backend"] == "gloo" and "8 frame(s) per collective" in out["config"]["exchange"]
     assert out["value"] > 0 and out["config"]["per_rank_fps_min_max"][0] <= out["config"]["per_rank_fps_min_max"][1]
     assert out["roofline"] is None and out["cpu_baseline"] is None      # not the product: nothing is priced
     assert "ALTERNATIVE BACKEND" in out["data"]

@@ -187,3 +187,61 @@ def test_fast_divisions_are_ieee(hip):
     # (6) colour running average c / newW: c = old*oldW + new in [0, 256], integer weights 1..256
     c = (rng.uniform(0, 1.0, n) * ww + rng.uniform(0, 1.0, n)).astype(np.float32)
     assert np.array_equal(_divide(hip, 2, c, ww).view(np.uint32), (c / ww).view(np.uint32))
+
+
+# ---- block directory (dense mirror of the hash table, infinitam_amd/csrc/itm_types.h) ------------------------------------
+DIRECTORY_CASES = [
+    SCENARIOS[0],
+    Scenario(name="hash_s_4mm_bench_traj6", voxelSize=0.004, frames=6, trajectory="bench"),
+    # 1 mm voxels: a block is 8 mm, the directory covers +-2.048 m, so the sphere (1.0-1.5 m) lies inside it and the wall
+    # (2.5 m) outside: rays start on directory lookups and finish on the table walk
+    Scenario(name="hash_s_1mm_wall_outside_directory", w=160, h=120, voxelSize=0.001, mu=0.004, frames=2),
+    Scenario(name="hash_s_rgb_yaw", voxelType=T.VOXEL_S_RGB, colour=True, voxelSize=0.005, frames=3, trajectory="yaw", w=320, h=240),
+]
+
+
+@pytest.mark.parametrize("sc", DIRECTORY_CASES, ids=lambda s: s.name)
+def test_directory_and_table_walk_agree_with_oracle(hip, oracle, sc):
+    """The ray caster normally looks blocks up in the block directory; ITM_DEBUG_NO_DIRECTORY (5) selects the table walk.
+    Both must reproduce the oracle bit for bit, including where rays leave the cube the directory covers."""
+    b = T.run_scenario(oracle, sc)
+    T.compare_results(T.run_scenario(hip, sc, fused=True), b, sc, what=sc.name + "/directory")
+    hip.check(hip.fn["debug_set"](5, 1), "debug_set")
+    try:
+        a = T.run_scenario(hip, sc, fused=True)
+    finally:
+        hip.check(hip.fn["debug_set"](5, 0), "debug_set")
+    T.compare_results(a, b, sc, what=sc.name + "/table walk")
+
+
+def test_directory_is_rebuilt_after_table_upload(hip, oracle):
+    """A scene whose hash table, voxels and free lists were uploaded (checkpoint restore, itm_upload) must ray-cast like
+    the scene that produced them: the upload rebuilds the directory from the table."""
+    sc = Scenario(name="dir_rebuild", w=320, h=240, voxelSize=0.005, frames=3, trajectory="bench")
+    src = T.Session(hip, sc)
+    for k in range(sc.frames):
+        src.frame(k, fused=True)
+    dst = T.Session(hip, sc)
+    for which in (T.BUF_HASH_ENTRIES, T.BUF_EXCESS_LIST, T.BUF_ALLOCATION_LIST, T.BUF_VOXEL_BLOCKS):
+        dst.scene.upload(which, src.scene.download(which))
+    for which in (T.BUF_VISIBLE_IDS, T.BUF_VISIBLE_TYPE):
+        dst.scene.upload(which, src.scene.download(which, src.rs), dst.rs)
+    c = src.scene.counters(src.rs)
+    dst.scene.set_counters(dst.rs, c["lastFreeBlockId"], c["lastFreeExcessListId"], c["noVisibleEntries"])
+    ref = T.Session(oracle, sc)
+    for k in range(sc.frames):
+        ref.frame(k)
+    for ses in (dst, ref):          # a fourth frame on the restored scene and on the oracle's uninterrupted run
+        ses.frame(3, fused=False)
+    x, y = dst.snapshot(), ref.snapshot()
+    T.compare_results(x, y, sc, what="restored scene, next frame")
+    # free-view ray cast from another pose through the rebuilt directory
+    M = T.synth.pose_matrix_yaw((0.05, -0.02, 0.1), 0.1)
+    for ses in (dst, ref):
+        ses.scene.vis.FindVisibleBlocks(M, sc.intr(), ses.rs)
+        ses.scene.vis.CreateExpectedDepths(M, sc.intr(), ses.rs)
+        ses.scene.vis.FindSurface(M, sc.intr(), ses.rs)
+    ra, rb = dst.scene.download(T.BUF_RAYCAST_RESULT, dst.rs), ref.scene.download(T.BUF_RAYCAST_RESULT, ref.rs)
+    assert np.array_equal(ra[..., 3], rb[..., 3])
+    hit = ra[..., 3] > 0
+    assert hit.sum() > 1000 and np.array_equal(ra[hit], rb[hit])

@@ -21,6 +21,8 @@ from infinitam_amd import capi, synth  # noqa: E402
 
 def run(cfg: int, frames: int):
     be = capi.Backend(os.environ['ITM_LIB'], 'itm_') if os.environ.get('ITM_LIB') else itm.load()
+    if os.environ.get('ITM_NO_DIRECTORY'):
+        be.check(be.fn['debug_set'](5, 1), 'debug_set')   # A/B: ray cast through the table walk instead of the block directory
     if cfg == 3:
         W, H, vox, idx, vs = 640, 480, capi.VOXEL_S, capi.INDEX_DENSE, 0.004
         prm = capi.default_params(voxelSize=vs, stopIntegratingAtMaxW=True)

@@ -7,6 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from infinitam_amd import capi, synth
 be = capi.Backend(sys.argv[1], "itm_")
+if os.environ.get("ITM_NO_DIRECTORY"):
+    be.check(be.fn["debug_set"](5, 1), "debug_set")   # A/B: table walk instead of the block directory
 W, H = 640, 480
 scene = be.create_scene(capi.VOXEL_S, capi.INDEX_HASH, capi.default_params(voxelSize=0.004), localBlockNum=0x40000)
 scene.reco.ResetScene()

@@ -9,6 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from infinitam_amd import capi, synth
 be = capi.Backend(sys.argv[1], "itm_")
+if os.environ.get("ITM_NO_DIRECTORY"):
+    be.check(be.fn["debug_set"](5, 1), "debug_set")   # A/B: table walk instead of the block directory
 W, H = 640, 480
 scene = be.create_scene(capi.VOXEL_S, capi.INDEX_HASH, capi.default_params(voxelSize=0.004), localBlockNum=0x40000)
 scene.reco.ResetScene()
@@ -32,5 +34,11 @@ os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 np.save(os.path.join(ROOT, "gpurun_out", "wave_stats.npy"), st)
 np.save(os.path.join(ROOT, "gpurun_out", "wave_trace.npy"), tr)
 tot, outer = st[:, 0].astype(float), st[:, 1].astype(float)
+if st[:, 2].any():   # directory march: extra columns
+    order = np.argsort(-tot)
+    lab = ["cycles", "outer", "inner", "steps", "run_cyc", "mem_cyc", "tri_cyc"]
+    print("slowest 8 waves  ", lab); print(st[order[:8], :7].astype(np.int64))
+    print("median 8 waves   "); print(st[order[len(order) // 2: len(order) // 2 + 8], :7].astype(np.int64))
+    print("means            ", st[:, :7].astype(float).mean(axis=0).round(0))
 print("wave cycles: mean %.0f p50 %.0f p90 %.0f max %.0f; outer iterations: mean %.1f max %.0f" % (
     tot.mean(), *np.percentile(tot, [50, 90]), tot.max(), outer.mean(), outer.max()))
