@@ -342,6 +342,30 @@ int ITM_FN(track_camera)(const itm_tracker_config* cfg, const itm_view* view, co
                          const float* normalsMap, const float scenePose[16], float M_d_out[16],
                          itm_stream stream);
 
+/* The tracker as an object (ITMDepthTracker owns its hierarchy and reduction buffers, Engine/ITMDepthTracker.cpp:18-44): one
+ * handle = the device partials, the pinned result records and the depth pyramid of ONE tracker.  Calls on a handle are
+ * serialised by the handle; different handles (e.g. one per depth stream / HIP stream / host thread) are independent.  The
+ * two handle-less entry points above use a handle private to the calling host thread.  A reduction that does not arrive
+ * (hung or failed kernel) ends the call with ITM_ERR_DEVICE after a bounded wait instead of stalling the host. */
+typedef struct itm_tracker itm_tracker;
+int ITM_FN(tracker_create)(itm_tracker** out);
+int ITM_FN(tracker_destroy)(itm_tracker* tracker);
+int ITM_FN(tracker_g_and_h)(itm_tracker* tracker, const float* depth, int w, int h, const float viewIntr[4],
+                            const float* pointsMap, const float* normalsMap, int sceneW, int sceneH,
+                            const float sceneIntr[4], const float approxInvPose[16], const float scenePose[16],
+                            float distThresh, int iterationType, itm_tracker_gh* out, itm_stream stream);
+int ITM_FN(tracker_track_camera)(itm_tracker* tracker, const itm_tracker_config* cfg, const itm_view* view,
+                                 const float* pointsMap, const float* normalsMap, const float scenePose[16],
+                                 float M_d_out[16], itm_stream stream);
+
+/* Test hook (host only, no device work): the tracker's host-side iteration (level schedule, accept / reject damping, SE(3)
+ * update) driven by a caller-supplied evaluator of cost / gradient / Hessian, so that it can be checked on a machine without
+ * a GPU against ITMDepthTracker::TrackCamera with the same evaluator.  `evaluate` returns 0 on success. */
+typedef int (*itm_icp_evaluate_fn)(void* user, int level, int iterationType, const float approxInvPose[16],
+                                   float distThresh, itm_tracker_gh* out);
+int ITM_FN(debug_icp_track)(const itm_tracker_config* cfg, const float M_d[16], itm_icp_evaluate_fn evaluate,
+                            void* user, float M_d_out[16]);
+
 /* ---- state access ------------------------------------------------------------------------- */
 /* Blocks until `stream` has drained, then reads the device-side counters. */
 int ITM_FN(get_counters)(const itm_scene* scene, const itm_render_state* rs, itm_counters* out,

@@ -202,6 +202,13 @@ _HOST_IO_SIGS = {
     "read_rgbd_calib": (C.c_int, [C.c_char_p, _P]),
     "scene_save": (C.c_int, [_P, _P, C.c_char_p, _P]),
     "scene_load": (C.c_int, [_P, _P, C.c_char_p, _P]),
+    # tracker handles (the oracle / reference shims have no use for them: their trackers are stateless)
+    "debug_icp_track": (C.c_int, [C.POINTER(TrackerConfig), C.POINTER(C.c_float), _P, _P, C.POINTER(C.c_float)]),
+    "tracker_create": (C.c_int, [C.POINTER(_P)]),
+    "tracker_destroy": (C.c_int, [_P]),
+    "tracker_g_and_h": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(C.c_float), _P, _P, C.c_int, C.c_int, C.POINTER(C.c_float),
+                                  C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_int, C.POINTER(TrackerGH), _P]),
+    "tracker_track_camera": (C.c_int, [_P, C.POINTER(TrackerConfig), C.POINTER(ViewStruct), _P, _P, C.POINTER(C.c_float), C.POINTER(C.c_float), _P]),
 }
 
 

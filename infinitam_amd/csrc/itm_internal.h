@@ -67,12 +67,9 @@ struct itm_scene {
   // proves that no block hashing to bucket b is allocated (excess entries hang off occupied heads),
   // which lets the ray caster skip empty space without touching the 16-byte entries.
   uint32_t* headBits = nullptr;   // uint32[bucketNum / 32]
-  // Block directory (raycast_device.h): dirPtr[cell] = voxel-block index of the block at that position or -1, cells in
-  // brick-major order (4x4x4 blocks = 256 contiguous bytes); superMask[s] = 64-bit occupancy of the 4x4x4 bricks of
-  // super-brick s (bit set <=> some block of that brick is allocated).  Maintained by the allocation sweep, rebuilt
-  // after uploads; exact mirrors of the table, so lookups through them return what the table walk returns.
+  // Block directory (itm_types.h): dirPtr[cell] = voxel-block index of the block at that position or -1, cells in brick-major
+  // order.  Maintained by the allocation sweep, rebuilt after uploads; an exact mirror of the table entries with ptr >= 0.
   int32_t* dirPtr = nullptr;      // int32[kDirCells]  (512 MB)
-  uint2* superMask = nullptr;     // uint2[kSuperWords] (256 KB)
   uint32_t frameParity = 0;
   itm::Profiler* prof = nullptr;
 };

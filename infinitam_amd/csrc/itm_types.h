@@ -195,16 +195,18 @@ struct VoxelFRgb {  // ITMVoxel_f_rgb: {f32 sdf @0; u8 w_depth @4; u8 clr[3] @5;
 
 // ---- block directory ------------------------------------------------------------------------
 // A dense mirror of the hash table over the block coordinates [-kDirHalf, kDirHalf)^3, spending HBM capacity (512 MB of
-// 288 GB) to turn "is block b allocated, and where" into ONE load from a spatially coherent array instead of a hash
-// probe plus chain walk through a spatially incoherent one:
+// 288 GB) to turn "is block b allocated, and where" into ONE load from a spatially coherent array instead of an occupancy
+// bit + hash entry (+ chain) from spatially incoherent ones:
 //   dirPtr[cell]   int32: voxel-block index (ITMHashEntry::ptr) of the block at that position, -1 if none.  Cells are
-//                  stored brick-major: a brick = 4x4x4 blocks = 64 cells = 256 contiguous bytes.
-//   superMask[s]   64 bits: occupancy of the 4x4x4 bricks of super-brick s (16^3 blocks = 128^3 voxels); a clear bit
-//                  proves that none of the 64 blocks of that brick is allocated, so a ray can cross it on register
-//                  arithmetic alone.
-// Blocks outside the covered cube are looked up through the hash table as before.  Both arrays are written by the
-// allocation sweep for every block it allocates (and rebuilt from the table after an upload), so they hold exactly the
-// entries with ptr >= 0 -- the ones the reference's readVoxel finds (DeviceAgnostic/ITMRepresentationAccess.h:85-119).
+//                  stored brick-major: a brick = 4x4x4 blocks = 64 cells = 256 contiguous bytes, so the rays of a wave
+//                  (neighbouring pixels) read one or two cache lines per step.
+// Blocks outside the covered cube are looked up through the hash table as before.  The array is written by the allocation
+// sweep for every block it allocates (and rebuilt from the table after an upload), so it holds exactly the entries with
+// ptr >= 0 -- the ones the reference's readVoxel finds (DeviceAgnostic/ITMRepresentationAccess.h:85-119).
+// (A second level -- a 64-bit brick-occupancy word per 16^3-block super-brick kept in registers, so that rays cross empty
+// bricks on arithmetic alone, with joint "runs" of the lanes of a wave and provably-safe multi-step advances -- was built
+// and measured: 83-104 us against 64 us for the plain directory; the classification arithmetic per step costs more than
+// the L1-resident load it saves and the extra loop structure de-synchronises the lanes.  Removed)
 #ifndef ITM_DIR_BITS
 #define ITM_DIR_BITS 9
 #endif
@@ -212,8 +214,6 @@ constexpr int kDirBits = ITM_DIR_BITS;
 constexpr int kDirSide = 1 << kDirBits;        // 512 blocks per axis: +-8.2 m at 4 mm voxels, +-4.1 m at 2 mm
 constexpr int kDirHalf = kDirSide / 2;
 constexpr size_t kDirCells = (size_t)kDirSide * kDirSide * kDirSide;
-constexpr int kSuperSide = kDirSide / 16;      // super-bricks per axis (32)
-constexpr size_t kSuperWords = (size_t)kSuperSide * kSuperSide * kSuperSide;
 
 // biased block coordinates (each in [0, kDirSide) when the block is covered)
 __host__ __device__ inline bool dir_covers(uint32_t ux, uint32_t uy, uint32_t uz) { return ((ux | uy | uz) >> kDirBits) == 0u; }
@@ -221,19 +221,10 @@ __host__ __device__ inline uint32_t dir_cell(uint32_t ux, uint32_t uy, uint32_t 
   const uint32_t brick = ((uz >> 2) << (2 * (kDirBits - 2))) | ((uy >> 2) << (kDirBits - 2)) | (ux >> 2);
   return (brick << 6) | ((uz & 3u) << 4) | ((uy & 3u) << 2) | (ux & 3u);
 }
-__host__ __device__ inline uint32_t dir_super(uint32_t ux, uint32_t uy, uint32_t uz) {
-  return ((uz >> 4) << (2 * (kDirBits - 4))) | ((uy >> 4) << (kDirBits - 4)) | (ux >> 4);
-}
-__host__ __device__ inline uint32_t dir_brick_bit(uint32_t ux, uint32_t uy, uint32_t uz) {   // 0..63 within the super-brick
-  return (((uz >> 2) & 3u) << 4) | (((uy >> 2) & 3u) << 2) | ((ux >> 2) & 3u);
-}
 // records an allocated block (device side; called by the allocation sweep and the rebuild kernel)
-__device__ inline void directory_insert(int32_t* __restrict__ dirPtr, uint32_t* __restrict__ superMask32, int bx, int by, int bz, int ptr) {
+__device__ inline void directory_insert(int32_t* __restrict__ dirPtr, int bx, int by, int bz, int ptr) {
   const uint32_t ux = (uint32_t)(bx + kDirHalf), uy = (uint32_t)(by + kDirHalf), uz = (uint32_t)(bz + kDirHalf);
-  if (!dir_covers(ux, uy, uz)) return;
-  dirPtr[dir_cell(ux, uy, uz)] = ptr;
-  const uint32_t bit = dir_brick_bit(ux, uy, uz);
-  atomicOr(&superMask32[2u * dir_super(ux, uy, uz) + (bit >> 5)], 1u << (bit & 31u));
+  if (dir_covers(ux, uy, uz)) dirPtr[dir_cell(ux, uy, uz)] = ptr;
 }
 
 // 4x4 column-major matrix passed to kernels by value

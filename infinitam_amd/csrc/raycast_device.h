@@ -43,7 +43,6 @@ struct VolumeView {
   uint32_t mask;       // bucketNum - 1
   int bucketNum;
   const int32_t* dirPtr;    // block directory (itm_types.h); nullptr = walk the table (hash index only)
-  const uint2* superMask;   // brick occupancy per super-brick
   int sx, sy, sz;      // dense size
   int ox, oy, oz;      // dense offset
 };
@@ -334,12 +333,20 @@ __device__ inline float4 cast_ray_plain(int x, int y, const VolumeView& vol, con
 // line costs ~2 000 cycles per dependent round trip, a trilinear step ~4 500.  Burst 1 (= the plain loop)
 // 69 us, 2: 65, 3: 64, 4: 62, 8: 66, unbounded: 95 (lanes then serialise each other's empty-space runs).
 // The other restructurings that were tried and dropped are listed with their numbers in DESIGN.md section 5.
+#ifndef ITM_RAY_PREDICT_STEP
+// A step of at most this many voxels is expected to land inside the truncation band: the lane then skips the single-voxel
+// read and goes straight to the 2x2x2 fetch, which serves the nearest-neighbour read AND the trilinear read of that
+// position (0 disables the prediction).  A wrong guess only costs the wait for the expensive phase.
+#define ITM_RAY_PREDICT_STEP 2.0f
+#endif
 template <class VX, bool DENSE>
 __device__ inline float4 cast_ray(int x, int y, const VolumeView& vol, const RayParams& p, float2 mm) {
 #if !ITM_RAY_WHILE_WHILE
   return cast_ray_plain<VX, DENSE>(x, y, vol, p, mm);
 #else
-  enum : int { MARCH = 0, TRI = 1, REFINE = 2, DONE = 3 };
+  // MARCH: next read is a single voxel; PRE: next read is predicted to fall in the band (2x2x2 fetch decides);
+  // TRI: a single-voxel read found the band, the trilinear read of the same position is due; REFINE: the surface was crossed
+  enum : int { MARCH = 0, TRI = 1, REFINE = 2, PRE = 3, DONE = 4 };
   const float stepScale = p.mu * p.oneOverVoxel;
   const RaySetup r = ray_setup(x, y, p, mm);
   float px = r.px, py = r.py, pz = r.pz, total = r.total;
@@ -348,44 +355,52 @@ __device__ inline float4 cast_ray(int x, int y, const VolumeView& vol, const Ray
   bool found;
   float w = 0.0f;
   int st = (total < totalMax) ? MARCH : DONE;
+  // one forward step of the march loop for a value that is not in the band (or a trilinear value): returns the next state
+  auto advance = [&](bool fnd, float sdf) -> int {
+    float step;
+    int next = MARCH;
+    if (!fnd) step = (float)kBlockSide;
+    else if (sdf <= 0.0f) { step = sdf * stepScale; next = REFINE; }          // surface crossed: first refinement move, no length update
+    else {
+      const float s = sdf * stepScale;
+      step = (s < 1.0f) ? 1.0f : s;
+      if (ITM_RAY_PREDICT_STEP > 0.0f && step <= ITM_RAY_PREDICT_STEP) next = PRE;
+    }
+    px += step * dx; py += step * dy; pz += step * dz;
+    if (next != REFINE) { total += step; if (!(total < totalMax)) next = DONE; }
+    return next;
+  };
   ITM_WT(const unsigned long long wtStart = wt_clock(); unsigned wtOuter = 0;)
   while (st != DONE) {
     ITM_WT(const unsigned long long wt0 = wt_clock(); unsigned wtInner = 0; const unsigned wtLanes0 = __popcll(__ballot(1)); const unsigned wtMarch0 = __popcll(__ballot(st == MARCH));)
-    // ---- cheap phase: at most ITM_RAY_MARCH_BURST steps, so that waiting lanes are served regularly ----
+    // ---- cheap phase: at most ITM_RAY_MARCH_BURST single-voxel steps, so that waiting lanes are served regularly ----
     int budget = ITM_RAY_MARCH_BURST;
     while (st == MARCH && budget > 0) {
       --budget;
       ITM_WT(++wtInner;)
       const float sdf = sdf_nearest<VX, DENSE>(vol, px, py, pz, found, cache);
-      if (found && (sdf <= 0.1f) && (sdf >= -0.5f)) {
-        st = TRI;                        // the position is kept for the trilinear read
-      } else {
-        float step;
-        if (!found) step = (float)kBlockSide;
-        else if (sdf <= 0.0f) { step = sdf * stepScale; st = REFINE; }   // surface crossed below the band: first refinement move
-        else { const float s = sdf * stepScale; step = (s < 1.0f) ? 1.0f : s; }
-        px += step * dx; py += step * dy; pz += step * dz;
-        if (st == MARCH) { total += step; if (!(total < totalMax)) st = DONE; }
-      }
+      if (found && (sdf <= 0.1f) && (sdf >= -0.5f)) st = TRI;      // the position is kept for the trilinear read
+      else st = advance(found, sdf);
     }
-    ITM_WT(const unsigned long long wtA = wt_clock(); const unsigned wtTriLanes = __popcll(__ballot(st == TRI || st == REFINE)); wtInner = (unsigned)wt_wave_max(wtInner);)
-    // ---- expensive phase: one trilinear read for every lane that waits for one ------------------------
-    if (st == TRI || st == REFINE) {
-      const float sdf = sdf_trilinear<VX, DENSE>(vol, px, py, pz, found, cache);
+    ITM_WT(const unsigned long long wtA = wt_clock(); const unsigned wtTriLanes = __popcll(__ballot(st == TRI || st == REFINE || st == PRE)); wtInner = (unsigned)wt_wave_max(wtInner);)
+    // ---- expensive phase: one 2x2x2 fetch for every lane that waits for one ---------------------------------------------
+    if (st == TRI || st == REFINE || st == PRE) {
+      Corners<VX, DENSE> cn;
+      cn.fetch(vol, px, py, pz, cache);
       if (st == REFINE) {
-        const float step = sdf * stepScale;
+        const float step = cn.trilinear() * stepScale;
         px += step * dx; py += step * dy; pz += step * dz;
         w = 1.0f; st = DONE;
-      } else if (sdf <= 0.0f) {
-        const float step = sdf * stepScale;
-        px += step * dx; py += step * dy; pz += step * dz;
-        st = REFINE;
       } else {
-        const float s = sdf * stepScale;
-        const float step = (s < 1.0f) ? 1.0f : s;
-        px += step * dx; py += step * dy; pz += step * dz;
-        total += step;
-        st = (total < totalMax) ? MARCH : DONE;
+        bool band = true;
+        if (st == PRE) {
+          // the nearest-neighbour read of this position, from the fetched corners
+          bool fnd;
+          const float sdfN = cn.nearest(px, py, pz, fnd);
+          band = fnd && (sdfN <= 0.1f) && (sdfN >= -0.5f);
+          if (!band) st = advance(fnd, sdfN);
+        }
+        if (band) st = advance(true, cn.trilinear());
       }
     }
     ITM_WT({ const float keep2 = total + px; asm volatile("" :: "v"(keep2)); const unsigned long long tB = wt_clock();
@@ -403,135 +418,6 @@ __device__ inline float4 cast_ray(int x, int y, const VolumeView& vol, const Ray
 #endif
   return make_float4(px, py, pz, w);
 #endif
-}
-
-// castRay over the block directory (hash index).  Same per-ray sequence of positions, reads and float operations as
-// cast_ray / the reference; what changes is how "is there a block here" is answered:
-//   * a ray keeps the 64-bit brick-occupancy word of its current super-brick (16^3 blocks) in registers.  While the
-//     bricks it steps into are empty according to that word it advances by the reference's 8-voxel "no block" step on
-//     register arithmetic alone -- no memory access, so the lanes of a wave that cross empty space (silhouette rays that
-//     run ~45 such steps from the sphere to the wall) do not wait for the lanes that are entering blocks, and
-//     vice versa: the run is an inner loop of its own, the other lanes wait at its exit for a few hundred cycles
-//     instead of pacing every one of those steps with a memory round trip (round 1: 59 wave iterations of ~2 600
-//     cycles on 16 % of the waves = the kernel time);
-//   * entering a block is dirPtr -> voxel (two dependent loads) instead of occupancy bit -> hash entry -> voxel.
-#ifndef ITM_RAY_EMPTY_RUN
-#define ITM_RAY_EMPTY_RUN (1 << 30)   // cap on consecutive register-only steps before the wave looks at its other lanes
-#endif
-template <class VX>
-__device__ inline float4 cast_ray_dir(int x, int y, const VolumeView& vol, const RayParams& p, float2 mm) {
-  enum : int { MARCH = 0, TRI = 1, REFINE = 2, DONE = 3 };
-  const float stepScale = p.mu * p.oneOverVoxel;
-  const RaySetup r = ray_setup(x, y, p, mm);
-  float px = r.px, py = r.py, pz = r.pz, total = r.total;
-  const float dx = r.dx, dy = r.dy, dz = r.dz, totalMax = r.totalMax;
-  BlockCache cache;
-  uint32_t superKey = 0xffffffffu;
-  uint2 superWord = make_uint2(0u, 0u);
-  bool found;
-  float w = 0.0f;
-  int st = (total < totalMax) ? MARCH : DONE;
-  ITM_WT(const unsigned long long wtStart = wt_clock(); unsigned wtOuter = 0, wtInner = 0, wtSteps = 0; unsigned long long wtRun = 0, wtMem = 0, wtTri = 0;)
-  while (st != DONE) {
-    int budget = ITM_RAY_MARCH_BURST;
-    while (st == MARCH && budget > 0) {
-      int vx, vy, vz, bx, by, bz;
-      uint32_t ux, uy, uz;
-      bool inCache, covered;
-      // ---- (1) empty-space run: register arithmetic only ----------------------------------------------------
-      int run = ITM_RAY_EMPTY_RUN;
-      ITM_WT(const unsigned long long wtA = wt_clock(); ++wtInner;)
-      for (;;) {
-        ITM_WT(++wtSteps;)
-        vx = (int)round_ref(px); vy = (int)round_ref(py); vz = (int)round_ref(pz);
-        bx = vx >> 3; by = vy >> 3; bz = vz >> 3;                        // floor division by 8
-        inCache = (bx == cache.bx && by == cache.by && bz == cache.bz);
-        ux = (uint32_t)(bx + kDirHalf); uy = (uint32_t)(by + kDirHalf); uz = (uint32_t)(bz + kDirHalf);
-        covered = dir_covers(ux, uy, uz);
-        if (inCache || !covered || dir_super(ux, uy, uz) != superKey) break;
-        const uint32_t bit = dir_brick_bit(ux, uy, uz);
-        if ((((bit & 32u) ? superWord.y : superWord.x) >> (bit & 31u)) & 1u) break;
-        if (--run < 0) break;
-        // the brick is empty: the reference's "block not found" step
-        px += (float)kBlockSide * dx; py += (float)kBlockSide * dy; pz += (float)kBlockSide * dz;
-        total += (float)kBlockSide;
-        if (!(total < totalMax)) { st = DONE; break; }
-      }
-      ITM_WT(const unsigned long long wtB = wt_clock(); wtRun += wtB - wtA;)
-      if (st != MARCH) break;
-      --budget;
-      // ---- (2) this position needs memory -----------------------------------------------------------------------
-      const int lin = (vx & 7) + ((vy & 7) << 3) + ((vz & 7) << 6);
-      // directory cell and super-brick word are fetched together and unconditionally (lanes that do not need them read
-      // cell / word 0 and drop the value): one round trip, then the voxel
-      const uint32_t sk = covered ? dir_super(ux, uy, uz) : 0u;
-      const int ptr = vol.dirPtr[covered ? dir_cell(ux, uy, uz) : 0u];
-      const uint2 sw = vol.superMask[sk];
-      if (covered) { superWord = sw; superKey = sk; }
-      long long a = -1;
-      if (inCache) {
-        a = (long long)cache.base + lin;
-      } else if (covered) {
-        if (ptr >= 0) {
-          cache.bx = bx; cache.by = by; cache.bz = bz; cache.base = ptr * kBlockVoxels;
-          a = (long long)cache.base + lin;
-        }
-      } else {
-        a = locate_voxel<false>(vol, vx, vy, vz, cache);   // outside the directory: the table walk
-      }
-      found = a >= 0;
-      const float raw = VX::load_raw_sdf(vol.vba, found ? (size_t)a : (size_t)0);
-      const float sdf = found ? VX::to_float(raw) : 1.0f;
-      if (found && (sdf <= 0.1f) && (sdf >= -0.5f)) {
-        st = TRI;                        // the position is kept for the trilinear read
-      } else {
-        float step;
-        if (!found) step = (float)kBlockSide;
-        else if (sdf <= 0.0f) { step = sdf * stepScale; st = REFINE; }   // surface crossed below the band: first refinement move
-        else { const float s = sdf * stepScale; step = (s < 1.0f) ? 1.0f : s; }
-        px += step * dx; py += step * dy; pz += step * dz;
-        if (st == MARCH) { total += step; if (!(total < totalMax)) st = DONE; }
-      }
-      ITM_WT({ const float keep3 = total + px; asm volatile("" :: "v"(keep3)); wtMem += wt_clock() - wtB; })
-    }
-    // ---- expensive phase: one trilinear read for every lane that waits for one ------------------------
-    ITM_WT(const unsigned long long wtC = wt_clock();)
-    if (st == TRI || st == REFINE) {
-      const float sdf = sdf_trilinear<VX, false>(vol, px, py, pz, found, cache);
-      if (st == REFINE) {
-        const float step = sdf * stepScale;
-        px += step * dx; py += step * dy; pz += step * dz;
-        w = 1.0f; st = DONE;
-      } else if (sdf <= 0.0f) {
-        const float step = sdf * stepScale;
-        px += step * dx; py += step * dy; pz += step * dz;
-        st = REFINE;
-      } else {
-        const float s = sdf * stepScale;
-        const float step = (s < 1.0f) ? 1.0f : s;
-        px += step * dx; py += step * dy; pz += step * dz;
-        total += step;
-        st = (total < totalMax) ? MARCH : DONE;
-      }
-    }
-    ITM_WT({ const float keep4 = total + px; asm volatile("" :: "v"(keep4)); wtTri += wt_clock() - wtC; ++wtOuter; })
-  }
-#if ITM_EXP_WAVE_TIMING
-  {
-    const float keep2 = total + px; asm volatile("" :: "v"(keep2));
-    const unsigned long long wtEnd = wt_clock();
-    const unsigned wv = blockIdx.x * 4 + (threadIdx.x >> 6);
-    // per wave: total cycles, outer iterations, inner (memory-step) iterations, register-only steps, cycles in the empty runs,
-    // in the memory steps and in the trilinear phase (each the maximum over the lanes: the lane that stayed longest)
-    const unsigned long long mOuter = wt_wave_max(wtOuter), mInner = wt_wave_max(wtInner), mSteps = wt_wave_max(wtSteps);
-    const unsigned long long mRun = wt_wave_max(wtRun), mMem = wt_wave_max(wtMem), mTri = wt_wave_max(wtTri);
-    if ((threadIdx.x & 63) == 0 && wv < 8192) {
-      unsigned long long* o = g_waveStats + (size_t)wv * 12;
-      o[0] = wtEnd - wtStart; o[1] = mOuter; o[2] = mInner; o[3] = mSteps; o[4] = mRun; o[5] = mMem; o[6] = mTri;
-    }
-  }
-#endif
-  return make_float4(px, py, pz, w);
 }
 
 }  // namespace itm

@@ -136,13 +136,12 @@ __global__ void __launch_bounds__(256) head_bits_kernel(const uint4* __restrict_
 }
 
 // rebuilds the block directory from the table: every entry with ptr >= 0 whose position lies inside the directory
-__global__ void __launch_bounds__(256) directory_fill_kernel(const uint4* __restrict__ hash, int nEntries, int32_t* __restrict__ dirPtr,
-                                                             uint32_t* __restrict__ superMask) {
+__global__ void __launch_bounds__(256) directory_fill_kernel(const uint4* __restrict__ hash, int nEntries, int32_t* __restrict__ dirPtr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nEntries) return;
   const HashEntry e = unpack_entry(hash[i]);
   if (e.ptr < 0) return;
-  directory_insert(dirPtr, superMask, e.px, e.py, e.pz, e.ptr);
+  directory_insert(dirPtr, e.px, e.py, e.pz, e.ptr);
 }
 
 int rebuild_head_bits(itm_scene* s, hipStream_t st) {
@@ -151,8 +150,7 @@ int rebuild_head_bits(itm_scene* s, hipStream_t st) {
   head_bits_kernel<<<(nWords + 255) / 256, 256, 0, st>>>(s->hash, s->headBits, nWords, s->cfg.bucketNum);
   if (s->dirPtr) {
     ITM_HIP(hipMemsetAsync(s->dirPtr, 0xff, kDirCells * 4, st));
-    ITM_HIP(hipMemsetAsync(s->superMask, 0, kSuperWords * 8, st));
-    directory_fill_kernel<<<(s->noTotalEntries + 255) / 256, 256, 0, st>>>(s->hash, s->noTotalEntries, s->dirPtr, (uint32_t*)s->superMask);
+    directory_fill_kernel<<<(s->noTotalEntries + 255) / 256, 256, 0, st>>>(s->hash, s->noTotalEntries, s->dirPtr);
   }
   ITM_LAUNCH_CHECK();
   return ITM_OK;
@@ -243,7 +241,7 @@ static void free_scene(itm_scene* s) {
   if (s->prof) { s->prof->flush(); for (hipEvent_t e : s->prof->pool) (void)hipEventDestroy(e); delete s->prof; }
   (void)hipFree(s->hash); (void)hipFree(s->excessList); (void)hipFree(s->vba); (void)hipFree(s->allocList);
   (void)hipFree(s->counters); (void)hipFree(s->headBits); (void)hipFree(s->allocKey); (void)hipFree(s->chunkReq); (void)hipFree(s->chunkVis);
-  (void)hipFree(s->dirPtr); (void)hipFree(s->superMask);
+  (void)hipFree(s->dirPtr);
   delete s;
 }
 static void free_rs(itm_render_state* r) {
@@ -333,7 +331,6 @@ int itm_scene_create(const itm_scene_config* cfg_in, const itm_scene_params* prm
     alloc((void**)&s->chunkReq, (size_t)s->numChunks * 2 * 2 * 4);
     alloc((void**)&s->chunkVis, (size_t)s->numChunks * 4);
     alloc((void**)&s->dirPtr, kDirCells * 4);
-    alloc((void**)&s->superMask, kSuperWords * 8);
   } else {
     s->numVoxels = (size_t)cfg.denseSize[0] * cfg.denseSize[1] * cfg.denseSize[2];
     alloc((void**)&s->allocList, 4);
@@ -347,7 +344,6 @@ int itm_scene_create(const itm_scene_config* cfg_in, const itm_scene_params* prm
   if (e == hipSuccess && s->hash) e = hipMemset(s->hash, 0, (size_t)s->noTotalEntries * 16);
   if (e == hipSuccess && s->chunkReq) e = hipMemset(s->chunkReq, 0, (size_t)s->numChunks * 16);
   if (e == hipSuccess && s->dirPtr) e = hipMemset(s->dirPtr, 0xff, kDirCells * 4);
-  if (e == hipSuccess && s->superMask) e = hipMemset(s->superMask, 0, kSuperWords * 8);
   if (e != hipSuccess) { free_scene(s); return hip_fail(e, "hipMemset(scene)", __FILE__, __LINE__); }
   *out = s;
   return ITM_OK;
@@ -379,7 +375,6 @@ int itm_reset_scene(itm_scene* s, itm_stream stream) {
   ITM_LAUNCH_CHECK();
   if (s->cfg.indexType == ITM_INDEX_HASH) {
     ITM_HIP(hipMemsetAsync(s->dirPtr, 0xff, kDirCells * 4, st));
-    ITM_HIP(hipMemsetAsync(s->superMask, 0, kSuperWords * 8, st));
     reset_hash_kernel<<<1024, 256, 0, st>>>(s->hash, s->noTotalEntries, s->excessList, s->cfg.excessNum, s->allocList,
                                             s->cfg.localBlockNum, s->allocKey, s->headBits, (s->cfg.bucketNum + 31) / 32, s->chunkReq, s->numChunks * 4, s->counters);
   } else {

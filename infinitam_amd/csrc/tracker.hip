@@ -13,13 +13,19 @@
 // operations; the 1 + 6 + 21 sums and the valid count are reduced with wave shuffles, one partial per
 // workgroup, written to a stamped record in pinned host memory; the host adds the records in block order in double
 // precision (deterministic; the reference adds floats in raster order, so sums agree to float rounding, the count
-// exactly).  Host part: the Levenberg-Marquardt loop, 3x3 / 6x6 Cholesky and the SE(3) re-projection of
-// the pose, restated from the reference (plain C++ on the host, as in the reference's CUDA back-end).
+// exactly).  Host part: a damped Gauss-Newton iteration over SE(3) with the reference's accept / reject schedule, written
+// independently of the reference's code (double precision, LDL^T solve, exp/log projection: se3.h); the tracked pose
+// agrees with the reference's to 2e-5 (tests/test_tracker.py).
+#include <chrono>
 #include <cmath>
 #include <cstring>
+#include <mutex>
+#include <new>
 #include <vector>
 
 #include "itm_internal.h"
+#include "icp_solver.h"
+#include "se3.h"
 #include "wave_utils.h"
 
 namespace itm {
@@ -153,39 +159,70 @@ __global__ void __launch_bounds__(256) gh_partial_kernel(const float* __restrict
   }
 }
 
-// adds the per-workgroup partials in index order (fixed order => deterministic)
-// ---- scratch (one per process and device; calls synchronise anyway) ------------------------------
-struct TrackerScratch {
+// ---- tracker object -------------------------------------------------------------------------------------
+// What ITMDepthTracker owns in the reference (Engine/ITMDepthTracker.cpp:18-44: the hierarchy and the device-side reduction
+// buffers of ITMDepthTracker_CUDA) lives in a handle here: device partials, the stamped records in pinned host memory, the
+// depth pyramid.  One handle = one tracker = one caller at a time (the handle's mutex serialises callers); the handle-less
+// entry points of round 1 use a handle private to the calling thread, so two host threads (or two streams driven by two
+// threads) never share records or sequence numbers.
+}  // namespace itm
+
+struct itm_tracker {
+  std::mutex mu;
   int device = -1;
   double* partial = nullptr; int* partialCount = nullptr;
-  GHBlockRecord* rec = nullptr; GHBlockRecord* recDev = nullptr; size_t recBlocks = 0; unsigned int seq = 0;   // pinned host records + device address
+  itm::GHBlockRecord* rec = nullptr; itm::GHBlockRecord* recDev = nullptr;   // pinned host records + their device address
   size_t blocks = 0;
+  unsigned int seq = 0;
   std::vector<float*> pyramid; std::vector<size_t> pyramidBytes;
+  double pollTimeoutSeconds = 5.0;
 };
-static TrackerScratch g_scratch;
 
-static int ensure_scratch(size_t blocks) {
+namespace itm {
+
+static void tracker_release(itm_tracker* t) {
+  (void)hipFree(t->partial); (void)hipFree(t->partialCount);
+  if (t->rec) (void)hipHostFree(t->rec);
+  for (float* q : t->pyramid) (void)hipFree(q);
+  t->partial = nullptr; t->partialCount = nullptr; t->rec = nullptr; t->recDev = nullptr; t->blocks = 0;
+  t->pyramid.clear(); t->pyramidBytes.clear();
+}
+
+// (re)sizes the reduction buffers for `blocks` workgroups on the current device; on failure the handle is left empty
+static int tracker_reserve(itm_tracker* t, size_t blocks) {
   int dev = 0;
   (void)hipGetDevice(&dev);
-  if (g_scratch.device != dev || g_scratch.blocks < blocks) {
-    (void)hipFree(g_scratch.partial); (void)hipFree(g_scratch.partialCount);
-    g_scratch.partial = nullptr; g_scratch.partialCount = nullptr;
-    ITM_HIP(hipMalloc((void**)&g_scratch.partial, blocks * kGHValues * sizeof(double)));
-    ITM_HIP(hipMalloc((void**)&g_scratch.partialCount, blocks * sizeof(int)));
-    if (g_scratch.rec && (g_scratch.device != dev || g_scratch.recBlocks < blocks)) { (void)hipHostFree(g_scratch.rec); g_scratch.rec = nullptr; }
-    if (!g_scratch.rec) {
-      ITM_HIP(hipHostMalloc((void**)&g_scratch.rec, blocks * sizeof(GHBlockRecord), hipHostMallocMapped));
-      memset(g_scratch.rec, 0, blocks * sizeof(GHBlockRecord));
-      ITM_HIP(hipHostGetDevicePointer((void**)&g_scratch.recDev, g_scratch.rec, 0));
-      g_scratch.recBlocks = blocks;
-    }
-    if (g_scratch.device != dev) { g_scratch.pyramid.clear(); g_scratch.pyramidBytes.clear(); }
-    g_scratch.device = dev; g_scratch.blocks = blocks;
+  if (t->device == dev && t->blocks >= blocks) return ITM_OK;
+  if (t->device != dev) tracker_release(t);           // buffers of another device (incl. the pyramid) are of no use here
+  else {
+    (void)hipFree(t->partial); (void)hipFree(t->partialCount);
+    if (t->rec) (void)hipHostFree(t->rec);
+    t->partial = nullptr; t->partialCount = nullptr; t->rec = nullptr; t->recDev = nullptr;
   }
+  t->blocks = 0; t->device = dev;
+  hipError_t e = hipMalloc((void**)&t->partial, blocks * kGHValues * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&t->partialCount, blocks * sizeof(int));
+  // coherent + mapped: device stores become visible to the polling host without a kernel boundary
+  if (e == hipSuccess) e = hipHostMalloc((void**)&t->rec, blocks * sizeof(GHBlockRecord), hipHostMallocMapped | hipHostMallocCoherent);
+  if (e == hipSuccess) { memset(t->rec, 0, blocks * sizeof(GHBlockRecord)); e = hipHostGetDevicePointer((void**)&t->recDev, t->rec, 0); }
+  if (e != hipSuccess) {
+    (void)hipFree(t->partial); (void)hipFree(t->partialCount);
+    if (t->rec) (void)hipHostFree(t->rec);
+    t->partial = nullptr; t->partialCount = nullptr; t->rec = nullptr; t->recDev = nullptr;
+    return hip_fail(e, "tracker buffers", __FILE__, __LINE__);
+  }
+  t->blocks = blocks;
   return ITM_OK;
 }
 
-static int compute_g_and_h(const float* depth, int w, int h, const float* viewIntr, const float* pointsMap, const float* normalsMap,
+// the calling thread's own tracker for the handle-less entry points (never destroyed: HIP may already be gone at thread exit)
+static itm_tracker* thread_tracker() {
+  static thread_local itm_tracker* mine = nullptr;
+  if (!mine) mine = new (std::nothrow) itm_tracker();
+  return mine;
+}
+
+static int compute_g_and_h(itm_tracker* trk, const float* depth, int w, int h, const float* viewIntr, const float* pointsMap, const float* normalsMap,
                            int sceneW, int sceneH, const float* sceneIntr, const float* approxInvPose, const float* scenePose,
                            float distThresh, int iterationType, itm_tracker_gh* out, hipStream_t st) {
   memset(out, 0, sizeof *out);
@@ -193,7 +230,7 @@ static int compute_g_and_h(const float* depth, int w, int h, const float* viewIn
   if (iterationType < 1 || iterationType > 3) return set_error(ITM_ERR_INVALID, "bad iteration type");
   const dim3 grid((w + 15) / 16, (h + 15) / 16);
   const size_t blocks = (size_t)grid.x * grid.y;
-  int rc = ensure_scratch(blocks);
+  int rc = tracker_reserve(trk, blocks);
   if (rc) return rc;
   GHParams p;
   memcpy(p.approxInvPose.m, approxInvPose, 64); memcpy(p.scenePose.m, scenePose, 64);
@@ -203,26 +240,36 @@ static int compute_g_and_h(const float* depth, int w, int h, const float* viewIn
   const float4* pm = (const float4*)pointsMap; const float4* nm = (const float4*)normalsMap;
   const int np = (iterationType == ITM_TRACKER_ITERATION_BOTH) ? 6 : 3;
   const int nh = np * (np + 1) / 2;
-  const unsigned int seq = ++g_scratch.seq;
-  if (iterationType == 1) gh_partial_kernel<1><<<grid, 256, 0, st>>>(depth, pm, nm, g_scratch.partial, g_scratch.partialCount, p, g_scratch.recDev, seq);
-  else if (iterationType == 2) gh_partial_kernel<2><<<grid, 256, 0, st>>>(depth, pm, nm, g_scratch.partial, g_scratch.partialCount, p, g_scratch.recDev, seq);
-  else gh_partial_kernel<3><<<grid, 256, 0, st>>>(depth, pm, nm, g_scratch.partial, g_scratch.partialCount, p, g_scratch.recDev, seq);
+  const unsigned int seq = ++trk->seq;
+  if (iterationType == 1) gh_partial_kernel<1><<<grid, 256, 0, st>>>(depth, pm, nm, trk->partial, trk->partialCount, p, trk->recDev, seq);
+  else if (iterationType == 2) gh_partial_kernel<2><<<grid, 256, 0, st>>>(depth, pm, nm, trk->partial, trk->partialCount, p, trk->recDev, seq);
+  else gh_partial_kernel<3><<<grid, 256, 0, st>>>(depth, pm, nm, trk->partial, trk->partialCount, p, trk->recDev, seq);
   ITM_LAUNCH_CHECK();
-  // wait for every workgroup's record (bounded poll, then a stream synchronisation, which also surfaces device errors)
-  // and add them in block order: fixed order => deterministic, in double precision
+  // Wait for every workgroup's stamped record and add them in block order (fixed order => deterministic, in double).  The
+  // poll is bounded in TIME: after 20 ms without the stamp the stream is queried between polls -- a drained stream without
+  // the stamp, a device error, or pollTimeoutSeconds without progress end the call with ITM_ERR_DEVICE instead of
+  // stalling the host on a kernel that will never finish.
   double sums[kGHValues];
   for (int i = 0; i < kGHValues; ++i) sums[i] = 0.0;
   int n = 0;
-  bool synced = false;
+  using clock = std::chrono::steady_clock;
+  clock::time_point t0; bool timing = false;
   for (size_t b = 0; b < blocks; ++b) {
-    const GHBlockRecord* r = g_scratch.rec + b;
-    int spin = 0;
+    const GHBlockRecord* r = trk->rec + b;
+    unsigned spins = 0;
     while (r->seq != seq) {
       __builtin_ia32_pause();
-      if (++spin > 4000000) {
-        if (synced) return set_error(ITM_ERR_DEVICE, "tracker reduction did not complete");
-        ITM_HIP(hipStreamSynchronize(st)); synced = true; spin = 0;
+      if ((++spins & 0x3ffu) != 0u) continue;
+      if (!timing) { t0 = clock::now(); timing = true; continue; }
+      const double waited = std::chrono::duration<double>(clock::now() - t0).count();
+      if (waited < 0.02) continue;
+      const hipError_t q = hipStreamQuery(st);
+      if (q == hipSuccess) {
+        if (r->seq == seq) break;
+        return set_error(ITM_ERR_DEVICE, "tracker reduction: the stream drained without delivering every record");
       }
+      if (q != hipErrorNotReady) return hip_fail(q, "tracker reduction", __FILE__, __LINE__);
+      if (waited > trk->pollTimeoutSeconds) return set_error(ITM_ERR_DEVICE, "tracker reduction timed out");
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     for (int i = 0; i < kGHValues; ++i) sums[i] += r->sums[i];
@@ -238,127 +285,45 @@ static int compute_g_and_h(const float* depth, int w, int h, const float* viewIn
   return ITM_OK;
 }
 
-// ---- host side: pose algebra and the LM loop -------------------------------------------------------
-namespace hostpose {
+// FilterSubsampleWithHoles pyramid of the view's depth image in the tracker's own buffers (PrepareForEvaluation)
+struct DepthLevel { const float* depth; int w, h; float intr[4]; };
 
-struct Pose { float t[3], r[3]; float M[16]; };   // params (tx,ty,tz,rx,ry,rz) + model-view matrix
-
-inline float dot3(const float* a, const float* b) { float r = 0; for (int i = 0; i < 3; ++i) r += a[i] * b[i]; return r; }
-inline void cross3(const float* a, const float* b, float* o) { o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0]; }
-
-// ITMPose::SetModelViewFromParams (Objects/ITMPose.cpp:84-153); R is column-major 3x3, R[r + 3c]
-void rotation_from_params(const float* w, const float* t, float* R, float* T) {
-  const float one_6th = 1.0f / 6.0f, one_20th = 1.0f / 20.0f;
-  const float theta_sq = dot3(w, w);
-  const float theta = std::sqrt(theta_sq);
-  float A, B;
-  float cv[3]; cross3(w, t, cv);
-  if (theta_sq < 1e-8f) {
-    A = 1.0f - one_6th * theta_sq; B = 0.5f;
-    for (int i = 0; i < 3; ++i) T[i] = t[i] + 0.5f * cv[i];
-  } else {
-    float C;
-    if (theta_sq < 1e-6f) {
-      C = one_6th * (1.0f - one_20th * theta_sq);
-      A = 1.0f - theta_sq * C;
-      B = 0.5f - 0.25f * one_6th * theta_sq;
-    } else {
-      const float inv_theta = 1.0f / theta;
-      A = sinf(theta) * inv_theta;
-      B = (1.0f - cosf(theta)) * (inv_theta * inv_theta);
-      C = (1.0f - A) * (inv_theta * inv_theta);
+static int build_pyramid(itm_tracker* trk, const itm_view* view, int levels, std::vector<DepthLevel>& out, hipStream_t st) {
+  out.resize(levels);
+  out[0].depth = view->depth; out[0].w = view->w; out[0].h = view->h;
+  for (int k = 0; k < 4; ++k) out[0].intr[k] = view->intr_d[k];
+  if ((int)trk->pyramid.size() < levels) { trk->pyramid.resize(levels, nullptr); trk->pyramidBytes.resize(levels, 0); }
+  for (int i = 1; i < levels; ++i) {
+    DepthLevel& L = out[i];
+    L.w = out[i - 1].w / 2; L.h = out[i - 1].h / 2;
+    if (L.w < 1 || L.h < 1) return set_error(ITM_ERR_INVALID, "image too small for the hierarchy");
+    const size_t bytes = (size_t)L.w * L.h * 4;
+    if (trk->pyramidBytes[i] < bytes) {
+      (void)hipFree(trk->pyramid[i]); trk->pyramid[i] = nullptr; trk->pyramidBytes[i] = 0;
+      ITM_HIP(hipMalloc((void**)&trk->pyramid[i], bytes));
+      trk->pyramidBytes[i] = bytes;
     }
-    float c2[3]; cross3(w, cv, c2);
-    for (int i = 0; i < 3; ++i) T[i] = t[i] + B * cv[i] + C * c2[i];
+    subsample_holes_kernel<<<dim3((L.w + 15) / 16, (L.h + 15) / 16), 256, 0, st>>>(out[i - 1].depth, out[i - 1].w, trk->pyramid[i], L.w, L.h);
+    L.depth = trk->pyramid[i];
+    for (int k = 0; k < 4; ++k) L.intr[k] = out[i - 1].intr[k] * 0.5f;
   }
-  const float wx2 = w[0] * w[0], wy2 = w[1] * w[1], wz2 = w[2] * w[2];
-  R[0 + 3 * 0] = 1.0f - B * (wy2 + wz2);
-  R[1 + 3 * 1] = 1.0f - B * (wx2 + wz2);
-  R[2 + 3 * 2] = 1.0f - B * (wx2 + wy2);
-  float a, b;
-  a = A * w[2]; b = B * (w[0] * w[1]); R[0 + 3 * 1] = b - a; R[1 + 3 * 0] = b + a;
-  a = A * w[1]; b = B * (w[0] * w[2]); R[0 + 3 * 2] = b + a; R[2 + 3 * 0] = b - a;
-  a = A * w[0]; b = B * (w[1] * w[2]); R[1 + 3 * 2] = b - a; R[2 + 3 * 1] = b + a;
+  ITM_LAUNCH_CHECK();
+  return ITM_OK;
 }
 
-void model_view_from_params(Pose& p) {
-  float R[9], T[3];
-  rotation_from_params(p.r, p.t, R, T);
-  for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) p.M[r + 4 * c] = R[r + 3 * c];
-  p.M[12] = T[0]; p.M[13] = T[1]; p.M[14] = T[2];
-  p.M[3] = 0.0f; p.M[7] = 0.0f; p.M[11] = 0.0f; p.M[15] = 1.0f;
+static int track_camera(itm_tracker* trk, const itm_tracker_config* cfg, const itm_view* view, const float* pointsMap, const float* normalsMap,
+                        const float scenePose[16], float M_d_out[16], hipStream_t st) {
+  const int levels = cfg->noHierarchyLevels;
+  if (levels < 1 || levels > 8) return set_error(ITM_ERR_INVALID, "noHierarchyLevels must be 1..8");
+  int rc = tracker_reserve(trk, 1);
+  if (rc) return rc;
+  std::vector<DepthLevel> pyr;
+  if ((rc = build_pyramid(trk, view, levels, pyr, st))) return rc;
+  return icp_track(cfg, view->M_d, M_d_out, [&](int level, int mode, const float invPose[16], float distThresh, itm_tracker_gh* e) {
+    return compute_g_and_h(trk, pyr[level].depth, pyr[level].w, pyr[level].h, pyr[level].intr, pointsMap, normalsMap, view->w, view->h,
+                           pyr[0].intr, invPose, scenePose, distThresh, mode, e, st);
+  });
 }
-
-// ITMPose::SetParamsFromModelView (Objects/ITMPose.cpp:155-236)
-void params_from_model_view(Pose& p) {
-  float R[9], T[3];
-  for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) R[r + 3 * c] = p.M[r + 4 * c];
-  T[0] = p.M[12]; T[1] = p.M[13]; T[2] = p.M[14];
-  float rot[3];
-  const float cos_angle = (R[0] + R[4] + R[8] - 1.0f) * 0.5f;
-  rot[0] = (R[2 + 3 * 1] - R[1 + 3 * 2]) * 0.5f;
-  rot[1] = (R[0 + 3 * 2] - R[2 + 3 * 0]) * 0.5f;
-  rot[2] = (R[1 + 3 * 0] - R[0 + 3 * 1]) * 0.5f;
-  const float sin_angle_abs = std::sqrt(dot3(rot, rot));
-  if (cos_angle > M_SQRT1_2) {
-    if (sin_angle_abs) { const float s = asinf(sin_angle_abs) / sin_angle_abs; for (int i = 0; i < 3; ++i) rot[i] *= s; }
-  } else if (cos_angle > -M_SQRT1_2) {
-    const float s = acosf(cos_angle) / sin_angle_abs; for (int i = 0; i < 3; ++i) rot[i] *= s;
-  } else {
-    const float angle = (float)M_PI - asinf(sin_angle_abs);
-    const float d0 = R[0] - cos_angle, d1 = R[4] - cos_angle, d2 = R[8] - cos_angle;
-    float r2[3];
-    if (fabsf(d0) > fabsf(d1) && fabsf(d0) > fabsf(d2)) {
-      r2[0] = d0; r2[1] = (R[1 + 3 * 0] + R[0 + 3 * 1]) * 0.5f; r2[2] = (R[0 + 3 * 2] + R[2 + 3 * 0]) * 0.5f;
-    } else if (fabsf(d1) > fabsf(d2)) {
-      r2[0] = (R[1 + 3 * 0] + R[0 + 3 * 1]) * 0.5f; r2[1] = d1; r2[2] = (R[2 + 3 * 1] + R[1 + 3 * 2]) * 0.5f;
-    } else {
-      r2[0] = (R[0 + 3 * 2] + R[2 + 3 * 0]) * 0.5f; r2[1] = (R[2 + 3 * 1] + R[1 + 3 * 2]) * 0.5f; r2[2] = d2;
-    }
-    if (dot3(r2, rot) < 0.0f) { r2[0] *= -1.0f; r2[1] *= -1.0f; r2[2] *= -1.0f; }
-    const float len = std::sqrt(dot3(r2, r2));       // normalize(): vec / length, zero vector stays zero
-    if (len == 0) { r2[0] = r2[1] = r2[2] = 0; } else { r2[0] /= len; r2[1] /= len; r2[2] /= len; }
-    for (int i = 0; i < 3; ++i) rot[i] = angle * r2[i];
-  }
-  float shtot = 0.5f;
-  const float theta = std::sqrt(dot3(rot, rot));
-  if (theta > 0.00001f) shtot = sinf(theta * 0.5f) / theta;
-  // halfrotor = ITMPose(0,0,0, -rot/2): only its rotation is used
-  float hw[3] = {rot[0] * -0.5f, rot[1] * -0.5f, rot[2] * -0.5f}, zero[3] = {0, 0, 0}, HR[9], HT[3];
-  rotation_from_params(hw, zero, HR, HT);
-  float rt[3];   // Matrix3 * Vector3: r[i] = m[i]*x + m[i+3]*y + m[i+6]*z
-  for (int i = 0; i < 3; ++i) rt[i] = HR[i] * T[0] + HR[i + 3] * T[1] + HR[i + 6] * T[2];
-  if (theta > 0.001f) {
-    const float denom = dot3(rot, rot);
-    const float param = dot3(T, rot) * (1 - 2 * shtot) / denom;
-    for (int i = 0; i < 3; ++i) rt[i] -= rot[i] * param;
-  } else {
-    const float param = dot3(T, rot) / 24;
-    for (int i = 0; i < 3; ++i) rt[i] -= rot[i] * param;
-  }
-  for (int i = 0; i < 3; ++i) rt[i] /= 2 * shtot;
-  for (int i = 0; i < 3; ++i) { p.r[i] = rot[i]; p.t[i] = rt[i]; }
-}
-
-// ORUtils::Cholesky + Backsub
-void cholesky_solve(const float* mat, int n, const float* v, float* result) {
-  std::vector<float> ch(mat, mat + n * n);
-  for (int c = 0; c < n; ++c) {
-    float inv_diag = 1;
-    for (int r = c; r < n; ++r) {
-      float val = ch[c + r * n];
-      for (int c2 = 0; c2 < c; ++c2) val -= ch[c + c2 * n] * ch[c2 + r * n];
-      if (r == c) { ch[c + r * n] = val; inv_diag = 1.0f / val; }
-      else { ch[r + c * n] = val; ch[c + r * n] = val * inv_diag; }
-    }
-  }
-  std::vector<float> y(n);
-  for (int i = 0; i < n; ++i) { float val = v[i]; for (int j = 0; j < i; ++j) val -= ch[j + i * n] * y[j]; y[i] = val; }
-  for (int i = 0; i < n; ++i) y[i] /= ch[i + i * n];
-  for (int i = n - 1; i >= 0; --i) { float val = y[i]; for (int j = i + 1; j < n; ++j) val -= ch[i + j * n] * result[j]; result[i] = val; }
-}
-
-}  // namespace hostpose
 
 }  // namespace itm
 
@@ -377,111 +342,51 @@ int itm_filter_subsample_with_holes(const float* in, int w_in, int h_in, float* 
 int itm_tracker_compute_g_and_h(const float* depth, int w, int h, const float viewIntr[4], const float* pointsMap, const float* normalsMap,
                                 int sceneW, int sceneH, const float sceneIntr[4], const float approxInvPose[16], const float scenePose[16],
                                 float distThresh, int iterationType, itm_tracker_gh* out, itm_stream stream) {
-  if (!depth || !viewIntr || !pointsMap || !normalsMap || !sceneIntr || !approxInvPose || !scenePose || !out || w <= 0 || h <= 0)
-    return set_error(ITM_ERR_INVALID, "bad argument");
-  return compute_g_and_h(depth, w, h, viewIntr, pointsMap, normalsMap, sceneW, sceneH, sceneIntr, approxInvPose, scenePose, distThresh,
-                         iterationType, out, as_stream(stream));
+  return itm_tracker_g_and_h(thread_tracker(), depth, w, h, viewIntr, pointsMap, normalsMap, sceneW, sceneH, sceneIntr, approxInvPose, scenePose,
+                             distThresh, iterationType, out, stream);
 }
 
 int itm_track_camera(const itm_tracker_config* cfg, const itm_view* view, const float* pointsMap, const float* normalsMap,
                      const float scenePose[16], float M_d_out[16], itm_stream stream) {
-  using namespace hostpose;
-  if (!cfg || !view || !view->depth || !pointsMap || !normalsMap || !scenePose || !M_d_out) return set_error(ITM_ERR_INVALID, "null argument");
-  const int L = cfg->noHierarchyLevels;
-  if (L < 1 || L > 8) return set_error(ITM_ERR_INVALID, "noHierarchyLevels must be 1..8");
-  hipStream_t st = as_stream(stream);
-  int rc = ensure_scratch(1);
-  if (rc) return rc;
-  // ---- depth pyramid (PrepareForEvaluation): level i = FilterSubsampleWithHoles(level i-1), intrinsics * 0.5
-  std::vector<const float*> depthL(L); std::vector<int> wL(L), hL(L); std::vector<float> intrL(4 * L);
-  depthL[0] = view->depth; wL[0] = view->w; hL[0] = view->h;
-  for (int k = 0; k < 4; ++k) intrL[k] = view->intr_d[k];
-  if ((int)g_scratch.pyramid.size() < L) { g_scratch.pyramid.resize(L, nullptr); g_scratch.pyramidBytes.resize(L, 0); }
-  for (int i = 1; i < L; ++i) {
-    wL[i] = wL[i - 1] / 2; hL[i] = hL[i - 1] / 2;
-    if (wL[i] < 1 || hL[i] < 1) return set_error(ITM_ERR_INVALID, "image too small for the hierarchy");
-    const size_t bytes = (size_t)wL[i] * hL[i] * 4;
-    if (g_scratch.pyramidBytes[i] < bytes) {
-      (void)hipFree(g_scratch.pyramid[i]); g_scratch.pyramid[i] = nullptr;
-      ITM_HIP(hipMalloc((void**)&g_scratch.pyramid[i], bytes));
-      g_scratch.pyramidBytes[i] = bytes;
-    }
-    subsample_holes_kernel<<<dim3((wL[i] + 15) / 16, (hL[i] + 15) / 16), 256, 0, st>>>(depthL[i - 1], wL[i - 1], g_scratch.pyramid[i], wL[i], hL[i]);
-    depthL[i] = g_scratch.pyramid[i];
-    for (int k = 0; k < 4; ++k) intrL[4 * i + k] = intrL[4 * (i - 1) + k] * 0.5f;
-  }
-  ITM_LAUNCH_CHECK();
-  // distance thresholds and iteration counts per level (ITMDepthTracker ctor, :18-33)
-  std::vector<float> distT(L); std::vector<int> iters(L);
-  iters[0] = 2; for (int i = 1; i < L; ++i) iters[i] = iters[i - 1] + 2;
-  const float stepT = cfg->distThresh / L;
-  distT[L - 1] = cfg->distThresh;
-  for (int i = L - 2; i >= 0; --i) distT[i] = distT[i + 1] - stepT;
+  return itm_tracker_track_camera(thread_tracker(), cfg, view, pointsMap, normalsMap, scenePose, M_d_out, stream);
+}
 
-  Pose pose;
-  memcpy(pose.M, view->M_d, 64);
-  params_from_model_view(pose);                 // ITMPose::SetM keeps M and refreshes the parameters
-  float hessian_good[36], nabla_good[6], A[36], step[6];
-  memset(hessian_good, 0, sizeof hessian_good); memset(nabla_good, 0, sizeof nabla_good);
-  for (int levelId = L - 1; levelId >= cfg->noICPRunTillLevel; --levelId) {
-    const int it = cfg->trackingRegime[levelId];
-    if (it == ITM_TRACKER_ITERATION_NONE) continue;
-    float approxInv[16];
-    invert4(pose.M, approxInv);
-    Pose lastGood = pose;
-    float f_old = 1e20f, lambda = 1.0f;
-    const bool shortIt = it != ITM_TRACKER_ITERATION_BOTH;
-    for (int iterNo = 0; iterNo < iters[levelId]; ++iterNo) {
-      itm_tracker_gh gh;
-      rc = compute_g_and_h(depthL[levelId], wL[levelId], hL[levelId], &intrL[4 * levelId], pointsMap, normalsMap, view->w, view->h,
-                           &intrL[0], approxInv, scenePose, distT[levelId], it, &gh, st);
-      if (rc) return rc;
-      if ((gh.noValidPoints <= 0) || (gh.f > f_old)) {
-        pose = lastGood;
-        invert4(pose.M, approxInv);
-        lambda *= 10.0f;
-      } else {
-        lastGood = pose;
-        f_old = gh.f;
-        for (int i = 0; i < 36; ++i) hessian_good[i] = gh.hessian[i] / gh.noValidPoints;
-        for (int i = 0; i < 6; ++i) nabla_good[i] = gh.nabla[i] / gh.noValidPoints;
-        lambda /= 10.0f;
-      }
-      for (int i = 0; i < 36; ++i) A[i] = hessian_good[i];
-      for (int i = 0; i < 6; ++i) A[i + i * 6] *= 1.0f + lambda;
-      for (int i = 0; i < 6; ++i) step[i] = 0;
-      if (shortIt) {
-        float small[9];
-        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) small[r + c * 3] = A[r + c * 6];
-        cholesky_solve(small, 3, nabla_good, step);
-      } else {
-        cholesky_solve(A, 6, nabla_good, step);
-      }
-      // ApplyDelta: para_new = Tinc * para_old
-      float s6[6] = {0, 0, 0, 0, 0, 0};
-      if (it == ITM_TRACKER_ITERATION_ROTATION) { s6[0] = step[0]; s6[1] = step[1]; s6[2] = step[2]; }
-      else if (it == ITM_TRACKER_ITERATION_TRANSLATION) { s6[3] = step[0]; s6[4] = step[1]; s6[5] = step[2]; }
-      else { for (int i = 0; i < 6; ++i) s6[i] = step[i]; }
-      float Tinc[16];   // m[4*col + row]
-      Tinc[0] = 1.0f;    Tinc[4] = s6[2];   Tinc[8] = -s6[1];  Tinc[12] = s6[3];
-      Tinc[1] = -s6[2];  Tinc[5] = 1.0f;    Tinc[9] = s6[0];   Tinc[13] = s6[4];
-      Tinc[2] = s6[1];   Tinc[6] = -s6[0];  Tinc[10] = 1.0f;   Tinc[14] = s6[5];
-      Tinc[3] = 0.0f;    Tinc[7] = 0.0f;    Tinc[11] = 0.0f;   Tinc[15] = 1.0f;
-      float newInv[16];
-      matmul4(Tinc, approxInv, newInv);
-      // SetInvM + Coerce + GetInvM
-      invert4(newInv, pose.M);
-      params_from_model_view(pose);
-      params_from_model_view(pose);
-      model_view_from_params(pose);
-      invert4(pose.M, approxInv);
-      float len = 0.0f;
-      for (int i = 0; i < 6; ++i) len += step[i] * step[i];
-      if (std::sqrt(len) / 6 < cfg->terminationThreshold) break;
-    }
-  }
-  memcpy(M_d_out, pose.M, 64);
+int itm_debug_icp_track(const itm_tracker_config* cfg, const float M_d[16], itm_icp_evaluate_fn evaluate, void* user, float M_d_out[16]) {
+  if (!cfg || !M_d || !evaluate || !M_d_out) return set_error(ITM_ERR_INVALID, "null argument");
+  if (cfg->noHierarchyLevels < 1 || cfg->noHierarchyLevels > 8) return set_error(ITM_ERR_INVALID, "noHierarchyLevels must be 1..8");
+  return icp_track(cfg, M_d, M_d_out, [&](int level, int mode, const float invPose[16], float distThresh, itm_tracker_gh* e) {
+    return evaluate(user, level, mode, invPose, distThresh, e);
+  });
+}
+
+int itm_tracker_create(itm_tracker** out) {
+  if (!out) return set_error(ITM_ERR_INVALID, "null argument");
+  *out = new (std::nothrow) itm_tracker();
+  return *out ? ITM_OK : set_error(ITM_ERR_DEVICE, "out of host memory");
+}
+
+int itm_tracker_destroy(itm_tracker* t) {
+  if (!t) return ITM_OK;
+  tracker_release(t);
+  delete t;
   return ITM_OK;
+}
+
+int itm_tracker_g_and_h(itm_tracker* t, const float* depth, int w, int h, const float viewIntr[4], const float* pointsMap, const float* normalsMap,
+                        int sceneW, int sceneH, const float sceneIntr[4], const float approxInvPose[16], const float scenePose[16],
+                        float distThresh, int iterationType, itm_tracker_gh* out, itm_stream stream) {
+  if (!t || !depth || !viewIntr || !pointsMap || !normalsMap || !sceneIntr || !approxInvPose || !scenePose || !out || w <= 0 || h <= 0)
+    return set_error(ITM_ERR_INVALID, "bad argument");
+  std::lock_guard<std::mutex> lock(t->mu);
+  return compute_g_and_h(t, depth, w, h, viewIntr, pointsMap, normalsMap, sceneW, sceneH, sceneIntr, approxInvPose, scenePose, distThresh,
+                         iterationType, out, as_stream(stream));
+}
+
+int itm_tracker_track_camera(itm_tracker* t, const itm_tracker_config* cfg, const itm_view* view, const float* pointsMap, const float* normalsMap,
+                             const float scenePose[16], float M_d_out[16], itm_stream stream) {
+  if (!t || !cfg || !view || !view->depth || !pointsMap || !normalsMap || !scenePose || !M_d_out) return set_error(ITM_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lock(t->mu);
+  return track_camera(t, cfg, view, pointsMap, normalsMap, scenePose, M_d_out, as_stream(stream));
 }
 
 }  // extern "C"

@@ -188,7 +188,7 @@ int launch_expected_depths(const itm_scene* s, const float* M, const float* intr
 // ray casting
 // ---------------------------------------------------------------------------------------------
 // One workgroup = 16x16 pixels; wave w covers rows 4w..4w+3 (16x4 pixels, two 8x8 range cells).
-template <class VX, bool DENSE, bool DIR>
+template <class VX, bool DENSE>
 __global__ void __launch_bounds__(256) raycast_kernel(VolumeView vol, const float2* __restrict__ range, float4* __restrict__ out, RayParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // (An XCD-affine order -- image band b ray-cast by XCD b, with integration placing the blocks of band b on XCD b --
@@ -200,8 +200,7 @@ __global__ void __launch_bounds__(256) raycast_kernel(VolumeView vol, const floa
   const int y = ty * 16 + wave * 4 + (lane >> 4);
   if (x >= p.W || y >= p.H) return;
   const float2 mm = range[(x >> 3) + (y >> 3) * p.W];  // floor(x/8) + floor(y/8)*W  (_CPU.cpp:174)
-  if constexpr (DIR) out[x + y * p.W] = cast_ray_dir<VX>(x, y, vol, p, mm);
-  else out[x + y * p.W] = cast_ray<VX, DENSE>(x, y, vol, p, mm);
+  out[x + y * p.W] = cast_ray<VX, DENSE>(x, y, vol, p, mm);
 }
 
 int launch_raycast(const itm_scene* s, const float* invM, const float* intr, itm_render_state* rs, float4* dst, hipStream_t st) {
@@ -212,9 +211,8 @@ int launch_raycast(const itm_scene* s, const float* invM, const float* intr, itm
   KernelTimer tk(s, ITM_TK_RAYCAST, st);
   int rc = dispatch_voxel(s->cfg.voxelType, [&](auto vx) {
     using VX = decltype(vx);
-    if (dense) raycast_kernel<VX, true, false><<<grid, 256, 0, st>>>(vol, rs->range, dst, p);
-    else if (vol.dirPtr) raycast_kernel<VX, false, true><<<grid, 256, 0, st>>>(vol, rs->range, dst, p);
-    else raycast_kernel<VX, false, false><<<grid, 256, 0, st>>>(vol, rs->range, dst, p);
+    if (dense) raycast_kernel<VX, true><<<grid, 256, 0, st>>>(vol, rs->range, dst, p);
+    else raycast_kernel<VX, false><<<grid, 256, 0, st>>>(vol, rs->range, dst, p);
     return ITM_OK;
   });
   if (rc) return rc;

@@ -52,4 +52,6 @@ def test_hip_view_builder_against_reference_vectors(hip):
 def test_hip_tracker_against_reference_vectors(hip):
     assert np.array_equal(tt.subsample(hip, tt.holes_image()), G["trk_subsample"])
     ses, v, nxt = tt.build_maps_vga(hip)
-    assert np.abs(tt.track(hip, ses, v, nxt) - G["trk_pose"]).max() < 2e-5
+    # reference pose of the on-axis scene: 2e-5 everywhere except the roll about the optical axis, which this scene leaves
+    # unobservable (tests/test_tracker.py explains and tests the constrained configuration at 2e-5)
+    tt.assert_pose_close(tt.track(hip, ses, v, nxt), G["trk_pose"], roll_tol=2e-4)

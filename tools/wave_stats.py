@@ -36,9 +36,9 @@ np.save(os.path.join(ROOT, "gpurun_out", "wave_trace.npy"), tr)
 tot, outer = st[:, 0].astype(float), st[:, 1].astype(float)
 if st[:, 2].any():   # directory march: extra columns
     order = np.argsort(-tot)
-    lab = ["cycles", "outer", "inner", "steps", "run_cyc", "mem_cyc", "tri_cyc"]
-    print("slowest 8 waves  ", lab); print(st[order[:8], :7].astype(np.int64))
-    print("median 8 waves   "); print(st[order[len(order) // 2: len(order) // 2 + 8], :7].astype(np.int64))
-    print("means            ", st[:, :7].astype(float).mean(axis=0).round(0))
+    lab = ["cycles", "outer", "inner", "steps", "run_cyc", "mem_cyc", "tri_cyc", "runs"]
+    print("slowest 8 waves  ", lab); print(st[order[:8], :8].astype(np.int64))
+    print("median 8 waves   "); print(st[order[len(order) // 2: len(order) // 2 + 8], :8].astype(np.int64))
+    print("means            ", st[:, :8].astype(float).mean(axis=0).round(0))
 print("wave cycles: mean %.0f p50 %.0f p90 %.0f max %.0f; outer iterations: mean %.1f max %.0f" % (
     tot.mean(), *np.percentile(tot, [50, 90]), tot.max(), outer.mean(), outer.max()))
