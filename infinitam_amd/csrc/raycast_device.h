@@ -67,8 +67,8 @@ __device__ inline long long locate_voxel(const VolumeView& vol, int px, int py, 
     if (qx < 0 || qx >= vol.sx || qy < 0 || qy >= vol.sy || qz < 0 || qz >= vol.sz) return -1;
     return (long long)(qx + qy * vol.sx + qz * vol.sx * vol.sy);
   } else {
-    const int bx = floor_div8(px), by = floor_div8(py), bz = floor_div8(pz);
-    const int lin = (px - bx * 8) + (py - by * 8) * 8 + (pz - bz * 8) * 64;
+    const int bx = px >> 3, by = py >> 3, bz = pz >> 3;                       // floor(p / 8): arithmetic shift
+    const int lin = (px & 7) + ((py & 7) << 3) + ((pz & 7) << 6);             // (p - 8 b) per axis
     if (bx == cache.bx && by == cache.by && bz == cache.bz) return (long long)cache.base + lin;
     {
       // covered by the block directory: one load instead of the table walk (same answer: the directory holds exactly
@@ -334,10 +334,22 @@ __device__ inline float4 cast_ray_plain(int x, int y, const VolumeView& vol, con
 // 69 us, 2: 65, 3: 64, 4: 62, 8: 66, unbounded: 95 (lanes then serialise each other's empty-space runs).
 // The other restructurings that were tried and dropped are listed with their numbers in DESIGN.md section 5.
 #ifndef ITM_RAY_PREDICT_STEP
-// A step of at most this many voxels is expected to land inside the truncation band: the lane then skips the single-voxel
-// read and goes straight to the 2x2x2 fetch, which serves the nearest-neighbour read AND the trilinear read of that
-// position (0 disables the prediction).  A wrong guess only costs the wait for the expensive phase.
-#define ITM_RAY_PREDICT_STEP 2.0f
+// Measurement option, OFF (0): a step of at most this many voxels is expected to land inside the truncation band; the lane then
+// skips the single-voxel read and goes straight to the 2x2x2 fetch, which serves the nearest-neighbour read AND the trilinear
+// read of that position.  Measured: 1.5 / 2 / 3 / 5 voxels -> 75 / 76 / 81 / 109 us against 66 us without: sixteen scattered
+// loads per lane cost more issue time than the phase they save.
+#define ITM_RAY_PREDICT_STEP 0.0f
+#endif
+#ifndef ITM_RAY_MISS_LOOKAHEAD
+// Measurement option, OFF: after a "block not found" step (hash index with the block directory) the directory cells of the next
+// K positions of the ray -- computed with the reference's own additions, pt += 8 dir -- are fetched together and the ray advances
+// over as many of them as are empty (a silhouette ray walks ~45 such steps from the sphere to the wall, each a dependent round
+// trip of ~1 000 cycles).  It shortens the slow waves (p90 of the per-wave cycles 89 k -> 65 k) but the kernel gets slower,
+// gated or not: K = 3 / 6 / 10 / 16 -> 64 / 69 / 77 / 92 us against 61 us without (in-frame, MI355X, config 2).
+#define ITM_RAY_MISS_LOOKAHEAD 0
+#endif
+#ifndef ITM_RAY_MISS_STREAK
+#define ITM_RAY_MISS_STREAK 3   // the look-ahead only starts after this many consecutive "not found" steps of the lane
 #endif
 template <class VX, bool DENSE>
 __device__ inline float4 cast_ray(int x, int y, const VolumeView& vol, const RayParams& p, float2 mm) {
@@ -355,6 +367,9 @@ __device__ inline float4 cast_ray(int x, int y, const VolumeView& vol, const Ray
   bool found;
   float w = 0.0f;
   int st = (total < totalMax) ? MARCH : DONE;
+#if ITM_RAY_MISS_LOOKAHEAD > 0
+  int missStreak = 0;
+#endif
   // one forward step of the march loop for a value that is not in the band (or a trilinear value): returns the next state
   auto advance = [&](bool fnd, float sdf) -> int {
     float step;
@@ -381,6 +396,37 @@ __device__ inline float4 cast_ray(int x, int y, const VolumeView& vol, const Ray
       const float sdf = sdf_nearest<VX, DENSE>(vol, px, py, pz, found, cache);
       if (found && (sdf <= 0.1f) && (sdf >= -0.5f)) st = TRI;      // the position is kept for the trilinear read
       else st = advance(found, sdf);
+#if ITM_RAY_MISS_LOOKAHEAD > 0
+      if constexpr (!DENSE) {
+        missStreak = found ? 0 : missStreak + 1;
+        if (vol.dirPtr && __any(missStreak >= ITM_RAY_MISS_STREAK && st == MARCH)) {
+          // directory cells of the positions q0 = pt, q1 = pt + 8 dir, ... (cell 0 / no use for lanes that are not in an empty run)
+          const bool runner = missStreak >= ITM_RAY_MISS_STREAK && st == MARCH;
+          const float sx = (float)kBlockSide * dx, sy = (float)kBlockSide * dy, sz = (float)kBlockSide * dz;   // exact products
+          int ahead[ITM_RAY_MISS_LOOKAHEAD];
+          {
+            float qx = px, qy = py, qz = pz;
+#pragma unroll
+            for (int j = 0; j < ITM_RAY_MISS_LOOKAHEAD; ++j) {
+              const uint32_t ux = (uint32_t)(((int)round_ref(qx) >> 3) + kDirHalf), uy = (uint32_t)(((int)round_ref(qy) >> 3) + kDirHalf),
+                             uz = (uint32_t)(((int)round_ref(qz) >> 3) + kDirHalf);
+              const bool use = runner && dir_covers(ux, uy, uz);
+              const int v = vol.dirPtr[use ? dir_cell(ux, uy, uz) : 0u];
+              ahead[j] = use ? v : 0;                               // 0 = "cannot tell / a block": stops the run
+              qx += sx; qy += sy; qz += sz;
+            }
+          }
+          if (runner) {
+#pragma unroll
+            for (int j = 0; j < ITM_RAY_MISS_LOOKAHEAD; ++j) {
+              if (ahead[j] >= 0) break;                             // q_j holds a block (or lies outside the directory): regular read next
+              px += sx; py += sy; pz += sz; total += (float)kBlockSide;   // the reference's step for a position without a block
+              if (!(total < totalMax)) { st = DONE; break; }
+            }
+          }
+        }
+      }
+#endif
     }
     ITM_WT(const unsigned long long wtA = wt_clock(); const unsigned wtTriLanes = __popcll(__ballot(st == TRI || st == REFINE || st == PRE)); wtInner = (unsigned)wt_wave_max(wtInner);)
     // ---- expensive phase: one 2x2x2 fetch for every lane that waits for one ---------------------------------------------
