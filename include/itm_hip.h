@@ -124,7 +124,7 @@ typedef struct itm_counters {
   int32_t noTotalPoints;
   int32_t noRenderingBlocks;   /* numRenderingBlocks of the last CreateExpectedDepths */
   int32_t noAllocRequests;     /* blocks requested by the last AllocateSceneFromDepth */
-  int32_t statusFlags;         /* bit0: alloc key overflow (too many ray steps)       */
+  int32_t statusFlags;         /* bit0: alloc key overflow (too many ray steps); bit1: one-pass visible list gave up waiting */
 } itm_counters;
 
 /* buffers addressable by itm_download / itm_upload (parity dumps, checkpoints) */
@@ -167,6 +167,8 @@ int ITM_FN(set_device)(int device);
 #define ITM_DEBUG_INTEGRATE_WORKGROUPS 3      /* tuning: persistent workgroups of the hash integration (0 = default) */
 #define ITM_DEBUG_NO_FUSED_PROJECTION 4       /* process_frame: keep integration and projection as two launches */
 #define ITM_DEBUG_NO_DIRECTORY 5              /* ray casting / free-view reads walk the hash table instead of the block directory */
+#define ITM_DEBUG_NO_FUSED_RANGE_REDUCE 6     /* process_frame: reduce the partial range images in their own launch, not in the ray cast */
+#define ITM_DEBUG_TWO_PASS_VISIBLE_LIST 7     /* AllocateSceneFromDepth: visible list by a count launch and a compaction launch */
 int ITM_FN(debug_set)(int key, int value);
 /* out[i] = SDF_valueToFloat(in[i]) of the short voxel types, i.e. in[i] / 32767.0f, through the same
  * device routine the kernels use (a 3-instruction correctly rounded division; test hook). */

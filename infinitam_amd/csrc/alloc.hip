@@ -30,6 +30,7 @@
 namespace itm {
 
 int g_debug_explicit_mark = 0;   // test hook: always run the explicit mark-previous launch
+int g_debug_two_pass_visible_list = 0;   // test hook: count and compact as two launches
 
 struct AllocParams {
   Mat4 invM;     // inverse of M_d (host, ORUtils cofactor scheme)
@@ -91,7 +92,7 @@ __global__ void __launch_bounds__(256) request_kernel(const float* __restrict__ 
   // touches carry bit 7; visible_count_kernel then reads every other non-zero type as "3".
   constexpr uint8_t kTouched = LAZY ? 0x80 : 0x00;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (FUSE_RANGE_INIT && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) rcnt->noRenderingBlocks = 0;
+  if (FUSE_RANGE_INIT && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { rcnt->noRenderingBlocks = 0; rcnt->renderingBlocksAccepted = -1; }
   const int x = blockIdx.x * 16 + (lane & 15);
   const int y = blockIdx.y * 16 + wave * 4 + (lane >> 4);
   if (x >= p.W || y >= p.H) return;
@@ -335,6 +336,90 @@ __global__ void __launch_bounds__(256) visible_compact_kernel(const uint8_t* __r
   }
 }
 
+// Passes 1 and 2 in ONE launch (AllocateSceneFromDepth): every workgroup counts its chunk as visible_count_kernel does, publishes
+// the count as an 8-byte {count, epoch} granule with a single device-scope store, then reads the granules of the chunks before
+// it (device-scope loads, polling until the epoch matches) for its base and compacts from the types it still holds in
+// registers.  A granule is one naturally aligned 8-byte store, so value and tag arrive together and no fence is needed; only
+// counts cross workgroups, the types and ids a workgroup writes are read by later launches.  All chunks' workgroups are
+// resident at once (numChunks * 4 waves << the chip's wave slots), and a workgroup only waits for lower-numbered ones; the poll
+// is bounded all the same and raises statusFlags bit 1 instead of hanging.
+template <bool COMMIT_ALLOC, bool LAZY>
+__global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__ visT, const uint4* __restrict__ hash,
+                                                           unsigned long long* __restrict__ chunkGran, uint32_t epoch,
+                                                           const int2* __restrict__ chunkReq, int numChunks, SceneCounters* __restrict__ counters,
+                                                           int32_t* __restrict__ ids, int capIds, RenderCounters* __restrict__ rc, AllocParams p) {
+  __shared__ int lds[12];
+  const int chunk = blockIdx.x, tid = threadIdx.x;
+  const int slot0 = chunk * kSweepChunk + tid * kSlotsPerThread;
+  int n = 0;
+  uint32_t w[2] = {0u, 0u};
+  if (slot0 < p.noTotalEntries) {  // noTotalEntries is a multiple of 8 (checked on the host)
+    const uint2 raw = *(const uint2*)(visT + slot0);
+    w[0] = raw.x; w[1] = raw.y;
+    if (raw.x | raw.y) {
+      bool changed = false;
+#pragma unroll
+      for (int k = 0; k < kSlotsPerThread; ++k) {
+        uint32_t t = (w[k >> 2] >> ((k & 3) * 8)) & 0xffu;
+        const uint32_t t0 = t;
+        if (LAZY && (t & 0x80u)) {
+          t &= 0x7fu;                         // touched this frame: type 1 / 2
+        } else if (LAZY ? (t != 0u) : (t == 3u)) {
+          // visible in the previous frame and not seen again: keep only if still in the frustum
+          HashEntry he = unpack_entry(hash[slot0 + k]);
+          t = block_in_frustum(he.px, he.py, he.pz, p.M, p.fx, p.fy, p.cx, p.cy, p.voxelSize, p.W, p.H) ? 3u : 0u;
+        }
+        if (t != t0) { w[k >> 2] = (w[k >> 2] & ~(0xffu << ((k & 3) * 8))) | (t << ((k & 3) * 8)); changed = true; }
+        n += (t > 0u);
+      }
+      if (changed) *(uint2*)(visT + slot0) = make_uint2(w[0], w[1]);
+    }
+  }
+  int mine;
+  const int pos0 = block_exclusive_scan<4>(n, lds, &mine);
+  if (tid == 0)
+    __hip_atomic_store(&chunkGran[chunk], ((unsigned long long)epoch << 32) | (unsigned long long)(uint32_t)mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (COMMIT_ALLOC && chunk == 0) {
+    int a = 0, b = 0;
+    for (int j = tid; j < numChunks; j += 256) { int2 c = chunkReq[j]; a += c.x; b += c.y; }
+    a = block_reduce_sum<4>(a, lds + 4);
+    b = block_reduce_sum<4>(b, lds + 8);
+    if (tid == 0) {
+      counters->lastFreeBlockId -= a;
+      counters->lastFreeExcessListId -= b;
+      counters->noAllocRequests = a;
+    }
+  }
+  // base = visible slots in all earlier chunks
+  int before = 0;
+  bool stuck = false;
+  for (int j = tid; j < chunk; j += 256) {
+    unsigned long long g = __hip_atomic_load(&chunkGran[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int spin = 0; (uint32_t)(g >> 32) != epoch; ++spin) {
+      if (spin > (1 << 22)) { stuck = true; break; }
+      __builtin_amdgcn_s_sleep(1);
+      g = __hip_atomic_load(&chunkGran[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    before += (int)(uint32_t)g;
+  }
+  if (stuck) atomicOr(&counters->statusFlags, 2);
+  const int base = block_reduce_sum<4>(before, lds + 4);
+  if (chunk == numChunks - 1 && tid == 0) {
+    const int total = base + mine;
+    rc->rawVisibleCount = total;
+    rc->noVisibleEntries = total < capIds ? total : capIds;
+  }
+  if (n == 0) return;
+  int pos = base + pos0;
+#pragma unroll
+  for (int k = 0; k < kSlotsPerThread; ++k) {
+    if (((w[k >> 2] >> ((k & 3) * 8)) & 0xffu) != 0u) {
+      if (pos < capIds) ids[pos] = slot0 + k;
+      ++pos;
+    }
+  }
+}
+
 // FindVisibleBlocks pass 1: flag every allocated slot whose block passes the frustum test.
 __global__ void __launch_bounds__(256) freeview_flag_kernel(const uint4* __restrict__ hash, uint8_t* __restrict__ flags,
                                                             int32_t* __restrict__ chunkVis, AllocParams p) {
@@ -424,11 +509,19 @@ int launch_sweep_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, bo
     s->frameParity++;
   }
   KernelTimer tv(s, ITM_TK_VISIBLE_LIST, st);
+  if (!g_debug_two_pass_visible_list) {
+    const uint32_t epoch = ++s->listEpoch;
+#define ITM_VL(CM, LZ) visible_list_kernel<CM, LZ><<<nChunks, 256, 0, st>>>(rs->visibleType, s->hash, s->chunkGran, epoch, reqCur, nChunks, s->counters, rs->visibleIds, rs->capIds, rs->counters, p)
+    if (onlyVisible) { if (lazy) ITM_VL(false, true); else ITM_VL(false, false); }
+    else { if (lazy) ITM_VL(true, true); else ITM_VL(true, false); }
+#undef ITM_VL
+  } else {
 #define ITM_CNT(CM, LZ) visible_count_kernel<CM, LZ><<<nChunks, 256, 0, st>>>(rs->visibleType, s->hash, s->chunkVis, reqCur, nChunks, s->counters, p)
-  if (onlyVisible) { if (lazy) ITM_CNT(false, true); else ITM_CNT(false, false); }
-  else { if (lazy) ITM_CNT(true, true); else ITM_CNT(true, false); }
+    if (onlyVisible) { if (lazy) ITM_CNT(false, true); else ITM_CNT(false, false); }
+    else { if (lazy) ITM_CNT(true, true); else ITM_CNT(true, false); }
 #undef ITM_CNT
-  visible_compact_kernel<<<nChunks, 256, 0, st>>>(rs->visibleType, s->chunkVis, nChunks, s->noTotalEntries, rs->visibleIds, rs->capIds, rs->counters);
+    visible_compact_kernel<<<nChunks, 256, 0, st>>>(rs->visibleType, s->chunkVis, nChunks, s->noTotalEntries, rs->visibleIds, rs->capIds, rs->counters);
+  }
   ITM_LAUNCH_CHECK();
   rs->listCoherent = true;   // list == non-zero visible types again
   return ITM_OK;

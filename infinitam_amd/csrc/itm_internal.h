@@ -25,7 +25,8 @@ struct RenderCounters {
   int32_t noTotalPoints;           // ITMPointCloud::noTotalPoints
   int32_t noRenderingBlocks;       // numRenderingBlocks of CreateExpectedDepths
   int32_t rawVisibleCount;         // visible slots before clamping to the list capacity
-  int32_t pad[3];
+  int32_t renderingBlocksAccepted; // -1, or the count after the cap replay when noRenderingBlocks reached MAX_RENDERING_BLOCKS
+  int32_t pad[2];
 };
 
 // hipEvent pairs around selected kernels (itm_profile_enable / itm_profile_read)
@@ -62,7 +63,9 @@ struct itm_scene {
   // per-slot winner key of this frame's block requests, zero between frames
   uint32_t* allocKey = nullptr;   // uint32[noTotalEntries]
   int32_t* chunkReq = nullptr;    // int2[2][numChunks]: (requests, excess requests) per sweep chunk, double-buffered
-  int32_t* chunkVis = nullptr;    // int[numChunks]: visible slots per sweep chunk
+  int32_t* chunkVis = nullptr;    // int[numChunks]: visible slots per sweep chunk (two-pass path, FindVisibleBlocks)
+  unsigned long long* chunkGran = nullptr;  // u64[numChunks]: {epoch, visible count} granules of the one-pass visible list
+  uint32_t listEpoch = 0;
   // occupancy bitmap of the ordered part of the table: bit b set <=> hash[b].ptr >= 0.  A clear bit
   // proves that no block hashing to bucket b is allocated (excess entries hang off occupied heads),
   // which lets the ray caster skip empty space without touching the 16-byte entries.
@@ -146,6 +149,7 @@ inline int dispatch_voxel(int voxelType, F&& f) {
 
 // entry points implemented per translation unit
 extern int g_debug_explicit_mark;
+extern int g_debug_two_pass_visible_list;
 extern int g_debug_integrate_wgs;
 extern int g_debug_no_fused_projection;
 int rebuild_head_bits(itm_scene* s, hipStream_t st);   // occupancy bitmap AND block directory, from the table
@@ -157,8 +161,8 @@ int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipS
 bool can_fuse_projection(const itm_scene* s, const itm_render_state* rs);
 int launch_find_visible(const itm_scene* s, const float* M, const float* intr, itm_render_state* rs, hipStream_t st);
 int launch_expected_depths(const itm_scene* s, const float* M, const float* intr, itm_render_state* rs, bool rangeAlreadyInit, hipStream_t st, bool projected = false);
-int launch_raycast(const itm_scene* s, const float* invM, const float* intr, itm_render_state* rs, float4* dst, hipStream_t st);
-int launch_icp_maps(const itm_scene* s, const itm_view* v, itm_render_state* rs, float4* points, float4* normals, hipStream_t st);
+int launch_raycast(const itm_scene* s, const float* invM, const float* intr, itm_render_state* rs, float4* dst, hipStream_t st, bool reduceRange = false);
+int launch_icp_maps(const itm_scene* s, const itm_view* v, itm_render_state* rs, float4* points, float4* normals, hipStream_t st, bool reduceRange = false);
 int launch_render_image(const itm_scene* s, const float* M, const float* intr, itm_render_state* rs, uchar4* out, int type, hipStream_t st);
 int launch_forward_render(const itm_scene* s, const itm_view* v, itm_render_state* rs, hipStream_t st);
 int launch_point_cloud(const itm_scene* s, const itm_view* v, itm_render_state* rs, bool skip, float4* loc, float4* col, hipStream_t st);

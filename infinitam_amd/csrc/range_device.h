@@ -83,7 +83,7 @@ __device__ inline void range_replay_capped(int tid, int nthreads, uint2* cells, 
       if (count + n >= p.maxBlocks) b.w = 0u; else { b.w = 1u; count += n; }
       projBuf[2 * e + 1] = b;
     }
-    rc->noRenderingBlocks = count;
+    rc->renderingBlocksAccepted = count;
   }
   __threadfence();
   __syncthreads();

@@ -240,7 +240,7 @@ static void free_scene(itm_scene* s) {
   if (!s) return;
   if (s->prof) { s->prof->flush(); for (hipEvent_t e : s->prof->pool) (void)hipEventDestroy(e); delete s->prof; }
   (void)hipFree(s->hash); (void)hipFree(s->excessList); (void)hipFree(s->vba); (void)hipFree(s->allocList);
-  (void)hipFree(s->counters); (void)hipFree(s->headBits); (void)hipFree(s->allocKey); (void)hipFree(s->chunkReq); (void)hipFree(s->chunkVis);
+  (void)hipFree(s->counters); (void)hipFree(s->headBits); (void)hipFree(s->allocKey); (void)hipFree(s->chunkReq); (void)hipFree(s->chunkVis); (void)hipFree(s->chunkGran);
   (void)hipFree(s->dirPtr);
   delete s;
 }
@@ -330,6 +330,7 @@ int itm_scene_create(const itm_scene_config* cfg_in, const itm_scene_params* prm
     alloc((void**)&s->headBits, (size_t)(cfg.bucketNum + 31) / 32 * 4);
     alloc((void**)&s->chunkReq, (size_t)s->numChunks * 2 * 2 * 4);
     alloc((void**)&s->chunkVis, (size_t)s->numChunks * 4);
+    alloc((void**)&s->chunkGran, (size_t)s->numChunks * 8);
     alloc((void**)&s->dirPtr, kDirCells * 4);
   } else {
     s->numVoxels = (size_t)cfg.denseSize[0] * cfg.denseSize[1] * cfg.denseSize[2];
@@ -343,6 +344,7 @@ int itm_scene_create(const itm_scene_config* cfg_in, const itm_scene_params* prm
   if (e == hipSuccess && s->headBits) e = hipMemset(s->headBits, 0, (size_t)(cfg.bucketNum + 31) / 32 * 4);
   if (e == hipSuccess && s->hash) e = hipMemset(s->hash, 0, (size_t)s->noTotalEntries * 16);
   if (e == hipSuccess && s->chunkReq) e = hipMemset(s->chunkReq, 0, (size_t)s->numChunks * 16);
+  if (e == hipSuccess && s->chunkGran) e = hipMemset(s->chunkGran, 0, (size_t)s->numChunks * 8);
   if (e == hipSuccess && s->dirPtr) e = hipMemset(s->dirPtr, 0xff, kDirCells * 4);
   if (e != hipSuccess) { free_scene(s); return hip_fail(e, "hipMemset(scene)", __FILE__, __LINE__); }
   *out = s;
@@ -487,7 +489,7 @@ int itm_get_counters(const itm_scene* s, const itm_render_state* rs, itm_counter
   out->noVisibleEntries = rc.noVisibleEntries;
   out->noFwdProjMissingPoints = rc.noFwdProjMissingPoints;
   out->noTotalPoints = rc.noTotalPoints;
-  out->noRenderingBlocks = rc.noRenderingBlocks;
+  out->noRenderingBlocks = (rc.renderingBlocksAccepted >= 0) ? rc.renderingBlocksAccepted : rc.noRenderingBlocks;
   return ITM_OK;
 }
 

@@ -35,6 +35,7 @@ namespace itm {
 
 int g_debug_force_global_range = 0;
 int g_debug_no_directory = 0;
+int g_debug_no_fused_range_reduce = 0;
 
 // ---------------------------------------------------------------------------------------------
 // expected depth range
@@ -42,7 +43,7 @@ int g_debug_no_directory = 0;
 __global__ void __launch_bounds__(256) range_init_kernel(float2* __restrict__ img, int n, float a, float b, RenderCounters* rc) {
   const int stride = gridDim.x * blockDim.x;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) img[i] = make_float2(a, b);
-  if (blockIdx.x == 0 && threadIdx.x == 0) rc->noRenderingBlocks = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { rc->noRenderingBlocks = 0; rc->renderingBlocksAccepted = -1; }
 }
 
 __device__ inline void merge_box(float2* __restrict__ range, int W, const Projected& r) {
@@ -91,7 +92,7 @@ __global__ void __launch_bounds__(256) range_overflow_kernel(RenderCounters* __r
       if (count + need >= p.maxBlocks) { b.w = 0u; } else { b.w = 1u; count += need; }
       projBuf[2 * e + 1] = b;
     }
-    rc->noRenderingBlocks = count;
+    rc->renderingBlocksAccepted = count;
   }
   __threadfence();
   __syncthreads();
@@ -188,8 +189,85 @@ int launch_expected_depths(const itm_scene* s, const float* M, const float* intr
 // ray casting
 // ---------------------------------------------------------------------------------------------
 // One workgroup = 16x16 pixels; wave w covers rows 4w..4w+3 (16x4 pixels, two 8x8 range cells).
-template <class VX, bool DENSE>
-__global__ void __launch_bounds__(256) raycast_kernel(VolumeView vol, const float2* __restrict__ range, float4* __restrict__ out, RayParams p) {
+//
+// REDUCE (itm_process_frame on hash scenes): the workgroup first reduces the kRangeParts partial range images of ITS 2x2 cells
+// (the second half of CreateExpectedDepths, otherwise range_reduce_kernel), stores them to the range image and casts its rays
+// from the LDS copy -- one launch and one 1.2 MB round trip through memory less per frame.  When the rendering-block cap of
+// the reference was reached (noRenderingBlocks >= MAX_RENDERING_BLOCKS, i.e. > 262 144 tiles: never with real data, but defined
+// behaviour) every workgroup replays the sequential accept / skip decisions over the visible list itself; slow, exact.
+struct RangeFuse {
+  const uint2* partials;      // [kRangeParts][RW * RH]
+  RenderCounters* rc;
+  const uint4* projBuf;       // per visible entry: box, z range, tile count
+  float2* range;              // range image (row stride W)
+  int RW, RH, maxBlocks;
+};
+
+__device__ inline void reduce_own_cells(const RangeFuse& f, int tx, int ty, int W, float2* cellRange) {
+  const int tid = threadIdx.x;
+  const int nCells = f.RW * f.RH;
+  const int total = f.rc->noRenderingBlocks;
+  if (total < f.maxBlocks) {
+    // 4 cells x kRangeParts partials: one load per lane of waves 0 and 1 (kRangeParts == 32), min / max over each 32-lane half
+    if (tid < 4 * kRangeParts) {
+      const int c = tid / kRangeParts, part = tid % kRangeParts;
+      const int cx = tx * 2 + (c & 1), cy = ty * 2 + (c >> 1);
+      const bool inside = cx < f.RW && cy < f.RH;
+      uint2 v = make_uint2(0xffffffffu, 0u);
+      if (inside) v = f.partials[(size_t)part * nCells + cx + cy * f.RW];
+#pragma unroll
+      for (int o = kRangeParts / 2; o > 0; o >>= 1) {
+        const uint32_t lo = __shfl_xor(v.x, o, 64), hi = __shfl_xor(v.y, o, 64);
+        v.x = lo < v.x ? lo : v.x; v.y = hi > v.y ? hi : v.y;
+      }
+      if (part == 0) {
+        const float2 r = make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+        cellRange[c] = r;
+        if (inside) f.range[cx + cy * W] = r;
+      }
+    }
+    return;
+  }
+  // ---- cap reached: sequential replay by wave 0, 64 entries per round ----
+  __shared__ uint32_t capCells[8];   // (min bits, max bits) x 4 cells
+  if (tid < 4) { capCells[2 * tid] = __float_as_uint(999999.9f); capCells[2 * tid + 1] = __float_as_uint(0.05f); }
+  __syncthreads();
+  if (tid < 64) {
+    const int nv = f.rc->noVisibleEntries;
+    int count = 0;
+    for (int base = 0; base < nv; base += 64) {
+      const int e = base + tid;
+      uint4 box = make_uint4(0, 0, 0, 0), zr = make_uint4(0, 0, 0, 0);
+      if (e < nv) { box = f.projBuf[2 * e]; zr = f.projBuf[2 * e + 1]; }
+      const int need = (int)zr.z;
+      unsigned long long accept = 0ull;
+      for (int l = 0; l < 64; ++l) {                        // the reference's loop, one entry at a time (uniform control flow)
+        const int n = __shfl(need, l, 64);
+        if (n != 0 && count + n < f.maxBlocks) { count += n; accept |= 1ull << l; }
+      }
+      if ((accept >> tid) & 1ull) {
+        for (int c = 0; c < 4; ++c) {
+          const int cx = tx * 2 + (c & 1), cy = ty * 2 + (c >> 1);
+          if (cx >= (int)box.x && cx <= (int)box.z && cy >= (int)box.y && cy <= (int)box.w) {
+            atomicMin(&capCells[2 * c], zr.x);
+            atomicMax(&capCells[2 * c + 1], zr.y);
+          }
+        }
+      }
+    }
+    if (blockIdx.x == 0 && tid == 0) f.rc->renderingBlocksAccepted = count;
+  }
+  __syncthreads();
+  if (tid < 4) {
+    const int cx = tx * 2 + (tid & 1), cy = ty * 2 + (tid >> 1);
+    const float2 r = make_float2(__uint_as_float(capCells[2 * tid]), __uint_as_float(capCells[2 * tid + 1]));
+    cellRange[tid] = r;
+    if (cx < f.RW && cy < f.RH) f.range[cx + cy * W] = r;
+  }
+}
+
+template <class VX, bool DENSE, bool REDUCE>
+__global__ void __launch_bounds__(256) raycast_kernel(VolumeView vol, const float2* __restrict__ range, float4* __restrict__ out, RayParams p, RangeFuse fuse) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // (An XCD-affine order -- image band b ray-cast by XCD b, with integration placing the blocks of band b on XCD b --
   // recovers 5 of the ~17 us the rays lose to voxel lines written on other XCDs, but costs integration 10 us; and 8x8
@@ -198,21 +276,32 @@ __global__ void __launch_bounds__(256) raycast_kernel(VolumeView vol, const floa
   const int tx = blockIdx.x % tilesX, ty = blockIdx.x / tilesX;
   const int x = tx * 16 + (lane & 15);
   const int y = ty * 16 + wave * 4 + (lane >> 4);
-  if (x >= p.W || y >= p.H) return;
-  const float2 mm = range[(x >> 3) + (y >> 3) * p.W];  // floor(x/8) + floor(y/8)*W  (_CPU.cpp:174)
+  float2 mm;
+  if constexpr (REDUCE) {
+    __shared__ float2 cellRange[4];
+    reduce_own_cells(fuse, tx, ty, p.W, cellRange);
+    __syncthreads();
+    if (x >= p.W || y >= p.H) return;
+    mm = cellRange[((lane & 15) >> 3) + 2 * (wave >> 1)];
+  } else {
+    if (x >= p.W || y >= p.H) return;
+    mm = range[(x >> 3) + (y >> 3) * p.W];  // floor(x/8) + floor(y/8)*W  (_CPU.cpp:174)
+  }
   out[x + y * p.W] = cast_ray<VX, DENSE>(x, y, vol, p, mm);
 }
 
-int launch_raycast(const itm_scene* s, const float* invM, const float* intr, itm_render_state* rs, float4* dst, hipStream_t st) {
+int launch_raycast(const itm_scene* s, const float* invM, const float* intr, itm_render_state* rs, float4* dst, hipStream_t st, bool reduceRange) {
   RayParams p; make_ray_params(s, invM, intr, rs->w, rs->h, p);
   const VolumeView vol = make_volume(s);
   const dim3 grid(((rs->w + 15) / 16) * ((rs->h + 15) / 16));
   const bool dense = s->cfg.indexType == ITM_INDEX_DENSE;
+  RangeFuse fuse{rs->rangePartials, rs->counters, rs->projBuf, rs->range, (rs->w + 7) / 8, (rs->h + 7) / 8, s->cfg.maxRenderingBlocks};
   KernelTimer tk(s, ITM_TK_RAYCAST, st);
   int rc = dispatch_voxel(s->cfg.voxelType, [&](auto vx) {
     using VX = decltype(vx);
-    if (dense) raycast_kernel<VX, true><<<grid, 256, 0, st>>>(vol, rs->range, dst, p);
-    else raycast_kernel<VX, false><<<grid, 256, 0, st>>>(vol, rs->range, dst, p);
+    if (dense) raycast_kernel<VX, true, false><<<grid, 256, 0, st>>>(vol, rs->range, dst, p, fuse);
+    else if (reduceRange) raycast_kernel<VX, false, true><<<grid, 256, 0, st>>>(vol, rs->range, dst, p, fuse);
+    else raycast_kernel<VX, false, false><<<grid, 256, 0, st>>>(vol, rs->range, dst, p, fuse);
     return ITM_OK;
   });
   if (rc) return rc;
@@ -253,10 +342,10 @@ __global__ void __launch_bounds__(256) icp_maps_kernel(const float4* __restrict_
   }
 }
 
-int launch_icp_maps(const itm_scene* s, const itm_view* v, itm_render_state* rs, float4* points, float4* normals, hipStream_t st) {
+int launch_icp_maps(const itm_scene* s, const itm_view* v, itm_render_state* rs, float4* points, float4* normals, hipStream_t st, bool reduceRange) {
   float invM[16];
   if (!invert4(v->M_d, invM)) return set_error(ITM_ERR_INVALID, "pose matrix is singular");
-  int rc = launch_raycast(s, invM, v->intr_d, rs, rs->raycast, st);
+  int rc = launch_raycast(s, invM, v->intr_d, rs, rs->raycast, st, reduceRange);
   if (rc) return rc;
   RayParams p; make_ray_params(s, invM, v->intr_d, rs->w, rs->h, p);
   const dim3 grid((rs->w + 15) / 16, (rs->h + 15) / 16);
@@ -330,6 +419,8 @@ int itm_debug_set(int key, int value) {
   if (key == ITM_DEBUG_INTEGRATE_WORKGROUPS) { g_debug_integrate_wgs = value; return ITM_OK; }
   if (key == ITM_DEBUG_NO_FUSED_PROJECTION) { g_debug_no_fused_projection = value; return ITM_OK; }
   if (key == ITM_DEBUG_NO_DIRECTORY) { g_debug_no_directory = value; return ITM_OK; }
+  if (key == ITM_DEBUG_NO_FUSED_RANGE_REDUCE) { g_debug_no_fused_range_reduce = value; return ITM_OK; }
+  if (key == ITM_DEBUG_TWO_PASS_VISIBLE_LIST) { g_debug_two_pass_visible_list = value; return ITM_OK; }
   return set_error(ITM_ERR_INVALID, "unknown debug key");
 }
 
@@ -374,8 +465,11 @@ int itm_process_frame(itm_scene* s, const itm_view* v, itm_render_state* rs, flo
   if (hashScene && (rc = launch_allocate(s, v, rs, false, true, st))) return rc;
   const bool fuse = hashScene && can_fuse_projection(s, rs);
   if ((rc = launch_integrate(s, v, rs, st, fuse))) return rc;
-  if ((rc = launch_expected_depths(s, v->M_d, v->intr_d, rs, hashScene, st, fuse))) return rc;
-  return launch_icp_maps(s, v, rs, (float4*)points, (float4*)normals, st);
+  // with the projection done inside the integration launch, the ray-cast workgroups reduce the partial range images of their
+  // own cells (raycast_kernel<.., REDUCE>); otherwise CreateExpectedDepths runs as its own launches
+  const bool reduceInRaycast = fuse && !g_debug_no_fused_range_reduce;
+  if (!reduceInRaycast && (rc = launch_expected_depths(s, v->M_d, v->intr_d, rs, hashScene, st, fuse))) return rc;
+  return launch_icp_maps(s, v, rs, (float4*)points, (float4*)normals, st, reduceInRaycast);
 }
 
 }  // extern "C"

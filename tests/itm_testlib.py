@@ -239,6 +239,8 @@ def compare_results(a: RunResult, b: RunResult, sc: Scenario, exact=True, what="
     Stated tolerances for the float maps when exact=False: raycast xyz 1e-3 voxel, points 1e-5 m,
     normals 1e-4, grey +-1."""
     tag = f"[{what or sc.name}] "
+    for c in list(a.counters) + list(b.counters):
+        assert (c.get("statusFlags", 0) & 2) == 0, tag + "the one-pass visible list gave up waiting for a predecessor (statusFlags bit 1)"
     for ca, cb in zip(a.counters, b.counters):
         for key in ("lastFreeBlockId", "lastFreeExcessListId", "noVisibleEntries", "noRenderingBlocks"):
             if key == "noRenderingBlocks" and (ca[key] == 0 or cb[key] == 0):

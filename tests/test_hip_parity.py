@@ -57,11 +57,24 @@ def test_engine_calls_match_oracle(hip, oracle, sc):
     T.compare_results(a, b, sc)
 
 
-@pytest.mark.parametrize("sc", [SCENARIOS[0], SCENARIOS[2], SCENARIOS[7]], ids=lambda s: s.name)
+@pytest.mark.parametrize("sc", [SCENARIOS[0], SCENARIOS[2], SCENARIOS[7], SCENARIOS[-1]], ids=lambda s: s.name)
 def test_fused_process_frame_matches_oracle(hip, oracle, sc):
+    """itm_process_frame: projection inside the integration launch, range reduction inside the ray-cast launch (the last
+    scenario reaches the rendering-block cap, so every ray-cast workgroup replays the accept / skip sequence itself)."""
     a = T.run_scenario(hip, sc, fused=True)
     b = T.run_scenario(oracle, sc)
     T.compare_results(a, b, sc, what=sc.name + "/fused")
+
+
+@pytest.mark.parametrize("sc", [SCENARIOS[2], SCENARIOS[-1]], ids=lambda s: s.name)
+def test_fused_frame_with_separate_range_reduction(hip, oracle, sc):
+    """ITM_DEBUG_NO_FUSED_RANGE_REDUCE (6): the reduction of the partial range images as its own launch."""
+    hip.check(hip.fn["debug_set"](6, 1), "debug_set")
+    try:
+        a = T.run_scenario(hip, sc, fused=True)
+    finally:
+        hip.check(hip.fn["debug_set"](6, 0), "debug_set")
+    T.compare_results(a, T.run_scenario(oracle, sc), sc, what=sc.name + "/fused, separate reduce")
 
 
 @pytest.mark.parametrize("sc", [SCENARIOS[0], SCENARIOS[-1]], ids=lambda s: s.name)
@@ -109,6 +122,19 @@ def test_fused_and_separate_calls_interleave(hip, oracle):
     x.counters = [ses.scene.counters(ses.rs)]
     y.counters = [ref.scene.counters(ref.rs)]
     T.compare_results(x, y, sc, what="interleaved")
+
+
+@pytest.mark.parametrize("sc", [SCENARIOS[3], SCENARIOS[10]], ids=lambda s: s.name)
+def test_two_pass_visible_list_path(hip, oracle, sc):
+    """AllocateSceneFromDepth builds the visible list in one launch (counts handed between workgroups as 8-byte granules);
+    ITM_DEBUG_TWO_PASS_VISIBLE_LIST (7) selects the count + compaction launches that FindVisibleBlocks still uses."""
+    hip.check(hip.fn["debug_set"](7, 1), "debug_set")
+    try:
+        a = T.run_scenario(hip, sc, fused=True)
+    finally:
+        hip.check(hip.fn["debug_set"](7, 0), "debug_set")
+    T.compare_results(a, T.run_scenario(oracle, sc), sc, what=sc.name + "/two-pass visible list")
+    assert a.counters[-1]["statusFlags"] == 0
 
 
 def test_explicit_mark_previous_path(hip, oracle):

@@ -21,6 +21,9 @@ from infinitam_amd import capi, synth  # noqa: E402
 
 def run(cfg: int, frames: int):
     be = capi.Backend(os.environ['ITM_LIB'], 'itm_') if os.environ.get('ITM_LIB') else itm.load()
+    for key in os.environ.get('ITM_DEBUG_KEYS', '').split(','):      # e.g. ITM_DEBUG_KEYS=4,6 -> debug_set(4,1), debug_set(6,1)
+        if key.strip():
+            be.check(be.fn['debug_set'](int(key), 1), 'debug_set')
     if os.environ.get('ITM_NO_DIRECTORY'):
         be.check(be.fn['debug_set'](5, 1), 'debug_set')   # A/B: ray cast through the table walk instead of the block directory
     if cfg == 3:
