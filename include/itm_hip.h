@@ -389,6 +389,28 @@ int ITM_FN(upload)(itm_scene* scene, itm_render_state* rs, int which, const void
  * the same configuration and continuing gives bit-identical results to the uninterrupted run.  `dir` must exist. */
 int ITM_FN(scene_save)(const itm_scene* scene, const itm_render_state* rs, const char* dir, itm_stream stream);
 int ITM_FN(scene_load)(itm_scene* scene, itm_render_state* rs, const char* dir, itm_stream stream);
+/* ---- scene export: marching-cubes mesh ----------------------------------------------------------------
+ * ITMMesh (Objects/ITMMesh.h:14-124): a triangle buffer of noMaxTriangles = SDF_LOCAL_BLOCK_NUM * 32 entries {p0, p1, p2} (nine
+ * floats, metres) in device memory; max_triangles == 0 selects that default for the scene's pool size.
+ * ITMMeshingEngine::MeshScene(mesh, scene) (Engine/ITMMeshingEngine.h:19-26, CPU: DeviceSpecific/CPU/ITMMeshingEngine_CPU.cpp:
+ * 19-58): clears the buffer, then appends the triangles of every cell of every allocated block in table-slot order, voxels in
+ * z, y, x order -- the same ORDER as the reference, and the same behaviour when the buffer is full (count stops at
+ * noMaxTriangles - 1, the last slot holds the last triangle generated).  Dense scenes produce no triangles, as in the
+ * reference (:70-72). */
+typedef struct itm_mesh itm_mesh;
+int ITM_FN(mesh_create)(const itm_scene* scene, uint32_t max_triangles, itm_mesh** out);
+int ITM_FN(mesh_destroy)(itm_mesh* mesh);
+int ITM_FN(mesh_scene)(const itm_scene* scene, itm_mesh* mesh, itm_stream stream);
+/* mesh->noTotalTriangles / noMaxTriangles / the triangle buffer; synchronises `stream`.  Any output pointer may be NULL. */
+int ITM_FN(mesh_info)(const itm_mesh* mesh, uint32_t* noTotalTriangles, uint32_t* noMaxTriangles,
+                      const float** triangles, itm_stream stream);
+/* copies min(noTotalTriangles, capacity) triangles (9 floats each) to host memory; synchronises `stream` */
+int ITM_FN(mesh_download)(const itm_mesh* mesh, float* dst_host, uint32_t capacityTriangles,
+                          uint32_t* noTotalTriangles, itm_stream stream);
+/* ITMMesh::WriteOBJ (Objects/ITMMesh.h:34-62) and ITMMesh::WriteSTL (:64-110), byte-identical files */
+int ITM_FN(mesh_write_obj)(const itm_mesh* mesh, const char* path, itm_stream stream);
+int ITM_FN(mesh_write_stl)(const itm_mesh* mesh, const char* path, itm_stream stream);
+
 /* Device address of a buffer (zero-copy hand-off to e.g. a collective); NULL if absent. */
 void* ITM_FN(buffer_ptr)(const itm_scene* scene, const itm_render_state* rs, int which);
 

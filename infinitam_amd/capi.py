@@ -189,6 +189,13 @@ _SIGS = {
     "profile_enable": (C.c_int, [_P, C.c_uint32]),
     "profile_read": (C.c_int, [_P, C.POINTER(Profile), C.c_int]),
     "export_visible_record": (C.c_int, [_P, C.POINTER(C.c_float), C.c_int, _P, _P]),
+    "mesh_create": (C.c_int, [_P, C.c_uint32, C.POINTER(_P)]),
+    "mesh_destroy": (C.c_int, [_P]),
+    "mesh_scene": (C.c_int, [_P, _P, _P]),
+    "mesh_info": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(_P), _P]),
+    "mesh_download": (C.c_int, [_P, _P, C.c_uint32, C.POINTER(C.c_uint32), _P]),
+    "mesh_write_obj": (C.c_int, [_P, C.c_char_p, _P]),
+    "mesh_write_stl": (C.c_int, [_P, C.c_char_p, _P]),
 }
 
 
@@ -441,6 +448,49 @@ class Scene:
     def close(self):
         if self.h:
             self.be.fn["scene_destroy"](_P(self.h))
+            self.h = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Mesh:
+    """ITMMesh + ITMMeshingEngine::MeshScene (Objects/ITMMesh.h, Engine/ITMMeshingEngine.h)."""
+
+    def __init__(self, scene: "Scene", max_triangles: int = 0):
+        self.scene = scene
+        p = _P()
+        scene.be.check(scene.be.fn["mesh_create"](_P(scene.h), max_triangles, C.byref(p)), "mesh_create")
+        self.h = p.value
+
+    def MeshScene(self, stream=None):
+        self.scene.be.check(self.scene.be.fn["mesh_scene"](_P(self.scene.h), _P(self.h), _P(stream)), "mesh_scene")
+
+    def info(self, stream=None):
+        n, cap = C.c_uint32(), C.c_uint32()
+        self.scene.be.check(self.scene.be.fn["mesh_info"](_P(self.h), C.byref(n), C.byref(cap), None, _P(stream)), "mesh_info")
+        return n.value, cap.value
+
+    def triangles(self, stream=None) -> np.ndarray:
+        """(noTotalTriangles, 3, 3) float32: p0, p1, p2 per triangle."""
+        n, _ = self.info(stream)
+        out = np.zeros((n, 3, 3), np.float32)
+        got = C.c_uint32()
+        self.scene.be.check(self.scene.be.fn["mesh_download"](_P(self.h), out.ctypes.data_as(_P), n, C.byref(got), _P(stream)), "mesh_download")
+        return out
+
+    def WriteOBJ(self, path: str, stream=None):
+        self.scene.be.check(self.scene.be.fn["mesh_write_obj"](_P(self.h), path.encode(), _P(stream)), "mesh_write_obj")
+
+    def WriteSTL(self, path: str, stream=None):
+        self.scene.be.check(self.scene.be.fn["mesh_write_stl"](_P(self.h), path.encode(), _P(stream)), "mesh_write_stl")
+
+    def close(self):
+        if self.h:
+            self.scene.be.fn["mesh_destroy"](_P(self.h))
             self.h = 0
 
     def __del__(self):

@@ -229,10 +229,6 @@ __global__ void __launch_bounds__(256) allocate_sweep_kernel(uint32_t* __restric
   }
 }
 
-__global__ void __launch_bounds__(256) clear_keys_kernel(uint32_t* allocKey, int n) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) allocKey[i] = 0u;
-}
-
 // checkBlockVisibility<false>: corners are reached by incremental +-f updates in a fixed order.
 __device__ inline bool corner_in_image(const Mat4& M, float fx, float fy, float cx, float cy, int W, int H, float x, float y, float z) {
   Vec3 q = transform_point(M, x, y, z);
@@ -533,17 +529,26 @@ int launch_allocate(itm_scene* s, const itm_view* v, itm_render_state* rs, bool 
   return launch_sweep_stage(s, v, rs, onlyVisible, st);
 }
 
+// ordered compaction of the slots flagged in `flags` (one byte per slot, chunk counts from the flagging pass) into ascending ids
+int launch_ordered_compaction(const uint8_t* flags, const int32_t* chunkCount, int nChunks, int nEntries, int32_t* ids, int cap, RenderCounters* rc, hipStream_t st) {
+  visible_compact_kernel<<<nChunks, 256, 0, st>>>(flags, chunkCount, nChunks, nEntries, ids, cap, rc);
+  ITM_LAUNCH_CHECK();
+  return ITM_OK;
+}
+
 int launch_find_visible(const itm_scene* s, const float* M, const float* intr, itm_render_state* rs, hipStream_t st) {
   AllocParams p;
   int rc = fill_params(s, M, intr, rs->w, rs->h, rs->capIds, p);
   if (rc) return rc;
   const int nChunks = s->numChunks;
-  // flags live in the allocation-key scratch (4 bytes per slot available, 1 used); it is zero
-  // between frames and is re-zeroed below.
-  uint8_t* flags = (uint8_t*)s->allocKey;
-  freeview_flag_kernel<<<nChunks, 256, 0, st>>>(s->hash, flags, s->chunkVis, p);
-  visible_compact_kernel<<<nChunks, 256, 0, st>>>(flags, s->chunkVis, nChunks, s->noTotalEntries, rs->visibleIds, rs->capIds, rs->counters);
-  clear_keys_kernel<<<512, 256, 0, st>>>(s->allocKey, (s->noTotalEntries + 3) / 4);
+  // The flags and per-chunk counts of a free-view query live in the RENDER STATE (allocated on first use): the scene is const
+  // here and a free-view render on another stream must not touch the allocation scratch a frame may be using.
+  if (!rs->viewFlags) {
+    ITM_HIP(hipMalloc((void**)&rs->viewFlags, (size_t)nChunks * kSweepChunk));
+    ITM_HIP(hipMalloc((void**)&rs->viewChunkVis, (size_t)nChunks * 4));
+  }
+  freeview_flag_kernel<<<nChunks, 256, 0, st>>>(s->hash, rs->viewFlags, rs->viewChunkVis, p);
+  visible_compact_kernel<<<nChunks, 256, 0, st>>>(rs->viewFlags, rs->viewChunkVis, nChunks, s->noTotalEntries, rs->visibleIds, rs->capIds, rs->counters);
   ITM_LAUNCH_CHECK();
   rs->listCoherent = false;   // the list no longer mirrors entriesVisibleType
   return ITM_OK;

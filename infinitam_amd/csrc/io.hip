@@ -158,13 +158,18 @@ int itm_read_rgbd_calib(const char* path, itm_rgbd_calib* out) {
 
 // ---- scene checkpoint ------------------------------------------------------------------------------------------
 
+// One memory block per file in the layout of ORUtils/MemoryBlockPersister.h:17-130: int32 element count, raw elements.
+// Written to "<file>.tmp" and renamed, so an interrupted save never leaves a half-written block under the final name.
 static int save_block(const std::string& file, const void* data, size_t bytes, size_t elemBytes) {
-  FILE* f = fopen(file.c_str(), "wb");
-  if (!f) return fail("cannot create " + file);
+  const std::string tmp = file + ".tmp";
+  FILE* f = fopen(tmp.c_str(), "wb");
+  if (!f) return fail("cannot create " + tmp);
   const int32_t count = (int32_t)(bytes / elemBytes);
   bool ok = fwrite(&count, 4, 1, f) == 1 && (bytes == 0 || fwrite(data, 1, bytes, f) == bytes);
-  fclose(f);
-  return ok ? ITM_OK : fail("short write to " + file);
+  ok = (fclose(f) == 0) && ok;
+  if (!ok) { remove(tmp.c_str()); return fail("short write to " + tmp); }
+  if (rename(tmp.c_str(), file.c_str()) != 0) { remove(tmp.c_str()); return fail("cannot rename " + tmp); }
+  return ITM_OK;
 }
 static int load_block(const std::string& file, void* data, size_t bytes, size_t elemBytes) {
   FILE* f = fopen(file.c_str(), "rb");
@@ -173,6 +178,7 @@ static int load_block(const std::string& file, void* data, size_t bytes, size_t 
   bool ok = fread(&count, 4, 1, f) == 1;
   if (ok && (size_t)count != bytes / elemBytes) { fclose(f); return fail("memory block of the wrong size in " + file); }
   ok = ok && (bytes == 0 || fread(data, 1, bytes, f) == bytes);
+  if (ok && fgetc(f) != EOF) { fclose(f); return fail("trailing bytes in " + file); }
   fclose(f);
   return ok ? ITM_OK : fail("truncated " + file);
 }
@@ -193,6 +199,8 @@ int itm_scene_save(const itm_scene* s, const itm_render_state* rs, const char* d
   const std::string d = std::string(dir) + "/";
   std::vector<BlockFile> blocks; checkpoint_blocks(s, blocks);
   std::vector<char> host;
+  // config.dat goes last: a directory without it is not a complete checkpoint
+  remove((d + "config.dat").c_str());
   for (const BlockFile& b : blocks) {
     if (b.render && !rs) continue;
     const size_t bytes = itm_buffer_bytes(s, rs, b.which);
@@ -210,6 +218,9 @@ int itm_scene_save(const itm_scene* s, const itm_render_state* rs, const char* d
   return save_block(d + "config.dat", cfg, sizeof cfg, 1);
 }
 
+// Everything is read into host memory and validated BEFORE the first byte reaches the scene: a truncated, mismatched or
+// corrupt checkpoint leaves the scene exactly as it was.  Checked: the configuration AND the scene parameters, every block's
+// element count, the counters against the pool sizes, every table entry / list element / visible id against its range.
 int itm_scene_load(itm_scene* s, itm_render_state* rs, const char* dir, itm_stream stream) {
   if (!s || !dir) return fail("null argument");
   if (rs && rs->scene != s) return fail("render state belongs to another scene");
@@ -218,17 +229,42 @@ int itm_scene_load(itm_scene* s, itm_render_state* rs, const char* dir, itm_stre
   int rc = load_block(d + "config.dat", cfg, sizeof cfg, 1);
   if (rc) return rc;
   if (memcmp(cfg, &s->cfg, sizeof(itm_scene_config)) != 0) return fail("checkpoint was written by a scene of a different configuration");
-  std::vector<BlockFile> blocks; checkpoint_blocks(s, blocks);
-  std::vector<char> host;
-  for (const BlockFile& b : blocks) {
-    if (b.render && !rs) continue;
-    const size_t bytes = itm_buffer_bytes(s, rs, b.which);
-    host.resize(bytes);
-    if ((rc = load_block(d + b.name, host.data(), bytes, b.elemBytes))) return rc;
-    if ((rc = itm_upload(s, rs, b.which, host.data(), bytes, stream))) return rc;   // also rebuilds the occupancy bitmap for the table
-  }
+  if (memcmp(cfg + sizeof(itm_scene_config), &s->prm, sizeof(itm_scene_params)) != 0) return fail("checkpoint was written with different scene parameters (voxelSize / mu / maxW / frustum)");
   itm_counters c;
   if ((rc = load_block(d + "counters.dat", &c, sizeof c, 4))) return rc;
+  const bool hash = s->cfg.indexType == ITM_INDEX_HASH;
+  const int nBlocks = hash ? s->cfg.localBlockNum : 1;
+  if (hash) {
+    // both counters keep decrementing once their pool is exhausted (as in the reference), so only the upper end is bounded
+    if (c.lastFreeBlockId < -(1 << 30) || c.lastFreeBlockId >= nBlocks) return fail("counters.dat: lastFreeBlockId out of range");
+    if (c.lastFreeExcessListId < -(1 << 30) || c.lastFreeExcessListId >= s->cfg.excessNum) return fail("counters.dat: lastFreeExcessListId out of range");
+    if (rs && (c.noVisibleEntries < 0 || c.noVisibleEntries > rs->capIds)) return fail("counters.dat: noVisibleEntries out of range");
+  }
+  std::vector<BlockFile> blocks; checkpoint_blocks(s, blocks);
+  std::vector<std::vector<char>> host(blocks.size());
+  for (size_t i = 0; i < blocks.size(); ++i) {
+    const BlockFile& b = blocks[i];
+    if (b.render && !rs) continue;
+    host[i].resize(itm_buffer_bytes(s, rs, b.which));
+    if ((rc = load_block(d + b.name, host[i].data(), host[i].size(), b.elemBytes))) return rc;
+    const size_t n = host[i].size() / b.elemBytes;
+    if (b.which == ITM_BUF_HASH_ENTRIES) {
+      const itm::HashEntry* e = (const itm::HashEntry*)host[i].data();
+      for (size_t k = 0; k < n; ++k)
+        if (e[k].ptr >= nBlocks || e[k].offset < 0 || e[k].offset > s->cfg.excessNum) return fail("hash.dat: entry with a pointer or chain offset outside the pools");
+    } else if (b.which == ITM_BUF_EXCESS_LIST || b.which == ITM_BUF_ALLOCATION_LIST || b.which == ITM_BUF_VISIBLE_IDS) {
+      const int32_t* v = (const int32_t*)host[i].data();
+      const int32_t lim = b.which == ITM_BUF_EXCESS_LIST ? s->cfg.excessNum : (b.which == ITM_BUF_ALLOCATION_LIST ? nBlocks : s->noTotalEntries);
+      const size_t used = (b.which == ITM_BUF_VISIBLE_IDS) ? (size_t)c.noVisibleEntries : n;     // the tail of the id list is unused
+      for (size_t k = 0; k < used && k < n; ++k)
+        if (v[k] < 0 || v[k] >= lim) return fail(std::string(b.name) + ": element out of range");
+    }
+  }
+  for (size_t i = 0; i < blocks.size(); ++i) {
+    const BlockFile& b = blocks[i];
+    if (b.render && !rs) continue;
+    if ((rc = itm_upload(s, rs, b.which, host[i].data(), host[i].size(), stream))) return rc;   // also rebuilds the occupancy bitmap / directory
+  }
   return itm_set_counters(s, rs, &c, stream);
 }
 

@@ -99,6 +99,8 @@ struct itm_render_state {
   uint2* rangePartials = nullptr;  // [32][ceil(w/8)*ceil(h/8)] partial range images (LDS path)
   int32_t* pixScratch = nullptr;  // int[h*w] (forward projection winners, ordered compaction flags)
   int32_t* pixChunk = nullptr;    // int[ceil(h*w / kSweepChunk)]
+  uint8_t* viewFlags = nullptr;   // FindVisibleBlocks: per-slot flags (uchar[numChunks * kSweepChunk]), allocated on first use
+  int32_t* viewChunkVis = nullptr; // FindVisibleBlocks: visible slots per chunk
 };
 
 namespace itm {

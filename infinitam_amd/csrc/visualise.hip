@@ -169,11 +169,13 @@ int launch_expected_depths(const itm_scene* s, const float* M, const float* intr
   const size_t ldsBytes = (size_t)RW * RH * sizeof(uint2);
   const bool forceGlobal = g_debug_force_global_range != 0;  // test hook for the fallback path
   if (ldsBytes <= 150 * 1024 && !forceGlobal && rs->rangePartials) {
-    static bool attrSet = false;
-    if (!attrSet) {
+    // per device (a function attribute belongs to the code object loaded on ONE device)
+    static bool attrSet[64] = {};
+    const int dev = (s->device >= 0 && s->device < 64) ? s->device : 0;
+    if (!attrSet[dev]) {
       ITM_HIP(hipFuncSetAttribute((const void*)project_partial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
       ITM_HIP(hipFuncSetAttribute((const void*)range_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-      attrSet = true;
+      attrSet[dev] = true;
     }
     if (!projected) project_partial_kernel<<<kRangeParts, 512, ldsBytes, st>>>(rs->visibleIds, rs->counters, s->hash, rs->range, rs->projBuf, rs->rangePartials, p, RW, RH);
     range_reduce_kernel<<<(RW * RH + 255) / 256, 256, ldsBytes, st>>>(rs->counters, rs->range, rs->projBuf, rs->rangePartials, p, RW, RH);

@@ -27,6 +27,12 @@ namespace Engine {
 inline void HipCheck(int rc, const char* what) {
   if (rc != ITM_OK) throw std::runtime_error(std::string(what) + ": " + itm_last_error());
 }
+// itm_memcpy_d2h only ENQUEUES the copy (include/itm_hip.h, conventions); the reference's host code reads its images as soon
+// as an engine method returns, so every download of an adapter ends with a synchronisation of the stream it was issued on.
+inline int HipDownload(void* dst_host, const void* src_dev, size_t bytes, itm_stream stream) {
+  const int rc = itm_memcpy_d2h(dst_host, src_dev, bytes, stream);
+  return rc != ITM_OK ? rc : itm_stream_synchronize(stream);
+}
 
 template <class TVoxel> struct HipVoxelTag;
 template <> struct HipVoxelTag<ITMVoxel_s> { enum { value = ITM_VOXEL_S }; };
@@ -241,7 +247,7 @@ class ITMVisualisationEngine_HIP : public ITMVisualisationEngine<TVoxel, TIndex>
     const int t = type == IITMVisualisationEngine::RENDER_COLOUR_FROM_VOLUME ? ITM_RENDER_COLOUR_FROM_VOLUME
                   : type == IITMVisualisationEngine::RENDER_COLOUR_FROM_NORMAL ? ITM_RENDER_COLOUR_FROM_NORMAL : ITM_RENDER_SHADED_GREYSCALE;
     int rc = itm_render_image(Dev(), pose->GetM().m, &intrinsics->projectionParamsSimple.all.x, HipRenderStateOf(renderState), (uint8_t*)out, t, 0);
-    if (rc == ITM_OK) rc = itm_memcpy_d2h(outputImage->GetData(MEMORYDEVICE_CPU), out, px * 4, 0);
+    if (rc == ITM_OK) rc = HipDownload(outputImage->GetData(MEMORYDEVICE_CPU), out, px * 4, 0);
     itm_dev_free(out);
     HipCheck(rc, "RenderImage");
     MirrorImages(const_cast<ITMRenderState*>(renderState), false, true, false);
@@ -256,16 +262,16 @@ class ITMVisualisationEngine_HIP : public ITMVisualisationEngine<TVoxel, TIndex>
     HipCheck(itm_create_point_cloud(Dev(), &v, HipRenderStateOf(renderState), skipPoints ? 1 : 0, (float*)st.points, (float*)st.normals, 0), "CreatePointCloud");
     itm_counters c; HipCheck(itm_get_counters(Dev(), HipRenderStateOf(renderState), &c, 0), "get_counters");
     trackingState->pointCloud->noTotalPoints = c.noTotalPoints;
-    HipCheck(itm_memcpy_d2h(trackingState->pointCloud->locations->GetData(MEMORYDEVICE_CPU), st.points, (size_t)c.noTotalPoints * 16, 0), "memcpy_d2h");
-    HipCheck(itm_memcpy_d2h(trackingState->pointCloud->colours->GetData(MEMORYDEVICE_CPU), st.normals, (size_t)c.noTotalPoints * 16, 0), "memcpy_d2h");
+    HipCheck(HipDownload(trackingState->pointCloud->locations->GetData(MEMORYDEVICE_CPU), st.points, (size_t)c.noTotalPoints * 16, 0), "memcpy_d2h");
+    HipCheck(HipDownload(trackingState->pointCloud->colours->GetData(MEMORYDEVICE_CPU), st.normals, (size_t)c.noTotalPoints * 16, 0), "memcpy_d2h");
     trackingState->pose_pointCloud->SetFrom(trackingState->pose_d);
   }
   void CreateICPMaps(const ITMView* view, ITMTrackingState* trackingState, ITMRenderState* renderState) const {
     itm_view v = HipStageView(view, trackingState->pose_d, false);
     HipRegistry::Stage& st = HipRegistry::Get().views[view];
     HipCheck(itm_create_icp_maps(Dev(), &v, HipRenderStateOf(renderState), (float*)st.points, (float*)st.normals, 0), "CreateICPMaps");
-    HipCheck(itm_memcpy_d2h(trackingState->pointCloud->locations->GetData(MEMORYDEVICE_CPU), st.points, st.pixels * 16, 0), "memcpy_d2h");
-    HipCheck(itm_memcpy_d2h(trackingState->pointCloud->colours->GetData(MEMORYDEVICE_CPU), st.normals, st.pixels * 16, 0), "memcpy_d2h");
+    HipCheck(HipDownload(trackingState->pointCloud->locations->GetData(MEMORYDEVICE_CPU), st.points, st.pixels * 16, 0), "memcpy_d2h");
+    HipCheck(HipDownload(trackingState->pointCloud->colours->GetData(MEMORYDEVICE_CPU), st.normals, st.pixels * 16, 0), "memcpy_d2h");
     trackingState->pose_pointCloud->SetFrom(trackingState->pose_d);   // ITMVisualisationEngine_CPU.cpp CreateICPMaps
     MirrorImages(renderState, false, true, true);
   }

@@ -89,19 +89,19 @@ class ITMViewBuilder_HIP : public ITMViewBuilder {
     HipCheck(itm_memcpy_h2d(devRaw, disp_in->GetData(MEMORYDEVICE_CPU), px * 2, 0), "memcpy_h2d");
     HipCheck(itm_convert_disparity((const int16_t*)devRaw, (float*)devA, disp_in->noDims.x, disp_in->noDims.y, disparityCalibParams.x, disparityCalibParams.y,
                                    depthIntrinsics->projectionParamsSimple.fx, 0), "ConvertDisparityToDepth");
-    HipCheck(itm_memcpy_d2h(depth_out->GetData(MEMORYDEVICE_CPU), devA, px * 4, 0), "memcpy_d2h");
+    HipCheck(HipDownload(depth_out->GetData(MEMORYDEVICE_CPU), devA, px * 4, 0), "memcpy_d2h");
   }
   void ConvertDepthAffineToFloat(ITMFloatImage* depth_out, const ITMShortImage* depth_in, Vector2f depthCalibParams) {
     const size_t px = (size_t)depth_in->noDims.x * depth_in->noDims.y; Ensure(px);
     HipCheck(itm_memcpy_h2d(devRaw, depth_in->GetData(MEMORYDEVICE_CPU), px * 2, 0), "memcpy_h2d");
     HipCheck(itm_convert_depth_affine((const int16_t*)devRaw, (float*)devA, depth_in->noDims.x, depth_in->noDims.y, depthCalibParams.x, depthCalibParams.y, 0), "ConvertDepthAffineToFloat");
-    HipCheck(itm_memcpy_d2h(depth_out->GetData(MEMORYDEVICE_CPU), devA, px * 4, 0), "memcpy_d2h");
+    HipCheck(HipDownload(depth_out->GetData(MEMORYDEVICE_CPU), devA, px * 4, 0), "memcpy_d2h");
   }
   void DepthFiltering(ITMFloatImage* image_out, const ITMFloatImage* image_in) {
     const size_t px = (size_t)image_in->noDims.x * image_in->noDims.y; Ensure(px);
     HipCheck(itm_memcpy_h2d(devA, image_in->GetData(MEMORYDEVICE_CPU), px * 4, 0), "memcpy_h2d");
     HipCheck(itm_filter_depth((const float*)devA, (float*)devB, image_in->noDims.x, image_in->noDims.y, 0), "DepthFiltering");
-    HipCheck(itm_memcpy_d2h(image_out->GetData(MEMORYDEVICE_CPU), devB, px * 4, 0), "memcpy_d2h");
+    HipCheck(HipDownload(image_out->GetData(MEMORYDEVICE_CPU), devB, px * 4, 0), "memcpy_d2h");
   }
   void ComputeNormalAndWeights(ITMFloat4Image* normal_out, ITMFloatImage* sigmaZ_out, const ITMFloatImage* depth_in, Vector4f intrinsic) {
     const size_t px = (size_t)depth_in->noDims.x * depth_in->noDims.y; Ensure(px);
@@ -110,8 +110,8 @@ class ITMViewBuilder_HIP : public ITMViewBuilder {
     HipCheck(itm_memcpy_h2d(devN, normal_out->GetData(MEMORYDEVICE_CPU), px * 16, 0), "memcpy_h2d");
     HipCheck(itm_memcpy_h2d(devS, sigmaZ_out->GetData(MEMORYDEVICE_CPU), px * 4, 0), "memcpy_h2d");
     HipCheck(itm_compute_normal_and_weights((const float*)devA, (float*)devN, (float*)devS, depth_in->noDims.x, depth_in->noDims.y, &intrinsic.x, 0), "ComputeNormalAndWeights");
-    HipCheck(itm_memcpy_d2h(normal_out->GetData(MEMORYDEVICE_CPU), devN, px * 16, 0), "memcpy_d2h");
-    HipCheck(itm_memcpy_d2h(sigmaZ_out->GetData(MEMORYDEVICE_CPU), devS, px * 4, 0), "memcpy_d2h");
+    HipCheck(HipDownload(normal_out->GetData(MEMORYDEVICE_CPU), devN, px * 16, 0), "memcpy_d2h");
+    HipCheck(HipDownload(sigmaZ_out->GetData(MEMORYDEVICE_CPU), devS, px * 4, 0), "memcpy_d2h");
   }
 
   // same object management as ITMViewBuilder_CPU::UpdateView; the image work is one itm_update_view call
@@ -136,10 +136,10 @@ class ITMViewBuilder_HIP : public ITMViewBuilder {
     HipCheck(itm_update_view((const int16_t*)devRaw, w, h, dc.type == ITMDisparityCalib::TRAFO_KINECT ? 0 : 1, dc.params.x, dc.params.y,
                              &view->calib->intrinsics_d.projectionParamsSimple.all.x, useBilateralFilter ? 1 : 0, modelSensorNoise ? 1 : 0,
                              (float*)devA, (float*)devB, (float*)devN, (float*)devS, 0), "UpdateView");
-    HipCheck(itm_memcpy_d2h(view->depth->GetData(MEMORYDEVICE_CPU), devA, px * 4, 0), "memcpy_d2h");
+    HipCheck(HipDownload(view->depth->GetData(MEMORYDEVICE_CPU), devA, px * 4, 0), "memcpy_d2h");
     if (modelSensorNoise) {
-      HipCheck(itm_memcpy_d2h(view->depthNormal->GetData(MEMORYDEVICE_CPU), devN, px * 16, 0), "memcpy_d2h");
-      HipCheck(itm_memcpy_d2h(view->depthUncertainty->GetData(MEMORYDEVICE_CPU), devS, px * 4, 0), "memcpy_d2h");
+      HipCheck(HipDownload(view->depthNormal->GetData(MEMORYDEVICE_CPU), devN, px * 16, 0), "memcpy_d2h");
+      HipCheck(HipDownload(view->depthUncertainty->GetData(MEMORYDEVICE_CPU), devS, px * 4, 0), "memcpy_d2h");
     }
   }
   void UpdateView(ITMView** view_ptr, ITMUChar4Image* rgbImage, ITMFloatImage* depthImage) {

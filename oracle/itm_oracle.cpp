@@ -184,6 +184,13 @@ struct itm_render_state {
   int noVisibleEntries = 0, noFwdProjMissingPoints = 0, noTotalPoints = 0, noRenderingBlocks = 0;
 };
 
+#include "../infinitam_amd/csrc/mc_tables.h"   // marching-cubes case table: DATA generated from the reference
+struct itm_mesh {
+  const itm_scene* scene;
+  uint32_t maxTriangles, noTotalTriangles;
+  std::vector<float> tri;   // ITMMesh::Triangle: 9 floats each
+};
+
 namespace {
 
 // ------------------------------------------------------------------------------------------
@@ -1015,6 +1022,69 @@ void point_cloud_t(const itm_scene* s, const itm_view* view, itm_render_state* r
   rs->noTotalPoints = total;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// MeshScene   DeviceSpecific/CPU/ITMMeshingEngine_CPU.cpp:19-58 ; findPointNeighbors / sdfInterp / buildVertList
+// DeviceAgnostic/ITMMeshingEngine.h:153-231 ; ITMMesh Objects/ITMMesh.h.  The case table is the data file generated from the
+// reference (infinitam_amd/csrc/mc_tables.h); the sequential loop, the early exits and the full-buffer behaviour are restated.
+// ------------------------------------------------------------------------------------------
+template <class V>
+void mesh_scene_t(const itm_scene* s, itm_mesh* m) {
+  Reader<V> rd(s);
+  const float factor = s->prm.voxelSize;
+  std::fill(m->tri.begin(), m->tri.end(), 0.0f);
+  uint32_t n = 0;
+  static const int off[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}, {0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}};
+  static const int edgeEnds[12][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {4, 5}, {5, 6}, {6, 7}, {7, 4}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
+  for (int entry = 0; entry < s->noTotalEntries; ++entry) {
+    const HashEntry& he = s->hash[entry];
+    if (he.ptr < 0) continue;
+    const int gx = he.px * 8, gy = he.py * 8, gz = he.pz * 8;
+    for (int z = 0; z < 8; ++z) for (int y = 0; y < 8; ++y) for (int x = 0; x < 8; ++x) {
+      float p[8][3], v[8];
+      bool ok = true;
+      for (int k = 0; k < 8 && ok; ++k) {
+        const int qx = gx + x + off[k][0], qy = gy + y + off[k][1], qz = gz + z + off[k][2];
+        bool found;
+        const V vox = rd.read(qx, qy, qz, found);
+        p[k][0] = (float)qx; p[k][1] = (float)qy; p[k][2] = (float)qz;
+        v[k] = Codec<V>::toF((float)vox.sdf);
+        if (!found || v[k] == 1.0f) ok = false;
+      }
+      if (!ok) continue;
+      int cube = 0;
+      for (int k = 0; k < 8; ++k) if (v[k] < 0) cube |= 1 << k;
+      int edges = 0;
+      for (int e = 0; e < 12; ++e) if (((cube >> edgeEnds[e][0]) ^ (cube >> edgeEnds[e][1])) & 1) edges |= 1 << e;
+      if (edges == 0) continue;
+      float vert[12][3];
+      for (int e = 0; e < 12; ++e) {
+        if (!(edges & (1 << e))) continue;
+        const float* p1 = p[edgeEnds[e][0]]; const float* p2 = p[edgeEnds[e][1]];
+        const float v1 = v[edgeEnds[e][0]], v2 = v[edgeEnds[e][1]];
+        const float* pick = nullptr;
+        if (std::fabs(0.0f - v1) < 0.00001f) pick = p1;
+        else if (std::fabs(0.0f - v2) < 0.00001f) pick = p2;
+        else if (std::fabs(v1 - v2) < 0.00001f) pick = p1;
+        if (pick) { vert[e][0] = pick[0]; vert[e][1] = pick[1]; vert[e][2] = pick[2]; }
+        else {
+          const float t = (0.0f - v1) / (v2 - v1);
+          for (int c = 0; c < 3; ++c) vert[e][c] = p1[c] + t * (p2[c] - p1[c]);
+        }
+      }
+      for (uint64_t l = itm::kTriangleCases[cube]; (l & 0xf) != 0xf; l >>= 12) {
+        float* o = &m->tri[(size_t)n * 9];
+        for (int k = 0; k < 3; ++k) {
+          const int e = (int)((l >> (4 * k)) & 0xf);
+          o[3 * k] = vert[e][0] * factor; o[3 * k + 1] = vert[e][1] * factor; o[3 * k + 2] = vert[e][2] * factor;
+        }
+        if (n < m->maxTriangles - 1) ++n;
+      }
+    }
+  }
+  m->noTotalTriangles = n;
+}
+
 template <class F>
 int dispatch_voxel(int voxelType, F&& f) {
   switch (voxelType) {
@@ -1312,6 +1382,61 @@ int itmo_debug_stats(long long* out, int clear) {
   if (out) std::memcpy(out, &g_stats, sizeof g_stats);
   if (clear) std::memset(&g_stats, 0, sizeof g_stats);
   return (int)(sizeof g_stats / sizeof(long long));
+}
+
+
+int itmo_mesh_create(const itm_scene* s, uint32_t maxTriangles, itm_mesh** out) {
+  if (!s || !out) return fail(ITM_ERR_INVALID, "null argument");
+  itm_mesh* m = new itm_mesh();
+  m->scene = s; m->noTotalTriangles = 0;
+  m->maxTriangles = maxTriangles ? maxTriangles : (uint32_t)s->cfg.localBlockNum * 32u;
+  if (m->maxTriangles < 2) { delete m; return fail(ITM_ERR_INVALID, "a mesh needs room for at least two triangles"); }
+  m->tri.assign((size_t)m->maxTriangles * 9, 0.0f);
+  *out = m;
+  return ITM_OK;
+}
+int itmo_mesh_destroy(itm_mesh* m) { delete m; return ITM_OK; }
+int itmo_mesh_scene(const itm_scene* s, itm_mesh* m, itm_stream) {
+  if (!s || !m || m->scene != s) return fail(ITM_ERR_INVALID, "bad argument");
+  if (s->cfg.indexType != ITM_INDEX_HASH) { std::fill(m->tri.begin(), m->tri.end(), 0.0f); m->noTotalTriangles = 0; return ITM_OK; }
+  return dispatch_voxel(s->cfg.voxelType, [&](auto tag) { mesh_scene_t<VOX_T>(s, m); });
+}
+int itmo_mesh_info(const itm_mesh* m, uint32_t* n, uint32_t* cap, const float** tri, itm_stream) {
+  if (!m) return fail(ITM_ERR_INVALID, "null mesh");
+  if (n) *n = m->noTotalTriangles;
+  if (cap) *cap = m->maxTriangles;
+  if (tri) *tri = m->tri.data();
+  return ITM_OK;
+}
+int itmo_mesh_download(const itm_mesh* m, float* dst, uint32_t capacity, uint32_t* n, itm_stream) {
+  if (!m || !n) return fail(ITM_ERR_INVALID, "null argument");
+  *n = m->noTotalTriangles;
+  const uint32_t k = *n < capacity ? *n : capacity;
+  if (k) std::memcpy(dst, m->tri.data(), (size_t)k * 36);
+  return ITM_OK;
+}
+int itmo_mesh_write_obj(const itm_mesh* m, const char* path, itm_stream) {
+  FILE* f = fopen(path, "w+");
+  if (!f) return fail(ITM_ERR_INVALID, "cannot create file");
+  const uint32_t n = m->noTotalTriangles;
+  for (uint32_t i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) fprintf(f, "v %f %f %f\n", m->tri[(size_t)i * 9 + 3 * k], m->tri[(size_t)i * 9 + 3 * k + 1], m->tri[(size_t)i * 9 + 3 * k + 2]);
+  for (uint32_t i = 0; i < n; ++i) fprintf(f, "f %d %d %d\n", i * 3 + 2 + 1, i * 3 + 1 + 1, i * 3 + 0 + 1);
+  fclose(f);
+  return ITM_OK;
+}
+int itmo_mesh_write_stl(const itm_mesh* m, const char* path, itm_stream) {
+  FILE* f = fopen(path, "wb+");
+  if (!f) return fail(ITM_ERR_INVALID, "cannot create file");
+  for (int i = 0; i < 80; ++i) fwrite(" ", 1, 1, f);
+  const uint32_t n = m->noTotalTriangles;
+  fwrite(&n, 4, 1, f);
+  const float zero[3] = {0, 0, 0}; const short attr = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const float* t = &m->tri[(size_t)i * 9];
+    fwrite(zero, 4, 3, f); fwrite(t + 6, 4, 3, f); fwrite(t + 3, 4, 3, f); fwrite(t, 4, 3, f); fwrite(&attr, 2, 1, f);
+  }
+  fclose(f);
+  return ITM_OK;
 }
 
 int itmo_export_visible_record(const itm_render_state* rs, const float M_d[16], int max_ids, void* dst, itm_stream) {

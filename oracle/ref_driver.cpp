@@ -22,6 +22,7 @@
 // <ITMVoxel_s, ITMVoxelBlockHash>.
 #include "ITMLib/Engine/DeviceSpecific/CPU/ITMSceneReconstructionEngine_CPU.cpp"
 #include "ITMLib/Engine/DeviceSpecific/CPU/ITMVisualisationEngine_CPU.cpp"
+#include "ITMLib/Engine/DeviceSpecific/CPU/ITMMeshingEngine_CPU.cpp"
 #include "ITMLib/Engine/DeviceAgnostic/ITMViewBuilder.h"
 #include "ITMLib/Engine/DeviceSpecific/CPU/ITMDepthTracker_CPU.h"
 #include "ITMLib/Engine/DeviceSpecific/CPU/ITMLowLevelEngine_CPU.h"
@@ -41,6 +42,13 @@ template class ITMLib::Engine::ITMSceneReconstructionEngine_CPU<ITMVoxel_s, ITMP
 template class ITMLib::Engine::ITMSceneReconstructionEngine_CPU<ITMVoxel_f, ITMPlainVoxelArray>;
 template class ITMLib::Engine::ITMSceneReconstructionEngine_CPU<ITMVoxel_s_rgb, ITMPlainVoxelArray>;
 template class ITMLib::Engine::ITMSceneReconstructionEngine_CPU<ITMVoxel_f_rgb, ITMPlainVoxelArray>;
+template class ITMLib::Engine::ITMMeshingEngine_CPU<ITMVoxel_f, ITMVoxelBlockHash>;
+template class ITMLib::Engine::ITMMeshingEngine_CPU<ITMVoxel_s_rgb, ITMVoxelBlockHash>;
+template class ITMLib::Engine::ITMMeshingEngine_CPU<ITMVoxel_f_rgb, ITMVoxelBlockHash>;
+template class ITMLib::Engine::ITMMeshingEngine_CPU<ITMVoxel_s, ITMPlainVoxelArray>;
+template class ITMLib::Engine::ITMMeshingEngine_CPU<ITMVoxel_f, ITMPlainVoxelArray>;
+template class ITMLib::Engine::ITMMeshingEngine_CPU<ITMVoxel_s_rgb, ITMPlainVoxelArray>;
+template class ITMLib::Engine::ITMMeshingEngine_CPU<ITMVoxel_f_rgb, ITMPlainVoxelArray>;
 template class ITMLib::Engine::ITMVisualisationEngine_CPU<ITMVoxel_f, ITMVoxelBlockHash>;
 template class ITMLib::Engine::ITMVisualisationEngine_CPU<ITMVoxel_s_rgb, ITMVoxelBlockHash>;
 template class ITMLib::Engine::ITMVisualisationEngine_CPU<ITMVoxel_f_rgb, ITMVoxelBlockHash>;
@@ -68,6 +76,7 @@ struct RefSceneBase {
   virtual void pointCloud(const ITMView*, ITMTrackingState*, ITMRenderState*, bool) = 0;
   virtual void icpMaps(const ITMView*, ITMTrackingState*, ITMRenderState*) = 0;
   virtual void forwardRender(const ITMView*, ITMTrackingState*, ITMRenderState*) = 0;
+  virtual void mesh(ITMMesh*) = 0;
   virtual void* buffer(int which, size_t* bytes) = 0;
   virtual int* lastFreeBlockId() = 0;
   virtual int lastFreeExcess() = 0;
@@ -105,6 +114,7 @@ struct RefScene : RefSceneBase {
   ITMScene<TVoxel, TIndex> scene;
   ITMSceneReconstructionEngine_CPU<TVoxel, TIndex> reco;
   ITMVisualisationEngine_CPU<TVoxel, TIndex> vis;
+  ITMMeshingEngine_CPU<TVoxel, TIndex> mesher;
   RefScene(const itm_scene_config& c, const itm_scene_params& p)
       : sp(p.mu, p.maxW, p.voxelSize, p.viewFrustum_min, p.viewFrustum_max, p.stopIntegratingAtMaxW != 0),
         scene(&sp, false, MEMORYDEVICE_CPU), vis(&scene) {
@@ -124,6 +134,7 @@ struct RefScene : RefSceneBase {
   void pointCloud(const ITMView* v, ITMTrackingState* t, ITMRenderState* r, bool skip) override { vis.CreatePointCloud(v, t, r, skip); }
   void icpMaps(const ITMView* v, ITMTrackingState* t, ITMRenderState* r) override { vis.CreateICPMaps(v, t, r); }
   void forwardRender(const ITMView* v, ITMTrackingState* t, ITMRenderState* r) override { vis.ForwardRender(v, t, r); }
+  void mesh(ITMMesh* m) override { mesher.MeshScene(m, &scene); }
   void* buffer(int which, size_t* bytes) override {
     switch (which) {
       case ITM_BUF_HASH_ENTRIES: return IndexOps<TIndex>::hashEntries(scene.index, bytes);
@@ -323,6 +334,30 @@ int itmr_process_frame(itm_scene* s, const itm_view* v, itm_render_state* r, flo
   s->impl->expectedDepths(r->ts->pose_d, &r->view->calib->intrinsics_d, r->rs);
   return itmr_create_icp_maps(s, v, r, pts, nrm, st);
 }
+
+// ---- meshing: the reference's ITMMesh + ITMMeshingEngine_CPU ----------------------------------------------------------------
+struct itm_mesh { const itm_scene* scene; ITMMesh* mesh; };
+int itmr_mesh_create(const itm_scene* s, uint32_t maxTriangles, itm_mesh** out) {
+  if (maxTriangles != 0 && maxTriangles != ITMMesh::noMaxTriangles) return fail(ITM_ERR_UNSUPPORTED, "ITMMesh::noMaxTriangles is a compile-time constant of the reference");
+  *out = new itm_mesh{s, new ITMMesh(MEMORYDEVICE_CPU)};
+  return ITM_OK;
+}
+int itmr_mesh_destroy(itm_mesh* m) { if (m) { delete m->mesh; delete m; } return ITM_OK; }
+int itmr_mesh_scene(const itm_scene* s, itm_mesh* m, itm_stream) { s->impl->mesh(m->mesh); return ITM_OK; }
+int itmr_mesh_info(const itm_mesh* m, uint32_t* n, uint32_t* cap, const float** tri, itm_stream) {
+  if (n) *n = m->mesh->noTotalTriangles;
+  if (cap) *cap = ITMMesh::noMaxTriangles;
+  if (tri) *tri = (const float*)m->mesh->triangles->GetData(MEMORYDEVICE_CPU);
+  return ITM_OK;
+}
+int itmr_mesh_download(const itm_mesh* m, float* dst, uint32_t capacity, uint32_t* n, itm_stream) {
+  *n = m->mesh->noTotalTriangles;
+  const uint32_t k = *n < capacity ? *n : capacity;
+  if (k) std::memcpy(dst, m->mesh->triangles->GetData(MEMORYDEVICE_CPU), (size_t)k * sizeof(ITMMesh::Triangle));
+  return ITM_OK;
+}
+int itmr_mesh_write_obj(const itm_mesh* m, const char* path, itm_stream) { m->mesh->WriteOBJ(path); return ITM_OK; }
+int itmr_mesh_write_stl(const itm_mesh* m, const char* path, itm_stream) { m->mesh->WriteSTL(path); return ITM_OK; }
 
 int itmr_convert_depth_affine(const int16_t* raw, float* out, int w, int h, float a, float b, itm_stream) {
   for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) convertDepthAffineToFloat(out, x, y, raw, Vector2i(w, h), Vector2f(a, b));

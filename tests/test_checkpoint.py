@@ -68,7 +68,71 @@ def test_block_files_and_errors(hip, tmp_path):
     with pytest.raises(capi.ItmError):
         other.load(d)
     other.close()
-    os.truncate(os.path.join(d, "voxel.dat"), 100)
+    # different scene parameters (config.dat holds them too) are refused as well
+    other = hip.create_scene(capi.VOXEL_S, capi.INDEX_HASH, capi.default_params(voxelSize=0.02))
     with pytest.raises(capi.ItmError):
-        ses.scene.load(d, ses.rs)
+        other.load(d)
+    other.close()
     ses.close()
+
+
+@pytest.mark.gpu
+def test_rejected_checkpoints_leave_the_scene_untouched(hip, tmp_path):
+    """itm_scene_load validates every file before the first upload: after a refused load the scene continues as if
+    nothing had happened (same next frame as an undisturbed twin)."""
+    import shutil
+    src = T.Session(hip, SC)
+    for k in range(2):
+        src.frame(k)
+    good = str(tmp_path / "good"); os.makedirs(good)
+    src.scene.save(good, src.rs)
+    assert not [f for f in os.listdir(good) if f.endswith(".tmp")]          # written through temporaries, all renamed
+    victim, twin = T.Session(hip, SC), T.Session(hip, SC)
+    for ses in (victim, twin):
+        for k in range(3):
+            ses.frame(k)
+
+    made = []
+
+    def corrupt(name, fn):
+        made.append(name)
+        bad = str(tmp_path / ("bad%d_%s" % (len(made), name))); shutil.copytree(good, bad)
+        path = os.path.join(bad, name)
+        fn(path)
+        with pytest.raises(capi.ItmError):
+            victim.scene.load(bad, victim.rs)
+
+    corrupt("voxel.dat", lambda p: os.truncate(p, 100))                       # short LATER file: earlier blocks must not be live
+    corrupt("hash.dat", lambda p: open(p, "ab").write(b"x"))                   # trailing bytes
+
+    def bad_counter(p):
+        raw = bytearray(open(p, "rb").read()); c = np.frombuffer(raw, np.int32).copy()
+        c[1 + 2] = 10 ** 9                                                     # noVisibleEntries beyond the id list
+        open(p, "wb").write(c.tobytes())
+    corrupt("counters.dat", bad_counter)
+
+    def bad_free_id(p):
+        c = np.frombuffer(open(p, "rb").read(), np.int32).copy(); c[1 + 0] = 1 << 20   # lastFreeBlockId beyond the pool
+        open(p, "wb").write(c.tobytes())
+    corrupt("counters.dat", bad_free_id)
+
+    def bad_entry(p):
+        raw = np.frombuffer(open(p, "rb").read(), np.uint8).copy()
+        e = raw[4:].view(capi.HASH_ENTRY_DTYPE); e["ptr"][5] = 1 << 24            # pointer outside the voxel pool
+        open(p, "wb").write(raw.tobytes())
+    corrupt("hash.dat", bad_entry)
+
+    def bad_id(p):
+        v = np.frombuffer(open(p, "rb").read(), np.int32).copy(); v[1] = -7
+        open(p, "wb").write(v.tobytes())
+    corrupt("visible_ids.dat", bad_id)
+
+    for ses in (victim, twin):
+        ses.frame(3, fused=True)
+    a, b = victim.snapshot(), twin.snapshot()
+    T.compare_results(a, b, SC, what="after refused loads")
+    assert np.array_equal(a.voxels, b.voxels)
+    # and the intact checkpoint still loads
+    victim.scene.load(good, victim.rs)
+    for ses in (src, victim, twin):
+        ses.close()
