@@ -92,7 +92,10 @@ __global__ void __launch_bounds__(256) request_kernel(const float* __restrict__ 
   // touches carry bit 7; visible_count_kernel then reads every other non-zero type as "3".
   constexpr uint8_t kTouched = LAZY ? 0x80 : 0x00;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (FUSE_RANGE_INIT && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { rcnt->noRenderingBlocks = 0; rcnt->renderingBlocksAccepted = -1; }
+  if (FUSE_RANGE_INIT && blockIdx.x == 0 && blockIdx.y == 0) {
+    if (threadIdx.x == 0) { rcnt->noRenderingBlocks = 0; rcnt->renderingBlocksAccepted = -1; }
+    if (threadIdx.x < 64) rcnt->integrateHeads[16 * threadIdx.x] = 0;     // work queues of this frame's integration launch
+  }
   const int x = blockIdx.x * 16 + (lane & 15);
   const int y = blockIdx.y * 16 + wave * 4 + (lane >> 4);
   if (x >= p.W || y >= p.H) return;

@@ -19,6 +19,12 @@
 
 namespace itm {
 
+#ifndef ITM_EXP_FUSED_STAMPS
+#define ITM_EXP_FUSED_STAMPS 0
+#endif
+#ifndef ITM_PROJECTION_PRIORITY
+#define ITM_PROJECTION_PRIORITY 1
+#endif
 int g_debug_integrate_wgs = 0;
 int g_debug_no_fused_projection = 0;
 
@@ -182,32 +188,65 @@ __device__ inline bool fuse_voxel(typename VX::Reg& r, float mx, float my, float
   return touched;
 }
 
+// Two ways of dealing the visible blocks to the persistent workgroups:
+//  * static striding (block e to workgroup e mod G): no synchronisation at all, the eight waves of a workgroup drift freely;
+//  * dynamic queues when there are many blocks per workgroup (>= kDynamicBlocksPerGroup, e.g. BASELINE configs[4]: 54 k colour
+//    blocks whose cost varies with the share of voxels inside the colour band): 8 queues (queue q owns the list positions
+//    q, q + 8, ...), a workgroup starts on queue blockIdx % 8 and moves on when a queue is empty; the next position is
+//    requested before the current block is processed.  Measured: config 5 integrate 243 -> 221 us.  With few blocks per
+//    workgroup (config 2: 12) the per-block barrier costs more than the balance gains (24 -> 44 us with 8 queues, whose heads
+//    also saturate at ~88 dequeues per us and word), so the kernel picks per launch.
+constexpr int kIntegrateQueues = 8;    // measured on config 5: 8 queues 221 us, 64 queues 263 us, static striding 243 us
+constexpr int kDynamicBlocksPerGroup = 24;
+
 template <class VX>
-__device__ inline void integrate_hash_body(int wgIdx, int wgCount, const int32_t* __restrict__ visibleIds, const RenderCounters* __restrict__ rc,
+__device__ inline void integrate_block(const HashEntry& he, int t, void* __restrict__ vba, const float* __restrict__ depth,
+                                       const uchar4* __restrict__ rgb, const FuseParams& p) {
+  if (he.ptr < 0) return;
+  const int x = t & 7, y = (t >> 3) & 7, z = t >> 6;
+  const size_t vi = (size_t)he.ptr * kBlockVoxels + t;
+  typename VX::Reg r = VX::load(vba, vi);
+  if (p.stopAtMax && VX::w_depth(r) == p.maxW) return;
+  const float mx = (float)(he.px * kBlockSide + x) * p.voxelSize;
+  const float my = (float)(he.py * kBlockSide + y) * p.voxelSize;
+  const float mz = (float)(he.pz * kBlockSide + z) * p.voxelSize;
+  if (fuse_voxel<VX>(r, mx, my, mz, depth, rgb, p)) VX::store(vba, vi, r);
+}
+
+template <class VX>
+__device__ inline void integrate_hash_body(int wgIdx, int wgCount, const int32_t* __restrict__ visibleIds, RenderCounters* __restrict__ rc,
                                            const uint4* __restrict__ hash, void* __restrict__ vba,
                                            const float* __restrict__ depth, const uchar4* __restrict__ rgb, const FuseParams& p) {
+  __shared__ int nextSlot[2];
   const int nv = rc->noVisibleEntries;
   const int t = threadIdx.x;
-  const int x = t & 7, y = (t >> 3) & 7, z = t >> 6;
-  // (A software-pipelined variant -- visible id three blocks ahead, hash entry two, voxels one -- was measured: no
-  // gain for ITMVoxel_s, config 5 253 -> 280 us.  The loop is not bound by its read chain: with colour voxels nearly
-  // every wave has a lane inside the colour band and pays the whole colour path, i.e. it is ALU bound.  Two blocks per
-  // trip with staged loads / projections / gathers / updates: config 5 244 -> 234 us but config 2 -2 % end to end.)
-  for (int e = wgIdx; e < nv; e += wgCount) {
-    const HashEntry he = unpack_entry(hash[visibleIds[e]]);
-    if (he.ptr < 0) continue;
-    const size_t vi = (size_t)he.ptr * kBlockVoxels + t;
-    typename VX::Reg r = VX::load(vba, vi);
-    if (p.stopAtMax && VX::w_depth(r) == p.maxW) continue;
-    const float mx = (float)(he.px * kBlockSide + x) * p.voxelSize;
-    const float my = (float)(he.py * kBlockSide + y) * p.voxelSize;
-    const float mz = (float)(he.pz * kBlockSide + z) * p.voxelSize;
-    if (fuse_voxel<VX>(r, mx, my, mz, depth, rgb, p)) VX::store(vba, vi, r);
+  if (nv < kDynamicBlocksPerGroup * wgCount) {
+    for (int e = wgIdx; e < nv; e += wgCount) integrate_block<VX>(unpack_entry(hash[visibleIds[e]]), t, vba, depth, rgb, p);
+    return;
+  }
+  int queue = wgIdx & (kIntegrateQueues - 1), tried = 0;
+  // fetch(): lane 0 takes the next position of the current queue; -1 once all queues are empty
+  auto fetch = [&]() -> int {
+    for (; tried < kIntegrateQueues; ++tried, queue = (queue + 1) & (kIntegrateQueues - 1)) {
+      const int k = atomicAdd(&rc->integrateHeads[16 * queue], 1);
+      const int e = queue + kIntegrateQueues * k;
+      if (e < nv) return e;
+    }
+    return -1;
+  };
+  if (t == 0) nextSlot[0] = fetch();
+  __syncthreads();
+  int e = nextSlot[0];
+  for (int it = 0; e >= 0; ++it) {
+    if (t == 0) nextSlot[(it + 1) & 1] = fetch();      // in flight while this block is processed
+    integrate_block<VX>(unpack_entry(hash[visibleIds[e]]), t, vba, depth, rgb, p);
+    __syncthreads();
+    e = nextSlot[(it + 1) & 1];
   }
 }
 
 template <class VX>
-__global__ void __launch_bounds__(512) integrate_hash_kernel(const int32_t* __restrict__ visibleIds, const RenderCounters* __restrict__ rc,
+__global__ void __launch_bounds__(512) integrate_hash_kernel(const int32_t* __restrict__ visibleIds, RenderCounters* __restrict__ rc,
                                                              const uint4* __restrict__ hash, void* __restrict__ vba,
                                                              const float* __restrict__ depth, const uchar4* __restrict__ rgb, FuseParams p) {
   integrate_hash_body<VX>(blockIdx.x, gridDim.x, visibleIds, rc, hash, vba, depth, rgb, p);
@@ -217,6 +256,13 @@ __global__ void __launch_bounds__(512) integrate_hash_kernel(const int32_t* __re
 // visible list, integration is ALU bound on every CU while the kRangeParts projection workgroups are bound by
 // LDS atomics on 32 CUs, so they overlap almost perfectly (17 + 11.5 us as two launches -> ~19 us).  The first
 // kRangeParts workgroups project, the others are the persistent integration workgroups.
+#if ITM_EXP_FUSED_STAMPS
+// measurement build: per-workgroup start / end of the fused launch on the constant-rate global clock (100 MHz)
+__device__ unsigned long long g_fusedStamps[2048 * 2];
+#define ITM_FS(...) __VA_ARGS__
+#else
+#define ITM_FS(...)
+#endif
 template <class VX>
 __global__ void __launch_bounds__(512) integrate_project_kernel(const int32_t* __restrict__ visibleIds, RenderCounters* __restrict__ rc,
                                                                 const uint4* __restrict__ hash, void* __restrict__ vba,
@@ -224,12 +270,22 @@ __global__ void __launch_bounds__(512) integrate_project_kernel(const int32_t* _
                                                                 float2* __restrict__ range, uint4* __restrict__ projBuf, uint2* __restrict__ partials,
                                                                 ProjParams pp, int RW, int RH) {
   extern __shared__ uint2 cells[];
+  ITM_FS(if (threadIdx.x == 0 && blockIdx.x < 2048) g_fusedStamps[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();)
   if (blockIdx.x < kRangeParts) {
+    // the few projection workgroups share their CUs with integration workgroups and would otherwise be the last to finish
+    // (21.8 us fused against 15.7 us for the integration alone): let their waves win the issue arbitration
+#if ITM_PROJECTION_PRIORITY
+    __builtin_amdgcn_s_setprio(3);
+#endif
     project_partial_body(blockIdx.x, cells, visibleIds, rc, hash, range, projBuf, partials, pp, RW, RH);
     return;
   }
   integrate_hash_body<VX>(blockIdx.x - kRangeParts, gridDim.x - kRangeParts, visibleIds, rc, hash, vba, depth, rgb, p);
+  ITM_FS(__syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 2048) g_fusedStamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();)
 }
+#if ITM_EXP_FUSED_STAMPS
+extern "C" int itm_debug_read_fused_stamps(unsigned long long* dst, int n) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_fusedStamps), (size_t)n * 8); }
+#endif
 
 // Dense volume, generic voxel type: one voxel per lane, x fastest (coalesced).
 template <class VX>
@@ -321,7 +377,7 @@ __global__ void __launch_bounds__(256) integrate_dense_s_x4_kernel(uint4* __rest
 
 // `fuseProjection`: also run the projection half of CreateExpectedDepths (hash scenes whose sub-sampled range image
 // fits four times in LDS; the caller checked can_fuse_projection and launches range_reduce afterwards).
-int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipStream_t st, bool fuseProjection) {
+int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipStream_t st, bool fuseProjection, bool queuesZeroed) {
   FuseParams p;
   memcpy(p.M_d.m, v->M_d, 64);
   matmul4(v->rgb_to_depth_inv, v->M_d, p.M_rgb.m);  // calib_inv * M_d (_CPU.cpp:61)
@@ -352,6 +408,7 @@ int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipS
       pp.fx = v->intr_d[0]; pp.fy = v->intr_d[1]; pp.cx = v->intr_d[2]; pp.cy = v->intr_d[3];
       pp.voxelSize = s->prm.voxelSize; pp.W = rs->w; pp.H = rs->h; pp.maxBlocks = s->cfg.maxRenderingBlocks;
     }
+    if (!queuesZeroed) ITM_HIP(hipMemsetAsync(rs->counters->integrateHeads, 0, sizeof(rs->counters->integrateHeads), st));
     int rc = dispatch_voxel(s->cfg.voxelType, [&](auto vx) {
       using VX = decltype(vx);
       if (fuseProjection)

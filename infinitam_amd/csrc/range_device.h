@@ -63,7 +63,10 @@ __device__ inline Projected project_block(const HashEntry& e, const ProjParams& 
 // writes that partial image to HBM (reduced by range_reduce_kernel).  Cells outside the region (the
 // reference clamps boxes to the FULL image size, a quirk that only touches cells no ray ever reads) go
 // through global atomics.
-constexpr int kRangeParts = 32;
+#ifndef ITM_RANGE_PARTS
+#define ITM_RANGE_PARTS 32
+#endif
+constexpr int kRangeParts = ITM_RANGE_PARTS;   // 32 or 64 (the ray-cast prologue reduces 4 cells x kRangeParts partials with <= 256 lanes)
 
 // Rendering-block cap of the reference reached (numRenderingBlocks >= MAX_RENDERING_BLOCKS): replays the sequential
 // accept / skip decisions and rebuilds the whole image from the accepted boxes.  One workgroup of `nthreads` lanes.

@@ -409,7 +409,7 @@ int itm_render_state_create(const itm_scene* s, int w, int h, itm_render_state**
     alloc((void**)&r->visibleIds, (size_t)r->capIds * 4);
     alloc((void**)&r->visibleType, (size_t)s->noTotalEntries);
     alloc((void**)&r->projBuf, (size_t)r->capIds * 32);
-    if ((size_t)((w + 7) / 8) * ((h + 7) / 8) * 8 <= 150 * 1024) alloc((void**)&r->rangePartials, (size_t)32 * ((w + 7) / 8) * ((h + 7) / 8) * 8);
+    if ((size_t)((w + 7) / 8) * ((h + 7) / 8) * 8 <= 150 * 1024) alloc((void**)&r->rangePartials, (size_t)64 * ((w + 7) / 8) * ((h + 7) / 8) * 8);   // room for up to 64 partial images
   }
   if (e != hipSuccess) { free_rs(r); return hip_fail(e, "hipMalloc(render state)", __FILE__, __LINE__); }
   // MemoryBlock<T> storage is zero-initialised in the reference (ORUtils/MemoryBlock.h Clear on allocate)

@@ -69,19 +69,40 @@ __device__ inline bool bilinear_holes(const float4* __restrict__ src, float px, 
 }
 
 // MODE: 1 rotation only (3 parameters), 2 translation only (3), 3 both (6)
+//
+// At most kGHGroups workgroups: each walks its 16x16-pixel tiles (tile = group, group + G, ...) and keeps its sums in
+// registers (double), so a call delivers at most kGHGroups records to the host whatever the image size -- with one record per
+// tile, the 1 200 records (288 KB over PCIe, two system fences per workgroup) of a 640x480 level cost 113 us per evaluation
+// against 20 us for the 40x30 level (tools/tracker_bench.py).
+#ifndef ITM_GH_GROUPS
+#define ITM_GH_GROUPS 256
+#endif
+#ifndef ITM_GH_WAVES
+#define ITM_GH_WAVES 4           // waves per workgroup (measured per 640x480 evaluation: 4 waves 43 us, 8 waves 51 us, 16 waves 73 us)
+#endif
+constexpr int kGHGroups = ITM_GH_GROUPS;
+constexpr int kGHWaves = ITM_GH_WAVES;
+constexpr int kGHThreads = 64 * kGHWaves;
+constexpr int kGHTileH = kGHThreads / 16;      // a tile is 16 pixels wide and kGHTileH tall
+
 template <int MODE>
-__global__ void __launch_bounds__(256) gh_partial_kernel(const float* __restrict__ depth, const float4* __restrict__ pointsMap,
+__global__ void __launch_bounds__(kGHThreads) gh_partial_kernel(const float* __restrict__ depth, const float4* __restrict__ pointsMap,
                                                         const float4* __restrict__ normalsMap, double* __restrict__ partial,
                                                         int* __restrict__ partialCount, GHParams p, GHBlockRecord* __restrict__ hostRec, unsigned int seq) {
   constexpr int NP = (MODE == 3) ? 6 : 3;
   constexpr int NH = NP * (NP + 1) / 2;
-  __shared__ double lds[4][kGHValues];
-  __shared__ int ldsCount[4];
+  __shared__ double lds[kGHWaves][kGHValues];
+  __shared__ int ldsCount[kGHWaves];
+  double acc[kGHValues];
+#pragma unroll
+  for (int i = 0; i < kGHValues; ++i) acc[i] = 0.0;
+  int valid = 0;
+  const int tilesX = (p.w + 15) / 16, tiles = tilesX * ((p.h + kGHTileH - 1) / kGHTileH);
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
   float vals[kGHValues];
 #pragma unroll
   for (int i = 0; i < kGHValues; ++i) vals[i] = 0.0f;
-  int valid = 0;
-  const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+  const int x = (tile % tilesX) * 16 + (threadIdx.x & 15), y = (tile / tilesX) * kGHTileH + (threadIdx.x >> 4);
   if (x < p.w && y < p.h) {
     const float d = depth[x + y * p.w];
     if (!(d <= 1e-8f)) {
@@ -117,13 +138,19 @@ __global__ void __launch_bounds__(256) gh_partial_kernel(const float* __restrict
 #pragma unroll
                 for (int c = 0; c <= r; ++c, ++k) vals[7 + k] = A[r] * A[c];
               }
-              valid = 1;
+              ++valid;
             }
           }
         }
       }
     }
   }
+#pragma unroll
+  for (int i = 0; i < kGHValues; ++i) {
+    const bool used = (i == 0) || (i >= 1 && i < 1 + NP) || (i >= 7 && i < 7 + NH);
+    if (used) acc[i] += (double)vals[i];
+  }
+  }   // tiles of this workgroup
   // wave reduction in double (fixed butterfly order), then one partial per workgroup
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -131,7 +158,7 @@ __global__ void __launch_bounds__(256) gh_partial_kernel(const float* __restrict
     const bool used = (i == 0) || (i >= 1 && i < 1 + NP) || (i >= 7 && i < 7 + NH);
     double s = 0.0;
     if (used) {
-      s = (double)vals[i];
+      s = acc[i];
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
     }
@@ -142,9 +169,14 @@ __global__ void __launch_bounds__(256) gh_partial_kernel(const float* __restrict
   for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
   if (lane == 0) ldsCount[wave] = c;
   __syncthreads();
-  const int blk = blockIdx.x + blockIdx.y * gridDim.x;
-  const double mine = (threadIdx.x < kGHValues) ? ((lds[0][threadIdx.x] + lds[1][threadIdx.x]) + lds[2][threadIdx.x]) + lds[3][threadIdx.x] : 0.0;
-  const int cnt = ((ldsCount[0] + ldsCount[1]) + ldsCount[2]) + ldsCount[3];
+  const int blk = blockIdx.x;
+  double mine = 0.0;
+  int cnt = 0;
+#pragma unroll
+  for (int wv = 0; wv < kGHWaves; ++wv) {          // fixed order: deterministic
+    if (threadIdx.x < kGHValues) mine += lds[wv][threadIdx.x];
+    cnt += ldsCount[wv];
+  }
   if (threadIdx.x < kGHValues) partial[(size_t)blk * kGHValues + threadIdx.x] = mine;
   if (threadIdx.x == 0) partialCount[blk] = cnt;
   if (hostRec) {
@@ -228,8 +260,10 @@ static int compute_g_and_h(itm_tracker* trk, const float* depth, int w, int h, c
   memset(out, 0, sizeof *out);
   if (iterationType == ITM_TRACKER_ITERATION_NONE) return ITM_OK;
   if (iterationType < 1 || iterationType > 3) return set_error(ITM_ERR_INVALID, "bad iteration type");
-  const dim3 grid((w + 15) / 16, (h + 15) / 16);
-  const size_t blocks = (size_t)grid.x * grid.y;
+  const int tiles = ((w + 15) / 16) * ((h + kGHTileH - 1) / kGHTileH);
+  const int rounds = (tiles + kGHGroups - 1) / kGHGroups;                  // tiles per workgroup, then as few workgroups as that needs
+  const dim3 grid((tiles + rounds - 1) / rounds);
+  const size_t blocks = grid.x;
   int rc = tracker_reserve(trk, blocks);
   if (rc) return rc;
   GHParams p;
@@ -241,9 +275,9 @@ static int compute_g_and_h(itm_tracker* trk, const float* depth, int w, int h, c
   const int np = (iterationType == ITM_TRACKER_ITERATION_BOTH) ? 6 : 3;
   const int nh = np * (np + 1) / 2;
   const unsigned int seq = ++trk->seq;
-  if (iterationType == 1) gh_partial_kernel<1><<<grid, 256, 0, st>>>(depth, pm, nm, trk->partial, trk->partialCount, p, trk->recDev, seq);
-  else if (iterationType == 2) gh_partial_kernel<2><<<grid, 256, 0, st>>>(depth, pm, nm, trk->partial, trk->partialCount, p, trk->recDev, seq);
-  else gh_partial_kernel<3><<<grid, 256, 0, st>>>(depth, pm, nm, trk->partial, trk->partialCount, p, trk->recDev, seq);
+  if (iterationType == 1) gh_partial_kernel<1><<<grid, kGHThreads, 0, st>>>(depth, pm, nm, trk->partial, trk->partialCount, p, trk->recDev, seq);
+  else if (iterationType == 2) gh_partial_kernel<2><<<grid, kGHThreads, 0, st>>>(depth, pm, nm, trk->partial, trk->partialCount, p, trk->recDev, seq);
+  else gh_partial_kernel<3><<<grid, kGHThreads, 0, st>>>(depth, pm, nm, trk->partial, trk->partialCount, p, trk->recDev, seq);
   ITM_LAUNCH_CHECK();
   // Wait for every workgroup's stamped record and add them in block order (fixed order => deterministic, in double).  The
   // poll is bounded in TIME: after 20 ms without the stamp the stream is queried between polls -- a drained stream without

@@ -210,7 +210,8 @@ __device__ inline void reduce_own_cells(const RangeFuse& f, int tx, int ty, int 
   const int nCells = f.RW * f.RH;
   const int total = f.rc->noRenderingBlocks;
   if (total < f.maxBlocks) {
-    // 4 cells x kRangeParts partials: one load per lane of waves 0 and 1 (kRangeParts == 32), min / max over each 32-lane half
+    // 4 cells x kRangeParts partials: one load per lane (kRangeParts 32: waves 0 and 1, min / max over each 32-lane half; 64: all
+    // four waves, one cell per wave)
     if (tid < 4 * kRangeParts) {
       const int c = tid / kRangeParts, part = tid % kRangeParts;
       const int cx = tx * 2 + (c & 1), cy = ty * 2 + (c >> 1);
@@ -466,7 +467,7 @@ int itm_process_frame(itm_scene* s, const itm_view* v, itm_render_state* rs, flo
   const bool hashScene = s->cfg.indexType == ITM_INDEX_HASH;
   if (hashScene && (rc = launch_allocate(s, v, rs, false, true, st))) return rc;
   const bool fuse = hashScene && can_fuse_projection(s, rs);
-  if ((rc = launch_integrate(s, v, rs, st, fuse))) return rc;
+  if ((rc = launch_integrate(s, v, rs, st, fuse, hashScene))) return rc;      // the request kernel of this frame zeroed the work queues
   // with the projection done inside the integration launch, the ray-cast workgroups reduce the partial range images of their
   // own cells (raycast_kernel<.., REDUCE>); otherwise CreateExpectedDepths runs as its own launches
   const bool reduceInRaycast = fuse && !g_debug_no_fused_range_reduce;

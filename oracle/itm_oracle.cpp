@@ -1486,8 +1486,10 @@ void subsample_holes(const float* in, int wIn, int hIn, float* out) {
   }
 }
 
+long long g_ghEvaluations = 0;   // test-only counter (itmo_debug_gh_evaluations)
 int g_and_h(const float* depth, int w, int h, const float* vi, const V4f* pts, const V4f* nrm, int sW, int sH, const float* si,
             const float* invPose, const float* scenePose, float distThresh, int type, itm_tracker_gh* out) {
+  ++g_ghEvaluations;
   std::memset(out, 0, sizeof *out);
   if (type == ITM_TRACKER_ITERATION_NONE) return 0;
   const bool shortIt = type != ITM_TRACKER_ITERATION_BOTH;
@@ -1610,6 +1612,7 @@ void chol_solve(const float* mat, int n, const float* v, float* result) {
 
 extern "C" {
 
+long long itmo_debug_gh_evaluations(int clear) { const long long v = g_ghEvaluations; if (clear) g_ghEvaluations = 0; return v; }
 int itmo_filter_subsample_with_holes(const float* in, int w_in, int h_in, float* out, itm_stream) {
   if (!in || !out || w_in < 2 || h_in < 2) return fail(ITM_ERR_INVALID, "bad argument");
   subsample_holes(in, w_in, h_in, out);

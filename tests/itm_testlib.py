@@ -74,6 +74,11 @@ def reference_pool40000_backend() -> Optional[Backend]:
 
 def hip_backend() -> Backend:
     import infinitam_amd
+    alt = os.environ.get("ITM_TEST_LIB")          # development: run the suite against another build of the product library
+    if alt:
+        if "hip_alt" not in _cache:
+            _cache["hip_alt"] = Backend(alt, "itm_")
+        return _cache["hip_alt"]
     return infinitam_amd.load()
 
 

@@ -24,6 +24,9 @@ def run(cfg: int, frames: int):
     for key in os.environ.get('ITM_DEBUG_KEYS', '').split(','):      # e.g. ITM_DEBUG_KEYS=4,6 -> debug_set(4,1), debug_set(6,1)
         if key.strip():
             be.check(be.fn['debug_set'](int(key), 1), 'debug_set')
+    for kv in os.environ.get('ITM_DEBUG_KV', '').split(','):         # e.g. ITM_DEBUG_KV=3:1056 -> debug_set(3, 1056)
+        if ':' in kv:
+            be.check(be.fn['debug_set'](int(kv.split(':')[0]), int(kv.split(':')[1])), 'debug_set')
     if os.environ.get('ITM_NO_DIRECTORY'):
         be.check(be.fn['debug_set'](5, 1), 'debug_set')   # A/B: ray cast through the table walk instead of the block directory
     if cfg == 3:
