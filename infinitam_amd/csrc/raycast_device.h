@@ -333,54 +333,52 @@ __device__ inline float4 cast_ray_plain(int x, int y, const VolumeView& vol, con
 // line costs ~2 000 cycles per dependent round trip, a trilinear step ~4 500.  Burst 1 (= the plain loop)
 // 69 us, 2: 65, 3: 64, 4: 62, 8: 66, unbounded: 95 (lanes then serialise each other's empty-space runs).
 // The other restructurings that were tried and dropped are listed with their numbers in DESIGN.md section 5.
-#ifndef ITM_RAY_PREDICT_STEP
-// Measurement option, OFF (0): a step of at most this many voxels is expected to land inside the truncation band; the lane then
-// skips the single-voxel read and goes straight to the 2x2x2 fetch, which serves the nearest-neighbour read AND the trilinear
-// read of that position.  Measured: 1.5 / 2 / 3 / 5 voxels -> 75 / 76 / 81 / 109 us against 66 us without: sixteen scattered
-// loads per lane cost more issue time than the phase they save.
-#define ITM_RAY_PREDICT_STEP 0.0f
+#ifndef ITM_RAY_PARK_STREAK
+// a ray that has just taken this many "block not found" steps in a row is crossing empty space (a silhouette ray on its way from
+// the sphere to the wall): phase 1 of the ray-cast workgroup parks it, phase 2 marches the parked rays in waves of their own.
+// Measured in-frame (MI355X; config 2 / config 5, one-phase kernel 60.4 / 132.5 us): streak 4: 76 / 152, 6: 62, 8: 54 / 129,
+// 10: 53 / 123, 12: 53 / 117, 16: 55 / 118, 24: 58 / 120 -- parking too early also catches rays that only skip a few blocks.
+#define ITM_RAY_PARK_STREAK 12
 #endif
-#ifndef ITM_RAY_MISS_LOOKAHEAD
-// Measurement option, OFF: after a "block not found" step (hash index with the block directory) the directory cells of the next
-// K positions of the ray -- computed with the reference's own additions, pt += 8 dir -- are fetched together and the ray advances
-// over as many of them as are empty (a silhouette ray walks ~45 such steps from the sphere to the wall, each a dependent round
-// trip of ~1 000 cycles).  It shortens the slow waves (p90 of the per-wave cycles 89 k -> 65 k) but the kernel gets slower,
-// gated or not: K = 3 / 6 / 10 / 16 -> 64 / 69 / 77 / 92 us against 61 us without (in-frame, MI355X, config 2).
-#define ITM_RAY_MISS_LOOKAHEAD 0
+#ifndef ITM_RAY_PARKED_LOOKAHEAD
+#define ITM_RAY_PARKED_LOOKAHEAD 6   // directory cells fetched together per round trip by a parked ray's empty-space run (4: 55 us, 6: 53, 8: 53)
 #endif
-#ifndef ITM_RAY_MISS_STREAK
-#define ITM_RAY_MISS_STREAK 3   // the look-ahead only starts after this many consecutive "not found" steps of the lane
-#endif
-template <class VX, bool DENSE>
-__device__ inline float4 cast_ray(int x, int y, const VolumeView& vol, const RayParams& p, float2 mm) {
-#if !ITM_RAY_WHILE_WHILE
-  return cast_ray_plain<VX, DENSE>(x, y, vol, p, mm);
-#else
-  // MARCH: next read is a single voxel; PRE: next read is predicted to fall in the band (2x2x2 fetch decides);
-  // TRI: a single-voxel read found the band, the trilinear read of the same position is due; REFINE: the surface was crossed
-  enum : int { MARCH = 0, TRI = 1, REFINE = 2, PRE = 3, DONE = 4 };
+
+// a parked ray: where it stands and how far it has come; direction, end of range etc. are recomputed from the pixel
+struct RayResume { float px, py, pz, total; };
+
+// castRay restructured as two nested loops ("while-while"), resumable.
+//   LOOKAHEAD > 0 (hash index with the block directory): after a "block not found" step the directory cells of the next K
+//     positions of the ray -- computed with the reference's own additions, pt += 8 dir -- are fetched together and the ray
+//     advances over as many of them as are empty: K dependent round trips become one.  In a wave where only SOME lanes cross
+//     empty space this loses (every lane pays the K classifications and loads: 61 -> 64 / 69 / 77 us for K = 3 / 6 / 10, gated or
+//     not); in a wave of nothing but such rays it is what makes their ~45-step runs cheap.
+//   PARK: the ray stops (parked = true, returns its position and length in xyz / w) once it has taken ITM_RAY_PARK_STREAK
+//     "not found" steps in a row; the caller appends it to the queue of the second pass.
+// Per ray the sequence of positions, reads and float operations is that of the reference, whatever the pass structure.
+template <class VX, bool DENSE, int LOOKAHEAD, bool PARK>
+__device__ inline float4 march_ray(int x, int y, const VolumeView& vol, const RayParams& p, float2 mm, const RayResume* resume, bool& parked) {
+  // MARCH: next read is a single voxel; TRI: a single-voxel read found the band, the trilinear read of the same position is
+  // due; REFINE: the surface was crossed
+  enum : int { MARCH = 0, TRI = 1, REFINE = 2, DONE = 4 };
   const float stepScale = p.mu * p.oneOverVoxel;
   const RaySetup r = ray_setup(x, y, p, mm);
   float px = r.px, py = r.py, pz = r.pz, total = r.total;
   const float dx = r.dx, dy = r.dy, dz = r.dz, totalMax = r.totalMax;
+  int missStreak = 0;
+  if (resume) { px = resume->px; py = resume->py; pz = resume->pz; total = resume->total; missStreak = ITM_RAY_PARK_STREAK; }
   BlockCache cache;
   bool found;
   float w = 0.0f;
+  parked = false;
   int st = (total < totalMax) ? MARCH : DONE;
-#if ITM_RAY_MISS_LOOKAHEAD > 0
-  int missStreak = 0;
-#endif
   // one forward step of the march loop for a value that is not in the band (or a trilinear value): returns the next state
   auto advance = [&](bool fnd, float sdf) -> int {
     float step;
     int next = MARCH;
     if (!fnd) step = (float)kBlockSide;
     else if (sdf <= 0.0f) { step = sdf * stepScale; next = REFINE; }          // surface crossed: first refinement move, no length update
-    else {
-      const float s = sdf * stepScale;
-      step = (s < 1.0f) ? 1.0f : s;
-      if (ITM_RAY_PREDICT_STEP > 0.0f && step <= ITM_RAY_PREDICT_STEP) next = PRE;
-    }
+    else { const float s = sdf * stepScale; step = (s < 1.0f) ? 1.0f : s; }
     px += step * dx; py += step * dy; pz += step * dz;
     if (next != REFINE) { total += step; if (!(total < totalMax)) next = DONE; }
     return next;
@@ -396,18 +394,20 @@ __device__ inline float4 cast_ray(int x, int y, const VolumeView& vol, const Ray
       const float sdf = sdf_nearest<VX, DENSE>(vol, px, py, pz, found, cache);
       if (found && (sdf <= 0.1f) && (sdf >= -0.5f)) st = TRI;      // the position is kept for the trilinear read
       else st = advance(found, sdf);
-#if ITM_RAY_MISS_LOOKAHEAD > 0
-      if constexpr (!DENSE) {
-        missStreak = found ? 0 : missStreak + 1;
-        if (vol.dirPtr && __any(missStreak >= ITM_RAY_MISS_STREAK && st == MARCH)) {
+      if constexpr (!DENSE && (PARK || LOOKAHEAD > 0)) missStreak = found ? 0 : missStreak + 1;
+      if constexpr (!DENSE && PARK) {
+        if (st == MARCH && missStreak >= ITM_RAY_PARK_STREAK) { parked = true; st = DONE; }
+      }
+      if constexpr (!DENSE && LOOKAHEAD > 0) {
+        if (vol.dirPtr && __any(missStreak >= ITM_RAY_PARK_STREAK && st == MARCH)) {
           // directory cells of the positions q0 = pt, q1 = pt + 8 dir, ... (cell 0 / no use for lanes that are not in an empty run)
-          const bool runner = missStreak >= ITM_RAY_MISS_STREAK && st == MARCH;
+          const bool runner = missStreak >= ITM_RAY_PARK_STREAK && st == MARCH;
           const float sx = (float)kBlockSide * dx, sy = (float)kBlockSide * dy, sz = (float)kBlockSide * dz;   // exact products
-          int ahead[ITM_RAY_MISS_LOOKAHEAD];
+          int ahead[LOOKAHEAD > 0 ? LOOKAHEAD : 1];
           {
             float qx = px, qy = py, qz = pz;
 #pragma unroll
-            for (int j = 0; j < ITM_RAY_MISS_LOOKAHEAD; ++j) {
+            for (int j = 0; j < LOOKAHEAD; ++j) {
               const uint32_t ux = (uint32_t)(((int)round_ref(qx) >> 3) + kDirHalf), uy = (uint32_t)(((int)round_ref(qy) >> 3) + kDirHalf),
                              uz = (uint32_t)(((int)round_ref(qz) >> 3) + kDirHalf);
               const bool use = runner && dir_covers(ux, uy, uz);
@@ -418,7 +418,7 @@ __device__ inline float4 cast_ray(int x, int y, const VolumeView& vol, const Ray
           }
           if (runner) {
 #pragma unroll
-            for (int j = 0; j < ITM_RAY_MISS_LOOKAHEAD; ++j) {
+            for (int j = 0; j < LOOKAHEAD; ++j) {
               if (ahead[j] >= 0) break;                             // q_j holds a block (or lies outside the directory): regular read next
               px += sx; py += sy; pz += sz; total += (float)kBlockSide;   // the reference's step for a position without a block
               if (!(total < totalMax)) { st = DONE; break; }
@@ -426,11 +426,10 @@ __device__ inline float4 cast_ray(int x, int y, const VolumeView& vol, const Ray
           }
         }
       }
-#endif
     }
-    ITM_WT(const unsigned long long wtA = wt_clock(); const unsigned wtTriLanes = __popcll(__ballot(st == TRI || st == REFINE || st == PRE)); wtInner = (unsigned)wt_wave_max(wtInner);)
+    ITM_WT(const unsigned long long wtA = wt_clock(); const unsigned wtTriLanes = __popcll(__ballot(st == TRI || st == REFINE)); wtInner = (unsigned)wt_wave_max(wtInner);)
     // ---- expensive phase: one 2x2x2 fetch for every lane that waits for one ---------------------------------------------
-    if (st == TRI || st == REFINE || st == PRE) {
+    if (st == TRI || st == REFINE) {
       Corners<VX, DENSE> cn;
       cn.fetch(vol, px, py, pz, cache);
       if (st == REFINE) {
@@ -438,15 +437,7 @@ __device__ inline float4 cast_ray(int x, int y, const VolumeView& vol, const Ray
         px += step * dx; py += step * dy; pz += step * dz;
         w = 1.0f; st = DONE;
       } else {
-        bool band = true;
-        if (st == PRE) {
-          // the nearest-neighbour read of this position, from the fetched corners
-          bool fnd;
-          const float sdfN = cn.nearest(px, py, pz, fnd);
-          band = fnd && (sdfN <= 0.1f) && (sdfN >= -0.5f);
-          if (!band) st = advance(fnd, sdfN);
-        }
-        if (band) st = advance(true, cn.trilinear());
+        st = advance(true, cn.trilinear());
       }
     }
     ITM_WT({ const float keep2 = total + px; asm volatile("" :: "v"(keep2)); const unsigned long long tB = wt_clock();
@@ -462,7 +453,18 @@ __device__ inline float4 cast_ray(int x, int y, const VolumeView& vol, const Ray
     if ((threadIdx.x & 63) == 0 && wv < 8192) { unsigned long long* o = g_waveStats + (size_t)wv * 12; o[0] = wtEnd - wtStart; o[1] = mOuter; }
   }
 #endif
+  if (PARK && parked) return make_float4(px, py, pz, total);
   return make_float4(px, py, pz, w);
+}
+
+// castRay for callers that want one ray start to finish
+template <class VX, bool DENSE>
+__device__ inline float4 cast_ray(int x, int y, const VolumeView& vol, const RayParams& p, float2 mm) {
+#if !ITM_RAY_WHILE_WHILE
+  return cast_ray_plain<VX, DENSE>(x, y, vol, p, mm);
+#else
+  bool parked;
+  return march_ray<VX, DENSE, 0, false>(x, y, vol, p, mm, nullptr, parked);
 #endif
 }
 

@@ -36,6 +36,7 @@ namespace itm {
 int g_debug_force_global_range = 0;
 int g_debug_no_directory = 0;
 int g_debug_no_fused_range_reduce = 0;
+int g_debug_single_pass_raycast = 0;
 
 // ---------------------------------------------------------------------------------------------
 // expected depth range
@@ -269,7 +270,14 @@ __device__ inline void reduce_own_cells(const RangeFuse& f, int tx, int ty, int 
   }
 }
 
-template <class VX, bool DENSE, bool REDUCE>
+// PARK (hash scenes with a block directory): rays that are crossing empty space -- in BASELINE configs[1] the 16 % of the rays
+// that pass the sphere's silhouette and walk ~45 "no block" steps to the wall -- are parked by phase 1 in a queue in LDS.  Mixed
+// into waves with ordinary rays they made those waves 3-5x longer than the median wave (sphere-side steps, then the run, then
+// the wall-side steps, one after the other for the whole wave), and the launch lasts as long as its slowest wave.  Phase 2 of
+// the same workgroup re-packs the parked rays 64 per wave: all lanes are then in the same phase, and the look-ahead of
+// march_ray turns the ~45 dependent round trips of the run into ~8.  (As a second LAUNCH over a global queue the parked rays
+// took 52 us on their own -- one wave per SIMD, other XCDs' cold L2s -- against 34 us for the first pass; measured, dropped.)
+template <class VX, bool DENSE, bool REDUCE, bool PARK>
 __global__ void __launch_bounds__(256) raycast_kernel(VolumeView vol, const float2* __restrict__ range, float4* __restrict__ out, RayParams p, RangeFuse fuse) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // (An XCD-affine order -- image band b ray-cast by XCD b, with integration placing the blocks of band b on XCD b --
@@ -279,18 +287,49 @@ __global__ void __launch_bounds__(256) raycast_kernel(VolumeView vol, const floa
   const int tx = blockIdx.x % tilesX, ty = blockIdx.x / tilesX;
   const int x = tx * 16 + (lane & 15);
   const int y = ty * 16 + wave * 4 + (lane >> 4);
-  float2 mm;
+  const bool inside = x < p.W && y < p.H;
+  __shared__ float2 cellRange[4];
+  __shared__ float4 parkState[PARK ? 256 : 1];   // (px, py, pz, total) of a parked ray
+  __shared__ int parkSource[PARK ? 256 : 1];     // the thread (= pixel of the tile) it belongs to
+  __shared__ int parkCount;
+  if (PARK && threadIdx.x == 0) parkCount = 0;
+  float2 mm = make_float2(0.0f, 0.0f);
   if constexpr (REDUCE) {
-    __shared__ float2 cellRange[4];
     reduce_own_cells(fuse, tx, ty, p.W, cellRange);
     __syncthreads();
-    if (x >= p.W || y >= p.H) return;
-    mm = cellRange[((lane & 15) >> 3) + 2 * (wave >> 1)];
+    if (inside) mm = cellRange[((lane & 15) >> 3) + 2 * (wave >> 1)];
   } else {
-    if (x >= p.W || y >= p.H) return;
-    mm = range[(x >> 3) + (y >> 3) * p.W];  // floor(x/8) + floor(y/8)*W  (_CPU.cpp:174)
+    if (PARK) __syncthreads();
+    if (inside) mm = range[(x >> 3) + (y >> 3) * p.W];  // floor(x/8) + floor(y/8)*W  (_CPU.cpp:174)
   }
-  out[x + y * p.W] = cast_ray<VX, DENSE>(x, y, vol, p, mm);
+  // ---- phase 1: every ray of the tile; rays that turn out to be crossing empty space are parked ----
+  bool parked = false;
+  if (inside) {
+    const float4 r = march_ray<VX, DENSE, 0, PARK>(x, y, vol, p, mm, nullptr, parked);
+    if (!parked) out[x + y * p.W] = r;
+    else if constexpr (PARK) {
+      const int slot = atomicAdd(&parkCount, 1);
+      parkState[slot] = r;
+      parkSource[slot] = (int)threadIdx.x;
+    }
+  }
+  if constexpr (PARK) {
+    __syncthreads();
+    // ---- phase 2: the parked rays, re-packed from lane 0 upwards ----
+    const int n = parkCount;
+    if ((int)threadIdx.x < n) {
+      const float4 q = parkState[threadIdx.x];
+      const int src = parkSource[threadIdx.x];
+      const int sl = src & 63, sw = src >> 6;
+      const int qx = tx * 16 + (sl & 15), qy = ty * 16 + sw * 4 + (sl >> 4);
+      float2 m2;
+      if constexpr (REDUCE) m2 = cellRange[((sl & 15) >> 3) + 2 * (sw >> 1)];
+      else m2 = range[(qx >> 3) + (qy >> 3) * p.W];
+      const RayResume rr{q.x, q.y, q.z, q.w};
+      bool again;
+      out[qx + qy * p.W] = march_ray<VX, DENSE, ITM_RAY_PARKED_LOOKAHEAD, false>(qx, qy, vol, p, m2, &rr, again);
+    }
+  }
 }
 
 int launch_raycast(const itm_scene* s, const float* invM, const float* intr, itm_render_state* rs, float4* dst, hipStream_t st, bool reduceRange) {
@@ -299,12 +338,18 @@ int launch_raycast(const itm_scene* s, const float* invM, const float* intr, itm
   const dim3 grid(((rs->w + 15) / 16) * ((rs->h + 15) / 16));
   const bool dense = s->cfg.indexType == ITM_INDEX_DENSE;
   RangeFuse fuse{rs->rangePartials, rs->counters, rs->projBuf, rs->range, (rs->w + 7) / 8, (rs->h + 7) / 8, s->cfg.maxRenderingBlocks};
+  // two phases whenever the block directory is in use
+  const bool park = !dense && vol.dirPtr != nullptr && !g_debug_single_pass_raycast;
   KernelTimer tk(s, ITM_TK_RAYCAST, st);
   int rc = dispatch_voxel(s->cfg.voxelType, [&](auto vx) {
     using VX = decltype(vx);
-    if (dense) raycast_kernel<VX, true, false><<<grid, 256, 0, st>>>(vol, rs->range, dst, p, fuse);
-    else if (reduceRange) raycast_kernel<VX, false, true><<<grid, 256, 0, st>>>(vol, rs->range, dst, p, fuse);
-    else raycast_kernel<VX, false, false><<<grid, 256, 0, st>>>(vol, rs->range, dst, p, fuse);
+    if (dense) raycast_kernel<VX, true, false, false><<<grid, 256, 0, st>>>(vol, rs->range, dst, p, fuse);
+    else if (park) {
+      if (reduceRange) raycast_kernel<VX, false, true, true><<<grid, 256, 0, st>>>(vol, rs->range, dst, p, fuse);
+      else raycast_kernel<VX, false, false, true><<<grid, 256, 0, st>>>(vol, rs->range, dst, p, fuse);
+    }
+    else if (reduceRange) raycast_kernel<VX, false, true, false><<<grid, 256, 0, st>>>(vol, rs->range, dst, p, fuse);
+    else raycast_kernel<VX, false, false, false><<<grid, 256, 0, st>>>(vol, rs->range, dst, p, fuse);
     return ITM_OK;
   });
   if (rc) return rc;
@@ -424,6 +469,7 @@ int itm_debug_set(int key, int value) {
   if (key == ITM_DEBUG_NO_DIRECTORY) { g_debug_no_directory = value; return ITM_OK; }
   if (key == ITM_DEBUG_NO_FUSED_RANGE_REDUCE) { g_debug_no_fused_range_reduce = value; return ITM_OK; }
   if (key == ITM_DEBUG_TWO_PASS_VISIBLE_LIST) { g_debug_two_pass_visible_list = value; return ITM_OK; }
+  if (key == ITM_DEBUG_SINGLE_PASS_RAYCAST) { g_debug_single_pass_raycast = value; return ITM_OK; }
   return set_error(ITM_ERR_INVALID, "unknown debug key");
 }
 

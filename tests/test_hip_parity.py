@@ -240,6 +240,18 @@ def test_directory_and_table_walk_agree_with_oracle(hip, oracle, sc):
     T.compare_results(a, b, sc, what=sc.name + "/table walk")
 
 
+@pytest.mark.parametrize("sc", [DIRECTORY_CASES[1], DIRECTORY_CASES[2]], ids=lambda s: s.name)
+def test_single_pass_ray_cast_path(hip, oracle, sc):
+    """Ray casting normally runs in two passes (rays crossing empty space are parked and finished by a second launch);
+    ITM_DEBUG_SINGLE_PASS_RAYCAST (8) casts every ray start to finish in one launch.  Same rays, same results."""
+    hip.check(hip.fn["debug_set"](8, 1), "debug_set")
+    try:
+        a = T.run_scenario(hip, sc, fused=True)
+    finally:
+        hip.check(hip.fn["debug_set"](8, 0), "debug_set")
+    T.compare_results(a, T.run_scenario(oracle, sc), sc, what=sc.name + "/single-pass ray cast")
+
+
 def test_directory_is_rebuilt_after_table_upload(hip, oracle):
     """A scene whose hash table, voxels and free lists were uploaded (checkpoint restore, itm_upload) must ray-cast like
     the scene that produced them: the upload rebuilds the directory from the table."""
