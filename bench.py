@@ -65,7 +65,7 @@ def parse():
     ap.add_argument("--no-exchange", action="store_true", help="skip the visible-list all-gather at N>1")
     ap.add_argument("--force-exchange", action="store_true", help="run the all-gather path even with one rank (self-test)")
     ap.add_argument("--exchange-batch", type=int, default=8,
-                    help="frames per all-gather; 1 = every frame (measured on MI355X through torch.distributed: per-frame costs 17 percent of the frame rate, the host-side collective call being the bound; 8 costs 3 percent, see DESIGN.md section 6)")
+                    help="frames per all-gather; 1 = every frame (measured on MI355X through torch.distributed: per-frame costs 24 percent of the frame rate, the host-side collective call being the bound; 8 costs 5 percent, see DESIGN.md section 6)")
     ap.add_argument("--streams-per-gpu", type=int, default=1,
                     help="independent scenes co-scheduled on one GPU, each on its own HIP stream (separate figure; headline is 1)")
     ap.add_argument("--lib", default=None, help="alternative shared library exporting the same C-ABI (tests: a host-memory backend)")
@@ -335,7 +335,7 @@ def read_roofline(config, wl, scene, counters):
             t = json.load(f).get(f"config{config}")
         if t:
             traffic, traffic_src = t.get("hbm_bytes_per_launch"), t.get("source")
-    kname = {2: "raycast_kernel<VoxelS,hash>", 3: "integrate_dense_s_x4_kernel", 5: "integrate_project_kernel<VoxelFRgb>"}[config]
+    kname = {2: "raycast_kernel<VoxelS,hash>", 3: "integrate_dense_s_x4_kernel", 5: "integrate_hash_kernel<VoxelFRgb>"}[config]
     return {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": round(alg), "avg_kernel_us": round(avg_s * 1e6, 2),

@@ -8,7 +8,7 @@ for c in 2 3 5; do
   steps=200; [ $c != 2 ] && steps=60
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/stats_c$c -o s -- python3 $R/bench.py --config $c --steps $steps --warmup 10 --no-cpu-baseline > $R/$O/stats_c$c.log 2>&1
 done
-declare -A RX=( [2]="raycast_kernel" [3]="integrate_dense" [5]="integrate_project" )
+declare -A RX=( [2]="raycast_kernel" [3]="integrate_dense" [5]="integrate_hash_kernel" )
 for c in 2 3 5; do
   for ctr in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --kernel-trace --pmc $ctr --kernel-include-regex "${RX[$c]}" --output-format csv -d $R/$O/pmc_c${c}_$ctr -o p -- python3 $R/bench.py --config $c --steps 20 --warmup 5 --no-cpu-baseline > $R/$O/pmc_c${c}_$ctr.log 2>&1
