@@ -272,6 +272,7 @@ class ITMViewBuilder_HIP {
 // of the previous frame; the gradient / Hessian reduction and the depth pyramid run on the GPU.
 class ITMDepthTracker_HIP {
   itm_tracker_config cfg;
+  itm_tracker* tracker = nullptr;     // this object's hierarchy + reduction buffers (ITMDepthTracker.cpp:18-44); one per tracker object
 
  public:
   itm_stream stream = nullptr;
@@ -280,13 +281,47 @@ class ITMDepthTracker_HIP {
     cfg.noHierarchyLevels = noHierarchyLevels;
     for (int i = 0; i < noHierarchyLevels && i < 8; ++i) cfg.trackingRegime[i] = trackingRegime[i];
     cfg.noICPRunTillLevel = noICPRunTillLevel; cfg.distThresh = distThresh; cfg.terminationThreshold = terminationThreshold;
+    check(itm_tracker_create(&tracker), "itm_tracker_create");
   }
+  ~ITMDepthTracker_HIP() { itm_tracker_destroy(tracker); }
+  ITMDepthTracker_HIP(const ITMDepthTracker_HIP&) = delete;
+  ITMDepthTracker_HIP& operator=(const ITMDepthTracker_HIP&) = delete;
   void TrackCamera(ITMTrackingState* trackingState, const ITMView* view) {
     itm_view v = make_view(view, trackingState);
     float M[16];
-    check(itm_track_camera(&cfg, &v, trackingState->pointCloud_locations, trackingState->pointCloud_colours,
-                           trackingState->pose_pointCloud.GetM(), M, stream), "TrackCamera");
+    check(itm_tracker_track_camera(tracker, &cfg, &v, trackingState->pointCloud_locations, trackingState->pointCloud_colours,
+                                   trackingState->pose_pointCloud.GetM(), M, stream), "TrackCamera");
     trackingState->pose_d.SetM(M);
+  }
+};
+
+// ITMMesh (Objects/ITMMesh.h:14-124): the triangle buffer lives in HBM; WriteOBJ / WriteSTL produce the reference's files.
+class ITMMesh {
+ public:
+  itm_mesh* handle = nullptr;
+  uint32_t noTotalTriangles = 0, noMaxTriangles = 0;
+  itm_stream stream = nullptr;
+  template <class TVoxel, class TIndex>
+  explicit ITMMesh(const ITMScene<TVoxel, TIndex>* scene, uint32_t maxTriangles = 0) {
+    check(itm_mesh_create(scene->handle, maxTriangles, &handle), "itm_mesh_create");
+    check(itm_mesh_info(handle, nullptr, &noMaxTriangles, nullptr, nullptr), "itm_mesh_info");
+  }
+  ~ITMMesh() { itm_mesh_destroy(handle); }
+  ITMMesh(const ITMMesh&) = delete;
+  ITMMesh& operator=(const ITMMesh&) = delete;
+  const float* triangles() const { const float* p = nullptr; check(itm_mesh_info(handle, nullptr, nullptr, &p, stream), "itm_mesh_info"); return p; }   // device pointer
+  void WriteOBJ(const char* fileName) const { check(itm_mesh_write_obj(handle, fileName, stream), "WriteOBJ"); }
+  void WriteSTL(const char* fileName) const { check(itm_mesh_write_stl(handle, fileName, stream), "WriteSTL"); }
+};
+
+// ITMMeshingEngine<TVoxel,TIndex>::MeshScene (Engine/ITMMeshingEngine.h:19-26)
+template <class TVoxel, class TIndex>
+class ITMMeshingEngine_HIP {
+ public:
+  itm_stream stream = nullptr;
+  void MeshScene(ITMMesh* mesh, const ITMScene<TVoxel, TIndex>* scene) {
+    check(itm_mesh_scene(scene->handle, mesh->handle, stream), "MeshScene");
+    check(itm_mesh_info(mesh->handle, &mesh->noTotalTriangles, nullptr, nullptr, stream), "itm_mesh_info");
   }
 };
 

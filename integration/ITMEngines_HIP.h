@@ -19,6 +19,7 @@
 
 #include "ITMLib/Engine/ITMSceneReconstructionEngine.h"
 #include "ITMLib/Engine/ITMVisualisationEngine.h"
+#include "ITMLib/Engine/ITMMeshingEngine.h"
 #include "itm_hip.h"
 
 namespace ITMLib {
@@ -284,6 +285,31 @@ class ITMVisualisationEngine_HIP : public ITMVisualisationEngine<TVoxel, TIndex>
     HipCheck(itm_download(Dev(), d, ITM_BUF_MISSING_POINTS, renderState->fwdProjMissingPoints->GetData(MEMORYDEVICE_CPU), px * 4, 0), "download");
     itm_counters c; HipCheck(itm_get_counters(Dev(), d, &c, 0), "get_counters");
     renderState->noFwdProjMissingPoints = c.noFwdProjMissingPoints;
+  }
+};
+
+
+// ITMMeshingEngine<TVoxel, TIndex> (Engine/ITMMeshingEngine.h:19-26) on the device scene twin: the mesh is built in HBM in the
+// reference's triangle order and mirrored into the reference's ITMMesh (triangles + noTotalTriangles), so WriteOBJ / WriteSTL of
+// the reference object work unchanged.
+template <class TVoxel, class TIndex>
+class ITMMeshingEngine_HIP : public ITMMeshingEngine<TVoxel, TIndex> {
+  itm_mesh* dev = nullptr;
+  const void* owner = nullptr;
+ public:
+  ~ITMMeshingEngine_HIP() { itm_mesh_destroy(dev); }
+  void MeshScene(ITMMesh* mesh, const ITMScene<TVoxel, TIndex>* scene) {
+    itm_scene* sc = HipSceneOf(scene);
+    if (!dev || owner != scene) {
+      itm_mesh_destroy(dev); dev = nullptr;
+      HipCheck(itm_mesh_create(sc, ITMMesh::noMaxTriangles, &dev), "itm_mesh_create");
+      owner = scene;
+    }
+    HipCheck(itm_mesh_scene(sc, dev, 0), "itm_mesh_scene");
+    uint32_t n = 0;
+    mesh->triangles->Clear();
+    HipCheck(itm_mesh_download(dev, (float*)mesh->triangles->GetData(MEMORYDEVICE_CPU), ITMMesh::noMaxTriangles, &n, 0), "itm_mesh_download");
+    mesh->noTotalTriangles = n;
   }
 };
 

@@ -12,6 +12,7 @@
 
 #include "ITMLib/Engine/DeviceSpecific/CPU/ITMSceneReconstructionEngine_CPU.cpp"
 #include "ITMLib/Engine/DeviceSpecific/CPU/ITMVisualisationEngine_CPU.cpp"
+#include "ITMLib/Engine/DeviceSpecific/CPU/ITMMeshingEngine_CPU.cpp"
 #include "ITMLib/Engine/DeviceSpecific/CPU/ITMDepthTracker_CPU.h"
 #include "ITMLib/Engine/DeviceSpecific/CPU/ITMLowLevelEngine_CPU.h"
 #include "ITMLib/Engine/DeviceSpecific/CPU/ITMViewBuilder_CPU.h"
@@ -23,6 +24,8 @@ using namespace ITMLib::Objects;
 
 template class ITMLib::Engine::ITMSceneReconstructionEngine_CPU<ITMVoxel_f_rgb, ITMVoxelBlockHash>;
 template class ITMLib::Engine::ITMVisualisationEngine_CPU<ITMVoxel_f_rgb, ITMVoxelBlockHash>;
+template class ITMLib::Engine::ITMMeshingEngine_CPU<ITMVoxel_f_rgb, ITMVoxelBlockHash>;
+template class ITMLib::Engine::ITMMeshingEngine_CPU<ITMVoxel_s, ITMPlainVoxelArray>;
 template class ITMLib::Engine::ITMSceneReconstructionEngine_CPU<ITMVoxel_s, ITMPlainVoxelArray>;
 template class ITMLib::Engine::ITMVisualisationEngine_CPU<ITMVoxel_s, ITMPlainVoxelArray>;
 
@@ -128,8 +131,19 @@ static bool run(const char* name, float voxelSize, int frames) {
     const Vector4f* p = ts[1]->pointCloud->locations->GetData(MEMORYDEVICE_CPU);
     for (int i = 0; i < W * H; ++i) hits += p[i].w > 0;
   }
-  std::printf("{\"config\": \"%s\", \"frames\": %d, \"equal\": %s, \"icp_points\": %lld, \"lastFreeBlockId\": %d, \"mismatch\": \"%s\"}\n", name, frames,
-              ok ? "true" : "false", hits, sceneB.localVBA.lastFreeBlockId, why.c_str());
+  long long triangles = -1;
+  if (ok) {
+    // ITMMainEngine::UpdateMesh: the reference's meshing engine on its scene vs the HIP one on the device twin, through the base class
+    ITMMeshingEngine<TVoxel, TIndex>* mesher[2] = {new ITMMeshingEngine_CPU<TVoxel, TIndex>(), new ITMMeshingEngine_HIP<TVoxel, TIndex>()};
+    ITMMesh* mesh[2] = {new ITMMesh(MEMORYDEVICE_CPU), new ITMMesh(MEMORYDEVICE_CPU)};
+    for (int e = 0; e < 2; ++e) mesher[e]->MeshScene(mesh[e], scene[e]);
+    triangles = mesh[1]->noTotalTriangles;
+    if (mesh[0]->noTotalTriangles != mesh[1]->noTotalTriangles) { ok = false; why = "noTotalTriangles"; }
+    else if (!same(mesh[0]->triangles->GetData(MEMORYDEVICE_CPU), mesh[1]->triangles->GetData(MEMORYDEVICE_CPU), (size_t)mesh[0]->noTotalTriangles)) { ok = false; why = "mesh triangles"; }
+    for (int e = 0; e < 2; ++e) { delete mesh[e]; delete mesher[e]; }
+  }
+  std::printf("{\"config\": \"%s\", \"frames\": %d, \"equal\": %s, \"icp_points\": %lld, \"lastFreeBlockId\": %d, \"triangles\": %lld, \"mismatch\": \"%s\"}\n", name, frames,
+              ok ? "true" : "false", hits, sceneB.localVBA.lastFreeBlockId, triangles, why.c_str());
   // teardown in the reference's order: render states, then engines (the HIP visualisation engine releases the scene twin)
   for (int e = 0; e < 2; ++e) { HipReleaseView(view[e]); delete rs[e]; delete view[e]; delete ts[e]; delete reco[e]; delete vis[e]; }
   return ok;

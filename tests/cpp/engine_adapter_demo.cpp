@@ -47,8 +47,18 @@ int main() {
   check(itm_stream_synchronize(nullptr), "sync");
   double sx = 0, sz = 0; long valid = 0;
   for (int i = 0; i < P; ++i) if (pts[4 * i + 3] > 0) { ++valid; sx += pts[4 * i]; sz += pts[4 * i + 2]; }
-  printf("{\"lastFreeBlockId\": %d, \"noVisibleEntries\": %d, \"valid\": %ld, \"sum_x\": %.9g, \"sum_z\": %.9g, \"age\": %d}\n",
-         c.lastFreeBlockId, c.noVisibleEntries, valid, sx, sz, ts.age_pointCloud);
+  // ITMMainEngine::UpdateMesh (Engine/ITMMainEngine.cpp:129-135): mesh the scene, read the triangles back
+  ITMMesh mesh(&scene);
+  ITMMeshingEngine_HIP<V, I> mesher;
+  mesher.MeshScene(&mesh, &scene);
+  std::vector<float> tri((size_t)mesh.noTotalTriangles * 9);
+  uint32_t n = 0;
+  check(itm_mesh_download(mesh.handle, tri.data(), mesh.noTotalTriangles, &n, nullptr), "mesh download");
+  double tz = 0;
+  for (size_t i = 2; i < tri.size(); i += 3) tz += tri[i];
+  printf("{\"lastFreeBlockId\": %d, \"noVisibleEntries\": %d, \"valid\": %ld, \"sum_x\": %.9g, \"sum_z\": %.9g, \"age\": %d, "
+         "\"triangles\": %u, \"maxTriangles\": %u, \"tri_sum_z\": %.9g}\n",
+         c.lastFreeBlockId, c.noVisibleEntries, valid, sx, sz, ts.age_pointCloud, mesh.noTotalTriangles, mesh.noMaxTriangles, tz);
   delete rs;
   itm_dev_free(dDepth); itm_dev_free(dPts); itm_dev_free(dNrm);
   return 0;

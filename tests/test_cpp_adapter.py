@@ -44,7 +44,11 @@ def oracle_expectation():
     c = s.counters(rs)
     p = pts.numpy()
     ok = p[:, 3] > 0
-    return {"lastFreeBlockId": c["lastFreeBlockId"], "noVisibleEntries": c["noVisibleEntries"], "valid": int(ok.sum()),
+    m = capi.Mesh(s)
+    m.MeshScene()
+    tri = m.triangles()
+    return {"triangles": int(tri.shape[0]), "maxTriangles": m.info()[1], "tri_sum_z": float(tri.reshape(-1, 3)[:, 2].astype(np.float64).sum()),
+            "lastFreeBlockId": c["lastFreeBlockId"], "noVisibleEntries": c["noVisibleEntries"], "valid": int(ok.sum()),
             "sum_x": float(p[ok, 0].astype(np.float64).sum()), "sum_z": float(p[ok, 2].astype(np.float64).sum())}
 
 
@@ -55,7 +59,8 @@ def test_adapter_matches_oracle():
     got = json.loads(out.strip().splitlines()[-1])
     want = oracle_expectation()
     assert got["age"] == 0   # -1 -> -2 -> 0, ITMTrackingController.cpp:37-38
-    for k in ("lastFreeBlockId", "noVisibleEntries", "valid"):
+    assert got["triangles"] > 1000
+    for k in ("lastFreeBlockId", "noVisibleEntries", "valid", "triangles", "maxTriangles"):
         assert got[k] == want[k], (k, got, want)
-    for k in ("sum_x", "sum_z"):
+    for k in ("sum_x", "sum_z", "tri_sum_z"):
         assert abs(got[k] - want[k]) <= 1e-6 * max(1.0, abs(want[k])), (k, got, want)
