@@ -277,6 +277,16 @@ __device__ inline void reduce_own_cells(const RangeFuse& f, int tx, int ty, int 
 // the same workgroup re-packs the parked rays 64 per wave: all lanes are then in the same phase, and the look-ahead of
 // march_ray turns the ~45 dependent round trips of the run into ~8.  (As a second LAUNCH over a global queue the parked rays
 // took 52 us on their own -- one wave per SIMD, other XCDs' cold L2s -- against 34 us for the first pass; measured, dropped.)
+#ifndef ITM_EXP_RAYCAST_STAMPS
+#define ITM_EXP_RAYCAST_STAMPS 0   // measurement build: per-wave timeline of the ray-cast launch on the 100 MHz clock (tools/raycast_timeline.py)
+#endif
+#if ITM_EXP_RAYCAST_STAMPS
+__device__ unsigned long long g_rayStamps[8192 * 4];   // per wave: start, after the prologue, end of phase 1, end of phase 2 | parked rays of the tile << 52
+#define ITM_RS(...) __VA_ARGS__
+#else
+#define ITM_RS(...)
+#endif
+
 template <class VX, bool DENSE, bool REDUCE, bool PARK>
 __global__ void __launch_bounds__(256) raycast_kernel(VolumeView vol, const float2* __restrict__ range, float4* __restrict__ out, RayParams p, RangeFuse fuse) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -293,6 +303,7 @@ __global__ void __launch_bounds__(256) raycast_kernel(VolumeView vol, const floa
   __shared__ int parkSource[PARK ? 256 : 1];     // the thread (= pixel of the tile) it belongs to
   __shared__ int parkCount;
   if (PARK && threadIdx.x == 0) parkCount = 0;
+  ITM_RS(unsigned long long* stamp = g_rayStamps + (size_t)((blockIdx.x * 4 + wave) & 8191) * 4; if (lane == 0) stamp[0] = __builtin_amdgcn_s_memrealtime();)
   float2 mm = make_float2(0.0f, 0.0f);
   if constexpr (REDUCE) {
     reduce_own_cells(fuse, tx, ty, p.W, cellRange);
@@ -302,6 +313,7 @@ __global__ void __launch_bounds__(256) raycast_kernel(VolumeView vol, const floa
     if (PARK) __syncthreads();
     if (inside) mm = range[(x >> 3) + (y >> 3) * p.W];  // floor(x/8) + floor(y/8)*W  (_CPU.cpp:174)
   }
+  ITM_RS(if (lane == 0) stamp[1] = __builtin_amdgcn_s_memrealtime();)
   // ---- phase 1: every ray of the tile; rays that turn out to be crossing empty space are parked ----
   bool parked = false;
   if (inside) {
@@ -313,6 +325,7 @@ __global__ void __launch_bounds__(256) raycast_kernel(VolumeView vol, const floa
       parkSource[slot] = (int)threadIdx.x;
     }
   }
+  ITM_RS(if (lane == 0) { stamp[2] = __builtin_amdgcn_s_memrealtime(); stamp[3] = 0; })
   if constexpr (PARK) {
     __syncthreads();
     // ---- phase 2: the parked rays, re-packed from lane 0 upwards ----
@@ -329,8 +342,12 @@ __global__ void __launch_bounds__(256) raycast_kernel(VolumeView vol, const floa
       bool again;
       out[qx + qy * p.W] = march_ray<VX, DENSE, ITM_RAY_PARKED_LOOKAHEAD, false>(qx, qy, vol, p, m2, &rr, again);
     }
+    ITM_RS(if (lane == 0) stamp[3] = __builtin_amdgcn_s_memrealtime() | ((unsigned long long)(wave == 0 ? n : 0) << 52);)
   }
 }
+#if ITM_EXP_RAYCAST_STAMPS
+extern "C" int itm_debug_read_raycast_stamps(unsigned long long* dst, int n) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_rayStamps), (size_t)n * 8); }
+#endif
 
 int launch_raycast(const itm_scene* s, const float* invM, const float* intr, itm_render_state* rs, float4* dst, hipStream_t st, bool reduceRange) {
   RayParams p; make_ray_params(s, invM, intr, rs->w, rs->h, p);
