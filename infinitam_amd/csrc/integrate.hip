@@ -12,6 +12,7 @@
 // persistent workgroups striding over the device-resident visible list, so no count is read back.
 // The dense kernel streams the volume with 16-byte accesses (4 ITMVoxel_s per lane) and writes
 // only 128-bit groups that changed.  The depth map is small (1.2 MB) and stays in L2.
+#include <cmath>
 #include <cstring>
 
 #include "itm_internal.h"
@@ -27,6 +28,7 @@ namespace itm {
 #endif
 int g_debug_integrate_wgs = 0;
 int g_debug_no_fused_projection = 0;
+int g_debug_dense_group_cull = 0;   // debug key 9: per-group frustum test instead of the per-column row interval
 
 struct FuseParams {
   Mat4 M_d, M_rgb;
@@ -310,9 +312,23 @@ __global__ void __launch_bounds__(256) integrate_dense_kernel(void* __restrict__
 // wave instruction; a group is written back only if one of its voxels changed.  blockIdx.y = z slice,
 // blockIdx.x splits the (y, x/4) plane; no 64-bit index division in the loop, two 16-byte loads in
 // flight per lane.
-template <bool POW2>
+// Frustum planes of a dense launch in VOXEL-INDEX space, computed by the host in double:
+//   g_k(xi, yi, zi) = a_k xi + b_k yi + cz_k zi + cm_k,   k = left, right, top, bottom, front
+// with cm_k = c_k + margin_k, so that g_k < 0 for a voxel implies that the exact float test of fuse_depth_project rejects it
+// (pc.z <= 0, or u / v outside [1, W-2] x [1, H-2]): margin_k = |a_k| + |b_k| (one voxel of slack along x and y) plus 1e-4 of
+// the magnitudes that enter g_k, three orders above the rounding of the float evaluation.  nb_k = -1 / b_k (0 when b_k == 0).
+struct ColumnCull {
+  double a[5], nb[5], cz[5], cm[5];
+  int kind[5];   // sign of b_k: +1 the plane bounds yi from below, -1 from above, 0 not at all (then g_k must be >= 0 as it is)
+};
+
+// CULL: 0 = per group with the exact arithmetic of two end voxels (any size); 1 = the rows [ylo, yhi] that can be inside the
+// frustum are computed ONCE per thread for its column of groups (every group a thread visits has the same x0 when the stride
+// is a multiple of the row length), the per-group test is then two integer comparisons.  Measured on BASELINE configs[2]
+// (512^3): the per-group test was ~40 % of the kernel's VALU work (70 instructions for each of 33.5 M groups).
+template <bool POW2, int CULL>
 __global__ void __launch_bounds__(256) integrate_dense_s_x4_kernel(uint4* __restrict__ vba, const float* __restrict__ depth, FuseParams p,
-                                                                   int sx, int sy, int sz, int ox, int oy, int oz, int log2sx4) {
+                                                                   int sx, int sy, int sz, int ox, int oy, int oz, int log2sx4, ColumnCull cc) {
   const int sx4 = sx >> 2;
   const int z = blockIdx.y;
   const int plane = sx4 * sy;                       // groups per z slice
@@ -364,6 +380,32 @@ __global__ void __launch_bounds__(256) integrate_dense_s_x4_kernel(uint4* __rest
                       ((aty < loy * a.z) && (bty < loy * b.z)) || ((aty > hiy * a.z) && (bty > hiy * b.z))));
   };
   int idx = blockIdx.x * 256 + threadIdx.x;
+  if constexpr (CULL == 1) {
+    // rows of this thread's column (x0 .. x0 + 3, slice z) that may be inside the frustum
+    const int x0 = (idx & (sx4 - 1)) * 4;
+    double ylo = -1e9, yhi = 1e9;
+    bool none = false;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      // the largest value g_k takes on the group: at x0 + 3 when a_k > 0, at x0 otherwise
+      const double t = __builtin_fma(cc.a[k], (double)(cc.a[k] > 0.0 ? x0 + 3 : x0), __builtin_fma(cc.cz[k], (double)z, cc.cm[k]));
+      if (cc.kind[k] > 0) ylo = fmax(ylo, t * cc.nb[k]);          // b_k yi + t >= 0  <=>  yi >= -t / b_k
+      else if (cc.kind[k] < 0) yhi = fmin(yhi, t * cc.nb[k]);     //                  <=>  yi <= -t / b_k   (b_k < 0)
+      else none |= t < 0.0;
+    }
+    const int rlo = none ? 0x7fffffff : (int)ceil(fmax(ylo, -1e9)), rhi = (int)floor(fmin(yhi, 1e9));
+    auto outside = [&](int i) { const int y = i >> log2sx4; return y < rlo || y > rhi; };
+    for (; idx + stride < plane; idx += 2 * stride) {
+      const bool c0 = outside(idx), c1 = outside(idx + stride);
+      uint4 q0, q1;
+      if (!c0) q0 = slice[idx];
+      if (!c1) q1 = slice[idx + stride];
+      if (!c0) process(idx, q0);
+      if (!c1) process(idx + stride, q1);
+    }
+    if (idx < plane && !outside(idx)) process(idx, slice[idx]);
+    return;
+  }
   for (; idx + stride < plane; idx += 2 * stride) {
     const bool c0 = culled(idx), c1 = culled(idx + stride);
     uint4 q0, q1;
@@ -373,6 +415,43 @@ __global__ void __launch_bounds__(256) integrate_dense_s_x4_kernel(uint4* __rest
     if (!c1) process(idx + stride, q1);
   }
   if (idx < plane && !culled(idx)) process(idx, slice[idx]);
+}
+
+// The five frustum planes of ColumnCull from the launch parameters; false when a coefficient is not finite (then the per-group
+// test runs).  pc_j = M[j] mx + M[j+4] my + M[j+8] mz + M[j+12] with m = (index + offset) * voxelSize is affine in the indices:
+//   left   fx pc_x - (1 - cx) pc_z >= 0      right   ((W - 2) - cx) pc_z - fx pc_x >= 0
+//   top    fy pc_y - (1 - cy) pc_z >= 0      bottom  ((H - 2) - cy) pc_z - fy pc_y >= 0      front  pc_z > 0
+static bool make_column_cull(const FuseParams& p, const int* size, const int* off, ColumnCull& cc) {
+  memset(&cc, 0, sizeof cc);
+  const double vs = p.voxelSize;
+  double Ax[3], Ay[3], Az[3], C[3];
+  for (int j = 0; j < 3; ++j) {
+    const double m0 = p.M_d.m[j], m1 = p.M_d.m[j + 4], m2 = p.M_d.m[j + 8], m3 = p.M_d.m[j + 12];
+    Ax[j] = m0 * vs; Ay[j] = m1 * vs; Az[j] = m2 * vs;
+    C[j] = (m0 * off[0] + m1 * off[1] + m2 * off[2]) * vs + m3;
+  }
+  const double lox = 1.0 - (double)p.cx, hix = (double)(p.W - 2) - (double)p.cx, loy = 1.0 - (double)p.cy, hiy = (double)(p.H - 2) - (double)p.cy;
+  const double fx = p.fx, fy = p.fy;
+  // plane k as weights (wx, wy, wz) on (pc_x, pc_y, pc_z)
+  const double w[5][3] = {{fx, 0, -lox}, {-fx, 0, hix}, {0, fy, -loy}, {0, -fy, hiy}, {0, 0, 1}};
+  for (int k = 0; k < 5; ++k) {
+    const double a = w[k][0] * Ax[0] + w[k][1] * Ax[1] + w[k][2] * Ax[2];
+    const double b = w[k][0] * Ay[0] + w[k][1] * Ay[1] + w[k][2] * Ay[2];
+    const double cz = w[k][0] * Az[0] + w[k][1] * Az[1] + w[k][2] * Az[2];
+    const double c = w[k][0] * C[0] + w[k][1] * C[1] + w[k][2] * C[2];
+    // magnitudes that enter g_k (not their sum, which may cancel)
+    double mag = 0.0;
+    for (int j = 0; j < 3; ++j)
+      mag += fabs(w[k][j]) * (fabs(Ax[j]) * size[0] + fabs(Ay[j]) * size[1] + fabs(Az[j]) * size[2] +
+                              (fabs((double)p.M_d.m[j] * off[0]) + fabs((double)p.M_d.m[j + 4] * off[1]) + fabs((double)p.M_d.m[j + 8] * off[2])) * vs + fabs((double)p.M_d.m[j + 12]));
+    const double margin = fabs(a) + fabs(b) + 1e-4 * mag;
+    if (!std::isfinite(a) || !std::isfinite(b) || !std::isfinite(cz) || !std::isfinite(c) || !std::isfinite(margin)) return false;
+    cc.a[k] = a; cc.cz[k] = cz; cc.cm[k] = c + margin;
+    cc.kind[k] = (b > 0.0) ? 1 : (b < 0.0) ? -1 : 0;
+    cc.nb[k] = (b != 0.0) ? -1.0 / b : 0.0;
+    if (!std::isfinite(cc.nb[k])) { cc.kind[k] = 0; cc.nb[k] = 0.0; cc.cm[k] += fabs(b) * size[1]; }   // a slope too small to divide by: let the plane pass
+  }
+  return true;
 }
 
 // `fuseProjection`: also run the projection half of CreateExpectedDepths (hash scenes whose sub-sampled range image
@@ -430,8 +509,11 @@ int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipS
       if (splits > 64) splits = 64;
       if (splits < 1) splits = 1;
       const dim3 grid(splits, sz[2]);
-      if (pow2) integrate_dense_s_x4_kernel<true><<<grid, 256, 0, st>>>((uint4*)s->vba, v->depth, p, sz[0], sz[1], sz[2], of[0], of[1], of[2], lg);
-      else integrate_dense_s_x4_kernel<false><<<grid, 256, 0, st>>>((uint4*)s->vba, v->depth, p, sz[0], sz[1], sz[2], of[0], of[1], of[2], lg);
+      ColumnCull cc;
+      const bool columns = pow2 && ((splits * 256) % sx4) == 0 && !g_debug_dense_group_cull && make_column_cull(p, sz, of, cc);
+      if (columns) integrate_dense_s_x4_kernel<true, 1><<<grid, 256, 0, st>>>((uint4*)s->vba, v->depth, p, sz[0], sz[1], sz[2], of[0], of[1], of[2], lg, cc);
+      else if (pow2) integrate_dense_s_x4_kernel<true, 0><<<grid, 256, 0, st>>>((uint4*)s->vba, v->depth, p, sz[0], sz[1], sz[2], of[0], of[1], of[2], lg, cc);
+      else integrate_dense_s_x4_kernel<false, 0><<<grid, 256, 0, st>>>((uint4*)s->vba, v->depth, p, sz[0], sz[1], sz[2], of[0], of[1], of[2], lg, cc);
     } else {
       int rc = dispatch_voxel(s->cfg.voxelType, [&](auto vx) {
         using VX = decltype(vx);
