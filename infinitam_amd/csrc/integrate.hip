@@ -190,60 +190,108 @@ __device__ inline bool fuse_voxel(typename VX::Reg& r, float mx, float my, float
   return touched;
 }
 
-// Two ways of dealing the visible blocks to the persistent workgroups:
-//  * static striding (block e to workgroup e mod G): no synchronisation at all, the eight waves of a workgroup drift freely;
-//  * dynamic queues when there are many blocks per workgroup (>= kDynamicBlocksPerGroup, e.g. BASELINE configs[4]: 54 k colour
-//    blocks whose cost varies with the share of voxels inside the colour band): 8 queues (queue q owns the list positions
-//    q, q + 8, ...), a workgroup starts on queue blockIdx % 8 and moves on when a queue is empty; the next position is
-//    requested before the current block is processed.  Measured: config 5 integrate 243 -> 221 us.  With few blocks per
-//    workgroup (config 2: 12) the per-block barrier costs more than the balance gains (24 -> 44 us with 8 queues, whose heads
-//    also saturate at ~88 dequeues per us and word), so the kernel picks per launch.
-constexpr int kIntegrateQueues = 8;    // measured on config 5: 8 queues 221 us, 64 queues 263 us, static striding 243 us
-constexpr int kDynamicBlocksPerGroup = 24;
+// Work item = kSlices consecutive z-slices of one visible block, done by ONE WAVE: lane <-> (x, y), one 64-voxel run per slice.
+// The persistent waves stride over the items (item i = block i / (8 / kSlices), slice group i % (8 / kSlices)), so the waves of a
+// workgroup sit on the same block or its list neighbours, and no wave ever waits for another.
+//
+// Why a wave and not a workgroup per block (rounds 1 and 2 until here: 512 lanes on one block, one voxel per lane): the counters
+// (profiles/r2_integrate_counters.md) show the hash kernels at 43-46 % VALU utilisation with waves waiting 62-80 % of their time:
+// every block costs a chain of dependent round trips -- list position -> hash entry -> voxels -> depth pixel (-> colour pixels) ->
+// store -- and a wave had just 64 voxels (256-768 B) in flight along it.  32 waves x 768 B per CU over ~2 us of loaded latency is
+// 3.1 TB/s for the whole chip, which is exactly what BASELINE configs[4] measured.  Here a wave has kSlices runs in flight at once
+// (their loads are issued together, then the projections, then the depth gathers together), the entry of its NEXT item is
+// requested before it starts on the current one, and the x / y partial sums of the projection are shared by the slices.
+// (Two x-neighbours per lane with packed fp32 arithmetic -- v_pk_mul / add / fma_f32, bit-exact -- was built and measured first:
+// -8 % VALU instructions, but +5 % time; the kernels are not VALU bound.)
+#ifndef ITM_INTEGRATE_SLICES
+#define ITM_INTEGRATE_SLICES 4
+#endif
+constexpr int kSlices = ITM_INTEGRATE_SLICES;
+constexpr int kItemsPerBlock = kBlockSide / kSlices;
+static_assert(kSlices == 1 || kSlices == 2 || kSlices == 4 || kSlices == 8, "slice groups tile the block");
+
+#ifndef ITM_INTEGRATE_PREFETCH
+// 1: the voxel runs of the wave's NEXT item are requested right behind the depth gathers of the current one.  Measured: BASELINE
+// configs[4] 189 -> 198 us (the second register set costs a wave of occupancy, 76 -> 92 VGPRs), configs[1] +-0.  Off.
+#define ITM_INTEGRATE_PREFETCH 0
+#endif
 
 template <class VX>
-__device__ inline void integrate_block(const HashEntry& he, int t, void* __restrict__ vba, const float* __restrict__ depth,
-                                       const uchar4* __restrict__ rgb, const FuseParams& p) {
-  if (he.ptr < 0) return;
-  const int x = t & 7, y = (t >> 3) & 7, z = t >> 6;
-  const size_t vi = (size_t)he.ptr * kBlockVoxels + t;
-  typename VX::Reg r = VX::load(vba, vi);
-  if (p.stopAtMax && VX::w_depth(r) == p.maxW) return;
+__device__ inline void load_item(const HashEntry& he, int z0, int lane, const void* __restrict__ vba, typename VX::Reg r[kSlices]) {
+  const size_t vi = (size_t)(he.ptr < 0 ? 0 : he.ptr) * kBlockVoxels + (size_t)z0 * 64 + lane;      // block 0 is always there
+#pragma unroll
+  for (int k = 0; k < kSlices; ++k) r[k] = VX::load(vba, vi + 64 * k);
+}
+
+// r: the item's voxels (already requested).  hasNext / next / nextR: the voxel runs of the following item are requested right
+// behind the depth gathers -- the wave then waits for those gathers only (the memory counter retires in issue order), and the new
+// runs travel while this item is updated and stored.
+template <class VX>
+__device__ inline void integrate_item(const HashEntry& he, int z0, int lane, typename VX::Reg r[kSlices], void* __restrict__ vba,
+                                      const float* __restrict__ depth, const uchar4* __restrict__ rgb, const FuseParams& p,
+                                      bool hasNext, const HashEntry& next, int nextZ0, typename VX::Reg nextR[kSlices]) {
+  const bool present = he.ptr >= 0;
+  const int x = lane & 7, y = lane >> 3;
+  const size_t vi = (size_t)(present ? he.ptr : 0) * kBlockVoxels + (size_t)z0 * 64 + lane;
   const float mx = (float)(he.px * kBlockSide + x) * p.voxelSize;
   const float my = (float)(he.py * kBlockSide + y) * p.voxelSize;
-  const float mz = (float)(he.pz * kBlockSide + z) * p.voxelSize;
-  if (fuse_voxel<VX>(r, mx, my, mz, depth, rgb, p)) VX::store(vba, vi, r);
+  // stage 1: project every slice's voxel; stage 2: all depth pixels together; stage 3: update (+ colour), store what changed
+  int pix[kSlices];
+  float pcz[kSlices], mz[kSlices];
+#pragma unroll
+  for (int k = 0; k < kSlices; ++k) {
+    mz[k] = (float)(he.pz * kBlockSide + z0 + k) * p.voxelSize;
+    pix[k] = -2;                                                            // -2: voxel skipped altogether (no block / stopIntegratingAtMaxW)
+    if (!present || (p.stopAtMax && VX::w_depth(r[k]) == p.maxW)) continue;
+    pix[k] = fuse_depth_project(mx, my, mz[k], p, pcz[k]);
+  }
+  float dm[kSlices];
+#pragma unroll
+  for (int k = 0; k < kSlices; ++k) dm[k] = depth[pix[k] >= 0 ? pix[k] : 0];
+  if (hasNext) load_item<VX>(next, nextZ0, lane, vba, nextR);
+#pragma unroll
+  for (int k = 0; k < kSlices; ++k) {
+    if (pix[k] == -2) continue;
+    bool touched = false;
+    const float eta = (pix[k] >= 0) ? fuse_depth_update<VX>(r[k], dm[k], pcz[k], p, touched) : -1.0f;
+    if constexpr (VX::kColor) {
+      if (!((eta > p.mu) || (fabsf(eta / p.mu) > 0.25f))) {
+        fuse_colour<VX>(r[k], mx, my, mz[k], rgb, p);
+        touched = true;
+      }
+    }
+    if (touched) VX::store(vba, vi + 64 * k, r[k]);
+  }
 }
 
 template <class VX>
 __device__ inline void integrate_hash_body(int wgIdx, int wgCount, const int32_t* __restrict__ visibleIds, RenderCounters* __restrict__ rc,
                                            const uint4* __restrict__ hash, void* __restrict__ vba,
                                            const float* __restrict__ depth, const uchar4* __restrict__ rgb, const FuseParams& p) {
-  __shared__ int nextSlot[2];
-  const int nv = rc->noVisibleEntries;
-  const int t = threadIdx.x;
-  if (nv < kDynamicBlocksPerGroup * wgCount) {
-    for (int e = wgIdx; e < nv; e += wgCount) integrate_block<VX>(unpack_entry(hash[visibleIds[e]]), t, vba, depth, rgb, p);
-    return;
-  }
-  int queue = wgIdx & (kIntegrateQueues - 1), tried = 0;
-  // fetch(): lane 0 takes the next position of the current queue; -1 once all queues are empty
-  auto fetch = [&]() -> int {
-    for (; tried < kIntegrateQueues; ++tried, queue = (queue + 1) & (kIntegrateQueues - 1)) {
-      const int k = atomicAdd(&rc->integrateHeads[16 * queue], 1);
-      const int e = queue + kIntegrateQueues * k;
-      if (e < nv) return e;
-    }
-    return -1;
-  };
-  if (t == 0) nextSlot[0] = fetch();
-  __syncthreads();
-  int e = nextSlot[0];
-  for (int it = 0; e >= 0; ++it) {
-    if (t == 0) nextSlot[(it + 1) & 1] = fetch();      // in flight while this block is processed
-    integrate_block<VX>(unpack_entry(hash[visibleIds[e]]), t, vba, depth, rgb, p);
-    __syncthreads();
-    e = nextSlot[(it + 1) & 1];
+  const int nItems = rc->noVisibleEntries * kItemsPerBlock;
+  const int lane = threadIdx.x & 63;
+  const int waves = wgCount * (int)(blockDim.x >> 6);
+  int i = __builtin_amdgcn_readfirstlane(wgIdx * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6));
+  if (i >= nItems) return;
+  HashEntry cur = unpack_entry(hash[visibleIds[i / kItemsPerBlock]]);
+  typename VX::Reg r[kSlices], rn[kSlices];
+  load_item<VX>(cur, (i % kItemsPerBlock) * kSlices, lane, vba, r);
+  for (;;) {
+    const int nxt = i + waves;
+    const bool more = nxt < nItems;
+    HashEntry ahead = cur;
+    if (more) ahead = unpack_entry(hash[visibleIds[nxt / kItemsPerBlock]]);
+    const int zn = (nxt % kItemsPerBlock) * kSlices;
+#if ITM_INTEGRATE_PREFETCH
+    integrate_item<VX>(cur, (i % kItemsPerBlock) * kSlices, lane, r, vba, depth, rgb, p, more, ahead, zn, rn);
+#else
+    integrate_item<VX>(cur, (i % kItemsPerBlock) * kSlices, lane, r, vba, depth, rgb, p, false, ahead, 0, rn);
+    if (more) load_item<VX>(ahead, zn, lane, vba, rn);
+#endif
+    if (!more) break;
+    cur = ahead; i = nxt;
+#pragma unroll
+    for (int k = 0; k < kSlices; ++k) r[k] = rn[k];
   }
 }
 
@@ -478,8 +526,9 @@ int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipS
 
   KernelTimer tk(s, ITM_TK_INTEGRATE, st);
   if (s->cfg.indexType == ITM_INDEX_HASH) {
-    // 4 x 512-lane workgroups per CU; with the projection fused in, the 38 KB LDS image limits residency to 3 per CU
-    const int grid = g_debug_integrate_wgs > 0 ? g_debug_integrate_wgs : (fuseProjection ? 256 * 3 : 256 * 4);
+    // 4096 workgroups of 8 waves: more waves than the chip holds at once, so that the dispatcher evens out what the static striding
+    // does not (measured, configs[4] / configs[1]: 768-1024 workgroups 189 / 21.3 us, 2048: 175 / 20.3, 4096: 170 / 20.4)
+    const int grid = g_debug_integrate_wgs > 0 ? g_debug_integrate_wgs : 4096;
     ProjParams pp;
     const int RW = (rs->w + 7) / 8, RH = (rs->h + 7) / 8;
     if (fuseProjection) {
@@ -487,7 +536,7 @@ int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipS
       pp.fx = v->intr_d[0]; pp.fy = v->intr_d[1]; pp.cx = v->intr_d[2]; pp.cy = v->intr_d[3];
       pp.voxelSize = s->prm.voxelSize; pp.W = rs->w; pp.H = rs->h; pp.maxBlocks = s->cfg.maxRenderingBlocks;
     }
-    if (!queuesZeroed) ITM_HIP(hipMemsetAsync(rs->counters->integrateHeads, 0, sizeof(rs->counters->integrateHeads), st));
+    (void)queuesZeroed;   // (the work queues of the workgroup-per-block kernel are gone)
     int rc = dispatch_voxel(s->cfg.voxelType, [&](auto vx) {
       using VX = decltype(vx);
       if (fuseProjection)

@@ -27,7 +27,7 @@ struct RenderCounters {
   int32_t rawVisibleCount;         // visible slots before clamping to the list capacity
   int32_t renderingBlocksAccepted; // -1, or the count after the cap replay when noRenderingBlocks reached MAX_RENDERING_BLOCKS
   int32_t pad[2];
-  // work queues of the hash integration (integrate.hip): next visible-list position of queue q is q + 8 * integrateHeads[16 q] (8 queues in use)
+  // (unused since the hash integration deals its work statically, one wave per slice group; kept so that the layout of the counters stays put)
   // (one head per 64-byte line); zeroed before every integration launch
   int32_t integrateHeads[64 * 16];
 };

@@ -1,11 +1,15 @@
 #!/bin/bash
-# usage: tools/build_variant.sh <name> "<extra hipcc flags>"  -> gpurun_variants/lib_<name>.so
-# Only the visualisation objects are rebuilt with the extra flags; the rest is linked from the in-tree build.
+# usage: tools/build_variant.sh <name> "<extra hipcc flags>" [source stem, default visualise]  -> gpurun_variants/lib_<name>.so
+# Only the named object is rebuilt with the extra flags; the rest is linked from the in-tree build.
 set -e
 cd "$(dirname "$0")/../infinitam_amd/csrc"
-name=$1; extra=$2
+name=$1; extra=$2; stem=${3:-visualise}
 obj=/tmp/itm_variant_$name; mkdir -p $obj ../../gpurun_variants
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math $extra"
-/opt/rocm/bin/hipcc $FL -c visualise.hip -o $obj/visualise.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../gpurun_variants/lib_$name.so scene.o alloc.o integrate.o $obj/visualise.o visualise_aux.o tracker.o viewbuilder.o io.o meshing.o
+/opt/rocm/bin/hipcc $FL -c $stem.hip -o $obj/$stem.o
+objs=""
+for f in scene alloc integrate visualise visualise_aux tracker viewbuilder io meshing; do
+  if [ $f = $stem ]; then objs="$objs $obj/$f.o"; else objs="$objs $f.o"; fi
+done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../gpurun_variants/lib_$name.so $objs
 echo built lib_$name.so
