@@ -68,6 +68,8 @@ def parse():
                     help="frames per all-gather; 1 = every frame (measured on MI355X through torch.distributed: per-frame costs 24 percent of the frame rate, the host-side collective call being the bound; 8 costs 5 percent, see DESIGN.md section 6)")
     ap.add_argument("--streams-per-gpu", type=int, default=1,
                     help="independent scenes co-scheduled on one GPU, each on its own HIP stream (separate figure; headline is 1)")
+    ap.add_argument("--no-host-threads", dest="host_threads", action="store_false",
+                    help="feed the k streams of --streams-per-gpu from one host thread instead of one thread per stream")
     ap.add_argument("--lib", default=None, help="alternative shared library exporting the same C-ABI (tests: a host-memory backend)")
     ap.add_argument("--lib-prefix", default="itm_")
     return ap.parse_args()
@@ -206,15 +208,45 @@ def worker(args) -> int:
         from infinitam_amd.streams import VisibleListExchange
         exs = [VisibleListExchange(be, world, rank, MAX_IDS, device=device, batch=max(1, args.exchange_batch)) for _ in streams]
 
+    def step_stream(j, k):
+        s = streams[j]
+        i = k % s.nd
+        rc = fn(s.sh, C.byref(s.views[i]), s.rh, s.pp, s.np_, s.sp)
+        if rc:
+            be.check(rc, "process_frame")
+        if exchange:
+            # record copy on the frame stream, all-gather on a side stream (off the critical path)
+            exs[j].step(s.rs.h, s.poses_c[i], s.hip_stream)
+
     def step(k):
-        for j, s in enumerate(streams):
-            i = k % s.nd
-            rc = fn(s.sh, C.byref(s.views[i]), s.rh, s.pp, s.np_, s.sp)
-            if rc:
-                be.check(rc, "process_frame")
-            if exchange:
-                # record copy on the frame stream, all-gather on a side stream (off the critical path)
-                exs[j].step(s.rs.h, s.poses_c[i], s.hip_stream)
+        for j in range(len(streams)):
+            step_stream(j, k)
+
+    def run(first, last):
+        """Frames [first, last) of every stream.  With k > 1 streams per GPU each stream is fed by its own host thread (the
+        library call releases the GIL): one thread issues ~6 launches per frame at ~10 us each, which is what bounded k = 4."""
+        if len(streams) == 1 or exchange or not args.host_threads:
+            for k in range(first, last):
+                step(k)
+            return
+        import threading
+        errors = []
+
+        def feed(j):
+            try:
+                if on_gpu:
+                    torch.cuda.set_device(local_rank)
+                for k in range(first, last):
+                    step_stream(j, k)
+            except BaseException as e:      # noqa: BLE001 -- re-raised on the main thread
+                errors.append(e)
+        threads = [threading.Thread(target=feed, args=(j,)) for j in range(len(streams))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
 
     def sync():
         if on_gpu:
@@ -227,16 +259,14 @@ def worker(args) -> int:
         sync()
 
     sync()
-    for k in range(args.warmup):
-        step(k)
+    run(0, args.warmup)
     barrier()
     timed_kernel = TK[wl["kernel"]]
     if rank == 0 and product:
         streams[0].scene.profile_read(reset=True)
         streams[0].scene.profile_enable(1 << timed_kernel)   # two hipEventRecord per frame around the roofline kernel
     t0 = time.perf_counter()
-    for k in range(args.warmup, args.warmup + args.steps):
-        step(k)
+    run(args.warmup, args.warmup + args.steps)
     barrier()
     elapsed_local = time.perf_counter() - t0
     elapsed = elapsed_local
@@ -271,6 +301,7 @@ def worker(args) -> int:
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" if product else "synthetic; ALTERNATIVE BACKEND (--lib) -- control-flow check, not a measurement of the product",
             "config": {"workload": wl["name"], "streams": world * k_streams, "streams_per_gpu": k_streams,
+                       "host_threads": (k_streams if (k_streams > 1 and args.host_threads and not exchange) else 1),
                        "world_size_seen": (dist.get_world_size() if dist.is_initialized() else 1), "collective_backend": backend_name,
                        "exchange": (f"all_gather of {17 + MAX_IDS}-word visible-block records, {max(1, args.exchange_batch)} frame(s) per collective, side stream"
                                     if exchange else "none"),

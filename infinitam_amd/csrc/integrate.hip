@@ -284,14 +284,15 @@ __device__ inline void integrate_hash_body(int wgIdx, int wgCount, const int32_t
     const int zn = (nxt % kItemsPerBlock) * kSlices;
 #if ITM_INTEGRATE_PREFETCH
     integrate_item<VX>(cur, (i % kItemsPerBlock) * kSlices, lane, r, vba, depth, rgb, p, more, ahead, zn, rn);
-#else
-    integrate_item<VX>(cur, (i % kItemsPerBlock) * kSlices, lane, r, vba, depth, rgb, p, false, ahead, 0, rn);
-    if (more) load_item<VX>(ahead, zn, lane, vba, rn);
-#endif
     if (!more) break;
-    cur = ahead; i = nxt;
 #pragma unroll
     for (int k = 0; k < kSlices; ++k) r[k] = rn[k];
+#else
+    integrate_item<VX>(cur, (i % kItemsPerBlock) * kSlices, lane, r, vba, depth, rgb, p, false, ahead, 0, rn);
+    if (!more) break;
+    load_item<VX>(ahead, zn, lane, vba, r);
+#endif
+    cur = ahead; i = nxt;
   }
 }
 
@@ -308,7 +309,7 @@ __global__ void __launch_bounds__(512) integrate_hash_kernel(const int32_t* __re
 // kRangeParts workgroups project, the others are the persistent integration workgroups.
 #if ITM_EXP_FUSED_STAMPS
 // measurement build: per-workgroup start / end of the fused launch on the constant-rate global clock (100 MHz)
-__device__ unsigned long long g_fusedStamps[2048 * 2];
+__device__ unsigned long long g_fusedStamps[8192 * 2];
 #define ITM_FS(...) __VA_ARGS__
 #else
 #define ITM_FS(...)
@@ -320,7 +321,7 @@ __global__ void __launch_bounds__(512) integrate_project_kernel(const int32_t* _
                                                                 float2* __restrict__ range, uint4* __restrict__ projBuf, uint2* __restrict__ partials,
                                                                 ProjParams pp, int RW, int RH) {
   extern __shared__ uint2 cells[];
-  ITM_FS(if (threadIdx.x == 0 && blockIdx.x < 2048) g_fusedStamps[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();)
+  ITM_FS(if (threadIdx.x == 0 && blockIdx.x < 8192) g_fusedStamps[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();)
   if (blockIdx.x < kRangeParts) {
     // the few projection workgroups share their CUs with integration workgroups and would otherwise be the last to finish
     // (21.8 us fused against 15.7 us for the integration alone): let their waves win the issue arbitration
@@ -328,10 +329,11 @@ __global__ void __launch_bounds__(512) integrate_project_kernel(const int32_t* _
     __builtin_amdgcn_s_setprio(3);
 #endif
     project_partial_body(blockIdx.x, cells, visibleIds, rc, hash, range, projBuf, partials, pp, RW, RH);
+    ITM_FS(__syncthreads(); if (threadIdx.x == 0) g_fusedStamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();)
     return;
   }
   integrate_hash_body<VX>(blockIdx.x - kRangeParts, gridDim.x - kRangeParts, visibleIds, rc, hash, vba, depth, rgb, p);
-  ITM_FS(__syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 2048) g_fusedStamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();)
+  ITM_FS(__syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 8192) g_fusedStamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();)
 }
 #if ITM_EXP_FUSED_STAMPS
 extern "C" int itm_debug_read_fused_stamps(unsigned long long* dst, int n) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_fusedStamps), (size_t)n * 8); }
@@ -526,9 +528,11 @@ int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipS
 
   KernelTimer tk(s, ITM_TK_INTEGRATE, st);
   if (s->cfg.indexType == ITM_INDEX_HASH) {
-    // 4096 workgroups of 8 waves: more waves than the chip holds at once, so that the dispatcher evens out what the static striding
-    // does not (measured, configs[4] / configs[1]: 768-1024 workgroups 189 / 21.3 us, 2048: 175 / 20.3, 4096: 170 / 20.4)
-    const int grid = g_debug_integrate_wgs > 0 ? g_debug_integrate_wgs : 4096;
+    // 2048 workgroups of 8 waves: more waves than the chip holds at once (768-1024 workgroups), so that the dispatcher evens out what
+    // the static striding does not, but few enough that most waves have work -- a workgroup without any still holds a slot for ~1 us
+    // (measured, configs[4] / configs[1]: 768-1024 workgroups 189 / 21.3 us, 1536: 177 / 19.9, 2048: 175 / 20.3, 4096: 170 / 20.4,
+    // where the last workgroup of configs[1] only STARTS after 15 us)
+    const int grid = g_debug_integrate_wgs > 0 ? g_debug_integrate_wgs : 2048;
     ProjParams pp;
     const int RW = (rs->w + 7) / 8, RH = (rs->h + 7) / 8;
     if (fuseProjection) {
