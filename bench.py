@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--force-exchange", action="store_true", help="run the all-gather path even with one rank (self-test)")
     ap.add_argument("--exchange-batch", type=int, default=8,
                     help="frames per all-gather; 1 = every frame (measured on MI355X through torch.distributed: per-frame costs 24 percent of the frame rate, the host-side collective call being the bound; 8 costs 5 percent, see DESIGN.md section 6)")
+    ap.add_argument("--exchange-impl", choices=["library", "torch"], default="library",
+                    help="who issues the collective: the library (RCCL from C++) or torch.distributed (always used by the CPU self-tests)")
     ap.add_argument("--streams-per-gpu", type=int, default=1,
                     help="independent scenes co-scheduled on one GPU, each on its own HIP stream (separate figure; headline is 1)")
     ap.add_argument("--no-host-threads", dest="host_threads", action="store_false",
@@ -159,6 +161,11 @@ def worker(args) -> int:
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with matching values", file=sys.stderr)
         return 2
+    # stdout carries ONE line, the JSON of rank 0.  RCCL prints a version banner through C stdio when a communicator is created:
+    # from here on file descriptor 1 is stderr for everything (C libraries and Python alike), the JSON goes to the saved descriptor.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     import numpy as np  # noqa: F401
     import torch
     import torch.distributed as dist
@@ -204,7 +211,21 @@ def worker(args) -> int:
 
     exchange = (world > 1 and not args.no_exchange) or args.force_exchange
     exs = []
-    if exchange:
+    # the exchange is issued by the library (RCCL called from C++, infinitam_amd/csrc/exchange.hip) whenever the product runs with one
+    # GPU per rank; the torch.distributed path remains for the CPU / shared-GPU self-tests and for --exchange-impl torch
+    native = exchange and product and on_gpu and not shared and args.exchange_impl == "library"
+    if exchange and native:
+        from infinitam_amd.streams import NativeExchange
+        for _ in streams:
+            uid = None
+            if world > 1:
+                t = torch.zeros(128, dtype=torch.uint8, device=device)
+                if rank == 0:
+                    t.copy_(torch.tensor(list(NativeExchange.unique_id(be)), dtype=torch.uint8))
+                dist.broadcast(t, 0)
+                uid = bytes(t.cpu().tolist())
+            exs.append(NativeExchange(be, world, rank, MAX_IDS, batch=max(1, args.exchange_batch), unique_id=uid))
+    elif exchange:
         from infinitam_amd.streams import VisibleListExchange
         exs = [VisibleListExchange(be, world, rank, MAX_IDS, device=device, batch=max(1, args.exchange_batch)) for _ in streams]
 
@@ -303,7 +324,8 @@ def worker(args) -> int:
             "config": {"workload": wl["name"], "streams": world * k_streams, "streams_per_gpu": k_streams,
                        "host_threads": (k_streams if (k_streams > 1 and args.host_threads and not exchange) else 1),
                        "world_size_seen": (dist.get_world_size() if dist.is_initialized() else 1), "collective_backend": backend_name,
-                       "exchange": (f"all_gather of {17 + MAX_IDS}-word visible-block records, {max(1, args.exchange_batch)} frame(s) per collective, side stream"
+                       "exchange": (f"all_gather of {17 + MAX_IDS}-word visible-block records, {max(1, args.exchange_batch)} frame(s) per collective, side stream, "
+                                    + ("issued by the library (RCCL from C++)" if native else "issued through torch.distributed")
                                     if exchange else "none"),
                        "per_rank_fps_min_max": fps_minmax,
                        "visible_blocks_last_frame": counters["noVisibleEntries"],
@@ -314,11 +336,10 @@ def worker(args) -> int:
     if dist.is_initialized():
         dist.destroy_process_group()
     if rank == 0:
-        # RCCL prints its version banner through C stdio, which a pipe only delivers at exit: flush it first so that the
-        # JSON line is the last line on stdout
         C.CDLL(None).fflush(None)
         sys.stdout.flush()
-        print(json.dumps(out), flush=True)
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     return 0
 
 

@@ -413,6 +413,22 @@ int ITM_FN(mesh_download)(const itm_mesh* mesh, float* dst_host, uint32_t capaci
 int ITM_FN(mesh_write_obj)(const itm_mesh* mesh, const char* path, itm_stream stream);
 int ITM_FN(mesh_write_stl)(const itm_mesh* mesh, const char* path, itm_stream stream);
 
+/* ---- multi-stream exchange (BASELINE configs[3]) ------------------------------------------------------------------
+ * One depth stream per GPU; fusion needs no collective.  Per frame every rank publishes the record of itm_export_visible_record
+ * ({M_d[16], noVisibleEntries, ids[max_ids]}); every `batch` frames the records are all-gathered with RCCL on a side stream owned by
+ * the exchange, so that each rank holds the pose and the live block list of every stream (input of a shared-map merger).  The frame
+ * stream never waits for a collective of the current batch.  RCCL is loaded on first use (dlopen); with world == 1 a device copy
+ * stands in for the collective.  Bootstrap: rank 0 calls itm_exchange_unique_id, the host hands the 128 bytes to every rank. */
+typedef struct itm_exchange itm_exchange;
+int ITM_FN(exchange_unique_id)(unsigned char id[128]);
+int ITM_FN(exchange_create)(int world, int rank, const unsigned char id[128], int max_ids, int batch, itm_exchange** out);
+int ITM_FN(exchange_destroy)(itm_exchange* exchange);
+/* frame f of this rank's stream: record copy on `frame_stream`; on the last frame of a batch also the collective (side stream) */
+int ITM_FN(exchange_step)(itm_exchange* exchange, const itm_render_state* rs, const float M_d[16], itm_stream frame_stream);
+int ITM_FN(exchange_info)(const itm_exchange* exchange, int* world, int* rank, int* max_ids, int* batch, const void** gathered_device);
+/* host copy of the gathered table, world x batch records of (17 + max_ids) int32 words, rank-major; synchronises the side stream */
+int ITM_FN(exchange_table)(itm_exchange* exchange, int32_t* dst_host, size_t words);
+
 /* Device address of a buffer (zero-copy hand-off to e.g. a collective); NULL if absent. */
 void* ITM_FN(buffer_ptr)(const itm_scene* scene, const itm_render_state* rs, int which);
 

@@ -325,4 +325,25 @@ class ITMMeshingEngine_HIP {
   }
 };
 
+// One rank's end of the multi-stream exchange: the record of this stream goes out with every frame, the table of all
+// streams comes back every `batch` frames.  Rank 0 creates the id, the host distributes it.
+class ITMStreamExchange_HIP {
+  itm_exchange* handle = nullptr;
+  int world, maxIds, batch;
+
+ public:
+  static void UniqueId(unsigned char id[128]) { check(itm_exchange_unique_id(id), "itm_exchange_unique_id"); }
+  ITMStreamExchange_HIP(int world_, int rank, const unsigned char id[128], int maxIds_ = 16384, int batch_ = 8) : world(world_), maxIds(maxIds_), batch(batch_) {
+    check(itm_exchange_create(world, rank, id, maxIds, batch, &handle), "itm_exchange_create");
+  }
+  ~ITMStreamExchange_HIP() { itm_exchange_destroy(handle); }
+  ITMStreamExchange_HIP(const ITMStreamExchange_HIP&) = delete;
+  ITMStreamExchange_HIP& operator=(const ITMStreamExchange_HIP&) = delete;
+  void Publish(const ITMRenderState* renderState, const ITMTrackingState* trackingState, itm_stream stream = nullptr) {
+    check(itm_exchange_step(handle, renderState->handle, trackingState->pose_d.GetM(), stream), "itm_exchange_step");
+  }
+  size_t TableWords() const { return (size_t)world * (size_t)batch * (size_t)(17 + maxIds); }
+  void Table(int32_t* hostTable) { check(itm_exchange_table(handle, hostTable, TableWords()), "itm_exchange_table"); }
+};
+
 }  // namespace itmhip

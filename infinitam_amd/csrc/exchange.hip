@@ -1,0 +1,180 @@
+// exchange.hip -- the per-frame exchange of visible-block records between depth streams (BASELINE configs[3]),
+// issued from the library: no interpreter and no tensor framework on the per-frame path.
+//
+// A scene never reads another stream's data, so N streams shard one per GPU with no collective on the fusion path.  What every
+// rank publishes per frame is one fixed-size record { float M_d[16]; int32 noVisibleEntries; int32 ids[max_ids] (padded with -1) },
+// written on the FRAME stream by a 3 us copy kernel right behind the frame's kernels (itm_export_visible_record).  Every `batch`
+// frames the records of the batch are all-gathered with RCCL on a SIDE stream that waits for the last copy; the frame stream only
+// ever waits for the collective that used the same batch buffer two batches earlier.  RCCL has no all-gather-v, hence the fixed
+// record size.  xGMI is point-to-point, so one 64 KB x batch all-gather per GPU is latency bound; batching trades record age
+// (at most `batch` frames) for fewer collectives.
+//
+// RCCL is loaded with dlopen when the first exchange is created: hosts that never exchange do not pay for it, and the library
+// has no link-time dependency on it.  The communicator is bootstrapped from a 128-byte id that rank 0 obtains from
+// itm_exchange_unique_id and the host distributes by whatever channel it has (a file, MPI, torch.distributed ...).
+#include <dlfcn.h>
+
+#include <cstring>
+#include <new>
+
+#include "itm_internal.h"
+
+namespace itm {
+
+constexpr int kRecordHeader = 17;   // 16 floats of pose + the count
+
+// the handful of RCCL entry points used, resolved at run time (signatures: rccl/rccl.h)
+struct Rccl {
+  typedef struct { char internal[128]; } UniqueId;
+  int (*GetUniqueId)(UniqueId*) = nullptr;
+  int (*CommInitRank)(void** comm, int nranks, UniqueId id, int rank) = nullptr;
+  int (*CommDestroy)(void* comm) = nullptr;
+  int (*AllGather)(const void* send, void* recv, size_t count, int datatype, void* comm, hipStream_t stream) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  void* lib = nullptr;
+  bool ok = false;
+};
+constexpr int kNcclInt32 = 2;       // ncclInt32 / ncclInt (rccl.h ncclDataType_t)
+
+static Rccl& rccl() {
+  static Rccl r;
+  static bool tried = false;
+  if (tried) return r;
+  tried = true;
+  const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  for (const char* n : names) { r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (r.lib) break; }
+  if (!r.lib) return r;
+  r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
+  r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
+  r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+  r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
+  r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+  r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.GetErrorString;
+  return r;
+}
+
+static int rccl_fail(int code, const char* what) {
+  char msg[256];
+  snprintf(msg, sizeof msg, "%s: %s", what, rccl().GetErrorString ? rccl().GetErrorString(code) : "RCCL error");
+  return set_error(ITM_ERR_DEVICE, msg);
+}
+
+}  // namespace itm
+
+struct itm_exchange {
+  int world = 1, rank = 0, maxIds = 0, batch = 1;
+  size_t words = 0;                       // per record
+  void* comm = nullptr;                   // ncclComm_t; null when world == 1 (a device copy stands in for the collective)
+  int32_t* buffers[2] = {nullptr, nullptr};   // batch records each (ping-pong)
+  int32_t* gathered = nullptr;            // world x batch records: rank-major, then frame of the batch
+  hipStream_t side = nullptr;
+  hipEvent_t copied[2] = {nullptr, nullptr}, released[2] = {nullptr, nullptr};
+  bool inFlight[2] = {false, false};
+  long long frame = 0;
+};
+
+using namespace itm;
+
+static void free_exchange(itm_exchange* x) {
+  if (!x) return;
+  if (x->side) (void)hipStreamSynchronize(x->side);
+  if (x->comm) rccl().CommDestroy(x->comm);
+  for (int b = 0; b < 2; ++b) {
+    if (x->buffers[b]) (void)hipFree(x->buffers[b]);
+    if (x->copied[b]) (void)hipEventDestroy(x->copied[b]);
+    if (x->released[b]) (void)hipEventDestroy(x->released[b]);
+  }
+  if (x->gathered) (void)hipFree(x->gathered);
+  if (x->side) (void)hipStreamDestroy(x->side);
+  delete x;
+}
+
+extern "C" {
+
+int itm_exchange_unique_id(unsigned char id[128]) {
+  if (!id) return set_error(ITM_ERR_INVALID, "null argument");
+  if (!rccl().ok) return set_error(ITM_ERR_DEVICE, "librccl.so could not be loaded");
+  Rccl::UniqueId u;
+  const int rc = rccl().GetUniqueId(&u);
+  if (rc) return rccl_fail(rc, "ncclGetUniqueId");
+  memcpy(id, u.internal, 128);
+  return ITM_OK;
+}
+
+int itm_exchange_create(int world, int rank, const unsigned char id[128], int max_ids, int batch, itm_exchange** out) {
+  if (!out || world < 1 || rank < 0 || rank >= world || max_ids < 0 || batch < 1) return set_error(ITM_ERR_INVALID, "bad argument");
+  if (world > 1 && !id) return set_error(ITM_ERR_INVALID, "a communicator of more than one rank needs the unique id of rank 0");
+  itm_exchange* x = new (std::nothrow) itm_exchange();
+  if (!x) return set_error(ITM_ERR_DEVICE, "out of host memory");
+  x->world = world; x->rank = rank; x->maxIds = max_ids; x->batch = batch;
+  x->words = (size_t)kRecordHeader + (size_t)max_ids;
+  const size_t batchBytes = x->words * (size_t)batch * 4;
+  hipError_t e = hipStreamCreateWithFlags(&x->side, hipStreamNonBlocking);
+  for (int b = 0; b < 2 && e == hipSuccess; ++b) {
+    e = hipMalloc((void**)&x->buffers[b], batchBytes);
+    if (e == hipSuccess) e = hipMemset(x->buffers[b], 0xFF, batchBytes);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&x->copied[b], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&x->released[b], hipEventDisableTiming);
+  }
+  if (e == hipSuccess) e = hipMalloc((void**)&x->gathered, batchBytes * (size_t)world);
+  if (e == hipSuccess) e = hipMemset(x->gathered, 0xFF, batchBytes * (size_t)world);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) { free_exchange(x); return hip_fail(e, "exchange buffers", __FILE__, __LINE__); }
+  if (world > 1) {
+    if (!rccl().ok) { free_exchange(x); return set_error(ITM_ERR_DEVICE, "librccl.so could not be loaded"); }
+    Rccl::UniqueId u;
+    memcpy(u.internal, id, 128);
+    const int rc = rccl().CommInitRank(&x->comm, world, u, rank);
+    if (rc) { x->comm = nullptr; free_exchange(x); return rccl_fail(rc, "ncclCommInitRank"); }
+  }
+  *out = x;
+  return ITM_OK;
+}
+
+int itm_exchange_destroy(itm_exchange* x) { free_exchange(x); return ITM_OK; }
+
+int itm_exchange_step(itm_exchange* x, const itm_render_state* rs, const float M_d[16], itm_stream frame_stream) {
+  if (!x || !rs || !M_d) return set_error(ITM_ERR_INVALID, "null argument");
+  hipStream_t fs = as_stream(frame_stream);
+  const int slot = (int)(x->frame % x->batch);
+  const int b = (int)((x->frame / x->batch) & 1);
+  if (slot == 0 && x->inFlight[b]) ITM_HIP(hipStreamWaitEvent(fs, x->released[b], 0));   // the collective two batches ago has let go of this buffer
+  int rc = itm_export_visible_record(rs, M_d, x->maxIds, x->buffers[b] + (size_t)slot * x->words, frame_stream);
+  if (rc) return rc;
+  if (slot == x->batch - 1) {
+    ITM_HIP(hipEventRecord(x->copied[b], fs));
+    ITM_HIP(hipStreamWaitEvent(x->side, x->copied[b], 0));
+    const size_t count = x->words * (size_t)x->batch;
+    if (x->comm) {
+      rc = rccl().AllGather(x->buffers[b], x->gathered, count, kNcclInt32, x->comm, x->side);
+      if (rc) return rccl_fail(rc, "ncclAllGather");
+    } else {
+      ITM_HIP(hipMemcpyAsync(x->gathered, x->buffers[b], count * 4, hipMemcpyDeviceToDevice, x->side));
+    }
+    ITM_HIP(hipEventRecord(x->released[b], x->side));
+    x->inFlight[b] = true;
+  }
+  ++x->frame;
+  return ITM_OK;
+}
+
+int itm_exchange_info(const itm_exchange* x, int* world, int* rank, int* max_ids, int* batch, const void** gathered_device) {
+  if (!x) return set_error(ITM_ERR_INVALID, "null argument");
+  if (world) *world = x->world;
+  if (rank) *rank = x->rank;
+  if (max_ids) *max_ids = x->maxIds;
+  if (batch) *batch = x->batch;
+  if (gathered_device) *gathered_device = x->gathered;
+  return ITM_OK;
+}
+
+int itm_exchange_table(itm_exchange* x, int32_t* dst_host, size_t words) {
+  if (!x || !dst_host) return set_error(ITM_ERR_INVALID, "null argument");
+  const size_t all = x->words * (size_t)x->batch * (size_t)x->world;
+  if (words < all) return set_error(ITM_ERR_INVALID, "destination too small for world x batch records");
+  ITM_HIP(hipStreamSynchronize(x->side));     // the table is written by the collectives on the side stream
+  ITM_HIP(hipMemcpy(dst_host, x->gathered, all * 4, hipMemcpyDeviceToHost));
+  return ITM_OK;
+}
+
+}  // extern "C"

@@ -113,3 +113,48 @@ class VisibleListExchange:
             nv = int(g[r, 16])
             out.append((M, g[r, 17:17 + min(nv, self.max_ids)].copy()))
         return out
+
+
+class NativeExchange:
+    """The same exchange issued from the library (exchange.hip): record copy on the frame stream, RCCL all-gather on a side stream
+    the library owns.  One C call per frame; no tensor framework on the per-frame path.  `unique_id` is the 128-byte RCCL id of
+    rank 0 (`NativeExchange.unique_id(backend)`), distributed by the host; not needed for world == 1."""
+
+    def __init__(self, backend, world: int, rank: int, max_ids: int = 16384, batch: int = 1, unique_id: bytes = None):
+        self.be, self.world, self.rank, self.max_ids, self.batch = backend, world, rank, max_ids, batch
+        self.words = RECORD_HEADER + max_ids
+        ida = None
+        if unique_id is not None:
+            ida = (C.c_ubyte * 128)(*unique_id)
+        h = C.c_void_p()
+        backend.check(backend.fn["exchange_create"](world, rank, ida, max_ids, batch, C.byref(h)), "exchange_create")
+        self.h = h
+
+    @staticmethod
+    def unique_id(backend) -> bytes:
+        ida = (C.c_ubyte * 128)()
+        backend.check(backend.fn["exchange_unique_id"](ida), "exchange_unique_id")
+        return bytes(ida)
+
+    def step(self, render_state_handle: int, M_d, frame_stream=None, group=None):
+        Ma = M_d if isinstance(M_d, C.Array) else VisibleListExchange.pose_array(M_d)
+        sp = C.c_void_p(frame_stream.cuda_stream) if frame_stream is not None else None
+        rc = self.be.fn["exchange_step"](self.h, C.c_void_p(render_state_handle), Ma, sp)
+        if rc:
+            self.be.check(rc, "exchange_step")
+
+    def table(self) -> List[Tuple[np.ndarray, np.ndarray]]:
+        g = np.empty(self.world * self.batch * self.words, np.int32)
+        self.be.check(self.be.fn["exchange_table"](self.h, g.ctypes.data_as(C.c_void_p), g.size), "exchange_table")
+        g = g.reshape(self.world, self.batch, self.words)[:, -1, :]
+        out = []
+        for r in range(self.world):
+            M = g[r, :16].view(np.float32).copy()
+            nv = int(g[r, 16])
+            out.append((M, g[r, 17:17 + min(nv, self.max_ids)].copy()))
+        return out
+
+    def close(self):
+        if self.h:
+            self.be.fn["exchange_destroy"](self.h)
+            self.h = None
