@@ -171,6 +171,8 @@ int ITM_FN(set_device)(int device);
 #define ITM_DEBUG_TWO_PASS_VISIBLE_LIST 7     /* AllocateSceneFromDepth: visible list by a count launch and a compaction launch */
 #define ITM_DEBUG_SINGLE_PASS_RAYCAST 8       /* ray casting: every ray start to finish in one launch (no parked-ray pass) */
 #define ITM_DEBUG_DENSE_GROUP_CULL 9          /* dense integration: frustum test per 4-voxel group instead of the per-column row interval */
+#define ITM_DEBUG_TRACKER_LAUNCH_PER_EVALUATION 10 /* TrackCamera: one launch per cost evaluation instead of one resident kernel per call */
+#define ITM_DEBUG_TRACKER_HOST_COMMAND 11     /* TrackCamera session: commands through pinned host memory (set before the tracker's first call) */
 int ITM_FN(debug_set)(int key, int value);
 /* out[i] = SDF_valueToFloat(in[i]) of the short voxel types, i.e. in[i] / 32767.0f, through the same
  * device routine the kernels use (a 3-instruction correctly rounded division; test hook). */

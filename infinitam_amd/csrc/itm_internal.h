@@ -157,6 +157,8 @@ extern int g_debug_explicit_mark;
 extern int g_debug_two_pass_visible_list;
 extern int g_debug_integrate_wgs;
 extern int g_debug_dense_group_cull;
+extern int g_debug_tracker_launch_per_evaluation;
+extern int g_debug_tracker_host_command;
 extern int g_debug_no_fused_projection;
 int rebuild_head_bits(itm_scene* s, hipStream_t st);   // occupancy bitmap AND block directory, from the table
 extern int g_debug_no_directory;

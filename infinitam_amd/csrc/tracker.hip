@@ -43,6 +43,45 @@ __global__ void __launch_bounds__(256) subsample_holes_kernel(const float* __res
   out[x + y * wOut] = acc;
 }
 
+// The whole FilterSubsampleWithHoles pyramid in one launch: a level-l pixel depends on a 2^l x 2^l block of the input only, so a
+// workgroup that owns a 16x16 input tile can produce every coarser pixel that lies under it (8x8, 4x4, 2x2, 1) through LDS --
+// the same nested averages of valid values, in the same order, as four launches of subsample_holes_kernel (4 x ~8 us of host time
+// per TrackCamera call).  Up to four coarser levels (the default hierarchy has exactly four).
+struct PyramidLevels { float* out[4]; int w[5], h[5]; int levels; };   // w[0], h[0]: the input; levels = number of coarser levels (1..4)
+
+__device__ inline float average_valid(float a, float b, float c, float d) {
+  float acc = 0.0f, good = 0.0f;
+  if (a > 0.0f) { acc += a; good++; }
+  if (b > 0.0f) { acc += b; good++; }
+  if (c > 0.0f) { acc += c; good++; }
+  if (d > 0.0f) { acc += d; good++; }
+  if (good > 0) acc /= good;
+  return acc;
+}
+
+__global__ void __launch_bounds__(256) pyramid_kernel(const float* __restrict__ in, PyramidLevels L) {
+  __shared__ float tile[2][16][16];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int gx = blockIdx.x * 16 + tx, gy = blockIdx.y * 16 + ty;
+  // pixels outside the input are never read by a pixel that exists on a coarser level (w[l+1] = w[l] / 2 rounds down)
+  tile[0][ty][tx] = (gx < L.w[0] && gy < L.h[0]) ? in[gx + gy * L.w[0]] : 0.0f;
+  __syncthreads();
+  int side = 8, cur = 0;
+#pragma unroll
+  for (int l = 0; l < 4; ++l) {
+    if (l < L.levels) {
+      if (tx < side && ty < side) {
+        const float v = average_valid(tile[cur][2 * ty][2 * tx], tile[cur][2 * ty][2 * tx + 1], tile[cur][2 * ty + 1][2 * tx], tile[cur][2 * ty + 1][2 * tx + 1]);
+        tile[cur ^ 1][ty][tx] = v;
+        const int ox = blockIdx.x * side + tx, oy = blockIdx.y * side + ty;
+        if (ox < L.w[l + 1] && oy < L.h[l + 1]) L.out[l][ox + oy * L.w[l + 1]] = v;
+      }
+      __syncthreads();
+      cur ^= 1; side >>= 1;
+    }
+  }
+}
+
 struct GHParams {
   Mat4 approxInvPose, scenePose;
   float vfx, vfy, vcx, vcy;   // view intrinsics (fx, fy, cx, cy)
@@ -85,20 +124,14 @@ constexpr int kGHWaves = ITM_GH_WAVES;
 constexpr int kGHThreads = 64 * kGHWaves;
 constexpr int kGHTileH = kGHThreads / 16;      // a tile is 16 pixels wide and kGHTileH tall
 
+// The tiles blk, blk + nBlocks, ... of one workgroup: every lane adds the residual rows of its pixels to `acc` (double) and counts them
 template <int MODE>
-__global__ void __launch_bounds__(kGHThreads) gh_partial_kernel(const float* __restrict__ depth, const float4* __restrict__ pointsMap,
-                                                        const float4* __restrict__ normalsMap, double* __restrict__ partial,
-                                                        int* __restrict__ partialCount, GHParams p, GHBlockRecord* __restrict__ hostRec, unsigned int seq) {
+__device__ inline void gh_accumulate(const float* __restrict__ depth, const float4* __restrict__ pointsMap, const float4* __restrict__ normalsMap,
+                                     const GHParams& p, int blk, int nBlocks, double acc[kGHValues], int& valid) {
   constexpr int NP = (MODE == 3) ? 6 : 3;
   constexpr int NH = NP * (NP + 1) / 2;
-  __shared__ double lds[kGHWaves][kGHValues];
-  __shared__ int ldsCount[kGHWaves];
-  double acc[kGHValues];
-#pragma unroll
-  for (int i = 0; i < kGHValues; ++i) acc[i] = 0.0;
-  int valid = 0;
   const int tilesX = (p.w + 15) / 16, tiles = tilesX * ((p.h + kGHTileH - 1) / kGHTileH);
-  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+  for (int tile = blk; tile < tiles; tile += nBlocks) {
   float vals[kGHValues];
 #pragma unroll
   for (int i = 0; i < kGHValues; ++i) vals[i] = 0.0f;
@@ -128,7 +161,7 @@ __global__ void __launch_bounds__(kGHThreads) gh_partial_kernel(const float* __r
                 A[0] = +q.z * n.y - q.y * n.z;
                 A[1] = -q.z * n.x + q.x * n.z;
                 A[2] = +q.y * n.x - q.x * n.y;
-                if (MODE == 3) { A[3] = n.x; A[4] = n.y; A[5] = n.z; }
+                if constexpr (MODE == 3) { A[3] = n.x; A[4] = n.y; A[5] = n.z; }
               }
               vals[0] = b * b;
               int k = 0;
@@ -151,7 +184,14 @@ __global__ void __launch_bounds__(kGHThreads) gh_partial_kernel(const float* __r
     if (used) acc[i] += (double)vals[i];
   }
   }   // tiles of this workgroup
-  // wave reduction in double (fixed butterfly order), then one partial per workgroup
+}
+
+// wave reduction in double (fixed butterfly order), then the waves in order: thread i < kGHValues ends up with value i of the
+// workgroup, every thread with its count
+template <int MODE>
+__device__ inline void gh_block_reduce(const double acc[kGHValues], int valid, double (*lds)[kGHValues], int* ldsCount, double& mine, int& cnt) {
+  constexpr int NP = (MODE == 3) ? 6 : 3;
+  constexpr int NH = NP * (NP + 1) / 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int i = 0; i < kGHValues; ++i) {
@@ -169,14 +209,28 @@ __global__ void __launch_bounds__(kGHThreads) gh_partial_kernel(const float* __r
   for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
   if (lane == 0) ldsCount[wave] = c;
   __syncthreads();
-  const int blk = blockIdx.x;
-  double mine = 0.0;
-  int cnt = 0;
+  mine = 0.0; cnt = 0;
 #pragma unroll
   for (int wv = 0; wv < kGHWaves; ++wv) {          // fixed order: deterministic
     if (threadIdx.x < kGHValues) mine += lds[wv][threadIdx.x];
     cnt += ldsCount[wv];
   }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(kGHThreads) gh_partial_kernel(const float* __restrict__ depth, const float4* __restrict__ pointsMap,
+                                                        const float4* __restrict__ normalsMap, double* __restrict__ partial,
+                                                        int* __restrict__ partialCount, GHParams p, GHBlockRecord* __restrict__ hostRec, unsigned int seq) {
+  __shared__ double lds[kGHWaves][kGHValues];
+  __shared__ int ldsCount[kGHWaves];
+  double acc[kGHValues];
+#pragma unroll
+  for (int i = 0; i < kGHValues; ++i) acc[i] = 0.0;
+  int valid = 0;
+  gh_accumulate<MODE>(depth, pointsMap, normalsMap, p, blockIdx.x, gridDim.x, acc, valid);
+  const int blk = blockIdx.x;
+  double mine; int cnt;
+  gh_block_reduce<MODE>(acc, valid, lds, ldsCount, mine, cnt);
   if (threadIdx.x < kGHValues) partial[(size_t)blk * kGHValues + threadIdx.x] = mine;
   if (threadIdx.x == 0) partialCount[blk] = cnt;
   if (hostRec) {
@@ -189,6 +243,139 @@ __global__ void __launch_bounds__(kGHThreads) gh_partial_kernel(const float* __r
     __syncthreads();
     if (threadIdx.x == 0) { r->seq = seq; __threadfence_system(); }
   }
+}
+
+// ---- evaluation session: ONE launch serves every evaluation of a TrackCamera call -------------------------------------------
+// TrackCamera evaluates cost / gradient / Hessian 5-12 times, each at a pose the host derives from the previous answer.  With a
+// launch per evaluation the floor was ~25-30 us each (launch, kernel, up to 256 records over PCIe, the host's summation).  Here
+// the workgroups stay resident for the duration of the call: the host writes a command (pose, level, mode; sequence number last)
+// into pinned memory, workgroup 0 polls it over PCIe and republishes it in device memory for the others, every workgroup
+// accumulates its tiles, the LAST one to arrive (device-scope counter) adds the partials in block order -- the order the host used,
+// so the sums are bit-identical to the per-launch path -- and writes one stamped result record to pinned memory.
+// The kernel cannot outlive its host: workgroup 0 ends the session when no command has arrived for kSessionIdleTicks (2 ms on
+// the 100 MHz clock; the other workgroups have their own, longer, limit) or when the host says so, and reports its exit in the
+// result record; a host that finds the session gone simply starts another one at the pending sequence number.
+constexpr unsigned int kSessionExit = 0xffffffffu;
+constexpr unsigned long long kSessionIdleTicks = 200000ull;   // 2 ms
+struct GHCommand {            // pinned host memory, host -> device; `seq` is written last
+  GHParams p;
+  const float* depth; const float4* points; const float4* normals;
+  int mode, activeBlocks;
+  unsigned int seq;
+};
+constexpr int kCommandWords = (int)(sizeof(GHCommand) / 4);
+static_assert(sizeof(GHCommand) % 4 == 0, "copied word by word");
+struct GHResult { double sums[kGHValues]; int count; volatile unsigned int seq; volatile unsigned int exited; };   // device -> host
+
+__global__ void __launch_bounds__(kGHThreads) gh_session_kernel(const unsigned int* __restrict__ hostCmd, unsigned int* __restrict__ devCmd,
+                                                                unsigned long long* __restrict__ devSeq, double* __restrict__ partial,
+                                                                int* __restrict__ partialCount, unsigned int* __restrict__ done,
+                                                                GHResult* __restrict__ hostRes, unsigned int session, unsigned int firstSeq, int direct) {
+  __shared__ __attribute__((aligned(16))) unsigned int cmdWords[kCommandWords];
+  __shared__ unsigned int nextSeq;
+  __shared__ int lastArriver;
+  __shared__ double lds[kGHWaves][kGHValues];
+  __shared__ int ldsCount[kGHWaves];
+  __shared__ double gathered[kGHGroups][kGHValues + 1];          // the last arriver's copy of every partial (+ count)
+  const GHCommand& cmd = *(const GHCommand*)cmdWords;
+  const unsigned int seqWord = (unsigned int)(offsetof(GHCommand, seq) / 4);
+  unsigned int last = firstSeq - 1u;
+  unsigned long long idleSince = __builtin_amdgcn_s_memrealtime();
+  for (;;) {
+    // ---- wait for the next command ----
+    if (threadIdx.x == 0) {
+      unsigned int s;
+      if (blockIdx.x == 0 || direct) {
+        // `direct`: the command block lies in fine-grained DEVICE memory that the host writes through the PCIe BAR, every workgroup
+        // reads it there; otherwise it lies in pinned HOST memory, workgroup 0 fetches it over PCIe and hands it on
+        const unsigned long long limit = (blockIdx.x == 0) ? kSessionIdleTicks : 4 * kSessionIdleTicks;
+        for (;;) {
+          s = __hip_atomic_load(hostCmd + seqWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (s != last) break;
+          if (__builtin_amdgcn_s_memrealtime() - idleSince > limit) { s = kSessionExit; break; }
+          __builtin_amdgcn_s_sleep(8);
+        }
+      } else {
+        for (;;) {
+          const unsigned long long v = __hip_atomic_load(devSeq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          s = (unsigned int)v;
+          if ((unsigned int)(v >> 32) == session && s != last) break;
+          if (__builtin_amdgcn_s_memrealtime() - idleSince > 4 * kSessionIdleTicks) { s = kSessionExit; break; }
+          __builtin_amdgcn_s_sleep(2);
+        }
+      }
+      nextSeq = s;
+    }
+    __syncthreads();
+    const unsigned int s = nextSeq;
+    // Everything that crosses workgroups or the PCIe link below travels in relaxed atomic accesses of agent / system scope, which
+    // bypass the non-coherent caches one word at a time; ordering needs no more than "my own accesses have completed" (workgroup
+    // fence = s_waitcnt) and barriers.  Agent- or system-scope FENCES would write back / invalidate the whole L2 of the XCD on
+    // every evaluation, and the depth and map tiles the evaluations re-read live there (measured: 40 us per evaluation with them).
+    if (s != kSessionExit) {
+      if (direct) {
+        if (threadIdx.x < kCommandWords) cmdWords[threadIdx.x] = __hip_atomic_load(hostCmd + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __syncthreads();
+      } else if (blockIdx.x == 0) {
+        // the command itself: read after its sequence number, handed on in device memory, then the number
+        if (threadIdx.x < kCommandWords) {
+          const unsigned int w = __hip_atomic_load(hostCmd + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          cmdWords[threadIdx.x] = w;
+          __hip_atomic_store(devCmd + threadIdx.x, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(devSeq, ((unsigned long long)session << 32) | s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        if (threadIdx.x < kCommandWords) cmdWords[threadIdx.x] = __hip_atomic_load(devCmd + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+      }
+    } else if (!direct && blockIdx.x == 0 && threadIdx.x == 0) {
+      __hip_atomic_store(devSeq, ((unsigned long long)session << 32) | kSessionExit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (s == kSessionExit) break;
+    // ---- this workgroup's share ----
+    const int nBlocks = cmd.activeBlocks;
+    double mine = 0.0; int cnt = 0;
+    if ((int)blockIdx.x < nBlocks) {
+      double acc[kGHValues];
+#pragma unroll
+      for (int i = 0; i < kGHValues; ++i) acc[i] = 0.0;
+      int valid = 0;
+      if (cmd.mode == 1) { gh_accumulate<1>(cmd.depth, cmd.points, cmd.normals, cmd.p, blockIdx.x, nBlocks, acc, valid); gh_block_reduce<1>(acc, valid, lds, ldsCount, mine, cnt); }
+      else if (cmd.mode == 2) { gh_accumulate<2>(cmd.depth, cmd.points, cmd.normals, cmd.p, blockIdx.x, nBlocks, acc, valid); gh_block_reduce<2>(acc, valid, lds, ldsCount, mine, cnt); }
+      else { gh_accumulate<3>(cmd.depth, cmd.points, cmd.normals, cmd.p, blockIdx.x, nBlocks, acc, valid); gh_block_reduce<3>(acc, valid, lds, ldsCount, mine, cnt); }
+      if (threadIdx.x < kGHValues) __hip_atomic_store(partial + (size_t)blockIdx.x * kGHValues + threadIdx.x, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (threadIdx.x == 0) __hip_atomic_store(partialCount + blockIdx.x, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    }
+    __syncthreads();
+    // only the workgroups that had tiles arrive (6 of 256 on the 40x30 level: 250 fewer read-modify-writes of one word)
+    if (threadIdx.x == 0) lastArriver = ((int)blockIdx.x < nBlocks) && __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)nBlocks - 1u;
+    __syncthreads();
+    if (lastArriver) {
+      // ---- every partial is in device memory: add them in block order, answer the host ----
+      for (int b = threadIdx.x; b < nBlocks; b += kGHThreads) {
+#pragma unroll
+        for (int i = 0; i < kGHValues; ++i) gathered[b][i] = __hip_atomic_load(partial + (size_t)b * kGHValues + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        gathered[b][kGHValues] = (double)__hip_atomic_load(partialCount + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      if (threadIdx.x <= kGHValues) {
+        double sum = 0.0;
+        for (int b = 0; b < nBlocks; ++b) sum += gathered[b][threadIdx.x];
+        if (threadIdx.x < kGHValues) __hip_atomic_store(&hostRes->sums[threadIdx.x], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        else __hip_atomic_store(&hostRes->count, (int)sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // counts are small integers: exact in double
+      }
+      if (threadIdx.x == 0) __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_store((unsigned int*)&hostRes->seq, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    last = s;
+    idleSince = __builtin_amdgcn_s_memrealtime();
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store((unsigned int*)&hostRes->exited, session, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---- tracker object -------------------------------------------------------------------------------------
@@ -208,6 +395,13 @@ struct itm_tracker {
   unsigned int seq = 0;
   std::vector<float*> pyramid; std::vector<size_t> pyramidBytes;
   double pollTimeoutSeconds = 5.0;
+  // evaluation session (gh_session_kernel)
+  itm::GHCommand* cmd = nullptr; unsigned int* cmdDev = nullptr;     // pinned command + its device address
+  itm::GHResult* res = nullptr; itm::GHResult* resDev = nullptr;     // pinned result + its device address
+  unsigned int* devCmd = nullptr; unsigned long long* devSeq = nullptr; unsigned int* done = nullptr;   // device memory
+  unsigned int session = 0;
+  bool sessionOpen = false;
+  bool cmdDirect = false;        // the command block is device memory the host writes through the BAR
 };
 
 namespace itm {
@@ -215,6 +409,11 @@ namespace itm {
 static void tracker_release(itm_tracker* t) {
   (void)hipFree(t->partial); (void)hipFree(t->partialCount);
   if (t->rec) (void)hipHostFree(t->rec);
+  if (t->cmd) { if (t->cmdDirect) (void)hipFree(t->cmd); else (void)hipHostFree(t->cmd); }
+  if (t->res) (void)hipHostFree(t->res);
+  (void)hipFree(t->devCmd); (void)hipFree(t->devSeq); (void)hipFree(t->done);
+  t->cmd = nullptr; t->cmdDev = nullptr; t->res = nullptr; t->resDev = nullptr; t->devCmd = nullptr; t->devSeq = nullptr; t->done = nullptr;
+  t->sessionOpen = false;
   for (float* q : t->pyramid) (void)hipFree(q);
   t->partial = nullptr; t->partialCount = nullptr; t->rec = nullptr; t->recDev = nullptr; t->blocks = 0;
   t->pyramid.clear(); t->pyramidBytes.clear();
@@ -319,6 +518,152 @@ static int compute_g_and_h(itm_tracker* trk, const float* depth, int w, int h, c
   return ITM_OK;
 }
 
+#ifndef ITM_EXP_TRACKER_TRACE
+#define ITM_EXP_TRACKER_TRACE 0   // measurement build: per-evaluation host-side latencies on stderr
+#endif
+#if ITM_EXP_TRACKER_TRACE
+#define ITM_TT(...) __VA_ARGS__
+#else
+#define ITM_TT(...)
+#endif
+
+// ---- evaluation session, host side -------------------------------------------------------------------------
+int g_debug_tracker_launch_per_evaluation = 0;   // debug key 10: TrackCamera with one launch per evaluation (the path before the session kernel)
+int g_debug_tracker_host_command = 0;            // debug key 11: session commands through pinned host memory even where the device has a large BAR
+
+static int session_reserve(itm_tracker* t) {
+  int rc = tracker_reserve(t, kGHGroups);
+  if (rc) return rc;
+  if (t->cmd) return ITM_OK;
+  // the command block: fine-grained device memory written by the host through the PCIe BAR where the device has a large BAR (every
+  // workgroup then polls local memory), pinned host memory fetched by workgroup 0 otherwise
+  hipError_t e = hipSuccess;
+  int dev = 0, largeBar = 0;
+  (void)hipGetDevice(&dev);
+  if (!g_debug_tracker_host_command && hipDeviceGetAttribute(&largeBar, hipDeviceAttributeIsLargeBar, dev) == hipSuccess && largeBar &&
+      hipExtMallocWithFlags((void**)&t->cmd, sizeof(GHCommand), hipDeviceMallocFinegrained) == hipSuccess) {
+    t->cmdDirect = true;
+    t->cmdDev = (unsigned int*)t->cmd;
+    GHCommand zero; memset(&zero, 0, sizeof zero); zero.seq = kSessionExit;
+    e = hipMemcpy(t->cmd, &zero, sizeof zero, hipMemcpyHostToDevice);
+  } else {
+    (void)hipGetLastError();
+    t->cmdDirect = false;
+    e = hipHostMalloc((void**)&t->cmd, sizeof(GHCommand), hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) { memset(t->cmd, 0, sizeof(GHCommand)); t->cmd->seq = kSessionExit; e = hipHostGetDevicePointer((void**)&t->cmdDev, t->cmd, 0); }
+  }
+  if (e == hipSuccess) e = hipHostMalloc((void**)&t->res, sizeof(GHResult), hipHostMallocMapped | hipHostMallocCoherent);
+  if (e == hipSuccess) { memset(t->res, 0, sizeof(GHResult)); e = hipHostGetDevicePointer((void**)&t->resDev, t->res, 0); }
+  if (e == hipSuccess) e = hipMalloc((void**)&t->devCmd, sizeof(GHCommand));
+  if (e == hipSuccess) e = hipMalloc((void**)&t->devSeq, 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&t->done, 4);
+  if (e == hipSuccess) e = hipMemset(t->devSeq, 0, 8);
+  if (e == hipSuccess) e = hipMemset(t->done, 0, 4);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) {
+    if (t->cmd) { if (t->cmdDirect) (void)hipFree(t->cmd); else (void)hipHostFree(t->cmd); }
+    if (t->res) (void)hipHostFree(t->res);
+    (void)hipFree(t->devCmd); (void)hipFree(t->devSeq); (void)hipFree(t->done);
+    t->cmd = nullptr; t->res = nullptr; t->devCmd = nullptr; t->devSeq = nullptr; t->done = nullptr;
+    return hip_fail(e, "tracker session buffers", __FILE__, __LINE__);
+  }
+  return ITM_OK;
+}
+
+static int session_launch(itm_tracker* t, unsigned int firstSeq, hipStream_t st) {
+  ++t->session;
+  gh_session_kernel<<<kGHGroups, kGHThreads, 0, st>>>(t->cmdDev, t->devCmd, t->devSeq, t->partial, t->partialCount, t->done, t->resDev, t->session, firstSeq, t->cmdDirect ? 1 : 0);
+  ITM_LAUNCH_CHECK();
+  t->sessionOpen = true;
+  return ITM_OK;
+}
+
+// tells the resident kernel to leave (it does so within microseconds; nothing waits for it: later work on the stream queues behind it)
+static void session_close(itm_tracker* t) {
+  if (!t->sessionOpen) return;
+  __atomic_thread_fence(__ATOMIC_RELEASE);
+  *(volatile unsigned int*)&t->cmd->seq = kSessionExit;
+  __builtin_ia32_sfence();
+  t->sessionOpen = false;
+}
+
+// one evaluation through the session: same arguments and the same sums as compute_g_and_h
+static int session_g_and_h(itm_tracker* trk, const float* depth, int w, int h, const float* viewIntr, const float* pointsMap, const float* normalsMap,
+                           int sceneW, int sceneH, const float* sceneIntr, const float* approxInvPose, const float* scenePose,
+                           float distThresh, int iterationType, itm_tracker_gh* out, hipStream_t st) {
+  memset(out, 0, sizeof *out);
+  if (iterationType == ITM_TRACKER_ITERATION_NONE) return ITM_OK;
+  if (iterationType < 1 || iterationType > 3) return set_error(ITM_ERR_INVALID, "bad iteration type");
+  int rc = session_reserve(trk);
+  if (rc) return rc;
+  const int tiles = ((w + 15) / 16) * ((h + kGHTileH - 1) / kGHTileH);
+  const int rounds = (tiles + kGHGroups - 1) / kGHGroups;
+  if (!trk->sessionOpen && trk->session != 0u) {
+    // the previous session was told to leave; make sure it has before the command word changes again (it polls every
+    // microsecond, so this is a formality -- but two resident kernels must never share the arrival counter)
+    using clock = std::chrono::steady_clock;
+    const clock::time_point t0 = clock::now();
+    unsigned spins = 0;
+    while (trk->res->exited != trk->session) {
+      __builtin_ia32_pause();
+      if ((++spins & 0xfffu) != 0u) continue;
+      if (hipStreamQuery(st) != hipErrorNotReady) break;                 // nothing is running on the stream any more
+      if (std::chrono::duration<double>(clock::now() - t0).count() > trk->pollTimeoutSeconds) return set_error(ITM_ERR_DEVICE, "tracker session did not end");
+    }
+  }
+  GHCommand* c = trk->cmd;
+  memcpy(c->p.approxInvPose.m, approxInvPose, 64); memcpy(c->p.scenePose.m, scenePose, 64);
+  c->p.vfx = viewIntr[0]; c->p.vfy = viewIntr[1]; c->p.vcx = viewIntr[2]; c->p.vcy = viewIntr[3];
+  c->p.sfx = sceneIntr[0]; c->p.sfy = sceneIntr[1]; c->p.scx = sceneIntr[2]; c->p.scy = sceneIntr[3];
+  c->p.distThresh = distThresh; c->p.w = w; c->p.h = h; c->p.sceneW = sceneW; c->p.sceneH = sceneH;
+  c->depth = depth; c->points = (const float4*)pointsMap; c->normals = (const float4*)normalsMap;
+  c->mode = iterationType; c->activeBlocks = (tiles + rounds - 1) / rounds;       // the grid of the per-launch path: same tiles per block, same sums
+  unsigned int seq = ++trk->seq;
+  if (seq == kSessionExit || seq == 0u) seq = trk->seq = 1u;
+  ITM_TT(const auto ttA = std::chrono::steady_clock::now();)
+  __atomic_thread_fence(__ATOMIC_RELEASE);
+  __builtin_ia32_sfence();                   // the block may be write-combined BAR memory: its body must leave the core before the number
+  *(volatile unsigned int*)&c->seq = seq;
+  __builtin_ia32_sfence();
+  if (!trk->sessionOpen && (rc = session_launch(trk, seq, st))) return rc;
+  ITM_TT(const auto ttB = std::chrono::steady_clock::now();)
+  // wait for the stamped result; a session that has left without answering (idle limit hit while this thread was away) is replaced
+  using clock = std::chrono::steady_clock;
+  clock::time_point t0; bool timing = false;
+  unsigned spins = 0;
+  const GHResult* r = trk->res;
+  while (r->seq != seq) {
+    __builtin_ia32_pause();
+    if ((++spins & 0xffu) != 0u) continue;
+    if (r->exited == trk->session && r->seq != seq) {
+      if ((rc = session_launch(trk, seq, st))) return rc;
+      continue;
+    }
+    if ((spins & 0x3fffu) != 0u) continue;
+    if (!timing) { t0 = clock::now(); timing = true; continue; }
+    const double waited = std::chrono::duration<double>(clock::now() - t0).count();
+    if (waited < 0.02) continue;
+    const hipError_t q = hipStreamQuery(st);
+    if (q != hipSuccess && q != hipErrorNotReady) { trk->sessionOpen = false; return hip_fail(q, "tracker session", __FILE__, __LINE__); }
+    if (waited > trk->pollTimeoutSeconds) { session_close(trk); return set_error(ITM_ERR_DEVICE, "tracker session timed out"); }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  ITM_TT({ const auto ttC = std::chrono::steady_clock::now();
+           fprintf(stderr, "[tracker trace] %dx%d mode %d: launch %.1f us, answer after %.1f us\n", w, h, iterationType,
+                   std::chrono::duration<double, std::micro>(ttB - ttA).count(), std::chrono::duration<double, std::micro>(ttC - ttB).count()); })
+  const int np = (iterationType == ITM_TRACKER_ITERATION_BOTH) ? 6 : 3;
+  const double* sums = r->sums;
+  const int n = r->count;
+  for (int a = 0, k = 0; a < np; ++a)
+    for (int b = 0; b <= a; ++b, ++k) out->hessian[a + b * 6] = (float)sums[7 + k];
+  for (int a = 0; a < np; ++a)
+    for (int b = a + 1; b < np; ++b) out->hessian[a + b * 6] = out->hessian[b + a * 6];
+  for (int a = 0; a < np; ++a) out->nabla[a] = (float)sums[1 + a];
+  out->noValidPoints = n;
+  out->f = (n > 100) ? std::sqrt((float)sums[0]) / n : 1e5f;
+  return ITM_OK;
+}
+
 // FilterSubsampleWithHoles pyramid of the view's depth image in the tracker's own buffers (PrepareForEvaluation)
 struct DepthLevel { const float* depth; int w, h; float intr[4]; };
 
@@ -337,9 +682,18 @@ static int build_pyramid(itm_tracker* trk, const itm_view* view, int levels, std
       ITM_HIP(hipMalloc((void**)&trk->pyramid[i], bytes));
       trk->pyramidBytes[i] = bytes;
     }
-    subsample_holes_kernel<<<dim3((L.w + 15) / 16, (L.h + 15) / 16), 256, 0, st>>>(out[i - 1].depth, out[i - 1].w, trk->pyramid[i], L.w, L.h);
     L.depth = trk->pyramid[i];
     for (int k = 0; k < 4; ++k) L.intr[k] = out[i - 1].intr[k] * 0.5f;
+  }
+  if (levels >= 2 && levels <= 5 && !g_debug_tracker_launch_per_evaluation) {
+    PyramidLevels P;
+    memset(&P, 0, sizeof P);
+    P.levels = levels - 1;
+    for (int i = 0; i < levels; ++i) { P.w[i] = out[i].w; P.h[i] = out[i].h; if (i > 0) P.out[i - 1] = trk->pyramid[i]; }
+    pyramid_kernel<<<dim3((view->w + 15) / 16, (view->h + 15) / 16), 256, 0, st>>>(view->depth, P);
+  } else {
+    for (int i = 1; i < levels; ++i)
+      subsample_holes_kernel<<<dim3((out[i].w + 15) / 16, (out[i].h + 15) / 16), 256, 0, st>>>(out[i - 1].depth, out[i - 1].w, trk->pyramid[i], out[i].w, out[i].h);
   }
   ITM_LAUNCH_CHECK();
   return ITM_OK;
@@ -353,10 +707,18 @@ static int track_camera(itm_tracker* trk, const itm_tracker_config* cfg, const i
   if (rc) return rc;
   std::vector<DepthLevel> pyr;
   if ((rc = build_pyramid(trk, view, levels, pyr, st))) return rc;
-  return icp_track(cfg, view->M_d, M_d_out, [&](int level, int mode, const float invPose[16], float distThresh, itm_tracker_gh* e) {
-    return compute_g_and_h(trk, pyr[level].depth, pyr[level].w, pyr[level].h, pyr[level].intr, pointsMap, normalsMap, view->w, view->h,
+  if (g_debug_tracker_launch_per_evaluation)
+    return icp_track(cfg, view->M_d, M_d_out, [&](int level, int mode, const float invPose[16], float distThresh, itm_tracker_gh* e) {
+      return compute_g_and_h(trk, pyr[level].depth, pyr[level].w, pyr[level].h, pyr[level].intr, pointsMap, normalsMap, view->w, view->h,
+                             pyr[0].intr, invPose, scenePose, distThresh, mode, e, st);
+    });
+  // one resident kernel for all evaluations of this call
+  rc = icp_track(cfg, view->M_d, M_d_out, [&](int level, int mode, const float invPose[16], float distThresh, itm_tracker_gh* e) {
+    return session_g_and_h(trk, pyr[level].depth, pyr[level].w, pyr[level].h, pyr[level].intr, pointsMap, normalsMap, view->w, view->h,
                            pyr[0].intr, invPose, scenePose, distThresh, mode, e, st);
   });
+  session_close(trk);
+  return rc;
 }
 
 }  // namespace itm

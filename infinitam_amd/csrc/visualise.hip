@@ -488,6 +488,8 @@ int itm_debug_set(int key, int value) {
   if (key == ITM_DEBUG_TWO_PASS_VISIBLE_LIST) { g_debug_two_pass_visible_list = value; return ITM_OK; }
   if (key == ITM_DEBUG_SINGLE_PASS_RAYCAST) { g_debug_single_pass_raycast = value; return ITM_OK; }
   if (key == ITM_DEBUG_DENSE_GROUP_CULL) { g_debug_dense_group_cull = value; return ITM_OK; }
+  if (key == ITM_DEBUG_TRACKER_LAUNCH_PER_EVALUATION) { g_debug_tracker_launch_per_evaluation = value; return ITM_OK; }
+  if (key == ITM_DEBUG_TRACKER_HOST_COMMAND) { g_debug_tracker_host_command = value; return ITM_OK; }
   return set_error(ITM_ERR_INVALID, "unknown debug key");
 }
 

@@ -180,6 +180,29 @@ def test_track_camera_hip_vs_oracle_well_conditioned(hip, oracle):
     assert_pose_close(poses[0], poses[1], roll_tol=2e-5)
 
 
+@pytest.mark.gpu
+def test_session_kernel_and_launch_per_evaluation_give_the_same_pose_bit_for_bit(hip):
+    """TrackCamera through the resident evaluation kernel (one launch per call) and through one launch per evaluation (debug key
+    10): the partial sums are formed over the same tiles and added in the same order, so the tracked poses are identical; and a
+    tracker handle survives many sessions back to back, also after its resident kernel has hit the idle limit."""
+    import time
+    ses, v, nxt = build_maps_offaxis(hip)
+    try:
+        a = track(hip, ses, v, nxt)
+        hip.check(hip.fn["debug_set"](10, 1), "debug_set")
+        try:
+            b = track(hip, ses, v, nxt)
+        finally:
+            hip.check(hip.fn["debug_set"](10, 0), "debug_set")
+        assert np.array_equal(a, b), np.abs(a - b).max()
+        for i in range(20):
+            assert np.array_equal(track(hip, ses, v, nxt), a), i
+        time.sleep(0.05)                                   # far beyond the 2 ms idle limit of a session
+        assert np.array_equal(track(hip, ses, v, nxt), a)
+    finally:
+        ses.close()
+
+
 # ---- the product's host-side solver against the reference's TrackCamera with the same evaluator (CPU) ------------------
 EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_float, C.POINTER(TrackerGH))
 
