@@ -344,6 +344,48 @@ __device__ inline float4 cast_ray_plain(int x, int y, const VolumeView& vol, con
 #define ITM_RAY_PARKED_LOOKAHEAD 6   // directory cells fetched together per round trip by a parked ray's empty-space run (4: 55 us, 6: 53, 8: 53)
 #endif
 
+#ifndef ITM_RAY_DENSE_LOOKAHEAD
+// Dense volumes: voxels fetched together by a ray that is crossing free space.  BASELINE configs[2] starts every ray 0.2 m in front
+// of the camera and the surface is 1.3-2.3 m away: ~65-115 steps of mu / voxelSize voxels through voxels that read exactly 1 (free
+// or never seen), each a dependent round trip.  Measured (config 3 ray cast, event timers): none 90.6 us, 4 voxels 86.6, 8: 92.5,
+// 12: 94.0, 16: 103.7 -- the run is NOT what bounds the dense ray cast (its neighbouring rays read the same lines from L2); kept at 4.
+#define ITM_RAY_DENSE_LOOKAHEAD 4
+#endif
+
+// One look-ahead round of a far-field run in a DENSE volume.  A ray whose single-voxel read returned exactly 1 steps by
+// max(1 * stepScale, 1) voxels and, in free space, reads 1 again: the voxels of the next K positions -- q0 = pt, q1 = pt + step dir,
+// ..., each computed with the reference's own operations -- are fetched together and the ray advances over as many of them as
+// read exactly 1 (the reference's step for such a value, with its length update and range test); it stops in front of the first
+// other value (or position outside the volume), which the regular loop then reads again.  K dependent round trips become one.
+template <class VX, int K>
+__device__ inline void far_run(const VolumeView& vol, bool runner, float& px, float& py, float& pz, float& total, float dx, float dy, float dz,
+                               float stepScale, float totalMax, bool& ended) {
+  const float one = 1.0f * stepScale;                       // sdf * stepScale with sdf == 1
+  const float step = (one < 1.0f) ? 1.0f : one;
+  const float sx = step * dx, sy = step * dy, sz = step * dz;
+  const float farRaw = VX::kShort ? 32767.0f : 1.0f;
+  float raw[K];
+  {
+    float qx = px, qy = py, qz = pz;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const int ix = (int)round_ref(qx) - vol.ox, iy = (int)round_ref(qy) - vol.oy, iz = (int)round_ref(qz) - vol.oz;
+      const bool use = runner && ix >= 0 && ix < vol.sx && iy >= 0 && iy < vol.sy && iz >= 0 && iz < vol.sz;
+      const float v = VX::load_raw_sdf(vol.vba, use ? (size_t)(ix + iy * vol.sx + iz * vol.sx * vol.sy) : (size_t)0);   // voxel 0 / no use for the others
+      raw[j] = use ? v : 0.0f;                              // 0 = "something else": stops the run
+      qx += sx; qy += sy; qz += sz;
+    }
+  }
+  if (runner) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      if (raw[j] != farRaw) break;
+      px += sx; py += sy; pz += sz; total += step;
+      if (!(total < totalMax)) { ended = true; break; }
+    }
+  }
+}
+
 // a parked ray: where it stands and how far it has come; direction, end of range etc. are recomputed from the pixel
 struct RayResume { float px, py, pz, total; };
 
@@ -394,6 +436,14 @@ __device__ inline float4 march_ray(int x, int y, const VolumeView& vol, const Ra
       const float sdf = sdf_nearest<VX, DENSE>(vol, px, py, pz, found, cache);
       if (found && (sdf <= 0.1f) && (sdf >= -0.5f)) st = TRI;      // the position is kept for the trilinear read
       else st = advance(found, sdf);
+      if constexpr (DENSE && LOOKAHEAD > 0) {
+        const bool far = st == MARCH && found && sdf == 1.0f;      // SDF_valueToFloat(32767) is exactly 1
+        if (__any(far)) {
+          bool ended = false;
+          far_run<VX, LOOKAHEAD>(vol, far, px, py, pz, total, dx, dy, dz, stepScale, totalMax, ended);
+          if (ended) st = DONE;
+        }
+      }
       if constexpr (!DENSE && (PARK || LOOKAHEAD > 0)) missStreak = found ? 0 : missStreak + 1;
       if constexpr (!DENSE && PARK) {
         if (st == MARCH && missStreak >= ITM_RAY_PARK_STREAK) { parked = true; st = DONE; }

@@ -317,7 +317,7 @@ __global__ void __launch_bounds__(256) raycast_kernel(VolumeView vol, const floa
   // ---- phase 1: every ray of the tile; rays that turn out to be crossing empty space are parked ----
   bool parked = false;
   if (inside) {
-    const float4 r = march_ray<VX, DENSE, 0, PARK>(x, y, vol, p, mm, nullptr, parked);
+    const float4 r = march_ray<VX, DENSE, DENSE ? ITM_RAY_DENSE_LOOKAHEAD : 0, PARK>(x, y, vol, p, mm, nullptr, parked);
     if (!parked) out[x + y * p.W] = r;
     else if constexpr (PARK) {
       const int slot = atomicAdd(&parkCount, 1);
