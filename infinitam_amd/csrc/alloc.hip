@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(256) allocate_sweep_kernel(uint32_t* __restric
                                                              int2* __restrict__ chunkReqNext, int numChunks, uint4* __restrict__ hash,
                                                              const int32_t* __restrict__ excessList, const int32_t* __restrict__ allocList,
                                                              uint8_t* __restrict__ visT, const SceneCounters* __restrict__ counters,
-                                                             uint32_t* __restrict__ headBits, int32_t* __restrict__ dirPtr,
+                                                             uint32_t* __restrict__ headBits, int32_t* __restrict__ dirPtr, int16_t* __restrict__ sdfMirror,
                                                              const float* __restrict__ depth, int lazy, AllocParams p) {
   __shared__ int lds[8];
   const int chunk = blockIdx.x;
@@ -219,6 +219,7 @@ __global__ void __launch_bounds__(256) allocate_sweep_kernel(uint32_t* __restric
         hash[p.bucketNum + off] = pack_entry(bx, by, bz, 0, ptr);
         visT[p.bucketNum + off] = lazy ? 0x81 : 1;
         directory_insert(dirPtr, bx, by, bz, ptr);
+        mirror_init_block(sdfMirror, bx, by, bz);
       }
     } else if (vbaIdx >= 0) {
       int bx, by, bz;
@@ -227,6 +228,7 @@ __global__ void __launch_bounds__(256) allocate_sweep_kernel(uint32_t* __restric
       hash[slot] = pack_entry(bx, by, bz, 0, ptr);
       atomicOr(&headBits[slot >> 5], 1u << (slot & 31));
       directory_insert(dirPtr, bx, by, bz, ptr);
+      mirror_init_block(sdfMirror, bx, by, bz);
     }
     allocKey[slot] = 0u;
   }
@@ -504,7 +506,7 @@ int launch_sweep_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, bo
   if (!onlyVisible) {
     KernelTimer ts(s, ITM_TK_ALLOC_SWEEP, st);
     allocate_sweep_kernel<<<nChunks, 256, 0, st>>>(s->allocKey, reqCur, reqNext, nChunks, s->hash, s->excessList, s->allocList,
-                                                   rs->visibleType, s->counters, s->headBits, s->dirPtr, v->depth, lazy ? 1 : 0, p);
+                                                   rs->visibleType, s->counters, s->headBits, s->dirPtr, s->sdfMirror, v->depth, lazy ? 1 : 0, p);
     s->frameParity++;
   }
   KernelTimer tv(s, ITM_TK_VISIBLE_LIST, st);

@@ -227,7 +227,7 @@ __device__ inline void load_item(const HashEntry& he, int z0, int lane, const vo
 // behind the depth gathers -- the wave then waits for those gathers only (the memory counter retires in issue order), and the new
 // runs travel while this item is updated and stored.
 template <class VX>
-__device__ inline void integrate_item(const HashEntry& he, int z0, int lane, typename VX::Reg r[kSlices], void* __restrict__ vba,
+__device__ inline void integrate_item(const HashEntry& he, int z0, int lane, typename VX::Reg r[kSlices], void* __restrict__ vba, int16_t* __restrict__ sdfMirror,
                                       const float* __restrict__ depth, const uchar4* __restrict__ rgb, const FuseParams& p,
                                       bool hasNext, const HashEntry& next, int nextZ0, typename VX::Reg nextR[kSlices]) {
   const bool present = he.ptr >= 0;
@@ -235,6 +235,9 @@ __device__ inline void integrate_item(const HashEntry& he, int z0, int lane, typ
   const size_t vi = (size_t)(present ? he.ptr : 0) * kBlockVoxels + (size_t)z0 * 64 + lane;
   const float mx = (float)(he.px * kBlockSide + x) * p.voxelSize;
   const float my = (float)(he.py * kBlockSide + y) * p.voxelSize;
+  size_t mbase = 0;
+  int16_t* mirror = nullptr;
+  if constexpr (VX::kShort) { if (sdfMirror && mirror_index(he.px * kBlockSide, he.py * kBlockSide, he.pz * kBlockSide, mbase)) mirror = sdfMirror; }
   // stage 1: project every slice's voxel; stage 2: all depth pixels together; stage 3: update (+ colour), store what changed
   int pix[kSlices];
   float pcz[kSlices], mz[kSlices];
@@ -260,13 +263,16 @@ __device__ inline void integrate_item(const HashEntry& he, int z0, int lane, typ
         touched = true;
       }
     }
-    if (touched) VX::store(vba, vi + 64 * k, r[k]);
+    if (touched) {
+      VX::store(vba, vi + 64 * k, r[k]);
+      if constexpr (VX::kShort) { if (mirror) mirror[mbase + (size_t)(z0 + k) * 64 + lane] = (int16_t)VX::raw_sdf(r[k]); }   // sdf mirror (itm_types.h)
+    }
   }
 }
 
 template <class VX>
 __device__ inline void integrate_hash_body(int wgIdx, int wgCount, const int32_t* __restrict__ visibleIds, RenderCounters* __restrict__ rc,
-                                           const uint4* __restrict__ hash, void* __restrict__ vba,
+                                           const uint4* __restrict__ hash, void* __restrict__ vba, int16_t* __restrict__ sdfMirror,
                                            const float* __restrict__ depth, const uchar4* __restrict__ rgb, const FuseParams& p) {
   const int nItems = rc->noVisibleEntries * kItemsPerBlock;
   const int lane = threadIdx.x & 63;
@@ -283,12 +289,12 @@ __device__ inline void integrate_hash_body(int wgIdx, int wgCount, const int32_t
     if (more) ahead = unpack_entry(hash[visibleIds[nxt / kItemsPerBlock]]);
     const int zn = (nxt % kItemsPerBlock) * kSlices;
 #if ITM_INTEGRATE_PREFETCH
-    integrate_item<VX>(cur, (i % kItemsPerBlock) * kSlices, lane, r, vba, depth, rgb, p, more, ahead, zn, rn);
+    integrate_item<VX>(cur, (i % kItemsPerBlock) * kSlices, lane, r, vba, sdfMirror, depth, rgb, p, more, ahead, zn, rn);
     if (!more) break;
 #pragma unroll
     for (int k = 0; k < kSlices; ++k) r[k] = rn[k];
 #else
-    integrate_item<VX>(cur, (i % kItemsPerBlock) * kSlices, lane, r, vba, depth, rgb, p, false, ahead, 0, rn);
+    integrate_item<VX>(cur, (i % kItemsPerBlock) * kSlices, lane, r, vba, sdfMirror, depth, rgb, p, false, ahead, 0, rn);
     if (!more) break;
     load_item<VX>(ahead, zn, lane, vba, r);
 #endif
@@ -298,9 +304,9 @@ __device__ inline void integrate_hash_body(int wgIdx, int wgCount, const int32_t
 
 template <class VX>
 __global__ void __launch_bounds__(512) integrate_hash_kernel(const int32_t* __restrict__ visibleIds, RenderCounters* __restrict__ rc,
-                                                             const uint4* __restrict__ hash, void* __restrict__ vba,
+                                                             const uint4* __restrict__ hash, void* __restrict__ vba, int16_t* __restrict__ sdfMirror,
                                                              const float* __restrict__ depth, const uchar4* __restrict__ rgb, FuseParams p) {
-  integrate_hash_body<VX>(blockIdx.x, gridDim.x, visibleIds, rc, hash, vba, depth, rgb, p);
+  integrate_hash_body<VX>(blockIdx.x, gridDim.x, visibleIds, rc, hash, vba, sdfMirror, depth, rgb, p);
 }
 
 // IntegrateIntoScene and the projection half of CreateExpectedDepths in ONE launch: both only depend on the
@@ -316,7 +322,7 @@ __device__ unsigned long long g_fusedStamps[8192 * 2];
 #endif
 template <class VX>
 __global__ void __launch_bounds__(512) integrate_project_kernel(const int32_t* __restrict__ visibleIds, RenderCounters* __restrict__ rc,
-                                                                const uint4* __restrict__ hash, void* __restrict__ vba,
+                                                                const uint4* __restrict__ hash, void* __restrict__ vba, int16_t* __restrict__ sdfMirror,
                                                                 const float* __restrict__ depth, const uchar4* __restrict__ rgb, FuseParams p,
                                                                 float2* __restrict__ range, uint4* __restrict__ projBuf, uint2* __restrict__ partials,
                                                                 ProjParams pp, int RW, int RH) {
@@ -332,7 +338,7 @@ __global__ void __launch_bounds__(512) integrate_project_kernel(const int32_t* _
     ITM_FS(__syncthreads(); if (threadIdx.x == 0) g_fusedStamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();)
     return;
   }
-  integrate_hash_body<VX>(blockIdx.x - kRangeParts, gridDim.x - kRangeParts, visibleIds, rc, hash, vba, depth, rgb, p);
+  integrate_hash_body<VX>(blockIdx.x - kRangeParts, gridDim.x - kRangeParts, visibleIds, rc, hash, vba, sdfMirror, depth, rgb, p);
   ITM_FS(__syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 8192) g_fusedStamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();)
 }
 #if ITM_EXP_FUSED_STAMPS
@@ -544,10 +550,10 @@ int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipS
     int rc = dispatch_voxel(s->cfg.voxelType, [&](auto vx) {
       using VX = decltype(vx);
       if (fuseProjection)
-        integrate_project_kernel<VX><<<grid, 512, (size_t)RW * RH * sizeof(uint2), st>>>(rs->visibleIds, rs->counters, s->hash, s->vba, v->depth, rgb, p,
+        integrate_project_kernel<VX><<<grid, 512, (size_t)RW * RH * sizeof(uint2), st>>>(rs->visibleIds, rs->counters, s->hash, s->vba, s->sdfMirror, v->depth, rgb, p,
                                                                                        rs->range, rs->projBuf, rs->rangePartials, pp, RW, RH);
       else
-        integrate_hash_kernel<VX><<<grid, 512, 0, st>>>(rs->visibleIds, rs->counters, s->hash, s->vba, v->depth, rgb, p);
+        integrate_hash_kernel<VX><<<grid, 512, 0, st>>>(rs->visibleIds, rs->counters, s->hash, s->vba, s->sdfMirror, v->depth, rgb, p);
       return ITM_OK;
     });
     if (rc) return rc;

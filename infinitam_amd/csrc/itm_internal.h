@@ -76,6 +76,7 @@ struct itm_scene {
   // Block directory (itm_types.h): dirPtr[cell] = voxel-block index of the block at that position or -1, cells in brick-major
   // order.  Maintained by the allocation sweep, rebuilt after uploads; an exact mirror of the table entries with ptr >= 0.
   int32_t* dirPtr = nullptr;      // int32[kDirCells]  (512 MB)
+  int16_t* sdfMirror = nullptr;   // int16[kMirrorCells * 512]  (17 GB; short voxel types of hash scenes, itm_types.h) or nullptr
   uint32_t frameParity = 0;
   itm::Profiler* prof = nullptr;
 };
@@ -159,6 +160,8 @@ extern int g_debug_integrate_wgs;
 extern int g_debug_dense_group_cull;
 extern int g_debug_tracker_launch_per_evaluation;
 extern int g_debug_tracker_host_command;
+extern int g_debug_no_sdf_mirror;
+int rebuild_sdf_mirror(itm_scene* s, hipStream_t st);
 extern int g_debug_no_fused_projection;
 int rebuild_head_bits(itm_scene* s, hipStream_t st);   // occupancy bitmap AND block directory, from the table
 extern int g_debug_no_directory;

@@ -144,6 +144,27 @@ __global__ void __launch_bounds__(256) directory_fill_kernel(const uint4* __rest
   directory_insert(dirPtr, e.px, e.py, e.pz, e.ptr);
 }
 
+// rebuilds the sdf mirror from the table and the pool: one workgroup per entry, the 512 sdf values of every allocated block inside the cube
+template <class VX>
+__global__ void __launch_bounds__(256) mirror_fill_kernel(const uint4* __restrict__ hash, int nEntries, const void* __restrict__ vba, int16_t* __restrict__ mirror) {
+  for (int i = blockIdx.x; i < nEntries; i += gridDim.x) {
+    const HashEntry e = unpack_entry(hash[i]);
+    if (e.ptr < 0) continue;
+    size_t base;
+    if (!mirror_index(e.px * kBlockSide, e.py * kBlockSide, e.pz * kBlockSide, base)) continue;
+    for (int t = threadIdx.x; t < kBlockVoxels; t += 256) mirror[base + t] = (int16_t)VX::load_raw_sdf(vba, (size_t)e.ptr * kBlockVoxels + t);
+  }
+}
+
+int rebuild_sdf_mirror(itm_scene* s, hipStream_t st) {
+  if (!s->sdfMirror) return ITM_OK;
+  ITM_HIP(hipMemsetD16Async(s->sdfMirror, (unsigned short)0x8000, kMirrorCells * 512, st));
+  if (s->cfg.voxelType == ITM_VOXEL_S) mirror_fill_kernel<VoxelS><<<4096, 256, 0, st>>>(s->hash, s->noTotalEntries, s->vba, s->sdfMirror);
+  else mirror_fill_kernel<VoxelSRgb><<<4096, 256, 0, st>>>(s->hash, s->noTotalEntries, s->vba, s->sdfMirror);
+  ITM_LAUNCH_CHECK();
+  return ITM_OK;
+}
+
 int rebuild_head_bits(itm_scene* s, hipStream_t st) {
   if (!s->headBits) return ITM_OK;
   const int nWords = (s->cfg.bucketNum + 31) / 32;
@@ -241,7 +262,7 @@ static void free_scene(itm_scene* s) {
   if (s->prof) { s->prof->flush(); for (hipEvent_t e : s->prof->pool) (void)hipEventDestroy(e); delete s->prof; }
   (void)hipFree(s->hash); (void)hipFree(s->excessList); (void)hipFree(s->vba); (void)hipFree(s->allocList);
   (void)hipFree(s->counters); (void)hipFree(s->headBits); (void)hipFree(s->allocKey); (void)hipFree(s->chunkReq); (void)hipFree(s->chunkVis); (void)hipFree(s->chunkGran);
-  (void)hipFree(s->dirPtr);
+  (void)hipFree(s->dirPtr); (void)hipFree(s->sdfMirror);
   delete s;
 }
 static void free_rs(itm_render_state* r) {
@@ -339,6 +360,15 @@ int itm_scene_create(const itm_scene_config* cfg_in, const itm_scene_params* prm
   alloc(&s->vba, s->numVoxels * vb + 16);
   alloc((void**)&s->counters, sizeof(SceneCounters));
   if (e != hipSuccess) { free_scene(s); return hip_fail(e, "hipMalloc(scene)", __FILE__, __LINE__); }
+  if (cfg.indexType == ITM_INDEX_HASH && (cfg.voxelType == ITM_VOXEL_S || cfg.voxelType == ITM_VOXEL_S_RGB) && !g_debug_no_sdf_mirror) {
+    // the sdf mirror is an accelerator: taken when the device has room to spare (it is 17 GB), silently left out otherwise
+    size_t freeB = 0, totalB = 0;
+    const size_t bytes = kMirrorCells * 512 * sizeof(int16_t);
+    if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB > 3 * bytes) {
+      if (hipMalloc((void**)&s->sdfMirror, bytes) != hipSuccess) { s->sdfMirror = nullptr; (void)hipGetLastError(); }
+      else if (hipMemsetD16(s->sdfMirror, (unsigned short)0x8000, kMirrorCells * 512) != hipSuccess) { (void)hipFree(s->sdfMirror); s->sdfMirror = nullptr; (void)hipGetLastError(); }
+    }
+  }
   e = hipMemset(s->counters, 0, sizeof(SceneCounters));
   if (e == hipSuccess && s->allocKey) e = hipMemset(s->allocKey, 0, (size_t)s->noTotalEntries * 4);
   if (e == hipSuccess && s->headBits) e = hipMemset(s->headBits, 0, (size_t)(cfg.bucketNum + 31) / 32 * 4);
@@ -377,6 +407,7 @@ int itm_reset_scene(itm_scene* s, itm_stream stream) {
   ITM_LAUNCH_CHECK();
   if (s->cfg.indexType == ITM_INDEX_HASH) {
     ITM_HIP(hipMemsetAsync(s->dirPtr, 0xff, kDirCells * 4, st));
+    if (s->sdfMirror) ITM_HIP(hipMemsetD16Async(s->sdfMirror, (unsigned short)0x8000, kMirrorCells * 512, st));
     reset_hash_kernel<<<1024, 256, 0, st>>>(s->hash, s->noTotalEntries, s->excessList, s->cfg.excessNum, s->allocList,
                                             s->cfg.localBlockNum, s->allocKey, s->headBits, (s->cfg.bucketNum + 31) / 32, s->chunkReq, s->numChunks * 4, s->counters);
   } else {
@@ -538,6 +569,7 @@ int itm_upload(itm_scene* s, itm_render_state* rs, int which, const void* src, s
   hipStream_t st = as_stream(stream);
   ITM_HIP(hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, st));
   if (which == ITM_BUF_HASH_ENTRIES) { int rc = rebuild_head_bits(s, st); if (rc) return rc; }
+  if (which == ITM_BUF_HASH_ENTRIES || which == ITM_BUF_VOXEL_BLOCKS) { int rc = rebuild_sdf_mirror(s, st); if (rc) return rc; }   // whichever comes last leaves it consistent
   if (rs && (which == ITM_BUF_VISIBLE_IDS || which == ITM_BUF_VISIBLE_TYPE)) rs->listCoherent = false;
   ITM_HIP(hipStreamSynchronize(st));
   return ITM_OK;

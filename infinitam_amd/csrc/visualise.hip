@@ -35,6 +35,7 @@ namespace itm {
 
 int g_debug_force_global_range = 0;
 int g_debug_no_directory = 0;
+int g_debug_no_sdf_mirror = 0;      // debug key 12: ray casting reads voxels through the directory / table although the scene has an sdf mirror
 int g_debug_no_fused_range_reduce = 0;
 int g_debug_single_pass_raycast = 0;
 
@@ -490,6 +491,7 @@ int itm_debug_set(int key, int value) {
   if (key == ITM_DEBUG_DENSE_GROUP_CULL) { g_debug_dense_group_cull = value; return ITM_OK; }
   if (key == ITM_DEBUG_TRACKER_LAUNCH_PER_EVALUATION) { g_debug_tracker_launch_per_evaluation = value; return ITM_OK; }
   if (key == ITM_DEBUG_TRACKER_HOST_COMMAND) { g_debug_tracker_host_command = value; return ITM_OK; }
+  if (key == ITM_DEBUG_NO_SDF_MIRROR) { g_debug_no_sdf_mirror = value; return ITM_OK; }
   return set_error(ITM_ERR_INVALID, "unknown debug key");
 }
 

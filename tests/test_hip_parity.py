@@ -238,6 +238,35 @@ def test_directory_and_table_walk_agree_with_oracle(hip, oracle, sc):
     finally:
         hip.check(hip.fn["debug_set"](5, 0), "debug_set")
     T.compare_results(a, b, sc, what=sc.name + "/table walk")
+    # the sdf mirror (voxels addressed by position, short voxel types) is what the default path read; ITM_DEBUG_NO_SDF_MIRROR (12)
+    # sends the same rays through the directory and the voxel pool
+    hip.check(hip.fn["debug_set"](12, 1), "debug_set")
+    try:
+        a = T.run_scenario(hip, sc, fused=True)
+    finally:
+        hip.check(hip.fn["debug_set"](12, 0), "debug_set")
+    T.compare_results(a, b, sc, what=sc.name + "/directory without the sdf mirror")
+
+
+def test_ray_cast_sees_blocks_that_were_allocated_but_never_integrated(hip, oracle):
+    """Engine calls in an order the main loop never uses: allocate for a new view, then ray-cast WITHOUT integrating.  The new
+    blocks hold the initial voxel value; the ray caster must find them (a block that exists reads 1 and makes the ray step
+    mu / voxelSize voxels, a missing block makes it step 8) -- on the sdf mirror too, which the allocation initialises."""
+    sc = Scenario(name="alloc_only", w=320, h=240, voxelSize=0.005, frames=2)
+    out = []
+    for be in (hip, oracle):
+        ses = T.Session(be, sc)
+        ses.frame(0)
+        v = ses.view(1)
+        M = T.synth.pose_matrix_yaw((0.3, 0.1, 0.0), 0.25)           # a view that sees new surface
+        v2 = T.View(v.depth, sc.w, sc.h, M_d=M, intr_d=sc.intr())
+        ses.scene.reco.AllocateSceneFromDepth(v2, ses.rs)
+        ses.scene.vis.CreateExpectedDepths(M, sc.intr(), ses.rs)
+        ses.scene.vis.FindSurface(M, sc.intr(), ses.rs)
+        out.append((ses.scene.download(T.BUF_RAYCAST_RESULT, ses.rs).copy(), ses.scene.counters(ses.rs)["lastFreeBlockId"]))
+        ses.close()
+    assert out[0][1] == out[1][1]
+    assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
 
 
 @pytest.mark.parametrize("sc", [DIRECTORY_CASES[1], DIRECTORY_CASES[2]], ids=lambda s: s.name)
