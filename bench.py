@@ -221,11 +221,27 @@ def worker(args) -> int:
             if world > 1:
                 t = torch.zeros(128, dtype=torch.uint8, device=device)
                 if rank == 0:
-                    t.copy_(torch.tensor(list(NativeExchange.unique_id(be)), dtype=torch.uint8))
+                    try:
+                        t.copy_(torch.tensor(list(NativeExchange.unique_id(be)), dtype=torch.uint8))
+                    except Exception as e:      # noqa: BLE001 -- an all-zero id tells every rank to take the torch path
+                        print(f"bench.py: no RCCL unique id ({e})", file=sys.stderr)
                 dist.broadcast(t, 0)
                 uid = bytes(t.cpu().tolist())
-            exs.append(NativeExchange(be, world, rank, MAX_IDS, batch=max(1, args.exchange_batch), unique_id=uid))
-    elif exchange:
+                if not any(uid):
+                    break
+            try:
+                exs.append(NativeExchange(be, world, rank, MAX_IDS, batch=max(1, args.exchange_batch), unique_id=uid))
+            except Exception as e:      # noqa: BLE001 -- reported below, every rank then takes the torch path together
+                print(f"bench.py: rank {rank}: library exchange unavailable ({e})", file=sys.stderr)
+                break
+        ok = torch.tensor([1 if len(exs) == len(streams) else 0], dtype=torch.int32, device=device)
+        if world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)      # all ranks or none
+        if int(ok.item()) == 0:
+            for ex in exs:
+                ex.close()
+            exs, native = [], False
+    if exchange and not native:
         from infinitam_amd.streams import VisibleListExchange
         exs = [VisibleListExchange(be, world, rank, MAX_IDS, device=device, batch=max(1, args.exchange_batch)) for _ in streams]
 

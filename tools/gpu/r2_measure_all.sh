@@ -3,9 +3,10 @@
 cd "$(dirname "$0")/../.."
 R=$PWD; O=gpurun_out/r2final; rm -rf $O; mkdir -p $O
 python bench.py > $O/bench_c2.json 2> $O/bench_c2.err
-python bench.py --config 3 --steps 60 --warmup 10 > $O/bench_c3.json 2> $O/bench_c3.err
-python bench.py --config 5 --steps 60 --warmup 10 > $O/bench_c5.json 2> $O/bench_c5.err
+python bench.py --config 3 > $O/bench_c3.json 2> $O/bench_c3.err
+python bench.py --config 5 > $O/bench_c5.json 2> $O/bench_c5.err
 python bench.py --streams-per-gpu 2 --no-cpu-baseline > $O/bench_k2.json 2> /dev/null
+python bench.py --streams-per-gpu 3 --no-cpu-baseline > $O/bench_k3.json 2> /dev/null
 python bench.py --streams-per-gpu 4 --no-cpu-baseline > $O/bench_k4.json 2> /dev/null
 python bench.py --force-exchange --exchange-batch 1 --no-cpu-baseline 2> /dev/null | tail -1 > $O/bench_fx1.json
 python bench.py --force-exchange --exchange-batch 8 --no-cpu-baseline 2> /dev/null | tail -1 > $O/bench_fx8.json
@@ -16,13 +17,8 @@ python tools/config_bench.py 2 200 | tail -1 > $O/cfg2.json
 python tools/config_bench.py 3 60 | tail -1 > $O/cfg3.json
 python tools/config_bench.py 5 60 | tail -1 > $O/cfg5.json
 ITM_DEBUG_KEYS=8 python tools/config_bench.py 2 200 | tail -1 > $O/cfg2_single_phase_raycast.json
+ITM_DEBUG_KEYS=12 python tools/config_bench.py 2 200 | tail -1 > $O/cfg2_no_sdf_mirror.json
 ITM_NO_DIRECTORY=1 python tools/config_bench.py 2 200 | tail -1 > $O/cfg2_table_walk.json
-python tools/wave_stats.py gpurun_variants/lib_wt.so > $O/wave_two_phase.txt 2>&1
-python - <<'PY' > $O/wave_hist.txt
-import numpy as np
-st = np.load("gpurun_out/wave_stats.npy"); tot = st[:4800, 0].astype(float) / 1000
-print("per-wave kilo-cycles of the ray-cast kernel (two-phase, in-kernel stamps), histogram edges", [0, 20, 30, 40, 60, 80, 100, 120, 160, 200])
-print(np.histogram(tot, bins=[0, 20, 30, 40, 60, 80, 100, 120, 160, 200])[0].tolist())
-PY
+python tools/raycast_timeline.py gpurun_variants/lib_rs.so > $O/raycast_timeline.txt 2>&1
 bash tools/gpu/r2_profiles.sh > $O/profiles.log 2>&1
-for f in $O/bench_*.json; do echo "$f: $(cut -c1-230 $f)"; done; cat $O/tracker.txt $O/closed_loop.txt $O/wave_two_phase.txt $O/wave_hist.txt; cut -c1-330 $O/cfg*.json; tail -40 $O/profiles.log
+for f in $O/bench_*.json; do echo "$f: $(cut -c1-230 $f)"; done; cat $O/tracker.txt $O/closed_loop.txt $O/raycast_timeline.txt; cut -c1-330 $O/cfg*.json; tail -40 $O/profiles.log

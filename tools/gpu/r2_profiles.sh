@@ -5,7 +5,7 @@ cd "$(dirname "$0")/../.."
 R=$PWD; O=gpurun_out/r2prof; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for c in 2 3 5; do
-  steps=200; [ $c != 2 ] && steps=60
+  steps=200
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/stats_c$c -o s -- python3 $R/bench.py --config $c --steps $steps --warmup 10 --no-cpu-baseline > $R/$O/stats_c$c.log 2>&1
 done
 declare -A RX=( [2]="raycast_kernel" [3]="integrate_dense" [5]="integrate_hash_kernel" )
