@@ -87,7 +87,7 @@ template <bool ONLY_VISIBLE, bool FUSE_RANGE_INIT, bool LAZY>
 __global__ void __launch_bounds__(256) request_kernel(const float* __restrict__ depth, const uint4* __restrict__ hash,
                                                       uint8_t* __restrict__ visT, uint32_t* __restrict__ allocKey,
                                                       int2* __restrict__ chunkReq, SceneCounters* __restrict__ counters,
-                                                      float2* __restrict__ range, RenderCounters* __restrict__ rcnt, AllocParams p) {
+                                                      float2* __restrict__ range, RenderCounters* __restrict__ rcnt, const int32_t* __restrict__ dirSlot, AllocParams p) {
   // LAZY: instead of first marking last frame's list as type 3 (a separate launch), this frame's
   // touches carry bit 7; visible_count_kernel then reads every other non-zero type as "3".
   constexpr uint8_t kTouched = LAZY ? 0x80 : 0x00;
@@ -109,6 +109,19 @@ __global__ void __launch_bounds__(256) request_kernel(const float* __restrict__ 
   }
   for (int i = 0; i < r.noSteps; ++i) {
     const int bx = (int)(int16_t)(int)floorf(r.px), by = (int)(int16_t)(int)floorf(r.py), bz = (int)(int16_t)(int)floorf(r.pz);
+    if (dirSlot) {
+      // a block that exists inside the directory's cube: its table slot from one coherent load (entries are never swapped out:
+      // ptr >= 0, hence type 1); every other case takes the probe below
+      const uint32_t ux = (uint32_t)(bx + kDirHalf), uy = (uint32_t)(by + kDirHalf), uz = (uint32_t)(bz + kDirHalf);
+      if (dir_covers(ux, uy, uz)) {
+        const int slot = dirSlot[dir_cell(ux, uy, uz)];
+        if (slot >= 0) {
+          visT[slot] = 1 | kTouched;
+          r.px += r.dx; r.py += r.dy; r.pz += r.dz;
+          continue;
+        }
+      }
+    }
     int idx = hash_index(bx, by, bz, p.mask);
     HashEntry he = unpack_entry(hash[idx]);
     bool found = false;
@@ -166,7 +179,7 @@ __global__ void __launch_bounds__(256) allocate_sweep_kernel(uint32_t* __restric
                                                              int2* __restrict__ chunkReqNext, int numChunks, uint4* __restrict__ hash,
                                                              const int32_t* __restrict__ excessList, const int32_t* __restrict__ allocList,
                                                              uint8_t* __restrict__ visT, const SceneCounters* __restrict__ counters,
-                                                             uint32_t* __restrict__ headBits, int32_t* __restrict__ dirPtr, int16_t* __restrict__ sdfMirror,
+                                                             uint32_t* __restrict__ headBits, int32_t* __restrict__ dirPtr, int32_t* __restrict__ dirSlot, int16_t* __restrict__ sdfMirror,
                                                              const float* __restrict__ depth, int lazy, AllocParams p) {
   __shared__ int lds[8];
   const int chunk = blockIdx.x;
@@ -218,7 +231,7 @@ __global__ void __launch_bounds__(256) allocate_sweep_kernel(uint32_t* __restric
         const int ptr = allocList[vbaIdx];
         hash[p.bucketNum + off] = pack_entry(bx, by, bz, 0, ptr);
         visT[p.bucketNum + off] = lazy ? 0x81 : 1;
-        directory_insert(dirPtr, bx, by, bz, ptr);
+        directory_insert(dirPtr, dirSlot, bx, by, bz, ptr, p.bucketNum + off);
         mirror_init_block(sdfMirror, bx, by, bz);
       }
     } else if (vbaIdx >= 0) {
@@ -227,7 +240,7 @@ __global__ void __launch_bounds__(256) allocate_sweep_kernel(uint32_t* __restric
       const int ptr = allocList[vbaIdx];
       hash[slot] = pack_entry(bx, by, bz, 0, ptr);
       atomicOr(&headBits[slot >> 5], 1u << (slot & 31));
-      directory_insert(dirPtr, bx, by, bz, ptr);
+      directory_insert(dirPtr, dirSlot, bx, by, bz, ptr, slot);
       mirror_init_block(sdfMirror, bx, by, bz);
     }
     allocKey[slot] = 0u;
@@ -481,7 +494,7 @@ int launch_request_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, 
   if (!lazy) mark_previous_kernel<<<64, 256, 0, st>>>(rs->visibleIds, rs->counters, rs->visibleType);
   dim3 grid((v->w + 15) / 16, (v->h + 15) / 16);
   KernelTimer tq(s, ITM_TK_REQUEST, st);
-#define ITM_REQ(OV, FU, LZ) request_kernel<OV, FU, LZ><<<grid, 256, 0, st>>>(v->depth, s->hash, rs->visibleType, s->allocKey, reqCur, s->counters, rs->range, rs->counters, p)
+#define ITM_REQ(OV, FU, LZ) request_kernel<OV, FU, LZ><<<grid, 256, 0, st>>>(v->depth, s->hash, rs->visibleType, s->allocKey, reqCur, s->counters, rs->range, rs->counters, g_debug_no_directory ? nullptr : s->dirSlot, p)
   if (onlyVisible) {
     if (fuseRangeInit) { if (lazy) ITM_REQ(true, true, true); else ITM_REQ(true, true, false); }
     else { if (lazy) ITM_REQ(true, false, true); else ITM_REQ(true, false, false); }
@@ -506,7 +519,7 @@ int launch_sweep_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, bo
   if (!onlyVisible) {
     KernelTimer ts(s, ITM_TK_ALLOC_SWEEP, st);
     allocate_sweep_kernel<<<nChunks, 256, 0, st>>>(s->allocKey, reqCur, reqNext, nChunks, s->hash, s->excessList, s->allocList,
-                                                   rs->visibleType, s->counters, s->headBits, s->dirPtr, s->sdfMirror, v->depth, lazy ? 1 : 0, p);
+                                                   rs->visibleType, s->counters, s->headBits, s->dirPtr, s->dirSlot, s->sdfMirror, v->depth, lazy ? 1 : 0, p);
     s->frameParity++;
   }
   KernelTimer tv(s, ITM_TK_VISIBLE_LIST, st);

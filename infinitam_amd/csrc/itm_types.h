@@ -222,9 +222,15 @@ __host__ __device__ inline uint32_t dir_cell(uint32_t ux, uint32_t uy, uint32_t 
   return (brick << 6) | ((uz & 3u) << 4) | ((uy & 3u) << 2) | (ux & 3u);
 }
 // records an allocated block (device side; called by the allocation sweep and the rebuild kernel)
-__device__ inline void directory_insert(int32_t* __restrict__ dirPtr, int bx, int by, int bz, int ptr) {
+// (dirSlot: the same cells holding the TABLE SLOT of the block instead of its voxel-block index -- what the allocation request
+// needs to mark a block that already exists as visible, one coherent 4-byte load instead of the 16-byte entry of a random bucket)
+__device__ inline void directory_insert(int32_t* __restrict__ dirPtr, int32_t* __restrict__ dirSlot, int bx, int by, int bz, int ptr, int slot) {
   const uint32_t ux = (uint32_t)(bx + kDirHalf), uy = (uint32_t)(by + kDirHalf), uz = (uint32_t)(bz + kDirHalf);
-  if (dir_covers(ux, uy, uz)) dirPtr[dir_cell(ux, uy, uz)] = ptr;
+  if (dir_covers(ux, uy, uz)) {
+    const uint32_t cell = dir_cell(ux, uy, uz);
+    dirPtr[cell] = ptr;
+    if (dirSlot) dirSlot[cell] = slot;
+  }
 }
 
 // ---- sdf mirror -------------------------------------------------------------------------------

@@ -136,12 +136,12 @@ __global__ void __launch_bounds__(256) head_bits_kernel(const uint4* __restrict_
 }
 
 // rebuilds the block directory from the table: every entry with ptr >= 0 whose position lies inside the directory
-__global__ void __launch_bounds__(256) directory_fill_kernel(const uint4* __restrict__ hash, int nEntries, int32_t* __restrict__ dirPtr) {
+__global__ void __launch_bounds__(256) directory_fill_kernel(const uint4* __restrict__ hash, int nEntries, int32_t* __restrict__ dirPtr, int32_t* __restrict__ dirSlot) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nEntries) return;
   const HashEntry e = unpack_entry(hash[i]);
   if (e.ptr < 0) return;
-  directory_insert(dirPtr, e.px, e.py, e.pz, e.ptr);
+  directory_insert(dirPtr, dirSlot, e.px, e.py, e.pz, e.ptr, i);
 }
 
 // rebuilds the sdf mirror from the table and the pool: one workgroup per entry, the 512 sdf values of every allocated block inside the cube
@@ -171,7 +171,8 @@ int rebuild_head_bits(itm_scene* s, hipStream_t st) {
   head_bits_kernel<<<(nWords + 255) / 256, 256, 0, st>>>(s->hash, s->headBits, nWords, s->cfg.bucketNum);
   if (s->dirPtr) {
     ITM_HIP(hipMemsetAsync(s->dirPtr, 0xff, kDirCells * 4, st));
-    directory_fill_kernel<<<(s->noTotalEntries + 255) / 256, 256, 0, st>>>(s->hash, s->noTotalEntries, s->dirPtr);
+    if (s->dirSlot) ITM_HIP(hipMemsetAsync(s->dirSlot, 0xff, kDirCells * 4, st));
+    directory_fill_kernel<<<(s->noTotalEntries + 255) / 256, 256, 0, st>>>(s->hash, s->noTotalEntries, s->dirPtr, s->dirSlot);
   }
   ITM_LAUNCH_CHECK();
   return ITM_OK;
@@ -262,7 +263,7 @@ static void free_scene(itm_scene* s) {
   if (s->prof) { s->prof->flush(); for (hipEvent_t e : s->prof->pool) (void)hipEventDestroy(e); delete s->prof; }
   (void)hipFree(s->hash); (void)hipFree(s->excessList); (void)hipFree(s->vba); (void)hipFree(s->allocList);
   (void)hipFree(s->counters); (void)hipFree(s->headBits); (void)hipFree(s->allocKey); (void)hipFree(s->chunkReq); (void)hipFree(s->chunkVis); (void)hipFree(s->chunkGran);
-  (void)hipFree(s->dirPtr); (void)hipFree(s->sdfMirror);
+  (void)hipFree(s->dirPtr); (void)hipFree(s->dirSlot); (void)hipFree(s->sdfMirror);
   delete s;
 }
 static void free_rs(itm_render_state* r) {
@@ -353,6 +354,7 @@ int itm_scene_create(const itm_scene_config* cfg_in, const itm_scene_params* prm
     alloc((void**)&s->chunkVis, (size_t)s->numChunks * 4);
     alloc((void**)&s->chunkGran, (size_t)s->numChunks * 8);
     alloc((void**)&s->dirPtr, kDirCells * 4);
+    alloc((void**)&s->dirSlot, kDirCells * 4);
   } else {
     s->numVoxels = (size_t)cfg.denseSize[0] * cfg.denseSize[1] * cfg.denseSize[2];
     alloc((void**)&s->allocList, 4);
@@ -376,6 +378,7 @@ int itm_scene_create(const itm_scene_config* cfg_in, const itm_scene_params* prm
   if (e == hipSuccess && s->chunkReq) e = hipMemset(s->chunkReq, 0, (size_t)s->numChunks * 16);
   if (e == hipSuccess && s->chunkGran) e = hipMemset(s->chunkGran, 0, (size_t)s->numChunks * 8);
   if (e == hipSuccess && s->dirPtr) e = hipMemset(s->dirPtr, 0xff, kDirCells * 4);
+  if (e == hipSuccess && s->dirSlot) e = hipMemset(s->dirSlot, 0xff, kDirCells * 4);
   if (e != hipSuccess) { free_scene(s); return hip_fail(e, "hipMemset(scene)", __FILE__, __LINE__); }
   *out = s;
   return ITM_OK;
@@ -407,6 +410,7 @@ int itm_reset_scene(itm_scene* s, itm_stream stream) {
   ITM_LAUNCH_CHECK();
   if (s->cfg.indexType == ITM_INDEX_HASH) {
     ITM_HIP(hipMemsetAsync(s->dirPtr, 0xff, kDirCells * 4, st));
+    ITM_HIP(hipMemsetAsync(s->dirSlot, 0xff, kDirCells * 4, st));
     if (s->sdfMirror) ITM_HIP(hipMemsetD16Async(s->sdfMirror, (unsigned short)0x8000, kMirrorCells * 512, st));
     reset_hash_kernel<<<1024, 256, 0, st>>>(s->hash, s->noTotalEntries, s->excessList, s->cfg.excessNum, s->allocList,
                                             s->cfg.localBlockNum, s->allocKey, s->headBits, (s->cfg.bucketNum + 31) / 32, s->chunkReq, s->numChunks * 4, s->counters);
