@@ -173,6 +173,7 @@ int ITM_FN(set_device)(int device);
 #define ITM_DEBUG_DENSE_GROUP_CULL 9          /* dense integration: frustum test per 4-voxel group instead of the per-column row interval */
 #define ITM_DEBUG_TRACKER_LAUNCH_PER_EVALUATION 10 /* TrackCamera: one launch per cost evaluation instead of one resident kernel per call */
 #define ITM_DEBUG_TRACKER_HOST_COMMAND 11     /* TrackCamera session: commands through pinned host memory (set before the tracker's first call) */
+#define ITM_DEBUG_SEPARATE_SWEEP 13           /* AllocateSceneFromDepth: allocation sweep as its own launch, not inside the visible-list launch */
 #define ITM_DEBUG_NO_SDF_MIRROR 12            /* ray casting: voxels through the directory / table although the scene has an sdf mirror; set before itm_scene_create: no mirror is allocated */
 int ITM_FN(debug_set)(int key, int value);
 /* out[i] = SDF_valueToFloat(in[i]) of the short voxel types, i.e. in[i] / 32767.0f, through the same

@@ -31,6 +31,7 @@ namespace itm {
 
 int g_debug_explicit_mark = 0;   // test hook: always run the explicit mark-previous launch
 int g_debug_two_pass_visible_list = 0;   // test hook: count and compact as two launches
+int g_debug_separate_sweep = 0;          // test hook (key 13): the allocation sweep as its own launch
 
 struct AllocParams {
   Mat4 invM;     // inverse of M_d (host, ORUtils cofactor scheme)
@@ -175,13 +176,17 @@ constexpr int kSlotsPerThread = kSweepChunk / 256;  // 8
 
 // Ascending-slot allocation sweep (_CPU.cpp:175-227).  chunkReq holds, per 2048-slot chunk, the
 // number of requested slots and of excess-list requests; next-frame counters are zeroed here.
-__global__ void __launch_bounds__(256) allocate_sweep_kernel(uint32_t* __restrict__ allocKey, const int2* __restrict__ chunkReq,
-                                                             int2* __restrict__ chunkReqNext, int numChunks, uint4* __restrict__ hash,
-                                                             const int32_t* __restrict__ excessList, const int32_t* __restrict__ allocList,
-                                                             uint8_t* __restrict__ visT, const SceneCounters* __restrict__ counters,
-                                                             uint32_t* __restrict__ headBits, int32_t* __restrict__ dirPtr, int32_t* __restrict__ dirSlot, int16_t* __restrict__ sdfMirror,
-                                                             const float* __restrict__ depth, int lazy, AllocParams p) {
-  __shared__ int lds[8];
+// The sweep of ONE chunk by its workgroup.  ACROSS: the visible type of a new excess entry lies in another chunk; when the visible
+// list is built by the same launch (visible_list_kernel<.., SWEEP>) the workgroup of that chunk reads it there, so it is written
+// with a device-scope store that bypasses the non-coherent L2s.
+template <bool ACROSS>
+__device__ inline void sweep_chunk(int* lds, uint32_t* __restrict__ allocKey, const int2* __restrict__ chunkReq,
+                                   int2* __restrict__ chunkReqNext, int numChunks, uint4* __restrict__ hash,
+                                   const int32_t* __restrict__ excessList, const int32_t* __restrict__ allocList,
+                                   uint8_t* __restrict__ visT, const SceneCounters* __restrict__ counters,
+                                   uint32_t* __restrict__ headBits, int32_t* __restrict__ dirPtr, int32_t* __restrict__ dirSlot, int16_t* __restrict__ sdfMirror,
+                                   const float* __restrict__ depth, int lazy, const AllocParams& p) {
+
   const int chunk = blockIdx.x;
   const int tid = threadIdx.x;
   if (tid == 0) chunkReqNext[chunk] = make_int2(0, 0);
@@ -230,7 +235,8 @@ __global__ void __launch_bounds__(256) allocate_sweep_kernel(uint32_t* __restric
         ((uint32_t*)&hash[slot])[2] = (uint32_t)(off + 1);                 // connect the chain tail to the child
         const int ptr = allocList[vbaIdx];
         hash[p.bucketNum + off] = pack_entry(bx, by, bz, 0, ptr);
-        visT[p.bucketNum + off] = lazy ? 0x81 : 1;
+        if (ACROSS) __hip_atomic_store(&visT[p.bucketNum + off], (uint8_t)(lazy ? 0x81 : 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else visT[p.bucketNum + off] = lazy ? 0x81 : 1;
         directory_insert(dirPtr, dirSlot, bx, by, bz, ptr, p.bucketNum + off);
         mirror_init_block(sdfMirror, bx, by, bz);
       }
@@ -245,6 +251,16 @@ __global__ void __launch_bounds__(256) allocate_sweep_kernel(uint32_t* __restric
     }
     allocKey[slot] = 0u;
   }
+}
+
+__global__ void __launch_bounds__(256) allocate_sweep_kernel(uint32_t* __restrict__ allocKey, const int2* __restrict__ chunkReq,
+                                                             int2* __restrict__ chunkReqNext, int numChunks, uint4* __restrict__ hash,
+                                                             const int32_t* __restrict__ excessList, const int32_t* __restrict__ allocList,
+                                                             uint8_t* __restrict__ visT, const SceneCounters* __restrict__ counters,
+                                                             uint32_t* __restrict__ headBits, int32_t* __restrict__ dirPtr, int32_t* __restrict__ dirSlot, int16_t* __restrict__ sdfMirror,
+                                                             const float* __restrict__ depth, int lazy, AllocParams p) {
+  __shared__ int lds[8];
+  sweep_chunk<false>(lds, allocKey, chunkReq, chunkReqNext, numChunks, hash, excessList, allocList, visT, counters, headBits, dirPtr, dirSlot, sdfMirror, depth, lazy, p);
 }
 
 // checkBlockVisibility<false>: corners are reached by incremental +-f updates in a fixed order.
@@ -357,18 +373,73 @@ __global__ void __launch_bounds__(256) visible_compact_kernel(const uint8_t* __r
 // counts cross workgroups, the types and ids a workgroup writes are read by later launches.  All chunks' workgroups are
 // resident at once (numChunks * 4 waves << the chip's wave slots), and a workgroup only waits for lower-numbered ones; the poll
 // is bounded all the same and raises statusFlags bit 1 instead of hanging.
-template <bool COMMIT_ALLOC, bool LAZY>
-__global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__ visT, const uint4* __restrict__ hash,
+//
+// SWEEP: the allocation sweep of the chunk runs first, in the same workgroup (one launch less per frame).  Ordered allocations only
+// touch the chunk's own slots.  An EXCESS allocation writes the visible type of an entry in the excess region, i.e. in another
+// chunk: a chunk with excess requests stamps sweepDone[chunk] with the launch's epoch once its stores have completed, and the
+// workgroup of an excess-region chunk waits for the stamps of all such chunks before it counts, then reads its types with a
+// device-scope load (the sweep wrote them with one).  No sweep waits for anything, so the waiting cannot cycle; in a frame without
+// excess requests -- almost all of them -- nobody waits.  The pool counters, which every sweep reads, are committed by the LAST
+// chunk after its look-back (all granules in = all sweeps done) instead of by chunk 0.
+struct SweepArgs {
+  uint32_t* allocKey; int2* chunkReqNext; const int32_t* excessList; const int32_t* allocList; uint32_t* headBits;
+  int32_t* dirPtr; int32_t* dirSlot; int16_t* sdfMirror; const float* depth; int lazy;
+  uint32_t* sweepDone;     // per chunk: the epoch of the launch whose sweep has placed the chunk's excess allocations
+};
+
+template <bool COMMIT_ALLOC, bool LAZY, bool SWEEP>
+__global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__ visT, uint4* __restrict__ hash,
                                                            unsigned long long* __restrict__ chunkGran, uint32_t epoch,
                                                            const int2* __restrict__ chunkReq, int numChunks, SceneCounters* __restrict__ counters,
-                                                           int32_t* __restrict__ ids, int capIds, RenderCounters* __restrict__ rc, AllocParams p) {
+                                                           int32_t* __restrict__ ids, int capIds, RenderCounters* __restrict__ rc, AllocParams p, SweepArgs sw) {
   __shared__ int lds[12];
+  __shared__ int sweepLds[8];
   const int chunk = blockIdx.x, tid = threadIdx.x;
   const int slot0 = chunk * kSweepChunk + tid * kSlotsPerThread;
+  const bool excessRegion = SWEEP && slot0 - tid * kSlotsPerThread >= p.bucketNum;      // uniform: bucketNum is a multiple of the chunk size (host)
+  int before = 0;
+  bool stuck = false;
+  // sums the granules of the chunks before this one, waiting for each to carry this launch's epoch
+  auto look_back = [&]() {
+    for (int j = tid; j < chunk; j += 256) {
+      unsigned long long g = __hip_atomic_load(&chunkGran[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int spin = 0; (uint32_t)(g >> 32) != epoch; ++spin) {
+        if (spin > (1 << 22)) { stuck = true; break; }
+        __builtin_amdgcn_s_sleep(1);
+        g = __hip_atomic_load(&chunkGran[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      before += (int)(uint32_t)g;
+    }
+  };
+  if constexpr (SWEEP) {
+    sweep_chunk<true>(sweepLds, sw.allocKey, chunkReq, sw.chunkReqNext, numChunks, hash, sw.excessList, sw.allocList, visT, counters, sw.headBits,
+                      sw.dirPtr, sw.dirSlot, sw.sdfMirror, sw.depth, sw.lazy, p);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // this thread's stores have completed ...
+    __syncthreads();
+    const bool wroteAcross = chunkReq[chunk].y > 0;            // ... before the chunk says that its excess allocations are in place
+    if (wroteAcross && tid == 0) __hip_atomic_store(&sw.sweepDone[chunk], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (excessRegion) {
+      // every chunk that had excess requests (any index: no sweep waits for anything, so this cannot cycle) must be through
+      for (int j = tid; j < numChunks; j += 256) {
+        if (chunkReq[j].y <= 0 || j == chunk) continue;
+        for (int spin = 0; __hip_atomic_load(&sw.sweepDone[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch; ++spin) {
+          if (spin > (1 << 22)) { stuck = true; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      __syncthreads();
+    }
+  }
   int n = 0;
   uint32_t w[2] = {0u, 0u};
   if (slot0 < p.noTotalEntries) {  // noTotalEntries is a multiple of 8 (checked on the host)
-    const uint2 raw = *(const uint2*)(visT + slot0);
+    uint2 raw;
+    if (excessRegion) {
+      const unsigned long long q = __hip_atomic_load((const unsigned long long*)(visT + slot0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      raw = make_uint2((uint32_t)q, (uint32_t)(q >> 32));
+    } else {
+      raw = *(const uint2*)(visT + slot0);
+    }
     w[0] = raw.x; w[1] = raw.y;
     if (raw.x | raw.y) {
       bool changed = false;
@@ -393,9 +464,15 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
   const int pos0 = block_exclusive_scan<4>(n, lds, &mine);
   if (tid == 0)
     __hip_atomic_store(&chunkGran[chunk], ((unsigned long long)epoch << 32) | (unsigned long long)(uint32_t)mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (COMMIT_ALLOC && chunk == 0) {
+  // base = visible slots in all earlier chunks
+  look_back();
+  if (stuck) atomicOr(&counters->statusFlags, 2);
+  const int base = block_reduce_sum<4>(before, lds + 4);
+  if (COMMIT_ALLOC && chunk == (SWEEP ? numChunks - 1 : 0)) {
+    // (with SWEEP every sweep has read the pool counters by now: all granules are in)
     int a = 0, b = 0;
     for (int j = tid; j < numChunks; j += 256) { int2 c = chunkReq[j]; a += c.x; b += c.y; }
+    __syncthreads();
     a = block_reduce_sum<4>(a, lds + 4);
     b = block_reduce_sum<4>(b, lds + 8);
     if (tid == 0) {
@@ -404,20 +481,6 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
       counters->noAllocRequests = a;
     }
   }
-  // base = visible slots in all earlier chunks
-  int before = 0;
-  bool stuck = false;
-  for (int j = tid; j < chunk; j += 256) {
-    unsigned long long g = __hip_atomic_load(&chunkGran[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int spin = 0; (uint32_t)(g >> 32) != epoch; ++spin) {
-      if (spin > (1 << 22)) { stuck = true; break; }
-      __builtin_amdgcn_s_sleep(1);
-      g = __hip_atomic_load(&chunkGran[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    before += (int)(uint32_t)g;
-  }
-  if (stuck) atomicOr(&counters->statusFlags, 2);
-  const int base = block_reduce_sum<4>(before, lds + 4);
   if (chunk == numChunks - 1 && tid == 0) {
     const int total = base + mine;
     rc->rawVisibleCount = total;
@@ -516,18 +579,25 @@ int launch_sweep_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, bo
   int2* reqCur = (int2*)s->chunkReq + (size_t)(s->frameParity & 1u) * nChunks;
   int2* reqNext = (int2*)s->chunkReq + (size_t)((s->frameParity + 1u) & 1u) * nChunks;
   const bool lazy = rs->lazyThisFrame;
+  // the sweep rides in the visible-list launch unless a test hook asks for separate launches (or the ordered part of the table
+  // does not end on a chunk boundary, which no configuration of the reference produces)
+  const bool fusedSweep = !onlyVisible && !g_debug_two_pass_visible_list && !g_debug_separate_sweep && (s->cfg.bucketNum % kSweepChunk) == 0;
   if (!onlyVisible) {
-    KernelTimer ts(s, ITM_TK_ALLOC_SWEEP, st);
-    allocate_sweep_kernel<<<nChunks, 256, 0, st>>>(s->allocKey, reqCur, reqNext, nChunks, s->hash, s->excessList, s->allocList,
-                                                   rs->visibleType, s->counters, s->headBits, s->dirPtr, s->dirSlot, s->sdfMirror, v->depth, lazy ? 1 : 0, p);
+    if (!fusedSweep) {
+      KernelTimer ts(s, ITM_TK_ALLOC_SWEEP, st);
+      allocate_sweep_kernel<<<nChunks, 256, 0, st>>>(s->allocKey, reqCur, reqNext, nChunks, s->hash, s->excessList, s->allocList,
+                                                     rs->visibleType, s->counters, s->headBits, s->dirPtr, s->dirSlot, s->sdfMirror, v->depth, lazy ? 1 : 0, p);
+    }
     s->frameParity++;
   }
   KernelTimer tv(s, ITM_TK_VISIBLE_LIST, st);
   if (!g_debug_two_pass_visible_list) {
     const uint32_t epoch = ++s->listEpoch;
-#define ITM_VL(CM, LZ) visible_list_kernel<CM, LZ><<<nChunks, 256, 0, st>>>(rs->visibleType, s->hash, s->chunkGran, epoch, reqCur, nChunks, s->counters, rs->visibleIds, rs->capIds, rs->counters, p)
-    if (onlyVisible) { if (lazy) ITM_VL(false, true); else ITM_VL(false, false); }
-    else { if (lazy) ITM_VL(true, true); else ITM_VL(true, false); }
+    const SweepArgs sw{s->allocKey, reqNext, s->excessList, s->allocList, s->headBits, s->dirPtr, s->dirSlot, s->sdfMirror, v->depth, lazy ? 1 : 0, s->chunkSweepDone};
+#define ITM_VL(CM, LZ, SW) visible_list_kernel<CM, LZ, SW><<<nChunks, 256, 0, st>>>(rs->visibleType, s->hash, s->chunkGran, epoch, reqCur, nChunks, s->counters, rs->visibleIds, rs->capIds, rs->counters, p, sw)
+    if (onlyVisible) { if (lazy) ITM_VL(false, true, false); else ITM_VL(false, false, false); }
+    else if (fusedSweep) { if (lazy) ITM_VL(true, true, true); else ITM_VL(true, false, true); }
+    else { if (lazy) ITM_VL(true, true, false); else ITM_VL(true, false, false); }
 #undef ITM_VL
   } else {
 #define ITM_CNT(CM, LZ) visible_count_kernel<CM, LZ><<<nChunks, 256, 0, st>>>(rs->visibleType, s->hash, s->chunkVis, reqCur, nChunks, s->counters, p)

@@ -68,6 +68,7 @@ struct itm_scene {
   int32_t* chunkReq = nullptr;    // int2[2][numChunks]: (requests, excess requests) per sweep chunk, double-buffered
   int32_t* chunkVis = nullptr;    // int[numChunks]: visible slots per sweep chunk (two-pass path, FindVisibleBlocks)
   unsigned long long* chunkGran = nullptr;  // u64[numChunks]: {epoch, visible count} granules of the one-pass visible list
+  uint32_t* chunkSweepDone = nullptr;        // u32[numChunks]: epoch stamps of chunks whose excess allocations are in place (fused sweep)
   uint32_t listEpoch = 0;
   // occupancy bitmap of the ordered part of the table: bit b set <=> hash[b].ptr >= 0.  A clear bit
   // proves that no block hashing to bucket b is allocated (excess entries hang off occupied heads),
@@ -162,6 +163,7 @@ extern int g_debug_dense_group_cull;
 extern int g_debug_tracker_launch_per_evaluation;
 extern int g_debug_tracker_host_command;
 extern int g_debug_no_sdf_mirror;
+extern int g_debug_separate_sweep;
 int rebuild_sdf_mirror(itm_scene* s, hipStream_t st);
 extern int g_debug_no_fused_projection;
 int rebuild_head_bits(itm_scene* s, hipStream_t st);   // occupancy bitmap AND block directory, from the table

@@ -262,7 +262,7 @@ static void free_scene(itm_scene* s) {
   if (!s) return;
   if (s->prof) { s->prof->flush(); for (hipEvent_t e : s->prof->pool) (void)hipEventDestroy(e); delete s->prof; }
   (void)hipFree(s->hash); (void)hipFree(s->excessList); (void)hipFree(s->vba); (void)hipFree(s->allocList);
-  (void)hipFree(s->counters); (void)hipFree(s->headBits); (void)hipFree(s->allocKey); (void)hipFree(s->chunkReq); (void)hipFree(s->chunkVis); (void)hipFree(s->chunkGran);
+  (void)hipFree(s->counters); (void)hipFree(s->headBits); (void)hipFree(s->allocKey); (void)hipFree(s->chunkReq); (void)hipFree(s->chunkVis); (void)hipFree(s->chunkGran); (void)hipFree(s->chunkSweepDone);
   (void)hipFree(s->dirPtr); (void)hipFree(s->dirSlot); (void)hipFree(s->sdfMirror);
   delete s;
 }
@@ -353,6 +353,7 @@ int itm_scene_create(const itm_scene_config* cfg_in, const itm_scene_params* prm
     alloc((void**)&s->chunkReq, (size_t)s->numChunks * 2 * 2 * 4);
     alloc((void**)&s->chunkVis, (size_t)s->numChunks * 4);
     alloc((void**)&s->chunkGran, (size_t)s->numChunks * 8);
+    alloc((void**)&s->chunkSweepDone, (size_t)s->numChunks * 4);
     alloc((void**)&s->dirPtr, kDirCells * 4);
     alloc((void**)&s->dirSlot, kDirCells * 4);
   } else {
@@ -377,6 +378,7 @@ int itm_scene_create(const itm_scene_config* cfg_in, const itm_scene_params* prm
   if (e == hipSuccess && s->hash) e = hipMemset(s->hash, 0, (size_t)s->noTotalEntries * 16);
   if (e == hipSuccess && s->chunkReq) e = hipMemset(s->chunkReq, 0, (size_t)s->numChunks * 16);
   if (e == hipSuccess && s->chunkGran) e = hipMemset(s->chunkGran, 0, (size_t)s->numChunks * 8);
+  if (e == hipSuccess && s->chunkSweepDone) e = hipMemset(s->chunkSweepDone, 0, (size_t)s->numChunks * 4);
   if (e == hipSuccess && s->dirPtr) e = hipMemset(s->dirPtr, 0xff, kDirCells * 4);
   if (e == hipSuccess && s->dirSlot) e = hipMemset(s->dirSlot, 0xff, kDirCells * 4);
   if (e != hipSuccess) { free_scene(s); return hip_fail(e, "hipMemset(scene)", __FILE__, __LINE__); }

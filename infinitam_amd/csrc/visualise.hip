@@ -492,6 +492,7 @@ int itm_debug_set(int key, int value) {
   if (key == ITM_DEBUG_TRACKER_LAUNCH_PER_EVALUATION) { g_debug_tracker_launch_per_evaluation = value; return ITM_OK; }
   if (key == ITM_DEBUG_TRACKER_HOST_COMMAND) { g_debug_tracker_host_command = value; return ITM_OK; }
   if (key == ITM_DEBUG_NO_SDF_MIRROR) { g_debug_no_sdf_mirror = value; return ITM_OK; }
+  if (key == ITM_DEBUG_SEPARATE_SWEEP) { g_debug_separate_sweep = value; return ITM_OK; }
   return set_error(ITM_ERR_INVALID, "unknown debug key");
 }
 

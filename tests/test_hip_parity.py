@@ -137,6 +137,26 @@ def test_two_pass_visible_list_path(hip, oracle, sc):
     assert a.counters[-1]["statusFlags"] == 0
 
 
+EXCESS_HEAVY = Scenario(name="hash_tiny_table_moving", frames=5, bucketNum=0x1000, excessNum=0x1000, w=320, h=240, voxelSize=0.01, trajectory="yaw")
+
+
+@pytest.mark.parametrize("sc", [SCENARIOS[3], SCENARIOS[10], EXCESS_HEAVY], ids=lambda s: s.name)
+def test_sweep_inside_the_visible_list_launch_and_as_its_own_launch(hip, oracle, sc):
+    """The allocation sweep normally rides in the visible-list launch (excess allocations are handed to the workgroups of the
+    excess region through per-chunk stamps); ITM_DEBUG_SEPARATE_SWEEP (13) runs it as its own launch.  Tables with 4 096
+    buckets make most allocations excess allocations, over several frames of a turning camera."""
+    b = T.run_scenario(oracle, sc)
+    a = T.run_scenario(hip, sc, fused=True)
+    T.compare_results(a, b, sc, what=sc.name + "/fused sweep")
+    assert a.counters[-1]["statusFlags"] & 2 == 0
+    hip.check(hip.fn["debug_set"](13, 1), "debug_set")
+    try:
+        a = T.run_scenario(hip, sc, fused=True)
+    finally:
+        hip.check(hip.fn["debug_set"](13, 0), "debug_set")
+    T.compare_results(a, b, sc, what=sc.name + "/separate sweep")
+
+
 def test_explicit_mark_previous_path(hip, oracle):
     """The allocation normally folds "mark last frame's list as type 3" into the type encoding; the explicit
     launch (used after FindVisibleBlocks / uploads on the same render state) must give the same scene."""
