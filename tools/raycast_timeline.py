@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 from infinitam_amd import capi, synth
 be = capi.Backend(sys.argv[1], "itm_")
 W, H = 640, 480
-scene = be.create_scene(capi.VOXEL_S, capi.INDEX_HASH, capi.default_params(voxelSize=0.004), localBlockNum=0x40000)
+scene = be.create_scene(capi.VOXEL_S, capi.INDEX_DENSE, capi.default_params(voxelSize=0.004, stopIntegratingAtMaxW=True)) if len(sys.argv) > 2 and sys.argv[2] == "dense" else be.create_scene(capi.VOXEL_S, capi.INDEX_HASH, capi.default_params(voxelSize=0.004), localBlockNum=0x40000)
 scene.reco.ResetScene()
 rs = scene.vis.CreateRenderState((W, H))
 intr = synth.intrinsics_for(W, H)
