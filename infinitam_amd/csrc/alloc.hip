@@ -8,19 +8,25 @@
 //
 // MI355X design (not the reference's, whose CUDA twin hands out blocks through atomicSub and is
 // therefore non-deterministic):
-//   1. mark_previous_kernel  : last frame's visible list -> type 3.
-//   2. request_kernel        : one lane per depth pixel (16x4 pixels per wave, coalesced depth
-//                              reads) walks its ray segment and probes the table.  A missing
-//                              block is requested by atomicMax of the key (pixel, step)+1 on the
-//                              target slot; the largest key is exactly the "last writer in raster
-//                              order, then step order" of the sequential loop.  The first
-//                              requester of a slot also bumps the per-chunk request counters.
-//   3. allocate_sweep_kernel : chunks of 2048 slots; ranks in ascending slot order come from the
-//                              per-chunk counters + a workgroup scan, so pointers are handed out
-//                              exactly as the sequential sweep does (vbaIdx = lastFree - rank).
-//                              Only the winning key's ray is recomputed to get the block coords.
-//   4. visible_count_kernel / visible_compact_kernel : frustum re-test of type-3 slots and an
-//                              ORDERED compaction (ascending slot ids) of the visible list.
+//   1. request_kernel        : one lane per depth pixel (16x4 pixels per wave, coalesced depth
+//                              reads) walks its ray segment.  A block that exists is found through
+//                              the slot directory (one coherent load) or by probing the table; a
+//                              missing block is requested by atomicMax of the key (pixel, step)+1 on
+//                              the target slot; the largest key is exactly the "last writer in raster
+//                              order, then step order" of the sequential loop.  The first requester
+//                              of a slot also bumps the per-chunk request counters.  "Last frame's
+//                              visible list -> type 3" is folded into the type encoding (a touched
+//                              bit); mark_previous_kernel remains for callers that rewrote the list.
+//   2. visible_list_kernel   : ONE launch per 2048-slot chunk and workgroup:
+//      a. sweep_chunk        : ranks in ascending slot order come from the per-chunk counters + a
+//                              workgroup scan, so pointers are handed out exactly as the sequential
+//                              sweep does (vbaIdx = lastFree - rank).  Only the winning key's ray is
+//                              recomputed to get the block coords.  Also fills the block directory,
+//                              the slot directory and the sdf mirror for the new block.
+//      b. visible list       : frustum re-test of type-3 slots and an ORDERED compaction (ascending
+//                              slot ids); counts travel between workgroups as 8-byte granules.
+//      (allocate_sweep_kernel / visible_count_kernel / visible_compact_kernel: the same steps as
+//      separate launches, kept for FindVisibleBlocks and behind test hooks.)
 // No host synchronisation: all counts stay in HBM.
 #include <cstring>
 
@@ -95,7 +101,6 @@ __global__ void __launch_bounds__(256) request_kernel(const float* __restrict__ 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (FUSE_RANGE_INIT && blockIdx.x == 0 && blockIdx.y == 0) {
     if (threadIdx.x == 0) { rcnt->noRenderingBlocks = 0; rcnt->renderingBlocksAccepted = -1; }
-    if (threadIdx.x < 64) rcnt->integrateHeads[16 * threadIdx.x] = 0;     // work queues of this frame's integration launch
   }
   const int x = blockIdx.x * 16 + (lane & 15);
   const int y = blockIdx.y * 16 + wave * 4 + (lane >> 4);

@@ -7,11 +7,11 @@
 //                               DeviceAgnostic/ITMSceneReconstructionEngine.h:9-139
 //   interpolateBilinear         DeviceAgnostic/ITMPixelUtils.h:11-39
 //
-// MI355X design: the hash kernel gives one 8x8x8 block to a 512-lane workgroup (8 waves, one z-slice
-// per wave, each wave reading/writing one contiguous 64-voxel run); the grid is a fixed number of
-// persistent workgroups striding over the device-resident visible list, so no count is read back.
-// The dense kernel streams the volume with 16-byte accesses (4 ITMVoxel_s per lane) and writes
-// only 128-bit groups that changed.  The depth map is small (1.2 MB) and stays in L2.
+// MI355X design: the hash kernel gives (block, 4 z-slices) to ONE WAVE -- four contiguous 64-voxel runs in flight together, then
+// four depth gathers together -- with 2 048 workgroups of 8 waves striding over the device-resident visible list, so no count is
+// read back; voxels of the short types are mirrored into the position-addressed sdf copy the ray caster reads (itm_types.h).
+// The dense kernel streams the volume with 16-byte accesses (4 ITMVoxel_s per lane), culls whole columns of groups against the
+// frustum with two integer comparisons and writes only 128-bit groups that changed.  The depth map is small (1.2 MB) and stays in L2.
 #include <cmath>
 #include <cstring>
 
@@ -512,7 +512,7 @@ static bool make_column_cull(const FuseParams& p, const int* size, const int* of
 
 // `fuseProjection`: also run the projection half of CreateExpectedDepths (hash scenes whose sub-sampled range image
 // fits four times in LDS; the caller checked can_fuse_projection and launches range_reduce afterwards).
-int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipStream_t st, bool fuseProjection, bool queuesZeroed) {
+int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipStream_t st, bool fuseProjection) {
   FuseParams p;
   memcpy(p.M_d.m, v->M_d, 64);
   matmul4(v->rgb_to_depth_inv, v->M_d, p.M_rgb.m);  // calib_inv * M_d (_CPU.cpp:61)
@@ -546,7 +546,6 @@ int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipS
       pp.fx = v->intr_d[0]; pp.fy = v->intr_d[1]; pp.cx = v->intr_d[2]; pp.cy = v->intr_d[3];
       pp.voxelSize = s->prm.voxelSize; pp.W = rs->w; pp.H = rs->h; pp.maxBlocks = s->cfg.maxRenderingBlocks;
     }
-    (void)queuesZeroed;   // (the work queues of the workgroup-per-block kernel are gone)
     int rc = dispatch_voxel(s->cfg.voxelType, [&](auto vx) {
       using VX = decltype(vx);
       if (fuseProjection)

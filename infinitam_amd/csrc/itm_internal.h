@@ -27,9 +27,6 @@ struct RenderCounters {
   int32_t rawVisibleCount;         // visible slots before clamping to the list capacity
   int32_t renderingBlocksAccepted; // -1, or the count after the cap replay when noRenderingBlocks reached MAX_RENDERING_BLOCKS
   int32_t pad[2];
-  // (unused since the hash integration deals its work statically, one wave per slice group; kept so that the layout of the counters stays put)
-  // (one head per 64-byte line); zeroed before every integration launch
-  int32_t integrateHeads[64 * 16];
 };
 
 // hipEvent pairs around selected kernels (itm_profile_enable / itm_profile_read)
@@ -171,7 +168,7 @@ extern int g_debug_no_directory;
 int launch_request_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, bool onlyVisible, bool fuseRangeInit, hipStream_t st);
 int launch_sweep_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, bool onlyVisible, hipStream_t st);
 int launch_allocate(itm_scene* s, const itm_view* v, itm_render_state* rs, bool onlyVisible, bool fuseRangeInit, hipStream_t st);
-int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipStream_t st, bool fuseProjection = false, bool queuesZeroed = false);
+int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipStream_t st, bool fuseProjection = false);
 bool can_fuse_projection(const itm_scene* s, const itm_render_state* rs);
 int launch_find_visible(const itm_scene* s, const float* M, const float* intr, itm_render_state* rs, hipStream_t st);
 int launch_expected_depths(const itm_scene* s, const float* M, const float* intr, itm_render_state* rs, bool rangeAlreadyInit, hipStream_t st, bool projected = false);

@@ -536,7 +536,7 @@ int itm_process_frame(itm_scene* s, const itm_view* v, itm_render_state* rs, flo
   const bool hashScene = s->cfg.indexType == ITM_INDEX_HASH;
   if (hashScene && (rc = launch_allocate(s, v, rs, false, true, st))) return rc;
   const bool fuse = hashScene && can_fuse_projection(s, rs);
-  if ((rc = launch_integrate(s, v, rs, st, fuse, hashScene))) return rc;      // the request kernel of this frame zeroed the work queues
+  if ((rc = launch_integrate(s, v, rs, st, fuse))) return rc;
   // with the projection done inside the integration launch, the ray-cast workgroups reduce the partial range images of their
   // own cells (raycast_kernel<.., REDUCE>); otherwise CreateExpectedDepths runs as its own launches
   const bool reduceInRaycast = fuse && !g_debug_no_fused_range_reduce;
