@@ -15,6 +15,7 @@
 #include <dlfcn.h>
 
 #include <cstring>
+#include <mutex>
 #include <new>
 
 #include "itm_internal.h"
@@ -36,21 +37,23 @@ struct Rccl {
 };
 constexpr int kNcclInt32 = 2;       // ncclInt32 / ncclInt (rccl.h ncclDataType_t)
 
+static void load_rccl(Rccl& r);
 static Rccl& rccl() {
   static Rccl r;
-  static bool tried = false;
-  if (tried) return r;
-  tried = true;
+  static std::once_flag once;
+  std::call_once(once, [] { load_rccl(r); });      // exchanges may be created from several host threads (one per stream)
+  return r;
+}
+static void load_rccl(Rccl& r) {
   const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
   for (const char* n : names) { r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (r.lib) break; }
-  if (!r.lib) return r;
+  if (!r.lib) return;
   r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
   r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
   r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
   r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
   r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
   r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.GetErrorString;
-  return r;
 }
 
 static int rccl_fail(int code, const char* what) {

@@ -407,6 +407,11 @@ struct itm_tracker {
 namespace itm {
 
 static void tracker_release(itm_tracker* t) {
+  if (t->cmd && t->sessionOpen) {                 // a call that failed half way: tell its resident kernel to leave before the buffers go
+    *(volatile unsigned int*)&t->cmd->seq = 0xffffffffu;
+    __builtin_ia32_sfence();
+    t->sessionOpen = false;
+  }
   (void)hipFree(t->partial); (void)hipFree(t->partialCount);
   if (t->rec) (void)hipHostFree(t->rec);
   if (t->cmd) { if (t->cmdDirect) (void)hipFree(t->cmd); else (void)hipHostFree(t->cmd); }
