@@ -521,7 +521,15 @@ __device__ inline float4 march_ray(int x, int y, const VolumeView& vol, const Ra
     }
     ITM_WT({ const float keep2 = total + px; asm volatile("" :: "v"(keep2)); const unsigned long long tB = wt_clock();
       const unsigned wv = blockIdx.x * 4 + (threadIdx.x >> 6);
-      if ((wv & 31) == 1 && (wv >> 5) < 160 && wtOuter < 64) { unsigned long long* tr = g_waveTrace + ((size_t)(wv >> 5) * 64 + wtOuter) * 4; tr[0] = wt0 - wtStart; tr[1] = wtA - wtStart; tr[2] = tB - wtStart; tr[3] = wtLanes0 | (wtMarch0 << 8) | (wtTriLanes << 16) | (wtInner << 24); }
+#ifdef ITM_EXP_TRACE_TILE0
+      // trace the four waves of 40 consecutive tiles starting at ITM_EXP_TRACE_TILE0, first pass only
+      const bool wtPick = !resume && wv >= 4u * ITM_EXP_TRACE_TILE0 && wv < 4u * ITM_EXP_TRACE_TILE0 + 160u;
+      const unsigned wtSlot = wv - 4u * ITM_EXP_TRACE_TILE0;
+#else
+      const bool wtPick = (wv & 31) == 1 && (wv >> 5) < 160;
+      const unsigned wtSlot = wv >> 5;
+#endif
+      if (wtPick && wtOuter < 64) { unsigned long long* tr = g_waveTrace + ((size_t)wtSlot * 64 + wtOuter) * 4; tr[0] = wt0 - wtStart; tr[1] = wtA - wtStart; tr[2] = tB - wtStart; tr[3] = wtLanes0 | (wtMarch0 << 8) | (wtTriLanes << 16) | (wtInner << 24); }
       ++wtOuter; })
   }
 #if ITM_EXP_WAVE_TIMING
