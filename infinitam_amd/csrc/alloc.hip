@@ -51,6 +51,7 @@ struct AllocParams {
   int noTotalEntries;
   int stepBits;
   int capIds;
+  int mirrorFloat;   // the sdf mirror holds floats (ITMVoxel_f / _f_rgb) rather than shorts
 };
 
 struct BlockRay {
@@ -189,7 +190,7 @@ __device__ inline void sweep_chunk(int* lds, uint32_t* __restrict__ allocKey, co
                                    int2* __restrict__ chunkReqNext, int numChunks, uint4* __restrict__ hash,
                                    const int32_t* __restrict__ excessList, const int32_t* __restrict__ allocList,
                                    uint8_t* __restrict__ visT, const SceneCounters* __restrict__ counters,
-                                   uint32_t* __restrict__ headBits, int32_t* __restrict__ dirPtr, int32_t* __restrict__ dirSlot, int16_t* __restrict__ sdfMirror,
+                                   uint32_t* __restrict__ headBits, int32_t* __restrict__ dirPtr, int32_t* __restrict__ dirSlot, void* __restrict__ sdfMirror,
                                    const float* __restrict__ depth, int lazy, const AllocParams& p) {
 
   const int chunk = blockIdx.x;
@@ -243,7 +244,7 @@ __device__ inline void sweep_chunk(int* lds, uint32_t* __restrict__ allocKey, co
         if (ACROSS) __hip_atomic_store(&visT[p.bucketNum + off], (uint8_t)(lazy ? 0x81 : 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else visT[p.bucketNum + off] = lazy ? 0x81 : 1;
         directory_insert(dirPtr, dirSlot, bx, by, bz, ptr, p.bucketNum + off);
-        mirror_init_block(sdfMirror, bx, by, bz);
+        mirror_init_block(sdfMirror, p.mirrorFloat != 0, bx, by, bz);
       }
     } else if (vbaIdx >= 0) {
       int bx, by, bz;
@@ -252,7 +253,7 @@ __device__ inline void sweep_chunk(int* lds, uint32_t* __restrict__ allocKey, co
       hash[slot] = pack_entry(bx, by, bz, 0, ptr);
       atomicOr(&headBits[slot >> 5], 1u << (slot & 31));
       directory_insert(dirPtr, dirSlot, bx, by, bz, ptr, slot);
-      mirror_init_block(sdfMirror, bx, by, bz);
+      mirror_init_block(sdfMirror, p.mirrorFloat != 0, bx, by, bz);
     }
     allocKey[slot] = 0u;
   }
@@ -262,7 +263,7 @@ __global__ void __launch_bounds__(256) allocate_sweep_kernel(uint32_t* __restric
                                                              int2* __restrict__ chunkReqNext, int numChunks, uint4* __restrict__ hash,
                                                              const int32_t* __restrict__ excessList, const int32_t* __restrict__ allocList,
                                                              uint8_t* __restrict__ visT, const SceneCounters* __restrict__ counters,
-                                                             uint32_t* __restrict__ headBits, int32_t* __restrict__ dirPtr, int32_t* __restrict__ dirSlot, int16_t* __restrict__ sdfMirror,
+                                                             uint32_t* __restrict__ headBits, int32_t* __restrict__ dirPtr, int32_t* __restrict__ dirSlot, void* __restrict__ sdfMirror,
                                                              const float* __restrict__ depth, int lazy, AllocParams p) {
   __shared__ int lds[8];
   sweep_chunk<false>(lds, allocKey, chunkReq, chunkReqNext, numChunks, hash, excessList, allocList, visT, counters, headBits, dirPtr, dirSlot, sdfMirror, depth, lazy, p);
@@ -388,7 +389,7 @@ __global__ void __launch_bounds__(256) visible_compact_kernel(const uint8_t* __r
 // chunk after its look-back (all granules in = all sweeps done) instead of by chunk 0.
 struct SweepArgs {
   uint32_t* allocKey; int2* chunkReqNext; const int32_t* excessList; const int32_t* allocList; uint32_t* headBits;
-  int32_t* dirPtr; int32_t* dirSlot; int16_t* sdfMirror; const float* depth; int lazy;
+  int32_t* dirPtr; int32_t* dirSlot; void* sdfMirror; const float* depth; int lazy;
   uint32_t* sweepDone;     // per chunk: the epoch of the launch whose sweep has placed the chunk's excess allocations
 };
 
@@ -538,6 +539,7 @@ static int fill_params(const itm_scene* s, const float* M, const float* intr, in
   p.bucketNum = s->cfg.bucketNum;
   p.noTotalEntries = s->noTotalEntries;
   p.capIds = capIds;
+  p.mirrorFloat = (s->cfg.voxelType == ITM_VOXEL_F || s->cfg.voxelType == ITM_VOXEL_F_RGB) ? 1 : 0;
   int pixBits = 1;
   while ((1ll << pixBits) < (long long)W * H) ++pixBits;
   p.stepBits = 31 - pixBits;

@@ -227,7 +227,7 @@ __device__ inline void load_item(const HashEntry& he, int z0, int lane, const vo
 // behind the depth gathers -- the wave then waits for those gathers only (the memory counter retires in issue order), and the new
 // runs travel while this item is updated and stored.
 template <class VX>
-__device__ inline void integrate_item(const HashEntry& he, int z0, int lane, typename VX::Reg r[kSlices], void* __restrict__ vba, int16_t* __restrict__ sdfMirror,
+__device__ inline void integrate_item(const HashEntry& he, int z0, int lane, typename VX::Reg r[kSlices], void* __restrict__ vba, void* __restrict__ sdfMirror,
                                       const float* __restrict__ depth, const uchar4* __restrict__ rgb, const FuseParams& p,
                                       bool hasNext, const HashEntry& next, int nextZ0, typename VX::Reg nextR[kSlices]) {
   const bool present = he.ptr >= 0;
@@ -235,9 +235,10 @@ __device__ inline void integrate_item(const HashEntry& he, int z0, int lane, typ
   const size_t vi = (size_t)(present ? he.ptr : 0) * kBlockVoxels + (size_t)z0 * 64 + lane;
   const float mx = (float)(he.px * kBlockSide + x) * p.voxelSize;
   const float my = (float)(he.py * kBlockSide + y) * p.voxelSize;
+  using MC = MirrorCodec<VX::kShort>;
   size_t mbase = 0;
-  int16_t* mirror = nullptr;
-  if constexpr (VX::kShort) { if (sdfMirror && mirror_index(he.px * kBlockSide, he.py * kBlockSide, he.pz * kBlockSide, mbase)) mirror = sdfMirror; }
+  typename MC::T* mirror = nullptr;
+  if (sdfMirror && mirror_index(he.px * kBlockSide, he.py * kBlockSide, he.pz * kBlockSide, mbase)) mirror = (typename MC::T*)sdfMirror;
   // stage 1: project every slice's voxel; stage 2: all depth pixels together; stage 3: update (+ colour), store what changed
   int pix[kSlices];
   float pcz[kSlices], mz[kSlices];
@@ -265,14 +266,14 @@ __device__ inline void integrate_item(const HashEntry& he, int z0, int lane, typ
     }
     if (touched) {
       VX::store(vba, vi + 64 * k, r[k]);
-      if constexpr (VX::kShort) { if (mirror) mirror[mbase + (size_t)(z0 + k) * 64 + lane] = (int16_t)VX::raw_sdf(r[k]); }   // sdf mirror (itm_types.h)
+      if (mirror) mirror[mbase + (size_t)(z0 + k) * 64 + lane] = MC::of(VX::raw_sdf(r[k]));   // sdf mirror (itm_types.h)
     }
   }
 }
 
 template <class VX>
 __device__ inline void integrate_hash_body(int wgIdx, int wgCount, const int32_t* __restrict__ visibleIds, RenderCounters* __restrict__ rc,
-                                           const uint4* __restrict__ hash, void* __restrict__ vba, int16_t* __restrict__ sdfMirror,
+                                           const uint4* __restrict__ hash, void* __restrict__ vba, void* __restrict__ sdfMirror,
                                            const float* __restrict__ depth, const uchar4* __restrict__ rgb, const FuseParams& p) {
   const int nItems = rc->noVisibleEntries * kItemsPerBlock;
   const int lane = threadIdx.x & 63;
@@ -304,7 +305,7 @@ __device__ inline void integrate_hash_body(int wgIdx, int wgCount, const int32_t
 
 template <class VX>
 __global__ void __launch_bounds__(512) integrate_hash_kernel(const int32_t* __restrict__ visibleIds, RenderCounters* __restrict__ rc,
-                                                             const uint4* __restrict__ hash, void* __restrict__ vba, int16_t* __restrict__ sdfMirror,
+                                                             const uint4* __restrict__ hash, void* __restrict__ vba, void* __restrict__ sdfMirror,
                                                              const float* __restrict__ depth, const uchar4* __restrict__ rgb, FuseParams p) {
   integrate_hash_body<VX>(blockIdx.x, gridDim.x, visibleIds, rc, hash, vba, sdfMirror, depth, rgb, p);
 }
@@ -322,7 +323,7 @@ __device__ unsigned long long g_fusedStamps[8192 * 2];
 #endif
 template <class VX>
 __global__ void __launch_bounds__(512) integrate_project_kernel(const int32_t* __restrict__ visibleIds, RenderCounters* __restrict__ rc,
-                                                                const uint4* __restrict__ hash, void* __restrict__ vba, int16_t* __restrict__ sdfMirror,
+                                                                const uint4* __restrict__ hash, void* __restrict__ vba, void* __restrict__ sdfMirror,
                                                                 const float* __restrict__ depth, const uchar4* __restrict__ rgb, FuseParams p,
                                                                 float2* __restrict__ range, uint4* __restrict__ projBuf, uint2* __restrict__ partials,
                                                                 ProjParams pp, int RW, int RH) {

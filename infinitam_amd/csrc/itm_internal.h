@@ -75,7 +75,7 @@ struct itm_scene {
   // order.  Maintained by the allocation sweep, rebuilt after uploads; an exact mirror of the table entries with ptr >= 0.
   int32_t* dirPtr = nullptr;      // int32[kDirCells]  (512 MB)
   int32_t* dirSlot = nullptr;     // int32[kDirCells]  (512 MB): table slot of the block at that position or -1 (request kernel)
-  int16_t* sdfMirror = nullptr;   // int16[kMirrorCells * 512]  (17 GB; short voxel types of hash scenes, itm_types.h) or nullptr
+  void* sdfMirror = nullptr;      // int16 / uint32 [kMirrorCells * 512]  (17 / 34 GB; hash scenes, itm_types.h) or nullptr
   uint32_t frameParity = 0;
   itm::Profiler* prof = nullptr;
 };

@@ -234,21 +234,36 @@ __device__ inline void directory_insert(int32_t* __restrict__ dirPtr, int32_t* _
 }
 
 // ---- sdf mirror -------------------------------------------------------------------------------
-// A second copy of the sdf of the short voxel types, addressed by POSITION instead of through the block pointer:
-//   sdfMirror[mirror_cell(block) * 512 + voxel-in-block]   int16: the voxel's sdf, or kMirrorAbsent where no block is allocated
-// over the block coordinates [-kMirrorHalf, kMirrorHalf)^3 (256^3 cells x 1 KB = 17 GB of the 288 GB).  The pointer chase of a
-// ray step -- directory cell, then voxel, two dependent round trips -- becomes one load whose address follows from the position
-// alone, and the eight reads of a trilinear sample are independent of any look-up.  -32768 cannot be a stored sdf
-// ((short)(f * 32767) with f in [-1, 1]), so it marks "no block here".  Written wherever voxels are written: at allocation (the
-// initial value), by the integration, and rebuilt from the table after an upload; blocks outside the cube use the directory.
+// A second copy of the sdf of every voxel, addressed by POSITION instead of through the block pointer:
+//   sdfMirror[mirror_cell(block) * 512 + voxel-in-block]   the voxel's raw sdf (int16 for the short voxel types, the float's bits
+//                                                          for the float types), or an "absent" pattern where no block is allocated
+// over the block coordinates [-128, 128) x [-128, 128) x [-64, 192) -- the world frame is the first camera's, scenes extend in +z --
+// i.e. 256^3 cells x 1 KB = 17 GB (short) / 2 KB = 34 GB (float) of the 288 GB.  The pointer chase of a ray step -- directory cell,
+// then voxel, two dependent round trips -- becomes one load whose address follows from the position alone, and the eight reads of a
+// trilinear sample are independent of any look-up.  "Absent": -32768 cannot be a stored short sdf ((short)(f * 32767) with f in
+// [-1, 1]); 0xFFFFFFFF is a NaN no arithmetic produces.  Written wherever voxels are written: at allocation (the initial value),
+// by the integration, and rebuilt from the table after an upload; blocks outside the cube use the directory.
 #ifndef ITM_MIRROR_BITS
 #define ITM_MIRROR_BITS 8
 #endif
 constexpr int kMirrorBits = ITM_MIRROR_BITS;
 constexpr int kMirrorSide = 1 << kMirrorBits;
 constexpr int kMirrorHalf = kMirrorSide / 2;
+constexpr int kMirrorShiftZ = kMirrorSide / 4;     // the cube is centred kMirrorShiftZ blocks in front of the origin
 constexpr size_t kMirrorCells = (size_t)kMirrorSide * kMirrorSide * kMirrorSide;
-constexpr int16_t kMirrorAbsent = (int16_t)-32768;
+template <bool SHORT> struct MirrorCodec;
+template <> struct MirrorCodec<true> {
+  using T = int16_t;
+  __host__ __device__ static bool absent(T v) { return v == (int16_t)-32768; }
+  __host__ __device__ static float raw(T v) { return (float)v; }
+  __host__ __device__ static T of(float rawSdf) { return (int16_t)rawSdf; }
+};
+template <> struct MirrorCodec<false> {
+  using T = uint32_t;
+  __host__ __device__ static bool absent(T v) { return v == 0xffffffffu; }
+  __device__ static float raw(T v) { return __uint_as_float(v); }
+  __device__ static T of(float rawSdf) { return __float_as_uint(rawSdf); }
+};
 __host__ __device__ inline bool mirror_covers(uint32_t ux, uint32_t uy, uint32_t uz) { return ((ux | uy | uz) >> kMirrorBits) == 0u; }
 __host__ __device__ inline uint32_t mirror_cell(uint32_t ux, uint32_t uy, uint32_t uz) {   // brick-major like the directory
   const uint32_t brick = ((uz >> 2) << (2 * (kMirrorBits - 2))) | ((uy >> 2) << (kMirrorBits - 2)) | (ux >> 2);
@@ -256,19 +271,25 @@ __host__ __device__ inline uint32_t mirror_cell(uint32_t ux, uint32_t uy, uint32
 }
 // mirror index of the voxel at integer point (px, py, pz); false when its block lies outside the mirrored cube
 __host__ __device__ inline bool mirror_index(int px, int py, int pz, size_t& idx) {
-  const uint32_t ux = (uint32_t)((px >> 3) + kMirrorHalf), uy = (uint32_t)((py >> 3) + kMirrorHalf), uz = (uint32_t)((pz >> 3) + kMirrorHalf);
+  const uint32_t ux = (uint32_t)((px >> 3) + kMirrorHalf), uy = (uint32_t)((py >> 3) + kMirrorHalf), uz = (uint32_t)((pz >> 3) + kMirrorHalf - kMirrorShiftZ);
   if (!mirror_covers(ux, uy, uz)) return false;
   idx = (size_t)mirror_cell(ux, uy, uz) * 512u + (size_t)((px & 7) + ((py & 7) << 3) + ((pz & 7) << 6));
   return true;
 }
 
-// a block has just been allocated: its voxels hold the initial value (sdf 32767); called by one thread (the allocation sweep)
-__device__ inline void mirror_init_block(int16_t* __restrict__ mirror, int bx, int by, int bz) {
+// a block has just been allocated: its voxels hold the initial value (sdf 32767 / 1.0f); called by one thread (the allocation sweep)
+__device__ inline void mirror_init_block(void* __restrict__ mirror, bool floatSdf, int bx, int by, int bz) {
   size_t base;
   if (!mirror || !mirror_index(bx * 8, by * 8, bz * 8, base)) return;
-  uint4* q = (uint4*)(mirror + base);                      // 1 KB, 16-byte aligned
-  const uint4 init = make_uint4(0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu);
-  for (int i = 0; i < 64; ++i) q[i] = init;
+  if (floatSdf) {
+    uint4* q = (uint4*)((uint32_t*)mirror + base);         // 2 KB, 16-byte aligned
+    const uint4 init = make_uint4(0x3f800000u, 0x3f800000u, 0x3f800000u, 0x3f800000u);
+    for (int i = 0; i < 128; ++i) q[i] = init;
+  } else {
+    uint4* q = (uint4*)((int16_t*)mirror + base);          // 1 KB
+    const uint4 init = make_uint4(0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu);
+    for (int i = 0; i < 64; ++i) q[i] = init;
+  }
 }
 
 // 4x4 column-major matrix passed to kernels by value

@@ -43,7 +43,7 @@ struct VolumeView {
   uint32_t mask;       // bucketNum - 1
   int bucketNum;
   const int32_t* dirPtr;    // block directory (itm_types.h); nullptr = walk the table (hash index only)
-  const int16_t* sdfMirror; // sdf by position (itm_types.h); nullptr = none (hash index, short voxel types only)
+  const void* sdfMirror;    // sdf by position (itm_types.h); nullptr = none (hash index only)
   int sx, sy, sz;      // dense size
   int ox, oy, oz;      // dense offset
 };
@@ -103,14 +103,15 @@ __device__ inline long long locate_voxel(const VolumeView& vol, int px, int py, 
 // raw (unconverted) sdf of the voxel at an integer point; the default voxel when absent
 template <class VX, bool DENSE>
 __device__ inline float read_raw_sdf(const VolumeView& vol, int px, int py, int pz, bool& found, BlockCache& cache) {
-  if constexpr (!DENSE && VX::kShort) {
+  if constexpr (!DENSE) {
     // sdf mirror: one load, address from the position alone (same value and same "found" as the walk below: the mirror holds
     // exactly the voxels of the allocated blocks inside its cube)
+    using MC = MirrorCodec<VX::kShort>;
     size_t mi;
     if (vol.sdfMirror && mirror_index(px, py, pz, mi)) {
-      const int16_t v = vol.sdfMirror[mi];
-      found = v != kMirrorAbsent;
-      return found ? (float)v : 32767.0f;
+      const typename MC::T v = ((const typename MC::T*)vol.sdfMirror)[mi];
+      found = !MC::absent(v);
+      return found ? MC::raw(v) : (VX::kShort ? 32767.0f : 1.0f);
     }
   }
   const long long a = locate_voxel<DENSE>(vol, px, py, pz, cache);
@@ -167,20 +168,21 @@ struct Corners {
         addr[c] = present[c] ? (size_t)a : (size_t)0;
       }
     } else {
-      if constexpr (VX::kShort) {
+      {
         // sdf mirror: eight independent loads.  Taken when every lane of the wave that is here can use it (a wave with a lane
         // outside the mirrored cube takes the general path as a whole: both give the same values)
+        using MC = MirrorCodec<VX::kShort>;
         if (vol.sdfMirror) {
           size_t mi[8];
           bool all = true;
 #pragma unroll
           for (int c = 0; c < 8; ++c) all &= mirror_index(ix + (c & 1), iy + ((c >> 1) & 1), iz + (c >> 2), mi[c]);
           if (__all(all)) {
-            int16_t m[8];
+            typename MC::T m[8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) m[c] = vol.sdfMirror[mi[c]];
+            for (int c = 0; c < 8; ++c) m[c] = ((const typename MC::T*)vol.sdfMirror)[mi[c]];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) { present[c] = m[c] != kMirrorAbsent; v[c] = present[c] ? (float)m[c] : dflt; }
+            for (int c = 0; c < 8; ++c) { present[c] = !MC::absent(m[c]); v[c] = present[c] ? MC::raw(m[c]) : dflt; }
             return;
           }
         }

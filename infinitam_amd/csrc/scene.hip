@@ -146,21 +146,36 @@ __global__ void __launch_bounds__(256) directory_fill_kernel(const uint4* __rest
 
 // rebuilds the sdf mirror from the table and the pool: one workgroup per entry, the 512 sdf values of every allocated block inside the cube
 template <class VX>
-__global__ void __launch_bounds__(256) mirror_fill_kernel(const uint4* __restrict__ hash, int nEntries, const void* __restrict__ vba, int16_t* __restrict__ mirror) {
+__global__ void __launch_bounds__(256) mirror_fill_kernel(const uint4* __restrict__ hash, int nEntries, const void* __restrict__ vba, void* __restrict__ mirror) {
+  using MC = MirrorCodec<VX::kShort>;
   for (int i = blockIdx.x; i < nEntries; i += gridDim.x) {
     const HashEntry e = unpack_entry(hash[i]);
     if (e.ptr < 0) continue;
     size_t base;
     if (!mirror_index(e.px * kBlockSide, e.py * kBlockSide, e.pz * kBlockSide, base)) continue;
-    for (int t = threadIdx.x; t < kBlockVoxels; t += 256) mirror[base + t] = (int16_t)VX::load_raw_sdf(vba, (size_t)e.ptr * kBlockVoxels + t);
+    for (int t = threadIdx.x; t < kBlockVoxels; t += 256) ((typename MC::T*)mirror)[base + t] = MC::of(VX::load_raw_sdf(vba, (size_t)e.ptr * kBlockVoxels + t));
   }
+}
+
+#ifndef ITM_MIRROR_FLOAT_TYPES
+#define ITM_MIRROR_FLOAT_TYPES 0
+#endif
+static bool mirror_is_float(const itm_scene* s) { return s->cfg.voxelType == ITM_VOXEL_F || s->cfg.voxelType == ITM_VOXEL_F_RGB; }
+// every cell "no block here": -32768 per short, all ones per float
+static hipError_t mirror_clear(itm_scene* s, hipStream_t st) {
+  if (mirror_is_float(s)) return hipMemsetAsync(s->sdfMirror, 0xff, kMirrorCells * 512 * 4, st);
+  return hipMemsetD16Async((unsigned short*)s->sdfMirror, (unsigned short)0x8000, kMirrorCells * 512, st);
 }
 
 int rebuild_sdf_mirror(itm_scene* s, hipStream_t st) {
   if (!s->sdfMirror) return ITM_OK;
-  ITM_HIP(hipMemsetD16Async(s->sdfMirror, (unsigned short)0x8000, kMirrorCells * 512, st));
-  if (s->cfg.voxelType == ITM_VOXEL_S) mirror_fill_kernel<VoxelS><<<4096, 256, 0, st>>>(s->hash, s->noTotalEntries, s->vba, s->sdfMirror);
-  else mirror_fill_kernel<VoxelSRgb><<<4096, 256, 0, st>>>(s->hash, s->noTotalEntries, s->vba, s->sdfMirror);
+  ITM_HIP(mirror_clear(s, st));
+  int rc = dispatch_voxel(s->cfg.voxelType, [&](auto vx) {
+    using VX = decltype(vx);
+    mirror_fill_kernel<VX><<<4096, 256, 0, st>>>(s->hash, s->noTotalEntries, s->vba, s->sdfMirror);
+    return ITM_OK;
+  });
+  if (rc) return rc;
   ITM_LAUNCH_CHECK();
   return ITM_OK;
 }
@@ -363,13 +378,15 @@ int itm_scene_create(const itm_scene_config* cfg_in, const itm_scene_params* prm
   alloc(&s->vba, s->numVoxels * vb + 16);
   alloc((void**)&s->counters, sizeof(SceneCounters));
   if (e != hipSuccess) { free_scene(s); return hip_fail(e, "hipMalloc(scene)", __FILE__, __LINE__); }
-  if (cfg.indexType == ITM_INDEX_HASH && (cfg.voxelType == ITM_VOXEL_S || cfg.voxelType == ITM_VOXEL_S_RGB) && !g_debug_no_sdf_mirror) {
-    // the sdf mirror is an accelerator: taken when the device has room to spare (it is 17 GB), silently left out otherwise
+  // The sdf mirror is an accelerator: taken when the device has room to spare, silently left out otherwise -- and only for the short
+  // voxel types.  For the float types (34 GB) it was measured on BASELINE configs[4]: ray cast 119 -> 106 us, but the integration pays
+  // 175 -> 189 us for the extra 4-byte stores: 2 609 -> 2 560 frames/s.  (ITM_MIRROR_FLOAT_TYPES=1 builds it in.)
+  if (cfg.indexType == ITM_INDEX_HASH && !g_debug_no_sdf_mirror && (ITM_MIRROR_FLOAT_TYPES || !mirror_is_float(s))) {
     size_t freeB = 0, totalB = 0;
-    const size_t bytes = kMirrorCells * 512 * sizeof(int16_t);
+    const size_t bytes = kMirrorCells * 512 * (mirror_is_float(s) ? 4 : 2);
     if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB > 3 * bytes) {
-      if (hipMalloc((void**)&s->sdfMirror, bytes) != hipSuccess) { s->sdfMirror = nullptr; (void)hipGetLastError(); }
-      else if (hipMemsetD16(s->sdfMirror, (unsigned short)0x8000, kMirrorCells * 512) != hipSuccess) { (void)hipFree(s->sdfMirror); s->sdfMirror = nullptr; (void)hipGetLastError(); }
+      if (hipMalloc(&s->sdfMirror, bytes) != hipSuccess) { s->sdfMirror = nullptr; (void)hipGetLastError(); }
+      else if (mirror_clear(s, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) { (void)hipFree(s->sdfMirror); s->sdfMirror = nullptr; (void)hipGetLastError(); }
     }
   }
   e = hipMemset(s->counters, 0, sizeof(SceneCounters));
@@ -413,7 +430,7 @@ int itm_reset_scene(itm_scene* s, itm_stream stream) {
   if (s->cfg.indexType == ITM_INDEX_HASH) {
     ITM_HIP(hipMemsetAsync(s->dirPtr, 0xff, kDirCells * 4, st));
     ITM_HIP(hipMemsetAsync(s->dirSlot, 0xff, kDirCells * 4, st));
-    if (s->sdfMirror) ITM_HIP(hipMemsetD16Async(s->sdfMirror, (unsigned short)0x8000, kMirrorCells * 512, st));
+    if (s->sdfMirror) ITM_HIP(mirror_clear(s, st));
     reset_hash_kernel<<<1024, 256, 0, st>>>(s->hash, s->noTotalEntries, s->excessList, s->cfg.excessNum, s->allocList,
                                             s->cfg.localBlockNum, s->allocKey, s->headBits, (s->cfg.bucketNum + 31) / 32, s->chunkReq, s->numChunks * 4, s->counters);
   } else {
