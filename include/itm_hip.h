@@ -176,6 +176,11 @@ int ITM_FN(set_device)(int device);
 #define ITM_DEBUG_SEPARATE_SWEEP 13           /* AllocateSceneFromDepth: allocation sweep as its own launch, not inside the visible-list launch */
 #define ITM_DEBUG_NO_SDF_MIRROR 12            /* ray casting: voxels through the directory / table although the scene has an sdf mirror; set before itm_scene_create: no mirror is allocated */
 int ITM_FN(debug_set)(int key, int value);
+/* Test hook (host only): rows [rlo, rhi] of the column of 4-voxel groups (x0 .. x0 + 3, slice z) that the dense integration visits for
+ * a volume of `size` voxels at `offset` seen from M_d; every voxel of the column outside that interval must fail the exact
+ * projection test of computeUpdatedVoxelDepthInfo.  Returns 1 when no cull planes can be formed (the kernel then tests per group). */
+int ITM_FN(debug_column_cull_rows)(const float M_d[16], const float intr[4], int w, int h, float voxelSize, const int size[3],
+                                   const int offset[3], int x0, int z, int* rlo, int* rhi);
 /* out[i] = SDF_valueToFloat(in[i]) of the short voxel types, i.e. in[i] / 32767.0f, through the same
  * device routine the kernels use (a 3-instruction correctly rounded division; test hook). */
 int ITM_FN(debug_div32767)(const float* in, float* out, int n, itm_stream stream);

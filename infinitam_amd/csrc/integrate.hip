@@ -379,6 +379,24 @@ struct ColumnCull {
   int kind[5];   // sign of b_k: +1 the plane bounds yi from below, -1 from above, 0 not at all (then g_k must be >= 0 as it is)
 };
 
+// Rows [rlo, rhi] of the column of groups (x0 .. x0 + 3, slice z) in which some voxel can pass the exact test (empty when rlo > rhi).
+// Host and device: the same double-precision operations (fma is exactly rounded on both), so the host-side property test
+// (tests/test_dense_cull.py, itm_debug_column_cull_rows) checks what the kernel computes.
+__host__ __device__ inline void column_rows(const ColumnCull& cc, int x0, int z, int& rlo, int& rhi) {
+  double ylo = -1e9, yhi = 1e9;
+  bool none = false;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    // the largest value g_k takes on the group: at x0 + 3 when a_k > 0, at x0 otherwise
+    const double t = __builtin_fma(cc.a[k], (double)(cc.a[k] > 0.0 ? x0 + 3 : x0), __builtin_fma(cc.cz[k], (double)z, cc.cm[k]));
+    if (cc.kind[k] > 0) ylo = fmax(ylo, t * cc.nb[k]);          // b_k yi + t >= 0  <=>  yi >= -t / b_k
+    else if (cc.kind[k] < 0) yhi = fmin(yhi, t * cc.nb[k]);     //                  <=>  yi <= -t / b_k   (b_k < 0)
+    else none |= t < 0.0;
+  }
+  rlo = none ? 0x7fffffff : (int)ceil(fmax(ylo, -1e9));
+  rhi = (int)floor(fmin(yhi, 1e9));
+}
+
 // CULL: 0 = per group with the exact arithmetic of two end voxels (any size); 1 = the rows [ylo, yhi] that can be inside the
 // frustum are computed ONCE per thread for its column of groups (every group a thread visits has the same x0 when the stride
 // is a multiple of the row length), the per-group test is then two integer comparisons.  Measured on BASELINE configs[2]
@@ -439,18 +457,8 @@ __global__ void __launch_bounds__(256) integrate_dense_s_x4_kernel(uint4* __rest
   int idx = blockIdx.x * 256 + threadIdx.x;
   if constexpr (CULL == 1) {
     // rows of this thread's column (x0 .. x0 + 3, slice z) that may be inside the frustum
-    const int x0 = (idx & (sx4 - 1)) * 4;
-    double ylo = -1e9, yhi = 1e9;
-    bool none = false;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      // the largest value g_k takes on the group: at x0 + 3 when a_k > 0, at x0 otherwise
-      const double t = __builtin_fma(cc.a[k], (double)(cc.a[k] > 0.0 ? x0 + 3 : x0), __builtin_fma(cc.cz[k], (double)z, cc.cm[k]));
-      if (cc.kind[k] > 0) ylo = fmax(ylo, t * cc.nb[k]);          // b_k yi + t >= 0  <=>  yi >= -t / b_k
-      else if (cc.kind[k] < 0) yhi = fmin(yhi, t * cc.nb[k]);     //                  <=>  yi <= -t / b_k   (b_k < 0)
-      else none |= t < 0.0;
-    }
-    const int rlo = none ? 0x7fffffff : (int)ceil(fmax(ylo, -1e9)), rhi = (int)floor(fmin(yhi, 1e9));
+    int rlo, rhi;
+    column_rows(cc, (idx & (sx4 - 1)) * 4, z, rlo, rhi);
     auto outside = [&](int i) { const int y = i >> log2sx4; return y < rlo || y > rhi; };
     for (; idx + stride < plane; idx += 2 * stride) {
       const bool c0 = outside(idx), c1 = outside(idx + stride);
@@ -589,6 +597,23 @@ int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipS
 }  // namespace itm
 
 using namespace itm;
+
+// Test hook (host only, no device work): the row interval the dense integration would use for the column of 4-voxel groups
+// (x0 .. x0 + 3, slice z) of a volume `size` / `offset` seen from pose M_d -- so that the conservativeness of the cull can be
+// checked against the exact per-voxel test for thousands of poses on a machine without a GPU.  Returns 1 when the planes could not be formed.
+extern "C" int itm_debug_column_cull_rows(const float M_d[16], const float intr[4], int w, int h, float voxelSize, const int size[3], const int offset[3],
+                                          int x0, int z, int* rlo, int* rhi) {
+  if (!M_d || !intr || !size || !offset || !rlo || !rhi) return set_error(ITM_ERR_INVALID, "null argument");
+  FuseParams p;
+  memset(&p, 0, sizeof p);
+  memcpy(p.M_d.m, M_d, 64);
+  p.fx = intr[0]; p.fy = intr[1]; p.cx = intr[2]; p.cy = intr[3];
+  p.W = w; p.H = h; p.voxelSize = voxelSize;
+  ColumnCull cc;
+  if (!make_column_cull(p, size, offset, cc)) return 1;
+  column_rows(cc, x0, z, *rlo, *rhi);
+  return ITM_OK;
+}
 
 extern "C" int itm_integrate_into_scene(itm_scene* s, const itm_view* v, itm_render_state* rs, itm_stream stream) {
   if (!s || !v || !rs) return set_error(ITM_ERR_INVALID, "null argument");

@@ -2,6 +2,8 @@
 computeUpdatedVoxelDepthInfo (DeviceAgnostic/ITMSceneReconstructionEngine.h:9-50) keeps.  The volume after integrating from cameras
 in general position -- rotated about all three axes, inside and outside the volume, looking along and across its faces -- must be
 bit-identical to the oracle's, and the per-group test (debug key 9) must give the same volume."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -75,3 +77,51 @@ def test_column_cull_equals_exact_test_for_cameras_in_general_position(hip, orac
         assert np.array_equal(a, c), "camera %d (per-group cull)" % i
         touched += int(np.count_nonzero(a.view(np.uint32) != want[i - 1].view(np.uint32))) if i else int(np.count_nonzero(a.view(np.uint32) != 32767))
     assert touched > 500000          # the cameras really see the volume
+
+
+# ---- the interval itself, on the host: thousands of poses against the exact float test ---------------------------------------------
+def exact_keep(M, intr, W, H, vs, off, xs, ys, z):
+    """computeUpdatedVoxelDepthInfo's projection test in float32, operation by operation (no FMA): True where the voxel is NOT rejected."""
+    f = np.float32
+    m = M.astype(f)
+    mx = (xs + off[0]).astype(f) * f(vs)
+    my = (ys + off[1]).astype(f) * f(vs)
+    mz = f(z + off[2]) * f(vs)
+    def row(j):
+        return ((m[j] * mx[None, :] + m[j + 4] * my[:, None]) + m[j + 8] * mz) + m[j + 12] * f(1.0)
+    pcx, pcy, pcz = row(0), row(1), row(2)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        u = f(intr[0]) * pcx / pcz + f(intr[2])
+        v = f(intr[1]) * pcy / pcz + f(intr[3])
+    return (~(pcz <= 0)) & ~((u < 1) | (u > f(W - 2)) | (v < 1) | (v > f(H - 2)))
+
+
+def test_column_interval_never_excludes_a_voxel_the_exact_test_keeps(hip_host):
+    rng = np.random.default_rng(11)
+    W, H = 160, 120
+    intr = np.array([145.0, 145.0, 80.0, 60.0], np.float32)
+    size = np.array([128, 128, 128], np.int32); off = np.array([-64, -64, 100], np.int32)
+    vs = 0.008
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    ys = np.arange(size[1])
+    kept_rows = needed_rows = checked = 0
+    poses = [pose(rotation(*ang), pos) for ang, pos in CAMERAS]
+    for _ in range(300):
+        ang = rng.uniform(-np.pi, np.pi, 3) * rng.choice([1.0, 0.2, 1e-3, 1e-6])
+        pos = rng.uniform(-2.0, 2.0, 3) + np.array([0.0, 0.0, 1.3])
+        poses.append(pose(rotation(*ang), pos))
+    for M in poses:
+        M = np.ascontiguousarray(M, np.float32)
+        for _ in range(40):
+            x0 = int(rng.integers(0, size[0] // 4)) * 4
+            z = int(rng.integers(0, size[2]))
+            lo, hi = C.c_int(), C.c_int()
+            rc = hip_host.fn["debug_column_cull_rows"](fp(M), fp(intr), W, H, vs, ip(size), ip(off), x0, z, C.byref(lo), C.byref(hi))
+            assert rc == 0
+            keep = exact_keep(M, intr, W, H, vs, off, np.arange(x0, x0 + 4), ys, z).any(axis=1)     # per row: some voxel of the group passes
+            inside = (ys >= lo.value) & (ys <= hi.value)
+            assert not np.any(keep & ~inside), (M.tolist(), x0, z, lo.value, hi.value, np.nonzero(keep & ~inside)[0][:5])
+            kept_rows += int(inside.sum()); needed_rows += int(keep.sum()); checked += 1
+    assert checked == len(poses) * 40 and needed_rows > 20000
+    assert kept_rows < 1.6 * needed_rows + 4 * checked          # and the interval is tight: a few rows of slack per column
