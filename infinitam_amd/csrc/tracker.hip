@@ -124,58 +124,78 @@ constexpr int kGHWaves = ITM_GH_WAVES;
 constexpr int kGHThreads = 64 * kGHWaves;
 constexpr int kGHTileH = kGHThreads / 16;      // a tile is 16 pixels wide and kGHTileH tall
 
-// The tiles blk, blk + nBlocks, ... of one workgroup: every lane adds the residual rows of its pixels to `acc` (double) and counts them
+// One depth pixel of the evaluation in three stages, so that the loads of a stage -- of several pixels -- are in flight together
+// instead of one dependent round trip after the other inside nested branches: (1) depth -> point in the scene frame -> position in
+// the rendered maps; (2) the four taps of the point map and of the normal map, fetched unconditionally (tap 0 of the map when the
+// pixel has dropped out); (3) the residual row.  The arithmetic is that of computePerPointGH_Depth_Ab, operation for operation.
+struct GHPixel { bool live; float qx, qy, qz, u, v; };
+
+__device__ inline GHPixel gh_project(const float* __restrict__ depth, const GHParams& p, int x, int y, bool inImage) {
+  GHPixel r{false, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  const float d = depth[inImage ? x + y * p.w : 0];
+  if (!inImage || d <= 1e-8f) return r;
+  // back-project, move to the scene frame, re-project into the rendered maps
+  const float cx3 = d * (((float)x - p.vcx) / p.vfx), cy3 = d * (((float)y - p.vcy) / p.vfy);
+  const Vec3 q = transform_point(p.approxInvPose, cx3, cy3, d);
+  const Vec3 rp = transform_point(p.scenePose, q.x, q.y, q.z);
+  if (rp.z <= 0.0f) return r;
+  const float u = p.sfx * rp.x / rp.z + p.scx, v = p.sfy * rp.y / rp.z + p.scy;
+  if (!((u >= 0.0f) && (u <= p.sceneW - 2) && (v >= 0.0f) && (v <= p.sceneH - 2))) return r;
+  r.live = true; r.qx = q.x; r.qy = q.y; r.qz = q.z; r.u = u; r.v = v;
+  return r;
+}
+
+struct GHTaps { float4 a, b, c, d; };
+__device__ inline GHTaps gh_taps(const float4* __restrict__ src, const GHPixel& px, int W) {
+  const int ix = (int)(int16_t)(int)floorf(px.u), iy = (int)(int16_t)(int)floorf(px.v);   // (short)floor(...)
+  const int i0 = px.live ? ix + iy * W : 0, i1 = px.live ? (ix + 1) + iy * W : 0, i2 = px.live ? ix + (iy + 1) * W : 0, i3 = px.live ? (ix + 1) + (iy + 1) * W : 0;
+  return GHTaps{src[i0], src[i1], src[i2], src[i3]};
+}
+// interpolateBilinear_withHoles on fetched taps; false when any tap is a hole (w < 0)
+__device__ inline bool gh_blend(const GHTaps& t, float px, float py, float4& r) {
+  const int ix = (int)(int16_t)(int)floorf(px), iy = (int)(int16_t)(int)floorf(py);
+  const float dx = px - (float)ix, dy = py - (float)iy;
+  if (t.a.w < 0 || t.b.w < 0 || t.c.w < 0 || t.d.w < 0) return false;
+  r.x = (t.a.x * (1.0f - dx) * (1.0f - dy) + t.b.x * dx * (1.0f - dy) + t.c.x * (1.0f - dx) * dy + t.d.x * dx * dy);
+  r.y = (t.a.y * (1.0f - dx) * (1.0f - dy) + t.b.y * dx * (1.0f - dy) + t.c.y * (1.0f - dx) * dy + t.d.y * dx * dy);
+  r.z = (t.a.z * (1.0f - dx) * (1.0f - dy) + t.b.z * dx * (1.0f - dy) + t.c.z * (1.0f - dx) * dy + t.d.z * dx * dy);
+  r.w = (t.a.w * (1.0f - dx) * (1.0f - dy) + t.b.w * dx * (1.0f - dy) + t.c.w * (1.0f - dx) * dy + t.d.w * dx * dy);
+  return true;
+}
+
 template <int MODE>
-__device__ inline void gh_accumulate(const float* __restrict__ depth, const float4* __restrict__ pointsMap, const float4* __restrict__ normalsMap,
-                                     const GHParams& p, int blk, int nBlocks, double acc[kGHValues], int& valid) {
+__device__ inline void gh_row(const GHPixel& px, const GHTaps& tp, const GHTaps& tn, const GHParams& p, double acc[kGHValues], int& valid) {
   constexpr int NP = (MODE == 3) ? 6 : 3;
   constexpr int NH = NP * (NP + 1) / 2;
-  const int tilesX = (p.w + 15) / 16, tiles = tilesX * ((p.h + kGHTileH - 1) / kGHTileH);
-  for (int tile = blk; tile < tiles; tile += nBlocks) {
   float vals[kGHValues];
 #pragma unroll
   for (int i = 0; i < kGHValues; ++i) vals[i] = 0.0f;
-  const int x = (tile % tilesX) * 16 + (threadIdx.x & 15), y = (tile / tilesX) * kGHTileH + (threadIdx.x >> 4);
-  if (x < p.w && y < p.h) {
-    const float d = depth[x + y * p.w];
-    if (!(d <= 1e-8f)) {
-      // back-project, move to the scene frame, re-project into the rendered maps
-      const float cx3 = d * (((float)x - p.vcx) / p.vfx), cy3 = d * (((float)y - p.vcy) / p.vfy);
-      const Vec3 q = transform_point(p.approxInvPose, cx3, cy3, d);
-      const Vec3 rp = transform_point(p.scenePose, q.x, q.y, q.z);
-      if (!(rp.z <= 0.0f)) {
-        const float u = p.sfx * rp.x / rp.z + p.scx, v = p.sfy * rp.y / rp.z + p.scy;
-        if ((u >= 0.0f) && (u <= p.sceneW - 2) && (v >= 0.0f) && (v <= p.sceneH - 2)) {
-          float4 cp;
-          if (bilinear_holes(pointsMap, u, v, p.sceneW, cp) && !(cp.w < 0.0f)) {
-            const float ex = cp.x - q.x, ey = cp.y - q.y, ez = cp.z - q.z;
-            const float dist = ex * ex + ey * ey + ez * ez;
-            float4 n;
-            if (!(dist > p.distThresh)) {
-              // a hole in the normals map yields the zero normal but still counts (the reference's check is commented out)
-              if (!bilinear_holes(normalsMap, u, v, p.sceneW, n)) n = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
-              const float b = n.x * ex + n.y * ey + n.z * ez;
-              float A[NP];
-              if (MODE == 2) { A[0] = n.x; A[1] = n.y; A[2] = n.z; }
-              else {
-                A[0] = +q.z * n.y - q.y * n.z;
-                A[1] = -q.z * n.x + q.x * n.z;
-                A[2] = +q.y * n.x - q.x * n.y;
-                if constexpr (MODE == 3) { A[3] = n.x; A[4] = n.y; A[5] = n.z; }
-              }
-              vals[0] = b * b;
-              int k = 0;
-#pragma unroll
-              for (int r = 0; r < NP; ++r) {
-                vals[1 + r] = b * A[r];
-#pragma unroll
-                for (int c = 0; c <= r; ++c, ++k) vals[7 + k] = A[r] * A[c];
-              }
-              ++valid;
-            }
-          }
-        }
+  float4 cp;
+  if (px.live && gh_blend(tp, px.u, px.v, cp) && !(cp.w < 0.0f)) {
+    const float ex = cp.x - px.qx, ey = cp.y - px.qy, ez = cp.z - px.qz;
+    const float dist = ex * ex + ey * ey + ez * ez;
+    if (!(dist > p.distThresh)) {
+      // a hole in the normals map yields the zero normal but still counts (the reference's check is commented out)
+      float4 n;
+      if (!gh_blend(tn, px.u, px.v, n)) n = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+      const float b = n.x * ex + n.y * ey + n.z * ez;
+      float A[NP];
+      if (MODE == 2) { A[0] = n.x; A[1] = n.y; A[2] = n.z; }
+      else {
+        A[0] = +px.qz * n.y - px.qy * n.z;
+        A[1] = -px.qz * n.x + px.qx * n.z;
+        A[2] = +px.qy * n.x - px.qx * n.y;
+        if constexpr (MODE == 3) { A[3] = n.x; A[4] = n.y; A[5] = n.z; }
       }
+      vals[0] = b * b;
+      int k = 0;
+#pragma unroll
+      for (int r = 0; r < NP; ++r) {
+        vals[1 + r] = b * A[r];
+#pragma unroll
+        for (int c = 0; c <= r; ++c, ++k) vals[7 + k] = A[r] * A[c];
+      }
+      ++valid;
     }
   }
 #pragma unroll
@@ -183,7 +203,25 @@ __device__ inline void gh_accumulate(const float* __restrict__ depth, const floa
     const bool used = (i == 0) || (i >= 1 && i < 1 + NP) || (i >= 7 && i < 7 + NH);
     if (used) acc[i] += (double)vals[i];
   }
-  }   // tiles of this workgroup
+}
+
+// The tiles blk, blk + nBlocks, ... of one workgroup, two at a time: every lane adds the residual rows of its pixels to `acc`
+// (double, in tile order) and counts them
+template <int MODE>
+__device__ inline void gh_accumulate(const float* __restrict__ depth, const float4* __restrict__ pointsMap, const float4* __restrict__ normalsMap,
+                                     const GHParams& p, int blk, int nBlocks, double acc[kGHValues], int& valid) {
+  const int tilesX = (p.w + 15) / 16, tiles = tilesX * ((p.h + kGHTileH - 1) / kGHTileH);
+  for (int tile = blk; tile < tiles; tile += 2 * nBlocks) {
+    const int tileB = tile + nBlocks;
+    const int xA = (tile % tilesX) * 16 + (threadIdx.x & 15), yA = (tile / tilesX) * kGHTileH + (threadIdx.x >> 4);
+    const int xB = (tileB % tilesX) * 16 + (threadIdx.x & 15), yB = (tileB / tilesX) * kGHTileH + (threadIdx.x >> 4);
+    const GHPixel pa = gh_project(depth, p, xA, yA, xA < p.w && yA < p.h);
+    const GHPixel pb = gh_project(depth, p, xB, yB, tileB < tiles && xB < p.w && yB < p.h);
+    const GHTaps ta = gh_taps(pointsMap, pa, p.sceneW), na = gh_taps(normalsMap, pa, p.sceneW);
+    const GHTaps tb = gh_taps(pointsMap, pb, p.sceneW), nb = gh_taps(normalsMap, pb, p.sceneW);
+    gh_row<MODE>(pa, ta, na, p, acc, valid);
+    gh_row<MODE>(pb, tb, nb, p, acc, valid);
+  }
 }
 
 // wave reduction in double (fixed butterfly order), then the waves in order: thread i < kGHValues ends up with value i of the
