@@ -283,6 +283,15 @@ __global__ void __launch_bounds__(kGHThreads) gh_partial_kernel(const float* __r
   }
 }
 
+#ifndef ITM_EXP_TRACKER_TRACE
+#define ITM_EXP_TRACKER_TRACE 0   // measurement build: per-evaluation host-side latencies on stderr
+#endif
+#if ITM_EXP_TRACKER_TRACE
+#define ITM_TT(...) __VA_ARGS__
+#else
+#define ITM_TT(...)
+#endif
+
 // ---- evaluation session: ONE launch serves every evaluation of a TrackCamera call -------------------------------------------
 // TrackCamera evaluates cost / gradient / Hessian 5-12 times, each at a pose the host derives from the previous answer.  With a
 // launch per evaluation the floor was ~25-30 us each (launch, kernel, up to 256 records over PCIe, the host's summation).  Here
@@ -303,7 +312,7 @@ struct GHCommand {            // pinned host memory, host -> device; `seq` is wr
 };
 constexpr int kCommandWords = (int)(sizeof(GHCommand) / 4);
 static_assert(sizeof(GHCommand) % 4 == 0, "copied word by word");
-struct GHResult { double sums[kGHValues]; int count; volatile unsigned int seq; volatile unsigned int exited; };   // device -> host
+struct GHResult { double sums[kGHValues]; int count; volatile unsigned int seq; volatile unsigned int exited; unsigned long long stamps[4]; };   // device -> host (stamps: measurement builds)
 
 __global__ void __launch_bounds__(kGHThreads) gh_session_kernel(const unsigned int* __restrict__ hostCmd, unsigned int* __restrict__ devCmd,
                                                                 unsigned long long* __restrict__ devSeq, double* __restrict__ partial,
@@ -346,6 +355,7 @@ __global__ void __launch_bounds__(kGHThreads) gh_session_kernel(const unsigned i
     }
     __syncthreads();
     const unsigned int s = nextSeq;
+    ITM_TT(if (blockIdx.x == 0 && threadIdx.x == 0 && s != kSessionExit) __hip_atomic_store(&hostRes->stamps[0], __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);)
     // Everything that crosses workgroups or the PCIe link below travels in relaxed atomic accesses of agent / system scope, which
     // bypass the non-coherent caches one word at a time; ordering needs no more than "my own accesses have completed" (workgroup
     // fence = s_waitcnt) and barriers.  Agent- or system-scope FENCES would write back / invalidate the whole L2 of the XCD on
@@ -392,6 +402,7 @@ __global__ void __launch_bounds__(kGHThreads) gh_session_kernel(const unsigned i
     if (threadIdx.x == 0) lastArriver = ((int)blockIdx.x < nBlocks) && __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)nBlocks - 1u;
     __syncthreads();
     if (lastArriver) {
+      ITM_TT(if (threadIdx.x == 0) __hip_atomic_store(&hostRes->stamps[1], __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);)
       // ---- every partial is in device memory: add them in block order, answer the host ----
       for (int b = threadIdx.x; b < nBlocks; b += kGHThreads) {
 #pragma unroll
@@ -408,6 +419,7 @@ __global__ void __launch_bounds__(kGHThreads) gh_session_kernel(const unsigned i
       if (threadIdx.x == 0) __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __syncthreads();
+      ITM_TT(if (threadIdx.x == 0) __hip_atomic_store(&hostRes->stamps[2], __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);)
       if (threadIdx.x == 0) __hip_atomic_store((unsigned int*)&hostRes->seq, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     last = s;
@@ -561,15 +573,6 @@ static int compute_g_and_h(itm_tracker* trk, const float* depth, int w, int h, c
   return ITM_OK;
 }
 
-#ifndef ITM_EXP_TRACKER_TRACE
-#define ITM_EXP_TRACKER_TRACE 0   // measurement build: per-evaluation host-side latencies on stderr
-#endif
-#if ITM_EXP_TRACKER_TRACE
-#define ITM_TT(...) __VA_ARGS__
-#else
-#define ITM_TT(...)
-#endif
-
 // ---- evaluation session, host side -------------------------------------------------------------------------
 int g_debug_tracker_launch_per_evaluation = 0;   // debug key 10: TrackCamera with one launch per evaluation (the path before the session kernel)
 int g_debug_tracker_host_command = 0;            // debug key 11: session commands through pinned host memory even where the device has a large BAR
@@ -692,8 +695,9 @@ static int session_g_and_h(itm_tracker* trk, const float* depth, int w, int h, c
   }
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
   ITM_TT({ const auto ttC = std::chrono::steady_clock::now();
-           fprintf(stderr, "[tracker trace] %dx%d mode %d: launch %.1f us, answer after %.1f us\n", w, h, iterationType,
-                   std::chrono::duration<double, std::micro>(ttB - ttA).count(), std::chrono::duration<double, std::micro>(ttC - ttB).count()); })
+           fprintf(stderr, "[tracker trace] %dx%d mode %d: launch %.1f us, answer after %.1f us; on the device: command seen -> last arrival %.2f us, -> result written %.2f us\n", w, h, iterationType,
+                   std::chrono::duration<double, std::micro>(ttB - ttA).count(), std::chrono::duration<double, std::micro>(ttC - ttB).count(),
+                   (double)(r->stamps[1] - r->stamps[0]) / 100.0, (double)(r->stamps[2] - r->stamps[0]) / 100.0); })
   const int np = (iterationType == ITM_TRACKER_ITERATION_BOTH) ? 6 : 3;
   const double* sums = r->sums;
   const int n = r->count;
