@@ -304,10 +304,15 @@ __global__ void __launch_bounds__(kGHThreads) gh_partial_kernel(const float* __r
 // result record; a host that finds the session gone simply starts another one at the pending sequence number.
 constexpr unsigned int kSessionExit = 0xffffffffu;
 constexpr unsigned long long kSessionIdleTicks = 200000ull;   // 2 ms
+#ifndef ITM_SESSION_TO_HOST_BLOCKS
+#define ITM_SESSION_TO_HOST_BLOCKS 96
+#endif
+constexpr int kSessionToHostBlocks = ITM_SESSION_TO_HOST_BLOCKS;   // evaluations with at most this many workgroups answer with per-workgroup records
 struct GHCommand {            // pinned host memory, host -> device; `seq` is written last
   GHParams p;
   const float* depth; const float4* points; const float4* normals;
   int mode, activeBlocks;
+  int toHost;                 // few workgroups: each writes its stamped partial record straight to pinned host memory, the host adds them
   unsigned int seq;
 };
 constexpr int kCommandWords = (int)(sizeof(GHCommand) / 4);
@@ -317,7 +322,7 @@ struct GHResult { double sums[kGHValues]; int count; volatile unsigned int seq; 
 __global__ void __launch_bounds__(kGHThreads) gh_session_kernel(const unsigned int* __restrict__ hostCmd, unsigned int* __restrict__ devCmd,
                                                                 unsigned long long* __restrict__ devSeq, double* __restrict__ partial,
                                                                 int* __restrict__ partialCount, unsigned int* __restrict__ done,
-                                                                GHResult* __restrict__ hostRes, unsigned int session, unsigned int firstSeq, int direct) {
+                                                                GHResult* __restrict__ hostRes, GHBlockRecord* __restrict__ hostRec, unsigned int session, unsigned int firstSeq, int direct) {
   __shared__ __attribute__((aligned(16))) unsigned int cmdWords[kCommandWords];
   __shared__ unsigned int nextSeq;
   __shared__ int lastArriver;
@@ -393,13 +398,24 @@ __global__ void __launch_bounds__(kGHThreads) gh_session_kernel(const unsigned i
       if (cmd.mode == 1) { gh_accumulate<1>(cmd.depth, cmd.points, cmd.normals, cmd.p, blockIdx.x, nBlocks, acc, valid); gh_block_reduce<1>(acc, valid, lds, ldsCount, mine, cnt); }
       else if (cmd.mode == 2) { gh_accumulate<2>(cmd.depth, cmd.points, cmd.normals, cmd.p, blockIdx.x, nBlocks, acc, valid); gh_block_reduce<2>(acc, valid, lds, ldsCount, mine, cnt); }
       else { gh_accumulate<3>(cmd.depth, cmd.points, cmd.normals, cmd.p, blockIdx.x, nBlocks, acc, valid); gh_block_reduce<3>(acc, valid, lds, ldsCount, mine, cnt); }
-      if (threadIdx.x < kGHValues) __hip_atomic_store(partial + (size_t)blockIdx.x * kGHValues + threadIdx.x, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (threadIdx.x == 0) __hip_atomic_store(partialCount + blockIdx.x, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (cmd.toHost) {
+        // a coarse level: the record goes to the host as it is (values, then -- once they have left -- the stamp); no arrival counter,
+        // no gathering workgroup, no second trip through device memory
+        GHBlockRecord* r = hostRec + blockIdx.x;
+        if (threadIdx.x < kGHValues) __hip_atomic_store(&r->sums[threadIdx.x], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (threadIdx.x == 0) __hip_atomic_store(&r->count, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store((unsigned int*)&r->seq, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      } else {
+        if (threadIdx.x < kGHValues) __hip_atomic_store(partial + (size_t)blockIdx.x * kGHValues + threadIdx.x, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) __hip_atomic_store(partialCount + blockIdx.x, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      }
     }
     __syncthreads();
     // only the workgroups that had tiles arrive (6 of 256 on the 40x30 level: 250 fewer read-modify-writes of one word)
-    if (threadIdx.x == 0) lastArriver = ((int)blockIdx.x < nBlocks) && __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)nBlocks - 1u;
+    if (threadIdx.x == 0) lastArriver = !cmd.toHost && ((int)blockIdx.x < nBlocks) && __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)nBlocks - 1u;
     __syncthreads();
     if (lastArriver) {
       ITM_TT(if (threadIdx.x == 0) __hip_atomic_store(&hostRes->stamps[1], __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);)
@@ -618,7 +634,7 @@ static int session_reserve(itm_tracker* t) {
 
 static int session_launch(itm_tracker* t, unsigned int firstSeq, hipStream_t st) {
   ++t->session;
-  gh_session_kernel<<<kGHGroups, kGHThreads, 0, st>>>(t->cmdDev, t->devCmd, t->devSeq, t->partial, t->partialCount, t->done, t->resDev, t->session, firstSeq, t->cmdDirect ? 1 : 0);
+  gh_session_kernel<<<kGHGroups, kGHThreads, 0, st>>>(t->cmdDev, t->devCmd, t->devSeq, t->partial, t->partialCount, t->done, t->resDev, t->recDev, t->session, firstSeq, t->cmdDirect ? 1 : 0);
   ITM_LAUNCH_CHECK();
   t->sessionOpen = true;
   return ITM_OK;
@@ -664,6 +680,9 @@ static int session_g_and_h(itm_tracker* trk, const float* depth, int w, int h, c
   c->p.distThresh = distThresh; c->p.w = w; c->p.h = h; c->p.sceneW = sceneW; c->p.sceneH = sceneH;
   c->depth = depth; c->points = (const float4*)pointsMap; c->normals = (const float4*)normalsMap;
   c->mode = iterationType; c->activeBlocks = (tiles + rounds - 1) / rounds;       // the grid of the per-launch path: same tiles per block, same sums
+  const int nBlocks = c->activeBlocks;
+  const bool toHost = nBlocks <= kSessionToHostBlocks;
+  c->toHost = toHost ? 1 : 0;
   unsigned int seq = ++trk->seq;
   if (seq == kSessionExit || seq == 0u) seq = trk->seq = 1u;
   ITM_TT(const auto ttA = std::chrono::steady_clock::now();)
@@ -678,10 +697,13 @@ static int session_g_and_h(itm_tracker* trk, const float* depth, int w, int h, c
   clock::time_point t0; bool timing = false;
   unsigned spins = 0;
   const GHResult* r = trk->res;
-  while (r->seq != seq) {
+  // coarse levels answer with one stamped record per workgroup: the last record's stamp is waited for here like the result's, the
+  // others right after (they are there or about to be)
+  const volatile unsigned int* answer = toHost ? &trk->rec[nBlocks - 1].seq : &r->seq;
+  while (*answer != seq) {
     __builtin_ia32_pause();
     if ((++spins & 0xffu) != 0u) continue;
-    if (r->exited == trk->session && r->seq != seq) {
+    if (r->exited == trk->session && *answer != seq) {
       if ((rc = session_launch(trk, seq, st))) return rc;
       continue;
     }
@@ -693,14 +715,30 @@ static int session_g_and_h(itm_tracker* trk, const float* depth, int w, int h, c
     if (q != hipSuccess && q != hipErrorNotReady) { trk->sessionOpen = false; return hip_fail(q, "tracker session", __FILE__, __LINE__); }
     if (waited > trk->pollTimeoutSeconds) { session_close(trk); return set_error(ITM_ERR_DEVICE, "tracker session timed out"); }
   }
+  double hostSums[kGHValues];
+  int hostCount = 0;
+  if (toHost) {
+    for (int i = 0; i < kGHValues; ++i) hostSums[i] = 0.0;
+    for (int b = 0; b < nBlocks; ++b) {                          // block order, as the device-side gather and the per-launch path
+      const GHBlockRecord* q = trk->rec + b;
+      const clock::time_point w0 = clock::now();
+      while (q->seq != seq) {
+        __builtin_ia32_pause();
+        if (std::chrono::duration<double>(clock::now() - w0).count() > trk->pollTimeoutSeconds) { session_close(trk); return set_error(ITM_ERR_DEVICE, "tracker session: a record did not arrive"); }
+      }
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      for (int i = 0; i < kGHValues; ++i) hostSums[i] += q->sums[i];
+      hostCount += q->count;
+    }
+  }
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
   ITM_TT({ const auto ttC = std::chrono::steady_clock::now();
            fprintf(stderr, "[tracker trace] %dx%d mode %d: launch %.1f us, answer after %.1f us; on the device: command seen -> last arrival %.2f us, -> result written %.2f us\n", w, h, iterationType,
                    std::chrono::duration<double, std::micro>(ttB - ttA).count(), std::chrono::duration<double, std::micro>(ttC - ttB).count(),
                    (double)(r->stamps[1] - r->stamps[0]) / 100.0, (double)(r->stamps[2] - r->stamps[0]) / 100.0); })
   const int np = (iterationType == ITM_TRACKER_ITERATION_BOTH) ? 6 : 3;
-  const double* sums = r->sums;
-  const int n = r->count;
+  const double* sums = toHost ? hostSums : r->sums;
+  const int n = toHost ? hostCount : r->count;
   for (int a = 0, k = 0; a < np; ++a)
     for (int b = 0; b <= a; ++b, ++k) out->hessian[a + b * 6] = (float)sums[7 + k];
   for (int a = 0; a < np; ++a)
