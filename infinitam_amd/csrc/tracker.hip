@@ -421,14 +421,28 @@ __global__ void __launch_bounds__(kGHThreads) gh_session_kernel(const unsigned i
       ITM_TT(if (threadIdx.x == 0) __hip_atomic_store(&hostRes->stamps[1], __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);)
       // ---- every partial is in device memory: add them in block order, answer the host ----
       for (int b = threadIdx.x; b < nBlocks; b += kGHThreads) {
+        // all loads of the record first (independent destinations: in flight together), then the copies into LDS
+        double rec[kGHValues];
 #pragma unroll
-        for (int i = 0; i < kGHValues; ++i) gathered[b][i] = __hip_atomic_load(partial + (size_t)b * kGHValues + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        gathered[b][kGHValues] = (double)__hip_atomic_load(partialCount + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = 0; i < kGHValues; ++i) rec[i] = __hip_atomic_load(partial + (size_t)b * kGHValues + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int recCount = __hip_atomic_load(partialCount + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int i = 0; i < kGHValues; ++i) gathered[b][i] = rec[i];
+        gathered[b][kGHValues] = (double)recCount;
       }
       __syncthreads();
       if (threadIdx.x <= kGHValues) {
+        // block order (the host's order); eight LDS reads in flight per step, the additions stay a chain
         double sum = 0.0;
-        for (int b = 0; b < nBlocks; ++b) sum += gathered[b][threadIdx.x];
+        int b = 0;
+        for (; b + 8 <= nBlocks; b += 8) {
+          double v8[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v8[k] = gathered[b + k][threadIdx.x];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) sum += v8[k];
+        }
+        for (; b < nBlocks; ++b) sum += gathered[b][threadIdx.x];
         if (threadIdx.x < kGHValues) __hip_atomic_store(&hostRes->sums[threadIdx.x], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         else __hip_atomic_store(&hostRes->count, (int)sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // counts are small integers: exact in double
       }
