@@ -349,6 +349,10 @@ def worker(args) -> int:
                        "backend": be.version()},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
+    for ex in exs:                     # communicators of the library exchange go before the process group they were bootstrapped over
+        if hasattr(ex, "close"):
+            sync()
+            ex.close()
     if dist.is_initialized():
         dist.destroy_process_group()
     if rank == 0:
