@@ -167,13 +167,14 @@ __global__ void __launch_bounds__(256) request_kernel(const float* __restrict__ 
 }
 
 // Block coordinates requested by (pixel, step): replays the winner's ray with identical arithmetic.
-__device__ inline void replay_block_pos(uint32_t key, const float* __restrict__ depth, const AllocParams& p, int& bx, int& by, int& bz) {
+// (`d` = the depth pixel of the key, depth[(key - 1) >> stepBits], fetched ahead by the caller)
+__device__ inline void replay_block_pos(uint32_t key, float d, const AllocParams& p, int& bx, int& by, int& bz) {
   const uint32_t k = key - 1u;
   const int loc = (int)(k >> p.stepBits);
   const int step = (int)(k & ((1u << p.stepBits) - 1u));
   const int y = loc / p.W, x = loc - y * p.W;
   BlockRay r;
-  make_block_ray(depth[loc], x, y, p, r);
+  make_block_ray(d, x, y, p, r);
   for (int i = 0; i < step; ++i) { r.px += r.dx; r.py += r.dy; r.pz += r.dz; }
   bx = (int)(int16_t)(int)floorf(r.px); by = (int)(int16_t)(int)floorf(r.py); bz = (int)(int16_t)(int)floorf(r.pz);
 }
@@ -199,57 +200,83 @@ __device__ inline void sweep_chunk(int* lds, uint32_t* __restrict__ allocKey, co
   const int2 mine = chunkReq[chunk];
   if (mine.x == 0) return;  // nothing requested in this chunk (uniform per workgroup)
 
-  // requests in all earlier chunks
+  // The sweep of a chunk with requests is a chain of dependent loads (keys -> entry / depth pixel -> free-list slot), and the
+  // whole visible-list launch waits for the slowest such chunk (per-workgroup timeline, tools/list_timeline.py: 8.9 us for it, 1 us
+  // for the others).  The loads are therefore issued in three rounds of independent ones, unconditionally from addresses that are
+  // always valid, instead of one by one inside the per-request branches.
+  // ---- round 1: the keys of this thread's slots, the pool counters, the request counts of the earlier chunks ----
+  const int slot0 = chunk * kSweepChunk + tid * kSlotsPerThread;
+  const bool inTable = slot0 < p.noTotalEntries;              // noTotalEntries is a multiple of 8 (checked on the host)
+  const uint4 ka = *(const uint4*)(allocKey + (inTable ? slot0 : 0)), kb = *(const uint4*)(allocKey + (inTable ? slot0 + 4 : 0));
+  const int lastFreeVBA = counters->lastFreeBlockId;
+  const int lastFreeExc = counters->lastFreeExcessListId;
   int b1 = 0, b2 = 0;
   for (int j = tid; j < chunk; j += 256) { int2 c = chunkReq[j]; b1 += c.x; b2 += c.y; }
+  uint32_t keys[kSlotsPerThread] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
+  if (!inTable) {
+#pragma unroll
+    for (int k = 0; k < kSlotsPerThread; ++k) keys[k] = 0u;
+  }
+  // ---- round 2: for every request its target entry (ordered or excess request?) and the depth pixel of the winning ray ----
+  int ptrOfTarget[kSlotsPerThread];
+  float depthOfKey[kSlotsPerThread];
+#pragma unroll
+  for (int k = 0; k < kSlotsPerThread; ++k) {
+    ptrOfTarget[k] = (int)((const uint32_t*)&hash[keys[k] ? slot0 + k : 0])[3];
+    depthOfKey[k] = depth[keys[k] ? (int)((keys[k] - 1u) >> p.stepBits) : 0];
+  }
   const int baseReq = block_reduce_sum<4>(b1, lds);
   const int baseExc = block_reduce_sum<4>(b2, lds + 4);
-
-  const int slot0 = chunk * kSweepChunk + tid * kSlotsPerThread;
-  uint32_t keys[kSlotsPerThread];
   uint32_t isExcessBits = 0;
   int n1 = 0, n2 = 0;
 #pragma unroll
   for (int k = 0; k < kSlotsPerThread; ++k) {
-    const int slot = slot0 + k;
-    keys[k] = (slot < p.noTotalEntries) ? allocKey[slot] : 0u;
     if (keys[k]) {
       ++n1;
       // target of an excess request is an occupied chain tail; of an ordered request an empty head
-      if ((int)hash[slot].w >= -1) { isExcessBits |= (1u << k); ++n2; }
+      if (ptrOfTarget[k] >= -1) { isExcessBits |= (1u << k); ++n2; }
     }
   }
   int tot;
   int r1 = baseReq + block_exclusive_scan<4>(n1, lds, &tot);
   int r2 = baseExc + block_exclusive_scan<4>(n2, lds + 4, &tot);
   if (n1 == 0) return;
-  const int lastFreeVBA = counters->lastFreeBlockId;
-  const int lastFreeExc = counters->lastFreeExcessListId;
+  // ---- round 3: the free-list entries the ranks select (ranks advance as in the sequential sweep, also past an empty pool) ----
+  int vbaIdx[kSlotsPerThread], exlIdx[kSlotsPerThread], ptrNew[kSlotsPerThread], offNew[kSlotsPerThread];
+#pragma unroll
+  for (int k = 0; k < kSlotsPerThread; ++k) {
+    vbaIdx[k] = -1; exlIdx[k] = -1;
+    if (keys[k]) {
+      vbaIdx[k] = lastFreeVBA - r1; ++r1;
+      if (isExcessBits & (1u << k)) { exlIdx[k] = lastFreeExc - r2; ++r2; }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kSlotsPerThread; ++k) {
+    ptrNew[k] = allocList[vbaIdx[k] >= 0 ? vbaIdx[k] : 0];
+    offNew[k] = excessList[exlIdx[k] >= 0 ? exlIdx[k] : 0];
+  }
 #pragma unroll
   for (int k = 0; k < kSlotsPerThread; ++k) {
     if (!keys[k]) continue;
     const int slot = slot0 + k;
-    const int vbaIdx = lastFreeVBA - r1;
-    ++r1;
     if (isExcessBits & (1u << k)) {
-      const int exlIdx = lastFreeExc - r2;
-      ++r2;
-      if (vbaIdx >= 0 && exlIdx >= 0) {
+      if (vbaIdx[k] >= 0 && exlIdx[k] >= 0) {
         int bx, by, bz;
-        replay_block_pos(keys[k], depth, p, bx, by, bz);
-        const int off = excessList[exlIdx];
+        replay_block_pos(keys[k], depthOfKey[k], p, bx, by, bz);
+        const int off = offNew[k];
         ((uint32_t*)&hash[slot])[2] = (uint32_t)(off + 1);                 // connect the chain tail to the child
-        const int ptr = allocList[vbaIdx];
+        const int ptr = ptrNew[k];
         hash[p.bucketNum + off] = pack_entry(bx, by, bz, 0, ptr);
         if (ACROSS) __hip_atomic_store(&visT[p.bucketNum + off], (uint8_t)(lazy ? 0x81 : 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else visT[p.bucketNum + off] = lazy ? 0x81 : 1;
         directory_insert(dirPtr, dirSlot, bx, by, bz, ptr, p.bucketNum + off);
         mirror_init_block(sdfMirror, p.mirrorFloat != 0, bx, by, bz);
       }
-    } else if (vbaIdx >= 0) {
+    } else if (vbaIdx[k] >= 0) {
       int bx, by, bz;
-      replay_block_pos(keys[k], depth, p, bx, by, bz);
-      const int ptr = allocList[vbaIdx];
+      replay_block_pos(keys[k], depthOfKey[k], p, bx, by, bz);
+      const int ptr = ptrNew[k];
       hash[slot] = pack_entry(bx, by, bz, 0, ptr);
       atomicOr(&headBits[slot >> 5], 1u << (slot & 31));
       directory_insert(dirPtr, dirSlot, bx, by, bz, ptr, slot);
@@ -393,6 +420,17 @@ struct SweepArgs {
   uint32_t* sweepDone;     // per chunk: the epoch of the launch whose sweep has placed the chunk's excess allocations
 };
 
+#ifndef ITM_EXP_LIST_STAMPS
+#define ITM_EXP_LIST_STAMPS 0     // measurement build: per-workgroup timeline of the visible-list launch (100 MHz clock)
+#endif
+#if ITM_EXP_LIST_STAMPS
+__device__ unsigned long long g_listStamps[1024 * 6];
+#define ITM_LS(k) if (threadIdx.x == 0 && blockIdx.x < 1024) g_listStamps[6 * blockIdx.x + (k)] = __builtin_amdgcn_s_memrealtime();
+extern "C" int itm_debug_read_list_stamps(unsigned long long* dst, int n) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_listStamps), (size_t)n * 8); }
+#else
+#define ITM_LS(k)
+#endif
+
 template <bool COMMIT_ALLOC, bool LAZY, bool SWEEP>
 __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__ visT, uint4* __restrict__ hash,
                                                            unsigned long long* __restrict__ chunkGran, uint32_t epoch,
@@ -403,6 +441,7 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
   const int chunk = blockIdx.x, tid = threadIdx.x;
   const int slot0 = chunk * kSweepChunk + tid * kSlotsPerThread;
   const bool excessRegion = SWEEP && slot0 - tid * kSlotsPerThread >= p.bucketNum;      // uniform: bucketNum is a multiple of the chunk size (host)
+  ITM_LS(0)
   int before = 0;
   bool stuck = false;
   // sums the granules of the chunks before this one, waiting for each to carry this launch's epoch
@@ -420,10 +459,12 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
   if constexpr (SWEEP) {
     sweep_chunk<true>(sweepLds, sw.allocKey, chunkReq, sw.chunkReqNext, numChunks, hash, sw.excessList, sw.allocList, visT, counters, sw.headBits,
                       sw.dirPtr, sw.dirSlot, sw.sdfMirror, sw.depth, sw.lazy, p);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // this thread's stores have completed ...
-    __syncthreads();
-    const bool wroteAcross = chunkReq[chunk].y > 0;            // ... before the chunk says that its excess allocations are in place
-    if (wroteAcross && tid == 0) __hip_atomic_store(&sw.sweepDone[chunk], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool wroteAcross = chunkReq[chunk].y > 0;            // (uniform) only excess allocations are read by other workgroups of this launch
+    if (wroteAcross) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this thread's stores have completed ...
+      __syncthreads();                                         // ... all of the chunk's have: say that its excess allocations are in place
+      if (tid == 0) __hip_atomic_store(&sw.sweepDone[chunk], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (excessRegion) {
       // every chunk that had excess requests (any index: no sweep waits for anything, so this cannot cycle) must be through
       for (int j = tid; j < numChunks; j += 256) {
@@ -436,6 +477,7 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
       __syncthreads();
     }
   }
+  ITM_LS(1)
   int n = 0;
   uint32_t w[2] = {0u, 0u};
   if (slot0 < p.noTotalEntries) {  // noTotalEntries is a multiple of 8 (checked on the host)
@@ -449,6 +491,17 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
     w[0] = raw.x; w[1] = raw.y;
     if (raw.x | raw.y) {
       bool changed = false;
+      // the entries of the slots that need the frustum re-test, fetched together (a thread's eight entries are 128 contiguous
+      // bytes) rather than one dependent load per slot inside the branch below
+      uint32_t retest = 0;
+#pragma unroll
+      for (int k = 0; k < kSlotsPerThread; ++k) {
+        const uint32_t t = (w[k >> 2] >> ((k & 3) * 8)) & 0xffu;
+        if (!(LAZY && (t & 0x80u)) && (LAZY ? (t != 0u) : (t == 3u))) retest |= 1u << k;
+      }
+      uint4 entry[kSlotsPerThread];
+#pragma unroll
+      for (int k = 0; k < kSlotsPerThread; ++k) entry[k] = hash[slot0 + ((retest >> k) & 1u ? k : 0)];
 #pragma unroll
       for (int k = 0; k < kSlotsPerThread; ++k) {
         uint32_t t = (w[k >> 2] >> ((k & 3) * 8)) & 0xffu;
@@ -457,7 +510,7 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
           t &= 0x7fu;                         // touched this frame: type 1 / 2
         } else if (LAZY ? (t != 0u) : (t == 3u)) {
           // visible in the previous frame and not seen again: keep only if still in the frustum
-          HashEntry he = unpack_entry(hash[slot0 + k]);
+          HashEntry he = unpack_entry(entry[k]);
           t = block_in_frustum(he.px, he.py, he.pz, p.M, p.fx, p.fy, p.cx, p.cy, p.voxelSize, p.W, p.H) ? 3u : 0u;
         }
         if (t != t0) { w[k >> 2] = (w[k >> 2] & ~(0xffu << ((k & 3) * 8))) | (t << ((k & 3) * 8)); changed = true; }
@@ -470,8 +523,10 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
   const int pos0 = block_exclusive_scan<4>(n, lds, &mine);
   if (tid == 0)
     __hip_atomic_store(&chunkGran[chunk], ((unsigned long long)epoch << 32) | (unsigned long long)(uint32_t)mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  ITM_LS(2)
   // base = visible slots in all earlier chunks
   look_back();
+  ITM_LS(3)
   if (stuck) atomicOr(&counters->statusFlags, 2);
   const int base = block_reduce_sum<4>(before, lds + 4);
   if (COMMIT_ALLOC && chunk == (SWEEP ? numChunks - 1 : 0)) {
@@ -492,6 +547,7 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
     rc->rawVisibleCount = total;
     rc->noVisibleEntries = total < capIds ? total : capIds;
   }
+  ITM_LS(4)
   if (n == 0) return;
   int pos = base + pos0;
 #pragma unroll
