@@ -212,11 +212,8 @@ __device__ inline void sweep_chunk(int* lds, uint32_t* __restrict__ allocKey, co
   const int lastFreeExc = counters->lastFreeExcessListId;
   int b1 = 0, b2 = 0;
   for (int j = tid; j < chunk; j += 256) { int2 c = chunkReq[j]; b1 += c.x; b2 += c.y; }
-  uint32_t keys[kSlotsPerThread] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
-  if (!inTable) {
-#pragma unroll
-    for (int k = 0; k < kSlotsPerThread; ++k) keys[k] = 0u;
-  }
+  const uint32_t keep = inTable ? 0xffffffffu : 0u;
+  const uint32_t keys[kSlotsPerThread] = {ka.x & keep, ka.y & keep, ka.z & keep, ka.w & keep, kb.x & keep, kb.y & keep, kb.z & keep, kb.w & keep};
   // ---- round 2: for every request its target entry (ordered or excess request?) and the depth pixel of the winning ray ----
   int ptrOfTarget[kSlotsPerThread];
   float depthOfKey[kSlotsPerThread];

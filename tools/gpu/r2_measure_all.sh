@@ -21,6 +21,7 @@ ITM_DEBUG_KEYS=12 python tools/config_bench.py 2 200 | tail -1 > $O/cfg2_no_sdf_
 ITM_NO_DIRECTORY=1 python tools/config_bench.py 2 200 | tail -1 > $O/cfg2_table_walk.json
 python tools/raycast_timeline.py gpurun_variants/lib_rs.so > $O/raycast_timeline.txt 2>&1
 python tools/fused_stamps.py gpurun_variants/lib_stamps.so > $O/fused_stamps.txt 2>&1
+python tools/list_timeline.py gpurun_variants/lib_ls.so > $O/list_timeline.txt 2>&1
 ITM_DEBUG_KEYS=13 python tools/config_bench.py 2 200 | tail -1 > $O/cfg2_separate_sweep.json
 bash tools/gpu/r2_profiles.sh > $O/profiles.log 2>&1
-for f in $O/bench_*.json; do echo "$f: $(cut -c1-230 $f)"; done; cat $O/tracker.txt $O/closed_loop.txt $O/raycast_timeline.txt; cut -c1-330 $O/cfg*.json; tail -40 $O/profiles.log
+for f in $O/bench_*.json; do echo "$f: $(cut -c1-230 $f)"; done; cat $O/tracker.txt $O/closed_loop.txt $O/raycast_timeline.txt $O/fused_stamps.txt $O/list_timeline.txt; cut -c1-330 $O/cfg*.json; tail -40 $O/profiles.log
