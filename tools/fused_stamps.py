@@ -19,7 +19,7 @@ for k in range(30):
     v = capi.View(d, W, H, M_d=synth.pose_matrix(t), intr_d=intr)
     scene.process_frame(v, rs, pts, nrm)
 be.sync()
-n = 2080
+n = 2048
 st = np.zeros((n, 2), np.uint64)
 assert be.lib.itm_debug_read_fused_stamps(st.ctypes.data_as(C.c_void_p), n * 2) == 0
 t0 = st[:, 0].min()
