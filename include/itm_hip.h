@@ -460,6 +460,10 @@ typedef struct itm_profile {
 /* kernel_mask: bit i enables timing of kernel i (0 disables everything).  Each timed launch costs
  * two hipEventRecord calls on the frame stream. */
 int ITM_FN(profile_enable)(itm_scene* scene, uint32_t kernel_mask);
+/* Time only every `every`-th launch of each enabled kernel (1 = every launch, the default): the
+ * event pair costs a few microseconds of stream time, which a throughput run should not pay on
+ * every frame.  The average launch duration is over the sampled launches. */
+int ITM_FN(profile_sample)(itm_scene* scene, int every);
 /* Waits for the recorded events, accumulates and returns the totals; reset != 0 clears them. */
 int ITM_FN(profile_read)(itm_scene* scene, itm_profile* out, int reset);
 

@@ -187,6 +187,7 @@ _SIGS = {
     "debug_div32767": (C.c_int, [_P, _P, C.c_int, _P]),
     "debug_divide": (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_int, _P]),
     "profile_enable": (C.c_int, [_P, C.c_uint32]),
+    "profile_sample": (C.c_int, [_P, C.c_int]),
     "profile_read": (C.c_int, [_P, C.POINTER(Profile), C.c_int]),
     "export_visible_record": (C.c_int, [_P, C.POINTER(C.c_float), C.c_int, _P, _P]),
     "mesh_create": (C.c_int, [_P, C.c_uint32, C.POINTER(_P)]),
@@ -425,6 +426,9 @@ class Scene:
 
     def profile_enable(self, mask: int):
         self.be.check(self.be.fn["profile_enable"](_P(self.h), mask), "profile_enable")
+
+    def profile_sample(self, every: int):
+        self.be.check(self.be.fn["profile_sample"](_P(self.h), every), "profile_sample")
 
     def profile_read(self, reset=True) -> dict:
         p = Profile()

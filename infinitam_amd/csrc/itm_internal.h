@@ -32,6 +32,8 @@ struct RenderCounters {
 // hipEvent pairs around selected kernels (itm_profile_enable / itm_profile_read)
 struct Profiler {
   uint32_t mask = 0;
+  int every = 1;                 // time every `every`-th launch of an enabled kernel
+  uint32_t tick[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   struct Rec { int id; hipEvent_t a, b; };
   std::vector<Rec> pending;
   std::vector<hipEvent_t> pool;
@@ -129,7 +131,7 @@ inline hipStream_t as_stream(itm_stream s) { return (hipStream_t)s; }
 struct KernelTimer {
   Profiler* p; hipStream_t st; int id; hipEvent_t a;
   KernelTimer(const itm_scene* s, int id_, hipStream_t st_) : p(s->prof), st(st_), id(id_), a(nullptr) {
-    if (p && (p->mask >> id) & 1u) { a = p->get(); (void)hipEventRecord(a, st); } else p = nullptr;
+    if (p && ((p->mask >> id) & 1u) && (p->tick[id]++ % (uint32_t)p->every) == 0) { a = p->get(); (void)hipEventRecord(a, st); } else p = nullptr;
   }
   ~KernelTimer() {
     if (p) { hipEvent_t b = p->get(); (void)hipEventRecord(b, st); p->pending.push_back({id, a, b}); }

@@ -518,6 +518,13 @@ int itm_profile_enable(itm_scene* s, uint32_t mask) {
   s->prof->mask = mask;
   return ITM_OK;
 }
+int itm_profile_sample(itm_scene* s, int every) {
+  if (!s || every < 1) return set_error(ITM_ERR_INVALID, "profile_sample: null scene or every < 1");
+  if (!s->prof) s->prof = new Profiler();
+  s->prof->every = every;
+  for (int i = 0; i < 8; ++i) s->prof->tick[i] = 0;
+  return ITM_OK;
+}
 int itm_profile_read(itm_scene* s, itm_profile* out, int reset) {
   if (!s || !out) return set_error(ITM_ERR_INVALID, "null argument");
   memset(out, 0, sizeof *out);
