@@ -92,7 +92,38 @@ struct GHParams {
 
 constexpr int kGHValues = 1 + 6 + 21;   // f, nabla, packed lower-triangular hessian
 
-struct GHBlockRecord { double sums[kGHValues]; int count; volatile unsigned int seq; };   // one per workgroup, in pinned host memory
+// Everything the tracker hands between host and device (and between workgroups) travels as TAGGED GRANULES: 8 aligned bytes = 4 bytes
+// of payload + the 4-byte sequence number of the evaluation they belong to.  An aligned 8-byte store is indivisible for the device,
+// across PCIe and for the host, so a reader that finds the expected number in a granule holds that granule's payload: no stamp
+// written after the values, and therefore no wait for the values to have left before the stamp may follow (one PCIe or memory
+// round trip per hand-off, 1.5-2 us each, measured).
+constexpr int kRecordWords = 2 * kGHValues + 1;   // 28 doubles as two words each, then the count
+struct GHBlockRecord { unsigned long long g[64]; };   // one per workgroup (pinned host memory) and the session's result; granule i = tag << 32 | word i
+static_assert(kRecordWords <= 64, "record granules");
+__host__ __device__ inline unsigned int next_seq(unsigned int s) { ++s; return (s == 0u || s == 0xffffffffu) ? 1u : s; }   // 0 and ~0 are never sequence numbers
+
+// thread i < kGHValues holds value i of the workgroup (`mine`); every thread holds `cnt`.  Lane i of the first wave stores granule i:
+// one store instruction over 512 contiguous bytes, which leaves the CU as whole 64-byte lines (granules written two per lane,
+// 16 bytes apart, crossed PCIe one by one and cost the host's memory a partial-line update each: 7 us per record, measured)
+template <int SCOPE>
+__device__ inline void send_record(GHBlockRecord* r, double mine, int cnt, unsigned int tag) {
+  if (threadIdx.x >= 64) return;
+  const int i = threadIdx.x;
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(__shfl(mine, i >> 1, 64));
+  unsigned int w = (i & 1) ? (unsigned int)(bits >> 32) : (unsigned int)bits;
+  if (i == 2 * kGHValues) w = (unsigned int)cnt;
+  if (i > 2 * kGHValues) w = 0u;
+  __hip_atomic_store(&r->g[i], ((unsigned long long)tag << 32) | w, __ATOMIC_RELAXED, SCOPE);
+}
+
+#ifndef ITM_EXP_TRACKER_TRACE
+#define ITM_EXP_TRACKER_TRACE 0   // measurement build: per-evaluation host-side latencies on stderr
+#endif
+#if ITM_EXP_TRACKER_TRACE
+#define ITM_TT(...) __VA_ARGS__
+#else
+#define ITM_TT(...)
+#endif
 
 // interpolateBilinear_withHoles for a Vector4f map; returns false when any tap is a hole (w < 0)
 __device__ inline bool bilinear_holes(const float4* __restrict__ src, float px, float py, int W, float4& r) {
@@ -209,7 +240,7 @@ __device__ inline void gh_row(const GHPixel& px, const GHTaps& tp, const GHTaps&
 // (double, in tile order) and counts them
 template <int MODE>
 __device__ inline void gh_accumulate(const float* __restrict__ depth, const float4* __restrict__ pointsMap, const float4* __restrict__ normalsMap,
-                                     const GHParams& p, int blk, int nBlocks, double acc[kGHValues], int& valid) {
+                                     const GHParams& p, int blk, int nBlocks, double acc[kGHValues], int& valid ITM_TT(, unsigned long long* tt = nullptr)) {
   const int tilesX = (p.w + 15) / 16, tiles = tilesX * ((p.h + kGHTileH - 1) / kGHTileH);
   for (int tile = blk; tile < tiles; tile += 2 * nBlocks) {
     const int tileB = tile + nBlocks;
@@ -217,15 +248,41 @@ __device__ inline void gh_accumulate(const float* __restrict__ depth, const floa
     const int xB = (tileB % tilesX) * 16 + (threadIdx.x & 15), yB = (tileB / tilesX) * kGHTileH + (threadIdx.x >> 4);
     const GHPixel pa = gh_project(depth, p, xA, yA, xA < p.w && yA < p.h);
     const GHPixel pb = gh_project(depth, p, xB, yB, tileB < tiles && xB < p.w && yB < p.h);
+    ITM_TT(if (tt && tile == blk) { __builtin_amdgcn_s_waitcnt(0); tt[0] = __builtin_amdgcn_s_memrealtime(); })
     const GHTaps ta = gh_taps(pointsMap, pa, p.sceneW), na = gh_taps(normalsMap, pa, p.sceneW);
     const GHTaps tb = gh_taps(pointsMap, pb, p.sceneW), nb = gh_taps(normalsMap, pb, p.sceneW);
+    ITM_TT(if (tt && tile == blk) { __builtin_amdgcn_s_waitcnt(0); tt[1] = __builtin_amdgcn_s_memrealtime(); })
     gh_row<MODE>(pa, ta, na, p, acc, valid);
     gh_row<MODE>(pb, tb, nb, p, acc, valid);
   }
 }
 
-// wave reduction in double (fixed butterfly order), then the waves in order: thread i < kGHValues ends up with value i of the
-// workgroup, every thread with its count
+// Sum of `s` over the 64 lanes of the wave, the same value in every lane: an inclusive scan inside each row of 16 lanes with DPP
+// row shifts (lanes that would read from outside their row add 0), then the four row totals in row order.  Data-parallel
+// primitives keep the exchange in the ALU; the ds_bpermute butterfly this replaces was one LDS round trip per step and value
+// (2.7 us per evaluation for the block reduction, measured).  The order of the additions is fixed: deterministic sums.
+template <int CTRL>
+__device__ inline double dpp_shifted(double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned int)b, CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned int)(b >> 32), CTRL, 0xf, 0xf, true);
+  return __longlong_as_double((long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo));
+}
+__device__ inline double lane_value(double v, int lane) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)b, lane), hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(b >> 32), lane);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ inline double wave_sum(double s) {
+  s += dpp_shifted<0x111>(s);   // row_shr:1
+  s += dpp_shifted<0x112>(s);   // row_shr:2
+  s += dpp_shifted<0x114>(s);   // row_shr:4
+  s += dpp_shifted<0x118>(s);   // row_shr:8  -> lane 15 of every row holds the row's sum
+  return ((lane_value(s, 15) + lane_value(s, 31)) + lane_value(s, 47)) + lane_value(s, 63);
+}
+
+// wave sums in double (fixed order), then the waves in order: thread i < kGHValues ends up with value i of the workgroup, every
+// thread with its count
 template <int MODE>
 __device__ inline void gh_block_reduce(const double acc[kGHValues], int valid, double (*lds)[kGHValues], int* ldsCount, double& mine, int& cnt) {
   constexpr int NP = (MODE == 3) ? 6 : 3;
@@ -234,18 +291,13 @@ __device__ inline void gh_block_reduce(const double acc[kGHValues], int valid, d
 #pragma unroll
   for (int i = 0; i < kGHValues; ++i) {
     const bool used = (i == 0) || (i >= 1 && i < 1 + NP) || (i >= 7 && i < 7 + NH);
-    double s = 0.0;
-    if (used) {
-      s = acc[i];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-    }
+    const double s = used ? wave_sum(acc[i]) : 0.0;
     if (lane == 0) lds[wave][i] = s;
   }
-  int c = valid;
+  int total = valid;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
-  if (lane == 0) ldsCount[wave] = c;
+  for (int o = 32; o > 0; o >>= 1) total += __shfl_down(total, o, 64);
+  if (lane == 0) ldsCount[wave] = total;
   __syncthreads();
   mine = 0.0; cnt = 0;
 #pragma unroll
@@ -271,58 +323,44 @@ __global__ void __launch_bounds__(kGHThreads) gh_partial_kernel(const float* __r
   gh_block_reduce<MODE>(acc, valid, lds, ldsCount, mine, cnt);
   if (threadIdx.x < kGHValues) partial[(size_t)blk * kGHValues + threadIdx.x] = mine;
   if (threadIdx.x == 0) partialCount[blk] = cnt;
-  if (hostRec) {
-    // the same partial goes to a record in pinned host memory, stamped with the call's sequence number: the host adds
-    // the records in block order itself (one launch per Levenberg-Marquardt iteration, no reduction launch, no copy)
-    GHBlockRecord* r = hostRec + blk;
-    if (threadIdx.x < kGHValues) r->sums[threadIdx.x] = mine;
-    if (threadIdx.x == 0) r->count = cnt;
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) { r->seq = seq; __threadfence_system(); }
-  }
+  // the same partial goes to a tagged record in pinned host memory: the host adds the records in block order itself (one launch
+  // per Levenberg-Marquardt iteration, no reduction launch, no copy)
+  if (hostRec) send_record<__HIP_MEMORY_SCOPE_SYSTEM>(hostRec + blk, mine, cnt, seq);
 }
-
-#ifndef ITM_EXP_TRACKER_TRACE
-#define ITM_EXP_TRACKER_TRACE 0   // measurement build: per-evaluation host-side latencies on stderr
-#endif
-#if ITM_EXP_TRACKER_TRACE
-#define ITM_TT(...) __VA_ARGS__
-#else
-#define ITM_TT(...)
-#endif
 
 // ---- evaluation session: ONE launch serves every evaluation of a TrackCamera call -------------------------------------------
 // TrackCamera evaluates cost / gradient / Hessian 5-12 times, each at a pose the host derives from the previous answer.  With a
 // launch per evaluation the floor was ~25-30 us each (launch, kernel, up to 256 records over PCIe, the host's summation).  Here
-// the workgroups stay resident for the duration of the call: the host writes a command (pose, level, mode; sequence number last)
-// into pinned memory, workgroup 0 polls it over PCIe and republishes it in device memory for the others, every workgroup
-// accumulates its tiles, the LAST one to arrive (device-scope counter) adds the partials in block order -- the order the host used,
-// so the sums are bit-identical to the per-launch path -- and writes one stamped result record to pinned memory.
-// The kernel cannot outlive its host: workgroup 0 ends the session when no command has arrived for kSessionIdleTicks (2 ms on
-// the 100 MHz clock; the other workgroups have their own, longer, limit) or when the host says so, and reports its exit in the
-// result record; a host that finds the session gone simply starts another one at the pending sequence number.
+// the workgroups stay resident for the duration of the call: the host writes a command (pose, level, mode) as tagged granules,
+// the first wave of every workgroup polls them -- the moment all carry the expected number the workgroup has the whole command --,
+// every workgroup accumulates its tiles, and answers with a tagged record: on coarse levels straight to pinned host memory (the host
+// adds the records in block order), on fine ones to device memory, where the LAST workgroup to arrive (device-scope counter) adds
+// the partials in block order -- the order the host uses, so the sums are bit-identical to the per-launch path -- and sends one record.
+// The kernel cannot outlive its host: a workgroup leaves when no command has arrived for kSessionIdleTicks (2 ms on the 100 MHz
+// clock; workgroup 0, which reports the exit; the others have a longer limit) or when the host says so; a host that finds the
+// session gone starts another one at the pending sequence number (same stream: it begins when the old one has left entirely).
 constexpr unsigned int kSessionExit = 0xffffffffu;
 constexpr unsigned long long kSessionIdleTicks = 200000ull;   // 2 ms
 #ifndef ITM_SESSION_TO_HOST_BLOCKS
 #define ITM_SESSION_TO_HOST_BLOCKS 96
 #endif
 constexpr int kSessionToHostBlocks = ITM_SESSION_TO_HOST_BLOCKS;   // evaluations with at most this many workgroups answer with per-workgroup records
-struct GHCommand {            // pinned host memory, host -> device; `seq` is written last
+struct GHCommand {            // the payload words of the command granules
   GHParams p;
   const float* depth; const float4* points; const float4* normals;
   int mode, activeBlocks;
-  int toHost;                 // few workgroups: each writes its stamped partial record straight to pinned host memory, the host adds them
-  unsigned int seq;
+  int toHost;                 // few workgroups: each sends its record straight to pinned host memory, the host adds them
+  unsigned int session;       // granule kCommandWords - 1; with the tag kSessionExit it tells session `session` to leave
 };
 constexpr int kCommandWords = (int)(sizeof(GHCommand) / 4);
-static_assert(sizeof(GHCommand) % 4 == 0, "copied word by word");
-struct GHResult { double sums[kGHValues]; int count; volatile unsigned int seq; volatile unsigned int exited; unsigned long long stamps[4]; };   // device -> host (stamps: measurement builds)
+static_assert(sizeof(GHCommand) % 4 == 0 && kCommandWords <= 64, "one granule per lane of the polling wave");
+constexpr int kExitGranule = kCommandWords - 1;
+struct GHResult { GHBlockRecord answer; volatile unsigned int exited; unsigned long long stamps[6]; };   // device -> host (stamps: measurement builds)
 
-__global__ void __launch_bounds__(kGHThreads) gh_session_kernel(const unsigned int* __restrict__ hostCmd, unsigned int* __restrict__ devCmd,
-                                                                unsigned long long* __restrict__ devSeq, double* __restrict__ partial,
-                                                                int* __restrict__ partialCount, unsigned int* __restrict__ done,
-                                                                GHResult* __restrict__ hostRes, GHBlockRecord* __restrict__ hostRec, unsigned int session, unsigned int firstSeq, int direct) {
+__global__ void __launch_bounds__(kGHThreads) gh_session_kernel(const unsigned long long* __restrict__ hostCmd, unsigned long long* __restrict__ devCmd,
+                                                                double* __restrict__ partial, int* __restrict__ partialCount, unsigned int* __restrict__ done,
+                                                                GHResult* __restrict__ hostRes, GHBlockRecord* __restrict__ hostRec, unsigned int session, unsigned int firstSeq,
+                                                                unsigned int arrived, int direct) {
   __shared__ __attribute__((aligned(16))) unsigned int cmdWords[kCommandWords];
   __shared__ unsigned int nextSeq;
   __shared__ int lastArriver;
@@ -330,63 +368,47 @@ __global__ void __launch_bounds__(kGHThreads) gh_session_kernel(const unsigned i
   __shared__ int ldsCount[kGHWaves];
   __shared__ double gathered[kGHGroups][kGHValues + 1];          // the last arriver's copy of every partial (+ count)
   const GHCommand& cmd = *(const GHCommand*)cmdWords;
-  const unsigned int seqWord = (unsigned int)(offsetof(GHCommand, seq) / 4);
-  unsigned int last = firstSeq - 1u;
+  unsigned int expected = firstSeq;
   unsigned long long idleSince = __builtin_amdgcn_s_memrealtime();
   for (;;) {
-    // ---- wait for the next command ----
-    if (threadIdx.x == 0) {
+    // ---- wait for the next command: lane i of the first wave watches granule i ----
+    // `direct`: the granules lie in fine-grained DEVICE memory that the host writes through the PCIe BAR and every workgroup reads
+    // there; otherwise they lie in pinned HOST memory, workgroup 0 fetches them over PCIe and republishes them in device memory.
+    // Everything that crosses workgroups or the PCIe link travels in relaxed atomic accesses of agent / system scope, which bypass
+    // the non-coherent caches one granule at a time.  Agent- or system-scope FENCES would write back / invalidate the whole L2 of
+    // the XCD on every evaluation, and the depth and map tiles the evaluations re-read live there (measured: 40 us per evaluation).
+    if (threadIdx.x < 64) {
+      const int lane = threadIdx.x;
+      const bool fromHost = blockIdx.x == 0 || direct;
+      const unsigned long long limit = (blockIdx.x == 0) ? kSessionIdleTicks : 4 * kSessionIdleTicks;
       unsigned int s;
-      if (blockIdx.x == 0 || direct) {
-        // `direct`: the command block lies in fine-grained DEVICE memory that the host writes through the PCIe BAR, every workgroup
-        // reads it there; otherwise it lies in pinned HOST memory, workgroup 0 fetches it over PCIe and hands it on
-        const unsigned long long limit = (blockIdx.x == 0) ? kSessionIdleTicks : 4 * kSessionIdleTicks;
-        for (;;) {
-          s = __hip_atomic_load(hostCmd + seqWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          if (s != last) break;
-          if (__builtin_amdgcn_s_memrealtime() - idleSince > limit) { s = kSessionExit; break; }
-          __builtin_amdgcn_s_sleep(8);
+      for (;;) {
+        unsigned long long v = 0;
+        if (lane < kCommandWords)
+          v = fromHost ? __hip_atomic_load(hostCmd + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : __hip_atomic_load(devCmd + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int tag = (unsigned int)(v >> 32);
+        if (__all(lane >= kCommandWords || tag == expected)) {
+          if (lane < kCommandWords) {
+            cmdWords[lane] = (unsigned int)v;
+            if (!direct && blockIdx.x == 0) __hip_atomic_store(devCmd + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          s = expected;
+          break;
         }
-      } else {
-        for (;;) {
-          const unsigned long long v = __hip_atomic_load(devSeq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          s = (unsigned int)v;
-          if ((unsigned int)(v >> 32) == session && s != last) break;
-          if (__builtin_amdgcn_s_memrealtime() - idleSince > 4 * kSessionIdleTicks) { s = kSessionExit; break; }
-          __builtin_amdgcn_s_sleep(2);
+        const bool leave = __any(lane == kExitGranule && tag == kSessionExit && (unsigned int)v == session) || (__builtin_amdgcn_s_memrealtime() - idleSince > limit);
+        if (leave) {
+          if (!direct && blockIdx.x == 0 && lane == kExitGranule) __hip_atomic_store(devCmd + lane, ((unsigned long long)kSessionExit << 32) | session, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          s = kSessionExit;
+          break;
         }
+        __builtin_amdgcn_s_sleep(4);
       }
-      nextSeq = s;
+      if (lane == 0) nextSeq = s;
     }
     __syncthreads();
     const unsigned int s = nextSeq;
-    ITM_TT(if (blockIdx.x == 0 && threadIdx.x == 0 && s != kSessionExit) __hip_atomic_store(&hostRes->stamps[0], __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);)
-    // Everything that crosses workgroups or the PCIe link below travels in relaxed atomic accesses of agent / system scope, which
-    // bypass the non-coherent caches one word at a time; ordering needs no more than "my own accesses have completed" (workgroup
-    // fence = s_waitcnt) and barriers.  Agent- or system-scope FENCES would write back / invalidate the whole L2 of the XCD on
-    // every evaluation, and the depth and map tiles the evaluations re-read live there (measured: 40 us per evaluation with them).
-    if (s != kSessionExit) {
-      if (direct) {
-        if (threadIdx.x < kCommandWords) cmdWords[threadIdx.x] = __hip_atomic_load(hostCmd + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __syncthreads();
-      } else if (blockIdx.x == 0) {
-        // the command itself: read after its sequence number, handed on in device memory, then the number
-        if (threadIdx.x < kCommandWords) {
-          const unsigned int w = __hip_atomic_load(hostCmd + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          cmdWords[threadIdx.x] = w;
-          __hip_atomic_store(devCmd + threadIdx.x, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(devSeq, ((unsigned long long)session << 32) | s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        if (threadIdx.x < kCommandWords) cmdWords[threadIdx.x] = __hip_atomic_load(devCmd + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-      }
-    } else if (!direct && blockIdx.x == 0 && threadIdx.x == 0) {
-      __hip_atomic_store(devSeq, ((unsigned long long)session << 32) | kSessionExit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     if (s == kSessionExit) break;
+    ITM_TT(const unsigned long long ttSeen = __builtin_amdgcn_s_memrealtime(); unsigned long long ttAcc = 0, ttRed = 0; unsigned long long ttIn[2] = {0, 0};)
     // ---- this workgroup's share ----
     const int nBlocks = cmd.activeBlocks;
     double mine = 0.0; int cnt = 0;
@@ -395,18 +417,18 @@ __global__ void __launch_bounds__(kGHThreads) gh_session_kernel(const unsigned i
 #pragma unroll
       for (int i = 0; i < kGHValues; ++i) acc[i] = 0.0;
       int valid = 0;
-      if (cmd.mode == 1) { gh_accumulate<1>(cmd.depth, cmd.points, cmd.normals, cmd.p, blockIdx.x, nBlocks, acc, valid); gh_block_reduce<1>(acc, valid, lds, ldsCount, mine, cnt); }
-      else if (cmd.mode == 2) { gh_accumulate<2>(cmd.depth, cmd.points, cmd.normals, cmd.p, blockIdx.x, nBlocks, acc, valid); gh_block_reduce<2>(acc, valid, lds, ldsCount, mine, cnt); }
-      else { gh_accumulate<3>(cmd.depth, cmd.points, cmd.normals, cmd.p, blockIdx.x, nBlocks, acc, valid); gh_block_reduce<3>(acc, valid, lds, ldsCount, mine, cnt); }
+      if (cmd.mode == 1) { gh_accumulate<1>(cmd.depth, cmd.points, cmd.normals, cmd.p, blockIdx.x, nBlocks, acc, valid ITM_TT(, ttIn)); ITM_TT(ttAcc = __builtin_amdgcn_s_memrealtime();) gh_block_reduce<1>(acc, valid, lds, ldsCount, mine, cnt); }
+      else if (cmd.mode == 2) { gh_accumulate<2>(cmd.depth, cmd.points, cmd.normals, cmd.p, blockIdx.x, nBlocks, acc, valid ITM_TT(, ttIn)); ITM_TT(ttAcc = __builtin_amdgcn_s_memrealtime();) gh_block_reduce<2>(acc, valid, lds, ldsCount, mine, cnt); }
+      else { gh_accumulate<3>(cmd.depth, cmd.points, cmd.normals, cmd.p, blockIdx.x, nBlocks, acc, valid ITM_TT(, ttIn)); ITM_TT(ttAcc = __builtin_amdgcn_s_memrealtime();) gh_block_reduce<3>(acc, valid, lds, ldsCount, mine, cnt); }
+      ITM_TT(ttRed = __builtin_amdgcn_s_memrealtime();)
       if (cmd.toHost) {
-        // a coarse level: the record goes to the host as it is (values, then -- once they have left -- the stamp); no arrival counter,
-        // no gathering workgroup, no second trip through device memory
-        GHBlockRecord* r = hostRec + blockIdx.x;
-        if (threadIdx.x < kGHValues) __hip_atomic_store(&r->sums[threadIdx.x], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (threadIdx.x == 0) __hip_atomic_store(&r->count, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store((unsigned int*)&r->seq, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // a coarse level: the record goes to the host as it is; no arrival counter, no gathering workgroup, no second trip
+        // through device memory
+        send_record<__HIP_MEMORY_SCOPE_SYSTEM>(hostRec + blockIdx.x, mine, cnt, s);
+        ITM_TT(if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                 __hip_atomic_store(&hostRes->stamps[0], ttSeen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(&hostRes->stamps[1], ttAcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                 __hip_atomic_store(&hostRes->stamps[2], ttRed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(&hostRes->stamps[3], now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                 __hip_atomic_store(&hostRes->stamps[4], ttIn[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(&hostRes->stamps[5], ttIn[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); })
       } else {
         if (threadIdx.x < kGHValues) __hip_atomic_store(partial + (size_t)blockIdx.x * kGHValues + threadIdx.x, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (threadIdx.x == 0) __hip_atomic_store(partialCount + blockIdx.x, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -414,11 +436,13 @@ __global__ void __launch_bounds__(kGHThreads) gh_session_kernel(const unsigned i
       }
     }
     __syncthreads();
-    // only the workgroups that had tiles arrive (6 of 256 on the 40x30 level: 250 fewer read-modify-writes of one word)
-    if (threadIdx.x == 0) lastArriver = !cmd.toHost && ((int)blockIdx.x < nBlocks) && __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)nBlocks - 1u;
+    // only the workgroups that had tiles arrive; the counter is never reset: every workgroup sees every command and so knows how
+    // many arrivals (`arrived`, continued from the handle's earlier sessions) preceded this evaluation
+    if (threadIdx.x == 0) lastArriver = !cmd.toHost && ((int)blockIdx.x < nBlocks) && __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == arrived + (unsigned int)nBlocks - 1u;
+    if (!cmd.toHost) arrived += (unsigned int)nBlocks;
     __syncthreads();
     if (lastArriver) {
-      ITM_TT(if (threadIdx.x == 0) __hip_atomic_store(&hostRes->stamps[1], __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);)
+      ITM_TT(const unsigned long long ttLast = __builtin_amdgcn_s_memrealtime();)
       // ---- every partial is in device memory: add them in block order, answer the host ----
       for (int b = threadIdx.x; b < nBlocks; b += kGHThreads) {
         // all loads of the record first (independent destinations: in flight together), then the copies into LDS
@@ -431,9 +455,9 @@ __global__ void __launch_bounds__(kGHThreads) gh_session_kernel(const unsigned i
         gathered[b][kGHValues] = (double)recCount;
       }
       __syncthreads();
+      double sum = 0.0;
       if (threadIdx.x <= kGHValues) {
         // block order (the host's order); eight LDS reads in flight per step, the additions stay a chain
-        double sum = 0.0;
         int b = 0;
         for (; b + 8 <= nBlocks; b += 8) {
           double v8[8];
@@ -443,16 +467,16 @@ __global__ void __launch_bounds__(kGHThreads) gh_session_kernel(const unsigned i
           for (int k = 0; k < 8; ++k) sum += v8[k];
         }
         for (; b < nBlocks; ++b) sum += gathered[b][threadIdx.x];
-        if (threadIdx.x < kGHValues) __hip_atomic_store(&hostRes->sums[threadIdx.x], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        else __hip_atomic_store(&hostRes->count, (int)sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // counts are small integers: exact in double
       }
-      if (threadIdx.x == 0) __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __syncthreads();
-      ITM_TT(if (threadIdx.x == 0) __hip_atomic_store(&hostRes->stamps[2], __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);)
-      if (threadIdx.x == 0) __hip_atomic_store((unsigned int*)&hostRes->seq, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      const int total = (int)__shfl(sum, kGHValues, 64);         // counts are small integers: exact in double
+      send_record<__HIP_MEMORY_SCOPE_SYSTEM>(&hostRes->answer, sum, total, s);
+      // (this workgroup's own times: command seen, tiles accumulated, last arrival known, sums added)
+      ITM_TT(if (threadIdx.x == 0) { const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+               __hip_atomic_store(&hostRes->stamps[0], ttSeen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(&hostRes->stamps[1], ttAcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+               __hip_atomic_store(&hostRes->stamps[2], ttLast, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(&hostRes->stamps[3], now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                 __hip_atomic_store(&hostRes->stamps[4], ttIn[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(&hostRes->stamps[5], ttIn[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); })
     }
-    last = s;
+    expected = next_seq(s);
     idleSince = __builtin_amdgcn_s_memrealtime();
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store((unsigned int*)&hostRes->exited, session, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -476,9 +500,10 @@ struct itm_tracker {
   std::vector<float*> pyramid; std::vector<size_t> pyramidBytes;
   double pollTimeoutSeconds = 5.0;
   // evaluation session (gh_session_kernel)
-  itm::GHCommand* cmd = nullptr; unsigned int* cmdDev = nullptr;     // pinned command + its device address
+  unsigned long long* cmd = nullptr; unsigned long long* cmdDev = nullptr;   // command granules (BAR-mapped device memory or pinned host memory) + their device address
   itm::GHResult* res = nullptr; itm::GHResult* resDev = nullptr;     // pinned result + its device address
-  unsigned int* devCmd = nullptr; unsigned long long* devSeq = nullptr; unsigned int* done = nullptr;   // device memory
+  unsigned long long* devCmd = nullptr; unsigned int* done = nullptr;   // device memory: republished command granules, arrival counter
+  unsigned int arrived = 0;      // arrivals counted by `done` so far (the counter is never reset between evaluations)
   unsigned int session = 0;
   bool sessionOpen = false;
   bool cmdDirect = false;        // the command block is device memory the host writes through the BAR
@@ -486,18 +511,23 @@ struct itm_tracker {
 
 namespace itm {
 
+static void write_exit(itm_tracker* t) {       // tells session t->session to leave: the exit tag with the session's number as payload
+  __atomic_thread_fence(__ATOMIC_RELEASE);
+  *(volatile unsigned long long*)&t->cmd[kExitGranule] = ((unsigned long long)kSessionExit << 32) | t->session;
+  __builtin_ia32_sfence();
+}
+
 static void tracker_release(itm_tracker* t) {
   if (t->cmd && t->sessionOpen) {                 // a call that failed half way: tell its resident kernel to leave before the buffers go
-    *(volatile unsigned int*)&t->cmd->seq = 0xffffffffu;
-    __builtin_ia32_sfence();
+    write_exit(t);
     t->sessionOpen = false;
   }
   (void)hipFree(t->partial); (void)hipFree(t->partialCount);
   if (t->rec) (void)hipHostFree(t->rec);
   if (t->cmd) { if (t->cmdDirect) (void)hipFree(t->cmd); else (void)hipHostFree(t->cmd); }
   if (t->res) (void)hipHostFree(t->res);
-  (void)hipFree(t->devCmd); (void)hipFree(t->devSeq); (void)hipFree(t->done);
-  t->cmd = nullptr; t->cmdDev = nullptr; t->res = nullptr; t->resDev = nullptr; t->devCmd = nullptr; t->devSeq = nullptr; t->done = nullptr;
+  (void)hipFree(t->devCmd); (void)hipFree(t->done);
+  t->cmd = nullptr; t->cmdDev = nullptr; t->res = nullptr; t->resDev = nullptr; t->devCmd = nullptr; t->done = nullptr;
   t->sessionOpen = false;
   for (float* q : t->pyramid) (void)hipFree(q);
   t->partial = nullptr; t->partialCount = nullptr; t->rec = nullptr; t->recDev = nullptr; t->blocks = 0;
@@ -538,6 +568,33 @@ static itm_tracker* thread_tracker() {
   return mine;
 }
 
+// Adds one tagged record to `sums` / `count` once every granule carries `tag`.  `slow(granule)` is called every 1024 polls of a
+// granule that has not arrived and decides whether the wait goes on (ITM_OK) or ends with an error code.
+template <class Slow>
+static inline int read_record(const GHBlockRecord* r, unsigned int tag, double* sums, int* count, Slow&& slow) {
+  unsigned int w[kRecordWords];
+  for (int i = 0; i < kRecordWords; ++i) {
+    const volatile unsigned long long* g = &r->g[i];
+    unsigned long long v;
+    unsigned spins = 0;
+    while ((unsigned int)((v = *g) >> 32) != tag) {
+      __builtin_ia32_pause();
+      if ((++spins & 0x3ffu) != 0u) continue;
+      const int rc = slow(g);
+      if (rc) return rc;
+    }
+    w[i] = (unsigned int)v;
+  }
+  for (int i = 0; i < kGHValues; ++i) {
+    const unsigned long long bits = (unsigned long long)w[2 * i] | ((unsigned long long)w[2 * i + 1] << 32);
+    double d;
+    memcpy(&d, &bits, 8);
+    sums[i] += d;
+  }
+  *count += (int)w[2 * kGHValues];
+  return ITM_OK;
+}
+
 static int compute_g_and_h(itm_tracker* trk, const float* depth, int w, int h, const float* viewIntr, const float* pointsMap, const float* normalsMap,
                            int sceneW, int sceneH, const float* sceneIntr, const float* approxInvPose, const float* scenePose,
                            float distThresh, int iterationType, itm_tracker_gh* out, hipStream_t st) {
@@ -558,40 +615,35 @@ static int compute_g_and_h(itm_tracker* trk, const float* depth, int w, int h, c
   const float4* pm = (const float4*)pointsMap; const float4* nm = (const float4*)normalsMap;
   const int np = (iterationType == ITM_TRACKER_ITERATION_BOTH) ? 6 : 3;
   const int nh = np * (np + 1) / 2;
-  const unsigned int seq = ++trk->seq;
+  const unsigned int seq = trk->seq = next_seq(trk->seq);
   if (iterationType == 1) gh_partial_kernel<1><<<grid, kGHThreads, 0, st>>>(depth, pm, nm, trk->partial, trk->partialCount, p, trk->recDev, seq);
   else if (iterationType == 2) gh_partial_kernel<2><<<grid, kGHThreads, 0, st>>>(depth, pm, nm, trk->partial, trk->partialCount, p, trk->recDev, seq);
   else gh_partial_kernel<3><<<grid, kGHThreads, 0, st>>>(depth, pm, nm, trk->partial, trk->partialCount, p, trk->recDev, seq);
   ITM_LAUNCH_CHECK();
-  // Wait for every workgroup's stamped record and add them in block order (fixed order => deterministic, in double).  The
-  // poll is bounded in TIME: after 20 ms without the stamp the stream is queried between polls -- a drained stream without
-  // the stamp, a device error, or pollTimeoutSeconds without progress end the call with ITM_ERR_DEVICE instead of
-  // stalling the host on a kernel that will never finish.
+  // Wait for every workgroup's tagged record and add them in block order (fixed order => deterministic, in double).  The
+  // poll is bounded in TIME: after 20 ms without a granule the stream is queried between polls -- a drained stream without
+  // it, a device error, or pollTimeoutSeconds without progress end the call with ITM_ERR_DEVICE instead of stalling the
+  // host on a kernel that will never finish.
   double sums[kGHValues];
   for (int i = 0; i < kGHValues; ++i) sums[i] = 0.0;
   int n = 0;
   using clock = std::chrono::steady_clock;
   clock::time_point t0; bool timing = false;
   for (size_t b = 0; b < blocks; ++b) {
-    const GHBlockRecord* r = trk->rec + b;
-    unsigned spins = 0;
-    while (r->seq != seq) {
-      __builtin_ia32_pause();
-      if ((++spins & 0x3ffu) != 0u) continue;
-      if (!timing) { t0 = clock::now(); timing = true; continue; }
+    rc = read_record(trk->rec + b, seq, sums, &n, [&](const volatile unsigned long long* g) -> int {
+      if (!timing) { t0 = clock::now(); timing = true; return ITM_OK; }
       const double waited = std::chrono::duration<double>(clock::now() - t0).count();
-      if (waited < 0.02) continue;
+      if (waited < 0.02) return ITM_OK;
       const hipError_t q = hipStreamQuery(st);
       if (q == hipSuccess) {
-        if (r->seq == seq) break;
+        if ((unsigned int)(*g >> 32) == seq) return ITM_OK;
         return set_error(ITM_ERR_DEVICE, "tracker reduction: the stream drained without delivering every record");
       }
       if (q != hipErrorNotReady) return hip_fail(q, "tracker reduction", __FILE__, __LINE__);
       if (waited > trk->pollTimeoutSeconds) return set_error(ITM_ERR_DEVICE, "tracker reduction timed out");
-    }
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    for (int i = 0; i < kGHValues; ++i) sums[i] += r->sums[i];
-    n += r->count;
+      return ITM_OK;
+    });
+    if (rc) return rc;
   }
   for (int r = 0, k = 0; r < np; ++r)
     for (int c = 0; c <= r; ++c, ++k) out->hessian[r + c * 6] = (float)sums[7 + k];
@@ -611,44 +663,48 @@ static int session_reserve(itm_tracker* t) {
   int rc = tracker_reserve(t, kGHGroups);
   if (rc) return rc;
   if (t->cmd) return ITM_OK;
-  // the command block: fine-grained device memory written by the host through the PCIe BAR where the device has a large BAR (every
-  // workgroup then polls local memory), pinned host memory fetched by workgroup 0 otherwise
+  // the command granules: fine-grained device memory written by the host through the PCIe BAR where the device has a large BAR (every
+  // workgroup then polls local memory), pinned host memory fetched by workgroup 0 otherwise.  All zero = no command (0 is never a tag).
+  const size_t cmdBytes = 64 * sizeof(unsigned long long);
   hipError_t e = hipSuccess;
   int dev = 0, largeBar = 0;
   (void)hipGetDevice(&dev);
   if (!g_debug_tracker_host_command && hipDeviceGetAttribute(&largeBar, hipDeviceAttributeIsLargeBar, dev) == hipSuccess && largeBar &&
-      hipExtMallocWithFlags((void**)&t->cmd, sizeof(GHCommand), hipDeviceMallocFinegrained) == hipSuccess) {
+      hipExtMallocWithFlags((void**)&t->cmd, cmdBytes, hipDeviceMallocFinegrained) == hipSuccess) {
     t->cmdDirect = true;
-    t->cmdDev = (unsigned int*)t->cmd;
-    GHCommand zero; memset(&zero, 0, sizeof zero); zero.seq = kSessionExit;
-    e = hipMemcpy(t->cmd, &zero, sizeof zero, hipMemcpyHostToDevice);
+    t->cmdDev = t->cmd;
+    e = hipMemset(t->cmd, 0, cmdBytes);
   } else {
     (void)hipGetLastError();
     t->cmdDirect = false;
-    e = hipHostMalloc((void**)&t->cmd, sizeof(GHCommand), hipHostMallocMapped | hipHostMallocCoherent);
-    if (e == hipSuccess) { memset(t->cmd, 0, sizeof(GHCommand)); t->cmd->seq = kSessionExit; e = hipHostGetDevicePointer((void**)&t->cmdDev, t->cmd, 0); }
+    e = hipHostMalloc((void**)&t->cmd, cmdBytes, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) { memset(t->cmd, 0, cmdBytes); e = hipHostGetDevicePointer((void**)&t->cmdDev, t->cmd, 0); }
   }
   if (e == hipSuccess) e = hipHostMalloc((void**)&t->res, sizeof(GHResult), hipHostMallocMapped | hipHostMallocCoherent);
   if (e == hipSuccess) { memset(t->res, 0, sizeof(GHResult)); e = hipHostGetDevicePointer((void**)&t->resDev, t->res, 0); }
-  if (e == hipSuccess) e = hipMalloc((void**)&t->devCmd, sizeof(GHCommand));
-  if (e == hipSuccess) e = hipMalloc((void**)&t->devSeq, 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&t->devCmd, cmdBytes);
   if (e == hipSuccess) e = hipMalloc((void**)&t->done, 4);
-  if (e == hipSuccess) e = hipMemset(t->devSeq, 0, 8);
+  if (e == hipSuccess) e = hipMemset(t->devCmd, 0, cmdBytes);
   if (e == hipSuccess) e = hipMemset(t->done, 0, 4);
   if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e != hipSuccess) {
     if (t->cmd) { if (t->cmdDirect) (void)hipFree(t->cmd); else (void)hipHostFree(t->cmd); }
     if (t->res) (void)hipHostFree(t->res);
-    (void)hipFree(t->devCmd); (void)hipFree(t->devSeq); (void)hipFree(t->done);
-    t->cmd = nullptr; t->res = nullptr; t->devCmd = nullptr; t->devSeq = nullptr; t->done = nullptr;
+    (void)hipFree(t->devCmd); (void)hipFree(t->done);
+    t->cmd = nullptr; t->res = nullptr; t->devCmd = nullptr; t->done = nullptr;
     return hip_fail(e, "tracker session buffers", __FILE__, __LINE__);
   }
+  t->arrived = 0;
   return ITM_OK;
 }
 
-static int session_launch(itm_tracker* t, unsigned int firstSeq, hipStream_t st) {
+// `afterExit`: the previous session of this handle left on its own (idle limit) while a command was pending; workgroups of it may
+// have counted arrivals for that command before they left, so the counter starts again from zero (in stream order: after them)
+static int session_launch(itm_tracker* t, unsigned int firstSeq, bool afterExit, hipStream_t st) {
+  if (afterExit) { ITM_HIP(hipMemsetAsync(t->done, 0, 4, st)); t->arrived = 0; }
   ++t->session;
-  gh_session_kernel<<<kGHGroups, kGHThreads, 0, st>>>(t->cmdDev, t->devCmd, t->devSeq, t->partial, t->partialCount, t->done, t->resDev, t->recDev, t->session, firstSeq, t->cmdDirect ? 1 : 0);
+  gh_session_kernel<<<kGHGroups, kGHThreads, 0, st>>>(t->cmdDev, t->devCmd, t->partial, t->partialCount, t->done, t->resDev, t->recDev, t->session, firstSeq,
+                                                      t->arrived, t->cmdDirect ? 1 : 0);
   ITM_LAUNCH_CHECK();
   t->sessionOpen = true;
   return ITM_OK;
@@ -657,10 +713,19 @@ static int session_launch(itm_tracker* t, unsigned int firstSeq, hipStream_t st)
 // tells the resident kernel to leave (it does so within microseconds; nothing waits for it: later work on the stream queues behind it)
 static void session_close(itm_tracker* t) {
   if (!t->sessionOpen) return;
-  __atomic_thread_fence(__ATOMIC_RELEASE);
-  *(volatile unsigned int*)&t->cmd->seq = kSessionExit;
-  __builtin_ia32_sfence();
+  write_exit(t);
   t->sessionOpen = false;
+}
+
+// the command as tagged granules; the last granule's payload is the session the command is for
+static void write_command(itm_tracker* t, const GHCommand& c, unsigned int seq) {
+  unsigned int w[kCommandWords];
+  memcpy(w, &c, sizeof c);
+  const unsigned long long tag = (unsigned long long)seq << 32;
+  volatile unsigned long long* g = t->cmd;
+  __atomic_thread_fence(__ATOMIC_RELEASE);
+  for (int i = 0; i < 64; ++i) g[i] = tag | (i < kCommandWords ? w[i] : 0u);     // 512 bytes: whole lines
+  __builtin_ia32_sfence();                   // the granules may sit in a write-combining buffer (BAR memory): send them now
 }
 
 // one evaluation through the session: same arguments and the same sums as compute_g_and_h
@@ -674,10 +739,10 @@ static int session_g_and_h(itm_tracker* trk, const float* depth, int w, int h, c
   if (rc) return rc;
   const int tiles = ((w + 15) / 16) * ((h + kGHTileH - 1) / kGHTileH);
   const int rounds = (tiles + kGHGroups - 1) / kGHGroups;
+  using clock = std::chrono::steady_clock;
   if (!trk->sessionOpen && trk->session != 0u) {
-    // the previous session was told to leave; make sure it has before the command word changes again (it polls every
-    // microsecond, so this is a formality -- but two resident kernels must never share the arrival counter)
-    using clock = std::chrono::steady_clock;
+    // the previous session was told to leave; make sure it has before its exit granule is overwritten (it polls every
+    // microsecond, so this is a formality -- but a session that missed its exit would wait out its idle limit)
     const clock::time_point t0 = clock::now();
     unsigned spins = 0;
     while (trk->res->exited != trk->session) {
@@ -687,72 +752,56 @@ static int session_g_and_h(itm_tracker* trk, const float* depth, int w, int h, c
       if (std::chrono::duration<double>(clock::now() - t0).count() > trk->pollTimeoutSeconds) return set_error(ITM_ERR_DEVICE, "tracker session did not end");
     }
   }
-  GHCommand* c = trk->cmd;
-  memcpy(c->p.approxInvPose.m, approxInvPose, 64); memcpy(c->p.scenePose.m, scenePose, 64);
-  c->p.vfx = viewIntr[0]; c->p.vfy = viewIntr[1]; c->p.vcx = viewIntr[2]; c->p.vcy = viewIntr[3];
-  c->p.sfx = sceneIntr[0]; c->p.sfy = sceneIntr[1]; c->p.scx = sceneIntr[2]; c->p.scy = sceneIntr[3];
-  c->p.distThresh = distThresh; c->p.w = w; c->p.h = h; c->p.sceneW = sceneW; c->p.sceneH = sceneH;
-  c->depth = depth; c->points = (const float4*)pointsMap; c->normals = (const float4*)normalsMap;
-  c->mode = iterationType; c->activeBlocks = (tiles + rounds - 1) / rounds;       // the grid of the per-launch path: same tiles per block, same sums
-  const int nBlocks = c->activeBlocks;
+  ITM_TT(const auto tt0 = clock::now();)
+  GHCommand c;
+  memset(&c, 0, sizeof c);
+  memcpy(c.p.approxInvPose.m, approxInvPose, 64); memcpy(c.p.scenePose.m, scenePose, 64);
+  c.p.vfx = viewIntr[0]; c.p.vfy = viewIntr[1]; c.p.vcx = viewIntr[2]; c.p.vcy = viewIntr[3];
+  c.p.sfx = sceneIntr[0]; c.p.sfy = sceneIntr[1]; c.p.scx = sceneIntr[2]; c.p.scy = sceneIntr[3];
+  c.p.distThresh = distThresh; c.p.w = w; c.p.h = h; c.p.sceneW = sceneW; c.p.sceneH = sceneH;
+  c.depth = depth; c.points = (const float4*)pointsMap; c.normals = (const float4*)normalsMap;
+  c.mode = iterationType; c.activeBlocks = (tiles + rounds - 1) / rounds;       // the grid of the per-launch path: same tiles per block, same sums
+  const int nBlocks = c.activeBlocks;
   const bool toHost = nBlocks <= kSessionToHostBlocks;
-  c->toHost = toHost ? 1 : 0;
-  unsigned int seq = ++trk->seq;
-  if (seq == kSessionExit || seq == 0u) seq = trk->seq = 1u;
-  ITM_TT(const auto ttA = std::chrono::steady_clock::now();)
-  __atomic_thread_fence(__ATOMIC_RELEASE);
-  __builtin_ia32_sfence();                   // the block may be write-combined BAR memory: its body must leave the core before the number
-  *(volatile unsigned int*)&c->seq = seq;
-  __builtin_ia32_sfence();
-  if (!trk->sessionOpen && (rc = session_launch(trk, seq, st))) return rc;
-  ITM_TT(const auto ttB = std::chrono::steady_clock::now();)
-  // wait for the stamped result; a session that has left without answering (idle limit hit while this thread was away) is replaced
-  using clock = std::chrono::steady_clock;
+  c.toHost = toHost ? 1 : 0;
+  c.session = trk->sessionOpen ? trk->session : trk->session + 1u;
+  const unsigned int seq = trk->seq = next_seq(trk->seq);
+  write_command(trk, c, seq);
+  ITM_TT(const auto ttA = clock::now();)
+  if (!trk->sessionOpen && (rc = session_launch(trk, seq, false, st))) return rc;
+  ITM_TT(const auto ttB = clock::now();)
+  // Wait for the tagged answer: on coarse levels one record per workgroup, added here in block order (the order of the device-side
+  // gather and of the per-launch path), otherwise the one record of the gathering workgroup.  A session that has left without
+  // answering (idle limit hit while this thread was away) is replaced; the wait is bounded in time like the per-launch path's.
   clock::time_point t0; bool timing = false;
-  unsigned spins = 0;
-  const GHResult* r = trk->res;
-  // coarse levels answer with one stamped record per workgroup: the last record's stamp is waited for here like the result's, the
-  // others right after (they are there or about to be)
-  const volatile unsigned int* answer = toHost ? &trk->rec[nBlocks - 1].seq : &r->seq;
-  while (*answer != seq) {
-    __builtin_ia32_pause();
-    if ((++spins & 0xffu) != 0u) continue;
-    if (r->exited == trk->session && *answer != seq) {
-      if ((rc = session_launch(trk, seq, st))) return rc;
-      continue;
-    }
-    if ((spins & 0x3fffu) != 0u) continue;
-    if (!timing) { t0 = clock::now(); timing = true; continue; }
+  auto slow = [&](const volatile unsigned long long* g) -> int {
+    if (trk->res->exited == trk->session && (unsigned int)(*g >> 32) != seq) return session_launch(trk, seq, true, st);
+    if (!timing) { t0 = clock::now(); timing = true; return ITM_OK; }
     const double waited = std::chrono::duration<double>(clock::now() - t0).count();
-    if (waited < 0.02) continue;
+    if (waited < 0.02) return ITM_OK;
     const hipError_t q = hipStreamQuery(st);
     if (q != hipSuccess && q != hipErrorNotReady) { trk->sessionOpen = false; return hip_fail(q, "tracker session", __FILE__, __LINE__); }
     if (waited > trk->pollTimeoutSeconds) { session_close(trk); return set_error(ITM_ERR_DEVICE, "tracker session timed out"); }
-  }
-  double hostSums[kGHValues];
-  int hostCount = 0;
+    return ITM_OK;
+  };
+  double sums[kGHValues];
+  for (int i = 0; i < kGHValues; ++i) sums[i] = 0.0;
+  int n = 0;
   if (toHost) {
-    for (int i = 0; i < kGHValues; ++i) hostSums[i] = 0.0;
-    for (int b = 0; b < nBlocks; ++b) {                          // block order, as the device-side gather and the per-launch path
-      const GHBlockRecord* q = trk->rec + b;
-      const clock::time_point w0 = clock::now();
-      while (q->seq != seq) {
-        __builtin_ia32_pause();
-        if (std::chrono::duration<double>(clock::now() - w0).count() > trk->pollTimeoutSeconds) { session_close(trk); return set_error(ITM_ERR_DEVICE, "tracker session: a record did not arrive"); }
-      }
-      __atomic_thread_fence(__ATOMIC_ACQUIRE);
-      for (int i = 0; i < kGHValues; ++i) hostSums[i] += q->sums[i];
-      hostCount += q->count;
-    }
+    for (int b = 0; b < nBlocks && !rc; ++b) rc = read_record(trk->rec + b, seq, sums, &n, slow);
+  } else {
+    rc = read_record(&trk->res->answer, seq, sums, &n, slow);
+    if (!rc) trk->arrived += (unsigned int)nBlocks;
   }
+  if (rc) return rc;
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
-  ITM_TT({ const auto ttC = std::chrono::steady_clock::now();
-           fprintf(stderr, "[tracker trace] %dx%d mode %d: launch %.1f us, answer after %.1f us; on the device: command seen -> last arrival %.2f us, -> result written %.2f us\n", w, h, iterationType,
-                   std::chrono::duration<double, std::micro>(ttB - ttA).count(), std::chrono::duration<double, std::micro>(ttC - ttB).count(),
-                   (double)(r->stamps[1] - r->stamps[0]) / 100.0, (double)(r->stamps[2] - r->stamps[0]) / 100.0); })
+  ITM_TT({ const auto ttC = clock::now();
+           const GHResult* r = trk->res;
+           fprintf(stderr, "[tracker trace] %dx%d mode %d: command %.2f us, launch %.1f us, answer after %.1f us; on the device, from the command seen: first depth %.2f, first taps %.2f, tiles accumulated %.2f, %s %.2f, record sent %.2f us\n", w, h, iterationType,
+                   std::chrono::duration<double, std::micro>(ttA - tt0).count(), std::chrono::duration<double, std::micro>(ttB - ttA).count(),
+                   std::chrono::duration<double, std::micro>(ttC - ttB).count(),
+                   (double)(r->stamps[4] - r->stamps[0]) / 100.0, (double)(r->stamps[5] - r->stamps[0]) / 100.0, (double)(r->stamps[1] - r->stamps[0]) / 100.0, toHost ? "reduced" : "last arrival", (double)(r->stamps[2] - r->stamps[0]) / 100.0, (double)(r->stamps[3] - r->stamps[0]) / 100.0); })
   const int np = (iterationType == ITM_TRACKER_ITERATION_BOTH) ? 6 : 3;
-  const double* sums = toHost ? hostSums : r->sums;
-  const int n = toHost ? hostCount : r->count;
   for (int a = 0, k = 0; a < np; ++a)
     for (int b = 0; b <= a; ++b, ++k) out->hessian[a + b * 6] = (float)sums[7 + k];
   for (int a = 0; a < np; ++a)
@@ -805,7 +854,9 @@ static int track_camera(itm_tracker* trk, const itm_tracker_config* cfg, const i
   int rc = tracker_reserve(trk, 1);
   if (rc) return rc;
   std::vector<DepthLevel> pyr;
+  ITM_TT(const auto tc0 = std::chrono::steady_clock::now();)
   if ((rc = build_pyramid(trk, view, levels, pyr, st))) return rc;
+  ITM_TT(const auto tc1 = std::chrono::steady_clock::now();)
   if (g_debug_tracker_launch_per_evaluation)
     return icp_track(cfg, view->M_d, M_d_out, [&](int level, int mode, const float invPose[16], float distThresh, itm_tracker_gh* e) {
       return compute_g_and_h(trk, pyr[level].depth, pyr[level].w, pyr[level].h, pyr[level].intr, pointsMap, normalsMap, view->w, view->h,
@@ -817,6 +868,8 @@ static int track_camera(itm_tracker* trk, const itm_tracker_config* cfg, const i
                            pyr[0].intr, invPose, scenePose, distThresh, mode, e, st);
   });
   session_close(trk);
+  ITM_TT(fprintf(stderr, "[tracker trace] call: pyramid launch %.1f us, evaluations %.1f us\n", std::chrono::duration<double, std::micro>(tc1 - tc0).count(),
+                 std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tc1).count());)
   return rc;
 }
 

@@ -18,7 +18,7 @@ from infinitam_amd import capi, synth  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 W, H = 640, 480
-be = itm.load()
+be = capi.Backend(os.environ["ITM_LIB"], "itm_") if os.environ.get("ITM_LIB") else itm.load()
 intr = synth.intrinsics_for(W, H)
 scene = be.create_scene(capi.VOXEL_S, capi.INDEX_HASH, capi.default_params(voxelSize=0.004), localBlockNum=0x40000)
 scene.reco.ResetScene()
