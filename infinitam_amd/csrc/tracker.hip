@@ -10,10 +10,10 @@
 //   ORUtils::Cholesky                  ORUtils/Cholesky.h
 //
 // Device part: one lane per depth pixel computes its residual row (A, b) with the reference's float
-// operations; the 1 + 6 + 21 sums and the valid count are reduced with wave shuffles, one partial per
-// workgroup, written to a stamped record in pinned host memory; the host adds the records in block order in double
-// precision (deterministic; the reference adds floats in raster order, so sums agree to float rounding, the count
-// exactly).  Host part: a damped Gauss-Newton iteration over SE(3) with the reference's accept / reject schedule, written
+// operations; the 1 + 6 + 21 sums and the valid count are reduced per wave with DPP row shifts, one partial per
+// workgroup, written as a record of tagged granules; the records are added in one fixed order (kSegBlocks) in double
+// precision wherever that happens (deterministic; the reference adds floats in raster order, so sums agree to float
+// rounding, the count exactly).  Host part: a damped Gauss-Newton iteration over SE(3) with the reference's accept / reject schedule, written
 // independently of the reference's code (double precision, LDL^T solve, exp/log projection: se3.h); the tracked pose
 // agrees with the reference's to 2e-5 (tests/test_tracker.py).
 #include <chrono>
@@ -88,6 +88,7 @@ struct GHParams {
   float sfx, sfy, scx, scy;   // scene intrinsics
   float distThresh;
   int w, h, sceneW, sceneH;
+  int tileH;                  // rows of a tile (gh_tiling)
 };
 
 constexpr int kGHValues = 1 + 6 + 21;   // f, nabla, packed lower-triangular hessian
@@ -101,6 +102,12 @@ constexpr int kRecordWords = 2 * kGHValues + 1;   // 28 doubles as two words eac
 struct GHBlockRecord { unsigned long long g[64]; };   // one per workgroup (pinned host memory) and the session's result; granule i = tag << 32 | word i
 static_assert(kRecordWords <= 64, "record granules");
 __host__ __device__ inline unsigned int next_seq(unsigned int s) { ++s; return (s == 0u || s == 0xffffffffu) ? 1u : s; }   // 0 and ~0 are never sequence numbers
+
+// ORDER OF THE ADDITIONS over the workgroups' records, the same wherever they are added (host: per-launch path and coarse levels
+// of a session; device: the gathering workgroup of a session), so that every path yields the same bits: records in segments of
+// kSegBlocks consecutive workgroups, each segment added up in block order, then the kSegs segment sums in segment order (an
+// empty segment contributes +0.0).  A single chain over 240 records was 2.5 us of dependent additions in the gathering workgroup.
+constexpr int kSegBlocks = 32;
 
 // thread i < kGHValues holds value i of the workgroup (`mine`); every thread holds `cnt`.  Lane i of the first wave stores granule i:
 // one store instruction over 512 contiguous bytes, which leaves the CU as whole 64-byte lines (granules written two per lane,
@@ -151,9 +158,21 @@ __device__ inline bool bilinear_holes(const float4* __restrict__ src, float px, 
 #define ITM_GH_WAVES 4           // waves per workgroup (measured per 640x480 evaluation: 4 waves 43 us, 8 waves 51 us, 16 waves 73 us)
 #endif
 constexpr int kGHGroups = ITM_GH_GROUPS;
+constexpr int kSegs = (kGHGroups + kSegBlocks - 1) / kSegBlocks;
 constexpr int kGHWaves = ITM_GH_WAVES;
+static_assert(kSegBlocks % kGHWaves == 0, "a gathering workgroup splits its segment evenly over its waves");
 constexpr int kGHThreads = 64 * kGHWaves;
-constexpr int kGHTileH = kGHThreads / 16;      // a tile is 16 pixels wide and kGHTileH tall
+constexpr int kGHTileH = kGHThreads / 16;      // a tile is 16 pixels wide and at most kGHTileH tall
+// Tiling of a w x h level: full tiles (one pixel per thread) where there are many; on the coarse levels, where a full tiling
+// would occupy a handful of compute units and each would push its four waves' divergent map taps through one texture path,
+// tiles of one or two waves' height -- more workgroups with one busy wave each -- as long as their count stays within `limit`
+// (the number of per-workgroup records the host adds itself).  Returns the number of tiles.
+__host__ __device__ inline int gh_tiling(int w, int h, int limit, int& tileH) {
+  const int tilesX = (w + 15) / 16;
+  for (tileH = 4; tileH < kGHTileH; tileH *= 2)
+    if (tilesX * ((h + tileH - 1) / tileH) <= limit) break;
+  return tilesX * ((h + tileH - 1) / tileH);
+}
 
 // One depth pixel of the evaluation in three stages, so that the loads of a stage -- of several pixels -- are in flight together
 // instead of one dependent round trip after the other inside nested branches: (1) depth -> point in the scene frame -> position in
@@ -241,11 +260,13 @@ __device__ inline void gh_row(const GHPixel& px, const GHTaps& tp, const GHTaps&
 template <int MODE>
 __device__ inline void gh_accumulate(const float* __restrict__ depth, const float4* __restrict__ pointsMap, const float4* __restrict__ normalsMap,
                                      const GHParams& p, int blk, int nBlocks, double acc[kGHValues], int& valid ITM_TT(, unsigned long long* tt = nullptr)) {
-  const int tilesX = (p.w + 15) / 16, tiles = tilesX * ((p.h + kGHTileH - 1) / kGHTileH);
+  const int tilesX = (p.w + 15) / 16, tiles = tilesX * ((p.h + p.tileH - 1) / p.tileH);
+  const int row = threadIdx.x >> 4;
+  if (row >= p.tileH) return;                   // a short tile: the waves below it have no pixels (whole waves: tileH is a multiple of 4)
   for (int tile = blk; tile < tiles; tile += 2 * nBlocks) {
     const int tileB = tile + nBlocks;
-    const int xA = (tile % tilesX) * 16 + (threadIdx.x & 15), yA = (tile / tilesX) * kGHTileH + (threadIdx.x >> 4);
-    const int xB = (tileB % tilesX) * 16 + (threadIdx.x & 15), yB = (tileB / tilesX) * kGHTileH + (threadIdx.x >> 4);
+    const int xA = (tile % tilesX) * 16 + (threadIdx.x & 15), yA = (tile / tilesX) * p.tileH + row;
+    const int xB = (tileB % tilesX) * 16 + (threadIdx.x & 15), yB = (tileB / tilesX) * p.tileH + row;
     const GHPixel pa = gh_project(depth, p, xA, yA, xA < p.w && yA < p.h);
     const GHPixel pb = gh_project(depth, p, xB, yB, tileB < tiles && xB < p.w && yB < p.h);
     ITM_TT(if (tt && tile == blk) { __builtin_amdgcn_s_waitcnt(0); tt[0] = __builtin_amdgcn_s_memrealtime(); })
@@ -281,6 +302,14 @@ __device__ inline double wave_sum(double s) {
   return ((lane_value(s, 15) + lane_value(s, 31)) + lane_value(s, 47)) + lane_value(s, 63);
 }
 
+__device__ inline int wave_count(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+  return __builtin_amdgcn_readlane(v, 15) + __builtin_amdgcn_readlane(v, 31) + __builtin_amdgcn_readlane(v, 47) + __builtin_amdgcn_readlane(v, 63);
+}
+
 // wave sums in double (fixed order), then the waves in order: thread i < kGHValues ends up with value i of the workgroup, every
 // thread with its count
 template <int MODE>
@@ -294,9 +323,7 @@ __device__ inline void gh_block_reduce(const double acc[kGHValues], int valid, d
     const double s = used ? wave_sum(acc[i]) : 0.0;
     if (lane == 0) lds[wave][i] = s;
   }
-  int total = valid;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) total += __shfl_down(total, o, 64);
+  const int total = wave_count(valid);
   if (lane == 0) ldsCount[wave] = total;
   __syncthreads();
   mine = 0.0; cnt = 0;
@@ -309,8 +336,7 @@ __device__ inline void gh_block_reduce(const double acc[kGHValues], int valid, d
 
 template <int MODE>
 __global__ void __launch_bounds__(kGHThreads) gh_partial_kernel(const float* __restrict__ depth, const float4* __restrict__ pointsMap,
-                                                        const float4* __restrict__ normalsMap, double* __restrict__ partial,
-                                                        int* __restrict__ partialCount, GHParams p, GHBlockRecord* __restrict__ hostRec, unsigned int seq) {
+                                                        const float4* __restrict__ normalsMap, GHParams p, GHBlockRecord* __restrict__ hostRec, unsigned int seq) {
   __shared__ double lds[kGHWaves][kGHValues];
   __shared__ int ldsCount[kGHWaves];
   double acc[kGHValues];
@@ -321,11 +347,9 @@ __global__ void __launch_bounds__(kGHThreads) gh_partial_kernel(const float* __r
   const int blk = blockIdx.x;
   double mine; int cnt;
   gh_block_reduce<MODE>(acc, valid, lds, ldsCount, mine, cnt);
-  if (threadIdx.x < kGHValues) partial[(size_t)blk * kGHValues + threadIdx.x] = mine;
-  if (threadIdx.x == 0) partialCount[blk] = cnt;
-  // the same partial goes to a tagged record in pinned host memory: the host adds the records in block order itself (one launch
-  // per Levenberg-Marquardt iteration, no reduction launch, no copy)
-  if (hostRec) send_record<__HIP_MEMORY_SCOPE_SYSTEM>(hostRec + blk, mine, cnt, seq);
+  // the partial goes to a tagged record in pinned host memory: the host adds the records itself (one launch per
+  // Levenberg-Marquardt iteration, no reduction launch, no copy)
+  send_record<__HIP_MEMORY_SCOPE_SYSTEM>(hostRec + blk, mine, cnt, seq);
 }
 
 // ---- evaluation session: ONE launch serves every evaluation of a TrackCamera call -------------------------------------------
@@ -341,6 +365,9 @@ __global__ void __launch_bounds__(kGHThreads) gh_partial_kernel(const float* __r
 // session gone starts another one at the pending sequence number (same stream: it begins when the old one has left entirely).
 constexpr unsigned int kSessionExit = 0xffffffffu;
 constexpr unsigned long long kSessionIdleTicks = 200000ull;   // 2 ms
+#ifndef ITM_SESSION_POLL_SLEEP
+#define ITM_SESSION_POLL_SLEEP 4      // s_sleep argument between two polls of the command granules (x64 clocks)
+#endif
 #ifndef ITM_SESSION_TO_HOST_BLOCKS
 #define ITM_SESSION_TO_HOST_BLOCKS 96
 #endif
@@ -355,18 +382,17 @@ struct GHCommand {            // the payload words of the command granules
 constexpr int kCommandWords = (int)(sizeof(GHCommand) / 4);
 static_assert(sizeof(GHCommand) % 4 == 0 && kCommandWords <= 64, "one granule per lane of the polling wave");
 constexpr int kExitGranule = kCommandWords - 1;
-struct GHResult { GHBlockRecord answer; volatile unsigned int exited; unsigned long long stamps[6]; };   // device -> host (stamps: measurement builds)
+struct GHResult { GHBlockRecord segment[kSegs]; volatile unsigned int exited; unsigned long long stamps[6]; };   // device -> host (stamps: measurement builds)
 
 __global__ void __launch_bounds__(kGHThreads) gh_session_kernel(const unsigned long long* __restrict__ hostCmd, unsigned long long* __restrict__ devCmd,
-                                                                double* __restrict__ partial, int* __restrict__ partialCount, unsigned int* __restrict__ done,
-                                                                GHResult* __restrict__ hostRes, GHBlockRecord* __restrict__ hostRec, unsigned int session, unsigned int firstSeq,
-                                                                unsigned int arrived, int direct) {
+                                                                GHBlockRecord* __restrict__ devRec, GHResult* __restrict__ hostRes, GHBlockRecord* __restrict__ hostRec,
+                                                                unsigned int session, unsigned int firstSeq, int direct) {
   __shared__ __attribute__((aligned(16))) unsigned int cmdWords[kCommandWords];
   __shared__ unsigned int nextSeq;
-  __shared__ int lastArriver;
+  __shared__ int gatherFailed;
   __shared__ double lds[kGHWaves][kGHValues];
   __shared__ int ldsCount[kGHWaves];
-  __shared__ double gathered[kGHGroups][kGHValues + 1];          // the last arriver's copy of every partial (+ count)
+  __shared__ double gathered[kSegBlocks][kGHValues + 1];          // a gathering workgroup's copy of its segment's records (+ counts)
   const GHCommand& cmd = *(const GHCommand*)cmdWords;
   unsigned int expected = firstSeq;
   unsigned long long idleSince = __builtin_amdgcn_s_memrealtime();
@@ -401,9 +427,11 @@ __global__ void __launch_bounds__(kGHThreads) gh_session_kernel(const unsigned l
           s = kSessionExit;
           break;
         }
-        __builtin_amdgcn_s_sleep(4);
+#if ITM_SESSION_POLL_SLEEP > 0
+        __builtin_amdgcn_s_sleep(ITM_SESSION_POLL_SLEEP);
+#endif
       }
-      if (lane == 0) nextSeq = s;
+      if (lane == 0) { nextSeq = s; gatherFailed = 0; }
     }
     __syncthreads();
     const unsigned int s = nextSeq;
@@ -430,52 +458,64 @@ __global__ void __launch_bounds__(kGHThreads) gh_session_kernel(const unsigned l
                  __hip_atomic_store(&hostRes->stamps[2], ttRed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(&hostRes->stamps[3], now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                  __hip_atomic_store(&hostRes->stamps[4], ttIn[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(&hostRes->stamps[5], ttIn[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); })
       } else {
-        if (threadIdx.x < kGHValues) __hip_atomic_store(partial + (size_t)blockIdx.x * kGHValues + threadIdx.x, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (threadIdx.x == 0) __hip_atomic_store(partialCount + blockIdx.x, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        send_record<__HIP_MEMORY_SCOPE_AGENT>(devRec + blockIdx.x, mine, cnt, s);
       }
     }
-    __syncthreads();
-    // only the workgroups that had tiles arrive; the counter is never reset: every workgroup sees every command and so knows how
-    // many arrivals (`arrived`, continued from the handle's earlier sessions) preceded this evaluation
-    if (threadIdx.x == 0) lastArriver = !cmd.toHost && ((int)blockIdx.x < nBlocks) && __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == arrived + (unsigned int)nBlocks - 1u;
-    if (!cmd.toHost) arrived += (unsigned int)nBlocks;
-    __syncthreads();
-    if (lastArriver) {
+    const int segments = (nBlocks + kSegBlocks - 1) / kSegBlocks;
+    if (!cmd.toHost && (int)blockIdx.x < segments) {
+      // ---- a fine level: workgroup g < segments collects the tagged records of segment g from device memory (no arrival counter,
+      // nobody waits for a store to have completed), adds them in block order and sends the segment's sums to the host, which adds
+      // the segments: the common order.  (One workgroup collecting all 240 records: 7-8 us, bound by the uncached loads it can keep in flight.)
       ITM_TT(const unsigned long long ttLast = __builtin_amdgcn_s_memrealtime();)
-      // ---- every partial is in device memory: add them in block order, answer the host ----
-      for (int b = threadIdx.x; b < nBlocks; b += kGHThreads) {
-        // all loads of the record first (independent destinations: in flight together), then the copies into LDS
-        double rec[kGHValues];
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      constexpr int kPerWave = kSegBlocks / kGHWaves;
+      const int base = blockIdx.x * kSegBlocks, count = min(kSegBlocks, nBlocks - base);
+      // lane i fetches granule i: one record = one 512-byte load; the wave's records in flight together, re-fetched until all are there
+      unsigned long long g[kPerWave];
+      for (;;) {
+        bool mineOk = true;
 #pragma unroll
-        for (int i = 0; i < kGHValues; ++i) rec[i] = __hip_atomic_load(partial + (size_t)b * kGHValues + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int recCount = __hip_atomic_load(partialCount + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < kPerWave; ++k) {
+          const int local = wave * kPerWave + k;
+          g[k] = (local < count) ? __hip_atomic_load(&devRec[base + local].g[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)s << 32);
+        }
 #pragma unroll
-        for (int i = 0; i < kGHValues; ++i) gathered[b][i] = rec[i];
-        gathered[b][kGHValues] = (double)recCount;
+        for (int k = 0; k < kPerWave; ++k) mineOk = mineOk && (unsigned int)(g[k] >> 32) == s;
+        if (__all(mineOk)) break;
+        if (__builtin_amdgcn_s_memrealtime() - idleSince > 4 * kSessionIdleTicks) { gatherFailed = 1; break; }   // a workgroup is gone: no answer, the host's time-out ends the call
+      }
+#pragma unroll
+      for (int k = 0; k < kPerWave; ++k) {
+        const int local = wave * kPerWave + k;
+        const unsigned int lo = (unsigned int)g[k], hi = (unsigned int)__shfl_down((int)lo, 1, 64);
+        if (local < count) {
+          if (lane < 2 * kGHValues && !(lane & 1)) gathered[local][lane >> 1] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+          if (lane == 2 * kGHValues) gathered[local][kGHValues] = (double)(int)lo;          // counts are small integers: exact in double
+        }
       }
       __syncthreads();
+      const bool complete = gatherFailed == 0;
       double sum = 0.0;
-      if (threadIdx.x <= kGHValues) {
-        // block order (the host's order); eight LDS reads in flight per step, the additions stay a chain
+      if (complete && threadIdx.x <= kGHValues) {
         int b = 0;
-        for (; b + 8 <= nBlocks; b += 8) {
+        for (; b + 8 <= count; b += 8) {            // eight LDS reads in flight per step, the additions stay a chain
           double v8[8];
 #pragma unroll
           for (int k = 0; k < 8; ++k) v8[k] = gathered[b + k][threadIdx.x];
 #pragma unroll
           for (int k = 0; k < 8; ++k) sum += v8[k];
         }
-        for (; b < nBlocks; ++b) sum += gathered[b][threadIdx.x];
+        for (; b < count; ++b) sum += gathered[b][threadIdx.x];
       }
-      const int total = (int)__shfl(sum, kGHValues, 64);         // counts are small integers: exact in double
-      send_record<__HIP_MEMORY_SCOPE_SYSTEM>(&hostRes->answer, sum, total, s);
-      // (this workgroup's own times: command seen, tiles accumulated, last arrival known, sums added)
-      ITM_TT(if (threadIdx.x == 0) { const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+      const int total = (int)__shfl(sum, kGHValues, 64);
+      if (complete) send_record<__HIP_MEMORY_SCOPE_SYSTEM>(&hostRes->segment[blockIdx.x], sum, total, s);
+      // (workgroup 0's own times: command seen, tiles accumulated, gathering begun, segment sent)
+      ITM_TT(if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long now = __builtin_amdgcn_s_memrealtime();
                __hip_atomic_store(&hostRes->stamps[0], ttSeen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(&hostRes->stamps[1], ttAcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                __hip_atomic_store(&hostRes->stamps[2], ttLast, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(&hostRes->stamps[3], now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                 __hip_atomic_store(&hostRes->stamps[4], ttIn[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(&hostRes->stamps[5], ttIn[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); })
+               __hip_atomic_store(&hostRes->stamps[4], ttIn[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(&hostRes->stamps[5], ttIn[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); })
     }
+    __syncthreads();          // the next command overwrites the command words in LDS
     expected = next_seq(s);
     idleSince = __builtin_amdgcn_s_memrealtime();
   }
@@ -493,7 +533,7 @@ __global__ void __launch_bounds__(kGHThreads) gh_session_kernel(const unsigned l
 struct itm_tracker {
   std::mutex mu;
   int device = -1;
-  double* partial = nullptr; int* partialCount = nullptr;
+  itm::GHBlockRecord* devRec = nullptr;       // device memory: the workgroups' records of a session's fine levels
   itm::GHBlockRecord* rec = nullptr; itm::GHBlockRecord* recDev = nullptr;   // pinned host records + their device address
   size_t blocks = 0;
   unsigned int seq = 0;
@@ -502,8 +542,7 @@ struct itm_tracker {
   // evaluation session (gh_session_kernel)
   unsigned long long* cmd = nullptr; unsigned long long* cmdDev = nullptr;   // command granules (BAR-mapped device memory or pinned host memory) + their device address
   itm::GHResult* res = nullptr; itm::GHResult* resDev = nullptr;     // pinned result + its device address
-  unsigned long long* devCmd = nullptr; unsigned int* done = nullptr;   // device memory: republished command granules, arrival counter
-  unsigned int arrived = 0;      // arrivals counted by `done` so far (the counter is never reset between evaluations)
+  unsigned long long* devCmd = nullptr;   // device memory: republished command granules
   unsigned int session = 0;
   bool sessionOpen = false;
   bool cmdDirect = false;        // the command block is device memory the host writes through the BAR
@@ -522,15 +561,15 @@ static void tracker_release(itm_tracker* t) {
     write_exit(t);
     t->sessionOpen = false;
   }
-  (void)hipFree(t->partial); (void)hipFree(t->partialCount);
+  (void)hipFree(t->devRec);
   if (t->rec) (void)hipHostFree(t->rec);
   if (t->cmd) { if (t->cmdDirect) (void)hipFree(t->cmd); else (void)hipHostFree(t->cmd); }
   if (t->res) (void)hipHostFree(t->res);
-  (void)hipFree(t->devCmd); (void)hipFree(t->done);
-  t->cmd = nullptr; t->cmdDev = nullptr; t->res = nullptr; t->resDev = nullptr; t->devCmd = nullptr; t->done = nullptr;
+  (void)hipFree(t->devCmd);
+  t->cmd = nullptr; t->cmdDev = nullptr; t->res = nullptr; t->resDev = nullptr; t->devCmd = nullptr;
   t->sessionOpen = false;
   for (float* q : t->pyramid) (void)hipFree(q);
-  t->partial = nullptr; t->partialCount = nullptr; t->rec = nullptr; t->recDev = nullptr; t->blocks = 0;
+  t->devRec = nullptr; t->rec = nullptr; t->recDev = nullptr; t->blocks = 0;
   t->pyramid.clear(); t->pyramidBytes.clear();
 }
 
@@ -541,20 +580,20 @@ static int tracker_reserve(itm_tracker* t, size_t blocks) {
   if (t->device == dev && t->blocks >= blocks) return ITM_OK;
   if (t->device != dev) tracker_release(t);           // buffers of another device (incl. the pyramid) are of no use here
   else {
-    (void)hipFree(t->partial); (void)hipFree(t->partialCount);
+    (void)hipFree(t->devRec);
     if (t->rec) (void)hipHostFree(t->rec);
-    t->partial = nullptr; t->partialCount = nullptr; t->rec = nullptr; t->recDev = nullptr;
+    t->devRec = nullptr; t->rec = nullptr; t->recDev = nullptr;
   }
   t->blocks = 0; t->device = dev;
-  hipError_t e = hipMalloc((void**)&t->partial, blocks * kGHValues * sizeof(double));
-  if (e == hipSuccess) e = hipMalloc((void**)&t->partialCount, blocks * sizeof(int));
+  hipError_t e = hipMalloc((void**)&t->devRec, blocks * sizeof(GHBlockRecord));
+  if (e == hipSuccess) e = hipMemset(t->devRec, 0, blocks * sizeof(GHBlockRecord));        // tag 0: no record
   // coherent + mapped: device stores become visible to the polling host without a kernel boundary
   if (e == hipSuccess) e = hipHostMalloc((void**)&t->rec, blocks * sizeof(GHBlockRecord), hipHostMallocMapped | hipHostMallocCoherent);
   if (e == hipSuccess) { memset(t->rec, 0, blocks * sizeof(GHBlockRecord)); e = hipHostGetDevicePointer((void**)&t->recDev, t->rec, 0); }
   if (e != hipSuccess) {
-    (void)hipFree(t->partial); (void)hipFree(t->partialCount);
+    (void)hipFree(t->devRec);
     if (t->rec) (void)hipHostFree(t->rec);
-    t->partial = nullptr; t->partialCount = nullptr; t->rec = nullptr; t->recDev = nullptr;
+    t->devRec = nullptr; t->rec = nullptr; t->recDev = nullptr;
     return hip_fail(e, "tracker buffers", __FILE__, __LINE__);
   }
   t->blocks = blocks;
@@ -570,6 +609,20 @@ static itm_tracker* thread_tracker() {
 
 // Adds one tagged record to `sums` / `count` once every granule carries `tag`.  `slow(granule)` is called every 1024 polls of a
 // granule that has not arrived and decides whether the wait goes on (ITM_OK) or ends with an error code.
+// the common order of the additions (kSegBlocks above) on the host
+struct OrderedSums {
+  double seg[kSegs][kGHValues];
+  OrderedSums() { for (int g = 0; g < kSegs; ++g) for (int i = 0; i < kGHValues; ++i) seg[g][i] = 0.0; }
+  double* of_block(size_t b) { return seg[b / kSegBlocks]; }
+  void total(double out[kGHValues]) const {
+    for (int i = 0; i < kGHValues; ++i) {
+      double s = 0.0;
+      for (int g = 0; g < kSegs; ++g) s += seg[g][i];
+      out[i] = s;
+    }
+  }
+};
+
 template <class Slow>
 static inline int read_record(const GHBlockRecord* r, unsigned int tag, double* sums, int* count, Slow&& slow) {
   unsigned int w[kRecordWords];
@@ -601,7 +654,8 @@ static int compute_g_and_h(itm_tracker* trk, const float* depth, int w, int h, c
   memset(out, 0, sizeof *out);
   if (iterationType == ITM_TRACKER_ITERATION_NONE) return ITM_OK;
   if (iterationType < 1 || iterationType > 3) return set_error(ITM_ERR_INVALID, "bad iteration type");
-  const int tiles = ((w + 15) / 16) * ((h + kGHTileH - 1) / kGHTileH);
+  int tileH;
+  const int tiles = gh_tiling(w, h, kSessionToHostBlocks, tileH);
   const int rounds = (tiles + kGHGroups - 1) / kGHGroups;                  // tiles per workgroup, then as few workgroups as that needs
   const dim3 grid((tiles + rounds - 1) / rounds);
   const size_t blocks = grid.x;
@@ -611,26 +665,25 @@ static int compute_g_and_h(itm_tracker* trk, const float* depth, int w, int h, c
   memcpy(p.approxInvPose.m, approxInvPose, 64); memcpy(p.scenePose.m, scenePose, 64);
   p.vfx = viewIntr[0]; p.vfy = viewIntr[1]; p.vcx = viewIntr[2]; p.vcy = viewIntr[3];
   p.sfx = sceneIntr[0]; p.sfy = sceneIntr[1]; p.scx = sceneIntr[2]; p.scy = sceneIntr[3];
-  p.distThresh = distThresh; p.w = w; p.h = h; p.sceneW = sceneW; p.sceneH = sceneH;
+  p.distThresh = distThresh; p.w = w; p.h = h; p.sceneW = sceneW; p.sceneH = sceneH; p.tileH = tileH;
   const float4* pm = (const float4*)pointsMap; const float4* nm = (const float4*)normalsMap;
   const int np = (iterationType == ITM_TRACKER_ITERATION_BOTH) ? 6 : 3;
   const int nh = np * (np + 1) / 2;
   const unsigned int seq = trk->seq = next_seq(trk->seq);
-  if (iterationType == 1) gh_partial_kernel<1><<<grid, kGHThreads, 0, st>>>(depth, pm, nm, trk->partial, trk->partialCount, p, trk->recDev, seq);
-  else if (iterationType == 2) gh_partial_kernel<2><<<grid, kGHThreads, 0, st>>>(depth, pm, nm, trk->partial, trk->partialCount, p, trk->recDev, seq);
-  else gh_partial_kernel<3><<<grid, kGHThreads, 0, st>>>(depth, pm, nm, trk->partial, trk->partialCount, p, trk->recDev, seq);
+  if (iterationType == 1) gh_partial_kernel<1><<<grid, kGHThreads, 0, st>>>(depth, pm, nm, p, trk->recDev, seq);
+  else if (iterationType == 2) gh_partial_kernel<2><<<grid, kGHThreads, 0, st>>>(depth, pm, nm, p, trk->recDev, seq);
+  else gh_partial_kernel<3><<<grid, kGHThreads, 0, st>>>(depth, pm, nm, p, trk->recDev, seq);
   ITM_LAUNCH_CHECK();
   // Wait for every workgroup's tagged record and add them in block order (fixed order => deterministic, in double).  The
   // poll is bounded in TIME: after 20 ms without a granule the stream is queried between polls -- a drained stream without
   // it, a device error, or pollTimeoutSeconds without progress end the call with ITM_ERR_DEVICE instead of stalling the
   // host on a kernel that will never finish.
-  double sums[kGHValues];
-  for (int i = 0; i < kGHValues; ++i) sums[i] = 0.0;
+  OrderedSums ordered;
   int n = 0;
   using clock = std::chrono::steady_clock;
   clock::time_point t0; bool timing = false;
   for (size_t b = 0; b < blocks; ++b) {
-    rc = read_record(trk->rec + b, seq, sums, &n, [&](const volatile unsigned long long* g) -> int {
+    rc = read_record(trk->rec + b, seq, ordered.of_block(b), &n, [&](const volatile unsigned long long* g) -> int {
       if (!timing) { t0 = clock::now(); timing = true; return ITM_OK; }
       const double waited = std::chrono::duration<double>(clock::now() - t0).count();
       if (waited < 0.02) return ITM_OK;
@@ -645,6 +698,8 @@ static int compute_g_and_h(itm_tracker* trk, const float* depth, int w, int h, c
     });
     if (rc) return rc;
   }
+  double sums[kGHValues];
+  ordered.total(sums);
   for (int r = 0, k = 0; r < np; ++r)
     for (int c = 0; c <= r; ++c, ++k) out->hessian[r + c * 6] = (float)sums[7 + k];
   for (int r = 0; r < np; ++r)
@@ -683,28 +738,21 @@ static int session_reserve(itm_tracker* t) {
   if (e == hipSuccess) e = hipHostMalloc((void**)&t->res, sizeof(GHResult), hipHostMallocMapped | hipHostMallocCoherent);
   if (e == hipSuccess) { memset(t->res, 0, sizeof(GHResult)); e = hipHostGetDevicePointer((void**)&t->resDev, t->res, 0); }
   if (e == hipSuccess) e = hipMalloc((void**)&t->devCmd, cmdBytes);
-  if (e == hipSuccess) e = hipMalloc((void**)&t->done, 4);
   if (e == hipSuccess) e = hipMemset(t->devCmd, 0, cmdBytes);
-  if (e == hipSuccess) e = hipMemset(t->done, 0, 4);
   if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e != hipSuccess) {
     if (t->cmd) { if (t->cmdDirect) (void)hipFree(t->cmd); else (void)hipHostFree(t->cmd); }
     if (t->res) (void)hipHostFree(t->res);
-    (void)hipFree(t->devCmd); (void)hipFree(t->done);
-    t->cmd = nullptr; t->res = nullptr; t->devCmd = nullptr; t->done = nullptr;
+    (void)hipFree(t->devCmd);
+    t->cmd = nullptr; t->res = nullptr; t->devCmd = nullptr;
     return hip_fail(e, "tracker session buffers", __FILE__, __LINE__);
   }
-  t->arrived = 0;
   return ITM_OK;
 }
 
-// `afterExit`: the previous session of this handle left on its own (idle limit) while a command was pending; workgroups of it may
-// have counted arrivals for that command before they left, so the counter starts again from zero (in stream order: after them)
-static int session_launch(itm_tracker* t, unsigned int firstSeq, bool afterExit, hipStream_t st) {
-  if (afterExit) { ITM_HIP(hipMemsetAsync(t->done, 0, 4, st)); t->arrived = 0; }
+static int session_launch(itm_tracker* t, unsigned int firstSeq, hipStream_t st) {
   ++t->session;
-  gh_session_kernel<<<kGHGroups, kGHThreads, 0, st>>>(t->cmdDev, t->devCmd, t->partial, t->partialCount, t->done, t->resDev, t->recDev, t->session, firstSeq,
-                                                      t->arrived, t->cmdDirect ? 1 : 0);
+  gh_session_kernel<<<kGHGroups, kGHThreads, 0, st>>>(t->cmdDev, t->devCmd, t->devRec, t->resDev, t->recDev, t->session, firstSeq, t->cmdDirect ? 1 : 0);
   ITM_LAUNCH_CHECK();
   t->sessionOpen = true;
   return ITM_OK;
@@ -737,7 +785,8 @@ static int session_g_and_h(itm_tracker* trk, const float* depth, int w, int h, c
   if (iterationType < 1 || iterationType > 3) return set_error(ITM_ERR_INVALID, "bad iteration type");
   int rc = session_reserve(trk);
   if (rc) return rc;
-  const int tiles = ((w + 15) / 16) * ((h + kGHTileH - 1) / kGHTileH);
+  int tileH;
+  const int tiles = gh_tiling(w, h, kSessionToHostBlocks, tileH);
   const int rounds = (tiles + kGHGroups - 1) / kGHGroups;
   using clock = std::chrono::steady_clock;
   if (!trk->sessionOpen && trk->session != 0u) {
@@ -758,7 +807,7 @@ static int session_g_and_h(itm_tracker* trk, const float* depth, int w, int h, c
   memcpy(c.p.approxInvPose.m, approxInvPose, 64); memcpy(c.p.scenePose.m, scenePose, 64);
   c.p.vfx = viewIntr[0]; c.p.vfy = viewIntr[1]; c.p.vcx = viewIntr[2]; c.p.vcy = viewIntr[3];
   c.p.sfx = sceneIntr[0]; c.p.sfy = sceneIntr[1]; c.p.scx = sceneIntr[2]; c.p.scy = sceneIntr[3];
-  c.p.distThresh = distThresh; c.p.w = w; c.p.h = h; c.p.sceneW = sceneW; c.p.sceneH = sceneH;
+  c.p.distThresh = distThresh; c.p.w = w; c.p.h = h; c.p.sceneW = sceneW; c.p.sceneH = sceneH; c.p.tileH = tileH;
   c.depth = depth; c.points = (const float4*)pointsMap; c.normals = (const float4*)normalsMap;
   c.mode = iterationType; c.activeBlocks = (tiles + rounds - 1) / rounds;       // the grid of the per-launch path: same tiles per block, same sums
   const int nBlocks = c.activeBlocks;
@@ -768,14 +817,14 @@ static int session_g_and_h(itm_tracker* trk, const float* depth, int w, int h, c
   const unsigned int seq = trk->seq = next_seq(trk->seq);
   write_command(trk, c, seq);
   ITM_TT(const auto ttA = clock::now();)
-  if (!trk->sessionOpen && (rc = session_launch(trk, seq, false, st))) return rc;
+  if (!trk->sessionOpen && (rc = session_launch(trk, seq, st))) return rc;
   ITM_TT(const auto ttB = clock::now();)
   // Wait for the tagged answer: on coarse levels one record per workgroup, added here in block order (the order of the device-side
   // gather and of the per-launch path), otherwise the one record of the gathering workgroup.  A session that has left without
   // answering (idle limit hit while this thread was away) is replaced; the wait is bounded in time like the per-launch path's.
   clock::time_point t0; bool timing = false;
   auto slow = [&](const volatile unsigned long long* g) -> int {
-    if (trk->res->exited == trk->session && (unsigned int)(*g >> 32) != seq) return session_launch(trk, seq, true, st);
+    if (trk->res->exited == trk->session && (unsigned int)(*g >> 32) != seq) return session_launch(trk, seq, st);
     if (!timing) { t0 = clock::now(); timing = true; return ITM_OK; }
     const double waited = std::chrono::duration<double>(clock::now() - t0).count();
     if (waited < 0.02) return ITM_OK;
@@ -788,10 +837,12 @@ static int session_g_and_h(itm_tracker* trk, const float* depth, int w, int h, c
   for (int i = 0; i < kGHValues; ++i) sums[i] = 0.0;
   int n = 0;
   if (toHost) {
-    for (int b = 0; b < nBlocks && !rc; ++b) rc = read_record(trk->rec + b, seq, sums, &n, slow);
+    OrderedSums ordered;
+    for (int b = 0; b < nBlocks && !rc; ++b) rc = read_record(trk->rec + b, seq, ordered.of_block(b), &n, slow);
+    ordered.total(sums);
   } else {
-    rc = read_record(&trk->res->answer, seq, sums, &n, slow);
-    if (!rc) trk->arrived += (unsigned int)nBlocks;
+    const int segments = (nBlocks + kSegBlocks - 1) / kSegBlocks;          // the device added each segment; the segments in order here
+    for (int g = 0; g < segments && !rc; ++g) rc = read_record(&trk->res->segment[g], seq, sums, &n, slow);
   }
   if (rc) return rc;
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
@@ -800,7 +851,7 @@ static int session_g_and_h(itm_tracker* trk, const float* depth, int w, int h, c
            fprintf(stderr, "[tracker trace] %dx%d mode %d: command %.2f us, launch %.1f us, answer after %.1f us; on the device, from the command seen: first depth %.2f, first taps %.2f, tiles accumulated %.2f, %s %.2f, record sent %.2f us\n", w, h, iterationType,
                    std::chrono::duration<double, std::micro>(ttA - tt0).count(), std::chrono::duration<double, std::micro>(ttB - ttA).count(),
                    std::chrono::duration<double, std::micro>(ttC - ttB).count(),
-                   (double)(r->stamps[4] - r->stamps[0]) / 100.0, (double)(r->stamps[5] - r->stamps[0]) / 100.0, (double)(r->stamps[1] - r->stamps[0]) / 100.0, toHost ? "reduced" : "last arrival", (double)(r->stamps[2] - r->stamps[0]) / 100.0, (double)(r->stamps[3] - r->stamps[0]) / 100.0); })
+                   (double)(r->stamps[4] - r->stamps[0]) / 100.0, (double)(r->stamps[5] - r->stamps[0]) / 100.0, (double)(r->stamps[1] - r->stamps[0]) / 100.0, toHost ? "reduced" : "gathering from", (double)(r->stamps[2] - r->stamps[0]) / 100.0, (double)(r->stamps[3] - r->stamps[0]) / 100.0); })
   const int np = (iterationType == ITM_TRACKER_ITERATION_BOTH) ? 6 : 3;
   for (int a = 0, k = 0; a < np; ++a)
     for (int b = 0; b <= a; ++b, ++k) out->hessian[a + b * 6] = (float)sums[7 + k];
