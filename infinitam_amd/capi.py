@@ -455,7 +455,7 @@ class Scene:
 
     def process_frame(self, view: View, rs: "RenderState", points: DevBuffer, normals: DevBuffer, stream=None):
         """ITMDenseMapper::ProcessFrame + ITMTrackingController::Prepare (Engine/ITMMainEngine.cpp:123-126)."""
-        vs = view.struct()
+        vs = view if isinstance(view, ViewStruct) else view.struct()      # callers on a hot loop keep one ViewStruct and update M_d in place
         self.be.check(self.be.fn["process_frame"](_P(self.h), C.byref(vs), _P(rs.h), _P(points.ptr), _P(normals.ptr), _P(stream)), "process_frame")
 
     def close(self):
