@@ -203,6 +203,73 @@ def test_session_kernel_and_launch_per_evaluation_give_the_same_pose_bit_for_bit
         ses.close()
 
 
+def track_with_handle(be, handle, ses, v, depth_next, cfg=None):
+    cfg = cfg or TrackerConfig.default()
+    d = be.to_backend(depth_next)
+    view = capi.View(d, ses.sc.w, ses.sc.h, M_d=v.M_d, intr_d=ses.sc.intr()).struct()
+    out = (C.c_float * 16)()
+    _, sp = fp(v.M_d)
+    be.check(be.fn["tracker_track_camera"](handle, C.byref(cfg), C.byref(view), ses.points.ptr, ses.normals.ptr, sp, out, None), "tracker_track_camera")
+    return np.array(out[:], np.float32)
+
+
+@pytest.mark.gpu
+def test_session_commands_through_host_memory_give_the_same_pose(hip):
+    """Debug key 11: the command granules lie in pinned host memory, workgroup 0 fetches them over PCIe and republishes them in
+    device memory for the others (the path of devices without a large BAR).  A tracker handle created under the key uses that
+    path for its whole life; poses are identical to the default path's, call after call and after an idle session has left."""
+    import time
+    ses, v, nxt = build_maps_offaxis(hip)
+    handle = C.c_void_p()
+    try:
+        a = track(hip, ses, v, nxt)
+        hip.check(hip.fn["debug_set"](11, 1), "debug_set")
+        try:
+            hip.check(hip.fn["tracker_create"](C.byref(handle)), "tracker_create")
+            b = track_with_handle(hip, handle, ses, v, nxt)          # the handle's buffers are chosen at its first session
+        finally:
+            hip.check(hip.fn["debug_set"](11, 0), "debug_set")
+        assert np.array_equal(a, b), np.abs(a - b).max()
+        for i in range(10):
+            assert np.array_equal(track_with_handle(hip, handle, ses, v, nxt), a), i
+        time.sleep(0.05)
+        assert np.array_equal(track_with_handle(hip, handle, ses, v, nxt), a)
+    finally:
+        if handle:
+            hip.check(hip.fn["tracker_destroy"](handle), "tracker_destroy")
+        ses.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [(632, 472), (336, 248), (200, 152)], ids=lambda s: "%dx%d" % s)
+def test_evaluation_on_ragged_levels_session_vs_launch_vs_oracle(hip, oracle, size):
+    """Image sizes that are no multiple of the 16-pixel tiles, of the one-wave-high coarse tiles or of the 32-workgroup segments:
+    TrackCamera through the session kernel == one launch per evaluation (bit for bit), and both follow the oracle."""
+    w, h = size
+    sc = Scenario(name="trk_ragged_%dx%d" % size, voxelSize=0.01, frames=3, stream=3, trajectory="yaw", w=w, h=h)
+    cfg = TrackerConfig.default()
+    cfg.noHierarchyLevels = 4
+    cfg.trackingRegime[:4] = [3, 3, 1, 1]
+    poses = []
+    for be in (hip, oracle):
+        ses = T.Session(be, sc)
+        try:
+            for k in range(sc.frames):
+                v = ses.frame(k)
+            nxt = sc.depth(sc.frames)
+            poses.append(track(be, ses, v, nxt, cfg))
+            if be is hip:
+                hip.check(hip.fn["debug_set"](10, 1), "debug_set")
+                try:
+                    per_launch = track(be, ses, v, nxt, cfg)
+                finally:
+                    hip.check(hip.fn["debug_set"](10, 0), "debug_set")
+                assert np.array_equal(poses[0], per_launch), np.abs(poses[0] - per_launch).max()
+        finally:
+            ses.close()
+    assert np.abs(poses[0] - poses[1]).max() < 2e-4, np.abs(poses[0] - poses[1]).max()
+
+
 # ---- the product's host-side solver against the reference's TrackCamera with the same evaluator (CPU) ------------------
 EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_float, C.POINTER(TrackerGH))
 
