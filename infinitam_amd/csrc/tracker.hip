@@ -302,14 +302,6 @@ __device__ inline double wave_sum(double s) {
   return ((lane_value(s, 15) + lane_value(s, 31)) + lane_value(s, 47)) + lane_value(s, 63);
 }
 
-__device__ inline int wave_count(int v) {
-  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
-  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
-  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
-  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
-  return __builtin_amdgcn_readlane(v, 15) + __builtin_amdgcn_readlane(v, 31) + __builtin_amdgcn_readlane(v, 47) + __builtin_amdgcn_readlane(v, 63);
-}
-
 // wave sums in double (fixed order), then the waves in order: thread i < kGHValues ends up with value i of the workgroup, every
 // thread with its count
 template <int MODE>
@@ -323,7 +315,7 @@ __device__ inline void gh_block_reduce(const double acc[kGHValues], int valid, d
     const double s = used ? wave_sum(acc[i]) : 0.0;
     if (lane == 0) lds[wave][i] = s;
   }
-  const int total = wave_count(valid);
+  const int total = wave_reduce_sum(valid);
   if (lane == 0) ldsCount[wave] = total;
   __syncthreads();
   mine = 0.0; cnt = 0;

@@ -10,22 +10,28 @@ constexpr int kWave = 64;
 __device__ inline int lane_id() { return threadIdx.x & (kWave - 1); }
 __device__ inline int wave_id() { return threadIdx.x / kWave; }
 
+// Cross-lane steps as data-parallel primitives (DPP): the shift happens in the ALU's operand path.  The __shfl_* forms they
+// replace are ds_bpermute instructions, one LDS round trip per step (a 6-step reduction cost 0.4-0.9 us of pure latency in the
+// ordered sweeps and in the tracker's reduction).
+//   row_shr:n   (0x110 + n)  lane i reads lane i - n of its row of 16; lanes without a source read 0 (bound_ctrl)
+//   row_bcast:15 (0x142)     lane 15 of every row to the next row      (row mask 0xa: rows 1 and 3 take it)
+//   row_bcast:31 (0x143)     lane 31 to the rows above it               (row mask 0xc: rows 2 and 3 take it)
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ inline int dpp_int(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, BOUND); }
+
 // inclusive scan across the 64 lanes of a wave
 __device__ inline int wave_inclusive_scan(int v) {
-  const int lane = lane_id();
-#pragma unroll
-  for (int d = 1; d < kWave; d <<= 1) {
-    int o = __shfl_up(v, d, kWave);
-    if (lane >= d) v += o;
-  }
+  v += dpp_int<0x111, 0xf, true>(v);
+  v += dpp_int<0x112, 0xf, true>(v);
+  v += dpp_int<0x114, 0xf, true>(v);
+  v += dpp_int<0x118, 0xf, true>(v);      // every row scanned
+  v += dpp_int<0x142, 0xa, false>(v);     // rows 1, 3 += total of the row before
+  v += dpp_int<0x143, 0xc, false>(v);     // rows 2, 3 += total of rows 0 + 1
   return v;
 }
 
-__device__ inline int wave_reduce_sum(int v) {
-#pragma unroll
-  for (int d = kWave / 2; d > 0; d >>= 1) v += __shfl_down(v, d, kWave);
-  return __shfl(v, 0, kWave);
-}
+// sum over the wave, the same value in every lane
+__device__ inline int wave_reduce_sum(int v) { return __builtin_amdgcn_readlane(wave_inclusive_scan(v), kWave - 1); }
 
 // Exclusive scan of one int per thread over a workgroup of NW waves (blockDim.x == NW*64).
 // `lds` needs NW+1 ints.  Returns the exclusive prefix; *total receives the workgroup sum.
