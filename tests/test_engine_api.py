@@ -194,3 +194,34 @@ def test_checkpoint_roundtrip_oracle(oracle):
 @pytest.mark.gpu
 def test_checkpoint_roundtrip_hip(hip):
     _roundtrip(hip)
+
+
+@pytest.mark.gpu
+def test_kernel_timers_count_and_sample(hip):
+    """itm_profile_enable / itm_profile_sample / itm_profile_read (the reference's NVTimer role): every enabled kernel of
+    itm_process_frame is counted once per frame, or once per `every` frames when sampling; disabled kernels are not timed; the
+    timers change nothing in the results (the session's frames are compared with an untimed run)."""
+    from infinitam_amd import capi
+    sc = Scenario(name="timers", voxelSize=0.005, frames=9, trajectory="bench")
+    plain = T.Session(hip, sc)
+    for k in range(sc.frames):
+        plain.frame(k, fused=True)
+    want = plain.snapshot()
+    ses = T.Session(hip, sc)
+    ray, integ = capi.TIMED_KERNELS.index("raycast"), capi.TIMED_KERNELS.index("integrate")
+    ses.scene.profile_read(reset=True)
+    ses.scene.profile_enable((1 << ray) | (1 << integ))
+    for k in range(4):
+        ses.frame(k, fused=True)
+    p = ses.scene.profile_read(reset=True)
+    assert p["raycast"]["calls"] == 4 and p["integrate"]["calls"] == 4 and p["request"]["calls"] == 0
+    assert 0.0 < p["raycast"]["total_ms"] < 50.0
+    ses.scene.profile_sample(3)                      # launches 0, 3 of the next five
+    for k in range(4, 9):
+        ses.frame(k, fused=True)
+    p = ses.scene.profile_read(reset=True)
+    assert p["raycast"]["calls"] == 2 and p["integrate"]["calls"] == 2
+    ses.scene.profile_enable(0)
+    T.compare_results(ses.snapshot(), want, sc, what="timed vs untimed")
+    with pytest.raises(Exception):
+        ses.scene.profile_sample(0)
