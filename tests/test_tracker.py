@@ -241,6 +241,63 @@ def test_session_commands_through_host_memory_give_the_same_pose(hip):
 
 
 @pytest.mark.gpu
+def test_four_trackers_on_four_streams_at_once(hip):
+    """Four host threads, each with its own tracker handle and HIP stream, call TrackCamera at the same time: four resident
+    evaluation kernels share the GPU, every call returns the pose a lone call returns."""
+    import threading
+    rt = C.CDLL("libamdhip64.so")            # the runtime the library is linked against (already loaded): streams of its own
+    rt.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+    rt.hipStreamDestroy.argtypes = [C.c_void_p]
+    ses, v, nxt = build_maps_offaxis(hip)
+    handles, streams = [], []
+    try:
+        want = track(hip, ses, v, nxt)
+        hip.sync()
+        d = hip.to_backend(nxt)
+        view = capi.View(d, ses.sc.w, ses.sc.h, M_d=v.M_d, intr_d=ses.sc.intr()).struct()
+        _, sp = fp(v.M_d)
+        cfg = TrackerConfig.default()
+        for _ in range(4):
+            h = C.c_void_p()
+            hip.check(hip.fn["tracker_create"](C.byref(h)), "tracker_create")
+            handles.append(h)
+            st = C.c_void_p()
+            assert rt.hipStreamCreate(C.byref(st)) == 0
+            streams.append(st)
+        results, errors = [[] for _ in range(4)], []
+        gate = threading.Barrier(4)
+
+        def work(i):
+            try:
+                gate.wait()
+                for _ in range(8):
+                    out = (C.c_float * 16)()
+                    hip.check(hip.fn["tracker_track_camera"](handles[i], C.byref(cfg), C.byref(view), ses.points.ptr, ses.normals.ptr, sp, out,
+                                                             streams[i]), "tracker_track_camera")
+                    results[i].append(np.array(out[:], np.float32))
+            except Exception as e:      # noqa: BLE001 -- reported below, in the main thread
+                errors.append(e)
+
+        threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        for i in range(4):
+            assert len(results[i]) == 8
+            for r in results[i]:
+                assert np.array_equal(r, want), (i, np.abs(r - want).max())
+    finally:
+        hip.sync()
+        for h in handles:
+            hip.check(hip.fn["tracker_destroy"](h), "tracker_destroy")
+        for st in streams:
+            rt.hipStreamDestroy(st)
+        ses.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("size", [(632, 472), (336, 248), (200, 152)], ids=lambda s: "%dx%d" % s)
 def test_evaluation_on_ragged_levels_session_vs_launch_vs_oracle(hip, oracle, size):
     """Image sizes that are no multiple of the 16-pixel tiles, of the one-wave-high coarse tiles or of the 32-workgroup segments:
