@@ -405,16 +405,27 @@ __global__ void __launch_bounds__(kGHThreads) gh_session_kernel(const unsigned l
         if (lane < kCommandWords)
           v = fromHost ? __hip_atomic_load(hostCmd + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : __hip_atomic_load(devCmd + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned int tag = (unsigned int)(v >> 32);
-        if (__all(lane >= kCommandWords || tag == expected)) {
+        const unsigned int tag0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)tag);
+        // the last granule says whom the block is for: its payload is a session number, under a command's tag or under the exit tag
+        const unsigned int lastTag = (unsigned int)__builtin_amdgcn_readlane((int)tag, kExitGranule);
+        const unsigned int forSession = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)v, kExitGranule);
+        // A command is taken when every granule carries the same number and that number is not behind the expected one.  It may be
+        // AHEAD: only the workgroups with tiles answer an evaluation, so the host can move on while a workgroup without tiles has not
+        // looked yet (on a GPU that other streams keep busy a poll can take longer than a coarse evaluation) -- it then simply joins
+        // at the command it finds.
+        if (__all(lane >= kCommandWords || tag == tag0) && tag0 != 0u && tag0 != kSessionExit && (int)(tag0 - expected) >= 0 && forSession == session) {
           if (lane < kCommandWords) {
             cmdWords[lane] = (unsigned int)v;
             if (!direct && blockIdx.x == 0) __hip_atomic_store(devCmd + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
-          s = expected;
+          s = tag0;
           break;
         }
-        const bool leave = __any(lane == kExitGranule && tag == kSessionExit && (unsigned int)v == session) || (__builtin_amdgcn_s_memrealtime() - idleSince > limit);
-        if (leave) {
+        // Leave when told to (exit tag with this session's number), when the block is addressed to ANOTHER session (this one is
+        // over: its exit was overwritten before this workgroup looked, or it has been replaced after an idle exit), or after the idle limit
+        const bool told = lastTag == kSessionExit && forSession == session;
+        const bool replaced = lastTag != 0u && lastTag != kSessionExit && forSession != session;
+        if (told || replaced || (__builtin_amdgcn_s_memrealtime() - idleSince > limit)) {
           if (!direct && blockIdx.x == 0 && lane == kExitGranule) __hip_atomic_store(devCmd + lane, ((unsigned long long)kSessionExit << 32) | session, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           s = kSessionExit;
           break;
@@ -816,7 +827,12 @@ static int session_g_and_h(itm_tracker* trk, const float* depth, int w, int h, c
   // answering (idle limit hit while this thread was away) is replaced; the wait is bounded in time like the per-launch path's.
   clock::time_point t0; bool timing = false;
   auto slow = [&](const volatile unsigned long long* g) -> int {
-    if (trk->res->exited == trk->session && (unsigned int)(*g >> 32) != seq) return session_launch(trk, seq, st);
+    if (trk->res->exited == trk->session && (unsigned int)(*g >> 32) != seq) {
+      ITM_TT(fprintf(stderr, "[tracker trace] %p session %u left without answering %u: relaunch\n", (void*)trk, trk->session, seq);)
+      c.session = trk->session + 1u;           // addressed to the new session: workgroups of the old one that are still around leave at once
+      write_command(trk, c, seq);
+      return session_launch(trk, seq, st);
+    }
     if (!timing) { t0 = clock::now(); timing = true; return ITM_OK; }
     const double waited = std::chrono::duration<double>(clock::now() - t0).count();
     if (waited < 0.02) return ITM_OK;
@@ -890,6 +906,11 @@ static int build_pyramid(itm_tracker* trk, const itm_view* view, int levels, std
   return ITM_OK;
 }
 
+static std::mutex& session_gate(int device) {
+  static std::mutex gates[64];
+  return gates[(device >= 0 ? device : 0) & 63];
+}
+
 static int track_camera(itm_tracker* trk, const itm_tracker_config* cfg, const itm_view* view, const float* pointsMap, const float* normalsMap,
                         const float scenePose[16], float M_d_out[16], hipStream_t st) {
   const int levels = cfg->noHierarchyLevels;
@@ -905,7 +926,12 @@ static int track_camera(itm_tracker* trk, const itm_tracker_config* cfg, const i
       return compute_g_and_h(trk, pyr[level].depth, pyr[level].w, pyr[level].h, pyr[level].intr, pointsMap, normalsMap, view->w, view->h,
                              pyr[0].intr, invPose, scenePose, distThresh, mode, e, st);
     });
-  // one resident kernel for all evaluations of this call
+  // One resident kernel for all evaluations of this call -- and one such kernel per DEVICE at a time: its workgroups take a compute
+  // unit's whole register budget for one wave per SIMD (256 VGPRs), so two sessions cannot share a compute unit, and two sessions
+  // that have each got hold of SOME compute units wait for the rest until their idle limits fire (measured with four closed loops
+  // on four streams: 10 frames/s).  Calls from other handles / streams / threads queue here for the ~100 us of a call; everything
+  // else those streams do (view building, fusion, ray casting) runs beside the session.
+  std::lock_guard<std::mutex> oneSession(session_gate(trk->device));
   rc = icp_track(cfg, view->M_d, M_d_out, [&](int level, int mode, const float invPose[16], float distThresh, itm_tracker_gh* e) {
     return session_g_and_h(trk, pyr[level].depth, pyr[level].w, pyr[level].h, pyr[level].intr, pointsMap, normalsMap, view->w, view->h,
                            pyr[0].intr, invPose, scenePose, distThresh, mode, e, st);
