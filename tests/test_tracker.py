@@ -413,23 +413,31 @@ def test_host_solver_schedule_and_rejection(hip_host):
     assert res[1, 2] != 0.0                              # rotated about x
 
 
-def closed_loop(be, frames=5):
-    """ITMMainEngine::ProcessFrame with the ICP tracker instead of external poses: Track -> fuse -> Prepare."""
+def closed_loop(be, frames=5, handle=None, stream=None, depths=None, start=None):
+    """ITMMainEngine::ProcessFrame with the ICP tracker instead of external poses: Track -> fuse -> Prepare.  With `handle` /
+    `stream` the loop runs on a tracker handle and a HIP stream of its own; `start` is a threading.Barrier to leave together."""
     sc = Scenario(name="loop", voxelSize=0.01, frames=frames)
     ses = T.Session(be, sc)
     pose = synth.pose_matrix(sc.position(0))
     traj = [pose.copy()]
+    cfg = TrackerConfig.default()
+    if start is not None:
+        start.wait()
     for k in range(frames):
-        d = be.to_backend(sc.depth(k))
+        d = depths[k] if depths is not None else be.to_backend(sc.depth(k))
         if k > 0:   # age_pointCloud != -1: track against the maps rendered from the previous pose
             view = capi.View(d, sc.w, sc.h, M_d=pose, intr_d=sc.intr()).struct()
             out = (C.c_float * 16)()
             _, sp = fp(pose)
-            be.check(be.fn["track_camera"](C.byref(TrackerConfig.default()), C.byref(view), ses.points.ptr, ses.normals.ptr, sp, out, None), "track")
+            if handle is None:
+                be.check(be.fn["track_camera"](C.byref(cfg), C.byref(view), ses.points.ptr, ses.normals.ptr, sp, out, stream), "track")
+            else:
+                be.check(be.fn["tracker_track_camera"](handle, C.byref(cfg), C.byref(view), ses.points.ptr, ses.normals.ptr, sp, out, stream), "track")
             pose = np.array(out[:], np.float32)
             traj.append(pose.copy())
         v = capi.View(d, sc.w, sc.h, M_d=pose, intr_d=sc.intr())
-        ses.scene.process_frame(v, ses.rs, ses.points, ses.normals)
+        ses.scene.process_frame(v, ses.rs, ses.points, ses.normals, stream=stream.value if stream is not None else None)
+    be.sync(stream.value if stream is not None else None)
     ses.close()
     return sc, np.array(traj)
 
@@ -450,3 +458,57 @@ def test_closed_loop_hip_follows_the_trajectory_and_the_oracle(hip, oracle):
     # part (translation) stays far below the voxel size (1 cm); the roll about the optical axis is unobservable
     # in this scene (sphere on the axis + frontal wall), drifts in both runs and is not compared.
     assert np.abs(a[:, 12:15] - b[:, 12:15]).max() < 2e-4
+
+
+@pytest.mark.gpu
+def test_four_closed_loops_on_four_streams_keep_trajectory_and_pace(hip):
+    """Four tracking + mapping loops on four streams from four host threads.  While one loop's evaluation kernel is resident the
+    others' fusion and ray-cast kernels share its compute units; workgroups of the evaluation kernel that have no tiles on a coarse
+    level then look at a command late -- they must join at the command they find, and a replaced session's stragglers must leave at
+    once (before: records missing on the next fine level, idle limits, 10 frames/s).  Every loop ends on the lone loop's trajectory,
+    bit for bit, and the four together take about as long as their tracking calls one after the other."""
+    import threading
+    import time
+    frames, loops = 30, 4
+    rt = C.CDLL("libamdhip64.so")
+    rt.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+    rt.hipStreamDestroy.argtypes = [C.c_void_p]
+    sc0 = Scenario(name="loop", voxelSize=0.01, frames=frames)
+    depths = [hip.to_backend(sc0.depth(k)) for k in range(frames)]
+    _, want = closed_loop(hip, frames=frames, depths=depths)
+    handles, streams = [], []
+    try:
+        for _ in range(loops):
+            h = C.c_void_p(); hip.check(hip.fn["tracker_create"](C.byref(h)), "tracker_create"); handles.append(h)
+            st = C.c_void_p(); assert rt.hipStreamCreate(C.byref(st)) == 0; streams.append(st)
+        results, errors = [None] * loops, []
+        start = threading.Barrier(loops + 1)
+
+        def work(i):
+            try:
+                results[i] = closed_loop(hip, frames=frames, handle=handles[i], stream=streams[i], depths=depths, start=start)[1]
+            except Exception as e:      # noqa: BLE001 -- reported below, in the main thread
+                errors.append(e)
+                try:
+                    start.abort()
+                except Exception:       # noqa: BLE001
+                    pass
+
+        threads = [threading.Thread(target=work, args=(i,)) for i in range(loops)]
+        for t in threads:
+            t.start()
+        start.wait()
+        t0 = time.perf_counter()
+        for t in threads:
+            t.join()
+        elapsed = time.perf_counter() - t0
+        assert not errors, errors
+        for i in range(loops):
+            assert np.array_equal(results[i], want), (i, np.abs(results[i] - want).max())
+        assert elapsed < 1.5, f"{loops} loops x {frames} frames took {elapsed:.2f} s (about 0.05 s when the sessions hand over cleanly)"
+    finally:
+        hip.sync()
+        for h in handles:
+            hip.check(hip.fn["tracker_destroy"](h), "tracker_destroy")
+        for st in streams:
+            rt.hipStreamDestroy(st)
