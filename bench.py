@@ -76,6 +76,7 @@ def parse():
                     help="bracket the roofline kernel with HIP events on every n-th frame of the timed region")
     ap.add_argument("--lib", default=None, help="alternative shared library exporting the same C-ABI (tests: a host-memory backend)")
     ap.add_argument("--lib-prefix", default="itm_")
+    ap.add_argument("--debug-keys", default="", help="comma-separated itm_debug_set keys switched on for the run (A/B of a replaced code path; a marked line, not the headline)")
     return ap.parse_args()
 
 
@@ -176,6 +177,8 @@ def worker(args) -> int:
     from infinitam_amd import capi, synth
     be = capi.Backend(args.lib, args.lib_prefix) if args.lib else itm.load()
     product = args.lib is None
+    for key in [k for k in args.debug_keys.split(",") if k.strip()]:
+        be.check(be.fn["debug_set"](int(key), 1), "debug_set")
     on_gpu = be.on_device
     if on_gpu and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
@@ -348,7 +351,8 @@ def worker(args) -> int:
                                     if exchange else "none"),
                        "per_rank_fps_min_max": fps_minmax,
                        "visible_blocks_last_frame": counters["noVisibleEntries"],
-                       "timing_note": "value includes two hipEventRecord per frame around the roofline kernel on rank 0",
+                       "timing_note": f"value includes a hipEventRecord pair around the roofline kernel on every {args.timer_every}-th frame of rank 0",
+                       **({"debug_keys": args.debug_keys} if args.debug_keys else {}),
                        "backend": be.version()},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }

@@ -106,6 +106,9 @@ struct itm_render_state {
   int32_t* pixChunk = nullptr;    // int[ceil(h*w / kSweepChunk)]
   uint8_t* viewFlags = nullptr;   // FindVisibleBlocks: per-slot flags (uchar[numChunks * kSweepChunk]), allocated on first use
   int32_t* viewChunkVis = nullptr; // FindVisibleBlocks: visible slots per chunk
+  // itm_process_frame on images too large for the fused projection: the projection runs beside the integration (visualise.hip)
+  hipStream_t sideStream = nullptr;
+  hipEvent_t listReady = nullptr, projectionDone = nullptr;
 };
 
 namespace itm {

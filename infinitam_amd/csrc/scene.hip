@@ -286,6 +286,9 @@ static void free_rs(itm_render_state* r) {
   (void)hipFree(r->range); (void)hipFree(r->raycast); (void)hipFree(r->fwdProj); (void)hipFree(r->missing);
   (void)hipFree(r->image); (void)hipFree(r->visibleIds); (void)hipFree(r->visibleType); (void)hipFree(r->counters);
   (void)hipFree(r->projBuf); (void)hipFree(r->rangePartials); (void)hipFree(r->pixScratch); (void)hipFree(r->pixChunk); (void)hipFree(r->viewFlags); (void)hipFree(r->viewChunkVis);
+  if (r->sideStream) { (void)hipStreamSynchronize(r->sideStream); (void)hipStreamDestroy(r->sideStream); }
+  if (r->listReady) (void)hipEventDestroy(r->listReady);
+  if (r->projectionDone) (void)hipEventDestroy(r->projectionDone);
   delete r;
 }
 

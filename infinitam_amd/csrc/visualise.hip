@@ -38,6 +38,7 @@ int g_debug_no_directory = 0;
 int g_debug_no_sdf_mirror = 0;      // debug key 12: ray casting reads voxels through the directory / table although the scene has an sdf mirror
 int g_debug_no_fused_range_reduce = 0;
 int g_debug_single_pass_raycast = 0;
+int g_debug_no_side_projection = 0;
 
 // ---------------------------------------------------------------------------------------------
 // expected depth range
@@ -151,6 +152,57 @@ bool can_fuse_projection(const itm_scene* s, const itm_render_state* rs) {
   return !g_debug_no_fused_projection && s->cfg.indexType == ITM_INDEX_HASH && ldsBytes <= 39 * 1024 && rs->rangePartials && !g_debug_force_global_range;
 }
 
+static int ensure_range_lds(const itm_scene* s) {
+  // per device (a function attribute belongs to the code object loaded on ONE device)
+  static bool attrSet[64] = {};
+  const int dev = (s->device >= 0 && s->device < 64) ? s->device : 0;
+  if (!attrSet[dev]) {
+    ITM_HIP(hipFuncSetAttribute((const void*)project_partial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    ITM_HIP(hipFuncSetAttribute((const void*)range_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    attrSet[dev] = true;
+  }
+  return ITM_OK;
+}
+
+static ProjParams make_proj_params(const itm_scene* s, const float* M, const float* intr, const itm_render_state* rs) {
+  ProjParams p;
+  memcpy(p.M.m, M, 64);
+  p.fx = intr[0]; p.fy = intr[1]; p.cx = intr[2]; p.cy = intr[3];
+  p.voxelSize = s->prm.voxelSize;
+  p.W = rs->w; p.H = rs->h;
+  p.maxBlocks = s->cfg.maxRenderingBlocks;
+  return p;
+}
+
+// The projection half of CreateExpectedDepths beside the integration instead of after it, for images whose sub-sampled range
+// image is too large for the fused launch (can_fuse_projection: 1280x960 needs 150 KB of LDS per projecting workgroup): it
+// depends on the visible list only, so it runs on a stream of the render state's own between the allocation and the reduction --
+// 28 us of config 5's frame that used to sit between the integration and the ray cast.  Returns 1 when it was launched (the caller
+// then passes projected = true to launch_expected_depths), 0 when this path does not apply, < 0 on error.
+int launch_projection_beside(const itm_scene* s, const float* M, const float* intr, itm_render_state* rs, hipStream_t st) {
+  if (s->cfg.indexType != ITM_INDEX_HASH || g_debug_force_global_range || g_debug_no_side_projection || !rs->rangePartials) return 0;
+  const int RW = (rs->w + 7) / 8, RH = (rs->h + 7) / 8;
+  const size_t ldsBytes = (size_t)RW * RH * sizeof(uint2);
+  if (ldsBytes > 150 * 1024) return 0;
+  if (!rs->sideStream) {
+    if (hipStreamCreateWithFlags(&rs->sideStream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&rs->listReady, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&rs->projectionDone, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      if (rs->sideStream) { (void)hipStreamDestroy(rs->sideStream); rs->sideStream = nullptr; }
+      return 0;
+    }
+  }
+  int rc = ensure_range_lds(s);
+  if (rc) return rc;
+  const ProjParams p = make_proj_params(s, M, intr, rs);
+  ITM_HIP(hipEventRecord(rs->listReady, st));
+  ITM_HIP(hipStreamWaitEvent(rs->sideStream, rs->listReady, 0));
+  project_partial_kernel<<<kRangeParts, 512, ldsBytes, rs->sideStream>>>(rs->visibleIds, rs->counters, s->hash, rs->range, rs->projBuf, rs->rangePartials, p, RW, RH);
+  ITM_LAUNCH_CHECK();
+  ITM_HIP(hipEventRecord(rs->projectionDone, rs->sideStream));
+  return 1;
+}
+
 // `projected`: project_partial already ran inside the integration launch, only the reduction is left
 int launch_expected_depths(const itm_scene* s, const float* M, const float* intr, itm_render_state* rs, bool rangeAlreadyInit, hipStream_t st, bool projected) {
   const int P = rs->w * rs->h;
@@ -160,25 +212,14 @@ int launch_expected_depths(const itm_scene* s, const float* M, const float* intr
     ITM_LAUNCH_CHECK();
     return ITM_OK;
   }
-  ProjParams p;
-  memcpy(p.M.m, M, 64);
-  p.fx = intr[0]; p.fy = intr[1]; p.cx = intr[2]; p.cy = intr[3];
-  p.voxelSize = s->prm.voxelSize;
-  p.W = rs->w; p.H = rs->h;
-  p.maxBlocks = s->cfg.maxRenderingBlocks;
+  const ProjParams p = make_proj_params(s, M, intr, rs);
   if (!rangeAlreadyInit) range_init_kernel<<<512, 256, 0, st>>>(rs->range, P, 999999.9f, 0.05f, rs->counters);
   const int RW = (rs->w + 7) / 8, RH = (rs->h + 7) / 8;
   const size_t ldsBytes = (size_t)RW * RH * sizeof(uint2);
   const bool forceGlobal = g_debug_force_global_range != 0;  // test hook for the fallback path
   if (ldsBytes <= 150 * 1024 && !forceGlobal && rs->rangePartials) {
-    // per device (a function attribute belongs to the code object loaded on ONE device)
-    static bool attrSet[64] = {};
-    const int dev = (s->device >= 0 && s->device < 64) ? s->device : 0;
-    if (!attrSet[dev]) {
-      ITM_HIP(hipFuncSetAttribute((const void*)project_partial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-      ITM_HIP(hipFuncSetAttribute((const void*)range_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-      attrSet[dev] = true;
-    }
+    int rc = ensure_range_lds(s);
+    if (rc) return rc;
     if (!projected) project_partial_kernel<<<kRangeParts, 512, ldsBytes, st>>>(rs->visibleIds, rs->counters, s->hash, rs->range, rs->projBuf, rs->rangePartials, p, RW, RH);
     range_reduce_kernel<<<(RW * RH + 255) / 256, 256, ldsBytes, st>>>(rs->counters, rs->range, rs->projBuf, rs->rangePartials, p, RW, RH);
   } else {
@@ -499,6 +540,7 @@ int itm_debug_set(int key, int value) {
   if (key == ITM_DEBUG_TRACKER_HOST_COMMAND) { g_debug_tracker_host_command = value; return ITM_OK; }
   if (key == ITM_DEBUG_NO_SDF_MIRROR) { g_debug_no_sdf_mirror = value; return ITM_OK; }
   if (key == ITM_DEBUG_SEPARATE_SWEEP) { g_debug_separate_sweep = value; return ITM_OK; }
+  if (key == ITM_DEBUG_NO_SIDE_PROJECTION) { g_debug_no_side_projection = value; return ITM_OK; }
   return set_error(ITM_ERR_INVALID, "unknown debug key");
 }
 
@@ -542,11 +584,15 @@ int itm_process_frame(itm_scene* s, const itm_view* v, itm_render_state* rs, flo
   const bool hashScene = s->cfg.indexType == ITM_INDEX_HASH;
   if (hashScene && (rc = launch_allocate(s, v, rs, false, true, st))) return rc;
   const bool fuse = hashScene && can_fuse_projection(s, rs);
+  // too large to ride in the integration launch: on the render state's side stream, beside the integration
+  int beside = 0;
+  if (hashScene && !fuse && (beside = launch_projection_beside(s, v->M_d, v->intr_d, rs, st)) < 0) return beside;
   if ((rc = launch_integrate(s, v, rs, st, fuse))) return rc;
+  if (beside) ITM_HIP(hipStreamWaitEvent(st, rs->projectionDone, 0));
   // with the projection done inside the integration launch, the ray-cast workgroups reduce the partial range images of their
   // own cells (raycast_kernel<.., REDUCE>); otherwise CreateExpectedDepths runs as its own launches
   const bool reduceInRaycast = fuse && !g_debug_no_fused_range_reduce;
-  if (!reduceInRaycast && (rc = launch_expected_depths(s, v->M_d, v->intr_d, rs, hashScene, st, fuse))) return rc;
+  if (!reduceInRaycast && (rc = launch_expected_depths(s, v->M_d, v->intr_d, rs, hashScene, st, fuse || beside))) return rc;
   return launch_icp_maps(s, v, rs, (float4*)points, (float4*)normals, st, reduceInRaycast);
 }
 

@@ -77,6 +77,21 @@ def test_fused_frame_with_separate_range_reduction(hip, oracle, sc):
     T.compare_results(a, T.run_scenario(oracle, sc), sc, what=sc.name + "/fused, separate reduce")
 
 
+def test_large_image_projection_beside_and_after_the_integration(hip, oracle):
+    """1280x960: the sub-sampled range image is too large for the fused launch, so itm_process_frame projects the visible blocks on
+    the render state's own stream beside the integration (default) -- or after it on the frame's stream (ITM_DEBUG_NO_SIDE_PROJECTION,
+    14).  Both equal the oracle, frame after frame (5 frames: the side stream and its events are reused)."""
+    sc = Scenario(name="large_image_side_projection", w=1280, h=960, voxelSize=0.004, frames=5, trajectory="bench", localBlockNum=0x20000)
+    want = T.run_scenario(oracle, sc)
+    T.compare_results(T.run_scenario(hip, sc, fused=True), want, sc, what="projection beside the integration")
+    hip.check(hip.fn["debug_set"](14, 1), "debug_set")
+    try:
+        a = T.run_scenario(hip, sc, fused=True)
+    finally:
+        hip.check(hip.fn["debug_set"](14, 0), "debug_set")
+    T.compare_results(a, want, sc, what="projection after the integration")
+
+
 @pytest.mark.parametrize("sc", [SCENARIOS[0], SCENARIOS[-1]], ids=lambda s: s.name)
 def test_range_image_global_atomic_path(hip, oracle, sc):
     """The fallback used when the range image does not fit LDS (and its cap replay)."""
