@@ -175,6 +175,7 @@ int ITM_FN(set_device)(int device);
 #define ITM_DEBUG_TRACKER_HOST_COMMAND 11     /* TrackCamera session: commands through pinned host memory (set before the tracker's first call) */
 #define ITM_DEBUG_SEPARATE_SWEEP 13           /* AllocateSceneFromDepth: allocation sweep as its own launch, not inside the visible-list launch */
 #define ITM_DEBUG_NO_SIDE_PROJECTION 14       /* itm_process_frame on large images: projection of the visible blocks after the integration on the frame's stream, not beside it on the render state's own */
+#define ITM_DEBUG_DENSE_RANGE_REFILL 15       /* dense scenes: write the constant expected-depth image on every frame, as the reference does, although it already holds it */
 #define ITM_DEBUG_NO_SDF_MIRROR 12            /* ray casting: voxels through the directory / table although the scene has an sdf mirror; set before itm_scene_create: no mirror is allocated */
 int ITM_FN(debug_set)(int key, int value);
 /* Test hook (host only): rows [rlo, rhi] of the column of 4-voxel groups (x0 .. x0 + 3, slice z) that the dense integration visits for

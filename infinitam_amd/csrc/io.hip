@@ -224,6 +224,7 @@ int itm_scene_save(const itm_scene* s, const itm_render_state* rs, const char* d
 int itm_scene_load(itm_scene* s, itm_render_state* rs, const char* dir, itm_stream stream) {
   if (!s || !dir) return fail("null argument");
   if (rs && rs->scene != s) return fail("render state belongs to another scene");
+  if (rs) rs->denseRangeReady = false;
   const std::string d = std::string(dir) + "/";
   char cfg[sizeof(itm_scene_config) + sizeof(itm_scene_params)];
   int rc = load_block(d + "config.dat", cfg, sizeof cfg, 1);

@@ -106,6 +106,10 @@ struct itm_render_state {
   int32_t* pixChunk = nullptr;    // int[ceil(h*w / kSweepChunk)]
   uint8_t* viewFlags = nullptr;   // FindVisibleBlocks: per-slot flags (uchar[numChunks * kSweepChunk]), allocated on first use
   int32_t* viewChunkVis = nullptr; // FindVisibleBlocks: visible slots per chunk
+  // dense scenes: the expected-depth image is the constant (0.2, 3.0) of ITMVisualisationEngine_CPU<TVoxel, ITMPlainVoxelArray>::
+  // CreateExpectedDepths and the rendering-block counters are its constants too; true once a launch has written them and nothing
+  // else has touched them since (uploads, set_counters and loads clear it), so later frames skip the refill
+  bool denseRangeReady = false;
   // itm_process_frame on images too large for the fused projection: the projection runs beside the integration (visualise.hip)
   hipStream_t sideStream = nullptr;
   hipEvent_t listReady = nullptr, projectionDone = nullptr;

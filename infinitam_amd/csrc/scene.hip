@@ -559,6 +559,7 @@ int itm_get_counters(const itm_scene* s, const itm_render_state* rs, itm_counter
 
 int itm_set_counters(itm_scene* s, itm_render_state* rs, const itm_counters* in, itm_stream stream) {
   if (!in) return set_error(ITM_ERR_INVALID, "null argument");
+  if (rs) rs->denseRangeReady = false;
   hipStream_t st = as_stream(stream);
   if (s) {
     SceneCounters sc{};
@@ -604,6 +605,7 @@ int itm_upload(itm_scene* s, itm_render_state* rs, int which, const void* src, s
   if (which == ITM_BUF_HASH_ENTRIES) { int rc = rebuild_head_bits(s, st); if (rc) return rc; }
   if (which == ITM_BUF_HASH_ENTRIES || which == ITM_BUF_VOXEL_BLOCKS) { int rc = rebuild_sdf_mirror(s, st); if (rc) return rc; }   // whichever comes last leaves it consistent
   if (rs && (which == ITM_BUF_VISIBLE_IDS || which == ITM_BUF_VISIBLE_TYPE)) rs->listCoherent = false;
+  if (rs) rs->denseRangeReady = false;
   ITM_HIP(hipStreamSynchronize(st));
   return ITM_OK;
 }

@@ -39,6 +39,7 @@ int g_debug_no_sdf_mirror = 0;      // debug key 12: ray casting reads voxels th
 int g_debug_no_fused_range_reduce = 0;
 int g_debug_single_pass_raycast = 0;
 int g_debug_no_side_projection = 0;
+int g_debug_dense_range_refill = 0;
 
 // ---------------------------------------------------------------------------------------------
 // expected depth range
@@ -208,8 +209,10 @@ int launch_expected_depths(const itm_scene* s, const float* M, const float* intr
   const int P = rs->w * rs->h;
   KernelTimer tk(s, ITM_TK_RANGE, st);
   if (s->cfg.indexType == ITM_INDEX_DENSE) {
+    if (rs->denseRangeReady && !g_debug_dense_range_refill) return ITM_OK;        // the image already holds the constant (5 us per frame of config 3)
     range_init_kernel<<<512, 256, 0, st>>>(rs->range, P, 0.2f, 3.0f, rs->counters);
     ITM_LAUNCH_CHECK();
+    rs->denseRangeReady = true;
     return ITM_OK;
   }
   const ProjParams p = make_proj_params(s, M, intr, rs);
@@ -541,6 +544,7 @@ int itm_debug_set(int key, int value) {
   if (key == ITM_DEBUG_NO_SDF_MIRROR) { g_debug_no_sdf_mirror = value; return ITM_OK; }
   if (key == ITM_DEBUG_SEPARATE_SWEEP) { g_debug_separate_sweep = value; return ITM_OK; }
   if (key == ITM_DEBUG_NO_SIDE_PROJECTION) { g_debug_no_side_projection = value; return ITM_OK; }
+  if (key == ITM_DEBUG_DENSE_RANGE_REFILL) { g_debug_dense_range_refill = value; return ITM_OK; }
   return set_error(ITM_ERR_INVALID, "unknown debug key");
 }
 

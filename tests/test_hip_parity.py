@@ -77,6 +77,29 @@ def test_fused_frame_with_separate_range_reduction(hip, oracle, sc):
     T.compare_results(a, T.run_scenario(oracle, sc), sc, what=sc.name + "/fused, separate reduce")
 
 
+def test_dense_scene_expected_depths_written_once_or_every_frame(hip, oracle):
+    """Plain voxel array: CreateExpectedDepths writes the constant (0.2, 3.0) image; the library writes it on the first frame and
+    leaves it alone afterwards (default) or rewrites it every frame like the reference (ITM_DEBUG_DENSE_RANGE_REFILL, 15); an
+    upload in between makes the next frame write it again.  Same results either way, equal to the oracle."""
+    sc = next(s for s in SCENARIOS if s.indexType == T.INDEX_DENSE)
+    want = T.run_scenario(oracle, sc)
+    T.compare_results(T.run_scenario(hip, sc, fused=True), want, sc, what="dense, range written once")
+    hip.check(hip.fn["debug_set"](15, 1), "debug_set")
+    try:
+        a = T.run_scenario(hip, sc, fused=True)
+    finally:
+        hip.check(hip.fn["debug_set"](15, 0), "debug_set")
+    T.compare_results(a, want, sc, what="dense, range rewritten every frame")
+    # a foreign range image uploaded between two frames must not survive the next frame
+    ses = T.Session(hip, sc)
+    ses.frame(0, fused=True)
+    good = ses.scene.download(T.capi.BUF_RANGE_IMAGE, ses.rs)
+    ses.scene.upload(T.capi.BUF_RANGE_IMAGE, np.full_like(good, 7.5), ses.rs)
+    ses.frame(1, fused=True)
+    assert np.array_equal(ses.scene.download(T.capi.BUF_RANGE_IMAGE, ses.rs), good)
+    ses.close()
+
+
 def test_large_image_projection_beside_and_after_the_integration(hip, oracle):
     """1280x960: the sub-sampled range image is too large for the fused launch, so itm_process_frame projects the visible blocks on
     the render state's own stream beside the integration (default) -- or after it on the frame's stream (ITM_DEBUG_NO_SIDE_PROJECTION,
