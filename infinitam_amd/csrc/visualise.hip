@@ -595,7 +595,7 @@ int itm_process_frame(itm_scene* s, const itm_view* v, itm_render_state* rs, flo
   if (beside) ITM_HIP(hipStreamWaitEvent(st, rs->projectionDone, 0));
   // with the projection done inside the integration launch, the ray-cast workgroups reduce the partial range images of their
   // own cells (raycast_kernel<.., REDUCE>); otherwise CreateExpectedDepths runs as its own launches
-  const bool reduceInRaycast = fuse && !g_debug_no_fused_range_reduce;
+  const bool reduceInRaycast = (fuse || beside) && !g_debug_no_fused_range_reduce;
   if (!reduceInRaycast && (rc = launch_expected_depths(s, v->M_d, v->intr_d, rs, hashScene, st, fuse || beside))) return rc;
   return launch_icp_maps(s, v, rs, (float4*)points, (float4*)normals, st, reduceInRaycast);
 }
