@@ -457,7 +457,33 @@ __device__ inline float4 march_ray(int x, int y, const VolumeView& vol, const Ra
     return next;
   };
   ITM_WT(const unsigned long long wtStart = wt_clock(); unsigned wtOuter = 0;)
+  bool missed = false;      // DENSE: the last single-voxel read found no voxel
   while (st != DONE) {
+    if constexpr (DENSE) {
+      // A ray that has LEFT the volume -- outside on an axis along which it moves away -- never comes back (its coordinate on that
+      // axis only grows in magnitude, additions of one sign are monotone in float arithmetic too, and so is the rounding of the
+      // look-up): every further read finds nothing and the reference takes its 8-voxel step until the range ends.  Once every lane
+      // of the wave is done or gone, those steps are taken here without the look-ups: the same additions in the same order, ~6
+      // instructions instead of ~35 per step (BASELINE configs[2]: the wall lies behind the volume, its rays take ~30 such steps).
+      if (__any(missed)) {
+        bool gone = false;
+        if (st == MARCH && missed) {
+          const int ix = (int)round_ref(px) - vol.ox, iy = (int)round_ref(py) - vol.oy, iz = (int)round_ref(pz) - vol.oz;
+          gone = (ix >= vol.sx && dx >= 0.0f) || (ix < 0 && dx <= 0.0f) || (iy >= vol.sy && dy >= 0.0f) || (iy < 0 && dy <= 0.0f) ||
+                 (iz >= vol.sz && dz >= 0.0f) || (iz < 0 && dz <= 0.0f);
+        }
+        if (__all(st == DONE || gone)) {
+          const float step = (float)kBlockSide;
+          const float sx = step * dx, sy = step * dy, sz = step * dz;        // the products of advance(false, .)
+          while (st == MARCH) {
+            px += sx; py += sy; pz += sz;
+            total += step;
+            if (!(total < totalMax)) st = DONE;
+          }
+          break;
+        }
+      }
+    }
     ITM_WT(const unsigned long long wt0 = wt_clock(); unsigned wtInner = 0; const unsigned wtLanes0 = __popcll(__ballot(1)); const unsigned wtMarch0 = __popcll(__ballot(st == MARCH));)
     // ---- cheap phase: at most ITM_RAY_MARCH_BURST single-voxel steps, so that waiting lanes are served regularly ----
     int budget = ITM_RAY_MARCH_BURST;
@@ -467,6 +493,7 @@ __device__ inline float4 march_ray(int x, int y, const VolumeView& vol, const Ra
       const float sdf = sdf_nearest<VX, DENSE>(vol, px, py, pz, found, cache);
       if (found && (sdf <= 0.1f) && (sdf >= -0.5f)) st = TRI;      // the position is kept for the trilinear read
       else st = advance(found, sdf);
+      if constexpr (DENSE) missed = !found;
       if constexpr (DENSE && LOOKAHEAD > 0) {
         const bool far = st == MARCH && found && sdf == 1.0f;      // SDF_valueToFloat(32767) is exactly 1
         if (__any(far)) {
