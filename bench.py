@@ -28,6 +28,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -235,7 +236,27 @@ def worker(args) -> int:
                 if not any(uid):
                     break
             try:
-                exs.append(NativeExchange(be, world, rank, MAX_IDS, batch=max(1, args.exchange_batch), unique_id=uid))
+                # communicator creation is a rendezvous of all ranks inside RCCL: bounded here (a daemon thread with this rank's device
+                # current), so that a rank that cannot complete it reports failure and every rank takes the torch path instead of
+                # the whole run hanging
+                box = {}
+
+                def make_exchange(uid=uid, box=box):
+                    try:
+                        if on_gpu:
+                            torch.cuda.set_device(device)
+                        box["ex"] = NativeExchange(be, world, rank, MAX_IDS, batch=max(1, args.exchange_batch), unique_id=uid)
+                    except Exception as e:      # noqa: BLE001
+                        box["err"] = e
+
+                th = threading.Thread(target=make_exchange, daemon=True)
+                th.start()
+                th.join(float(os.environ.get("ITM_EXCHANGE_INIT_TIMEOUT", "120")))
+                if th.is_alive():
+                    raise TimeoutError("no RCCL communicator within the time limit")
+                if "err" in box:
+                    raise box["err"]
+                exs.append(box["ex"])
             except Exception as e:      # noqa: BLE001 -- reported below, every rank then takes the torch path together
                 print(f"bench.py: rank {rank}: library exchange unavailable ({e})", file=sys.stderr)
                 break
