@@ -125,3 +125,38 @@ def test_column_interval_never_excludes_a_voxel_the_exact_test_keeps(hip_host):
             kept_rows += int(inside.sum()); needed_rows += int(keep.sum()); checked += 1
     assert checked == len(poses) * 40 and needed_rows > 20000
     assert kept_rows < 1.6 * needed_rows + 4 * checked          # and the interval is tight: a few rows of slack per column
+
+
+def raycast_all(be):
+    """The volume of integrate_all seen again from every camera: CreateExpectedDepths + FindSurface, the hit maps of all cameras."""
+    W, H = 160, 120
+    s = be.create_scene(capi.VOXEL_S, capi.INDEX_DENSE, capi.default_params(voxelSize=0.008, mu=0.04), denseSize=(128, 128, 128), denseOffset=(-64, -64, 100))
+    s.reco.ResetScene()
+    rs = s.vis.CreateRenderState((W, H))
+    rng = np.random.default_rng(7)
+    intr = (145.0, 145.0, 80.0, 60.0)
+    for ang, pos in CAMERAS:
+        depth = ((5.0 if pos[2] < -1 else 1.0) + 0.5 * rng.random((H, W))).astype(F)
+        depth[::7, ::5] = 0.0
+        s.reco.IntegrateIntoScene(capi.View(be.to_backend(depth), W, H, M_d=pose(rotation(*ang), pos), intr_d=intr), rs)
+    hits = []
+    for ang, pos in CAMERAS:
+        M = pose(rotation(*ang), pos)
+        s.vis.CreateExpectedDepths(M, intr, rs)
+        s.vis.FindSurface(M, intr, rs)
+        hits.append(s.download(capi.BUF_RAYCAST_RESULT, rs).copy())
+    return hits
+
+
+@pytest.mark.gpu
+def test_dense_ray_cast_from_cameras_in_general_position(hip, oracle):
+    """Rays leave the dense volume through every face, start inside, beside and behind it: the wave-level shortcut for rays that
+    have left the volume (raycast_device.h) must reproduce the reference's remaining steps -- the end POSITION of a ray that finds
+    nothing is part of the result -- bit for bit."""
+    want = raycast_all(oracle)
+    got = raycast_all(hip)
+    found = 0
+    for i, (a, b) in enumerate(zip(want, got)):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "camera %d: %d components differ" % (i, int(np.count_nonzero(a.view(np.uint32) != b.view(np.uint32))))
+        found += int(np.count_nonzero(a.reshape(-1, 4)[:, 3] > 0))
+    assert found > 20000          # the cameras really hit the surface, and most rays leave without a hit
