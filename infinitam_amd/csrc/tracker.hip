@@ -350,8 +350,9 @@ __global__ void __launch_bounds__(kGHThreads) gh_partial_kernel(const float* __r
 // the workgroups stay resident for the duration of the call: the host writes a command (pose, level, mode) as tagged granules,
 // the first wave of every workgroup polls them -- the moment all carry the expected number the workgroup has the whole command --,
 // every workgroup accumulates its tiles, and answers with a tagged record: on coarse levels straight to pinned host memory (the host
-// adds the records in block order), on fine ones to device memory, where the LAST workgroup to arrive (device-scope counter) adds
-// the partials in block order -- the order the host uses, so the sums are bit-identical to the per-launch path -- and sends one record.
+// adds the records in the common order, kSegBlocks), on fine ones to device memory, where workgroup g < 8 collects the records of
+// segment g, adds them in block order and sends the segment's sums to the host, which adds the segments -- the same order again, so
+// the sums are bit-identical to the per-launch path.
 // The kernel cannot outlive its host: a workgroup leaves when no command has arrived for kSessionIdleTicks (2 ms on the 100 MHz
 // clock; workgroup 0, which reports the exit; the others have a longer limit) or when the host says so; a host that finds the
 // session gone starts another one at the pending sequence number (same stream: it begins when the old one has left entirely).
@@ -527,7 +528,7 @@ __global__ void __launch_bounds__(kGHThreads) gh_session_kernel(const unsigned l
 
 // ---- tracker object -------------------------------------------------------------------------------------
 // What ITMDepthTracker owns in the reference (Engine/ITMDepthTracker.cpp:18-44: the hierarchy and the device-side reduction
-// buffers of ITMDepthTracker_CUDA) lives in a handle here: device partials, the stamped records in pinned host memory, the
+// buffers of ITMDepthTracker_CUDA) lives in a handle here: the workgroups' records (device memory and pinned host memory), the command block, the
 // depth pyramid.  One handle = one tracker = one caller at a time (the handle's mutex serialises callers); the handle-less
 // entry points of round 1 use a handle private to the calling thread, so two host threads (or two streams driven by two
 // threads) never share records or sequence numbers.
