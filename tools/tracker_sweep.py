@@ -30,7 +30,7 @@ for size in ((640, 480), (328, 248), (208, 152)):
         cfg = TrackerConfig.default()
         levels = int(rng.integers(2, 6)) if min(size) >= 240 else int(rng.integers(2, 4))
         cfg.noHierarchyLevels = levels
-        regime = [3] * min(2, levels) + [1] * (levels - min(2, levels))
+        regime = [int(rng.integers(1, 4)) for _ in range(levels)]          # rotation only / translation only / both, any mix
         cfg.trackingRegime[:levels] = regime
         view = capi.View(d, sc.w, sc.h, M_d=M, intr_d=sc.intr()).struct()
         sp = np.ascontiguousarray(np.array(v.M_d, np.float32))
