@@ -17,26 +17,33 @@ namespace {
 
 enum Fmt { FMT_UNKNOWN, FMT_MONO8, FMT_RGB8, FMT_MONO16S, FMT_MONO16U };
 
-// identifier, width, height, maxval, one separator byte; maxval decides between 8 and 16 bit samples
+// Header of a PGM / PPM file as the reference's reader accepts it (Utils/FileUtils.cpp:125-172): magic "P2" / "P3" (ASCII samples) or
+// "P5" / "P6" (binary), then width, height and maxval as C integers ("%i": octal and hex are accepted as there), then ONE separator
+// byte.  maxval selects the sample type: up to 256 bytes; for grey images up to 32 768 signed and up to 65 536 unsigned 16-bit words.
 Fmt read_pnm_header(FILE* f, int* w, int* h, bool* binary) {
-  char id[1024];
-  if (fscanf(f, "%1023[^ \n\t]", id) != 1) return FMT_UNKNOWN;
-  Fmt t; bool bin = true;
-  if (!strcmp(id, "P5")) t = FMT_MONO8;
-  else if (!strcmp(id, "P2")) { t = FMT_MONO8; bin = false; }
-  else if (!strcmp(id, "P6")) t = FMT_RGB8;
-  else if (!strcmp(id, "P3")) { t = FMT_RGB8; bin = false; }
-  else return FMT_UNKNOWN;
-  int xs = 0, ys = 0, maxv = 0;
-  if (fscanf(f, "%i", &xs) != 1 || fscanf(f, "%i", &ys) != 1 || fscanf(f, "%i", &maxv) != 1) return FMT_UNKNOWN;
-  if (maxv < 0) return FMT_UNKNOWN;
-  if (maxv <= (1 << 8)) {}
-  else if (maxv <= (1 << 15) && t == FMT_MONO8) t = FMT_MONO16S;
-  else if (maxv <= (1 << 16) && t == FMT_MONO8) t = FMT_MONO16U;
-  else return FMT_UNKNOWN;
+  char magic[1024];
+  if (fscanf(f, "%1023[^ \n\t]", magic) != 1 || magic[0] != 'P' || magic[1] == '\0' || magic[2] != '\0') return FMT_UNKNOWN;
+  bool grey;
+  switch (magic[1]) {
+    case '2': grey = true; *binary = false; break;
+    case '5': grey = true; *binary = true; break;
+    case '3': grey = false; *binary = false; break;
+    case '6': grey = false; *binary = true; break;
+    default: return FMT_UNKNOWN;
+  }
+  int field[3] = {0, 0, 0};                         // width, height, maxval
+  for (int& v : field)
+    if (fscanf(f, "%i", &v) != 1) return FMT_UNKNOWN;
+  const int maxval = field[2];
+  if (maxval < 0) return FMT_UNKNOWN;
+  Fmt fmt = grey ? FMT_MONO8 : FMT_RGB8;
+  if (maxval > (1 << 8)) {
+    if (!grey || maxval > (1 << 16)) return FMT_UNKNOWN;
+    fmt = maxval <= (1 << 15) ? FMT_MONO16S : FMT_MONO16U;
+  }
   fgetc(f);
-  *w = xs; *h = ys; *binary = bin;
-  return t;
+  *w = field[0]; *h = field[1];
+  return fmt;
 }
 
 template <class T>

@@ -76,41 +76,36 @@ __device__ inline float raw_at(const VolumeView& vol, int x, int y, int z) {
   return read_raw_sdf<VX, DENSE>(vol, x, y, z, f, c);
 }
 
+// One component of the sdf gradient at a fractional position (computeSingleNormalFromSDF, DeviceAgnostic/ITMRepresentationAccess.h:
+// 187-252): along AXIS the volume is sampled on the four integer planes k = -1, 0, 1, 2 around the position, each plane blended
+// bilinearly over the other two axes (u, v: the remaining axes in x < y < z order); the component is the difference between the
+// linear blends of planes (1, 2) and of planes (0, -1).  The products and sums are the reference's, term for term:
+//   plane = s00 (1-fu)(1-fv) + s10 fu (1-fv) + s01 (1-fu) fv + s11 fu fv,   lower = plane0 fa + plane-1 (1-fa),   upper = plane1 (1-fa) + plane2 fa
+template <class VX, bool DENSE, int AXIS>
+__device__ inline float gradient_component(const VolumeView& vol, int ix, int iy, int iz, float fa, float fu, float fv) {
+  auto sample = [&](int k, int u, int v) {
+    const int dx = (AXIS == 0) ? k : u;
+    const int dy = (AXIS == 1) ? k : (AXIS == 0 ? u : v);
+    const int dz = (AXIS == 2) ? k : v;
+    return raw_at<VX, DENSE>(vol, ix + dx, iy + dy, iz + dz);
+  };
+  const float gu = 1.0f - fu, gv = 1.0f - fv, ga = 1.0f - fa;
+  float plane[4];
+#pragma unroll
+  for (int k = -1; k <= 2; ++k)
+    plane[k + 1] = sample(k, 0, 0) * gu * gv + sample(k, 1, 0) * fu * gv + sample(k, 0, 1) * gu * fv + sample(k, 1, 1) * fu * fv;
+  const float lower = plane[1] * fa + plane[0] * ga;
+  return VX::to_float(plane[2] * ga + plane[3] * fa - lower);
+}
+
 template <class VX, bool DENSE>
 __device__ inline void sdf_gradient(const VolumeView& vol, float px, float py, float pz, float& gx, float& gy, float& gz) {
-  const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
-  const float cx = px - flx, cy = py - fly, cz = pz - flz;
-  const int ix = (int)flx, iy = (int)fly, iz = (int)flz;
-  const float nx = 1.0f - cx, ny = 1.0f - cy, nz = 1.0f - cz;
-#define R(dx, dy, dz) raw_at<VX, DENSE>(vol, ix + (dx), iy + (dy), iz + (dz))
-  const float f000 = R(0, 0, 0), f100 = R(1, 0, 0), f010 = R(0, 1, 0), f110 = R(1, 1, 0);
-  const float f001 = R(0, 0, 1), f101 = R(1, 0, 1), f011 = R(0, 1, 1), f111 = R(1, 1, 1);
-  float p1, p2, v1, a, b, c, d;
-  p1 = f000 * ny * nz + f010 * cy * nz + f001 * ny * cz + f011 * cy * cz;
-  a = R(-1, 0, 0); b = R(-1, 1, 0); c = R(-1, 0, 1); d = R(-1, 1, 1);
-  p2 = a * ny * nz + b * cy * nz + c * ny * cz + d * cy * cz;
-  v1 = p1 * cx + p2 * nx;
-  p1 = f100 * ny * nz + f110 * cy * nz + f101 * ny * cz + f111 * cy * cz;
-  a = R(2, 0, 0); b = R(2, 1, 0); c = R(2, 0, 1); d = R(2, 1, 1);
-  p2 = a * ny * nz + b * cy * nz + c * ny * cz + d * cy * cz;
-  gx = VX::to_float(p1 * nx + p2 * cx - v1);
-  p1 = f000 * nx * nz + f100 * cx * nz + f001 * nx * cz + f101 * cx * cz;
-  a = R(0, -1, 0); b = R(1, -1, 0); c = R(0, -1, 1); d = R(1, -1, 1);
-  p2 = a * nx * nz + b * cx * nz + c * nx * cz + d * cx * cz;
-  v1 = p1 * cy + p2 * ny;
-  p1 = f010 * nx * nz + f110 * cx * nz + f011 * nx * cz + f111 * cx * cz;
-  a = R(0, 2, 0); b = R(1, 2, 0); c = R(0, 2, 1); d = R(1, 2, 1);
-  p2 = a * nx * nz + b * cx * nz + c * nx * cz + d * cx * cz;
-  gy = VX::to_float(p1 * ny + p2 * cy - v1);
-  p1 = f000 * nx * ny + f100 * cx * ny + f010 * nx * cy + f110 * cx * cy;
-  a = R(0, 0, -1); b = R(1, 0, -1); c = R(0, 1, -1); d = R(1, 1, -1);
-  p2 = a * nx * ny + b * cx * ny + c * nx * cy + d * cx * cy;
-  v1 = p1 * cz + p2 * nz;
-  p1 = f001 * nx * ny + f101 * cx * ny + f011 * nx * cy + f111 * cx * cy;
-  a = R(0, 0, 2); b = R(1, 0, 2); c = R(0, 1, 2); d = R(1, 1, 2);
-  p2 = a * nx * ny + b * cx * ny + c * nx * cy + d * cx * cy;
-  gz = VX::to_float(p1 * nz + p2 * cz - v1);
-#undef R
+  const float bx = floorf(px), by = floorf(py), bz = floorf(pz);
+  const float fx = px - bx, fy = py - by, fz = pz - bz;
+  const int ix = (int)bx, iy = (int)by, iz = (int)bz;
+  gx = gradient_component<VX, DENSE, 0>(vol, ix, iy, iz, fx, fy, fz);
+  gy = gradient_component<VX, DENSE, 1>(vol, ix, iy, iz, fy, fx, fz);
+  gz = gradient_component<VX, DENSE, 2>(vol, ix, iy, iz, fz, fx, fy);
 }
 
 template <class VX, bool DENSE>
