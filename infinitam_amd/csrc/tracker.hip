@@ -672,7 +672,6 @@ static int compute_g_and_h(itm_tracker* trk, const float* depth, int w, int h, c
   p.distThresh = distThresh; p.w = w; p.h = h; p.sceneW = sceneW; p.sceneH = sceneH; p.tileH = tileH;
   const float4* pm = (const float4*)pointsMap; const float4* nm = (const float4*)normalsMap;
   const int np = (iterationType == ITM_TRACKER_ITERATION_BOTH) ? 6 : 3;
-  const int nh = np * (np + 1) / 2;
   const unsigned int seq = trk->seq = next_seq(trk->seq);
   if (iterationType == 1) gh_partial_kernel<1><<<grid, kGHThreads, 0, st>>>(depth, pm, nm, p, trk->recDev, seq);
   else if (iterationType == 2) gh_partial_kernel<2><<<grid, kGHThreads, 0, st>>>(depth, pm, nm, p, trk->recDev, seq);
