@@ -37,6 +37,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MAX_IDS = 16384              # ids per exchanged visible-block record
 PERIOD = 100                 # the benchmark trajectory repeats every 100 frames
+DEBUG_KEYS_FALLBACK = {1: 5, 2: 12}          # include/itm_hip.h: ITM_DEBUG_NO_DIRECTORY, ITM_DEBUG_NO_SDF_MIRROR
 TK = {"request": 0, "alloc_sweep": 1, "visible_list": 2, "integrate": 3, "range": 4, "raycast": 5, "icp_maps": 6}
 
 WORKLOADS = {
@@ -75,6 +76,14 @@ def parse():
                     help="feed the k streams of --streams-per-gpu from one host thread instead of one thread per stream")
     ap.add_argument("--timer-every", type=int, default=8,
                     help="bracket the roofline kernel with HIP events on every n-th frame of the timed region")
+    ap.add_argument("--raw-depth", action="store_true",
+                    help="SURVEY 8d second figure as the run's value: each step uploads the 16-bit raw frame from pinned host memory "
+                         "(w*h*2 bytes over PCIe) and converts it with itm_update_view inside the timed region (never the headline)")
+    ap.add_argument("--origin-offset", default="0,0,0",
+                    help="X,Y,Z metres added to every camera position (scene and trajectory translated together: same depth images, "
+                         "block coordinates far from the world origin)")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the secondary measurements of the default run (PCIe-inclusive rate, table-walk ray cast, stream-copy peak)")
     ap.add_argument("--lib", default=None, help="alternative shared library exporting the same C-ABI (tests: a host-memory backend)")
     ap.add_argument("--lib-prefix", default="itm_")
     ap.add_argument("--debug-keys", default="", help="comma-separated itm_debug_set keys switched on for the run (A/B of a replaced code path; a marked line, not the headline)")
@@ -128,9 +137,10 @@ def launch_ranks(args) -> int:
 class Stream:
     """One depth stream: scene + render state + its frames resident in the backend's memory."""
 
-    def __init__(self, be, capi, synth, torch, wl, stream_id, device, hip_stream):
+    def __init__(self, be, capi, synth, torch, wl, stream_id, device, hip_stream, offset=(0.0, 0.0, 0.0), raw=False):
         import numpy as np
         w, h = wl["w"], wl["h"]
+        self.w, self.h, self.torch = w, h, torch
         vox = {"s": capi.VOXEL_S, "f_rgb": capi.VOXEL_F_RGB}[wl["voxel"]]
         idx = capi.INDEX_HASH if wl["index"] == "hash" else capi.INDEX_DENSE
         params = capi.default_params(voxelSize=wl["voxelSize"], mu=wl["mu"], stopIntegratingAtMaxW=wl["stopAtMax"])
@@ -146,7 +156,8 @@ class Stream:
         self.points = torch.empty((h, w, 4), dtype=torch.float32, device=device)
         self.normals = torch.empty((h, w, 4), dtype=torch.float32, device=device)
         self.rgb = torch.from_numpy(synth.rgb_frame(w, h)).to(device) if wl["colour"] else None
-        self.poses = [synth.pose_matrix(synth.bench_position(k, stream_id)) for k in ks]
+        off = [np.float32(v) for v in offset]
+        self.poses = [synth.pose_matrix([np.float32(p) + o for p, o in zip(synth.bench_position(k, stream_id), off)]) for k in ks]
         self.views = [capi.View(self.depth[i].data_ptr(), w, h, M_d=self.poses[i], intr_d=intr,
                                 rgb=(self.rgb.data_ptr() if self.rgb is not None else None), w_rgb=w, h_rgb=h, intr_rgb=intr).struct()
                       for i in range(nd)]
@@ -156,6 +167,29 @@ class Stream:
         self.sp = C.c_void_p(hip_stream.cuda_stream if hip_stream is not None else None)
         self.sh, self.rh = C.c_void_p(self.scene.h), C.c_void_p(self.rs.h)
         self.pp, self.np_ = C.c_void_p(self.points.data_ptr()), C.c_void_p(self.normals.data_ptr())
+        self.raw_ready = False
+        self.intr_c = (C.c_float * 4)(*intr)
+        self.synth, self.capi, self.intr, self.ks, self.device, self.stream_id = synth, capi, intr, ks, device, stream_id
+        if raw:
+            self.enable_raw()
+
+    def enable_raw(self):
+        """Raw 16-bit frames in pinned host memory + the buffers of itm_update_view; the views of this mode read the converted image."""
+        if self.raw_ready:
+            return
+        import numpy as np
+        torch, synth, capi, w, h = self.torch, self.synth, self.capi, self.w, self.h
+        raws = np.stack([synth.raw_depth_mm(w, h, synth.bench_position(k, self.stream_id), self.intr) for k in self.ks])
+        self.raw_host = torch.from_numpy(raws)
+        if self.device != "cpu":
+            self.raw_host = self.raw_host.pin_memory()
+        self.raw_dev = torch.empty((2, h, w), dtype=torch.int16, device=self.device)      # two upload slots
+        self.depth_conv = torch.empty((h, w), dtype=torch.float32, device=self.device)
+        self.scratch = torch.empty((h, w), dtype=torch.float32, device=self.device)
+        self.raw_views = [self.capi.View(self.depth_conv.data_ptr(), w, h, M_d=self.poses[i], intr_d=self.intr,
+                                         rgb=(self.rgb.data_ptr() if self.rgb is not None else None), w_rgb=w, h_rgb=h, intr_rgb=self.intr).struct()
+                          for i in range(self.nd)]
+        self.raw_ready = True
 
 
 def worker(args) -> int:
@@ -206,14 +240,17 @@ def worker(args) -> int:
         be.check(be.fn["set_device"](local_rank), "set_device")
 
     wl = WORKLOADS[args.config]
+    offset = tuple(float(v) for v in args.origin_offset.split(","))
+    assert len(offset) == 3, "--origin-offset X,Y,Z"
     k_streams = max(1, args.streams_per_gpu)
     streams = []
     for j in range(k_streams):
         hs = None
         if on_gpu:
             hs = torch.cuda.current_stream() if k_streams == 1 else torch.cuda.Stream()
-        streams.append(Stream(be, capi, synth, torch, wl, rank * k_streams + j, device, hs))
+        streams.append(Stream(be, capi, synth, torch, wl, rank * k_streams + j, device, hs, offset=offset, raw=args.raw_depth))
     fn = be.fn["process_frame"]
+    fn_view = be.fn["update_view"]
 
     exchange = (world > 1 and not args.no_exchange) or args.force_exchange
     exs = []
@@ -271,10 +308,28 @@ def worker(args) -> int:
         from infinitam_amd.streams import VisibleListExchange
         exs = [VisibleListExchange(be, world, rank, MAX_IDS, device=device, batch=max(1, args.exchange_batch)) for _ in streams]
 
+    mode = {"raw": args.raw_depth}
+
     def step_stream(j, k):
         s = streams[j]
         i = k % s.nd
-        rc = fn(s.sh, C.byref(s.views[i]), s.rh, s.pp, s.np_, s.sp)
+        if mode["raw"]:
+            # the frame as the sensor delivers it: 16-bit raw over PCIe from pinned memory, convertDepthAffineToFloat on the device,
+            # all on the frame's stream (two upload slots: the copy of frame k+1 may not overtake the conversion of frame k-1 -- it
+            # cannot, one stream -- the second slot only keeps the copy engine's writes away from the conversion's reads)
+            slot = s.raw_dev[k & 1]
+            if on_gpu:
+                with torch.cuda.stream(s.hip_stream):
+                    slot.copy_(s.raw_host[i], non_blocking=True)
+            else:
+                slot.copy_(s.raw_host[i])
+            rc = fn_view(C.c_void_p(slot.data_ptr()), s.w, s.h, 1, 0.001, 0.0, s.intr_c, 0, 0, C.c_void_p(s.depth_conv.data_ptr()),
+                         C.c_void_p(s.scratch.data_ptr()), None, None, s.sp)
+            if rc:
+                be.check(rc, "update_view")
+            rc = fn(s.sh, C.byref(s.raw_views[i]), s.rh, s.pp, s.np_, s.sp)
+        else:
+            rc = fn(s.sh, C.byref(s.views[i]), s.rh, s.pp, s.np_, s.sp)
         if rc:
             be.check(rc, "process_frame")
         if exchange:
@@ -350,6 +405,44 @@ def worker(args) -> int:
         roofline = read_roofline(args.config, wl, streams[0].scene, counters, args.timer_every)
         streams[0].scene.profile_enable(0)
 
+    # ---- secondary figures of the default single-GPU run (after the timed region; none of them is `value`) --------------------
+    extra = {}
+    if rank == 0 and world == 1 and product and k_streams == 1 and on_gpu and not exchange and not args.no_extra_legs and not args.raw_depth:
+        s0 = streams[0]
+        n2 = args.steps
+        # (1) SURVEY 8d's second figure: the frame arrives as 16-bit raw depth in pinned host memory; H2D copy + itm_update_view
+        #     (convertDepthAffineToFloat) inside the timed region
+        s0.enable_raw()
+        mode["raw"] = True
+        run(0, args.warmup); sync()
+        t1 = time.perf_counter()
+        run(args.warmup, args.warmup + n2); sync()
+        dt = time.perf_counter() - t1
+        mode["raw"] = False
+        extra["with_h2d_raw_depth"] = {"value": round(n2 / dt, 2), "unit": "frames/s", "steps": n2,
+                                       "what": f"per frame {wl['w'] * wl['h'] * 2} bytes of raw short depth from pinned host memory over PCIe + itm_update_view (affine conversion) + the same fused frame"}
+        # (2) the same roofline kernel when the acceleration structures (block directory, sdf mirror) do not answer -- blocks whose
+        #     cells are owned by other blocks, or a device without room for them -- i.e. on the reference's own table walk
+        if wl["index"] == "hash":
+            for key in (1, 2):                 # ITM_DEBUG_NO_DIRECTORY, ITM_DEBUG_NO_SDF_MIRROR
+                be.check(be.fn["debug_set"](DEBUG_KEYS_FALLBACK[key], 1), "debug_set")
+            run(0, args.warmup); sync()
+            s0.scene.profile_read(reset=True)
+            s0.scene.profile_enable(1 << timed_kernel)
+            s0.scene.profile_sample(1)
+            t1 = time.perf_counter()
+            run(args.warmup, args.warmup + n2); sync()
+            dt = time.perf_counter() - t1
+            prof = s0.scene.profile_read(reset=True)[wl["kernel"]]
+            s0.scene.profile_enable(0)
+            for key in (1, 2):
+                be.check(be.fn["debug_set"](DEBUG_KEYS_FALLBACK[key], 0), "debug_set")
+            extra["table_walk_fallback"] = {"value": round(n2 / dt, 2), "unit": "frames/s", "steps": n2,
+                                            "kernel_us": round(prof["total_ms"] * 1e3 / max(1, prof["calls"]), 2),
+                                            "what": "block directory and sdf mirror switched off: every look-up walks the hash table as the reference does (event pair on every launch)"}
+    if rank == 0 and world == 1 and product and on_gpu and roofline is not None and not args.no_extra_legs:
+        roofline["peak_measured"] = measured_stream_peak()
+
     cpu_baseline = None
     if rank == 0 and world == 1 and product and k_streams == 1 and not args.no_cpu_baseline:
         cpu_baseline = run_cpu_baseline(args.config, wl, args.cpu_frames)
@@ -372,10 +465,14 @@ def worker(args) -> int:
                                     if exchange else "none"),
                        "per_rank_fps_min_max": fps_minmax,
                        "visible_blocks_last_frame": counters["noVisibleEntries"],
+                       "origin_offset_m": list(offset),
+                       "input": ("16-bit raw depth from pinned host memory: H2D + itm_update_view inside the timed region" if args.raw_depth
+                                 else "float depth frames resident in HBM"),
                        "timing_note": f"value includes a hipEventRecord pair around the roofline kernel on every {args.timer_every}-th frame of rank 0",
                        **({"debug_keys": args.debug_keys} if args.debug_keys else {}),
                        "backend": be.version()},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
+            **extra,
         }
     for ex in exs:                     # communicators of the library exchange go before the process group they were bootstrapped over
         if hasattr(ex, "close"):
@@ -430,17 +527,36 @@ def read_roofline(config, wl, scene, counters, timer_every=1):
     alg = algorithmic_bytes(config, wl, counters)
     achieved = alg / avg_s / 1e9
     traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "traffic_r02.json")
-    if os.path.exists(tpath):
-        with open(tpath) as f:
-            t = json.load(f).get(f"config{config}")
-        if t:
-            traffic, traffic_src = t.get("hbm_bytes_per_launch"), t.get("source")
+    for tname in ("traffic_r03.json", "traffic_r02.json"):        # the newest PMC collection that has this config
+        tpath = os.path.join(ROOT, "profiles", tname)
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                t = json.load(f).get(f"config{config}")
+            if t:
+                traffic, traffic_src = t.get("hbm_bytes_per_launch"), t.get("source")
+                break
     kname = {2: "raycast_kernel<VoxelS,hash>", 3: "integrate_dense_s_x4_kernel", 5: "integrate_hash_kernel<VoxelFRgb>"}[config]
     return {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            # the same fraction on the bytes the kernel really moved (PMC counters of a separate pass) instead of the reference algorithm's
+            "frac_traffic": (round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
             "algorithmic_bytes_per_launch": round(alg), "avg_kernel_us": round(avg_s * 1e6, 2),
             "launches_timed": r["calls"], "timer_every": timer_every}
+
+
+def measured_stream_peak():
+    """The device-stream-copy peak of THIS box beside the 8.0 TB/s vendor figure: tools/microbench/stream_copy (built by
+    __graft_entry__.build(), a child process) streams 2 GiB buffers; None when the binary is not there."""
+    exe = os.path.join(ROOT, "tools", "microbench", "stream_copy")
+    if not os.path.exists(exe):
+        return None
+    try:
+        r = subprocess.run([exe, "2048"], capture_output=True, timeout=120, text=True)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        return {"read_GBs": d["read_GBs"], "copy_GBs": d["copy_GBs"], "fill_GBs": d["fill_GBs"], "unit": "GB/s",
+                "what": "tools/microbench/stream_copy: best of 5 streaming launches over 2 GiB buffers (read-only / read+write / write-only)"}
+    except Exception as e:      # noqa: BLE001 -- a missing figure, not a failed run
+        return {"error": str(e)[:200]}
 
 
 # -------------------------------------------------------------------------------------------------------------

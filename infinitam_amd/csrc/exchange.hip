@@ -4,8 +4,12 @@
 // A scene never reads another stream's data, so N streams shard one per GPU with no collective on the fusion path.  What every
 // rank publishes per frame is one fixed-size record { float M_d[16]; int32 noVisibleEntries; int32 ids[max_ids] (padded with -1) },
 // written on the FRAME stream by a 3 us copy kernel right behind the frame's kernels (itm_export_visible_record).  Every `batch`
-// frames the records of the batch are all-gathered with RCCL on a SIDE stream that waits for the last copy; the frame stream only
-// ever waits for the collective that used the same batch buffer two batches earlier.  RCCL has no all-gather-v, hence the fixed
+// frames the records of the batch are all-gathered with RCCL on a SIDE stream that waits for the last copy.  The batch buffers form
+// a ring of four; before a buffer is written again the HOST checks that the collective which last read it has finished (it used the
+// buffer four batches earlier: the check returns at once unless the host runs that far ahead of the GPU) -- the frame stream itself
+// never waits for a collective.  The one event recorded on the frame stream per batch uses a DEVICE-scope release: the default
+// system-scope release of hipEventRecord writes back the L2s, and the next frame's kernels then start on cold caches (measured:
+// per-frame exchange 8.0 k frames/s against 11.2 k without exchange, whoever performed the collective).  RCCL has no all-gather-v, hence the fixed
 // record size.  xGMI is point-to-point, so one 64 KB x batch all-gather per GPU is latency bound; batching trades record age
 // (at most `batch` frames) for fewer collectives.
 //
@@ -13,7 +17,9 @@
 // has no link-time dependency on it.  The communicator is bootstrapped from a 128-byte id that rank 0 obtains from
 // itm_exchange_unique_id and the host distributes by whatever channel it has (a file, MPI, torch.distributed ...).
 #include <dlfcn.h>
+#include <rccl/rccl.h>              // types and prototypes only: the entry points are resolved with dlsym, nothing links against RCCL
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -24,18 +30,18 @@ namespace itm {
 
 constexpr int kRecordHeader = 17;   // 16 floats of pose + the count
 
-// the handful of RCCL entry points used, resolved at run time (signatures: rccl/rccl.h)
+// the handful of RCCL entry points used, resolved at run time; their types are the header's own declarations, so a
+// signature that drifts in a later RCCL fails to compile here instead of misbehaving on the 8-GPU node
 struct Rccl {
-  typedef struct { char internal[128]; } UniqueId;
-  int (*GetUniqueId)(UniqueId*) = nullptr;
-  int (*CommInitRank)(void** comm, int nranks, UniqueId id, int rank) = nullptr;
-  int (*CommDestroy)(void* comm) = nullptr;
-  int (*AllGather)(const void* send, void* recv, size_t count, int datatype, void* comm, hipStream_t stream) = nullptr;
-  const char* (*GetErrorString)(int) = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
   void* lib = nullptr;
   bool ok = false;
 };
-constexpr int kNcclInt32 = 2;       // ncclInt32 / ncclInt (rccl.h ncclDataType_t)
+static_assert(sizeof(ncclUniqueId) == 128, "itm_exchange_unique_id hands out 128 bytes");
 
 static void load_rccl(Rccl& r);
 static Rccl& rccl() {
@@ -56,7 +62,7 @@ static void load_rccl(Rccl& r) {
   r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.GetErrorString;
 }
 
-static int rccl_fail(int code, const char* what) {
+static int rccl_fail(ncclResult_t code, const char* what) {
   char msg[256];
   snprintf(msg, sizeof msg, "%s: %s", what, rccl().GetErrorString ? rccl().GetErrorString(code) : "RCCL error");
   return set_error(ITM_ERR_DEVICE, msg);
@@ -67,12 +73,13 @@ static int rccl_fail(int code, const char* what) {
 struct itm_exchange {
   int world = 1, rank = 0, maxIds = 0, batch = 1;
   size_t words = 0;                       // per record
-  void* comm = nullptr;                   // ncclComm_t; null when world == 1 (a device copy stands in for the collective)
-  int32_t* buffers[2] = {nullptr, nullptr};   // batch records each (ping-pong)
+  ncclComm_t comm = nullptr;              // a communicator for EVERY world size, one rank included; null only behind ITM_EXCHANGE_DEVICE_COPY=1 (debug)
+  static constexpr int kRing = 4;
+  int32_t* buffers[kRing] = {};           // batch records each
   int32_t* gathered = nullptr;            // world x batch records: rank-major, then frame of the batch
   hipStream_t side = nullptr;
-  hipEvent_t copied[2] = {nullptr, nullptr}, released[2] = {nullptr, nullptr};
-  bool inFlight[2] = {false, false};
+  hipEvent_t copied[kRing] = {}, released[kRing] = {};
+  bool inFlight[kRing] = {};
   long long frame = 0;
 };
 
@@ -82,7 +89,7 @@ static void free_exchange(itm_exchange* x) {
   if (!x) return;
   if (x->side) (void)hipStreamSynchronize(x->side);
   if (x->comm) rccl().CommDestroy(x->comm);
-  for (int b = 0; b < 2; ++b) {
+  for (int b = 0; b < itm_exchange::kRing; ++b) {
     if (x->buffers[b]) (void)hipFree(x->buffers[b]);
     if (x->copied[b]) (void)hipEventDestroy(x->copied[b]);
     if (x->released[b]) (void)hipEventDestroy(x->released[b]);
@@ -97,8 +104,8 @@ extern "C" {
 int itm_exchange_unique_id(unsigned char id[128]) {
   if (!id) return set_error(ITM_ERR_INVALID, "null argument");
   if (!rccl().ok) return set_error(ITM_ERR_DEVICE, "librccl.so could not be loaded");
-  Rccl::UniqueId u;
-  const int rc = rccl().GetUniqueId(&u);
+  ncclUniqueId u;
+  const ncclResult_t rc = rccl().GetUniqueId(&u);
   if (rc) return rccl_fail(rc, "ncclGetUniqueId");
   memcpy(id, u.internal, 128);
   return ITM_OK;
@@ -113,21 +120,31 @@ int itm_exchange_create(int world, int rank, const unsigned char id[128], int ma
   x->words = (size_t)kRecordHeader + (size_t)max_ids;
   const size_t batchBytes = x->words * (size_t)batch * 4;
   hipError_t e = hipStreamCreateWithFlags(&x->side, hipStreamNonBlocking);
-  for (int b = 0; b < 2 && e == hipSuccess; ++b) {
+  const char* sys = getenv("ITM_EXCHANGE_SYSTEM_SCOPE_EVENTS");       // A/B: the default (system-scope) release of hipEventRecord
+  const unsigned evFlags = hipEventDisableTiming | ((sys && sys[0] == '1') ? 0u : (unsigned)hipEventReleaseToDevice);
+  for (int b = 0; b < itm_exchange::kRing && e == hipSuccess; ++b) {
     e = hipMalloc((void**)&x->buffers[b], batchBytes);
     if (e == hipSuccess) e = hipMemset(x->buffers[b], 0xFF, batchBytes);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&x->copied[b], hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&x->released[b], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&x->copied[b], evFlags);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&x->released[b], evFlags);
   }
   if (e == hipSuccess) e = hipMalloc((void**)&x->gathered, batchBytes * (size_t)world);
   if (e == hipSuccess) e = hipMemset(x->gathered, 0xFF, batchBytes * (size_t)world);
   if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e != hipSuccess) { free_exchange(x); return hip_fail(e, "exchange buffers", __FILE__, __LINE__); }
-  if (world > 1) {
+  // One code path for every world size: a single rank gets a communicator too (its id made here) and runs the same ncclAllGather
+  // as eight do.  ITM_EXCHANGE_DEVICE_COPY=1 replaces the one-rank collective by a device copy (debug / A-B measurements only).
+  const char* dbg = getenv("ITM_EXCHANGE_DEVICE_COPY");
+  const bool deviceCopy = world == 1 && dbg && dbg[0] == '1';
+  if (!deviceCopy) {
     if (!rccl().ok) { free_exchange(x); return set_error(ITM_ERR_DEVICE, "librccl.so could not be loaded"); }
-    Rccl::UniqueId u;
-    memcpy(u.internal, id, 128);
-    const int rc = rccl().CommInitRank(&x->comm, world, u, rank);
+    ncclUniqueId u;
+    if (id) memcpy(u.internal, id, 128);
+    else {
+      const ncclResult_t rc = rccl().GetUniqueId(&u);
+      if (rc) { free_exchange(x); return rccl_fail(rc, "ncclGetUniqueId"); }
+    }
+    const ncclResult_t rc = rccl().CommInitRank(&x->comm, world, u, rank);
     if (rc) { x->comm = nullptr; free_exchange(x); return rccl_fail(rc, "ncclCommInitRank"); }
   }
   *out = x;
@@ -140,8 +157,8 @@ int itm_exchange_step(itm_exchange* x, const itm_render_state* rs, const float M
   if (!x || !rs || !M_d) return set_error(ITM_ERR_INVALID, "null argument");
   hipStream_t fs = as_stream(frame_stream);
   const int slot = (int)(x->frame % x->batch);
-  const int b = (int)((x->frame / x->batch) & 1);
-  if (slot == 0 && x->inFlight[b]) ITM_HIP(hipStreamWaitEvent(fs, x->released[b], 0));   // the collective two batches ago has let go of this buffer
+  const int b = (int)((x->frame / x->batch) % itm_exchange::kRing);
+  if (slot == 0 && x->inFlight[b]) { ITM_HIP(hipEventSynchronize(x->released[b])); x->inFlight[b] = false; }   // host-side: the collective four batches ago has let go of this buffer
   int rc = itm_export_visible_record(rs, M_d, x->maxIds, x->buffers[b] + (size_t)slot * x->words, frame_stream);
   if (rc) return rc;
   if (slot == x->batch - 1) {
@@ -149,8 +166,8 @@ int itm_exchange_step(itm_exchange* x, const itm_render_state* rs, const float M
     ITM_HIP(hipStreamWaitEvent(x->side, x->copied[b], 0));
     const size_t count = x->words * (size_t)x->batch;
     if (x->comm) {
-      rc = rccl().AllGather(x->buffers[b], x->gathered, count, kNcclInt32, x->comm, x->side);
-      if (rc) return rccl_fail(rc, "ncclAllGather");
+      const ncclResult_t nrc = rccl().AllGather(x->buffers[b], x->gathered, count, ncclInt32, x->comm, x->side);
+      if (nrc) return rccl_fail(nrc, "ncclAllGather");
     } else {
       ITM_HIP(hipMemcpyAsync(x->gathered, x->buffers[b], count * 4, hipMemcpyDeviceToDevice, x->side));
     }

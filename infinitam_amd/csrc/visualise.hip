@@ -186,8 +186,8 @@ int launch_projection_beside(const itm_scene* s, const float* M, const float* in
   const size_t ldsBytes = (size_t)RW * RH * sizeof(uint2);
   if (ldsBytes > 150 * 1024) return 0;
   if (!rs->sideStream) {
-    if (hipStreamCreateWithFlags(&rs->sideStream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&rs->listReady, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&rs->projectionDone, hipEventDisableTiming) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&rs->sideStream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&rs->listReady, hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess ||
+        hipEventCreateWithFlags(&rs->projectionDone, hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess) {
       (void)hipGetLastError();
       if (rs->sideStream) { (void)hipStreamDestroy(rs->sideStream); rs->sideStream = nullptr; }
       return 0;

@@ -23,6 +23,20 @@ import numpy as np
 RECORD_HEADER = 17  # 16 floats of pose + 1 count
 
 
+def decode_table(words: np.ndarray, world: int, batch: int, max_ids: int) -> List[Tuple[np.ndarray, np.ndarray]]:
+    """ONE reader for the gathered table of both implementations (the library's exchange.hip and VisibleListExchange below):
+    world x batch records of (17 + max_ids) int32 words, rank-major then frame of the batch; a record is 16 words holding the
+    float bits of M_d (column-major, as handed to the frame), the visible count, then the ids padded with -1.
+    Returns per stream the NEWEST record of the batch as (M_d[16] float32, ids[min(count, max_ids)] int32)."""
+    g = np.asarray(words, np.int32).reshape(world, batch, RECORD_HEADER + max_ids)[:, -1, :]
+    out = []
+    for r in range(world):
+        M = g[r, :16].view(np.float32).copy()
+        nv = int(g[r, 16])
+        out.append((M, g[r, 17:17 + min(nv, max_ids)].copy()))
+    return out
+
+
 def stream_of_rank(rank: int, world: int) -> int:
     """Stream g <-> rank g: weak scaling, per-GPU work is fixed."""
     return rank
@@ -106,19 +120,20 @@ class VisibleListExchange:
         """Host view of the gathered records: per stream (M_d[16] float32, visible ids int32[nv])."""
         if self._cuda:
             self.side.synchronize()      # the gathered table is written by collectives on the side stream
-        g = self.gathered.cpu().numpy().reshape(self.world, self.batch, self.words)[:, -1, :]   # newest record of each stream
-        out = []
-        for r in range(self.world):
-            M = g[r, :16].view(np.float32).copy()
-            nv = int(g[r, 16])
-            out.append((M, g[r, 17:17 + min(nv, self.max_ids)].copy()))
-        return out
+        return decode_table(self.gathered.cpu().numpy(), self.world, self.batch, self.max_ids)
+
+    def raw_table(self) -> np.ndarray:
+        """The gathered words as they lie in memory: world x batch x (17 + max_ids) int32, rank-major."""
+        if self._cuda:
+            self.side.synchronize()
+        return self.gathered.cpu().numpy().reshape(self.world, self.batch, self.words).copy()
 
 
 class NativeExchange:
     """The same exchange issued from the library (exchange.hip): record copy on the frame stream, RCCL all-gather on a side stream
     the library owns.  One C call per frame; no tensor framework on the per-frame path.  `unique_id` is the 128-byte RCCL id of
-    rank 0 (`NativeExchange.unique_id(backend)`), distributed by the host; not needed for world == 1."""
+    rank 0 (`NativeExchange.unique_id(backend)`), distributed by the host; for world == 1 the library makes its own id -- a one-rank
+    communicator runs the same ncclAllGather as eight ranks do."""
 
     def __init__(self, backend, world: int, rank: int, max_ids: int = 16384, batch: int = 1, unique_id: bytes = None):
         self.be, self.world, self.rank, self.max_ids, self.batch = backend, world, rank, max_ids, batch
@@ -144,15 +159,12 @@ class NativeExchange:
             self.be.check(rc, "exchange_step")
 
     def table(self) -> List[Tuple[np.ndarray, np.ndarray]]:
+        return decode_table(self.raw_table(), self.world, self.batch, self.max_ids)
+
+    def raw_table(self) -> np.ndarray:
         g = np.empty(self.world * self.batch * self.words, np.int32)
         self.be.check(self.be.fn["exchange_table"](self.h, g.ctypes.data_as(C.c_void_p), g.size), "exchange_table")
-        g = g.reshape(self.world, self.batch, self.words)[:, -1, :]
-        out = []
-        for r in range(self.world):
-            M = g[r, :16].view(np.float32).copy()
-            nv = int(g[r, 16])
-            out.append((M, g[r, 17:17 + min(nv, self.max_ids)].copy()))
-        return out
+        return g.reshape(self.world, self.batch, self.words)
 
     def close(self):
         if self.h:

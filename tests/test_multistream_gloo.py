@@ -87,3 +87,30 @@ def test_single_rank_exchange_is_identity():
     assert nv > 64 and len(ids) == 64
     assert np.array_equal(ids, ses.scene.download(T.BUF_VISIBLE_IDS, ses.rs)[:64])
     assert np.array_equal(M, np.asarray(v.M_d, np.float32))
+
+
+def test_record_words_are_the_documented_layout():
+    """The format both exchange implementations carry (include/itm_hip.h itm_export_visible_record, exchange.hip, streams.py):
+    per record 16 words of M_d float bits, the FULL visible count (also when the list is truncated), ids, then -1 padding;
+    table = world x batch records, frame of the batch ascending.  Built by hand from the scene's own buffers here."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import itm_testlib as T
+    from infinitam_amd.streams import VisibleListExchange, decode_table, RECORD_HEADER
+    ob = T.oracle_backend()
+    sc = T.Scenario(name="ms2", w=160, h=120, voxelSize=0.01, frames=3)
+    ses = T.Session(ob, sc)
+    for max_ids in (4096, 64):
+        ex = VisibleListExchange(ob, 1, 0, max_ids=max_ids, device="cpu", batch=3)
+        want = np.full((1, 3, RECORD_HEADER + max_ids), -1, np.int32)
+        for k in range(3):
+            v = ses.frame(k, fused=True)
+            ex.step(ses.rs.h, v.M_d, None)
+            nv = ses.scene.counters(ses.rs)["noVisibleEntries"]
+            ids = ses.scene.download(T.BUF_VISIBLE_IDS, ses.rs)[:nv]
+            want[0, k, :16] = np.asarray(v.M_d, np.float32).reshape(16).view(np.int32)
+            want[0, k, 16] = nv
+            n = min(nv, max_ids)
+            want[0, k, 17:17 + n] = ids[:n]
+        assert np.array_equal(ex.raw_table(), want)
+        (M, ids2), = decode_table(want, 1, 3, max_ids)
+        assert np.array_equal(M, np.asarray(v.M_d, np.float32).reshape(16)) and np.array_equal(ids2, ids[:max_ids])

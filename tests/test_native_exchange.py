@@ -1,7 +1,7 @@
 """The exchange issued from the library (infinitam_amd/csrc/exchange.hip): record copy on the frame stream + all-gather on a side stream.
-On the one-GPU box the communicator has one rank (a device copy stands in for the collective); the record layout, the batch
-ping-pong and the stream ordering are the ones every rank runs.  RCCL itself is exercised through itm_exchange_unique_id (the library
-is loaded and answers) and, with two ranks, by the driver's multi-GPU bench."""
+On the one-GPU box the communicator has ONE rank, but it is a real RCCL communicator (ncclCommInitRank) and the collective is a real
+ncclAllGather on the side stream -- the record layout, the batch ping-pong, the stream ordering and the RCCL calls are the ones every
+rank of an 8-GPU run makes.  The torch.distributed implementation (VisibleListExchange) is pinned to the same words."""
 import numpy as np
 import pytest
 
@@ -44,3 +44,49 @@ def test_single_rank_table_is_the_streams_own_record(hip, batch):
 def test_rccl_is_loadable_and_hands_out_a_unique_id(hip):
     a, b = NativeExchange.unique_id(hip), NativeExchange.unique_id(hip)
     assert len(a) == 128 and a != b and any(a)
+
+
+@pytest.mark.gpu
+def test_library_and_torch_exchange_hold_the_same_words(hip):
+    """Both implementations fill world x batch x (17 + max_ids) int32 words; word for word equal over several batches."""
+    import torch
+    from infinitam_amd.streams import VisibleListExchange
+    sc = T.Scenario(name="ex2", w=160, h=120, voxelSize=0.01, frames=8)
+    ses = T.Session(hip, sc)
+    lib = NativeExchange(hip, 1, 0, max_ids=1024, batch=4)
+    tor = VisibleListExchange(hip, 1, 0, max_ids=1024, device="cuda", batch=4)
+    cur = torch.cuda.current_stream()
+    try:
+        for k in range(sc.frames):
+            v = ses.frame(k, fused=True)
+            lib.step(ses.rs.h, v.M_d, None)
+            tor.step(ses.rs.h, v.M_d, cur)
+            if (k + 1) % 4 == 0:
+                torch.cuda.synchronize()
+                a, b = lib.raw_table(), tor.raw_table()
+                assert a.shape == b.shape == (1, 4, 17 + 1024) and np.array_equal(a, b)
+                assert (a[0, :, 16] > 100).all()                        # four different frames' counts, none empty
+                assert len({a[0, i, :16].tobytes() for i in range(4)}) == 4   # four different poses travelled
+    finally:
+        lib.close()
+        ses.close()
+
+
+@pytest.mark.gpu
+def test_one_rank_collective_equals_the_device_copy(hip, monkeypatch):
+    """ITM_EXCHANGE_DEVICE_COPY=1 (debug) replaces the one-rank ncclAllGather by a memcpy: same table."""
+    sc = T.Scenario(name="ex3", w=160, h=120, voxelSize=0.01, frames=4)
+    tables = []
+    for key in ("0", "1"):
+        monkeypatch.setenv("ITM_EXCHANGE_DEVICE_COPY", key)
+        ses = T.Session(hip, sc)
+        ex = NativeExchange(hip, 1, 0, max_ids=512, batch=2)
+        try:
+            for k in range(sc.frames):
+                v = ses.frame(k, fused=True)
+                ex.step(ses.rs.h, v.M_d, None)
+            tables.append(ex.raw_table().copy())
+        finally:
+            ex.close()
+            ses.close()
+    assert np.array_equal(tables[0], tables[1]) and (tables[0][0, :, 16] > 100).all()
