@@ -213,7 +213,8 @@ def worker(args) -> int:
     be = capi.Backend(args.lib, args.lib_prefix) if args.lib else itm.load()
     product = args.lib is None
     for key in [k for k in args.debug_keys.split(",") if k.strip()]:
-        be.check(be.fn["debug_set"](int(key), 1), "debug_set")
+        key, _, val = key.partition("=")                      # "9" switches key 9 on, "16=2" sets key 16 to 2
+        be.check(be.fn["debug_set"](int(key), int(val) if val else 1), "debug_set")
     on_gpu = be.on_device
     if on_gpu and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")

@@ -177,7 +177,11 @@ int ITM_FN(set_device)(int device);
 #define ITM_DEBUG_NO_SIDE_PROJECTION 14       /* itm_process_frame on large images: projection of the visible blocks after the integration on the frame's stream, not beside it on the render state's own */
 #define ITM_DEBUG_DENSE_RANGE_REFILL 15       /* dense scenes: write the constant expected-depth image on every frame, as the reference does, although it already holds it */
 #define ITM_DEBUG_NO_SDF_MIRROR 12            /* ray casting: voxels through the directory / table although the scene has an sdf mirror; set before itm_scene_create: no mirror is allocated */
+#define ITM_DEBUG_DENSE_CLASSIFY 16            /* dense integration: 0 = 4-voxel groups classified against the depth tiles before the fetch (default), 1 = no classification, 2 = classified after the fetch, 3 = check mode (itm_debug_dense_classify_check) */
+#define ITM_DEBUG_DENSE_NO_STRIPS 17           /* dense integration: the launch shape of rounds 1-2 (four groups per lane, 131 072 short waves) instead of the strip kernel */
 int ITM_FN(debug_set)(int key, int value);
+/* dense integration, check mode of key 16: {free groups, shadow groups, mixed groups, violations}; reset != 0 clears */
+int ITM_FN(debug_dense_classify_check)(int32_t out[4], int reset);
 /* Test hook (host only): rows [rlo, rhi] of the column of 4-voxel groups (x0 .. x0 + 3, slice z) that the dense integration visits for
  * a volume of `size` voxels at `offset` seen from M_d; every voxel of the column outside that interval must fail the exact
  * projection test of computeUpdatedVoxelDepthInfo.  Returns 1 when no cull planes can be formed (the kernel then tests per group). */

@@ -219,6 +219,7 @@ _HOST_IO_SIGS = {
     "tracker_track_camera": (C.c_int, [_P, C.POINTER(TrackerConfig), C.POINTER(ViewStruct), _P, _P, C.POINTER(C.c_float), C.POINTER(C.c_float), _P]),
     "debug_column_cull_rows": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int, C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                          C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "debug_dense_classify_check": (C.c_int, [C.POINTER(C.c_int32), C.c_int]),
     # multi-stream exchange issued from the library (RCCL); the CPU shims exchange through torch.distributed (streams.py)
     "exchange_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
     "exchange_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.POINTER(_P)]),

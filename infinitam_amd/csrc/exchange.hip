@@ -81,6 +81,7 @@ struct itm_exchange {
   hipEvent_t copied[kRing] = {}, released[kRing] = {};
   bool inFlight[kRing] = {};
   long long frame = 0;
+  int experiment = 0;                     // ITM_EXCHANGE_EXPERIMENT (measurement hook, tools/exchange_cost.py): how much of a batch's hand-off is issued
 };
 
 using namespace itm;
@@ -134,6 +135,7 @@ int itm_exchange_create(int world, int rank, const unsigned char id[128], int ma
   if (e != hipSuccess) { free_exchange(x); return hip_fail(e, "exchange buffers", __FILE__, __LINE__); }
   // One code path for every world size: a single rank gets a communicator too (its id made here) and runs the same ncclAllGather
   // as eight do.  ITM_EXCHANGE_DEVICE_COPY=1 replaces the one-rank collective by a device copy (debug / A-B measurements only).
+  if (const char* ex = getenv("ITM_EXCHANGE_EXPERIMENT")) x->experiment = atoi(ex);
   const char* dbg = getenv("ITM_EXCHANGE_DEVICE_COPY");
   const bool deviceCopy = world == 1 && dbg && dbg[0] == '1';
   if (!deviceCopy) {
@@ -161,16 +163,27 @@ int itm_exchange_step(itm_exchange* x, const itm_render_state* rs, const float M
   if (slot == 0 && x->inFlight[b]) { ITM_HIP(hipEventSynchronize(x->released[b])); x->inFlight[b] = false; }   // host-side: the collective four batches ago has let go of this buffer
   int rc = itm_export_visible_record(rs, M_d, x->maxIds, x->buffers[b] + (size_t)slot * x->words, frame_stream);
   if (rc) return rc;
-  if (slot == x->batch - 1) {
-    ITM_HIP(hipEventRecord(x->copied[b], fs));
-    ITM_HIP(hipStreamWaitEvent(x->side, x->copied[b], 0));
+  if (slot == x->batch - 1 && x->experiment != 1) {
+    // experiments (measurement only, the table is then not valid): 1 = record copy only; 2 = + event on the frame stream;
+    // 3 = + the side stream waits for it; 4 = + the collective, but no release event; 5 = the collective on the FRAME stream, no events
     const size_t count = x->words * (size_t)x->batch;
+    if (x->experiment == 5) {
+      const ncclResult_t nrc = x->comm ? rccl().AllGather(x->buffers[b], x->gathered, count, ncclInt32, x->comm, fs) : ncclSuccess;
+      if (nrc) return rccl_fail(nrc, "ncclAllGather");
+      ++x->frame;
+      return ITM_OK;
+    }
+    ITM_HIP(hipEventRecord(x->copied[b], fs));
+    if (x->experiment == 2) { ++x->frame; return ITM_OK; }
+    ITM_HIP(hipStreamWaitEvent(x->side, x->copied[b], 0));
+    if (x->experiment == 3) { ++x->frame; return ITM_OK; }
     if (x->comm) {
       const ncclResult_t nrc = rccl().AllGather(x->buffers[b], x->gathered, count, ncclInt32, x->comm, x->side);
       if (nrc) return rccl_fail(nrc, "ncclAllGather");
     } else {
       ITM_HIP(hipMemcpyAsync(x->gathered, x->buffers[b], count * 4, hipMemcpyDeviceToDevice, x->side));
     }
+    if (x->experiment == 4) { ++x->frame; return ITM_OK; }
     ITM_HIP(hipEventRecord(x->released[b], x->side));
     x->inFlight[b] = true;
   }

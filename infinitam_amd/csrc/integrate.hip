@@ -29,6 +29,8 @@ namespace itm {
 int g_debug_integrate_wgs = 0;
 int g_debug_no_fused_projection = 0;
 int g_debug_dense_group_cull = 0;   // debug key 9: per-group frustum test instead of the per-column row interval
+int g_debug_dense_no_strips = 0;    // debug key 17: the launch shape of rounds 1-2 (four groups per lane) instead of the strip kernel
+int g_debug_dense_classify = 0;     // debug key 16: 0 = classify groups before the fetch, 1 = no classification, 2 = after the fetch, 3 = check mode
 
 struct FuseParams {
   Mat4 M_d, M_rgb;
@@ -72,21 +74,12 @@ __device__ inline int fuse_depth_project(float mx, float my, float mz, const Fus
   return (int)(u + 0.5f) + (int)(v + 0.5f) * p.W;
 }
 
-// Stage 2: the running average with the measured depth dm of that pixel.  Returns eta (or -1 when the voxel is not
-// touched); `touched` tells whether the register image changed.
+// The running average of computeUpdatedVoxelDepthInfo (DeviceAgnostic/ITMSceneReconstructionEngine.h:45-55) with the clamped
+// observation newF = MIN(1, eta / mu).
 template <class VX>
-__device__ inline float fuse_depth_update(typename VX::Reg& r, float dm, float pcz, const FuseParams& p, bool& touched) {
-  if (dm <= 0.0f) return -1;
-  const float eta = dm - pcz;
-  if (eta < -p.mu) return eta;
+__device__ inline void fuse_average(typename VX::Reg& r, float newF, const FuseParams& p) {
   const float oldF = VX::to_float(VX::raw_sdf(r));
   const int oldW = VX::w_depth(r);
-#if ITM_FAST_DIVISIONS
-  float newF = p.muFast ? div_markstein(eta, p.mu, p.rcpMu) : eta / p.mu;
-#else
-  float newF = eta / p.mu;
-#endif
-  newF = (1.0f < newF) ? 1.0f : newF;
   int newW = 1;
   newF = (float)oldW * oldF + (float)newW * newF;
   newW = oldW + newW;
@@ -102,6 +95,22 @@ __device__ inline float fuse_depth_update(typename VX::Reg& r, float dm, float p
 #endif
   newW = (newW < p.maxW) ? newW : p.maxW;
   r = VX::with_depth(r, newF, newW);
+}
+
+// Stage 2: the running average with the measured depth dm of that pixel.  Returns eta (or -1 when the voxel is not
+// touched); `touched` tells whether the register image changed.
+template <class VX>
+__device__ inline float fuse_depth_update(typename VX::Reg& r, float dm, float pcz, const FuseParams& p, bool& touched) {
+  if (dm <= 0.0f) return -1;
+  const float eta = dm - pcz;
+  if (eta < -p.mu) return eta;
+#if ITM_FAST_DIVISIONS
+  float newF = p.muFast ? div_markstein(eta, p.mu, p.rcpMu) : eta / p.mu;
+#else
+  float newF = eta / p.mu;
+#endif
+  newF = (1.0f < newF) ? 1.0f : newF;
+  fuse_average<VX>(r, newF, p);
   touched = true;
   return eta;
 }
@@ -365,6 +374,122 @@ __global__ void __launch_bounds__(256) integrate_dense_kernel(void* __restrict__
   }
 }
 
+// ---- depth tiles: min / max of the depth image over tiles of 8, 16, 32 and 64 pixels ------------------------------------------
+// Most voxels a dense volume presents to a frame lie in observed free space (eta >= mu: the observation is clamped to exactly 1)
+// or in the shadow of a surface (eta < -mu: the voxel is not touched).  For a 4-voxel group whose whole pixel footprint falls into
+// tiles with  min depth - max pc.z >= mu  (resp.  max depth - min pc.z < -mu)  every voxel of the group takes that branch of
+// computeUpdatedVoxelDepthInfo, so neither the projection with its two divisions nor the depth gathers are needed: the free-space
+// update is the running average with newF = 1 (for a voxel still holding the initial 32767 simply w + 1), the shadow group is not
+// even fetched.  The bounds are conservative (one and a half pixels and 1e-5 of the coordinate magnitudes of slack, two orders above
+// the rounding of the exact path), so the result is the exact path's, bit for bit; tests/test_dense_cull.py runs the classified
+// kernel against the exact one over whole volumes and checks every classified group against the exact per-voxel outcome
+// (itm_debug_dense_classify_check).
+constexpr int kTileLevels = 4;       // tile sides 8, 16, 32, 64
+struct TileLevels {
+  int off[kTileLevels], tw[kTileLevels], th[kTileLevels];
+  int total;
+};
+static TileLevels tile_levels(int w, int h) {
+  TileLevels t; int o = 0;
+  for (int l = 0; l < kTileLevels; ++l) {
+    const int side = 8 << l;
+    t.off[l] = o; t.tw[l] = (w + side - 1) / side; t.th[l] = (h + side - 1) / side;
+    o += t.tw[l] * t.th[l];
+  }
+  t.total = o;
+  return t;
+}
+// One workgroup per 64 x 64 pixels: lane <-> a 4 x 4 patch, LDS reduction to the 8-, 16-, 32- and 64-pixel tiles.
+// A NaN pixel makes its tiles (-inf, +inf): no group over them is ever classified.
+__global__ void __launch_bounds__(256) depth_tiles_kernel(const float* __restrict__ depth, int W, int H, float2* __restrict__ tiles, TileLevels tl) {
+  __shared__ float2 s8[64], s16[16], s32[4];
+  const int t = threadIdx.x;
+  const int px = blockIdx.x * 64 + (t & 15) * 4, py = blockIdx.y * 64 + (t >> 4) * 4;
+  float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (py + j >= H) break;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (px + i >= W) break;
+      const float d = depth[(size_t)(py + j) * W + px + i];
+      if (d != d) { mn = -INFINITY; mx = INFINITY; }
+      mn = fminf(mn, d); mx = fmaxf(mx, d);
+    }
+  }
+  // 2 x 2 patches -> one 8-pixel tile: lanes (t & 15) ^ 1 and (t >> 4) ^ 1 (t ^ 1, t ^ 16)
+  mn = fminf(mn, __shfl_xor(mn, 1)); mx = fmaxf(mx, __shfl_xor(mx, 1));
+  mn = fminf(mn, __shfl_xor(mn, 16)); mx = fmaxf(mx, __shfl_xor(mx, 16));
+  const int cx = (t & 15) >> 1, cy = t >> 5;          // 8 x 8 tiles of 8 pixels in this workgroup
+  if (((t & 1) | ((t >> 4) & 1)) == 0) s8[cy * 8 + cx] = make_float2(mn, mx);
+  __syncthreads();
+  auto put = [&](int level, int lx, int ly, float2 v) {
+    const int gx = blockIdx.x * (8 >> level) + lx, gy = blockIdx.y * (8 >> level) + ly;
+    if (gx < tl.tw[level] && gy < tl.th[level]) tiles[tl.off[level] + gy * tl.tw[level] + gx] = v;
+  };
+  auto merge = [](float2 a, float2 b) { return make_float2(fminf(a.x, b.x), fmaxf(a.y, b.y)); };
+  if (t < 64) put(0, t & 7, t >> 3, s8[t]);
+  if (t < 16) {
+    const int x = t & 3, y = t >> 2;
+    const float2 v = merge(merge(s8[(2 * y) * 8 + 2 * x], s8[(2 * y) * 8 + 2 * x + 1]), merge(s8[(2 * y + 1) * 8 + 2 * x], s8[(2 * y + 1) * 8 + 2 * x + 1]));
+    s16[t] = v; put(1, x, y, v);
+  }
+  __syncthreads();
+  if (t < 4) {
+    const int x = t & 1, y = t >> 1;
+    const float2 v = merge(merge(s16[(2 * y) * 4 + 2 * x], s16[(2 * y) * 4 + 2 * x + 1]), merge(s16[(2 * y + 1) * 4 + 2 * x], s16[(2 * y + 1) * 4 + 2 * x + 1]));
+    s32[t] = v; put(2, x, y, v);
+  }
+  __syncthreads();
+  if (t == 0) put(3, 0, 0, merge(merge(s32[0], s32[1]), merge(s32[2], s32[3])));
+}
+
+// What the classification of a dense launch needs beside FuseParams.  Camera-space position of a group's centre voxel index
+// (x0 + 1.5, y, z): pc = C + x0 * Ax + y * Ay + z * Az (float, evaluated with FMAs: an approximation with a known error bound,
+// never stored).  h*: half extent of the group along its x run in camera space, 1.5 * voxelSize * |M column 0|.
+struct GroupClassify {
+  const float2* tiles;
+  TileLevels tl;
+  float Ax[3], Ay[3], Az[3], C[3];
+  float hx, hy, hz;
+  float slackZ;        // absolute slack on pc.z (metres): 1e-5 of the magnitudes that enter it
+  int enabled;
+};
+enum { kGroupMixed = 0, kGroupFree = 1, kGroupShadow = 2 };
+
+__device__ inline int classify_group(const GroupClassify& g, const FuseParams& p, int x0, int y, int z) {
+  const float fx0 = (float)x0, fy = (float)y, fz = (float)z;
+  const float pcx = __builtin_fmaf(g.Ax[0], fx0, __builtin_fmaf(g.Ay[0], fy, __builtin_fmaf(g.Az[0], fz, g.C[0])));
+  const float pcy = __builtin_fmaf(g.Ax[1], fx0, __builtin_fmaf(g.Ay[1], fy, __builtin_fmaf(g.Az[1], fz, g.C[1])));
+  const float pcz = __builtin_fmaf(g.Ax[2], fx0, __builtin_fmaf(g.Ay[2], fy, __builtin_fmaf(g.Az[2], fz, g.C[2])));
+  const float ez = g.hz + g.slackZ;
+  const float zmin = pcz - ez, zmax = pcz + ez;
+  if (!(zmin > 1e-3f)) return kGroupMixed;                       // near or behind the camera plane (or NaN): exact path
+  const float rz = __builtin_amdgcn_rcpf(pcz), rzmin = __builtin_amdgcn_rcpf(zmin) * 1.00001f;
+  const float tx = pcx * rz, ty = pcy * rz;
+  const float uc = __builtin_fmaf(p.fx, tx, p.cx), vc = __builtin_fmaf(p.fy, ty, p.cy);
+  // |u(voxel) - u(centre)| <= fx (hx + |x / z| hz) / zmin exactly; + 0.5 for (int)(u + 0.5), + 1 pixel for the approximations here
+  const float ru = fabsf(p.fx) * (g.hx + fabsf(tx) * g.hz) * rzmin + 1.5f + 1e-5f * fabsf(uc);
+  const float rv = fabsf(p.fy) * (g.hy + fabsf(ty) * g.hz) * rzmin + 1.5f + 1e-5f * fabsf(vc);
+  const float r = fmaxf(ru, rv);
+  if (!(r <= 31.5f)) return kGroupMixed;
+  const int level = (r <= 3.5f) ? 0 : (r <= 7.5f) ? 1 : (r <= 15.5f) ? 2 : 3;
+  const float ulo = uc - ru, uhi = uc + ru, vlo = vc - rv, vhi = vc + rv;
+  if (!(uhi >= 0.0f && vhi >= 0.0f && ulo <= (float)(p.W - 1) && vlo <= (float)(p.H - 1))) return kGroupMixed;   // footprint off the image: the column cull's business
+  const bool inside = ulo >= 1.0f && vlo >= 1.0f && uhi <= (float)(p.W - 2) && vhi <= (float)(p.H - 2);
+  const int sh = 3 + level;
+  const int px0 = max((int)floorf(ulo), 0) >> sh, px1 = min((int)floorf(uhi), p.W - 1) >> sh;
+  const int py0 = max((int)floorf(vlo), 0) >> sh, py1 = min((int)floorf(vhi), p.H - 1) >> sh;
+  const float2* __restrict__ t = g.tiles + g.tl.off[level];
+  const int tw = g.tl.tw[level];
+  const float2 a = t[py0 * tw + px0], b = t[py0 * tw + px1], c = t[py1 * tw + px0], d = t[py1 * tw + px1];
+  const float mn = fminf(fminf(a.x, b.x), fminf(c.x, d.x)), mx = fmaxf(fmaxf(a.y, b.y), fmaxf(c.y, d.y));
+  const float slack = 1e-5f * (fabsf(mx) + fabsf(mn) + zmax) + 1e-6f * p.mu;
+  if (inside && (mn - zmax >= p.mu + slack)) return kGroupFree;        // every pixel valid (mn > 0 follows) and at least mu behind every voxel
+  if (mx - zmin < -p.mu - slack) return kGroupShadow;                  // every pixel invalid or more than mu in front of every voxel
+  return kGroupMixed;
+}
+
 // Dense volume of ITMVoxel_s with sx % 4 == 0: 4 voxels (16 B) per lane, one 1 KiB row segment per
 // wave instruction; a group is written back only if one of its voxels changed.  blockIdx.y = z slice,
 // blockIdx.x splits the (y, x/4) plane; no 64-bit index division in the loop, two 16-byte loads in
@@ -401,16 +526,58 @@ __host__ __device__ inline void column_rows(const ColumnCull& cc, int x0, int z,
 // frustum are computed ONCE per thread for its column of groups (every group a thread visits has the same x0 when the stride
 // is a multiple of the row length), the per-group test is then two integer comparisons.  Measured on BASELINE configs[2]
 // (512^3): the per-group test was ~40 % of the kernel's VALU work (70 instructions for each of 33.5 M groups).
-template <bool POW2, int CULL>
+// CLASSIFY: 0 = every fetched group takes the exact per-voxel path; 1 = groups are classified against the depth tiles BEFORE they
+// are fetched (shadow groups are never read); 2 = after the fetch, and only groups that still have an unsaturated voxel;
+// 3 = measurement of the classification itself (itm_debug_dense_classify_check): classify, run the exact path, count disagreements.
+__device__ int g_classifyCheck[4];     // CLASSIFY == 3: free groups, shadow groups, mixed groups, VIOLATIONS
+template <bool POW2, int CULL, int CLASSIFY>
 __global__ void __launch_bounds__(256) integrate_dense_s_x4_kernel(uint4* __restrict__ vba, const float* __restrict__ depth, FuseParams p,
-                                                                   int sx, int sy, int sz, int ox, int oy, int oz, int log2sx4, ColumnCull cc) {
+                                                                   int sx, int sy, int sz, int ox, int oy, int oz, int log2sx4, ColumnCull cc, GroupClassify gc) {
   const int sx4 = sx >> 2;
   const int z = blockIdx.y;
   const int plane = sx4 * sy;                       // groups per z slice
   uint4* __restrict__ slice = vba + (size_t)z * plane;
   const float mz = (float)(z + oz) * p.voxelSize;
   const int stride = gridDim.x * 256;
-  auto process = [&](int idx, uint4 q) {
+  // free-space group: the observation of every voxel is exactly 1 (fuse_depth_update with eta >= mu)
+  auto update_free = [&](int idx, uint4 q) {
+    uint32_t v[4] = {q.x, q.y, q.z, q.w};
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t w = (v[k] >> 16) & 0xffu;
+      if (p.stopAtMax && (int)w == p.maxW) continue;
+      uint32_t nv;
+      if ((v[k] & 0xffffu) == 32767u) {            // (w * 1.0 + 1) / (w + 1) == 1.0 exactly: the sdf stays, the weight counts
+        const int nw = ((int)w + 1 < p.maxW) ? (int)w + 1 : p.maxW;
+        nv = 32767u | ((uint32_t)(nw & 0xff) << 16);
+      } else {
+        nv = v[k];
+        fuse_average<VoxelS>(nv, 1.0f, p);
+      }
+      any |= nv != v[k];
+      v[k] = nv;
+    }
+    if (any) slice[idx] = make_uint4(v[0], v[1], v[2], v[3]);
+  };
+  auto saturated = [&](const uint4& q) {
+    const uint32_t m = (uint32_t)(p.maxW & 0xff);
+    return p.stopAtMax && ((q.x >> 16) & 0xffu) == m && ((q.y >> 16) & 0xffu) == m && ((q.z >> 16) & 0xffu) == m && ((q.w >> 16) & 0xffu) == m;
+  };
+  auto group_class = [&](int idx) {
+    const int y = POW2 ? (idx >> log2sx4) : (idx / sx4);
+    const int x0 = (POW2 ? (idx & (sx4 - 1)) : (idx - y * sx4)) * 4;
+    return classify_group(gc, p, x0, y, z);
+  };
+  auto process = [&](int idx, uint4 q, int cls) {
+    if constexpr (CLASSIFY == 2) {
+      if (saturated(q)) return;
+      cls = group_class(idx);
+    }
+    if constexpr (CLASSIFY == 1 || CLASSIFY == 2) {
+      if (cls == kGroupShadow) return;
+      if (cls == kGroupFree) { update_free(idx, q); return; }
+    }
     const int y = POW2 ? (idx >> log2sx4) : (idx / sx4);
     const int x0 = (POW2 ? (idx & (sx4 - 1)) : (idx - y * sx4)) * 4;
     uint32_t v[4] = {q.x, q.y, q.z, q.w};
@@ -426,11 +593,33 @@ __global__ void __launch_bounds__(256) integrate_dense_s_x4_kernel(uint4* __rest
 #pragma unroll
     for (int k = 0; k < 4; ++k) dm[k] = (pix[k] >= 0) ? depth[pix[k]] : 0.0f;
     bool any = false;
+    [[maybe_unused]] int bad = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       bool touched = false;
-      if (pix[k] >= 0) fuse_depth_update<VoxelS>(v[k], dm[k], pcz[k], p, touched);
+      [[maybe_unused]] float eta = -1.0f;
+      if (pix[k] >= 0) eta = fuse_depth_update<VoxelS>(v[k], dm[k], pcz[k], p, touched);
+      if constexpr (CLASSIFY == 3) {
+        const bool skipped = p.stopAtMax && VoxelS::w_depth((&q.x)[k]) == p.maxW;
+        // free: every voxel that is not skipped must have been updated with an observation that clamps to 1
+        if (cls == kGroupFree && !skipped && !(touched && dm[k] > 0.0f && (p.muFast ? div_markstein(eta, p.mu, p.rcpMu) : eta / p.mu) >= 1.0f)) ++bad;
+        if (cls == kGroupShadow && touched) ++bad;
+      }
       any |= touched;
+    }
+    if constexpr (CLASSIFY == 3) {
+      atomicAdd(&g_classifyCheck[cls == kGroupFree ? 0 : cls == kGroupShadow ? 1 : 2], 1);
+      if (bad) atomicAdd(&g_classifyCheck[3], bad);
+      if (cls == kGroupFree) {                      // and the shortcut must produce the exact path's words
+        uint32_t f[4] = {q.x, q.y, q.z, q.w};
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t w = (f[k] >> 16) & 0xffu;
+          if (p.stopAtMax && (int)w == p.maxW) continue;
+          if ((f[k] & 0xffffu) == 32767u) { const int nw = ((int)w + 1 < p.maxW) ? (int)w + 1 : p.maxW; f[k] = 32767u | ((uint32_t)(nw & 0xff) << 16); }
+          else fuse_average<VoxelS>(f[k], 1.0f, p);
+          if (f[k] != v[k]) atomicAdd(&g_classifyCheck[3], 1);
+        }
+      }
     }
     if (any) slice[idx] = make_uint4(v[0], v[1], v[2], v[3]);
   };
@@ -460,15 +649,29 @@ __global__ void __launch_bounds__(256) integrate_dense_s_x4_kernel(uint4* __rest
     int rlo, rhi;
     column_rows(cc, (idx & (sx4 - 1)) * 4, z, rlo, rhi);
     auto outside = [&](int i) { const int y = i >> log2sx4; return y < rlo || y > rhi; };
+    if constexpr (CLASSIFY == 1 || CLASSIFY == 3) {
+      // classified before the fetch: a shadow group is never read (CLASSIFY == 3 reads everything: it checks the classes)
+      for (; idx + stride < plane; idx += 2 * stride) {
+        const int k0 = outside(idx) ? -1 : group_class(idx), k1 = outside(idx + stride) ? -1 : group_class(idx + stride);
+        const bool f0 = k0 >= 0 && (CLASSIFY == 3 || k0 != kGroupShadow), f1 = k1 >= 0 && (CLASSIFY == 3 || k1 != kGroupShadow);
+        uint4 q0, q1;
+        if (f0) q0 = slice[idx];
+        if (f1) q1 = slice[idx + stride];
+        if (f0) process(idx, q0, k0);
+        if (f1) process(idx + stride, q1, k1);
+      }
+      if (idx < plane && !outside(idx)) { const int k0 = group_class(idx); if (CLASSIFY == 3 || k0 != kGroupShadow) process(idx, slice[idx], k0); }
+      return;
+    }
     for (; idx + stride < plane; idx += 2 * stride) {
       const bool c0 = outside(idx), c1 = outside(idx + stride);
       uint4 q0, q1;
       if (!c0) q0 = slice[idx];
       if (!c1) q1 = slice[idx + stride];
-      if (!c0) process(idx, q0);
-      if (!c1) process(idx + stride, q1);
+      if (!c0) process(idx, q0, kGroupMixed);
+      if (!c1) process(idx + stride, q1, kGroupMixed);
     }
-    if (idx < plane && !outside(idx)) process(idx, slice[idx]);
+    if (idx < plane && !outside(idx)) process(idx, slice[idx], kGroupMixed);
     return;
   }
   for (; idx + stride < plane; idx += 2 * stride) {
@@ -476,10 +679,184 @@ __global__ void __launch_bounds__(256) integrate_dense_s_x4_kernel(uint4* __rest
     uint4 q0, q1;
     if (!c0) q0 = slice[idx];
     if (!c1) q1 = slice[idx + stride];
-    if (!c0) process(idx, q0);
-    if (!c1) process(idx + stride, q1);
+    if (!c0) process(idx, q0, kGroupMixed);
+    if (!c1) process(idx + stride, q1, kGroupMixed);
   }
-  if (idx < plane && !culled(idx)) process(idx, slice[idx]);
+  if (idx < plane && !culled(idx)) process(idx, slice[idx], kGroupMixed);
+}
+
+// ---- the strip kernel ------------------------------------------------------------------------------------------------------------
+// What the counters say about the kernel above (profiles/r3_dense_counters.md, BASELINE configs[2]): 90 M vector instructions per
+// launch, issue bound, and hardly fewer (81 M) once the weights have reached maxW -- the voxels in the SHADOW of the surface are
+// never updated, so they never saturate and are projected in every frame, and a wave whose 64 lanes lie along x executes the
+// projection for all of them as long as one lane needs it.  Classifying the groups against the depth tiles does not help that
+// kernel (measured: 119 M instructions): its waves straddle the class boundaries, so nearly every wave still runs the exact path,
+// now on top of the classification.
+// Here the exact path is taken by PACKED lanes: a wave owns a strip (64 adjacent columns of 4-voxel groups of one z slice, 1 KiB of
+// every row), takes four consecutive rows at a time -- a PATCH of 4 x 4 voxels per lane, classified once --, updates free-space patches
+// in place, and QUEUES the groups of the patches that need the exact arithmetic in LDS; whenever 64 are waiting, they are taken off the queue and projected / gathered / averaged with every lane
+// busy.  Shadow groups and saturated groups cost their classification only.  A strip is dealt out row by row over kStripPhases
+// work items so that the waves working on it at one time read adjacent rows (waves each walking a row chunk 64 KB apart took
+// 290 us for a 512^3 launch, whatever the arithmetic: all of them at the same offset modulo the chunk at the same time); items go
+// round-robin over persistent waves, far slices first (a shared work counter was measured too: an atomic with a return value on
+// one address is ~16 ns, serialised at the memory side -- 350 us for the 24 k draws of a launch).
+#ifndef ITM_STRIP_PHASES
+#define ITM_STRIP_PHASES 16
+#endif
+#ifndef ITM_STRIP_OCC
+#define ITM_STRIP_OCC 1
+#endif
+constexpr int kStripPhases = ITM_STRIP_PHASES;   // work items per strip
+constexpr int kStripQueue = 128;                 // queued groups per wave: fewer than 64 left over + at most 64 of one row
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITM_STRIP_OCC))) integrate_dense_strip_kernel(uint4* __restrict__ vba, const float* __restrict__ depth, FuseParams p,
+                                                                    int sx, int sy, int sz, int ox, int oy, int oz, ColumnCull cc, GroupClassify gc) {
+  __shared__ uint4 sQ[4][kStripQueue];
+  __shared__ int sTag[4][kStripQueue];
+  const int sx4 = sx >> 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int xblocks = (sx4 + 63) >> 6;
+  const unsigned int perSlice = (unsigned int)(xblocks * kStripPhases);
+  const unsigned int nItems = (unsigned int)sz * perSlice;
+  const unsigned int nWaves = gridDim.x * (blockDim.x >> 6);
+  for (unsigned int item = blockIdx.x * (blockDim.x >> 6) + wave; item < nItems; item += nWaves) {
+    const int zi = (int)(item / perSlice), rem = (int)(item - (unsigned int)zi * perSlice);
+    const int z = sz - 1 - zi;                                // far slices first
+    const int phase = rem / xblocks, xb = rem - phase * xblocks;
+    const int x4 = xb * 64 + lane, x0 = x4 * 4;
+    uint4* __restrict__ slice = vba + (size_t)z * sx4 * sy;
+    const float mz = (float)(z + oz) * p.voxelSize;
+    int rlo, rhi;
+    column_rows(cc, x0, z, rlo, rhi);
+    rlo = max(rlo, 0); rhi = min(rhi, sy - 1);
+    if (x4 >= sx4) { rlo = 1; rhi = 0; }                       // a row need not be a multiple of 64 groups
+    // rows any lane of the wave needs (the loop bounds are the wave's, the test inside is the lane's)
+    int wlo = (rlo <= rhi) ? rlo : 0x7fffffff, whi = (rlo <= rhi) ? rhi : -1;
+#pragma unroll
+    for (int off = 32; off; off >>= 1) { wlo = min(wlo, __shfl_xor(wlo, off)); whi = max(whi, __shfl_xor(whi, off)); }
+    if (wlo > whi) continue;
+
+    // the exact path for one queued group: tag = row * 64 + lane that queued it
+    auto exact = [&](uint4 q, int tag) {
+      const int y = tag >> 6, gx4 = xb * 64 + (tag & 63), gx0 = gx4 * 4;
+      uint32_t v[4] = {q.x, q.y, q.z, q.w};
+      const float my = (float)(y + oy) * p.voxelSize;
+      int pix[4]; float pcz[4], dm[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        pix[k] = -1;
+        if (p.stopAtMax && VoxelS::w_depth(v[k]) == p.maxW) continue;
+        pix[k] = fuse_depth_project((float)(gx0 + k + ox) * p.voxelSize, my, mz, p, pcz[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dm[k] = (pix[k] >= 0) ? depth[pix[k]] : 0.0f;
+      bool any = false;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        bool touched = false;
+        if (pix[k] >= 0) fuse_depth_update<VoxelS>(v[k], dm[k], pcz[k], p, touched);
+        any |= touched;
+      }
+      if (any) slice[(size_t)y * sx4 + gx4] = make_uint4(v[0], v[1], v[2], v[3]);
+    };
+    int queued = 0;                                            // the same in every lane
+    auto take = [&](int n) {                                   // the last n (<= 64) queued groups
+      __builtin_amdgcn_wave_barrier();
+      if (lane < n) exact(sQ[wave][queued - n + lane], sTag[wave][queued - n + lane]);
+      __builtin_amdgcn_wave_barrier();
+      queued -= n;
+    };
+
+    const uint4* __restrict__ dummy = slice + (size_t)wlo * sx4 + xb * 64;     // what a lane outside its interval reads (one line, dropped)
+    const uint32_t wmax = (uint32_t)(p.maxW & 0xff);
+    // rows in PATCHES of four: patch G = rows 4 G .. 4 G + 3; this item takes the patches G = phase (mod kStripPhases)
+    for (int G = (wlo >> 2) + (((phase - (wlo >> 2)) % kStripPhases + kStripPhases) % kStripPhases); 4 * G <= whi; G += kStripPhases) {
+      const int y = 4 * G;
+      uint4 qa[4];
+      bool need[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool in = y + u >= rlo && y + u <= rhi;
+        const uint4* a = in ? slice + (size_t)(y + u) * sx4 + x4 : dummy;
+        qa[u] = *a;
+        need[u] = in;
+      }
+      bool any = false;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint4 q = qa[u];
+        const bool sat = p.stopAtMax && ((q.x >> 16) & 0xffu) == wmax && ((q.y >> 16) & 0xffu) == wmax && ((q.z >> 16) & 0xffu) == wmax && ((q.w >> 16) & 0xffu) == wmax;
+        need[u] = need[u] && !sat;
+        any |= need[u];
+      }
+      if (!__any(any)) continue;
+      // one class for the 4 x 4 patch (gc was made for patches: centre (x0 + 1.5, y + 1.5), extents of both runs)
+      const int cls = any ? classify_group(gc, p, x0, y, z) : kGroupShadow;
+      if (cls == kGroupFree) {
+        // every voxel of the patch observes free space: the observation is exactly 1 (fuse_depth_update with eta >= mu)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (!need[u]) continue;
+          uint32_t v[4] = {qa[u].x, qa[u].y, qa[u].z, qa[u].w};
+          bool changed = false;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const uint32_t w = (v[k] >> 16) & 0xffu;
+            if (p.stopAtMax && w == wmax) continue;
+            uint32_t nv;
+            if ((v[k] & 0xffffu) == 32767u) {          // (w * 1.0 + 1) / (w + 1) == 1.0 exactly: the sdf stays, the weight counts
+              const int nw = ((int)w + 1 < p.maxW) ? (int)w + 1 : p.maxW;
+              nv = 32767u | ((uint32_t)(nw & 0xff) << 16);
+            } else {
+              nv = v[k];
+              fuse_average<VoxelS>(nv, 1.0f, p);
+            }
+            changed |= nv != v[k];
+            v[k] = nv;
+          }
+          if (changed) slice[(size_t)(y + u) * sx4 + x4] = make_uint4(v[0], v[1], v[2], v[3]);
+        }
+      }
+      if (!__any(cls == kGroupMixed)) continue;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool mixed = cls == kGroupMixed && need[u];
+        const unsigned long long m = __ballot(mixed);
+        if (m) {
+          if (mixed) {
+            const int pos = queued + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            sQ[wave][pos] = qa[u]; sTag[wave][pos] = (y + u) * 64 + lane;
+          }
+          queued += __popcll(m);
+          if (queued >= 64) take(64);
+        }
+      }
+    }
+    if (queued > 0) take(queued);
+  }
+}
+
+// the classification's inputs for one launch; false when a coefficient is not finite (then nothing is classified)
+// `rows`: 1 = a class per 4-voxel group; 4 = a class per PATCH of four such groups in consecutive rows (the strip kernel)
+static bool make_group_classify(const FuseParams& p, const int* size, const int* off, const float2* tiles, const TileLevels& tl, GroupClassify& g, int rows = 1) {
+  memset(&g, 0, sizeof g);
+  g.tiles = tiles; g.tl = tl;
+  const double vs = p.voxelSize;
+  double mag = 0.0;
+  for (int j = 0; j < 3; ++j) {
+    const double m0 = p.M_d.m[j], m1 = p.M_d.m[j + 4], m2 = p.M_d.m[j + 8], m3 = p.M_d.m[j + 12];
+    g.Ax[j] = (float)(m0 * vs); g.Ay[j] = (float)(m1 * vs); g.Az[j] = (float)(m2 * vs);
+    g.C[j] = (float)((m0 * (off[0] + 1.5) + m1 * (off[1] + 0.5 * (rows - 1)) + m2 * off[2]) * vs + m3);       // centre of the run x0 .. x0 + 3 (of the rows y .. y + rows - 1)
+    if (j == 2) mag = (fabs(m0) * (fabs((double)off[0]) + size[0]) + fabs(m1) * (fabs((double)off[1]) + size[1]) + fabs(m2) * (fabs((double)off[2]) + size[2])) * vs + fabs(m3);
+    if (!std::isfinite(g.Ax[j]) || !std::isfinite(g.Ay[j]) || !std::isfinite(g.Az[j]) || !std::isfinite(g.C[j])) return false;
+  }
+  const double ry = 0.5 * (rows - 1);      // half extent along y in voxels
+  g.hx = (float)((1.5 * fabs((double)p.M_d.m[0]) + ry * fabs((double)p.M_d.m[4])) * vs * 1.0001);
+  g.hy = (float)((1.5 * fabs((double)p.M_d.m[1]) + ry * fabs((double)p.M_d.m[5])) * vs * 1.0001);
+  g.hz = (float)((1.5 * fabs((double)p.M_d.m[2]) + ry * fabs((double)p.M_d.m[6])) * vs * 1.0001);
+  g.slackZ = (float)(1e-5 * mag + 1e-7);
+  g.enabled = 1;
+  return std::isfinite(g.slackZ) && std::isfinite(p.fx) && std::isfinite(p.fy) && std::isfinite(p.cx) && std::isfinite(p.cy);
 }
 
 // The five frustum planes of ColumnCull from the launch parameters; false when a coefficient is not finite (then the per-group
@@ -574,13 +951,46 @@ int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipS
       const int plane = sx4 * sz[1];
       int splits = (plane + 2 * 256 - 1) / (2 * 256);        // every lane gets ~2 groups per pass
       if (splits > 64) splits = 64;
+      if (g_debug_dense_no_strips > 1) splits = g_debug_dense_no_strips;      // measurement: debug key 17 = n > 1 sets the number of splits of a slice
       if (splits < 1) splits = 1;
       const dim3 grid(splits, sz[2]);
       ColumnCull cc;
-      const bool columns = pow2 && ((splits * 256) % sx4) == 0 && !g_debug_dense_group_cull && make_column_cull(p, sz, of, cc);
-      if (columns) integrate_dense_s_x4_kernel<true, 1><<<grid, 256, 0, st>>>((uint4*)s->vba, v->depth, p, sz[0], sz[1], sz[2], of[0], of[1], of[2], lg, cc);
-      else if (pow2) integrate_dense_s_x4_kernel<true, 0><<<grid, 256, 0, st>>>((uint4*)s->vba, v->depth, p, sz[0], sz[1], sz[2], of[0], of[1], of[2], lg, cc);
-      else integrate_dense_s_x4_kernel<false, 0><<<grid, 256, 0, st>>>((uint4*)s->vba, v->depth, p, sz[0], sz[1], sz[2], of[0], of[1], of[2], lg, cc);
+      const bool planes = !g_debug_dense_group_cull && make_column_cull(p, sz, of, cc);
+      const bool columns = pow2 && ((splits * 256) % sx4) == 0 && planes;
+      GroupClassify gc;
+      memset(&gc, 0, sizeof gc);
+      int classify = 0;
+      const bool wantStrips = planes && !g_debug_dense_no_strips && g_debug_dense_classify != 1 && g_debug_dense_classify != 3 && sz[1] < (1 << 24);
+      if (planes && g_debug_dense_classify != 1) {
+        // min / max depth tiles of this frame (one small launch), then groups are classified against them
+        const TileLevels tl = tile_levels(v->w, v->h);
+        if (s->depthTilesCap < (size_t)tl.total) {
+          if (s->depthTiles) (void)hipFree(s->depthTiles);
+          s->depthTiles = nullptr; s->depthTilesCap = 0;
+          if (hipMalloc((void**)&s->depthTiles, (size_t)tl.total * sizeof(float2)) == hipSuccess) s->depthTilesCap = (size_t)tl.total;
+          else (void)hipGetLastError();
+        }
+        if (s->depthTiles && make_group_classify(p, sz, of, s->depthTiles, tl, gc, wantStrips ? 4 : 1)) {
+          depth_tiles_kernel<<<dim3((v->w + 63) / 64, (v->h + 63) / 64), 256, 0, st>>>(v->depth, v->w, v->h, s->depthTiles, tl);
+          classify = g_debug_dense_classify == 2 ? 2 : g_debug_dense_classify == 3 ? 3 : 1;
+        }
+      }
+#define ITM_DENSE(P2, CU, CL) integrate_dense_s_x4_kernel<P2, CU, CL><<<grid, 256, 0, st>>>((uint4*)s->vba, v->depth, p, sz[0], sz[1], sz[2], of[0], of[1], of[2], lg, cc, gc)
+      // the strip kernel: volumes whose rows are whole strips of 64 groups (debug key 17 keeps the launch shape of rounds 1-2)
+      const bool strips = wantStrips && classify != 0;
+      if (strips) {
+        // 16 384 waves for the 16 384 items of a 512^3 volume: one item each, dispatched as slots free up (measured, BASELINE configs[2]:
+        // 1 024 workgroups 102-110 us, 2 048: 95-104, 3 072: 93-107, 4 096: 91-105)
+        const int wgs = g_debug_integrate_wgs > 0 ? g_debug_integrate_wgs : 4096;
+        integrate_dense_strip_kernel<<<wgs, 256, 0, st>>>((uint4*)s->vba, v->depth, p, sz[0], sz[1], sz[2], of[0], of[1], of[2], cc, gc);
+      }
+      else if (columns && classify == 1) ITM_DENSE(true, 1, 1);
+      else if (columns && classify == 2) ITM_DENSE(true, 1, 2);
+      else if (columns && classify == 3) ITM_DENSE(true, 1, 3);
+      else if (columns) ITM_DENSE(true, 1, 0);
+      else if (pow2) ITM_DENSE(true, 0, 0);
+      else ITM_DENSE(false, 0, 0);
+#undef ITM_DENSE
     } else {
       int rc = dispatch_voxel(s->cfg.voxelType, [&](auto vx) {
         using VX = decltype(vx);
@@ -612,6 +1022,16 @@ extern "C" int itm_debug_column_cull_rows(const float M_d[16], const float intr[
   ColumnCull cc;
   if (!make_column_cull(p, size, offset, cc)) return 1;
   column_rows(cc, x0, z, *rlo, *rhi);
+  return ITM_OK;
+}
+
+// Test hook: the counters of the classification check (debug key 16 = 3): {free groups, shadow groups, mixed groups, violations};
+// reset != 0 clears them.  A violation is a voxel of a classified group whose exact per-voxel outcome differs from its class.
+extern "C" int itm_debug_dense_classify_check(int32_t out[4], int reset) {
+  if (!out) return set_error(ITM_ERR_INVALID, "null argument");
+  ITM_HIP(hipDeviceSynchronize());
+  ITM_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_classifyCheck), 16));
+  if (reset) { const int32_t z[4] = {0, 0, 0, 0}; ITM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_classifyCheck), z, 16)); }
   return ITM_OK;
 }
 

@@ -79,6 +79,9 @@ struct itm_scene {
   int32_t* dirSlot = nullptr;     // int32[kDirCells]  (512 MB): table slot of the block at that position or -1 (request kernel)
   void* sdfMirror = nullptr;      // int16 / uint32 [kMirrorCells * 512]  (17 / 34 GB; hash scenes, itm_types.h) or nullptr
   uint32_t frameParity = 0;
+  // dense integration: min / max tiles of the frame's depth image (integrate.hip), allocated on first use
+  float2* depthTiles = nullptr;
+  size_t depthTilesCap = 0;
   itm::Profiler* prof = nullptr;
 };
 
@@ -166,6 +169,8 @@ extern int g_debug_explicit_mark;
 extern int g_debug_two_pass_visible_list;
 extern int g_debug_integrate_wgs;
 extern int g_debug_dense_group_cull;
+extern int g_debug_dense_classify;
+extern int g_debug_dense_no_strips;
 extern int g_debug_tracker_launch_per_evaluation;
 extern int g_debug_tracker_host_command;
 extern int g_debug_no_sdf_mirror;

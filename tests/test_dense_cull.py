@@ -44,9 +44,13 @@ CAMERAS = [
 ]
 
 
-def integrate_all(be, keys=()):
+def integrate_all(be, keys=(), values=None):
+    values = dict(values or {})
     for k in keys:
-        be.check(be.fn["debug_set"](k, 1), "debug_set")
+        values[k] = 1
+    keys = list(values)
+    for k, val in values.items():
+        be.check(be.fn["debug_set"](k, val), "debug_set")
     try:
         W, H = 160, 120
         s = be.create_scene(capi.VOXEL_S, capi.INDEX_DENSE, capi.default_params(voxelSize=0.008, mu=0.04), denseSize=(128, 128, 128), denseOffset=(-64, -64, 100))
@@ -71,10 +75,19 @@ def test_column_cull_equals_exact_test_for_cameras_in_general_position(hip, orac
     want = integrate_all(oracle)
     got = integrate_all(hip)
     per_group = integrate_all(hip, keys=(9,))
+    unclassified = integrate_all(hip, values={16: 1})           # groups not classified against the depth tiles
+    after_fetch = integrate_all(hip, values={16: 2, 17: 1})     # classified after the fetch, launch shape of rounds 1-2
+    old_shape = integrate_all(hip, values={17: 1})              # four groups per lane instead of strips, classified before the fetch
+    old_plain = integrate_all(hip, values={16: 1, 17: 1})       # ... not classified
     touched = 0
-    for i, (a, b, c) in enumerate(zip(want, got, per_group)):
+    for i, (a, f, g) in enumerate(zip(want, old_shape, old_plain)):
+        assert np.array_equal(a, f), "camera %d (four groups per lane)" % i
+        assert np.array_equal(a, g), "camera %d (four groups per lane, no classification)" % i
+    for i, (a, b, c, d, e) in enumerate(zip(want, got, per_group, unclassified, after_fetch)):
         assert np.array_equal(a, b), "camera %d: %d voxels differ" % (i, int(np.count_nonzero(a.view(np.uint32) != b.view(np.uint32))))
         assert np.array_equal(a, c), "camera %d (per-group cull)" % i
+        assert np.array_equal(a, d), "camera %d (no classification)" % i
+        assert np.array_equal(a, e), "camera %d (classification after the fetch)" % i
         touched += int(np.count_nonzero(a.view(np.uint32) != want[i - 1].view(np.uint32))) if i else int(np.count_nonzero(a.view(np.uint32) != 32767))
     assert touched > 500000          # the cameras really see the volume
 
@@ -160,3 +173,71 @@ def test_dense_ray_cast_from_cameras_in_general_position(hip, oracle):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "camera %d: %d components differ" % (i, int(np.count_nonzero(a.view(np.uint32) != b.view(np.uint32))))
         found += int(np.count_nonzero(a.reshape(-1, 4)[:, 3] > 0))
     assert found > 20000          # the cameras really hit the surface, and most rays leave without a hit
+
+
+# ---- free-space / shadow classification of 4-voxel groups against the depth tiles (integrate.hip, classify_group) -------------------
+def smooth_scene_volumes(be, stop_at_max, mode, frames=7, check=None, no_strips=0):
+    """The sphere + wall scene fused into a 128^3 dense volume around the sphere (smooth depth: most groups lie in observed free
+    space or in the sphere's shadow), from the parity trajectory and two rotated cameras; maxW 4, so weights saturate on the way."""
+    W, H = 320, 240
+    be.check(be.fn["debug_set"](16, mode), "debug_set")
+    be.check(be.fn["debug_set"](17, no_strips), "debug_set")
+    try:
+        prm = capi.default_params(voxelSize=0.008, mu=0.04, maxW=4, stopIntegratingAtMaxW=stop_at_max)
+        s = be.create_scene(capi.VOXEL_S, capi.INDEX_DENSE, prm, denseSize=(128, 128, 128), denseOffset=(-64, -64, 100))
+        s.reco.ResetScene()
+        rs = s.vis.CreateRenderState((W, H))
+        intr = T.synth.intrinsics_for(W, H)
+        out = []
+        for k in range(frames):
+            t = T.synth.parity_position(3 * k)
+            depth = T.synth.depth_frame(W, H, t, intr)
+            if k == 2:
+                depth[100:140, 50:90] = -1.0           # a hole: invalid pixels inside a smooth region
+            if k == 4:
+                depth[5, 7] = np.nan                   # a NaN pixel: its tiles are never classified
+            M = T.synth.pose_matrix(t) if k < 5 else pose(rotation(0.05 * k, -0.04 * k, 0.3), (0.01 * k, 0.0, 0.0))
+            s.reco.IntegrateIntoScene(capi.View(be.to_backend(depth), W, H, M_d=M, intr_d=intr), rs)
+            if check is not None:
+                c = (C.c_int32 * 4)()
+                be.check(be.fn["debug_dense_classify_check"](c, 1), "classify_check")
+                check.append(list(c))
+            out.append(s.download(capi.BUF_VOXEL_BLOCKS).copy())
+        return out
+    finally:
+        be.check(be.fn["debug_set"](16, 0), "debug_set")
+        be.check(be.fn["debug_set"](17, 0), "debug_set")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stop_at_max", [False, True])
+def test_classified_dense_integration_equals_the_exact_path(hip, oracle, stop_at_max):
+    want = smooth_scene_volumes(oracle, stop_at_max, 0)
+    # strips (the default launch shape): classified / not; four groups per lane: classified before the fetch / not / after the fetch
+    for mode, no_strips in ((0, 0), (1, 0), (0, 1), (1, 1), (2, 1)):
+        got = smooth_scene_volumes(hip, stop_at_max, mode, no_strips=no_strips)
+        for k, (a, b) in enumerate(zip(want, got)):
+            assert np.array_equal(a, b), "mode %d%s frame %d: %d voxels differ" % (mode, " (no strips)" if no_strips else "", k, int(np.count_nonzero(a.view(np.uint32) != b.view(np.uint32))))
+    v = want[-1].view(np.uint32).reshape(-1)
+    assert np.count_nonzero((v & 0xffff) != 32767) > 100000 and np.count_nonzero(((v >> 16) & 0xff) == 4) > 500000      # a surface, and saturated weights
+
+
+@pytest.mark.gpu
+def test_every_classified_group_agrees_with_its_exact_per_voxel_outcome(hip, oracle):
+    """Check mode: the kernel classifies every group, runs the exact path on it anyway and counts the voxels whose exact outcome
+    contradicts the class (a free-space voxel not updated with an observation of exactly 1, a shadow voxel touched) or whose
+    shortcut result differs from the exact words."""
+    c = (C.c_int32 * 4)()
+    hip.check(hip.fn["debug_dense_classify_check"](c, 1), "classify_check")
+    checks = []
+    got = smooth_scene_volumes(hip, False, 3, check=checks)
+    want = smooth_scene_volumes(oracle, False, 0)
+    assert all(np.array_equal(a, b) for a, b in zip(want, got))
+    for k, (free, shadow, mixed, bad) in enumerate(checks):
+        assert bad == 0, (k, checks)
+        assert free > 20000 and shadow > 2000 and mixed > 0, (k, checks)
+    # the noisy cameras of the cull test: hardly any free group (every tile holds an invalid pixel), shadow groups, no violation
+    hip.check(hip.fn["debug_dense_classify_check"](c, 1), "classify_check")
+    integrate_all(hip, values={16: 3})
+    hip.check(hip.fn["debug_dense_classify_check"](c, 1), "classify_check")
+    assert c[3] == 0 and c[1] > 1000, list(c)
