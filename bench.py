@@ -466,6 +466,7 @@ def worker(args) -> int:
                                     if exchange else "none"),
                        "per_rank_fps_min_max": fps_minmax,
                        "visible_blocks_last_frame": counters["noVisibleEntries"],
+                       **({"acceleration_structures": streams[0].scene.accel_info()} if (product and wl["index"] == "hash") else {}),
                        "origin_offset_m": list(offset),
                        "input": ("16-bit raw depth from pinned host memory: H2D + itm_update_view inside the timed region" if args.raw_depth
                                  else "float depth frames resident in HBM"),

@@ -446,6 +446,21 @@ int ITM_FN(exchange_info)(const itm_exchange* exchange, int* world, int* rank, i
 /* host copy of the gathered table, world x batch records of (17 + max_ids) int32 words, rank-major; synchronises the side stream */
 int ITM_FN(exchange_table)(itm_exchange* exchange, int32_t* dst_host, size_t words);
 
+/* The acceleration structures a hash scene carries beside the reference's table (none of them part of the reference's state, all
+ * derived from it): a block directory and a slot directory over a cube of 512^3 blocks, an sdf mirror over 256^3 blocks for the
+ * short voxel types.  The cubes are NOT tied to the world origin: the first frame places them around its camera (the reference's
+ * table has no spatial limit, Objects/ITMVoxelBlockHash.h:22-100, and an external pose source chooses the world frame), a frame
+ * whose view leaves a cube moves it (emptied and refilled from the table on the frame's stream, O(allocated blocks)).  Blocks outside
+ * a cube are found through the table as the reference finds them.  origin_*: block coordinates of cell (0, 0, 0); moves: cube moves
+ * since creation; *_bytes: device memory of each structure (0 = absent). */
+typedef struct itm_accel_info {
+  int64_t directory_bytes, slot_directory_bytes, mirror_bytes;
+  int32_t origin_directory[3], origin_mirror[3];
+  int32_t placed;
+  int64_t moves;
+} itm_accel_info;
+int ITM_FN(scene_accel_info)(const itm_scene* scene, itm_accel_info* out);
+
 /* Device address of a buffer (zero-copy hand-off to e.g. a collective); NULL if absent. */
 void* ITM_FN(buffer_ptr)(const itm_scene* scene, const itm_render_state* rs, int which);
 

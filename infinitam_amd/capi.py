@@ -136,6 +136,12 @@ def declared_functions() -> list:
     return sorted(set(n for n in names if n != "name"))
 
 
+class AccelInfo(C.Structure):
+    """itm_accel_info (include/itm_hip.h)."""
+    _fields_ = [("directory_bytes", C.c_int64), ("slot_directory_bytes", C.c_int64), ("mirror_bytes", C.c_int64),
+                ("origin_directory", C.c_int32 * 3), ("origin_mirror", C.c_int32 * 3), ("placed", C.c_int32), ("moves", C.c_int64)]
+
+
 class ItmError(RuntimeError):
     pass
 
@@ -220,6 +226,7 @@ _HOST_IO_SIGS = {
     "debug_column_cull_rows": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int, C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                          C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "debug_dense_classify_check": (C.c_int, [C.POINTER(C.c_int32), C.c_int]),
+    "scene_accel_info": (C.c_int, [_P, C.POINTER(AccelInfo)]),
     # multi-stream exchange issued from the library (RCCL); the CPU shims exchange through torch.distributed (streams.py)
     "exchange_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
     "exchange_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.POINTER(_P)]),
@@ -453,6 +460,13 @@ class Scene:
 
     def buffer_ptr(self, which, rs=None) -> int:
         return self.be.fn["buffer_ptr"](_P(self.h), _P(rs.h if rs else None), which) or 0
+
+    def accel_info(self) -> dict:
+        """Sizes, placement and move count of the directory / mirror cubes (product library only)."""
+        a = AccelInfo()
+        self.be.check(self.be.fn["scene_accel_info"](_P(self.h), C.byref(a)), "scene_accel_info")
+        return {"directory_bytes": a.directory_bytes, "slot_directory_bytes": a.slot_directory_bytes, "mirror_bytes": a.mirror_bytes,
+                "origin_directory": list(a.origin_directory), "origin_mirror": list(a.origin_mirror), "placed": bool(a.placed), "moves": a.moves}
 
     def process_frame(self, view: View, rs: "RenderState", points: DevBuffer, normals: DevBuffer, stream=None):
         """ITMDenseMapper::ProcessFrame + ITMTrackingController::Prepare (Engine/ITMMainEngine.cpp:123-126)."""

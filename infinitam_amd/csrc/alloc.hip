@@ -52,6 +52,7 @@ struct AllocParams {
   int stepBits;
   int capIds;
   int mirrorFloat;   // the sdf mirror holds floats (ITMVoxel_f / _f_rgb) rather than shorts
+  AccelOrigin org;   // where the block directory / slot directory / sdf mirror cubes lie (itm_types.h)
 };
 
 struct BlockRay {
@@ -119,7 +120,7 @@ __global__ void __launch_bounds__(256) request_kernel(const float* __restrict__ 
     if (dirSlot) {
       // a block that exists inside the directory's cube: its table slot from one coherent load (entries are never swapped out:
       // ptr >= 0, hence type 1); every other case takes the probe below
-      const uint32_t ux = (uint32_t)(bx + kDirHalf), uy = (uint32_t)(by + kDirHalf), uz = (uint32_t)(bz + kDirHalf);
+      const uint32_t ux = (uint32_t)(bx - p.org.dx), uy = (uint32_t)(by - p.org.dy), uz = (uint32_t)(bz - p.org.dz);
       if (dir_covers(ux, uy, uz)) {
         const int slot = dirSlot[dir_cell(ux, uy, uz)];
         if (slot >= 0) {
@@ -267,8 +268,8 @@ __device__ inline void sweep_chunk(int* lds, uint32_t* __restrict__ allocKey, co
         hash[p.bucketNum + off] = pack_entry(bx, by, bz, 0, ptr);
         if (ACROSS) __hip_atomic_store(&visT[p.bucketNum + off], (uint8_t)(lazy ? 0x81 : 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else visT[p.bucketNum + off] = lazy ? 0x81 : 1;
-        directory_insert(dirPtr, dirSlot, bx, by, bz, ptr, p.bucketNum + off);
-        mirror_init_block(sdfMirror, p.mirrorFloat != 0, bx, by, bz);
+        directory_insert(dirPtr, dirSlot, p.org, bx, by, bz, ptr, p.bucketNum + off);
+        mirror_init_block(sdfMirror, p.mirrorFloat != 0, p.org, bx, by, bz);
       }
     } else if (vbaIdx[k] >= 0) {
       int bx, by, bz;
@@ -276,8 +277,8 @@ __device__ inline void sweep_chunk(int* lds, uint32_t* __restrict__ allocKey, co
       const int ptr = ptrNew[k];
       hash[slot] = pack_entry(bx, by, bz, 0, ptr);
       atomicOr(&headBits[slot >> 5], 1u << (slot & 31));
-      directory_insert(dirPtr, dirSlot, bx, by, bz, ptr, slot);
-      mirror_init_block(sdfMirror, p.mirrorFloat != 0, bx, by, bz);
+      directory_insert(dirPtr, dirSlot, p.org, bx, by, bz, ptr, slot);
+      mirror_init_block(sdfMirror, p.mirrorFloat != 0, p.org, bx, by, bz);
     }
     allocKey[slot] = 0u;
   }
@@ -593,6 +594,7 @@ static int fill_params(const itm_scene* s, const float* M, const float* intr, in
   p.noTotalEntries = s->noTotalEntries;
   p.capIds = capIds;
   p.mirrorFloat = (s->cfg.voxelType == ITM_VOXEL_F || s->cfg.voxelType == ITM_VOXEL_F_RGB) ? 1 : 0;
+  p.org = s->org;
   int pixBits = 1;
   while ((1ll << pixBits) < (long long)W * H) ++pixBits;
   p.stepBits = 31 - pixBits;
@@ -609,6 +611,11 @@ int launch_request_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, 
   AllocParams p;
   int rc = fill_params(s, v->M_d, v->intr_d, v->w, v->h, rs->capIds, p);
   if (rc) return rc;
+  // the acceleration cubes follow the camera: placed by the first frame, moved (emptied and refilled from the table, on this stream)
+  // when the view leaves them
+  rc = accel_place(s, p.invM.m, st);
+  if (rc) return rc;
+  p.org = s->org;
   if (p.stepBits < 4) return set_error(ITM_ERR_INVALID, "depth image too large for the allocation key");
   const int nChunks = s->numChunks;
   int2* reqCur = (int2*)s->chunkReq + (size_t)(s->frameParity & 1u) * nChunks;

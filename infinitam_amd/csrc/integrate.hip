@@ -42,6 +42,7 @@ struct FuseParams {
   int maxW;
   int W, H, Wc, Hc;
   int stopAtMax;
+  AccelOrigin org;  // where the sdf mirror cube lies (hash scenes)
 };
 
 // Depth part, stage 1: project the voxel; returns the index of the depth pixel it falls on, or -1 when the voxel
@@ -247,7 +248,7 @@ __device__ inline void integrate_item(const HashEntry& he, int z0, int lane, typ
   using MC = MirrorCodec<VX::kShort>;
   size_t mbase = 0;
   typename MC::T* mirror = nullptr;
-  if (sdfMirror && mirror_index(he.px * kBlockSide, he.py * kBlockSide, he.pz * kBlockSide, mbase)) mirror = (typename MC::T*)sdfMirror;
+  if (sdfMirror && mirror_index(p.org, he.px * kBlockSide, he.py * kBlockSide, he.pz * kBlockSide, mbase)) mirror = (typename MC::T*)sdfMirror;
   // stage 1: project every slice's voxel; stage 2: all depth pixels together; stage 3: update (+ colour), store what changed
   int pix[kSlices];
   float pcz[kSlices], mz[kSlices];
@@ -914,6 +915,7 @@ int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipS
   }
   p.W = v->w; p.H = v->h; p.Wc = v->w_rgb; p.Hc = v->h_rgb;
   p.stopAtMax = s->prm.stopIntegratingAtMaxW;
+  p.org = s->org;
   const uchar4* rgb = (const uchar4*)v->rgb;
   const bool colour = (s->cfg.voxelType == ITM_VOXEL_S_RGB || s->cfg.voxelType == ITM_VOXEL_F_RGB);
   if (colour && (!rgb || v->w_rgb <= 0 || v->h_rgb <= 0)) return set_error(ITM_ERR_INVALID, "colour voxels need an rgb image");

@@ -78,6 +78,12 @@ struct itm_scene {
   int32_t* dirPtr = nullptr;      // int32[kDirCells]  (512 MB)
   int32_t* dirSlot = nullptr;     // int32[kDirCells]  (512 MB): table slot of the block at that position or -1 (request kernel)
   void* sdfMirror = nullptr;      // int16 / uint32 [kMirrorCells * 512]  (17 / 34 GB; hash scenes, itm_types.h) or nullptr
+  // Where the two cubes lie (scene.hip, accel_place): re-placed around the camera when the view leaves them.  Invariant: the only
+  // non-empty cells of dirPtr / dirSlot / sdfMirror are those of table entries with ptr >= 0 at `org` -- every path that replaces
+  // the table or moves the origin empties exactly those cells first (O(allocated blocks), no 18 GB memset)
+  itm::AccelOrigin org = {-itm::kDirHalf, -itm::kDirHalf, -itm::kDirHalf, -itm::kMirrorHalf, -itm::kMirrorHalf, -itm::kMirrorHalf + itm::kMirrorShift};
+  bool orgPlaced = false;         // false until the first frame (or an upload) has placed the cubes
+  long long accelMoves = 0;       // times the cubes were re-placed (itm_scene_accel_info)
   uint32_t frameParity = 0;
   // dense integration: min / max tiles of the frame's depth image (integrate.hip), allocated on first use
   float2* depthTiles = nullptr;
@@ -176,6 +182,8 @@ extern int g_debug_tracker_host_command;
 extern int g_debug_no_sdf_mirror;
 extern int g_debug_separate_sweep;
 int rebuild_sdf_mirror(itm_scene* s, hipStream_t st);
+int accel_unfill(itm_scene* s, hipStream_t st);                      // empties the cubes through the table that filled them
+int accel_place(itm_scene* s, const float* invM, hipStream_t st);    // (re-)places the cubes around a view
 extern int g_debug_no_fused_projection;
 int rebuild_head_bits(itm_scene* s, hipStream_t st);   // occupancy bitmap AND block directory, from the table
 extern int g_debug_no_directory;

@@ -200,6 +200,9 @@ struct VoxelFRgb {  // ITMVoxel_f_rgb: {f32 sdf @0; u8 w_depth @4; u8 clr[3] @5;
 //   dirPtr[cell]   int32: voxel-block index (ITMHashEntry::ptr) of the block at that position, -1 if none.  Cells are
 //                  stored brick-major: a brick = 4x4x4 blocks = 64 cells = 256 contiguous bytes, so the rays of a wave
 //                  (neighbouring pixels) read one or two cache lines per step.
+// The cube is NOT tied to the world origin: AccelOrigin (below) holds the block coordinate of its cell (0, 0, 0), placed around the
+// camera when the first frame arrives and moved when the camera leaves (scene.hip, accel_place): the reference's table has no
+// spatial limit (Objects/ITMVoxelBlockHash.h:22-100), and the frame an external pose source uses is not ours to choose.
 // Blocks outside the covered cube are looked up through the hash table as before.  The array is written by the allocation
 // sweep for every block it allocates (and rebuilt from the table after an upload), so it holds exactly the entries with
 // ptr >= 0 -- the ones the reference's readVoxel finds (DeviceAgnostic/ITMRepresentationAccess.h:85-119).
@@ -215,7 +218,14 @@ constexpr int kDirSide = 1 << kDirBits;        // 512 blocks per axis: +-8.2 m a
 constexpr int kDirHalf = kDirSide / 2;
 constexpr size_t kDirCells = (size_t)kDirSide * kDirSide * kDirSide;
 
-// biased block coordinates (each in [0, kDirSide) when the block is covered)
+// Where the two acceleration cubes lie in the world: block coordinates of the directory's cell (0, 0, 0) and of the mirror's.
+// Passed to kernels by value; changed only by the host between launches (scene.hip: accel_place re-fills the cubes around it).
+struct AccelOrigin {
+  int32_t dx, dy, dz;
+  int32_t mx, my, mz;
+};
+
+// cube-relative block coordinates (each in [0, kDirSide) when the block is covered)
 __host__ __device__ inline bool dir_covers(uint32_t ux, uint32_t uy, uint32_t uz) { return ((ux | uy | uz) >> kDirBits) == 0u; }
 __host__ __device__ inline uint32_t dir_cell(uint32_t ux, uint32_t uy, uint32_t uz) {
   const uint32_t brick = ((uz >> 2) << (2 * (kDirBits - 2))) | ((uy >> 2) << (kDirBits - 2)) | (ux >> 2);
@@ -224,8 +234,8 @@ __host__ __device__ inline uint32_t dir_cell(uint32_t ux, uint32_t uy, uint32_t 
 // records an allocated block (device side; called by the allocation sweep and the rebuild kernel)
 // (dirSlot: the same cells holding the TABLE SLOT of the block instead of its voxel-block index -- what the allocation request
 // needs to mark a block that already exists as visible, one coherent 4-byte load instead of the 16-byte entry of a random bucket)
-__device__ inline void directory_insert(int32_t* __restrict__ dirPtr, int32_t* __restrict__ dirSlot, int bx, int by, int bz, int ptr, int slot) {
-  const uint32_t ux = (uint32_t)(bx + kDirHalf), uy = (uint32_t)(by + kDirHalf), uz = (uint32_t)(bz + kDirHalf);
+__device__ inline void directory_insert(int32_t* __restrict__ dirPtr, int32_t* __restrict__ dirSlot, const AccelOrigin& org, int bx, int by, int bz, int ptr, int slot) {
+  const uint32_t ux = (uint32_t)(bx - org.dx), uy = (uint32_t)(by - org.dy), uz = (uint32_t)(bz - org.dz);
   if (dir_covers(ux, uy, uz)) {
     const uint32_t cell = dir_cell(ux, uy, uz);
     dirPtr[cell] = ptr;
@@ -237,8 +247,8 @@ __device__ inline void directory_insert(int32_t* __restrict__ dirPtr, int32_t* _
 // A second copy of the sdf of every voxel, addressed by POSITION instead of through the block pointer:
 //   sdfMirror[mirror_cell(block) * 512 + voxel-in-block]   the voxel's raw sdf (int16 for the short voxel types, the float's bits
 //                                                          for the float types), or an "absent" pattern where no block is allocated
-// over the block coordinates [-128, 128) x [-128, 128) x [-64, 192) -- the world frame is the first camera's, scenes extend in +z --
-// i.e. 256^3 cells x 1 KB = 17 GB (short) / 2 KB = 34 GB (float) of the 288 GB.  The pointer chase of a ray step -- directory cell,
+// over a cube of 256^3 blocks placed in front of the camera (AccelOrigin: centred kMirrorShift blocks along the viewing direction
+// of the frame that placed it, moved when the view leaves it), i.e. 256^3 cells x 1 KB = 17 GB (short) / 2 KB = 34 GB (float) of the 288 GB.  The pointer chase of a ray step -- directory cell,
 // then voxel, two dependent round trips -- becomes one load whose address follows from the position alone, and the eight reads of a
 // trilinear sample are independent of any look-up.  "Absent": -32768 cannot be a stored short sdf ((short)(f * 32767) with f in
 // [-1, 1]); 0xFFFFFFFF is a NaN no arithmetic produces.  Written wherever voxels are written: at allocation (the initial value),
@@ -249,7 +259,7 @@ __device__ inline void directory_insert(int32_t* __restrict__ dirPtr, int32_t* _
 constexpr int kMirrorBits = ITM_MIRROR_BITS;
 constexpr int kMirrorSide = 1 << kMirrorBits;
 constexpr int kMirrorHalf = kMirrorSide / 2;
-constexpr int kMirrorShiftZ = kMirrorSide / 4;     // the cube is centred kMirrorShiftZ blocks in front of the origin
+constexpr int kMirrorShift = kMirrorSide / 4;      // the cube is centred kMirrorShift blocks in front of the camera that placed it
 constexpr size_t kMirrorCells = (size_t)kMirrorSide * kMirrorSide * kMirrorSide;
 template <bool SHORT> struct MirrorCodec;
 template <> struct MirrorCodec<true> {
@@ -270,17 +280,17 @@ __host__ __device__ inline uint32_t mirror_cell(uint32_t ux, uint32_t uy, uint32
   return (brick << 6) | ((uz & 3u) << 4) | ((uy & 3u) << 2) | (ux & 3u);
 }
 // mirror index of the voxel at integer point (px, py, pz); false when its block lies outside the mirrored cube
-__host__ __device__ inline bool mirror_index(int px, int py, int pz, size_t& idx) {
-  const uint32_t ux = (uint32_t)((px >> 3) + kMirrorHalf), uy = (uint32_t)((py >> 3) + kMirrorHalf), uz = (uint32_t)((pz >> 3) + kMirrorHalf - kMirrorShiftZ);
+__host__ __device__ inline bool mirror_index(const AccelOrigin& org, int px, int py, int pz, size_t& idx) {
+  const uint32_t ux = (uint32_t)((px >> 3) - org.mx), uy = (uint32_t)((py >> 3) - org.my), uz = (uint32_t)((pz >> 3) - org.mz);
   if (!mirror_covers(ux, uy, uz)) return false;
   idx = (size_t)mirror_cell(ux, uy, uz) * 512u + (size_t)((px & 7) + ((py & 7) << 3) + ((pz & 7) << 6));
   return true;
 }
 
 // a block has just been allocated: its voxels hold the initial value (sdf 32767 / 1.0f); called by one thread (the allocation sweep)
-__device__ inline void mirror_init_block(void* __restrict__ mirror, bool floatSdf, int bx, int by, int bz) {
+__device__ inline void mirror_init_block(void* __restrict__ mirror, bool floatSdf, const AccelOrigin& org, int bx, int by, int bz) {
   size_t base;
-  if (!mirror || !mirror_index(bx * 8, by * 8, bz * 8, base)) return;
+  if (!mirror || !mirror_index(org, bx * 8, by * 8, bz * 8, base)) return;
   if (floatSdf) {
     uint4* q = (uint4*)((uint32_t*)mirror + base);         // 2 KB, 16-byte aligned
     const uint4 init = make_uint4(0x3f800000u, 0x3f800000u, 0x3f800000u, 0x3f800000u);

@@ -83,7 +83,7 @@ __device__ inline void edge_vertex(const float* p1, const float* p2, float v1, f
 
 // block base (voxel index of its first voxel) of block (bx, by, bz), or -1: directory where it covers, table walk elsewhere
 __device__ inline int block_base(const VolumeView& vol, int bx, int by, int bz) {
-  const uint32_t ux = (uint32_t)(bx + kDirHalf), uy = (uint32_t)(by + kDirHalf), uz = (uint32_t)(bz + kDirHalf);
+  const uint32_t ux = (uint32_t)(bx - vol.org.dx), uy = (uint32_t)(by - vol.org.dy), uz = (uint32_t)(bz - vol.org.dz);
   if (vol.dirPtr && dir_covers(ux, uy, uz)) {
     const int ptr = vol.dirPtr[dir_cell(ux, uy, uz)];
     return ptr < 0 ? -1 : ptr * kBlockVoxels;

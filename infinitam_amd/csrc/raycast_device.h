@@ -44,6 +44,7 @@ struct VolumeView {
   int bucketNum;
   const int32_t* dirPtr;    // block directory (itm_types.h); nullptr = walk the table (hash index only)
   const void* sdfMirror;    // sdf by position (itm_types.h); nullptr = none (hash index only)
+  AccelOrigin org;          // where the directory / mirror cubes lie
   int sx, sy, sz;      // dense size
   int ox, oy, oz;      // dense offset
 };
@@ -74,7 +75,7 @@ __device__ inline long long locate_voxel(const VolumeView& vol, int px, int py, 
     {
       // covered by the block directory: one load instead of the table walk (same answer: the directory holds exactly
       // the entries with ptr >= 0)
-      const uint32_t ux = (uint32_t)(bx + kDirHalf), uy = (uint32_t)(by + kDirHalf), uz = (uint32_t)(bz + kDirHalf);
+      const uint32_t ux = (uint32_t)(bx - vol.org.dx), uy = (uint32_t)(by - vol.org.dy), uz = (uint32_t)(bz - vol.org.dz);
       if (vol.dirPtr && dir_covers(ux, uy, uz)) {
         const int ptr = vol.dirPtr[dir_cell(ux, uy, uz)];
         if (ptr < 0) return -1;
@@ -108,7 +109,7 @@ __device__ inline float read_raw_sdf(const VolumeView& vol, int px, int py, int 
     // exactly the voxels of the allocated blocks inside its cube)
     using MC = MirrorCodec<VX::kShort>;
     size_t mi;
-    if (vol.sdfMirror && mirror_index(px, py, pz, mi)) {
+    if (vol.sdfMirror && mirror_index(vol.org, px, py, pz, mi)) {
       const typename MC::T v = ((const typename MC::T*)vol.sdfMirror)[mi];
       found = !MC::absent(v);
       return found ? MC::raw(v) : (VX::kShort ? 32767.0f : 1.0f);
@@ -176,7 +177,7 @@ struct Corners {
           size_t mi[8];
           bool all = true;
 #pragma unroll
-          for (int c = 0; c < 8; ++c) all &= mirror_index(ix + (c & 1), iy + ((c >> 1) & 1), iz + (c >> 2), mi[c]);
+          for (int c = 0; c < 8; ++c) all &= mirror_index(vol.org, ix + (c & 1), iy + ((c >> 1) & 1), iz + (c >> 2), mi[c]);
           if (__all(all)) {
             typename MC::T m[8];
 #pragma unroll
@@ -193,7 +194,7 @@ struct Corners {
       const int cross = (lx == 7 ? 1 : 0) | (ly == 7 ? 2 : 0) | (lz == 7 ? 4 : 0);
       const bool cached = (bx == cache.bx && by == cache.by && bz == cache.bz);
       int base[8];
-      const uint32_t ux = (uint32_t)(bx + kDirHalf), uy = (uint32_t)(by + kDirHalf), uz = (uint32_t)(bz + kDirHalf);
+      const uint32_t ux = (uint32_t)(bx - vol.org.dx), uy = (uint32_t)(by - vol.org.dy), uz = (uint32_t)(bz - vol.org.dz);
       const bool viaDir = vol.dirPtr && dir_covers(ux, uy, uz) && dir_covers(ux + 1u, uy + 1u, uz + 1u);
       // block directory: the blocks of the 2x2x2 neighbourhood are eight 4-byte cells, mostly of one 256-byte brick.  A wave
       // whose lanes all sit inside their cached block and away from its upper faces skips the round altogether.
@@ -516,8 +517,8 @@ __device__ inline float4 march_ray(int x, int y, const VolumeView& vol, const Ra
             float qx = px, qy = py, qz = pz;
 #pragma unroll
             for (int j = 0; j < LOOKAHEAD; ++j) {
-              const uint32_t ux = (uint32_t)(((int)round_ref(qx) >> 3) + kDirHalf), uy = (uint32_t)(((int)round_ref(qy) >> 3) + kDirHalf),
-                             uz = (uint32_t)(((int)round_ref(qz) >> 3) + kDirHalf);
+              const uint32_t ux = (uint32_t)(((int)round_ref(qx) >> 3) - vol.org.dx), uy = (uint32_t)(((int)round_ref(qy) >> 3) - vol.org.dy),
+                             uz = (uint32_t)(((int)round_ref(qz) >> 3) - vol.org.dz);
               const bool use = runner && dir_covers(ux, uy, uz);
               const int v = vol.dirPtr[use ? dir_cell(ux, uy, uz) : 0u];
               ahead[j] = use ? v : 0;                               // 0 = "cannot tell / a block": stops the run

@@ -137,25 +137,39 @@ __global__ void __launch_bounds__(256) head_bits_kernel(const uint4* __restrict_
   headBits[w] = bits;
 }
 
-// rebuilds the block directory from the table: every entry with ptr >= 0 whose position lies inside the directory
-__global__ void __launch_bounds__(256) directory_fill_kernel(const uint4* __restrict__ hash, int nEntries, int32_t* __restrict__ dirPtr, int32_t* __restrict__ dirSlot) {
+// ---- the acceleration cubes (block directory, slot directory, sdf mirror; itm_types.h) -------------------------------------------
+// Invariant: the only non-empty cells are those of table entries with ptr >= 0, at the scene's current origin.  So the cubes are
+// emptied by visiting exactly those entries (unfill) -- before the table is reset or replaced, or before the origin moves -- and
+// filled again from the table afterwards: O(allocated blocks) instead of an 18 GB memset per ResetScene / upload / move.
+
+// FILL: records every entry with ptr >= 0 in the directory cubes; !FILL: empties those cells
+template <bool FILL>
+__global__ void __launch_bounds__(256) directory_fill_kernel(const uint4* __restrict__ hash, int nEntries, int32_t* __restrict__ dirPtr, int32_t* __restrict__ dirSlot, AccelOrigin org) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nEntries) return;
   const HashEntry e = unpack_entry(hash[i]);
   if (e.ptr < 0) return;
-  directory_insert(dirPtr, dirSlot, e.px, e.py, e.pz, e.ptr, i);
+  directory_insert(dirPtr, dirSlot, org, e.px, e.py, e.pz, FILL ? e.ptr : -1, FILL ? i : -1);
 }
 
-// rebuilds the sdf mirror from the table and the pool: one workgroup per entry, the 512 sdf values of every allocated block inside the cube
-template <class VX>
-__global__ void __launch_bounds__(256) mirror_fill_kernel(const uint4* __restrict__ hash, int nEntries, const void* __restrict__ vba, void* __restrict__ mirror) {
+// FILL: the 512 sdf values of every allocated block inside the mirror cube, from the pool; !FILL: "no block here" in those cells.
+// One workgroup per entry.
+template <class VX, bool FILL>
+__global__ void __launch_bounds__(256) mirror_fill_kernel(const uint4* __restrict__ hash, int nEntries, const void* __restrict__ vba, void* __restrict__ mirror, AccelOrigin org, size_t numVoxels) {
   using MC = MirrorCodec<VX::kShort>;
   for (int i = blockIdx.x; i < nEntries; i += gridDim.x) {
     const HashEntry e = unpack_entry(hash[i]);
     if (e.ptr < 0) continue;
     size_t base;
-    if (!mirror_index(e.px * kBlockSide, e.py * kBlockSide, e.pz * kBlockSide, base)) continue;
-    for (int t = threadIdx.x; t < kBlockVoxels; t += 256) ((typename MC::T*)mirror)[base + t] = MC::of(VX::load_raw_sdf(vba, (size_t)e.ptr * kBlockVoxels + t));
+    if (!mirror_index(org, e.px * kBlockSide, e.py * kBlockSide, e.pz * kBlockSide, base)) continue;
+    if (FILL && (size_t)e.ptr * kBlockVoxels + kBlockVoxels > numVoxels) continue;      // an uploaded table may hold anything
+    for (int t = threadIdx.x; t < kBlockVoxels; t += 256) {
+      typename MC::T v;
+      if constexpr (FILL) v = MC::of(VX::load_raw_sdf(vba, (size_t)e.ptr * kBlockVoxels + t));
+      else if constexpr (VX::kShort) v = (typename MC::T)-32768;
+      else v = (typename MC::T)0xffffffffu;
+      ((typename MC::T*)mirror)[base + t] = v;
+    }
   }
 }
 
@@ -163,36 +177,114 @@ __global__ void __launch_bounds__(256) mirror_fill_kernel(const uint4* __restric
 #define ITM_MIRROR_FLOAT_TYPES 0
 #endif
 static bool mirror_is_float(const itm_scene* s) { return s->cfg.voxelType == ITM_VOXEL_F || s->cfg.voxelType == ITM_VOXEL_F_RGB; }
-// every cell "no block here": -32768 per short, all ones per float
+// every cell "no block here": -32768 per short, all ones per float (scene creation only)
 static hipError_t mirror_clear(itm_scene* s, hipStream_t st) {
   if (mirror_is_float(s)) return hipMemsetAsync(s->sdfMirror, 0xff, kMirrorCells * 512 * 4, st);
   return hipMemsetD16Async((unsigned short*)s->sdfMirror, (unsigned short)0x8000, kMirrorCells * 512, st);
 }
 
-int rebuild_sdf_mirror(itm_scene* s, hipStream_t st) {
+template <bool FILL>
+static int mirror_pass(itm_scene* s, hipStream_t st) {
   if (!s->sdfMirror) return ITM_OK;
-  ITM_HIP(mirror_clear(s, st));
   int rc = dispatch_voxel(s->cfg.voxelType, [&](auto vx) {
     using VX = decltype(vx);
-    mirror_fill_kernel<VX><<<4096, 256, 0, st>>>(s->hash, s->noTotalEntries, s->vba, s->sdfMirror);
+    mirror_fill_kernel<VX, FILL><<<4096, 256, 0, st>>>(s->hash, s->noTotalEntries, s->vba, s->sdfMirror, s->org, s->numVoxels);
     return ITM_OK;
   });
   if (rc) return rc;
   ITM_LAUNCH_CHECK();
   return ITM_OK;
 }
+template <bool FILL>
+static int directory_pass(itm_scene* s, hipStream_t st) {
+  if (!s->dirPtr) return ITM_OK;
+  directory_fill_kernel<FILL><<<(s->noTotalEntries + 255) / 256, 256, 0, st>>>(s->hash, s->noTotalEntries, s->dirPtr, s->dirSlot, s->org);
+  ITM_LAUNCH_CHECK();
+  return ITM_OK;
+}
 
+// the mirror's values again from the pool (the voxels were replaced, the table was not)
+int rebuild_sdf_mirror(itm_scene* s, hipStream_t st) { return mirror_pass<true>(s, st); }
+
+// empties the cubes: to be called while the table still holds the entries that filled them
+int accel_unfill(itm_scene* s, hipStream_t st) {
+  int rc = directory_pass<false>(s, st);
+  if (rc) return rc;
+  return mirror_pass<false>(s, st);
+}
+
+// occupancy bitmap AND both cubes, from the table (after the table was replaced: accel_unfill ran before the replacement)
 int rebuild_head_bits(itm_scene* s, hipStream_t st) {
   if (!s->headBits) return ITM_OK;
   const int nWords = (s->cfg.bucketNum + 31) / 32;
   head_bits_kernel<<<(nWords + 255) / 256, 256, 0, st>>>(s->hash, s->headBits, nWords, s->cfg.bucketNum);
-  if (s->dirPtr) {
-    ITM_HIP(hipMemsetAsync(s->dirPtr, 0xff, kDirCells * 4, st));
-    if (s->dirSlot) ITM_HIP(hipMemsetAsync(s->dirSlot, 0xff, kDirCells * 4, st));
-    directory_fill_kernel<<<(s->noTotalEntries + 255) / 256, 256, 0, st>>>(s->hash, s->noTotalEntries, s->dirPtr, s->dirSlot);
-  }
   ITM_LAUNCH_CHECK();
-  return ITM_OK;
+  int rc = directory_pass<true>(s, st);
+  if (rc) return rc;
+  return mirror_pass<true>(s, st);
+}
+
+// Where the cubes should lie for a camera at block `cb` looking along `dir`, reaching `reach` blocks: the frustum lies inside
+// the ball of radius 0.7 reach around the point half a reach ahead of the camera.
+static inline int round4(double v) { return (int)floor(v / 4.0 + 0.5) * 4; }
+static bool cube_keeps(const int org[3], int half, const double m[3], double rho) {
+  // the ball (m, rho) inside the cube -- or, for a cube smaller than the ball, its centre within a quarter of the cube's side of m
+  const double slack = rho < half ? half - rho : half * 0.5;
+  for (int k = 0; k < 3; ++k) if (fabs(m[k] - (org[k] + half)) > slack) return false;
+  return true;
+}
+
+// Places (first frame) or re-places the cubes around the view of `invM` (camera -> world).  Moving a cube empties and refills
+// it from the table on `st`: two passes over the table, a kilobyte per allocated block each.
+int accel_place(itm_scene* s, const float* invM, hipStream_t st) {
+  if (!s->dirPtr && !s->sdfMirror) return ITM_OK;
+  const double bs = (double)s->prm.voxelSize * kBlockSide;
+  if (!(bs > 0.0)) return ITM_OK;
+  double cb[3], dir[3], len = 0.0;
+  for (int k = 0; k < 3; ++k) { cb[k] = (double)invM[12 + k] / bs; dir[k] = invM[8 + k]; len += dir[k] * dir[k]; }
+  len = sqrt(len);
+  if (!(len > 0.0) || !std::isfinite(cb[0]) || !std::isfinite(cb[1]) || !std::isfinite(cb[2])) return ITM_OK;
+  const double reach = fmin((double)s->prm.viewFrustum_max / bs + 2.0, 30000.0);
+  double m[3];
+  for (int k = 0; k < 3; ++k) m[k] = cb[k] + dir[k] / len * reach * 0.5;
+  const double rho = 0.7 * reach;
+  AccelOrigin o = s->org;
+  const int dOrg[3] = {o.dx, o.dy, o.dz}, mOrg[3] = {o.mx, o.my, o.mz};
+  const bool moveDir = !s->orgPlaced || !cube_keeps(dOrg, kDirHalf, m, rho);
+  const bool moveMir = !s->orgPlaced || !cube_keeps(mOrg, kMirrorHalf, m, rho);
+  if (!moveDir && !moveMir) return ITM_OK;
+  // a cube smaller than the view is centred further towards the camera (the near part of the frustum holds most rays' steps)
+  auto centre = [&](int half, int k) { const double ahead = fmin(reach * 0.5, (double)half * 0.5); return round4(cb[k] + dir[k] / len * ahead); };
+  if (moveDir) { o.dx = centre(kDirHalf, 0) - kDirHalf; o.dy = centre(kDirHalf, 1) - kDirHalf; o.dz = centre(kDirHalf, 2) - kDirHalf; }
+  if (moveMir) { o.mx = centre(kMirrorHalf, 0) - kMirrorHalf; o.my = centre(kMirrorHalf, 1) - kMirrorHalf; o.mz = centre(kMirrorHalf, 2) - kMirrorHalf; }
+  const bool first = !s->orgPlaced;
+  s->orgPlaced = true;
+  if (first) { s->org = o; return ITM_OK; }       // nothing allocated yet: the cubes are empty wherever they lie
+  int rc = ITM_OK;
+  if (moveDir) rc = directory_pass<false>(s, st);
+  if (!rc && moveMir) rc = mirror_pass<false>(s, st);
+  if (rc) return rc;
+  s->org = o;
+  ++s->accelMoves;
+  if (moveDir) rc = directory_pass<true>(s, st);
+  if (!rc && moveMir) rc = mirror_pass<true>(s, st);
+  return rc;
+}
+
+// after an upload of the table: the cubes around the centre of the allocated blocks of `entries` (host copy of what was uploaded)
+static void accel_place_for_table(itm_scene* s, const HashEntry* entries, size_t n) {
+  long long lo[3] = {1 << 30, 1 << 30, 1 << 30}, hi[3] = {-(1 << 30), -(1 << 30), -(1 << 30)};
+  bool any = false;
+  for (size_t i = 0; i < n; ++i) {
+    if (entries[i].ptr < 0) continue;
+    const int c[3] = {entries[i].px, entries[i].py, entries[i].pz};
+    for (int k = 0; k < 3; ++k) { if (c[k] < lo[k]) lo[k] = c[k]; if (c[k] > hi[k]) hi[k] = c[k]; }
+    any = true;
+  }
+  if (!any) { s->orgPlaced = false; return; }
+  const int c[3] = {round4((lo[0] + hi[0]) * 0.5), round4((lo[1] + hi[1]) * 0.5), round4((lo[2] + hi[2]) * 0.5)};
+  s->org = {c[0] - kDirHalf, c[1] - kDirHalf, c[2] - kDirHalf, c[0] - kMirrorHalf, c[1] - kMirrorHalf, c[2] - kMirrorHalf};
+  s->orgPlaced = true;
 }
 
 __global__ void reset_dense_kernel(int32_t* allocList, SceneCounters* counters) {
@@ -410,6 +502,19 @@ int itm_scene_create(const itm_scene_config* cfg_in, const itm_scene_params* prm
 
 int itm_scene_destroy(itm_scene* s) { free_scene(s); return ITM_OK; }
 
+int itm_scene_accel_info(const itm_scene* s, itm_accel_info* out) {
+  if (!s || !out) return set_error(ITM_ERR_INVALID, "null argument");
+  memset(out, 0, sizeof *out);
+  out->directory_bytes = s->dirPtr ? (int64_t)(kDirCells * 4) : 0;
+  out->slot_directory_bytes = s->dirSlot ? (int64_t)(kDirCells * 4) : 0;
+  out->mirror_bytes = s->sdfMirror ? (int64_t)(kMirrorCells * 512 * (s->cfg.voxelType == ITM_VOXEL_F || s->cfg.voxelType == ITM_VOXEL_F_RGB ? 4 : 2)) : 0;
+  out->origin_directory[0] = s->org.dx; out->origin_directory[1] = s->org.dy; out->origin_directory[2] = s->org.dz;
+  out->origin_mirror[0] = s->org.mx; out->origin_mirror[1] = s->org.my; out->origin_mirror[2] = s->org.mz;
+  out->placed = s->orgPlaced ? 1 : 0;
+  out->moves = s->accelMoves;
+  return ITM_OK;
+}
+
 int itm_scene_get_config(const itm_scene* s, itm_scene_config* c, itm_scene_params* p) {
   if (!s) return set_error(ITM_ERR_INVALID, "null scene");
   if (c) *c = s->cfg;
@@ -433,9 +538,10 @@ int itm_reset_scene(itm_scene* s, itm_stream stream) {
   }
   ITM_LAUNCH_CHECK();
   if (s->cfg.indexType == ITM_INDEX_HASH) {
-    ITM_HIP(hipMemsetAsync(s->dirPtr, 0xff, kDirCells * 4, st));
-    ITM_HIP(hipMemsetAsync(s->dirSlot, 0xff, kDirCells * 4, st));
-    if (s->sdfMirror) ITM_HIP(mirror_clear(s, st));
+    // the cubes are emptied through the table that filled them (a few MB of stores instead of an 18 GB memset), then the table is reset;
+    // the next frame places them around its camera
+    { int rc = accel_unfill(s, st); if (rc) return rc; }
+    s->orgPlaced = false;
     reset_hash_kernel<<<1024, 256, 0, st>>>(s->hash, s->noTotalEntries, s->excessList, s->cfg.excessNum, s->allocList,
                                             s->cfg.localBlockNum, s->allocKey, s->headBits, (s->cfg.bucketNum + 31) / 32, s->chunkReq, s->numChunks * 4, s->counters);
   } else {
@@ -603,9 +709,18 @@ int itm_upload(itm_scene* s, itm_render_state* rs, int which, const void* src, s
   size_t b; void* p = buffer_of(s, rs, which, &b);
   if (!p || !src || bytes > b) return set_error(ITM_ERR_INVALID, "bad buffer / size");
   hipStream_t st = as_stream(stream);
+  if (which == ITM_BUF_HASH_ENTRIES) { int rc = accel_unfill(s, st); if (rc) return rc; }      // while the table still holds what filled the cubes
   ITM_HIP(hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, st));
-  if (which == ITM_BUF_HASH_ENTRIES) { int rc = rebuild_head_bits(s, st); if (rc) return rc; }
-  if (which == ITM_BUF_HASH_ENTRIES || which == ITM_BUF_VOXEL_BLOCKS) { int rc = rebuild_sdf_mirror(s, st); if (rc) return rc; }   // whichever comes last leaves it consistent
+  if (which == ITM_BUF_HASH_ENTRIES) {
+    if (bytes < b) {          // a partial upload: the rest of the table stays; place by the whole table as it now is
+      std::vector<HashEntry> all(b / sizeof(HashEntry));
+      ITM_HIP(hipMemcpyAsync(all.data(), p, b, hipMemcpyDeviceToHost, st));
+      ITM_HIP(hipStreamSynchronize(st));
+      accel_place_for_table(s, all.data(), all.size());
+    } else accel_place_for_table(s, (const HashEntry*)src, bytes / sizeof(HashEntry));
+    int rc = rebuild_head_bits(s, st); if (rc) return rc;
+  }
+  if (which == ITM_BUF_VOXEL_BLOCKS) { int rc = rebuild_sdf_mirror(s, st); if (rc) return rc; }   // the table is the same, the values are new
   if (rs && (which == ITM_BUF_VISIBLE_IDS || which == ITM_BUF_VISIBLE_TYPE)) rs->listCoherent = false;
   if (rs) rs->denseRangeReady = false;
   ITM_HIP(hipStreamSynchronize(st));

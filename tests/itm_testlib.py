@@ -105,6 +105,7 @@ class Scenario:
     maxRenderingBlocks: int = 0
     colour: bool = False
     noise_seed: Optional[int] = None
+    origin: tuple = (0.0, 0.0, 0.0)   # metres added to every camera position: the scene and its trajectory far from the world origin (same depth images)
 
     def params(self):
         return default_params(self.voxelSize, self.mu, self.maxW, 0.35, 3.0, self.stopIntegratingAtMaxW)
@@ -119,6 +120,8 @@ class Scenario:
 
     def pose(self, k):
         t = self.position(k)
+        if any(self.origin):
+            t = tuple(np.float32(a) + np.float32(b) for a, b in zip(t, self.origin))
         if self.trajectory == "yaw":
             return synth.pose_matrix_yaw(t, 0.02 * k)
         return synth.pose_matrix(t)

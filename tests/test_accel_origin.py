@@ -1,0 +1,158 @@
+"""The acceleration structures (block directory, slot directory, sdf mirror) follow the camera instead of sitting at the world origin:
+the reference's table has no spatial limit (Objects/ITMVoxelBlockHash.h:22-100) and this fork takes poses from an external source
+(ITMExternalTracker.cpp:27-30) in whatever world frame the robot uses.  Results far from the origin, across cube moves, after a
+reset and after an upload must equal the oracle's bit for bit -- a stale or missing cell would show up as a different ray-cast hit --
+and the cubes must actually be where the camera is (otherwise every look-up silently walks the table)."""
+import numpy as np
+import pytest
+
+import itm_testlib as T
+from infinitam_amd import capi, synth
+
+F = np.float32
+
+
+def cam_block(M_d, voxel_size):
+    """Block coordinates of the camera centre of a world->camera pose (column-major 16 floats)."""
+    M = np.asarray(M_d, np.float64).reshape(4, 4).T
+    c = -M[:3, :3].T @ M[:3, 3]
+    return c / (voxel_size * 8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("origin", [(20.0, -12.0, 8.0), (-150.0, 3.0, -40.0)])
+def test_scene_far_from_the_world_origin(hip, oracle, origin):
+    sc = T.Scenario(name="far", w=320, h=240, voxelSize=0.005, frames=3, origin=origin)
+    ses = T.Session(hip, sc)
+    for k in range(sc.frames):
+        v = ses.frame(k, fused=True)
+    a = ses.snapshot()
+    a.counters = [ses.scene.counters(ses.rs)]
+    info = ses.scene.accel_info()
+    b = T.run_scenario(oracle, sc)
+    b.counters = b.counters[-1:]
+    T.compare_results(a, b, sc, what="far from the origin")
+    # the cubes were placed around this camera: it sits well inside both
+    cb = cam_block(v.M_d, sc.voxelSize)
+    assert info["placed"] and info["directory_bytes"] > 0
+    assert np.all(np.abs(np.array(info["origin_directory"]) + 256 - cb) < 200), (info, cb)
+    if info["mirror_bytes"]:
+        assert np.all(np.abs(np.array(info["origin_mirror"]) + 128 - cb) < 100), (info, cb)
+    assert np.count_nonzero(a.raycast[..., 3] > 0) > 20000
+    ses.close()
+
+
+def walk_poses():
+    """A camera that walks 9 m along x, 6 m along z and then turns around: further than either cube reaches at 5 mm voxels."""
+    poses, pos = [], np.zeros(3)
+    for k in range(6):
+        poses.append(synth.pose_matrix(pos.astype(F)))
+        pos = pos + np.array([1.5, 0.0, 0.0])
+    for k in range(3):
+        poses.append(synth.pose_matrix(pos.astype(F)))
+        pos = pos + np.array([0.0, 0.0, 2.0])
+    for k in range(4):
+        poses.append(synth.pose_matrix_yaw(pos.astype(F), 1.0 * (k + 1)))
+    return poses
+
+
+def walk(be, per_frame, fused):
+    sc = T.Scenario(name="walk", w=160, h=120, voxelSize=0.005, localBlockNum=0x40000)
+    ses = T.Session(be, sc)
+    intr = sc.intr()
+    out = []
+    for k, M in enumerate(walk_poses()):
+        depth = be.to_backend(synth.depth_frame(sc.w, sc.h, synth.parity_position(k), intr))
+        v = capi.View(depth, sc.w, sc.h, M_d=M, intr_d=intr)
+        if fused:
+            ses.scene.process_frame(v, ses.rs, ses.points, ses.normals)
+        else:
+            ses.scene.reco.AllocateSceneFromDepth(v, ses.rs)
+            ses.scene.reco.IntegrateIntoScene(v, ses.rs)
+            ses.scene.vis.CreateExpectedDepths(v.M_d, v.intr_d, ses.rs)
+            ses.scene.vis.CreateICPMaps(v, ses.rs, ses.points, ses.normals)
+        if per_frame:
+            out.append((ses.scene.counters(ses.rs), ses.scene.download(capi.BUF_RAYCAST_RESULT, ses.rs).copy(), ses.points.numpy().copy()))
+    return ses, sc, out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [True, False])
+def test_cubes_follow_a_camera_that_walks_away_and_turns_around(hip, oracle, fused):
+    hs, sc, got = walk(hip, True, fused)
+    os_, _, want = walk(oracle, True, fused)
+    for k, ((ca, ra, pa), (cb, rb, pb)) in enumerate(zip(got, want)):
+        for key in ("lastFreeBlockId", "lastFreeExcessListId", "noVisibleEntries"):
+            assert ca[key] == cb[key], (k, key, ca, cb)
+        assert np.array_equal(ra[..., 3], rb[..., 3]), "frame %d: hit mask" % k
+        hit = ra[..., 3] > 0
+        assert np.array_equal(ra[hit], rb[hit]), "frame %d: ray-cast hits" % k
+        assert np.array_equal(pa, pb), "frame %d: ICP points" % k
+    a, b = hs.snapshot(), os_.snapshot()
+    T.compare_results(a, b, sc, what="after the walk")
+    info = hs.scene.accel_info()
+    assert info["moves"] >= 3, info              # the walk really left the cubes, several times
+    # the first pose is far outside both cubes now: a free-view ray cast from there walks the table, as the reference does
+    M0 = walk_poses()[0]
+    for ses in (hs, os_):
+        ses.scene.vis.FindVisibleBlocks(M0, sc.intr(), ses.rs)
+        ses.scene.vis.CreateExpectedDepths(M0, sc.intr(), ses.rs)
+        ses.scene.vis.FindSurface(M0, sc.intr(), ses.rs)
+    ra, rb = hs.scene.download(capi.BUF_RAYCAST_RESULT, hs.rs), os_.scene.download(capi.BUF_RAYCAST_RESULT, os_.rs)
+    assert np.array_equal(ra[..., 3], rb[..., 3]) and np.array_equal(ra[ra[..., 3] > 0], rb[rb[..., 3] > 0])
+    assert np.count_nonzero(ra[..., 3] > 0) > 5000
+    hs.close(); os_.close()
+
+
+@pytest.mark.gpu
+def test_reset_empties_the_cubes_and_the_next_frame_places_them_anew(hip, oracle):
+    """ResetScene empties the cubes through the table that filled them (no 18 GB memset): a block of the first life must not be
+    found in the second."""
+    sc1 = T.Scenario(name="life1", w=160, h=120, voxelSize=0.01, frames=2)
+    sc2 = T.Scenario(name="life2", w=160, h=120, voxelSize=0.01, frames=2, origin=(0.3, 0.1, -0.4))     # overlapping the first life's blocks
+    results = []
+    for be in (hip, oracle):                     # the same two lives on both (the render state keeps its visible list across the reset, as the reference's does)
+        ses = T.Session(be, sc1)
+        for k in range(2):
+            ses.frame(k, fused=True)
+        ses.scene.reco.ResetScene()
+        if be is hip:
+            assert not ses.scene.accel_info()["placed"]
+        ses.sc = sc2
+        for k in range(2):
+            ses.frame(k, fused=True)
+        r = ses.snapshot()
+        r.counters = [ses.scene.counters(ses.rs)]
+        results.append(r)
+        ses.close()
+    T.compare_results(results[0], results[1], sc2, what="second life")
+    assert np.count_nonzero(results[0].raycast[..., 3] > 0) > 5000
+
+
+@pytest.mark.gpu
+def test_uploaded_table_places_the_cubes_around_its_blocks(hip, oracle):
+    """A scene built far from the origin, copied into a fresh scene buffer by buffer: the upload empties the cubes through the old
+    table, places them around the new table's blocks and fills them; the ray cast through them equals the oracle's."""
+    sc = T.Scenario(name="copy", w=160, h=120, voxelSize=0.01, frames=2, origin=(-30.0, 25.0, 5.0))
+    src = T.Session(hip, sc)
+    for k in range(2):
+        v = src.frame(k, fused=True)
+    dst = T.Session(hip, T.Scenario(name="dst", w=160, h=120, voxelSize=0.01))
+    dst.frame(0, fused=True)                     # something else in the table and the cubes first
+    for which in (capi.BUF_HASH_ENTRIES, capi.BUF_EXCESS_LIST, capi.BUF_ALLOCATION_LIST, capi.BUF_VOXEL_BLOCKS):
+        dst.scene.upload(which, src.scene.download(which))
+    c = src.scene.counters(src.rs)
+    dst.scene.set_counters(dst.rs, c["lastFreeBlockId"], c["lastFreeExcessListId"], 0)
+    info = dst.scene.accel_info()
+    assert info["placed"] and np.all(np.abs(np.array(info["origin_directory"]) + 256 - cam_block(v.M_d, sc.voxelSize)) < 200), info
+    ref = T.Session(oracle, sc)
+    for k in range(2):
+        ref.frame(k, fused=True)
+    for ses in (dst, ref):
+        ses.scene.vis.FindVisibleBlocks(v.M_d, sc.intr(), ses.rs)
+        ses.scene.vis.CreateExpectedDepths(v.M_d, sc.intr(), ses.rs)
+        ses.scene.vis.FindSurface(v.M_d, sc.intr(), ses.rs)
+    ra, rb = dst.scene.download(capi.BUF_RAYCAST_RESULT, dst.rs), ref.scene.download(capi.BUF_RAYCAST_RESULT, ref.rs)
+    assert np.array_equal(ra[..., 3], rb[..., 3]) and np.array_equal(ra[ra[..., 3] > 0], rb[rb[..., 3] > 0])
+    assert np.count_nonzero(ra[..., 3] > 0) > 3000
+    src.close(); dst.close(); ref.close()
