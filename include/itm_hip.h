@@ -159,6 +159,11 @@ int ITM_FN(dev_free)(void* ptr);
 int ITM_FN(memcpy_h2d)(void* dst_dev, const void* src_host, size_t bytes, itm_stream stream);
 int ITM_FN(memcpy_d2h)(void* dst_host, const void* src_dev, size_t bytes, itm_stream stream);
 int ITM_FN(stream_synchronize)(itm_stream stream);
+/* A stream of the runtime THIS library runs on (hipStreamCreateWithFlags(hipStreamNonBlocking)), for hosts that have no HIP binding of
+ * their own -- or whose process holds a second copy of the runtime (a framework that bundles one): a stream must come from the runtime
+ * that launches on it.  Every `itm_stream` argument also accepts a hipStream_t the host created itself, or NULL (the null stream). */
+int ITM_FN(stream_create)(itm_stream* out);
+int ITM_FN(stream_destroy)(itm_stream stream);
 int ITM_FN(set_device)(int device);
 
 /* Test hooks (no effect on results): select alternative code paths so that they can be covered. */
@@ -179,6 +184,7 @@ int ITM_FN(set_device)(int device);
 #define ITM_DEBUG_NO_SDF_MIRROR 12            /* ray casting: voxels through the directory / table although the scene has an sdf mirror; set before itm_scene_create: no mirror is allocated */
 #define ITM_DEBUG_DENSE_CLASSIFY 16            /* dense integration: 0 = 4-voxel groups classified against the depth tiles before the fetch (default), 1 = no classification, 2 = classified after the fetch, 3 = check mode (itm_debug_dense_classify_check) */
 #define ITM_DEBUG_DENSE_NO_STRIPS 17           /* dense integration: the launch shape of rounds 1-2 (four groups per lane, 131 072 short waves) instead of the strip kernel */
+#define ITM_DEBUG_TRACKER_SESSION_UNUSABLE 18  /* TrackCamera: the resident evaluation kernel reports itself unusable at the n-th evaluation of a handle (n = value): the call must finish through one launch per evaluation with the same pose */
 int ITM_FN(debug_set)(int key, int value);
 /* dense integration, check mode of key 16: {free groups, shadow groups, mixed groups, violations}; reset != 0 clears */
 int ITM_FN(debug_dense_classify_check)(int32_t out[4], int reset);

@@ -227,6 +227,8 @@ _HOST_IO_SIGS = {
                                          C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "debug_dense_classify_check": (C.c_int, [C.POINTER(C.c_int32), C.c_int]),
     "scene_accel_info": (C.c_int, [_P, C.POINTER(AccelInfo)]),
+    "stream_create": (C.c_int, [C.POINTER(_P)]),
+    "stream_destroy": (C.c_int, [_P]),
     # multi-stream exchange issued from the library (RCCL); the CPU shims exchange through torch.distributed (streams.py)
     "exchange_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
     "exchange_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.POINTER(_P)]),

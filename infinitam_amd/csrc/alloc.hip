@@ -28,6 +28,7 @@
 //      (allocate_sweep_kernel / visible_count_kernel / visible_compact_kernel: the same steps as
 //      separate launches, kept for FindVisibleBlocks and behind test hooks.)
 // No host synchronisation: all counts stay in HBM.
+#include <cstdlib>
 #include <cstring>
 
 #include "itm_internal.h"
@@ -104,6 +105,7 @@ __global__ void __launch_bounds__(256) request_kernel(const float* __restrict__ 
   if (FUSE_RANGE_INIT && blockIdx.x == 0 && blockIdx.y == 0) {
     if (threadIdx.x == 0) { rcnt->noRenderingBlocks = 0; rcnt->renderingBlocksAccepted = -1; }
   }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) rcnt->listInvalid = 0;
   const int x = blockIdx.x * 16 + (lane & 15);
   const int y = blockIdx.y * 16 + wave * 4 + (lane >> 4);
   if (x >= p.W || y >= p.H) return;
@@ -459,7 +461,11 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
                       sw.dirPtr, sw.dirSlot, sw.sdfMirror, sw.depth, sw.lazy, p);
     const bool wroteAcross = chunkReq[chunk].y > 0;            // (uniform) only excess allocations are read by other workgroups of this launch
     if (wroteAcross) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this thread's stores have completed ...
+      // this thread's stores must have COMPLETED before the stamp may follow: on gfx950 a workgroup-scope release fence is only
+      // s_waitcnt lgkmcnt(0) -- it does not wait for vector stores -- so the wait is spelled out (loads and stores share vmcnt);
+      // the type bytes and entries were stored with device scope (write-through), nothing is left to write back
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __syncthreads();                                         // ... all of the chunk's have: say that its excess allocations are in place
       if (tid == 0) __hip_atomic_store(&sw.sweepDone[chunk], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -525,7 +531,7 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
   // base = visible slots in all earlier chunks
   look_back();
   ITM_LS(3)
-  if (stuck) atomicOr(&counters->statusFlags, 2);
+  if (stuck) { atomicOr(&counters->statusFlags, 2); rc->listInvalid = 1; }      // sticky for the host; the frame is not fused (integrate.hip)
   const int base = block_reduce_sum<4>(before, lds + 4);
   if (COMMIT_ALLOC && chunk == (SWEEP ? numChunks - 1 : 0)) {
     // (with SWEEP every sweep has read the pool counters by now: all granules are in)
@@ -577,6 +583,13 @@ __global__ void __launch_bounds__(256) freeview_flag_kernel(const uint4* __restr
   }
   const int sum = block_reduce_sum<4>(n, lds);
   if (tid == 0) chunkVis[chunk] = sum;
+}
+
+// Is this scene alone on its device?  (scene.hip keeps the count of live hash scenes.)
+static bool one_pass_list_is_safe(const itm_scene* s) {
+  static const int forced = [] { const char* e = getenv("ITM_ONE_PASS_LIST"); return e ? atoi(e) : -1; }();      // A/B: 1 = always, 0 = never
+  if (forced >= 0) return forced != 0;
+  return live_hash_scenes(s->device) <= 1;
 }
 
 static int fill_params(const itm_scene* s, const float* M, const float* intr, int W, int H, int capIds, AllocParams& p) {
@@ -648,7 +661,15 @@ int launch_sweep_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, bo
   const bool lazy = rs->lazyThisFrame;
   // the sweep rides in the visible-list launch unless a test hook asks for separate launches (or the ordered part of the table
   // does not end on a chunk boundary, which no configuration of the reference produces)
-  const bool fusedSweep = !onlyVisible && !g_debug_two_pass_visible_list && !g_debug_separate_sweep && (s->cfg.bucketNum % kSweepChunk) == 0;
+  // The one-launch list (and the sweep inside it) hand counts from workgroup to workgroup through memory, i.e. workgroups WAIT for
+  // others of the same launch.  That is the fastest form while the scene has the device to itself.  With several scenes live on one
+  // device the launches that never wait are used instead -- separate sweep, count and compaction: waiting workgroups hold compute
+  // units the other scenes' kernels could use (3 scenes: 21.3 k frames/s with the one-launch list, 22.2 k without), and when the
+  // process drives more hardware queues than the device runs at once (GPU_MAX_HW_QUEUES=8, 6 scenes) the queues are time-sliced and
+  // the waits collapse the frame rate (492 frames/s against 19.2 k).  No frame of a multi-scene process contains a wait between
+  // workgroups.
+  const bool onePass = !g_debug_two_pass_visible_list && one_pass_list_is_safe(s);
+  const bool fusedSweep = !onlyVisible && onePass && !g_debug_separate_sweep && (s->cfg.bucketNum % kSweepChunk) == 0;
   if (!onlyVisible) {
     if (!fusedSweep) {
       KernelTimer ts(s, ITM_TK_ALLOC_SWEEP, st);
@@ -658,7 +679,7 @@ int launch_sweep_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, bo
     s->frameParity++;
   }
   KernelTimer tv(s, ITM_TK_VISIBLE_LIST, st);
-  if (!g_debug_two_pass_visible_list) {
+  if (onePass) {
     const uint32_t epoch = ++s->listEpoch;
     const SweepArgs sw{s->allocKey, reqNext, s->excessList, s->allocList, s->headBits, s->dirPtr, s->dirSlot, s->sdfMirror, v->depth, lazy ? 1 : 0, s->chunkSweepDone};
 #define ITM_VL(CM, LZ, SW) visible_list_kernel<CM, LZ, SW><<<nChunks, 256, 0, st>>>(rs->visibleType, s->hash, s->chunkGran, epoch, reqCur, nChunks, s->counters, rs->visibleIds, rs->capIds, rs->counters, p, sw)

@@ -285,6 +285,7 @@ template <class VX>
 __device__ inline void integrate_hash_body(int wgIdx, int wgCount, const int32_t* __restrict__ visibleIds, RenderCounters* __restrict__ rc,
                                            const uint4* __restrict__ hash, void* __restrict__ vba, void* __restrict__ sdfMirror,
                                            const float* __restrict__ depth, const uchar4* __restrict__ rgb, const FuseParams& p) {
+  if (rc->listInvalid) return;                        // the list of this frame is not the reference's: fuse nothing (alloc.hip, statusFlags bit 1)
   const int nItems = rc->noVisibleEntries * kItemsPerBlock;
   const int lane = threadIdx.x & 63;
   const int waves = wgCount * (int)(blockDim.x >> 6);

@@ -26,7 +26,9 @@ struct RenderCounters {
   int32_t noRenderingBlocks;       // numRenderingBlocks of CreateExpectedDepths
   int32_t rawVisibleCount;         // visible slots before clamping to the list capacity
   int32_t renderingBlocksAccepted; // -1, or the count after the cap replay when noRenderingBlocks reached MAX_RENDERING_BLOCKS
-  int32_t pad[2];
+  int32_t listInvalid;             // this frame's visible list could not be ordered (a bounded wait of the one-launch list expired):
+                                   // the integration skips the frame instead of fusing through a wrong list; cleared by the next request
+  int32_t pad[1];
 };
 
 // hipEvent pairs around selected kernels (itm_profile_enable / itm_profile_read)
@@ -82,6 +84,7 @@ struct itm_scene {
   // non-empty cells of dirPtr / dirSlot / sdfMirror are those of table entries with ptr >= 0 at `org` -- every path that replaces
   // the table or moves the origin empties exactly those cells first (O(allocated blocks), no 18 GB memset)
   itm::AccelOrigin org = {-itm::kDirHalf, -itm::kDirHalf, -itm::kDirHalf, -itm::kMirrorHalf, -itm::kMirrorHalf, -itm::kMirrorHalf + itm::kMirrorShift};
+  bool countedLive = false;       // this scene is in the per-device count of live hash scenes
   bool orgPlaced = false;         // false until the first frame (or an upload) has placed the cubes
   long long accelMoves = 0;       // times the cubes were re-placed (itm_scene_accel_info)
   uint32_t frameParity = 0;
@@ -179,9 +182,11 @@ extern int g_debug_dense_classify;
 extern int g_debug_dense_no_strips;
 extern int g_debug_tracker_launch_per_evaluation;
 extern int g_debug_tracker_host_command;
+extern int g_debug_tracker_session_unusable;
 extern int g_debug_no_sdf_mirror;
 extern int g_debug_separate_sweep;
 int rebuild_sdf_mirror(itm_scene* s, hipStream_t st);
+int live_hash_scenes(int device);                                     // hash scenes alive on a device (scene.hip)
 int accel_unfill(itm_scene* s, hipStream_t st);                      // empties the cubes through the table that filled them
 int accel_place(itm_scene* s, const float* invM, hipStream_t st);    // (re-)places the cubes around a view
 extern int g_debug_no_fused_projection;

@@ -4,6 +4,7 @@
 //   ITMScene / ITMLocalVBA   Objects/ITMScene.h:37-43, Objects/ITMLocalVBA.h:40-48
 //   ITMRenderState(_VH)      Objects/ITMRenderState.h:51-75, Objects/ITMRenderState_VH.h:38-47
 //   view builder conversions DeviceAgnostic/ITMViewBuilder.h:7-28
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -367,8 +368,12 @@ static void* buffer_of(const itm_scene* s, const itm_render_state* rs, int which
   return nullptr;
 }
 
+static std::atomic<int> g_liveHashScenes[64];
+int live_hash_scenes(int device) { return (device >= 0 && device < 64) ? g_liveHashScenes[device].load() : 2; }
+
 static void free_scene(itm_scene* s) {
   if (!s) return;
+  if (s->countedLive && s->device >= 0 && s->device < 64) g_liveHashScenes[s->device].fetch_sub(1);
   if (s->prof) { s->prof->flush(); for (hipEvent_t e : s->prof->pool) (void)hipEventDestroy(e); delete s->prof; }
   (void)hipFree(s->hash); (void)hipFree(s->excessList); (void)hipFree(s->vba); (void)hipFree(s->allocList);
   (void)hipFree(s->counters); (void)hipFree(s->headBits); (void)hipFree(s->allocKey); (void)hipFree(s->chunkReq); (void)hipFree(s->chunkVis); (void)hipFree(s->chunkGran); (void)hipFree(s->chunkSweepDone);
@@ -486,6 +491,7 @@ int itm_scene_create(const itm_scene_config* cfg_in, const itm_scene_params* prm
       else if (mirror_clear(s, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) { (void)hipFree(s->sdfMirror); s->sdfMirror = nullptr; (void)hipGetLastError(); }
     }
   }
+  if (cfg.indexType == ITM_INDEX_HASH && s->device >= 0 && s->device < 64) { g_liveHashScenes[s->device].fetch_add(1); s->countedLive = true; }
   e = hipMemset(s->counters, 0, sizeof(SceneCounters));
   if (e == hipSuccess && s->allocKey) e = hipMemset(s->allocKey, 0, (size_t)s->noTotalEntries * 4);
   if (e == hipSuccess && s->headBits) e = hipMemset(s->headBits, 0, (size_t)(cfg.bucketNum + 31) / 32 * 4);
@@ -501,6 +507,19 @@ int itm_scene_create(const itm_scene_config* cfg_in, const itm_scene_params* prm
 }
 
 int itm_scene_destroy(itm_scene* s) { free_scene(s); return ITM_OK; }
+
+int itm_stream_create(itm_stream* out) {
+  if (!out) return set_error(ITM_ERR_INVALID, "null argument");
+  hipStream_t st = nullptr;
+  ITM_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  *out = (itm_stream)st;
+  return ITM_OK;
+}
+int itm_stream_destroy(itm_stream stream) {
+  if (!stream) return ITM_OK;
+  ITM_HIP(hipStreamDestroy(as_stream(stream)));
+  return ITM_OK;
+}
 
 int itm_scene_accel_info(const itm_scene* s, itm_accel_info* out) {
   if (!s || !out) return set_error(ITM_ERR_INVALID, "null argument");

@@ -543,6 +543,10 @@ struct itm_tracker {
   unsigned int seq = 0;
   std::vector<float*> pyramid; std::vector<size_t> pyramidBytes;
   double pollTimeoutSeconds = 5.0;
+  double sessionTimeoutSeconds = 0.5;     // an evaluation through the resident kernel answers in microseconds; after this long it goes through a launch
+  int sessionUsable = -1;                 // -1 not probed yet, 0 launch per evaluation, 1 resident evaluation kernel
+  int sessionFallbacks = 0;
+  int debugEvaluations = 0;
   // evaluation session (gh_session_kernel)
   unsigned long long* cmd = nullptr; unsigned long long* cmdDev = nullptr;   // command granules (BAR-mapped device memory or pinned host memory) + their device address
   itm::GHResult* res = nullptr; itm::GHResult* resDev = nullptr;     // pinned result + its device address
@@ -715,7 +719,10 @@ static int compute_g_and_h(itm_tracker* trk, const float* depth, int w, int h, c
 
 // ---- evaluation session, host side -------------------------------------------------------------------------
 int g_debug_tracker_launch_per_evaluation = 0;   // debug key 10: TrackCamera with one launch per evaluation (the path before the session kernel)
+int g_debug_tracker_session_unusable = 0;        // debug key 18: the resident kernel reports itself unusable at the n-th evaluation of a call (tests the fall-back)
 int g_debug_tracker_host_command = 0;            // debug key 11: session commands through pinned host memory even where the device has a large BAR
+
+constexpr int kSessionUnusable = -1000;     // internal: the resident kernel cannot serve this evaluation, use a launch instead
 
 static int session_reserve(itm_tracker* t) {
   int rc = tracker_reserve(t, kGHGroups);
@@ -826,9 +833,13 @@ static int session_g_and_h(itm_tracker* trk, const float* depth, int w, int h, c
   // gather and of the per-launch path), otherwise the one record of the gathering workgroup.  A session that has left without
   // answering (idle limit hit while this thread was away) is replaced; the wait is bounded in time like the per-launch path's.
   clock::time_point t0; bool timing = false;
+  int relaunches = 0;
   auto slow = [&](const volatile unsigned long long* g) -> int {
     if (trk->res->exited == trk->session && (unsigned int)(*g >> 32) != seq) {
       ITM_TT(fprintf(stderr, "[tracker trace] %p session %u left without answering %u: relaunch\n", (void*)trk, trk->session, seq);)
+      // a session whose workgroups cannot all be resident (compute units masked or taken by another process) leaves again and
+      // again without an answer: after a few replacements the caller takes the launch-per-evaluation path instead
+      if (++relaunches > 3) { trk->sessionOpen = false; return set_error(kSessionUnusable, "tracker session keeps leaving without an answer"); }
       c.session = trk->session + 1u;           // addressed to the new session: workgroups of the old one that are still around leave at once
       write_command(trk, c, seq);
       return session_launch(trk, seq, st);
@@ -838,7 +849,7 @@ static int session_g_and_h(itm_tracker* trk, const float* depth, int w, int h, c
     if (waited < 0.02) return ITM_OK;
     const hipError_t q = hipStreamQuery(st);
     if (q != hipSuccess && q != hipErrorNotReady) { trk->sessionOpen = false; return hip_fail(q, "tracker session", __FILE__, __LINE__); }
-    if (waited > trk->pollTimeoutSeconds) { session_close(trk); return set_error(ITM_ERR_DEVICE, "tracker session timed out"); }
+    if (waited > trk->sessionTimeoutSeconds) { session_close(trk); return set_error(kSessionUnusable, "tracker session timed out"); }
     return ITM_OK;
   };
   double sums[kGHValues];
@@ -931,10 +942,34 @@ static int track_camera(itm_tracker* trk, const itm_tracker_config* cfg, const i
   // that have each got hold of SOME compute units wait for the rest until their idle limits fire (measured with four closed loops
   // on four streams: 10 frames/s).  Calls from other handles / streams / threads queue here for the ~100 us of a call; everything
   // else those streams do (view building, fusion, ray casting) runs beside the session.
+  // The resident kernel needs all kGHGroups workgroups on the device at once (workgroups wait for each other's records).  Where the
+  // device cannot hold them -- fewer compute units than workgroups (partitioned or masked devices, smaller parts) -- and whenever a
+  // session proves unusable at run time (it keeps leaving without an answer, or times out: compute units taken by another process),
+  // evaluations go through one launch each, which needs no co-residency; the sums and the pose are the same bit for bit.
+  if (trk->sessionUsable < 0) {
+    int perCU = 0, dev = 0, cus = 0;
+    (void)hipGetDevice(&dev);
+    const bool ok = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, gh_session_kernel, kGHThreads, 0) == hipSuccess &&
+                    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess;
+    (void)hipGetLastError();
+    trk->sessionUsable = (ok && (long long)perCU * cus >= kGHGroups) ? 1 : 0;
+  }
+  auto per_launch = [&](int level, int mode, const float invPose[16], float distThresh, itm_tracker_gh* e) {
+    return compute_g_and_h(trk, pyr[level].depth, pyr[level].w, pyr[level].h, pyr[level].intr, pointsMap, normalsMap, view->w, view->h,
+                           pyr[0].intr, invPose, scenePose, distThresh, mode, e, st);
+  };
+  if (!trk->sessionUsable) return icp_track(cfg, view->M_d, M_d_out, per_launch);
   std::lock_guard<std::mutex> oneSession(session_gate(trk->device));
   rc = icp_track(cfg, view->M_d, M_d_out, [&](int level, int mode, const float invPose[16], float distThresh, itm_tracker_gh* e) {
-    return session_g_and_h(trk, pyr[level].depth, pyr[level].w, pyr[level].h, pyr[level].intr, pointsMap, normalsMap, view->w, view->h,
-                           pyr[0].intr, invPose, scenePose, distThresh, mode, e, st);
+    if (trk->sessionUsable) {
+      const int r = (g_debug_tracker_session_unusable > 0 && ++trk->debugEvaluations == g_debug_tracker_session_unusable) ? kSessionUnusable : session_g_and_h(trk, pyr[level].depth, pyr[level].w, pyr[level].h, pyr[level].intr, pointsMap, normalsMap, view->w, view->h,
+                                    pyr[0].intr, invPose, scenePose, distThresh, mode, e, st);
+      if (r != kSessionUnusable) return r;
+      session_close(trk);
+      trk->sessionUsable = 0;          // this handle stays on the launch-per-evaluation path
+      ++trk->sessionFallbacks;
+    }
+    return per_launch(level, mode, invPose, distThresh, e);
   });
   session_close(trk);
   ITM_TT(fprintf(stderr, "[tracker trace] call: pyramid launch %.1f us, evaluations %.1f us\n", std::chrono::duration<double, std::micro>(tc1 - tc0).count(),

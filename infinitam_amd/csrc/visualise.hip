@@ -546,6 +546,7 @@ int itm_debug_set(int key, int value) {
   if (key == ITM_DEBUG_NO_SIDE_PROJECTION) { g_debug_no_side_projection = value; return ITM_OK; }
   if (key == ITM_DEBUG_DENSE_RANGE_REFILL) { g_debug_dense_range_refill = value; return ITM_OK; }
   if (key == ITM_DEBUG_DENSE_CLASSIFY) { g_debug_dense_classify = value; return ITM_OK; }
+  if (key == ITM_DEBUG_TRACKER_SESSION_UNUSABLE) { g_debug_tracker_session_unusable = value; return ITM_OK; }
   if (key == ITM_DEBUG_DENSE_NO_STRIPS) { g_debug_dense_no_strips = value; return ITM_OK; }
   return set_error(ITM_ERR_INVALID, "unknown debug key");
 }

@@ -203,6 +203,30 @@ def test_session_kernel_and_launch_per_evaluation_give_the_same_pose_bit_for_bit
         ses.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("nth", [1, 3, 7])
+def test_unusable_session_falls_back_to_one_launch_per_evaluation(hip, nth):
+    """A resident evaluation kernel that cannot serve (its workgroups not co-resident: masked compute units, another process's
+    session, a smaller device) ends the session; the call -- and the handle's later calls -- finish through one launch per
+    evaluation with the same pose, instead of failing with ITM_ERR_DEVICE (debug key 18 makes the n-th evaluation report it)."""
+    ses, v, nxt = build_maps_offaxis(hip)
+    h = C.c_void_p()
+    hip.check(hip.fn["tracker_create"](C.byref(h)), "tracker_create")
+    try:
+        want = track(hip, ses, v, nxt)
+        hip.check(hip.fn["debug_set"](18, nth), "debug_set")
+        try:
+            got = track_with_handle(hip, h, ses, v, nxt)          # the session gives up at evaluation `nth` of this call
+        finally:
+            hip.check(hip.fn["debug_set"](18, 0), "debug_set")
+        assert np.array_equal(got, want), np.abs(got - want).max()
+        for _ in range(3):                                         # and the handle keeps working (launch per evaluation from now on)
+            assert np.array_equal(track_with_handle(hip, h, ses, v, nxt), want)
+    finally:
+        hip.fn["tracker_destroy"](h)
+        ses.close()
+
+
 def track_with_handle(be, handle, ses, v, depth_next, cfg=None):
     cfg = cfg or TrackerConfig.default()
     d = be.to_backend(depth_next)
@@ -245,9 +269,8 @@ def test_four_trackers_on_four_streams_at_once(hip):
     """Four host threads, each with its own tracker handle and HIP stream, call TrackCamera at the same time: four resident
     evaluation kernels share the GPU, every call returns the pose a lone call returns."""
     import threading
-    rt = C.CDLL("libamdhip64.so")            # the runtime the library is linked against (already loaded): streams of its own
-    rt.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
-    rt.hipStreamDestroy.argtypes = [C.c_void_p]
+    # streams from the library's own runtime (itm_stream_create): a process that also holds a framework's bundled copy of the HIP
+    # runtime would otherwise hand the library streams of the wrong one
     ses, v, nxt = build_maps_offaxis(hip)
     handles, streams = [], []
     try:
@@ -262,7 +285,7 @@ def test_four_trackers_on_four_streams_at_once(hip):
             hip.check(hip.fn["tracker_create"](C.byref(h)), "tracker_create")
             handles.append(h)
             st = C.c_void_p()
-            assert rt.hipStreamCreate(C.byref(st)) == 0
+            hip.check(hip.fn["stream_create"](C.byref(st)), "stream_create")
             streams.append(st)
         results, errors = [[] for _ in range(4)], []
         gate = threading.Barrier(4)
@@ -293,7 +316,7 @@ def test_four_trackers_on_four_streams_at_once(hip):
         for h in handles:
             hip.check(hip.fn["tracker_destroy"](h), "tracker_destroy")
         for st in streams:
-            rt.hipStreamDestroy(st)
+            hip.fn["stream_destroy"](st)
         ses.close()
 
 
@@ -470,9 +493,6 @@ def test_four_closed_loops_on_four_streams_keep_trajectory_and_pace(hip):
     import threading
     import time
     frames, loops = 30, 4
-    rt = C.CDLL("libamdhip64.so")
-    rt.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
-    rt.hipStreamDestroy.argtypes = [C.c_void_p]
     sc0 = Scenario(name="loop", voxelSize=0.01, frames=frames)
     depths = [hip.to_backend(sc0.depth(k)) for k in range(frames)]
     _, want = closed_loop(hip, frames=frames, depths=depths)
@@ -480,7 +500,7 @@ def test_four_closed_loops_on_four_streams_keep_trajectory_and_pace(hip):
     try:
         for _ in range(loops):
             h = C.c_void_p(); hip.check(hip.fn["tracker_create"](C.byref(h)), "tracker_create"); handles.append(h)
-            st = C.c_void_p(); assert rt.hipStreamCreate(C.byref(st)) == 0; streams.append(st)
+            st = C.c_void_p(); hip.check(hip.fn["stream_create"](C.byref(st)), "stream_create"); streams.append(st)
         results, errors = [None] * loops, []
         start = threading.Barrier(loops + 1)
 
@@ -511,4 +531,4 @@ def test_four_closed_loops_on_four_streams_keep_trajectory_and_pace(hip):
         for h in handles:
             hip.check(hip.fn["tracker_destroy"](h), "tracker_destroy")
         for st in streams:
-            rt.hipStreamDestroy(st)
+            hip.fn["stream_destroy"](st)

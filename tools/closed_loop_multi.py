@@ -21,8 +21,6 @@ K = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 W, H = 640, 480
 be = capi.Backend(os.environ["ITM_LIB"], "itm_") if os.environ.get("ITM_LIB") else itm.load()
-rt = C.CDLL("libamdhip64.so")
-rt.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
 intr = synth.intrinsics_for(W, H)
 ip = (C.c_float * 4)(*intr)
 raws = [be.to_backend(np.round(synth.depth_frame(W, H, synth.bench_position(k), intr) * 1000.0).astype(np.int16)) for k in range(N)]
@@ -36,7 +34,7 @@ class Loop:
         self.rs = self.scene.vis.CreateRenderState((W, H))
         self.pts = capi.DevBuffer(be, W * H * 16); self.nrm = capi.DevBuffer(be, W * H * 16)
         self.depth = capi.DevBuffer(be, W * H * 4); self.scratch = capi.DevBuffer(be, W * H * 4)
-        self.stream = C.c_void_p(); assert rt.hipStreamCreate(C.byref(self.stream)) == 0
+        self.stream = C.c_void_p(); be.check(be.fn["stream_create"](C.byref(self.stream)), "stream_create")
         self.tracker = C.c_void_p(); be.check(be.fn["tracker_create"](C.byref(self.tracker)), "tracker_create")
         self.cfg = capi.TrackerConfig.default()
         self.view = capi.View(self.depth, W, H, M_d=synth.pose_matrix(synth.bench_position(0)), intr_d=intr).struct()
