@@ -239,6 +239,7 @@ def worker(args) -> int:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if on_gpu:
         be.check(be.fn["set_device"](local_rank), "set_device")
+    ctl_device = "cpu" if backend_name.startswith("gloo") else device      # where the control plane's small tensors live
 
     wl = WORKLOADS[args.config]
     offset = tuple(float(v) for v in args.origin_offset.split(","))
@@ -263,7 +264,7 @@ def worker(args) -> int:
         for _ in streams:
             uid = None
             if world > 1:
-                t = torch.zeros(128, dtype=torch.uint8, device=device)
+                t = torch.zeros(128, dtype=torch.uint8, device=ctl_device)
                 if rank == 0:
                     try:
                         t.copy_(torch.tensor(list(NativeExchange.unique_id(be)), dtype=torch.uint8))
@@ -298,7 +299,7 @@ def worker(args) -> int:
             except Exception as e:      # noqa: BLE001 -- reported below, every rank then takes the torch path together
                 print(f"bench.py: rank {rank}: library exchange unavailable ({e})", file=sys.stderr)
                 break
-        ok = torch.tensor([1 if len(exs) == len(streams) else 0], dtype=torch.int32, device=device)
+        ok = torch.tensor([1 if len(exs) == len(streams) else 0], dtype=torch.int32, device=ctl_device)
         if world > 1:
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)      # all ranks or none
         if int(ok.item()) == 0:
@@ -392,13 +393,29 @@ def worker(args) -> int:
     elapsed = elapsed_local
     fps_minmax = None
     if world > 1:
-        tt = torch.tensor([elapsed_local], dtype=torch.float64, device=device)
+        tt = torch.tensor([elapsed_local], dtype=torch.float64, device=ctl_device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        tn = torch.tensor([elapsed_local], dtype=torch.float64, device=device)
+        tn = torch.tensor([elapsed_local], dtype=torch.float64, device=ctl_device)
         dist.all_reduce(tn, op=dist.ReduceOp.MIN)
         per = k_streams * args.steps
         fps_minmax = [round(per / elapsed, 1), round(per / float(tn.item()), 1)]
+
+    # what the exchange costs THIS run: the same frames once more without it (every rank, no collective involved)
+    exchange_cost = None
+    if exchange and on_gpu:
+        n3 = min(args.steps, 200)
+        was, exchange = exchange, False
+        run(0, min(args.warmup, 20)); sync()
+        t2 = time.perf_counter()
+        run(args.warmup, args.warmup + n3); sync()
+        without = k_streams * n3 / (time.perf_counter() - t2)
+        exchange = was
+        with_ = k_streams * args.steps / elapsed_local
+        exchange_cost = {"frames_per_collective": max(1, args.exchange_batch), "rank0_fps_with_exchange": round(with_, 1),
+                         "rank0_fps_without_exchange": round(without, 1), "cost_percent": round(100.0 * (1.0 - with_ / without), 1),
+                         "why_not_every_frame": "one collective per frame was measured at 8.6 percent of the frame rate issued from a C loop and 28 percent from "
+                                                "this harness on one MI355X (DESIGN.md section 6); --exchange-batch 1 selects it"}
 
     counters = streams[0].scene.counters(streams[0].rs)
     roofline = None
@@ -464,6 +481,7 @@ def worker(args) -> int:
                        "exchange": (f"all_gather of {17 + MAX_IDS}-word visible-block records, {max(1, args.exchange_batch)} frame(s) per collective, side stream, "
                                     + ("issued by the library (RCCL from C++)" if native else "issued through torch.distributed")
                                     if exchange else "none"),
+                       "exchange_cost_measured": exchange_cost,
                        "per_rank_fps_min_max": fps_minmax,
                        "visible_blocks_last_frame": counters["noVisibleEntries"],
                        **({"acceleration_structures": streams[0].scene.accel_info()} if (product and wl["index"] == "hash") else {}),

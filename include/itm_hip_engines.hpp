@@ -70,6 +70,8 @@ struct ITMView {
   Vector2i depthSize{0, 0}, rgbSize{0, 0};
 };
 
+struct ITMSceneParamsDefaults { float mu = 0.02f; int maxW = 100; float voxelSize = 0.005f, viewFrustum_min = 0.35f, viewFrustum_max = 3.0f; bool stopIntegratingAtMaxW = false; };
+
 // ITMTrackingState (Objects/ITMTrackingState.h): pose + the ICP maps written by CreateICPMaps
 struct ITMTrackingState {
   ITMPose pose_d, pose_pointCloud;
@@ -77,6 +79,40 @@ struct ITMTrackingState {
   float* pointCloud_colours = nullptr;    // device Vector4f[h*w] (normals for the ICP tracker)
   int age_pointCloud = -1;
   bool requiresFullRendering = true;
+
+  // camera centre -1 * (R^T T) of a world->camera matrix, component i = column i of R dotted with T, summed left to right
+  // (Matrix3::t() and Matrix3 * Vector3 of ORUtils/Matrix.h:270-296)
+  static void CameraCentre(const float* M, float c[3]) {
+    for (int i = 0; i < 3; ++i) c[i] = -1.0f * (M[0 + 4 * i] * M[12] + M[1 + 4 * i] * M[13] + M[2 + 4 * i] * M[14]);
+  }
+  // ITMTrackingState::TrackerFarFromPointCloud (Objects/ITMTrackingState.h:41-59)
+  bool TrackerFarFromPointCloud() const {
+    if (age_pointCloud < 0) return true;       // no point cloud exists yet
+    if (age_pointCloud > 5) return true;       // older than n frames
+    float pc[3], live[3];
+    CameraCentre(pose_pointCloud.GetM(), pc);
+    CameraCentre(pose_d.GetM(), live);
+    const float dx = pc[0] - live[0], dy = pc[1] - live[1], dz = pc[2] - live[2];
+    const float diff = dx * dx + dy * dy + dz * dz;
+    return diff > 0.0005f;                     // the camera centre has moved by more than the threshold
+  }
+};
+
+// ITMLibSettings (Utils/ITMLibSettings.h / .cpp:9-90): the members the path's callers read, with the reference's defaults
+struct ITMLibSettings {
+  enum TrackerType { TRACKER_COLOR, TRACKER_ICP, TRACKER_EXTERNAL };
+  ITMSceneParamsDefaults sceneParamsDefaults;   // (0.02, 100, 0.005, 0.35, 3.0, false), ITMLibSettings.cpp:10
+  float depthTrackerICPThreshold = 0.1f * 0.1f;
+  float depthTrackerTerminationThreshold = 1e-3f;
+  bool skipPoints = true;
+  bool useApproximateRaycast = false;
+  bool useBilateralFilter = false;
+  bool modelSensorNoise = false;
+  TrackerType trackerType = TRACKER_EXTERNAL;   // this fork's default: poses come from outside (ITMExternalTracker.cpp:27-30)
+  int noHierarchyLevels = 5;
+  int trackingRegime[8] = {ITM_TRACKER_ITERATION_BOTH, ITM_TRACKER_ITERATION_BOTH, ITM_TRACKER_ITERATION_ROTATION, ITM_TRACKER_ITERATION_ROTATION,
+                           ITM_TRACKER_ITERATION_ROTATION, 0, 0, 0};
+  int noICPRunTillLevel = 0;
 };
 
 struct ITMSceneParams : itm_scene_params {
@@ -212,31 +248,6 @@ class ITMDenseMapper_HIP {
   }
 };
 
-template <class TVoxel, class TIndex>
-class ITMTrackingController_HIP {
-  const ITMVisualisationEngine_HIP<TVoxel, TIndex>* vis;
-  bool useApproximateRaycast;
-
- public:
-  ITMTrackingController_HIP(const ITMVisualisationEngine_HIP<TVoxel, TIndex>* v, bool approximate = false) : vis(v), useApproximateRaycast(approximate) {}
-  // ITMTrackingController::Track with the external (no-op) tracker of this fork
-  void Track(ITMTrackingState* ts, const ITMView*) {
-    const bool far = ts->age_pointCloud < 0 || ts->age_pointCloud > 5;   // TrackerFarFromPointCloud, pose test omitted for external poses
-    ts->requiresFullRendering = far || !useApproximateRaycast;
-  }
-  void Prepare(ITMTrackingState* ts, const ITMView* view, ITMRenderState* rs) {
-    vis->CreateExpectedDepths(&ts->pose_d, &view->calib.intrinsics_d, rs);
-    if (ts->requiresFullRendering) {
-      vis->CreateICPMaps(view, ts, rs);
-      ts->pose_pointCloud = ts->pose_d;
-      if (ts->age_pointCloud == -1) ts->age_pointCloud = -2; else ts->age_pointCloud = 0;
-    } else {
-      vis->ForwardRender(view, ts, rs);
-      ts->age_pointCloud++;
-    }
-  }
-};
-
 // ITMViewBuilder (Engine/ITMViewBuilder.h:17-60): raw depth frame (device short image) -> ITMView::depth in metres,
 // optional 5-pass bilateral filter and normal / uncertainty images.  The caller owns the device images.
 class ITMViewBuilder_HIP {
@@ -293,6 +304,157 @@ class ITMDepthTracker_HIP {
                                    trackingState->pose_pointCloud.GetM(), M, stream), "TrackCamera");
     trackingState->pose_d.SetM(M);
   }
+};
+
+// ITMTracker (Engine/ITMTracker.h): what ITMTrackingController::Track calls
+class ITMTracker {
+ public:
+  virtual void TrackCamera(ITMTrackingState* trackingState, const ITMView* view) = 0;
+  virtual ~ITMTracker() {}
+};
+// ITMExternalTracker of this fork (Engine/ITMExternalTracker.cpp:27-30): the pose was put into trackingState->pose_d from outside
+class ITMExternalTracker : public ITMTracker {
+ public:
+  void TrackCamera(ITMTrackingState*, const ITMView*) override {}
+};
+// adapter: ITMDepthTracker_HIP behind the ITMTracker interface
+class ITMDepthTrackerAdapter : public ITMTracker {
+  ITMDepthTracker_HIP* t;
+ public:
+  explicit ITMDepthTrackerAdapter(ITMDepthTracker_HIP* t_) : t(t_) {}
+  void TrackCamera(ITMTrackingState* ts, const ITMView* view) override { t->TrackCamera(ts, view); }
+};
+
+// 4x4 product as ORUtils/Matrix.h:96-104 forms it (column-major, r(x, y) accumulated from zero over k)
+inline void matmul4(const float* lhs, const float* rhs, float* out) {
+  for (int x = 0; x < 4; ++x) for (int y = 0; y < 4; ++y) {
+    float r = 0.0f;
+    for (int k = 0; k < 4; ++k) r += lhs[k * 4 + y] * rhs[x * 4 + k];
+    out[x * 4 + y] = r;
+  }
+}
+
+// ITMTrackingController (Engine/ITMTrackingController.cpp:11-46): Track and Prepare, statement for statement
+template <class TVoxel, class TIndex>
+class ITMTrackingController_HIP {
+  ITMTracker* tracker;
+  const ITMVisualisationEngine_HIP<TVoxel, TIndex>* visualisationEngine;
+  const ITMLibSettings* settings;
+  ITMLibSettings ownSettings;
+
+ public:
+  ITMTrackingController_HIP(ITMTracker* tracker_, const ITMVisualisationEngine_HIP<TVoxel, TIndex>* vis, const ITMLibSettings* settings_)
+      : tracker(tracker_), visualisationEngine(vis), settings(settings_) {}
+  // external poses (no tracker object), `approximate` = ITMLibSettings::useApproximateRaycast
+  explicit ITMTrackingController_HIP(const ITMVisualisationEngine_HIP<TVoxel, TIndex>* vis, bool approximate = false)
+      : tracker(nullptr), visualisationEngine(vis), settings(&ownSettings) { ownSettings.useApproximateRaycast = approximate; }
+
+  void Track(ITMTrackingState* trackingState, const ITMView* view) {
+    if (trackingState->age_pointCloud != -1 && tracker) tracker->TrackCamera(trackingState, view);
+    trackingState->requiresFullRendering = trackingState->TrackerFarFromPointCloud() || !settings->useApproximateRaycast;
+  }
+  void Prepare(ITMTrackingState* trackingState, const ITMView* view, ITMRenderState* renderState) {
+    if (settings->trackerType == ITMLibSettings::TRACKER_COLOR) {
+      ITMPose pose_rgb;
+      float M[16];
+      matmul4(view->calib.trafo_rgb_to_depth_calib_inv, trackingState->pose_d.GetM(), M);
+      pose_rgb.SetM(M);
+      visualisationEngine->CreateExpectedDepths(&pose_rgb, &view->calib.intrinsics_rgb, renderState);
+      visualisationEngine->CreatePointCloud(view, trackingState, renderState, settings->skipPoints);
+      trackingState->age_pointCloud = 0;
+    } else {
+      visualisationEngine->CreateExpectedDepths(&trackingState->pose_d, &view->calib.intrinsics_d, renderState);
+      if (trackingState->requiresFullRendering) {
+        visualisationEngine->CreateICPMaps(view, trackingState, renderState);
+        trackingState->pose_pointCloud = trackingState->pose_d;
+        if (trackingState->age_pointCloud == -1) trackingState->age_pointCloud = -2;
+        else trackingState->age_pointCloud = 0;
+      } else {
+        visualisationEngine->ForwardRender(view, trackingState, renderState);
+        trackingState->age_pointCloud++;
+      }
+    }
+  }
+};
+
+// ITMMainEngine (Engine/ITMMainEngine.cpp:7-127,194-197) for raw frames already in device memory: builds the view, tracks, fuses
+// unless integration is switched off, and prepares the maps for the next frame -- with the reference's switches.  Owns the scene,
+// the engines, the live render state, the tracking state and the view's depth images.
+template <class TVoxel, class TIndex>
+class ITMMainEngine_HIP {
+  ITMLibSettings settings;
+  ITMSceneParams sceneParams;
+  ITMScene<TVoxel, TIndex> scene;
+  ITMDenseMapper_HIP<TVoxel, TIndex> denseMapper;
+  ITMVisualisationEngine_HIP<TVoxel, TIndex> visualisationEngine;
+  ITMDepthTracker_HIP* depthTracker = nullptr;
+  ITMTracker* tracker = nullptr;
+  ITMTrackingController_HIP<TVoxel, TIndex>* trackingController = nullptr;
+  ITMViewBuilder_HIP* viewBuilder = nullptr;
+  ITMRenderState* renderState_live = nullptr;
+  ITMTrackingState trackingState;
+  ITMView view;
+  void *depthBuf = nullptr, *scratchBuf = nullptr, *normalBuf = nullptr, *sigmaBuf = nullptr, *pointsBuf = nullptr, *coloursBuf = nullptr;
+  bool fusionActive = true, mainProcessingActive = true;
+
+ public:
+  // calibType / c0 / c1: ITMDisparityCalib (0 = TRAFO_KINECT, 1 = TRAFO_AFFINE); sizes as ITMMainEngine's imgSize_rgb / imgSize_d
+  ITMMainEngine_HIP(const ITMLibSettings& settings_, const ITMSceneParams& params, const ITMRGBDCalib& calib, Vector2i imgSize_rgb, Vector2i imgSize_d,
+                    int calibType = 1, float c0 = 0.001f, float c1 = 0.0f, int localBlockNum = 0)
+      : settings(settings_), sceneParams(params), scene(&sceneParams, localBlockNum), visualisationEngine(&scene) {
+    view.calib = calib;
+    view.depthSize = imgSize_d; view.rgbSize = imgSize_rgb;
+    const size_t P = (size_t)imgSize_d.x * imgSize_d.y;
+    // the tracked image: rgb for the colour tracker, depth otherwise (ITMTrackingController::GetTrackedImageSize)
+    const Vector2i tracked = settings.trackerType == ITMLibSettings::TRACKER_COLOR ? imgSize_rgb : imgSize_d;
+    const size_t PT = (size_t)tracked.x * tracked.y;
+    check(itm_dev_malloc(&depthBuf, P * 4), "malloc"); check(itm_dev_malloc(&scratchBuf, P * 4), "malloc");
+    check(itm_dev_malloc(&normalBuf, P * 16), "malloc"); check(itm_dev_malloc(&sigmaBuf, P * 4), "malloc");
+    check(itm_dev_malloc(&pointsBuf, PT * 16), "malloc"); check(itm_dev_malloc(&coloursBuf, PT * 16), "malloc");
+    trackingState.pointCloud_locations = (float*)pointsBuf; trackingState.pointCloud_colours = (float*)coloursBuf;
+    denseMapper.ResetScene(&scene);
+    viewBuilder = new ITMViewBuilder_HIP(&view.calib, calibType, c0, c1);
+    if (settings.trackerType == ITMLibSettings::TRACKER_ICP) {
+      depthTracker = new ITMDepthTracker_HIP(settings.trackingRegime, settings.noHierarchyLevels, settings.noICPRunTillLevel,
+                                             settings.depthTrackerICPThreshold, settings.depthTrackerTerminationThreshold);
+      tracker = new ITMDepthTrackerAdapter(depthTracker);
+    } else {
+      tracker = new ITMExternalTracker();          // TRACKER_EXTERNAL, and TRACKER_COLOR with poses from outside (the colour tracker itself is not part of the path)
+    }
+    trackingController = new ITMTrackingController_HIP<TVoxel, TIndex>(tracker, &visualisationEngine, &settings);
+    renderState_live = visualisationEngine.CreateRenderState(tracked);
+  }
+  ~ITMMainEngine_HIP() {
+    delete renderState_live; delete trackingController; delete tracker; delete depthTracker; delete viewBuilder;
+    for (void* p : {depthBuf, scratchBuf, normalBuf, sigmaBuf, pointsBuf, coloursBuf}) itm_dev_free(p);
+  }
+  ITMMainEngine_HIP(const ITMMainEngine_HIP&) = delete;
+  ITMMainEngine_HIP& operator=(const ITMMainEngine_HIP&) = delete;
+
+  ITMView* GetView() { return &view; }
+  ITMTrackingState* GetTrackingState() { return &trackingState; }
+  ITMScene<TVoxel, TIndex>* GetScene() { return &scene; }
+  ITMRenderState* GetRenderState() { return renderState_live; }
+  const ITMVisualisationEngine_HIP<TVoxel, TIndex>* GetVisualisationEngine() const { return &visualisationEngine; }
+
+  // rgbImage: device uchar4 (may be null without colour), rawDepthImage: device short
+  void ProcessFrame(const uint8_t* rgbImage, const int16_t* rawDepthImage) {
+    // prepare image and turn it into a depth image
+    view.rgb = rgbImage;
+    viewBuilder->UpdateView(&view, rawDepthImage, (float*)depthBuf, (float*)scratchBuf, settings.useBilateralFilter, settings.modelSensorNoise,
+                            (float*)normalBuf, (float*)sigmaBuf);
+    if (!mainProcessingActive) return;
+    // tracking
+    trackingController->Track(&trackingState, &view);
+    // fusion
+    if (fusionActive) denseMapper.ProcessFrame(&view, &trackingState, &scene, renderState_live);
+    // raycast to renderState_live for tracking and free visualisation
+    trackingController->Prepare(&trackingState, &view, renderState_live);
+  }
+  void turnOnIntegration() { fusionActive = true; }
+  void turnOffIntegration() { fusionActive = false; }
+  void turnOnMainProcessing() { mainProcessingActive = true; }
+  void turnOffMainProcessing() { mainProcessingActive = false; }
 };
 
 // ITMMesh (Objects/ITMMesh.h:14-124): the triangle buffer lives in HBM; WriteOBJ / WriteSTL produce the reference's files.

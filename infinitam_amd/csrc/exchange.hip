@@ -5,8 +5,8 @@
 // rank publishes per frame is one fixed-size record { float M_d[16]; int32 noVisibleEntries; int32 ids[max_ids] (padded with -1) },
 // written on the FRAME stream by a 3 us copy kernel right behind the frame's kernels (itm_export_visible_record).  Every `batch`
 // frames the records of the batch are all-gathered with RCCL on a SIDE stream that waits for the last copy.  The batch buffers form
-// a ring of four; before a buffer is written again the HOST checks that the collective which last read it has finished (it used the
-// buffer four batches earlier: the check returns at once unless the host runs that far ahead of the GPU) -- the frame stream itself
+// a ring of eight; before a buffer is written again the HOST checks that the collective which last read it has finished (it used the
+// buffer eight batches earlier: the check returns at once unless the host runs that far ahead of the GPU) -- the frame stream itself
 // never waits for a collective.  The one event recorded on the frame stream per batch uses a DEVICE-scope release: the default
 // system-scope release of hipEventRecord writes back the L2s, and the next frame's kernels then start on cold caches (measured:
 // per-frame exchange 8.0 k frames/s against 11.2 k without exchange, whoever performed the collective).  RCCL has no all-gather-v, hence the fixed
@@ -19,6 +19,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>              // types and prototypes only: the entry points are resolved with dlsym, nothing links against RCCL
 
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -74,7 +75,7 @@ struct itm_exchange {
   int world = 1, rank = 0, maxIds = 0, batch = 1;
   size_t words = 0;                       // per record
   ncclComm_t comm = nullptr;              // a communicator for EVERY world size, one rank included; null only behind ITM_EXCHANGE_DEVICE_COPY=1 (debug)
-  static constexpr int kRing = 4;
+  static constexpr int kRing = 8;
   int32_t* buffers[kRing] = {};           // batch records each
   int32_t* gathered = nullptr;            // world x batch records: rank-major, then frame of the batch
   hipStream_t side = nullptr;
@@ -160,7 +161,20 @@ int itm_exchange_step(itm_exchange* x, const itm_render_state* rs, const float M
   hipStream_t fs = as_stream(frame_stream);
   const int slot = (int)(x->frame % x->batch);
   const int b = (int)((x->frame / x->batch) % itm_exchange::kRing);
-  if (slot == 0 && x->inFlight[b]) { ITM_HIP(hipEventSynchronize(x->released[b])); x->inFlight[b] = false; }   // host-side: the collective four batches ago has let go of this buffer
+  if (slot == 0 && x->inFlight[b]) {
+    // polled, not hipEventSynchronize: the blocking wait of the runtime was measured at ~60 ms per call in a process whose other
+    // threads keep the cores busy (bench.py with a gloo control plane: 33 frames/s), a query is a load
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+      const hipError_t q = hipEventQuery(x->released[b]);
+      if (q == hipSuccess) break;
+      if (q != hipErrorNotReady) return hip_fail(q, "exchange: collective", __FILE__, __LINE__);
+      if ((spins & 0x3ffu) == 0x3ffu && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0)
+        return set_error(ITM_ERR_DEVICE, "exchange: the collective that used this buffer eight batches ago has not finished");
+      __builtin_ia32_pause();
+    }
+    x->inFlight[b] = false;
+  }   // host-side: the collective eight batches ago has let go of this buffer
   int rc = itm_export_visible_record(rs, M_d, x->maxIds, x->buffers[b] + (size_t)slot * x->words, frame_stream);
   if (rc) return rc;
   if (slot == x->batch - 1 && x->experiment != 1) {

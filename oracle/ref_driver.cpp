@@ -605,3 +605,94 @@ int itmr_track_camera(const itm_tracker_config* cfg, const itm_view* view, const
 }
 
 }  // extern "C"
+
+// ---- the callers of the path, on the reference's objects --------------------------------------------------------------------------
+// ITMMainEngine::ProcessFrame (Engine/ITMMainEngine.cpp:111-127) over a sequence of raw frames, with the reference's view builder,
+// ITMTrackingState (TrackerFarFromPointCloud is ITS code, Objects/ITMTrackingState.h:41-59), engines and ITMDepthTracker_CPU.  The three
+// functions of the control flow itself -- ITMMainEngine::ProcessFrame, ITMTrackingController::Track / ::Prepare
+// (Engine/ITMTrackingController.cpp:11-46) and ITMDenseMapper::ProcessFrame (Engine/ITMDenseMapper.cpp:50-58) -- cannot be compiled
+// from the reference here: their translation units include ITMLib.h -> ITMTrackerFactory.h -> <glog/logging.h>, which this image
+// lacks (and no stand-in is written).  Their statements are restated below, in their order, around the reference's objects.
+// trackerType: 0 colour (external poses, point cloud for the colour tracker), 1 ICP (ITMDepthTracker_CPU), 2 external poses.
+// Per frame k: age[k], full[k], pose[16 k ..], digest[4 k ..] = FNV-1a of {points, colours/normals, raycastImage, visible ids}.
+namespace {
+uint64_t fnv(const void* p, size_t n, uint64_t h = 1469598103934665603ull) {
+  const unsigned char* b = (const unsigned char*)p;
+  for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+  return h;
+}
+}  // namespace
+
+extern "C" int itmr_debug_main_engine_sequence(itm_scene* s, itm_render_state* r, int w, int h, const float intr[4], int nFrames, const int16_t* raw,
+                                               const float* externalPoses, int trackerType, int useApproximateRaycast, int skipPoints,
+                                               const uint8_t* fusionActive, const uint8_t* mainProcessingActive, const itm_tracker_config* cfg,
+                                               int32_t* age, int32_t* full, float* poses, uint64_t* digest) {
+  const Vector2i sz(w, h);
+  ITMRGBDCalib& calib = r->calib;
+  calib.intrinsics_d.SetFrom(intr[0], intr[1], intr[2], intr[3], (float)w, (float)h);
+  calib.intrinsics_rgb.SetFrom(intr[0], intr[1], intr[2], intr[3], (float)w, (float)h);
+  calib.disparityCalib.params = Vector2f(0.001f, 0.0f);
+  calib.disparityCalib.type = ITMDisparityCalib::TRAFO_AFFINE;
+  ITMViewBuilder_CPU viewBuilder(&calib);
+  ITMLowLevelEngine_CPU ll;
+  ITMDepthTracker_CPU* tracker = NULL;
+  if (trackerType == 1) {
+    TrackerIterationType regime[8];
+    for (int i = 0; i < cfg->noHierarchyLevels; ++i) regime[i] = (TrackerIterationType)cfg->trackingRegime[i];
+    tracker = new ITMDepthTracker_CPU(sz, regime, cfg->noHierarchyLevels, cfg->noICPRunTillLevel, cfg->distThresh, cfg->terminationThreshold, &ll);
+  }
+  ITMTrackingState* ts = r->ts;
+  ITMView* view = NULL;
+  ITMUChar4Image rgb(sz, true, false);
+  for (int i = 0; i < w * h; ++i) rgb.GetData(MEMORYDEVICE_CPU)[i] = Vector4u((unsigned char)(i % w), (unsigned char)(i / w), (unsigned char)((i % w) ^ (i / w)), 255);
+  ITMShortImage rawImg(sz, true, false);
+  for (int k = 0; k < nFrames; ++k) {
+    std::memcpy(rawImg.GetData(MEMORYDEVICE_CPU), raw + (size_t)k * w * h, (size_t)w * h * 2);
+    if (externalPoses) { Matrix4f M; set_matrix(M, externalPoses + 16 * k); ts->pose_d->SetM(M); }     // the pose source of this fork writes it before the frame
+    // ---- ITMMainEngine::ProcessFrame
+    viewBuilder.UpdateView(&view, &rgb, &rawImg, false, false);
+    if (mainProcessingActive[k]) {
+      // ---- ITMTrackingController::Track
+      if (ts->age_pointCloud != -1 && tracker) tracker->TrackCamera(ts, view);
+      ts->requiresFullRendering = ts->TrackerFarFromPointCloud() || !useApproximateRaycast;
+      // ---- ITMDenseMapper::ProcessFrame (no swapping)
+      if (fusionActive[k]) {
+        s->impl->allocate(view, ts, r->rs, false);
+        s->impl->integrate(view, ts, r->rs);
+      }
+      // ---- ITMTrackingController::Prepare
+      if (trackerType == 0) {
+        ITMPose pose_rgb(view->calib->trafo_rgb_to_depth.calib_inv * ts->pose_d->GetM());
+        s->impl->expectedDepths(&pose_rgb, &(view->calib->intrinsics_rgb), r->rs);
+        s->impl->pointCloud(view, ts, r->rs, skipPoints != 0);
+        ts->age_pointCloud = 0;
+      } else {
+        s->impl->expectedDepths(ts->pose_d, &(view->calib->intrinsics_d), r->rs);
+        if (ts->requiresFullRendering) {
+          s->impl->icpMaps(view, ts, r->rs);
+          ts->pose_pointCloud->SetFrom(ts->pose_d);
+          if (ts->age_pointCloud == -1) ts->age_pointCloud = -2;
+          else ts->age_pointCloud = 0;
+        } else {
+          s->impl->forwardRender(view, ts, r->rs);
+          ts->age_pointCloud++;
+        }
+      }
+    }
+    age[k] = ts->age_pointCloud; full[k] = ts->requiresFullRendering ? 1 : 0;
+    std::memcpy(poses + 16 * k, ts->pose_d->GetM().m, 64);
+    const size_t nPts = trackerType == 0 ? (size_t)ts->pointCloud->noTotalPoints : (size_t)w * h;
+    digest[4 * k + 0] = fnv(ts->pointCloud->locations->GetData(MEMORYDEVICE_CPU), nPts * 16);
+    digest[4 * k + 1] = fnv(ts->pointCloud->colours->GetData(MEMORYDEVICE_CPU), nPts * 16);
+    digest[4 * k + 2] = fnv(r->rs->raycastImage->GetData(MEMORYDEVICE_CPU), (size_t)w * h * 4);
+    uint64_t dv = nPts;
+    if (r->hash) {
+      ITMRenderState_VH* vh = (ITMRenderState_VH*)r->rs;
+      dv = fnv(vh->GetVisibleEntryIDs(), (size_t)vh->noVisibleEntries * 4, fnv(&vh->noVisibleEntries, 4));
+    }
+    digest[4 * k + 3] = dv;
+  }
+  delete view;
+  delete tracker;
+  return ITM_OK;
+}
