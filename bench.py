@@ -292,7 +292,10 @@ def worker(args) -> int:
                 th.start()
                 th.join(float(os.environ.get("ITM_EXCHANGE_INIT_TIMEOUT", "120")))
                 if th.is_alive():
-                    raise TimeoutError("no RCCL communicator within the time limit")
+                    # the thread may be inside ncclCommInitRank holding RCCL and device state: this rank cannot go on beside it.
+                    # Say so and leave with a failure (the launcher then fails the run) instead of tearing down around a stuck thread.
+                    print(f"bench.py: rank {rank}: no RCCL communicator within the time limit", file=sys.stderr, flush=True)
+                    os._exit(3)
                 if "err" in box:
                     raise box["err"]
                 exs.append(box["ex"])

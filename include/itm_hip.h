@@ -96,6 +96,9 @@ typedef struct itm_scene_config {
   int32_t denseOffsetSet; /* non-zero: use denseOffset even if it is all zero   */
   int32_t maxRenderingBlocks; /* MAX_RENDERING_BLOCKS (DeviceAgnostic/ITMVisualisationEngine.h:24);
                                  0 = 262144.  Runtime so that the cap path can be tested.       */
+  int32_t useSwapping;        /* ITMScene(..., useSwapping, ...) Objects/ITMScene.h:37-43: the scene owns an ITMGlobalCache in host
+                                 memory and AllocateSceneFromDepth keeps the swap states (hash index only)                          */
+  int32_t transferBlockNum;   /* SDF_TRANSFER_BLOCK_NUM (Utils/ITMLibDefines.h): blocks moved per swapping call; 0 = 0x1000        */
 } itm_scene_config;
 
 /* The inputs an engine method takes from `const ITMView*` and `const ITMTrackingState*`:
@@ -139,7 +142,8 @@ enum itm_buffer {
   ITM_BUF_RAYCAST_RESULT = 7,   /* Vector4f[h*w]  renderState->raycastResult        */
   ITM_BUF_RAYCAST_IMAGE = 8,    /* Vector4u[h*w]  renderState->raycastImage         */
   ITM_BUF_FORWARD_PROJECTION = 9, /* Vector4f[h*w] renderState->forwardProjection   */
-  ITM_BUF_MISSING_POINTS = 10   /* int[h*w]       renderState->fwdProjMissingPoints */
+  ITM_BUF_MISSING_POINTS = 10,  /* int[h*w]       renderState->fwdProjMissingPoints */
+  ITM_BUF_SWAP_STATES = 11      /* uchar[noTotalEntries] globalCache->GetSwapStates(): ITMHashSwapState::state (scenes with useSwapping) */
 };
 
 typedef struct itm_scene itm_scene;               /* ITMScene<TVoxel,TIndex> + engine scratch */
@@ -451,6 +455,24 @@ int ITM_FN(exchange_step)(itm_exchange* exchange, const itm_render_state* rs, co
 int ITM_FN(exchange_info)(const itm_exchange* exchange, int* world, int* rank, int* max_ids, int* batch, const void** gathered_device);
 /* host copy of the gathered table, world x batch records of (17 + max_ids) int32 words, rank-major; synchronises the side stream */
 int ITM_FN(exchange_table)(itm_exchange* exchange, int32_t* dst_host, size_t words);
+
+/* ---- swapping (Engine/ITMSwappingEngine.h:19-36, DeviceSpecific/CPU/ITMSwappingEngine_CPU.cpp, Objects/ITMGlobalCache.h) ----
+ * Scenes created with useSwapping keep an ITMGlobalCache in HOST memory (one block slot + one `hasStoredData` flag per table entry) and
+ * a swap state per entry on the device (0 host has the newest data / never loaded, 1 visible and still to be combined with the host's
+ * copy, 2 the device has the newest data).  ITMDenseMapper::ProcessFrame calls the two methods after the integration
+ * (Engine/ITMDenseMapper.cpp:59-64):
+ *   IntegrateGlobalIntoLocal  the first transferBlockNum entries in state 1, in table order: the host's stored block (if any) is
+ *                             combined voxel by voxel into the device block (weighted by w_depth / w_color), state -> 2
+ *   SaveToGlobalMemory        the first transferBlockNum entries in state 2 that hold a block and are not visible: the block goes to
+ *                             the host cache, the entry's ptr becomes -1, the voxel block returns to the allocation list, state -> 0
+ * Both synchronise with the host (the reference's CUDA twin does, through cudaMemcpy).  Return ITM_ERR_INVALID for scenes without swapping. */
+int ITM_FN(swap_integrate_global_into_local)(itm_scene* scene, itm_render_state* rs, itm_stream stream);
+int ITM_FN(swap_save_to_global_memory)(itm_scene* scene, itm_render_state* rs, itm_stream stream);
+/* ITMGlobalCache::HasStoredData / GetStoredVoxelBlock: copies the stored block of table entry `entry` (512 voxels) to dst_host if there
+ * is one; *has = 1 / 0 */
+int ITM_FN(global_cache_get)(const itm_scene* scene, int entry, void* dst_host, int* has);
+/* hasStoredData[noTotalEntries] as bytes */
+int ITM_FN(global_cache_flags)(const itm_scene* scene, uint8_t* dst_host, size_t bytes);
 
 /* The acceleration structures a hash scene carries beside the reference's table (none of them part of the reference's state, all
  * derived from it): a block directory and a slot directory over a cube of 512^3 blocks, an sdf mirror over 256^3 blocks for the

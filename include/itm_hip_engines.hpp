@@ -128,11 +128,14 @@ class ITMScene {
  public:
   itm_scene* handle = nullptr;
   const ITMSceneParams* sceneParams;
-  explicit ITMScene(const ITMSceneParams* params, int localBlockNum = 0, int bucketNum = 0, int excessNum = 0) : sceneParams(params) {
+  bool useSwapping;
+  explicit ITMScene(const ITMSceneParams* params, int localBlockNum = 0, int bucketNum = 0, int excessNum = 0, bool useSwapping_ = false)
+      : sceneParams(params), useSwapping(useSwapping_) {
     itm_scene_config cfg;
     std::memset(&cfg, 0, sizeof cfg);
     cfg.voxelType = TVoxel::kType; cfg.indexType = TIndex::kType;
     cfg.localBlockNum = localBlockNum; cfg.bucketNum = bucketNum; cfg.excessNum = excessNum;
+    cfg.useSwapping = useSwapping ? 1 : 0;        // the scene then owns an ITMGlobalCache in host memory (Objects/ITMScene.h:37-43)
     check(itm_scene_create(&cfg, params, &handle), "itm_scene_create");
   }
   ~ITMScene() { itm_scene_destroy(handle); }
@@ -232,16 +235,34 @@ class ITMVisualisationEngine_HIP {
 // The callers of the path, same call order and state machine as
 // ITMDenseMapper::ProcessFrame / UpdateVisibleList (Engine/ITMDenseMapper.cpp:50-71) and
 // ITMTrackingController::Prepare (Engine/ITMTrackingController.cpp:18-46, non-colour trackers).
+// ITMSwappingEngine<TVoxel, TIndex> (Engine/ITMSwappingEngine.h:19-36)
+template <class TVoxel, class TIndex>
+class ITMSwappingEngine_HIP {
+ public:
+  itm_stream stream = nullptr;
+  void IntegrateGlobalIntoLocal(ITMScene<TVoxel, TIndex>* scene, ITMRenderState* renderState) {
+    check(itm_swap_integrate_global_into_local(scene->handle, renderState->handle, stream), "IntegrateGlobalIntoLocal");
+  }
+  void SaveToGlobalMemory(ITMScene<TVoxel, TIndex>* scene, ITMRenderState* renderState) {
+    check(itm_swap_save_to_global_memory(scene->handle, renderState->handle, stream), "SaveToGlobalMemory");
+  }
+};
+
 template <class TVoxel, class TIndex>
 class ITMDenseMapper_HIP {
   ITMSceneReconstructionEngine_HIP<TVoxel, TIndex> reco;
+  ITMSwappingEngine_HIP<TVoxel, TIndex> swappingEngine;
 
  public:
-  void SetStream(itm_stream s) { reco.stream = s; }
+  void SetStream(itm_stream s) { reco.stream = s; swappingEngine.stream = s; }
   void ResetScene(ITMScene<TVoxel, TIndex>* scene) { reco.ResetScene(scene); }
   void ProcessFrame(const ITMView* view, const ITMTrackingState* ts, ITMScene<TVoxel, TIndex>* scene, ITMRenderState* rs) {
     reco.AllocateSceneFromDepth(scene, view, ts, rs);
     reco.IntegrateIntoScene(scene, view, ts, rs);
+    if (scene->useSwapping) {                     // ITMDenseMapper.cpp:59-64 (settings->useSwapping)
+      swappingEngine.IntegrateGlobalIntoLocal(scene, rs);     // swapping: host -> device
+      swappingEngine.SaveToGlobalMemory(scene, rs);           // swapping: device -> host
+    }
   }
   void UpdateVisibleList(const ITMView* view, const ITMTrackingState* ts, ITMScene<TVoxel, TIndex>* scene, ITMRenderState* rs) {
     reco.AllocateSceneFromDepth(scene, view, ts, rs, true);

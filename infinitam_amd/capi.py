@@ -26,7 +26,7 @@ INDEX_HASH, INDEX_DENSE = 0, 1
 RENDER_SHADED_GREYSCALE, RENDER_COLOUR_FROM_VOLUME, RENDER_COLOUR_FROM_NORMAL = 0, 1, 2
 (BUF_HASH_ENTRIES, BUF_EXCESS_LIST, BUF_VOXEL_BLOCKS, BUF_ALLOCATION_LIST, BUF_VISIBLE_IDS,
  BUF_VISIBLE_TYPE, BUF_RANGE_IMAGE, BUF_RAYCAST_RESULT, BUF_RAYCAST_IMAGE, BUF_FORWARD_PROJECTION,
- BUF_MISSING_POINTS) = range(11)
+ BUF_MISSING_POINTS, BUF_SWAP_STATES) = range(12)
 ERR_INVALID, ERR_DEVICE, ERR_UNSUPPORTED = -1, -2, -3
 
 VOXEL_NAMES = {VOXEL_S: "ITMVoxel_s", VOXEL_F: "ITMVoxel_f", VOXEL_S_RGB: "ITMVoxel_s_rgb",
@@ -61,7 +61,7 @@ class SceneConfig(C.Structure):
     _fields_ = [("voxelType", C.c_int32), ("indexType", C.c_int32), ("bucketNum", C.c_int32),
                 ("excessNum", C.c_int32), ("localBlockNum", C.c_int32),
                 ("denseSize", C.c_int32 * 3), ("denseOffset", C.c_int32 * 3),
-                ("denseOffsetSet", C.c_int32), ("maxRenderingBlocks", C.c_int32)]
+                ("denseOffsetSet", C.c_int32), ("maxRenderingBlocks", C.c_int32), ("useSwapping", C.c_int32), ("transferBlockNum", C.c_int32)]
 
 
 class ViewStruct(C.Structure):
@@ -227,6 +227,10 @@ _HOST_IO_SIGS = {
                                          C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "debug_dense_classify_check": (C.c_int, [C.POINTER(C.c_int32), C.c_int]),
     "scene_accel_info": (C.c_int, [_P, C.POINTER(AccelInfo)]),
+    "swap_integrate_global_into_local": (C.c_int, [_P, _P, _P]),
+    "swap_save_to_global_memory": (C.c_int, [_P, _P, _P]),
+    "global_cache_get": (C.c_int, [_P, C.c_int, _P, C.POINTER(C.c_int)]),
+    "global_cache_flags": (C.c_int, [_P, _P, C.c_size_t]),
     "stream_create": (C.c_int, [C.POINTER(_P)]),
     "stream_destroy": (C.c_int, [_P]),
     # multi-stream exchange issued from the library (RCCL); the CPU shims exchange through torch.distributed (streams.py)
@@ -315,8 +319,9 @@ class Backend:
 
     def create_scene(self, voxelType=VOXEL_S, indexType=INDEX_HASH, params: Optional[SceneParams] = None,
                      bucketNum=0, excessNum=0, localBlockNum=0, denseSize=(0, 0, 0), denseOffset=None,
-                     maxRenderingBlocks=0) -> "Scene":
+                     maxRenderingBlocks=0, useSwapping=False, transferBlockNum=0) -> "Scene":
         cfg = SceneConfig()
+        cfg.useSwapping, cfg.transferBlockNum = (1 if useSwapping else 0), transferBlockNum
         cfg.voxelType, cfg.indexType = voxelType, indexType
         cfg.bucketNum, cfg.excessNum, cfg.localBlockNum = bucketNum, excessNum, localBlockNum
         cfg.denseSize[:] = denseSize
@@ -432,7 +437,7 @@ class Scene:
                 BUF_VISIBLE_IDS: np.dtype("<i4"), BUF_VISIBLE_TYPE: np.dtype("u1"),
                 BUF_RANGE_IMAGE: np.dtype("<f4"), BUF_RAYCAST_RESULT: np.dtype("<f4"),
                 BUF_RAYCAST_IMAGE: np.dtype("u1"), BUF_FORWARD_PROJECTION: np.dtype("<f4"),
-                BUF_MISSING_POINTS: np.dtype("<i4")}[which]
+                BUF_MISSING_POINTS: np.dtype("<i4"), BUF_SWAP_STATES: np.dtype("u1")}[which]
 
     def profile_enable(self, mask: int):
         self.be.check(self.be.fn["profile_enable"](_P(self.h), mask), "profile_enable")
@@ -462,6 +467,25 @@ class Scene:
 
     def buffer_ptr(self, which, rs=None) -> int:
         return self.be.fn["buffer_ptr"](_P(self.h), _P(rs.h if rs else None), which) or 0
+
+    # ITMSwappingEngine (scenes created with useSwapping)
+    def swap_integrate_global_into_local(self, rs, stream=None):
+        self.be.check(self.be.fn["swap_integrate_global_into_local"](_P(self.h), _P(rs.h), _P(stream)), "swap_integrate_global_into_local")
+
+    def swap_save_to_global_memory(self, rs, stream=None):
+        self.be.check(self.be.fn["swap_save_to_global_memory"](_P(self.h), _P(rs.h), _P(stream)), "swap_save_to_global_memory")
+
+    def global_cache_flags(self) -> np.ndarray:
+        n = self.be.fn["buffer_bytes"](_P(self.h), None, BUF_SWAP_STATES)
+        out = np.zeros(n, np.uint8)
+        self.be.check(self.be.fn["global_cache_flags"](_P(self.h), out.ctypes.data_as(_P), n), "global_cache_flags")
+        return out
+
+    def global_cache_block(self, entry: int):
+        out = np.zeros(512, self.voxel_dtype)
+        has = C.c_int()
+        self.be.check(self.be.fn["global_cache_get"](_P(self.h), int(entry), out.ctypes.data_as(_P), C.byref(has)), "global_cache_get")
+        return out if has.value else None
 
     def accel_info(self) -> dict:
         """Sizes, placement and move count of the directory / mirror cubes (product library only)."""

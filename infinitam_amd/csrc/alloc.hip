@@ -54,6 +54,7 @@ struct AllocParams {
   int capIds;
   int mirrorFloat;   // the sdf mirror holds floats (ITMVoxel_f / _f_rgb) rather than shorts
   AccelOrigin org;   // where the block directory / slot directory / sdf mirror cubes lie (itm_types.h)
+  int useSwapping;   // scenes with a global cache: enlarged frustum for the re-test of the previous list (checkBlockVisibility<true>)
 };
 
 struct BlockRay {
@@ -318,6 +319,32 @@ __device__ inline bool block_in_frustum(int bx, int by, int bz, const Mat4& M, f
   return false;
 }
 
+// checkBlockVisibility<true> (DeviceAgnostic/ITMSceneReconstructionEngine.h:243-342): a corner outside the image but inside the image
+// enlarged by an eighth on every side makes the block "visible enlarged"; the walk ends at the first corner inside the image proper
+__device__ inline bool block_in_frustum_enlarged(int bx, int by, int bz, const Mat4& M, float fx, float fy, float cx, float cy, float voxelSize, int W, int H) {
+  const float f = (float)kBlockSide * voxelSize;
+  float x = (float)bx * f, y = (float)by * f, z = (float)bz * f;
+  bool enlarged = false;
+  auto corner = [&]() -> bool {
+    Vec3 q = transform_point(M, x, y, z);
+    if (q.z < 1e-10f) return false;
+    const float u = fx * q.x / q.z + cx, v = fy * q.y / q.z + cy;
+    if (u >= 0 && u < W && v >= 0 && v < H) { enlarged = true; return true; }
+    const int lx = -W / 8, hx = W + W / 8, ly = -H / 8, hy = H + H / 8;
+    if (u >= lx && u < hx && v >= ly && v < hy) enlarged = true;
+    return false;
+  };
+  if (corner()) return true;
+  z += f; if (corner()) return true;
+  y += f; if (corner()) return true;
+  x += f; if (corner()) return true;
+  z -= f; if (corner()) return true;
+  y -= f; if (corner()) return true;
+  x -= f; y += f; if (corner()) return true;
+  x += f; y -= f; z += f; if (corner()) return true;
+  return enlarged;
+}
+
 // Pass 1 of the visible list (_CPU.cpp:229-269): re-test type-3 slots, count visible slots per
 // chunk.  Workgroup 0 also commits the pool counters of the allocation sweep (:287-290).
 template <bool COMMIT_ALLOC, bool LAZY>
@@ -342,7 +369,9 @@ __global__ void __launch_bounds__(256) visible_count_kernel(uint8_t* __restrict_
         } else if (LAZY ? (t != 0u) : (t == 3u)) {
           // visible in the previous frame and not seen again: keep only if still in the frustum
           HashEntry he = unpack_entry(hash[slot0 + k]);
-          t = block_in_frustum(he.px, he.py, he.pz, p.M, p.fx, p.fy, p.cx, p.cy, p.voxelSize, p.W, p.H) ? 3u : 0u;
+          const bool keep = p.useSwapping ? block_in_frustum_enlarged(he.px, he.py, he.pz, p.M, p.fx, p.fy, p.cx, p.cy, p.voxelSize, p.W, p.H)
+                                          : block_in_frustum(he.px, he.py, he.pz, p.M, p.fx, p.fy, p.cx, p.cy, p.voxelSize, p.W, p.H);
+          t = keep ? 3u : 0u;
         }
         if (t != t0) { w[k >> 2] = (w[k >> 2] & ~(0xffu << ((k & 3) * 8))) | (t << ((k & 3) * 8)); changed = true; }
         n += (t > 0u);
@@ -588,6 +617,7 @@ __global__ void __launch_bounds__(256) freeview_flag_kernel(const uint4* __restr
 // Is this scene alone on its device?  (scene.hip keeps the count of live hash scenes.)
 static bool one_pass_list_is_safe(const itm_scene* s) {
   static const int forced = [] { const char* e = getenv("ITM_ONE_PASS_LIST"); return e ? atoi(e) : -1; }();      // A/B: 1 = always, 0 = never
+  if (s->cfg.useSwapping) return false;        // the swapping hooks live in the separate launches
   if (forced >= 0) return forced != 0;
   return live_hash_scenes(s->device) <= 1;
 }
@@ -608,6 +638,7 @@ static int fill_params(const itm_scene* s, const float* M, const float* intr, in
   p.capIds = capIds;
   p.mirrorFloat = (s->cfg.voxelType == ITM_VOXEL_F || s->cfg.voxelType == ITM_VOXEL_F_RGB) ? 1 : 0;
   p.org = s->org;
+  p.useSwapping = s->cfg.useSwapping;
   int pixBits = 1;
   while ((1ll << pixBits) < (long long)W * H) ++pixBits;
   p.stepBits = 31 - pixBits;
@@ -696,6 +727,7 @@ int launch_sweep_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, bo
   }
   ITM_LAUNCH_CHECK();
   rs->listCoherent = true;   // list == non-zero visible types again
+  if (s->cfg.useSwapping) return launch_swap_after_allocation(s, rs, st);      // swap states + re-allocation of swapped-out entries (_CPU.cpp:250-253,271-285)
   return ITM_OK;
 }
 

@@ -206,23 +206,34 @@ int itm_scene_save(const itm_scene* s, const itm_render_state* rs, const char* d
   const std::string d = std::string(dir) + "/";
   std::vector<BlockFile> blocks; checkpoint_blocks(s, blocks);
   std::vector<char> host;
-  // config.dat goes last: a directory without it is not a complete checkpoint
-  remove((d + "config.dat").c_str());
+  // Two phases, so that a save that fails or is interrupted while the (large) blocks are being written leaves the PREVIOUS checkpoint
+  // of the directory intact: every block goes to "<name>.new" first; only when all of them are on disk are they renamed over the old
+  // files, config.dat last (a directory whose config.dat is older than its blocks cannot result: the window is the renames alone).
+  std::vector<std::string> written;
+  auto abandon = [&](int rc) { for (const std::string& f : written) remove((f + ".new").c_str()); return rc; };
+  auto stage = [&](const std::string& file, const void* data, size_t bytes, size_t elemBytes) {
+    const int rc = save_block(file + ".new", data, bytes, elemBytes);
+    if (!rc) written.push_back(file);
+    return rc;
+  };
   for (const BlockFile& b : blocks) {
     if (b.render && !rs) continue;
     const size_t bytes = itm_buffer_bytes(s, rs, b.which);
     host.resize(bytes);
     int rc = itm_download(s, rs, b.which, host.data(), bytes, stream);
-    if (rc) return rc;
-    if ((rc = save_block(d + b.name, host.data(), bytes, b.elemBytes))) return rc;
+    if (rc) return abandon(rc);
+    if ((rc = stage(d + b.name, host.data(), bytes, b.elemBytes))) return abandon(rc);
   }
   itm_counters c;
   int rc = itm_get_counters(s, rs, &c, stream);
-  if (rc) return rc;
-  if ((rc = save_block(d + "counters.dat", &c, sizeof c, 4))) return rc;
+  if (rc) return abandon(rc);
+  if ((rc = stage(d + "counters.dat", &c, sizeof c, 4))) return abandon(rc);
   char cfg[sizeof(itm_scene_config) + sizeof(itm_scene_params)];
   memcpy(cfg, &s->cfg, sizeof(itm_scene_config)); memcpy(cfg + sizeof(itm_scene_config), &s->prm, sizeof(itm_scene_params));
-  return save_block(d + "config.dat", cfg, sizeof cfg, 1);
+  if ((rc = stage(d + "config.dat", cfg, sizeof cfg, 1))) return abandon(rc);
+  for (const std::string& f : written)
+    if (rename((f + ".new").c_str(), f.c_str()) != 0) return abandon(fail("cannot rename " + f + ".new"));
+  return ITM_OK;
 }
 
 // Everything is read into host memory and validated BEFORE the first byte reaches the scene: a truncated, mismatched or
@@ -231,7 +242,6 @@ int itm_scene_save(const itm_scene* s, const itm_render_state* rs, const char* d
 int itm_scene_load(itm_scene* s, itm_render_state* rs, const char* dir, itm_stream stream) {
   if (!s || !dir) return fail("null argument");
   if (rs && rs->scene != s) return fail("render state belongs to another scene");
-  if (rs) rs->denseRangeReady = false;
   const std::string d = std::string(dir) + "/";
   char cfg[sizeof(itm_scene_config) + sizeof(itm_scene_params)];
   int rc = load_block(d + "config.dat", cfg, sizeof cfg, 1);
@@ -246,8 +256,8 @@ int itm_scene_load(itm_scene* s, itm_render_state* rs, const char* dir, itm_stre
     // both counters keep decrementing once their pool is exhausted (as in the reference), so only the upper end is bounded
     if (c.lastFreeBlockId < -(1 << 30) || c.lastFreeBlockId >= nBlocks) return fail("counters.dat: lastFreeBlockId out of range");
     if (c.lastFreeExcessListId < -(1 << 30) || c.lastFreeExcessListId >= s->cfg.excessNum) return fail("counters.dat: lastFreeExcessListId out of range");
-    if (rs && (c.noVisibleEntries < 0 || c.noVisibleEntries > rs->capIds)) return fail("counters.dat: noVisibleEntries out of range");
   }
+  if (rs && (c.noVisibleEntries < 0 || (hash && c.noVisibleEntries > rs->capIds))) return fail("counters.dat: noVisibleEntries out of range");
   std::vector<BlockFile> blocks; checkpoint_blocks(s, blocks);
   std::vector<std::vector<char>> host(blocks.size());
   for (size_t i = 0; i < blocks.size(); ++i) {
@@ -266,8 +276,13 @@ int itm_scene_load(itm_scene* s, itm_render_state* rs, const char* dir, itm_stre
       const size_t used = (b.which == ITM_BUF_VISIBLE_IDS) ? (size_t)c.noVisibleEntries : n;     // the tail of the id list is unused
       for (size_t k = 0; k < used && k < n; ++k)
         if (v[k] < 0 || v[k] >= lim) return fail(std::string(b.name) + ": element out of range");
+    } else if (b.which == ITM_BUF_VISIBLE_TYPE) {
+      const unsigned char* t = (const unsigned char*)host[i].data();        // entriesVisibleType: 0 invisible, 1 / 2 visible (in memory / swapped out), 3 visible in the previous frame
+      for (size_t k = 0; k < n; ++k)
+        if (t[k] > 3) return fail("visible_type.dat: not a visibility type");
     }
   }
+  if (rs) rs->denseRangeReady = false;        // validated: from here on the scene is being replaced
   for (size_t i = 0; i < blocks.size(); ++i) {
     const BlockFile& b = blocks[i];
     if (b.render && !rs) continue;

@@ -71,7 +71,8 @@ struct itm_scene {
   unsigned long long* chunkGran = nullptr;  // u64[numChunks]: {epoch, visible count} granules of the one-pass visible list
   uint32_t* chunkSweepDone = nullptr;        // u32[numChunks]: epoch stamps of chunks whose excess allocations are in place (fused sweep)
   uint32_t listEpoch = 0;
-  // occupancy bitmap of the ordered part of the table: bit b set <=> hash[b].ptr >= 0.  A clear bit
+  // occupancy bitmap of the ordered part of the table: bit b set <=> hash[b].ptr >= -1 (an entry lives there: allocated, or swapped
+  // out with its chain possibly still resident).  A clear bit
   // proves that no block hashing to bucket b is allocated (excess entries hang off occupied heads),
   // which lets the ray caster skip empty space without touching the 16-byte entries.
   uint32_t* headBits = nullptr;   // uint32[bucketNum / 32]
@@ -84,6 +85,9 @@ struct itm_scene {
   // non-empty cells of dirPtr / dirSlot / sdfMirror are those of table entries with ptr >= 0 at `org` -- every path that replaces
   // the table or moves the origin empties exactly those cells first (O(allocated blocks), no 18 GB memset)
   itm::AccelOrigin org = {-itm::kDirHalf, -itm::kDirHalf, -itm::kDirHalf, -itm::kMirrorHalf, -itm::kMirrorHalf, -itm::kMirrorHalf + itm::kMirrorShift};
+  // swapping (scenes with cfg.useSwapping; swapping.hip): ITMHashSwapState per entry on the device, the ITMGlobalCache in host memory
+  uint8_t* swapStates = nullptr;           // uchar[noTotalEntries]
+  struct SwapHost* swapHost = nullptr;
   bool countedLive = false;       // this scene is in the per-device count of live hash scenes
   bool orgPlaced = false;         // false until the first frame (or an upload) has placed the cubes
   long long accelMoves = 0;       // times the cubes were re-placed (itm_scene_accel_info)
@@ -186,6 +190,9 @@ extern int g_debug_tracker_session_unusable;
 extern int g_debug_no_sdf_mirror;
 extern int g_debug_separate_sweep;
 int rebuild_sdf_mirror(itm_scene* s, hipStream_t st);
+int launch_swap_after_allocation(itm_scene* s, itm_render_state* rs, hipStream_t st);   // swapping.hip
+void free_swap_state(itm_scene* s);
+int create_swap_state(itm_scene* s);
 int live_hash_scenes(int device);                                     // hash scenes alive on a device (scene.hip)
 int accel_unfill(itm_scene* s, hipStream_t st);                      // empties the cubes through the table that filled them
 int accel_place(itm_scene* s, const float* invM, hipStream_t st);    // (re-)places the cubes around a view

@@ -236,7 +236,7 @@ __host__ __device__ inline uint32_t dir_cell(uint32_t ux, uint32_t uy, uint32_t 
 // needs to mark a block that already exists as visible, one coherent 4-byte load instead of the 16-byte entry of a random bucket)
 __device__ inline void directory_insert(int32_t* __restrict__ dirPtr, int32_t* __restrict__ dirSlot, const AccelOrigin& org, int bx, int by, int bz, int ptr, int slot) {
   const uint32_t ux = (uint32_t)(bx - org.dx), uy = (uint32_t)(by - org.dy), uz = (uint32_t)(bz - org.dz);
-  if (dir_covers(ux, uy, uz)) {
+  if (dirPtr && dir_covers(ux, uy, uz)) {          // a scene may run without the directories (scene.hip)
     const uint32_t cell = dir_cell(ux, uy, uz);
     dirPtr[cell] = ptr;
     if (dirSlot) dirSlot[cell] = slot;

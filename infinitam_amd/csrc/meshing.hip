@@ -23,6 +23,8 @@
 #include <new>
 #include <vector>
 
+#include <mutex>
+
 #include "itm_internal.h"
 #include "mc_tables.h"
 #include "shading_device.h"
@@ -213,10 +215,13 @@ static void free_mesh(itm_mesh* m) {
 }
 
 static int upload_tables() {
+  // once per device, also when several host threads create meshes at the same time
+  static std::mutex guard;
   static bool done[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 64) dev = 0;
+  std::lock_guard<std::mutex> lock(guard);
   if (!done[dev]) {
     ITM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(d_triangleCases), kTriangleCases, sizeof(kTriangleCases)));
     done[dev] = true;

@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(256) head_bits_kernel(const uint4* __restrict_
   uint32_t bits = 0;
   for (int k = 0; k < 32; ++k) {
     const int slot = w * 32 + k;
-    if (slot < bucketNum && (int)hash[slot].w >= 0) bits |= 1u << k;
+    if (slot < bucketNum && (int)hash[slot].w >= -1) bits |= 1u << k;      // -1: swapped out, its chain may still hold resident blocks
   }
   headBits[w] = bits;
 }
@@ -351,6 +351,7 @@ static void* buffer_of(const itm_scene* s, const itm_render_state* rs, int which
     case ITM_BUF_EXCESS_LIST: if (hashScene) { *bytes = (size_t)s->cfg.excessNum * 4; return s->excessList; } break;
     case ITM_BUF_VOXEL_BLOCKS: if (s) { *bytes = s->numVoxels * s->voxBytes; return s->vba; } break;
     case ITM_BUF_ALLOCATION_LIST: if (s) { *bytes = (hashScene ? (size_t)s->cfg.localBlockNum : 1) * 4; return s->allocList; } break;
+    case ITM_BUF_SWAP_STATES: if (hashScene && s->swapStates) { *bytes = (size_t)s->noTotalEntries; return s->swapStates; } break;
     default: break;
   }
   if (!rs) return nullptr;
@@ -374,6 +375,7 @@ int live_hash_scenes(int device) { return (device >= 0 && device < 64) ? g_liveH
 static void free_scene(itm_scene* s) {
   if (!s) return;
   if (s->countedLive && s->device >= 0 && s->device < 64) g_liveHashScenes[s->device].fetch_sub(1);
+  free_swap_state(s);
   if (s->prof) { s->prof->flush(); for (hipEvent_t e : s->prof->pool) (void)hipEventDestroy(e); delete s->prof; }
   (void)hipFree(s->hash); (void)hipFree(s->excessList); (void)hipFree(s->vba); (void)hipFree(s->allocList);
   (void)hipFree(s->counters); (void)hipFree(s->headBits); (void)hipFree(s->allocKey); (void)hipFree(s->chunkReq); (void)hipFree(s->chunkVis); (void)hipFree(s->chunkGran); (void)hipFree(s->chunkSweepDone);
@@ -471,8 +473,6 @@ int itm_scene_create(const itm_scene_config* cfg_in, const itm_scene_params* prm
     alloc((void**)&s->chunkVis, (size_t)s->numChunks * 4);
     alloc((void**)&s->chunkGran, (size_t)s->numChunks * 8);
     alloc((void**)&s->chunkSweepDone, (size_t)s->numChunks * 4);
-    alloc((void**)&s->dirPtr, kDirCells * 4);
-    alloc((void**)&s->dirSlot, kDirCells * 4);
   } else {
     s->numVoxels = (size_t)cfg.denseSize[0] * cfg.denseSize[1] * cfg.denseSize[2];
     alloc((void**)&s->allocList, 4);
@@ -480,10 +480,16 @@ int itm_scene_create(const itm_scene_config* cfg_in, const itm_scene_params* prm
   alloc(&s->vba, s->numVoxels * vb + 16);
   alloc((void**)&s->counters, sizeof(SceneCounters));
   if (e != hipSuccess) { free_scene(s); return hip_fail(e, "hipMalloc(scene)", __FILE__, __LINE__); }
+  // The directories are accelerators like the mirror below: a device without a gigabyte to spare runs without them (every look-up then
+  // walks the table, as the reference does) instead of failing to create the scene
+  if (cfg.indexType == ITM_INDEX_HASH && !getenv("ITM_NO_ACCELERATION_CUBES")) {
+    if (hipMalloc((void**)&s->dirPtr, kDirCells * 4) != hipSuccess) { s->dirPtr = nullptr; (void)hipGetLastError(); }
+    else if (hipMalloc((void**)&s->dirSlot, kDirCells * 4) != hipSuccess) { (void)hipFree(s->dirPtr); s->dirPtr = nullptr; s->dirSlot = nullptr; (void)hipGetLastError(); }
+  }
   // The sdf mirror is an accelerator: taken when the device has room to spare, silently left out otherwise -- and only for the short
   // voxel types.  For the float types (34 GB) it was measured on BASELINE configs[4]: ray cast 119 -> 106 us, but the integration pays
   // 175 -> 189 us for the extra 4-byte stores: 2 609 -> 2 560 frames/s.  (ITM_MIRROR_FLOAT_TYPES=1 builds it in.)
-  if (cfg.indexType == ITM_INDEX_HASH && !g_debug_no_sdf_mirror && (ITM_MIRROR_FLOAT_TYPES || !mirror_is_float(s))) {
+  if (cfg.indexType == ITM_INDEX_HASH && s->dirPtr && !g_debug_no_sdf_mirror && (ITM_MIRROR_FLOAT_TYPES || !mirror_is_float(s))) {
     size_t freeB = 0, totalB = 0;
     const size_t bytes = kMirrorCells * 512 * (mirror_is_float(s) ? 4 : 2);
     if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB > 3 * bytes) {
@@ -502,6 +508,10 @@ int itm_scene_create(const itm_scene_config* cfg_in, const itm_scene_params* prm
   if (e == hipSuccess && s->dirPtr) e = hipMemset(s->dirPtr, 0xff, kDirCells * 4);
   if (e == hipSuccess && s->dirSlot) e = hipMemset(s->dirSlot, 0xff, kDirCells * 4);
   if (e != hipSuccess) { free_scene(s); return hip_fail(e, "hipMemset(scene)", __FILE__, __LINE__); }
+  if (cfg.useSwapping && cfg.indexType == ITM_INDEX_HASH) {
+    const int rc = create_swap_state(s);
+    if (rc) { free_scene(s); return rc; }
+  }
   *out = s;
   return ITM_OK;
 }

@@ -164,6 +164,12 @@ struct itm_scene {
   std::vector<uint8_t> allocType;
   std::vector<int16_t> blockCoords;  // 4 shorts per slot
   int noAllocRequests = 0;
+  // ITMGlobalCache (Objects/ITMGlobalCache.h), scenes with useSwapping
+  std::vector<uint8_t> swapStates;     // ITMHashSwapState::state per entry
+  std::vector<uint8_t> hasStoredData;
+  uint8_t* storedBlocks = nullptr;     // noTotalEntries x 512 voxels, calloc: untouched pages cost nothing
+  ~itm_scene() { std::free(storedBlocks); }
+  int transferBlockNum() const { return cfg.transferBlockNum > 0 ? cfg.transferBlockNum : 0x1000; }
   size_t numVoxels() const {
     return cfg.indexType == ITM_INDEX_HASH ? (size_t)cfg.localBlockNum * 512
                                            : (size_t)cfg.denseSize[0] * cfg.denseSize[1] * cfg.denseSize[2];
@@ -479,6 +485,34 @@ bool block_visible(const HashEntry& e, const float* M, const float* intr, float 
   return false;
 }
 
+// checkBlockVisibility<true> (:277-342 with checkPointVisibility<true> :243-275): a corner outside the image but inside the image
+// enlarged by an eighth on every side makes the block "visible enlarged"; the walk over the corners ends at the first corner
+// that is inside the image proper
+bool block_visible_enlarged(const HashEntry& e, const float* M, const float* intr, float voxelSize, int w, int h) {
+  float f = (float)ITM_SDF_BLOCK_SIZE * voxelSize;
+  V4f p = {(float)e.px * f, (float)e.py * f, (float)e.pz * f, 1.0f};
+  bool enlarged = false;
+  auto corner = [&](const V4f& c) -> bool {      // returns isVisible
+    V4f q = mul(M, c);
+    if (q.z < 1e-10f) return false;
+    float u = intr[0] * q.x / q.z + intr[2];
+    float v = intr[1] * q.y / q.z + intr[3];
+    if (u >= 0 && u < w && v >= 0 && v < h) { enlarged = true; return true; }
+    const int lx = -w / 8, hx = w + w / 8, ly = -h / 8, hy = h + h / 8;
+    if (u >= lx && u < hx && v >= ly && v < hy) enlarged = true;
+    return false;
+  };
+  if (corner(p)) return true;
+  p.z += f; if (corner(p)) return true;
+  p.y += f; if (corner(p)) return true;
+  p.x += f; if (corner(p)) return true;
+  p.z -= f; if (corner(p)) return true;
+  p.y -= f; if (corner(p)) return true;
+  p.x -= f; p.y += f; if (corner(p)) return true;
+  p.x += f; p.y -= f; p.z += f; if (corner(p)) return true;
+  return enlarged;
+}
+
 // ------------------------------------------------------------------------------------------
 // AllocateSceneFromDepth (hash)  _CPU.cpp:116-291 with buildHashAllocAndVisibleTypePP
 // DeviceAgnostic/ITMSceneReconstructionEngine.h:141-241 (useSwapping == false)
@@ -592,18 +626,108 @@ void allocate_hash(itm_scene* s, const itm_view* view, itm_render_state* rs, boo
   for (int t = 0; t < s->noTotalEntries; ++t) {
     uint8_t vt = visT[t];
     if (vt == 3) {
-      if (!block_visible(table[t], view->M_d, view->intr_d, vs, W, H)) vt = 0;
+      if (s->cfg.useSwapping) { if (!block_visible_enlarged(table[t], view->M_d, view->intr_d, vs, W, H)) vt = 0; }
+      else if (!block_visible(table[t], view->M_d, view->intr_d, vs, W, H)) vt = 0;
       visT[t] = vt;
     }
+    if (s->cfg.useSwapping) { if (vt > 0 && s->swapStates[t] != 2) s->swapStates[t] = 1; }     // _CPU.cpp:250-253
     if (vt > 0) {
       // the reference writes past visibleEntryIDs[SDF_LOCAL_BLOCK_NUM] here; this ABI clamps
       if (nv < rs->capIds) rs->visibleIds[nv] = t;
       nv++;
     }
   }
+  // reallocate deleted ones from previous swap operation (_CPU.cpp:271-285)
+  if (s->cfg.useSwapping) {
+    for (int t = 0; t < s->noTotalEntries; ++t) {
+      if (visT[t] > 0 && table[t].ptr == -1) {
+        int vbaIdx = lastFreeVBA; lastFreeVBA--;
+        if (vbaIdx >= 0) table[t].ptr = s->allocList[vbaIdx];
+      }
+    }
+  }
   rs->noVisibleEntries = (nv < rs->capIds) ? nv : rs->capIds;
   s->lastFreeBlockId = lastFreeVBA;
   s->lastFreeExcessListId = lastFreeExcess;
+}
+
+// ------------------------------------------------------------------------------------------
+// ITMSwappingEngine_CPU (DeviceSpecific/CPU/ITMSwappingEngine_CPU.cpp:21-168) with CombineVoxelInformation
+// (DeviceAgnostic/ITMSwappingEngine.h:7-69)
+// ------------------------------------------------------------------------------------------
+inline uint8_t to_uchar_ref(float x) {            // TO_UCHAR3 per component: round half away from zero, then clamp (ORUtils/Vector.h:245-247, MathUtils.h:21-23)
+  int v = (int)round_ref(x);
+  v = (v < 255) ? v : 255;
+  return (uint8_t)((0 < v) ? v : 0);
+}
+inline void combine_colour(const VoxS&, VoxS&, int) {}
+inline void combine_colour(const VoxF&, VoxF&, int) {}
+template <class V>
+inline void combine_colour(const V& src, V& dst, int maxW) {     // combineVoxelColorInformation
+  int newW = dst.wc, oldW = src.wc;
+  float newC[3], oldC[3];
+  for (int k = 0; k < 3; ++k) { newC[k] = (float)dst.clr[k] / 255.0f; oldC[k] = (float)src.clr[k] / 255.0f; }
+  if (oldW == 0) return;
+  for (int k = 0; k < 3; ++k) newC[k] = oldC[k] * (float)oldW + newC[k] * (float)newW;
+  newW = oldW + newW;
+  for (int k = 0; k < 3; ++k) newC[k] /= (float)newW;
+  newW = std::min(newW, maxW);
+  for (int k = 0; k < 3; ++k) dst.clr[k] = to_uchar_ref(newC[k] * 255.0f);
+  dst.wc = (uint8_t)newW;
+}
+template <class V>
+void combine_voxel(const V& src, V& dst, int maxW) {              // CombineVoxelInformation<hasColor, TVoxel>::compute
+  int newW = dst.w, oldW = src.w;
+  float newF = Codec<V>::toF(dst.sdf), oldF = Codec<V>::toF(src.sdf);
+  if (oldW != 0) {                                                // combineVoxelDepthInformation returns here; the colour part still runs
+    newF = oldW * oldF + newW * newF;
+    newW = oldW + newW;
+    newF /= newW;
+    newW = std::min(newW, maxW);
+    dst.w = (uint8_t)newW;
+    dst.sdf = Codec<V>::toV(newF);
+  }
+  combine_colour(src, dst, maxW);
+}
+template <class V>
+void swap_integrate_t(itm_scene* s) {
+  const int N = s->noTotalEntries, cap = s->transferBlockNum();
+  std::vector<int> needed;
+  for (int e = 0; e < N && (int)needed.size() < cap; ++e) if (s->swapStates[e] == 1) needed.push_back(e);
+  V* vba = (V*)s->vba.data();
+  for (int id : needed) {
+    if (s->hasStoredData[id] && s->hash[id].ptr >= 0) {          // (the reference dereferences ptr unchecked; a state-1 entry without a block cannot be combined)
+      const V* src = (const V*)s->storedBlocks + (size_t)id * 512;
+      V* dst = vba + (size_t)s->hash[id].ptr * 512;
+      for (int v = 0; v < 512; ++v) combine_voxel(src[v], dst[v], s->prm.maxW);
+    }
+    s->swapStates[id] = 2;
+  }
+}
+template <class V>
+void swap_save_t(itm_scene* s, itm_render_state* rs) {
+  const int N = s->noTotalEntries, cap = s->transferBlockNum();
+  V* vba = (V*)s->vba.data();
+  int noNeeded = 0, noAllocated = s->lastFreeBlockId;
+  for (int e = 0; e < N; ++e) {
+    if (noNeeded >= cap) break;
+    const int localPtr = s->hash[e].ptr;
+    if (s->swapStates[e] == 2 && localPtr >= 0 && rs->visibleType[e] == 0) {
+      V* loc = vba + (size_t)localPtr * 512;
+      s->hasStoredData[e] = 1;
+      std::memcpy(s->storedBlocks + (size_t)e * 512 * sizeof(V), loc, 512 * sizeof(V));
+      s->swapStates[e] = 0;
+      const int vbaIdx = noAllocated;
+      if (vbaIdx < s->cfg.bucketNum - 1) {                       // (sic: SDF_BUCKET_NUM, ITMSwappingEngine_CPU.cpp:146)
+        noAllocated++;
+        s->allocList[vbaIdx + 1] = localPtr;
+        s->hash[e].ptr = -1;
+        for (int i = 0; i < 512; ++i) loc[i] = Codec<V>::init();
+      }
+      noNeeded++;
+    }
+  }
+  s->lastFreeBlockId = noAllocated;
 }
 
 // FindVisibleBlocks  DeviceSpecific/CPU/ITMVisualisationEngine_CPU.cpp:39-77
@@ -1153,6 +1277,12 @@ int itmo_scene_create(const itm_scene_config* cfg_in, const itm_scene_params* pr
     s->allocList.assign(cfg.localBlockNum, 0);
     s->allocType.assign(s->noTotalEntries, 0);
     s->blockCoords.assign((size_t)s->noTotalEntries * 4, 0);
+    if (cfg.useSwapping) {
+      s->swapStates.assign(s->noTotalEntries, 0);
+      s->hasStoredData.assign(s->noTotalEntries, 0);
+      s->storedBlocks = (uint8_t*)std::calloc((size_t)s->noTotalEntries * 512, vb);
+      if (!s->storedBlocks) { delete s; return fail(ITM_ERR_DEVICE, "out of memory (global cache)"); }
+    }
   } else {
     s->allocList.assign(1, 0);
   }
@@ -1203,6 +1333,27 @@ int itmo_allocate_scene_from_depth(itm_scene* s, const itm_view* v, itm_render_s
 int itmo_integrate_into_scene(itm_scene* s, const itm_view* v, itm_render_state* rs, itm_stream) {
   if (!s || !v || !rs) return fail(ITM_ERR_INVALID, "null argument");
   return dispatch_voxel(s->cfg.voxelType, [&](auto tag) { integrate_t<VOX_T>(s, v, rs); });
+}
+
+// ITMSwappingEngine<TVoxel, ITMVoxelBlockHash>::IntegrateGlobalIntoLocal / SaveToGlobalMemory and the ITMGlobalCache accessors
+int itmo_swap_integrate_global_into_local(itm_scene* s, itm_render_state* rs, itm_stream) {
+  if (!s || !rs || !s->cfg.useSwapping) return fail(ITM_ERR_INVALID, "scene without swapping");
+  return dispatch_voxel(s->cfg.voxelType, [&](auto tag) { swap_integrate_t<VOX_T>(s); });
+}
+int itmo_swap_save_to_global_memory(itm_scene* s, itm_render_state* rs, itm_stream) {
+  if (!s || !rs || !s->cfg.useSwapping) return fail(ITM_ERR_INVALID, "scene without swapping");
+  return dispatch_voxel(s->cfg.voxelType, [&](auto tag) { swap_save_t<VOX_T>(s, rs); });
+}
+int itmo_global_cache_get(const itm_scene* s, int entry, void* dst, int* has) {
+  if (!s || !s->cfg.useSwapping || entry < 0 || entry >= s->noTotalEntries || !has) return fail(ITM_ERR_INVALID, "bad argument");
+  *has = s->hasStoredData[entry];
+  if (*has && dst) std::memcpy(dst, s->storedBlocks + (size_t)entry * 512 * s->voxBytes, 512 * s->voxBytes);
+  return ITM_OK;
+}
+int itmo_global_cache_flags(const itm_scene* s, uint8_t* dst, size_t bytes) {
+  if (!s || !s->cfg.useSwapping || !dst || bytes > (size_t)s->noTotalEntries) return fail(ITM_ERR_INVALID, "bad argument");
+  std::memcpy(dst, s->hasStoredData.data(), bytes);
+  return ITM_OK;
 }
 
 int itmo_find_visible_blocks(const itm_scene* s, const float M[16], const float intr[4], itm_render_state* rs, itm_stream) {
@@ -1358,6 +1509,7 @@ static void* buf_of(const itm_scene* s, const itm_render_state* rs, int which, s
     case ITM_BUF_RAYCAST_IMAGE: if (rs) { *bytes = rs->image.size() * 4; return (void*)rs->image.data(); } break;
     case ITM_BUF_FORWARD_PROJECTION: if (rs) { *bytes = rs->fwdProj.size() * sizeof(V4f); return (void*)rs->fwdProj.data(); } break;
     case ITM_BUF_MISSING_POINTS: if (rs) { *bytes = rs->missing.size() * 4; return (void*)rs->missing.data(); } break;
+    case ITM_BUF_SWAP_STATES: if (s && !s->swapStates.empty()) { *bytes = s->swapStates.size(); return (void*)s->swapStates.data(); } break;
   }
   return nullptr;
 }

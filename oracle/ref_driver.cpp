@@ -23,6 +23,7 @@
 #include "ITMLib/Engine/DeviceSpecific/CPU/ITMSceneReconstructionEngine_CPU.cpp"
 #include "ITMLib/Engine/DeviceSpecific/CPU/ITMVisualisationEngine_CPU.cpp"
 #include "ITMLib/Engine/DeviceSpecific/CPU/ITMMeshingEngine_CPU.cpp"
+#include "ITMLib/Engine/DeviceSpecific/CPU/ITMSwappingEngine_CPU.cpp"
 #include "ITMLib/Engine/DeviceAgnostic/ITMViewBuilder.h"
 #include "ITMLib/Engine/DeviceSpecific/CPU/ITMDepthTracker_CPU.h"
 #include "ITMLib/Engine/DeviceSpecific/CPU/ITMLowLevelEngine_CPU.h"
@@ -42,6 +43,9 @@ template class ITMLib::Engine::ITMSceneReconstructionEngine_CPU<ITMVoxel_s, ITMP
 template class ITMLib::Engine::ITMSceneReconstructionEngine_CPU<ITMVoxel_f, ITMPlainVoxelArray>;
 template class ITMLib::Engine::ITMSceneReconstructionEngine_CPU<ITMVoxel_s_rgb, ITMPlainVoxelArray>;
 template class ITMLib::Engine::ITMSceneReconstructionEngine_CPU<ITMVoxel_f_rgb, ITMPlainVoxelArray>;
+template class ITMLib::Engine::ITMSwappingEngine_CPU<ITMVoxel_f, ITMVoxelBlockHash>;
+template class ITMLib::Engine::ITMSwappingEngine_CPU<ITMVoxel_s_rgb, ITMVoxelBlockHash>;
+template class ITMLib::Engine::ITMSwappingEngine_CPU<ITMVoxel_f_rgb, ITMVoxelBlockHash>;
 template class ITMLib::Engine::ITMMeshingEngine_CPU<ITMVoxel_f, ITMVoxelBlockHash>;
 template class ITMLib::Engine::ITMMeshingEngine_CPU<ITMVoxel_s_rgb, ITMVoxelBlockHash>;
 template class ITMLib::Engine::ITMMeshingEngine_CPU<ITMVoxel_f_rgb, ITMVoxelBlockHash>;
@@ -77,6 +81,10 @@ struct RefSceneBase {
   virtual void icpMaps(const ITMView*, ITMTrackingState*, ITMRenderState*) = 0;
   virtual void forwardRender(const ITMView*, ITMTrackingState*, ITMRenderState*) = 0;
   virtual void mesh(ITMMesh*) = 0;
+  virtual void swapIn(ITMRenderState*) = 0;
+  virtual void swapOut(ITMRenderState*) = 0;
+  virtual bool cacheGet(int entry, void* dst) = 0;
+  virtual void cacheFlags(uint8_t* dst, size_t n) = 0;
   virtual void* buffer(int which, size_t* bytes) = 0;
   virtual int* lastFreeBlockId() = 0;
   virtual int lastFreeExcess() = 0;
@@ -115,9 +123,10 @@ struct RefScene : RefSceneBase {
   ITMSceneReconstructionEngine_CPU<TVoxel, TIndex> reco;
   ITMVisualisationEngine_CPU<TVoxel, TIndex> vis;
   ITMMeshingEngine_CPU<TVoxel, TIndex> mesher;
+  ITMSwappingEngine_CPU<TVoxel, TIndex> swapper;
   RefScene(const itm_scene_config& c, const itm_scene_params& p)
       : sp(p.mu, p.maxW, p.voxelSize, p.viewFrustum_min, p.viewFrustum_max, p.stopIntegratingAtMaxW != 0),
-        scene(&sp, false, MEMORYDEVICE_CPU), vis(&scene) {
+        scene(&sp, c.useSwapping != 0 && c.indexType == ITM_INDEX_HASH, MEMORYDEVICE_CPU), vis(&scene) {
     cfg = c; prm = p;
     IndexOps<TIndex>::configure(scene.index, c);
   }
@@ -135,7 +144,20 @@ struct RefScene : RefSceneBase {
   void icpMaps(const ITMView* v, ITMTrackingState* t, ITMRenderState* r) override { vis.CreateICPMaps(v, t, r); }
   void forwardRender(const ITMView* v, ITMTrackingState* t, ITMRenderState* r) override { vis.ForwardRender(v, t, r); }
   void mesh(ITMMesh* m) override { mesher.MeshScene(m, &scene); }
+  void swapIn(ITMRenderState* r) override { swapper.IntegrateGlobalIntoLocal(&scene, r); }
+  void swapOut(ITMRenderState* r) override { swapper.SaveToGlobalMemory(&scene, r); }
+  bool cacheGet(int entry, void* dst) override {
+    if (!scene.useSwapping || !scene.globalCache->HasStoredData(entry)) return false;
+    if (dst) std::memcpy(dst, scene.globalCache->GetStoredVoxelBlock(entry), sizeof(TVoxel) * SDF_BLOCK_SIZE3);
+    return true;
+  }
+  void cacheFlags(uint8_t* dst, size_t n) override { for (size_t i = 0; i < n; ++i) dst[i] = scene.useSwapping && scene.globalCache->HasStoredData((int)i) ? 1 : 0; }
   void* buffer(int which, size_t* bytes) override {
+    if (which == ITM_BUF_SWAP_STATES) {
+      if (!scene.useSwapping) { *bytes = 0; return 0; }
+      *bytes = (size_t)scene.globalCache->noTotalEntries * sizeof(ITMHashSwapState);
+      return scene.globalCache->GetSwapStates(false);
+    }
     switch (which) {
       case ITM_BUF_HASH_ENTRIES: return IndexOps<TIndex>::hashEntries(scene.index, bytes);
       case ITM_BUF_EXCESS_LIST: return IndexOps<TIndex>::excess(scene.index, bytes);
@@ -232,6 +254,7 @@ int itmr_scene_create(const itm_scene_config* cin, const itm_scene_params* prm, 
   if (c.indexType == ITM_INDEX_HASH &&
       (c.bucketNum != SDF_BUCKET_NUM || c.excessNum != SDF_EXCESS_LIST_SIZE || c.localBlockNum != SDF_LOCAL_BLOCK_NUM))
     return fail(ITM_ERR_UNSUPPORTED, "reference pool sizes are compile-time constants");
+  if (c.transferBlockNum != 0 && c.transferBlockNum != SDF_TRANSFER_BLOCK_NUM) return fail(ITM_ERR_UNSUPPORTED, "SDF_TRANSFER_BLOCK_NUM is a compile-time constant of the reference");
   if (c.indexType == ITM_INDEX_DENSE && (size_t)c.denseSize[0] * c.denseSize[1] * c.denseSize[2] > (size_t)512 * 512 * 512)
     return fail(ITM_ERR_UNSUPPORTED, "dense array larger than the reference allocation");
   RefSceneBase* impl = 0;
@@ -327,6 +350,18 @@ int itmr_forward_render(const itm_scene* s, const itm_view* v, itm_render_state*
   s->impl->forwardRender(r->view, r->ts, r->rs);
   return ITM_OK;
 }
+// the reference's ITMSwappingEngine_CPU and ITMGlobalCache (scenes created with useSwapping)
+int itmr_swap_integrate_global_into_local(itm_scene* s, itm_render_state* r, itm_stream) {
+  if (!s->impl->cfg.useSwapping) return fail(ITM_ERR_INVALID, "scene without swapping");
+  s->impl->swapIn(r->rs); return ITM_OK;
+}
+int itmr_swap_save_to_global_memory(itm_scene* s, itm_render_state* r, itm_stream) {
+  if (!s->impl->cfg.useSwapping) return fail(ITM_ERR_INVALID, "scene without swapping");
+  s->impl->swapOut(r->rs); return ITM_OK;
+}
+int itmr_global_cache_get(const itm_scene* s, int entry, void* dst, int* has) { *has = s->impl->cacheGet(entry, dst) ? 1 : 0; return ITM_OK; }
+int itmr_global_cache_flags(const itm_scene* s, uint8_t* dst, size_t bytes) { s->impl->cacheFlags(dst, bytes); return ITM_OK; }
+
 int itmr_process_frame(itm_scene* s, const itm_view* v, itm_render_state* r, float* pts, float* nrm, itm_stream st) {
   // ITMDenseMapper::ProcessFrame + ITMTrackingController::Prepare (requiresFullRendering)
   load_view(r, v);
@@ -490,7 +525,7 @@ int itmr_set_counters(itm_scene* s, itm_render_state* r, const itm_counters* c, 
 
 static void* buf_of(const itm_scene* s, const itm_render_state* r, int which, size_t* bytes) {
   *bytes = 0;
-  if (which <= ITM_BUF_ALLOCATION_LIST) return s ? s->impl->buffer(which, bytes) : 0;
+  if (which <= ITM_BUF_ALLOCATION_LIST || which == ITM_BUF_SWAP_STATES) return s ? s->impl->buffer(which, bytes) : 0;
   if (!r) return 0;
   size_t P = (size_t)r->w * r->h;
   switch (which) {
