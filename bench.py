@@ -82,6 +82,9 @@ def parse():
     ap.add_argument("--origin-offset", default="0,0,0",
                     help="X,Y,Z metres added to every camera position (scene and trajectory translated together: same depth images, "
                          "block coordinates far from the world origin)")
+    ap.add_argument("--no-lookahead", action="store_true",
+                    help="itm_process_frame instead of itm_process_frame_ahead (the next frame's block requests beside this frame's ICP maps; "
+                         "the frames are resident, so the next view is always known)")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the secondary measurements of the default run (PCIe-inclusive rate, table-walk ray cast, stream-copy peak)")
     ap.add_argument("--lib", default=None, help="alternative shared library exporting the same C-ABI (tests: a host-memory backend)")
@@ -252,6 +255,7 @@ def worker(args) -> int:
             hs = torch.cuda.current_stream() if k_streams == 1 else torch.cuda.Stream()
         streams.append(Stream(be, capi, synth, torch, wl, rank * k_streams + j, device, hs, offset=offset, raw=args.raw_depth))
     fn = be.fn["process_frame"]
+    fn_ahead = be.fn["process_frame_ahead"] if (product and wl["index"] == "hash" and not args.no_lookahead) else None
     fn_view = be.fn["update_view"]
 
     exchange = (world > 1 and not args.no_exchange) or args.force_exchange
@@ -315,7 +319,7 @@ def worker(args) -> int:
 
     mode = {"raw": args.raw_depth}
 
-    def step_stream(j, k):
+    def step_stream(j, k, last=False):
         s = streams[j]
         i = k % s.nd
         if mode["raw"]:
@@ -333,6 +337,9 @@ def worker(args) -> int:
             if rc:
                 be.check(rc, "update_view")
             rc = fn(s.sh, C.byref(s.raw_views[i]), s.rh, s.pp, s.np_, s.sp)
+        elif fn_ahead is not None:
+            # the last frame of a run() names no successor: the next leg may start anywhere
+            rc = fn_ahead(s.sh, C.byref(s.views[i]), (None if last else C.byref(s.views[(k + 1) % s.nd])), s.rh, s.pp, s.np_, s.sp)
         else:
             rc = fn(s.sh, C.byref(s.views[i]), s.rh, s.pp, s.np_, s.sp)
         if rc:
@@ -341,16 +348,16 @@ def worker(args) -> int:
             # record copy on the frame stream, all-gather on a side stream (off the critical path)
             exs[j].step(s.rs.h, s.poses_c[i], s.hip_stream)
 
-    def step(k):
+    def step(k, last=False):
         for j in range(len(streams)):
-            step_stream(j, k)
+            step_stream(j, k, last)
 
     def run(first, last):
         """Frames [first, last) of every stream.  With k > 1 streams per GPU each stream is fed by its own host thread (the
         library call releases the GIL): one thread issues ~6 launches per frame at ~10 us each, which is what bounded k = 4."""
         if len(streams) == 1 or exchange or not args.host_threads:
             for k in range(first, last):
-                step(k)
+                step(k, k == last - 1)
             return
         import threading
         errors = []
@@ -360,7 +367,7 @@ def worker(args) -> int:
                 if on_gpu:
                     torch.cuda.set_device(local_rank)
                 for k in range(first, last):
-                    step_stream(j, k)
+                    step_stream(j, k, k == last - 1)
             except BaseException as e:      # noqa: BLE001 -- re-raised on the main thread
                 errors.append(e)
         threads = [threading.Thread(target=feed, args=(j,)) for j in range(len(streams))]
@@ -489,6 +496,8 @@ def worker(args) -> int:
                        "visible_blocks_last_frame": counters["noVisibleEntries"],
                        **({"acceleration_structures": streams[0].scene.accel_info()} if (product and wl["index"] == "hash") else {}),
                        "origin_offset_m": list(offset),
+                       "frame_call": ("itm_process_frame_ahead (the next resident frame's block requests ride in this frame's last launch)" if fn_ahead is not None
+                                      else "itm_process_frame"),
                        "input": ("16-bit raw depth from pinned host memory: H2D + itm_update_view inside the timed region" if args.raw_depth
                                  else "float depth frames resident in HBM"),
                        "timing_note": f"value includes a hipEventRecord pair around the roofline kernel on every {args.timer_every}-th frame of rank 0",

@@ -282,6 +282,14 @@ int ITM_FN(forward_render)(const itm_scene* scene, const itm_view* view, itm_ren
  * one after another; this entry point only removes launch overhead. */
 int ITM_FN(process_frame)(itm_scene* scene, const itm_view* view, itm_render_state* rs,
                           float* points, float* normals, itm_stream stream);
+/* The same frame, for a host that already HAS the next frame (an offline sequence, a buffered sensor): `next` (may be NULL) is the view
+ * the next call will be made for.  Its per-pixel block requests -- the first stage of its AllocateSceneFromDepth, which only reads the
+ * table as this frame's allocation leaves it -- ride in this frame's last launch, beside the ICP maps; the next frame then starts with
+ * its visible-list launch (4 launches per frame instead of 5).  Results are identical to itm_process_frame, frame by frame.  Contract:
+ * the next allocation on this render state (itm_process_frame[_ahead] or itm_allocate_scene_from_depth) must be for exactly that view
+ * (same depth pointer, size, pose, intrinsics), else it returns ITM_ERR_INVALID. */
+int ITM_FN(process_frame_ahead)(itm_scene* scene, const itm_view* view, const itm_view* next, itm_render_state* rs,
+                                float* points, float* normals, itm_stream stream);
 
 /* ---- view builder (the step before the path) -------------------------------- */
 /* convertDepthAffineToFloat  DeviceAgnostic/ITMViewBuilder.h:22-28 */

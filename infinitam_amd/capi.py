@@ -174,6 +174,7 @@ _SIGS = {
     "create_icp_maps": (C.c_int, [_P, C.POINTER(ViewStruct), _P, _P, _P, _P]),
     "forward_render": (C.c_int, [_P, C.POINTER(ViewStruct), _P, _P]),
     "process_frame": (C.c_int, [_P, C.POINTER(ViewStruct), _P, _P, _P, _P]),
+    "process_frame_ahead": (C.c_int, [_P, C.POINTER(ViewStruct), C.POINTER(ViewStruct), _P, _P, _P, _P]),
     "convert_depth_affine": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_float, C.c_float, _P]),
     "convert_disparity": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, _P]),
     "filter_depth": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
@@ -498,6 +499,13 @@ class Scene:
         """ITMDenseMapper::ProcessFrame + ITMTrackingController::Prepare (Engine/ITMMainEngine.cpp:123-126)."""
         vs = view if isinstance(view, ViewStruct) else view.struct()      # callers on a hot loop keep one ViewStruct and update M_d in place
         self.be.check(self.be.fn["process_frame"](_P(self.h), C.byref(vs), _P(rs.h), _P(points.ptr), _P(normals.ptr), _P(stream)), "process_frame")
+
+    def process_frame_ahead(self, view, next_view, rs: "RenderState", points: DevBuffer, normals: DevBuffer, stream=None):
+        """itm_process_frame with the next frame's block requests issued beside this frame's ICP maps (next_view may be None)."""
+        vs = view if isinstance(view, ViewStruct) else view.struct()
+        ns = None if next_view is None else (next_view if isinstance(next_view, ViewStruct) else next_view.struct())
+        self.be.check(self.be.fn["process_frame_ahead"](_P(self.h), C.byref(vs), (C.byref(ns) if ns is not None else None), _P(rs.h), _P(points.ptr), _P(normals.ptr),
+                                                        _P(stream)), "process_frame_ahead")
 
     def close(self):
         if self.h:

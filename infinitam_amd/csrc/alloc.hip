@@ -32,6 +32,7 @@
 #include <cstring>
 
 #include "itm_internal.h"
+#include "alloc_device.h"
 #include "wave_utils.h"
 
 namespace itm {
@@ -40,134 +41,16 @@ int g_debug_explicit_mark = 0;   // test hook: always run the explicit mark-prev
 int g_debug_two_pass_visible_list = 0;   // test hook: count and compact as two launches
 int g_debug_separate_sweep = 0;          // test hook (key 13): the allocation sweep as its own launch
 
-struct AllocParams {
-  Mat4 invM;     // inverse of M_d (host, ORUtils cofactor scheme)
-  Mat4 M;        // M_d
-  float ifx, ify, cx, cy;   // (1/fx, 1/fy, cx, cy)
-  float fx, fy;
-  float mu, oneOverBlock, vfmin, vfmax, voxelSize;
-  int W, H;
-  uint32_t mask;
-  int bucketNum;
-  int noTotalEntries;
-  int stepBits;
-  int capIds;
-  int mirrorFloat;   // the sdf mirror holds floats (ITMVoxel_f / _f_rgb) rather than shorts
-  AccelOrigin org;   // where the block directory / slot directory / sdf mirror cubes lie (itm_types.h)
-  int useSwapping;   // scenes with a global cache: enlarged frustum for the re-test of the previous list (checkBlockVisibility<true>)
-};
-
-struct BlockRay {
-  float px, py, pz;  // current point in block units
-  float dx, dy, dz;
-  int noSteps;
-};
-
-// Ray segment [d-mu, d+mu] of one depth pixel in block coordinates; same operation order as
-// DeviceAgnostic/ITMSceneReconstructionEngine.h:155-184.  Returns false for rejected pixels.
-__device__ inline bool make_block_ray(float d, int x, int y, const AllocParams& p, BlockRay& r) {
-  if (d <= 0 || (d - p.mu) < 0 || (d - p.mu) < p.vfmin || (d + p.mu) > p.vfmax) return false;
-  float cz = d;
-  float cxp = cz * (((float)x - p.cx) * p.ifx);
-  float cyp = cz * (((float)y - p.cy) * p.ify);
-  float norm = sqrtf(cxp * cxp + cyp * cyp + cz * cz);
-  float sa = 1.0f - p.mu / norm;
-  Vec3 a = transform_point(p.invM, cxp * sa, cyp * sa, cz * sa);
-  float sx = a.x * p.oneOverBlock, sy = a.y * p.oneOverBlock, sz = a.z * p.oneOverBlock;
-  float sb = 1.0f + p.mu / norm;
-  Vec3 b = transform_point(p.invM, cxp * sb, cyp * sb, cz * sb);
-  float ex = b.x * p.oneOverBlock, ey = b.y * p.oneOverBlock, ez = b.z * p.oneOverBlock;
-  float dx = ex - sx, dy = ey - sy, dz = ez - sz;
-  norm = sqrtf(dx * dx + dy * dy + dz * dz);
-  int noSteps = (int)ceilf(2.0f * norm);
-  float div = (float)(noSteps - 1);
-  r.px = sx; r.py = sy; r.pz = sz;
-  r.dx = dx / div; r.dy = dy / div; r.dz = dz / div;
-  r.noSteps = noSteps;
-  return true;
-}
-
 __global__ void __launch_bounds__(256) mark_previous_kernel(const int32_t* __restrict__ ids, RenderCounters* __restrict__ rc,
                                                             uint8_t* __restrict__ visT) {
   const int nv = rc->noVisibleEntries;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += gridDim.x * blockDim.x) visT[ids[i]] = 3;
 }
 
-// One workgroup = 16x16 pixels, one wave = 16x4 pixels.
+// One workgroup = 16x16 pixels, one wave = 16x4 pixels (the body: alloc_device.h).
 template <bool ONLY_VISIBLE, bool FUSE_RANGE_INIT, bool LAZY>
-__global__ void __launch_bounds__(256) request_kernel(const float* __restrict__ depth, const uint4* __restrict__ hash,
-                                                      uint8_t* __restrict__ visT, uint32_t* __restrict__ allocKey,
-                                                      int2* __restrict__ chunkReq, SceneCounters* __restrict__ counters,
-                                                      float2* __restrict__ range, RenderCounters* __restrict__ rcnt, const int32_t* __restrict__ dirSlot, AllocParams p) {
-  // LAZY: instead of first marking last frame's list as type 3 (a separate launch), this frame's
-  // touches carry bit 7; visible_count_kernel then reads every other non-zero type as "3".
-  constexpr uint8_t kTouched = LAZY ? 0x80 : 0x00;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (FUSE_RANGE_INIT && blockIdx.x == 0 && blockIdx.y == 0) {
-    if (threadIdx.x == 0) { rcnt->noRenderingBlocks = 0; rcnt->renderingBlocksAccepted = -1; }
-  }
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) rcnt->listInvalid = 0;
-  const int x = blockIdx.x * 16 + (lane & 15);
-  const int y = blockIdx.y * 16 + wave * 4 + (lane >> 4);
-  if (x >= p.W || y >= p.H) return;
-  const int loc = x + y * p.W;
-  if (FUSE_RANGE_INIT) range[loc] = make_float2(999999.9f, 0.05f);  // CreateExpectedDepths init, fused
-  BlockRay r;
-  if (!make_block_ray(depth[loc], x, y, p, r)) return;
-  if (!ONLY_VISIBLE && r.noSteps > (1 << p.stepBits)) {
-    atomicOr(&counters->statusFlags, 1);
-    r.noSteps = 1 << p.stepBits;
-  }
-  for (int i = 0; i < r.noSteps; ++i) {
-    const int bx = (int)(int16_t)(int)floorf(r.px), by = (int)(int16_t)(int)floorf(r.py), bz = (int)(int16_t)(int)floorf(r.pz);
-    if (dirSlot) {
-      // a block that exists inside the directory's cube: its table slot from one coherent load (entries are never swapped out:
-      // ptr >= 0, hence type 1); every other case takes the probe below
-      const uint32_t ux = (uint32_t)(bx - p.org.dx), uy = (uint32_t)(by - p.org.dy), uz = (uint32_t)(bz - p.org.dz);
-      if (dir_covers(ux, uy, uz)) {
-        const int slot = dirSlot[dir_cell(ux, uy, uz)];
-        if (slot >= 0) {
-          visT[slot] = 1 | kTouched;
-          r.px += r.dx; r.py += r.dy; r.pz += r.dz;
-          continue;
-        }
-      }
-    }
-    int idx = hash_index(bx, by, bz, p.mask);
-    HashEntry he = unpack_entry(hash[idx]);
-    bool found = false;
-    if (he.px == bx && he.py == by && he.pz == bz && he.ptr >= -1) {
-      visT[idx] = ((he.ptr == -1) ? 2 : 1) | kTouched;
-      found = true;
-    }
-    if (!found) {
-      bool isExcess = false;
-      if (he.ptr >= -1) {
-        while (he.offset >= 1) {
-          idx = p.bucketNum + he.offset - 1;
-          he = unpack_entry(hash[idx]);
-          if (he.px == bx && he.py == by && he.pz == bz && he.ptr >= -1) {
-            visT[idx] = ((he.ptr == -1) ? 2 : 1) | kTouched;
-            found = true;
-            break;
-          }
-        }
-        isExcess = true;
-      }
-      if (!found) {
-        if (!isExcess) visT[idx] = 1 | kTouched;
-        if (!ONLY_VISIBLE) {
-          const uint32_t key = (((uint32_t)loc << p.stepBits) | (uint32_t)i) + 1u;
-          const uint32_t old = atomicMax(&allocKey[idx], key);
-          if (old == 0u) {
-            atomicAdd(&chunkReq[idx / kSweepChunk].x, 1);
-            if (isExcess) atomicAdd(&chunkReq[idx / kSweepChunk].y, 1);
-          }
-        }
-      }
-    }
-    r.px += r.dx; r.py += r.dy; r.pz += r.dz;
-  }
+__global__ void __launch_bounds__(256) request_kernel(RequestArgs a, AllocParams p) {
+  request_tile<ONLY_VISIBLE, FUSE_RANGE_INIT, LAZY>(blockIdx.x, blockIdx.y, a, p);
 }
 
 // Block coordinates requested by (pixel, step): replays the winner's ray with identical arithmetic.
@@ -651,24 +534,49 @@ static int fill_params(const itm_scene* s, const float* M, const float* intr, in
 // Stage 1: per-pixel block requests.  When the visible list and the visible types are known to be
 // coherent (always, unless the caller rewrote one of them) the "mark previous list as type 3" launch is
 // skipped and folded into the type encoding (LAZY, see request_kernel).
-int launch_request_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, bool onlyVisible, bool fuseRangeInit, hipStream_t st) {
-  AllocParams p;
+// Everything of the request stage up to the launch: parameters, the acceleration cubes placed for this view, the request counters of
+// this frame's parity.  `lazy`: the previous list need not be marked (see request_kernel).
+int prepare_request_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, hipStream_t st, AllocParams& p, RequestArgs& ra, bool& lazy) {
   int rc = fill_params(s, v->M_d, v->intr_d, v->w, v->h, rs->capIds, p);
   if (rc) return rc;
+  if (p.stepBits < 4) return set_error(ITM_ERR_INVALID, "depth image too large for the allocation key");
   // the acceleration cubes follow the camera: placed by the first frame, moved (emptied and refilled from the table, on this stream)
   // when the view leaves them
   rc = accel_place(s, p.invM.m, st);
   if (rc) return rc;
   p.org = s->org;
-  if (p.stepBits < 4) return set_error(ITM_ERR_INVALID, "depth image too large for the allocation key");
-  const int nChunks = s->numChunks;
-  int2* reqCur = (int2*)s->chunkReq + (size_t)(s->frameParity & 1u) * nChunks;
-  const bool lazy = rs->listCoherent && !g_debug_explicit_mark;
+  int2* reqCur = (int2*)s->chunkReq + (size_t)(s->frameParity & 1u) * s->numChunks;
+  lazy = rs->listCoherent && !g_debug_explicit_mark;
+  ra = RequestArgs{v->depth, s->hash, rs->visibleType, s->allocKey, reqCur, s->counters, rs->range, rs->counters, g_debug_no_directory ? nullptr : s->dirSlot};
+  return ITM_OK;
+}
+
+static bool same_view(const itm_render_state* rs, const itm_view* v) {
+  return rs->ahead.depth == v->depth && rs->ahead.w == v->w && rs->ahead.h == v->h && memcmp(rs->ahead.M_d, v->M_d, 64) == 0 && memcmp(rs->ahead.intr_d, v->intr_d, 16) == 0;
+}
+
+// Stage 1 (reads the table, writes the request keys / visible types): can overlap the previous
+// frame's integration and ray casting, which do not touch these buffers.
+// Stage 1: per-pixel block requests.  When the visible list and the visible types are known to be
+// coherent (always, unless the caller rewrote one of them) the "mark previous list as type 3" launch is
+// skipped and folded into the type encoding (LAZY, see request_kernel).
+int launch_request_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, bool onlyVisible, bool fuseRangeInit, hipStream_t st) {
+  if (rs->ahead.valid) {
+    // the requests of this frame rode in the previous frame's last launch (itm_process_frame_ahead)
+    if (onlyVisible || !same_view(rs, v))
+      return set_error(ITM_ERR_INVALID, "the block requests of another view were issued ahead (itm_process_frame_ahead): the next allocation must be for that view");
+    rs->ahead.valid = false;
+    rs->lazyThisFrame = rs->ahead.lazy;
+    return ITM_OK;
+  }
+  AllocParams p; RequestArgs ra; bool lazy;
+  int rc = prepare_request_stage(s, v, rs, st, p, ra, lazy);
+  if (rc) return rc;
   rs->lazyThisFrame = lazy;
   if (!lazy) mark_previous_kernel<<<64, 256, 0, st>>>(rs->visibleIds, rs->counters, rs->visibleType);
   dim3 grid((v->w + 15) / 16, (v->h + 15) / 16);
   KernelTimer tq(s, ITM_TK_REQUEST, st);
-#define ITM_REQ(OV, FU, LZ) request_kernel<OV, FU, LZ><<<grid, 256, 0, st>>>(v->depth, s->hash, rs->visibleType, s->allocKey, reqCur, s->counters, rs->range, rs->counters, g_debug_no_directory ? nullptr : s->dirSlot, p)
+#define ITM_REQ(OV, FU, LZ) request_kernel<OV, FU, LZ><<<grid, 256, 0, st>>>(ra, p)
   if (onlyVisible) {
     if (fuseRangeInit) { if (lazy) ITM_REQ(true, true, true); else ITM_REQ(true, true, false); }
     else { if (lazy) ITM_REQ(true, false, true); else ITM_REQ(true, false, false); }

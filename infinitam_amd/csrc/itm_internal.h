@@ -129,6 +129,9 @@ struct itm_render_state {
   // itm_process_frame on images too large for the fused projection: the projection runs beside the integration (visualise.hip)
   hipStream_t sideStream = nullptr;
   hipEvent_t listReady = nullptr, projectionDone = nullptr;
+  // itm_process_frame_ahead: the block requests of the NEXT frame were issued beside this frame's ICP maps; the next allocation
+  // must be for exactly this view and skips its request launch
+  struct { bool valid = false; const float* depth = nullptr; int w = 0, h = 0; float M_d[16] = {}, intr_d[4] = {}; bool lazy = false; } ahead;
 };
 
 namespace itm {
@@ -207,7 +210,8 @@ bool can_fuse_projection(const itm_scene* s, const itm_render_state* rs);
 int launch_find_visible(const itm_scene* s, const float* M, const float* intr, itm_render_state* rs, hipStream_t st);
 int launch_expected_depths(const itm_scene* s, const float* M, const float* intr, itm_render_state* rs, bool rangeAlreadyInit, hipStream_t st, bool projected = false);
 int launch_raycast(const itm_scene* s, const float* invM, const float* intr, itm_render_state* rs, float4* dst, hipStream_t st, bool reduceRange = false);
-int launch_icp_maps(const itm_scene* s, const itm_view* v, itm_render_state* rs, float4* points, float4* normals, hipStream_t st, bool reduceRange = false);
+int launch_icp_maps(const itm_scene* s, const itm_view* v, itm_render_state* rs, float4* points, float4* normals, hipStream_t st, bool reduceRange = false,
+                    itm_scene* sceneForNext = nullptr, const itm_view* next = nullptr);
 int launch_render_image(const itm_scene* s, const float* M, const float* intr, itm_render_state* rs, uchar4* out, int type, hipStream_t st);
 int launch_forward_render(const itm_scene* s, const itm_view* v, itm_render_state* rs, hipStream_t st);
 int launch_point_cloud(const itm_scene* s, const itm_view* v, itm_render_state* rs, bool skip, float4* loc, float4* col, hipStream_t st);

@@ -22,6 +22,7 @@
 #include <cstring>
 
 #include "itm_internal.h"
+#include "alloc_device.h"
 #include "shading_device.h"
 #include "range_device.h"
 #include "wave_utils.h"
@@ -458,13 +459,64 @@ __global__ void __launch_bounds__(256) icp_maps_kernel(const float4* __restrict_
   }
 }
 
-int launch_icp_maps(const itm_scene* s, const itm_view* v, itm_render_state* rs, float4* points, float4* normals, hipStream_t st, bool reduceRange) {
+// The ICP maps of frame N and the block requests of frame N + 1 in ONE launch (itm_process_frame_ahead): the request stage only reads
+// the table / slot directory as the allocation of frame N left them and the next depth image, and writes the request keys, the visible
+// types and the request counters -- none of which the ICP maps touch -- so the two halves of the launch are independent; frame N + 1
+// then starts with its visible-list launch (4 launches per frame instead of 5).  The first nIcp workgroups compute the maps.
+__global__ void __launch_bounds__(256) icp_maps_request_kernel(const float4* __restrict__ rays, float4* __restrict__ points, float4* __restrict__ normals,
+                                                               uchar4* __restrict__ image, RayParams p, int icpTilesX, int nIcp, RequestArgs ra, AllocParams ap, int reqTilesX) {
+  const int b = blockIdx.x;
+  if (b >= nIcp) {
+    const int r = b - nIcp;
+    request_tile<false, true, true>(r % reqTilesX, r / reqTilesX, ra, ap);
+    return;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int x = (b % icpTilesX) * 16 + (lane & 15);
+  const int y = (b / icpTilesX) * 16 + wave * 4 + (lane >> 4);
+  if (x >= p.W || y >= p.H) return;
+  const int loc = x + y * p.W;
+  const float4 r = rays[loc];
+  bool found = r.w > 0.0f;
+  float nx = 0, ny = 0, nz = 0, angle = 0;
+  if (found) found = normal_from_hits(rays, x, y, p.W, p.H, p.voxelSize, p.lx, p.ly, p.lz, nx, ny, nz, angle);
+  if (found) {
+    nt_store(&image[loc], grey_pixel(angle));
+    nt_store(&points[loc], make_float4(r.x * p.voxelSize, r.y * p.voxelSize, r.z * p.voxelSize, 1.0f));
+    nt_store(&normals[loc], make_float4(nx, ny, nz, 0.0f));
+  } else {
+    const float4 inv = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+    nt_store(&points[loc], inv); nt_store(&normals[loc], inv); nt_store(&image[loc], make_uchar4(0, 0, 0, 0));
+  }
+}
+
+int prepare_request_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, hipStream_t st, AllocParams& p, RequestArgs& ra, bool& lazy);
+
+// `next` (with the scene as a mutable object): also issue the block requests of that view, see icp_maps_request_kernel
+int launch_icp_maps(const itm_scene* s, const itm_view* v, itm_render_state* rs, float4* points, float4* normals, hipStream_t st, bool reduceRange,
+                    itm_scene* sceneForNext, const itm_view* next) {
   float invM[16];
   if (!invert4(v->M_d, invM)) return set_error(ITM_ERR_INVALID, "pose matrix is singular");
   int rc = launch_raycast(s, invM, v->intr_d, rs, rs->raycast, st, reduceRange);
   if (rc) return rc;
   RayParams p; make_ray_params(s, invM, v->intr_d, rs->w, rs->h, p);
   const dim3 grid((rs->w + 15) / 16, (rs->h + 15) / 16);
+  if (next && sceneForNext) {
+    AllocParams ap; RequestArgs ra; bool lazy = false;
+    // (placing the cubes for the next view may move them: after this frame's ray cast, which is the last reader of their old place)
+    rc = prepare_request_stage(sceneForNext, next, rs, st, ap, ra, lazy);
+    if (rc) return rc;
+    if (lazy) {
+      const int reqX = (next->w + 15) / 16, reqY = (next->h + 15) / 16, nIcp = (int)(grid.x * grid.y);
+      KernelTimer tk(s, ITM_TK_ICP_MAPS, st);
+      icp_maps_request_kernel<<<nIcp + reqX * reqY, 256, 0, st>>>(rs->raycast, points, normals, rs->image, p, (int)grid.x, nIcp, ra, ap, reqX);
+      ITM_LAUNCH_CHECK();
+      rs->ahead.valid = true; rs->ahead.depth = next->depth; rs->ahead.w = next->w; rs->ahead.h = next->h; rs->ahead.lazy = true;
+      memcpy(rs->ahead.M_d, next->M_d, 64); memcpy(rs->ahead.intr_d, next->intr_d, 16);
+      return ITM_OK;
+    }
+    // (the previous list would need its explicit mark first: no request ahead, the next frame issues its own)
+  }
   KernelTimer tk(s, ITM_TK_ICP_MAPS, st);
   icp_maps_kernel<<<grid, 256, 0, st>>>(rs->raycast, points, normals, rs->image, p);
   ITM_LAUNCH_CHECK();
@@ -583,7 +635,12 @@ int itm_render_image(const itm_scene* s, const float M[16], const float intr[4],
 // beside integration -- was measured SLOWER on MI355X, 170 vs 157 us/frame: the four cross-stream
 // event dependencies cost more than the ~25 us of overlap they buy.  Not kept.)
 int itm_process_frame(itm_scene* s, const itm_view* v, itm_render_state* rs, float* points, float* normals, itm_stream stream) {
+  return itm_process_frame_ahead(s, v, nullptr, rs, points, normals, stream);
+}
+
+int itm_process_frame_ahead(itm_scene* s, const itm_view* v, const itm_view* next, itm_render_state* rs, float* points, float* normals, itm_stream stream) {
   if (!s || !v || !rs || !points || !normals) return set_error(ITM_ERR_INVALID, "null argument");
+  if (next && (!next->depth || next->w != rs->w || next->h != rs->h)) return set_error(ITM_ERR_INVALID, "next view / render state mismatch");
   if (!v->depth) return set_error(ITM_ERR_INVALID, "null depth image");
   if (rs->scene != s || v->w != rs->w || v->h != rs->h) return set_error(ITM_ERR_INVALID, "view / render state mismatch");
   hipStream_t st = as_stream(stream);
@@ -600,7 +657,8 @@ int itm_process_frame(itm_scene* s, const itm_view* v, itm_render_state* rs, flo
   // own cells (raycast_kernel<.., REDUCE>); otherwise CreateExpectedDepths runs as its own launches
   const bool reduceInRaycast = (fuse || beside) && !g_debug_no_fused_range_reduce;
   if (!reduceInRaycast && (rc = launch_expected_depths(s, v->M_d, v->intr_d, rs, hashScene, st, fuse || beside))) return rc;
-  return launch_icp_maps(s, v, rs, (float4*)points, (float4*)normals, st, reduceInRaycast);
+  const bool ahead = next && hashScene && !s->cfg.useSwapping;
+  return launch_icp_maps(s, v, rs, (float4*)points, (float4*)normals, st, reduceInRaycast, ahead ? s : nullptr, ahead ? next : nullptr);
 }
 
 }  // extern "C"

@@ -1403,6 +1403,11 @@ int itmo_process_frame(itm_scene* s, const itm_view* v, itm_render_state* rs, fl
   return itmo_create_icp_maps(s, v, rs, pts, nrm, st);
 }
 
+// (the look-ahead of the product's entry point is a launch-level matter: the results are those of the frame alone)
+int itmo_process_frame_ahead(itm_scene* s, const itm_view* v, const itm_view*, itm_render_state* rs, float* pts, float* nrm, itm_stream st) {
+  return itmo_process_frame(s, v, rs, pts, nrm, st);
+}
+
 // convertDepthAffineToFloat / convertDisparityToDepth  DeviceAgnostic/ITMViewBuilder.h:7-28
 int itmo_convert_depth_affine(const int16_t* raw, float* out, int w, int h, float a, float b, itm_stream) {
   for (int i = 0; i < w * h; ++i) { int16_t d = raw[i]; out[i] = ((d <= 0) || (d > 32000)) ? -1.0f : (float)d * a + b; }

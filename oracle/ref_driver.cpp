@@ -371,6 +371,10 @@ int itmr_process_frame(itm_scene* s, const itm_view* v, itm_render_state* r, flo
   return itmr_create_icp_maps(s, v, r, pts, nrm, st);
 }
 
+int itmr_process_frame_ahead(itm_scene* s, const itm_view* v, const itm_view*, itm_render_state* r, float* pts, float* nrm, itm_stream st) {
+  return itmr_process_frame(s, v, r, pts, nrm, st);
+}
+
 // ---- meshing: the reference's ITMMesh + ITMMeshingEngine_CPU ----------------------------------------------------------------
 struct itm_mesh { const itm_scene* scene; ITMMesh* mesh; };
 int itmr_mesh_create(const itm_scene* s, uint32_t maxTriangles, itm_mesh** out) {
