@@ -334,8 +334,21 @@ __device__ unsigned long long g_rayStamps[8192 * 4];   // per wave: start, after
 #define ITM_RS(...)
 #endif
 
-template <class VX, bool DENSE, bool REDUCE, bool PARK>
-__global__ void __launch_bounds__(256) raycast_kernel(VolumeView vol, const float2* __restrict__ range, float4* __restrict__ out, RayParams p, RangeFuse fuse) {
+// AHEAD (itm_process_frame_ahead): the workgroups beyond the image's tiles issue the block requests of the NEXT frame.  They are
+// dispatched last, i.e. into the compute units that the ordinary tiles leave while the launch waits for its silhouette tiles (81 % of
+// the tiles are done after a third of the launch): the request stage of the next frame costs the frame nothing.  It reads the table /
+// slot directory / next depth image and writes request keys, visible types and request counters, none of which a ray touches.
+struct AheadRequest { RequestArgs ra; AllocParams ap; int rayTiles, reqTilesX; };
+
+template <class VX, bool DENSE, bool REDUCE, bool PARK, bool AHEAD = false>
+__global__ void __launch_bounds__(256) raycast_kernel(VolumeView vol, const float2* __restrict__ range, float4* __restrict__ out, RayParams p, RangeFuse fuse, AheadRequest ahead) {
+  if constexpr (AHEAD) {
+    if ((int)blockIdx.x >= ahead.rayTiles) {
+      const int r = (int)blockIdx.x - ahead.rayTiles;
+      request_tile<false, false, true>(r % ahead.reqTilesX, r / ahead.reqTilesX, ahead.ra, ahead.ap);
+      return;
+    }
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // (An XCD-affine order -- image band b ray-cast by XCD b, with integration placing the blocks of band b on XCD b --
   // recovers 5 of the ~17 us the rays lose to voxel lines written on other XCDs, but costs integration 10 us; and 8x8
@@ -401,29 +414,44 @@ __global__ void __launch_bounds__(256) raycast_kernel(VolumeView vol, const floa
 extern "C" int itm_debug_read_raycast_stamps(unsigned long long* dst, int n) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_rayStamps), (size_t)n * 8); }
 #endif
 
-int launch_raycast(const itm_scene* s, const float* invM, const float* intr, itm_render_state* rs, float4* dst, hipStream_t st, bool reduceRange) {
+int launch_raycast(const itm_scene* s, const float* invM, const float* intr, itm_render_state* rs, float4* dst, hipStream_t st, bool reduceRange, const AheadRequest* aheadIn) {
   RayParams p; make_ray_params(s, invM, intr, rs->w, rs->h, p);
   const VolumeView vol = make_volume(s);
-  const dim3 grid(((rs->w + 15) / 16) * ((rs->h + 15) / 16));
+  const int rayTiles = ((rs->w + 15) / 16) * ((rs->h + 15) / 16);
   const bool dense = s->cfg.indexType == ITM_INDEX_DENSE;
   RangeFuse fuse{rs->rangePartials, rs->counters, rs->projBuf, rs->range, (rs->w + 7) / 8, (rs->h + 7) / 8, s->cfg.maxRenderingBlocks};
   // two phases whenever the block directory is in use
   const bool park = !dense && vol.dirPtr != nullptr && !g_debug_single_pass_raycast;
+  AheadRequest ahead;
+  memset(&ahead, 0, sizeof ahead);
+  int reqTiles = 0;
+  if (aheadIn && !dense) { ahead = *aheadIn; ahead.rayTiles = rayTiles; reqTiles = ahead.reqTilesX * ((ahead.ap.H + 15) / 16); }
+  const dim3 grid(rayTiles + reqTiles);
   KernelTimer tk(s, ITM_TK_RAYCAST, st);
   int rc = dispatch_voxel(s->cfg.voxelType, [&](auto vx) {
     using VX = decltype(vx);
-    if (dense) raycast_kernel<VX, true, false, false><<<grid, 256, 0, st>>>(vol, rs->range, dst, p, fuse);
-    else if (park) {
-      if (reduceRange) raycast_kernel<VX, false, true, true><<<grid, 256, 0, st>>>(vol, rs->range, dst, p, fuse);
-      else raycast_kernel<VX, false, false, true><<<grid, 256, 0, st>>>(vol, rs->range, dst, p, fuse);
+    if (dense) raycast_kernel<VX, true, false, false><<<grid, 256, 0, st>>>(vol, rs->range, dst, p, fuse, ahead);
+    else if (reqTiles) {
+      if (park) { if (reduceRange) raycast_kernel<VX, false, true, true, true><<<grid, 256, 0, st>>>(vol, rs->range, dst, p, fuse, ahead);
+                  else raycast_kernel<VX, false, false, true, true><<<grid, 256, 0, st>>>(vol, rs->range, dst, p, fuse, ahead); }
+      else if (reduceRange) raycast_kernel<VX, false, true, false, true><<<grid, 256, 0, st>>>(vol, rs->range, dst, p, fuse, ahead);
+      else raycast_kernel<VX, false, false, false, true><<<grid, 256, 0, st>>>(vol, rs->range, dst, p, fuse, ahead);
     }
-    else if (reduceRange) raycast_kernel<VX, false, true, false><<<grid, 256, 0, st>>>(vol, rs->range, dst, p, fuse);
-    else raycast_kernel<VX, false, false, false><<<grid, 256, 0, st>>>(vol, rs->range, dst, p, fuse);
+    else if (park) {
+      if (reduceRange) raycast_kernel<VX, false, true, true><<<grid, 256, 0, st>>>(vol, rs->range, dst, p, fuse, ahead);
+      else raycast_kernel<VX, false, false, true><<<grid, 256, 0, st>>>(vol, rs->range, dst, p, fuse, ahead);
+    }
+    else if (reduceRange) raycast_kernel<VX, false, true, false><<<grid, 256, 0, st>>>(vol, rs->range, dst, p, fuse, ahead);
+    else raycast_kernel<VX, false, false, false><<<grid, 256, 0, st>>>(vol, rs->range, dst, p, fuse, ahead);
     return ITM_OK;
   });
   if (rc) return rc;
   ITM_LAUNCH_CHECK();
   return ITM_OK;
+}
+// (the entry points of the other translation units know nothing of requests ahead)
+int launch_raycast(const itm_scene* s, const float* invM, const float* intr, itm_render_state* rs, float4* dst, hipStream_t st, bool reduceRange) {
+  return launch_raycast(s, invM, intr, rs, dst, st, reduceRange, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -459,23 +487,18 @@ __global__ void __launch_bounds__(256) icp_maps_kernel(const float4* __restrict_
   }
 }
 
-// The ICP maps of frame N and the block requests of frame N + 1 in ONE launch (itm_process_frame_ahead): the request stage only reads
-// the table / slot directory as the allocation of frame N left them and the next depth image, and writes the request keys, the visible
-// types and the request counters -- none of which the ICP maps touch -- so the two halves of the launch are independent; frame N + 1
-// then starts with its visible-list launch (4 launches per frame instead of 5).  The first nIcp workgroups compute the maps.
-__global__ void __launch_bounds__(256) icp_maps_request_kernel(const float4* __restrict__ rays, float4* __restrict__ points, float4* __restrict__ normals,
-                                                               uchar4* __restrict__ image, RayParams p, int icpTilesX, int nIcp, RequestArgs ra, AllocParams ap, int reqTilesX) {
-  const int b = blockIdx.x;
-  if (b >= nIcp) {
-    const int r = b - nIcp;
-    request_tile<false, true, true>(r % reqTilesX, r / reqTilesX, ra, ap);
-    return;
-  }
+// The ICP maps of a frame whose successor's block requests rode in the ray-cast launch (itm_process_frame_ahead): what the request
+// launch of the successor would have initialised -- the range image and the rendering-block counters of its CreateExpectedDepths --
+// is initialised here, after this frame's ray cast has read them.
+__global__ void __launch_bounds__(256) icp_maps_init_next_kernel(const float4* __restrict__ rays, float4* __restrict__ points, float4* __restrict__ normals,
+                                                                 uchar4* __restrict__ image, RayParams p, float2* __restrict__ range, RenderCounters* __restrict__ rcnt) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int x = (b % icpTilesX) * 16 + (lane & 15);
-  const int y = (b / icpTilesX) * 16 + wave * 4 + (lane >> 4);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { rcnt->noRenderingBlocks = 0; rcnt->renderingBlocksAccepted = -1; }
+  const int x = blockIdx.x * 16 + (lane & 15);
+  const int y = blockIdx.y * 16 + wave * 4 + (lane >> 4);
   if (x >= p.W || y >= p.H) return;
   const int loc = x + y * p.W;
+  range[loc] = make_float2(999999.9f, 0.05f);
   const float4 r = rays[loc];
   bool found = r.w > 0.0f;
   float nx = 0, ny = 0, nz = 0, angle = 0;
@@ -492,33 +515,33 @@ __global__ void __launch_bounds__(256) icp_maps_request_kernel(const float4* __r
 
 int prepare_request_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, hipStream_t st, AllocParams& p, RequestArgs& ra, bool& lazy);
 
-// `next` (with the scene as a mutable object): also issue the block requests of that view, see icp_maps_request_kernel
+// `next` (with the scene as a mutable object): also issue the block requests of that view, in the tail of the ray-cast launch
 int launch_icp_maps(const itm_scene* s, const itm_view* v, itm_render_state* rs, float4* points, float4* normals, hipStream_t st, bool reduceRange,
                     itm_scene* sceneForNext, const itm_view* next) {
   float invM[16];
   if (!invert4(v->M_d, invM)) return set_error(ITM_ERR_INVALID, "pose matrix is singular");
-  int rc = launch_raycast(s, invM, v->intr_d, rs, rs->raycast, st, reduceRange);
+  AheadRequest ahead;
+  bool issueAhead = false;
+  if (next && sceneForNext) {
+    // (placing the cubes for the next view may move them: before this frame's ray cast, which then reads them at their new place)
+    bool lazy = false;
+    int rc = prepare_request_stage(sceneForNext, next, rs, st, ahead.ap, ahead.ra, lazy);
+    if (rc) return rc;
+    issueAhead = lazy;          // (otherwise the previous list needs its explicit mark first: the next frame issues its own requests)
+    ahead.reqTilesX = (next->w + 15) / 16;
+  }
+  int rc = launch_raycast(s, invM, v->intr_d, rs, rs->raycast, st, reduceRange, issueAhead ? &ahead : nullptr);
   if (rc) return rc;
   RayParams p; make_ray_params(s, invM, v->intr_d, rs->w, rs->h, p);
   const dim3 grid((rs->w + 15) / 16, (rs->h + 15) / 16);
-  if (next && sceneForNext) {
-    AllocParams ap; RequestArgs ra; bool lazy = false;
-    // (placing the cubes for the next view may move them: after this frame's ray cast, which is the last reader of their old place)
-    rc = prepare_request_stage(sceneForNext, next, rs, st, ap, ra, lazy);
-    if (rc) return rc;
-    if (lazy) {
-      const int reqX = (next->w + 15) / 16, reqY = (next->h + 15) / 16, nIcp = (int)(grid.x * grid.y);
-      KernelTimer tk(s, ITM_TK_ICP_MAPS, st);
-      icp_maps_request_kernel<<<nIcp + reqX * reqY, 256, 0, st>>>(rs->raycast, points, normals, rs->image, p, (int)grid.x, nIcp, ra, ap, reqX);
-      ITM_LAUNCH_CHECK();
-      rs->ahead.valid = true; rs->ahead.depth = next->depth; rs->ahead.w = next->w; rs->ahead.h = next->h; rs->ahead.lazy = true;
-      memcpy(rs->ahead.M_d, next->M_d, 64); memcpy(rs->ahead.intr_d, next->intr_d, 16);
-      return ITM_OK;
-    }
-    // (the previous list would need its explicit mark first: no request ahead, the next frame issues its own)
-  }
   KernelTimer tk(s, ITM_TK_ICP_MAPS, st);
-  icp_maps_kernel<<<grid, 256, 0, st>>>(rs->raycast, points, normals, rs->image, p);
+  if (issueAhead) {
+    icp_maps_init_next_kernel<<<grid, 256, 0, st>>>(rs->raycast, points, normals, rs->image, p, rs->range, rs->counters);
+    rs->ahead.valid = true; rs->ahead.depth = next->depth; rs->ahead.w = next->w; rs->ahead.h = next->h; rs->ahead.lazy = true;
+    memcpy(rs->ahead.M_d, next->M_d, 64); memcpy(rs->ahead.intr_d, next->intr_d, 16);
+  } else {
+    icp_maps_kernel<<<grid, 256, 0, st>>>(rs->raycast, points, normals, rs->image, p);
+  }
   ITM_LAUNCH_CHECK();
   return ITM_OK;
 }
