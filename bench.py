@@ -531,7 +531,9 @@ def algorithmic_bytes(config, wl, counters):
       R_found = nearest reads that find a voxel, R_t = trilinear reads, H = 16-byte hash entries the reference's
       readVoxel dereferences (every cache-miss probe incl. chain links and the misses of empty-space steps).
     config 5, hash integrate: Nv*(512*V*2 + E + 4) + 4*P (+ 4*P rgb), Nv live from the device counters.
-    config 3, dense integrate: 512^3*V read + 4*P (the writes of updated voxels, U*V <= 3 %, are NOT counted)."""
+    config 3, dense integrate: 512^3*V read + 4*P (the reference reads every voxel's weight in every frame; the writes of updated
+      voxels are NOT counted.  The kernel itself fetches far less -- the frustum cull decides before fetching, roofline.frac_traffic
+      prices what the PMC counters saw)."""
     P = wl["w"] * wl["h"]
     E = 16
     if config == 2:
@@ -567,7 +569,7 @@ def read_roofline(config, wl, scene, counters, timer_every=1):
             if t:
                 traffic, traffic_src = t.get("hbm_bytes_per_launch"), t.get("source")
                 break
-    kname = {2: "raycast_kernel<VoxelS,hash>", 3: "integrate_dense_s_x4_kernel", 5: "integrate_hash_kernel<VoxelFRgb>"}[config]
+    kname = {2: "raycast_kernel<VoxelS,hash>", 3: "integrate_dense_strip_kernel", 5: "integrate_hash_kernel<VoxelFRgb>"}[config]
     return {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
             # the same fraction on the bytes the kernel really moved (PMC counters of a separate pass) instead of the reference algorithm's

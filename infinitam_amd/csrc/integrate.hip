@@ -14,6 +14,7 @@
 // frustum with two integer comparisons and writes only 128-bit groups that changed.  The depth map is small (1.2 MB) and stays in L2.
 #include <cmath>
 #include <cstring>
+#include <memory>
 
 #include "itm_internal.h"
 #include "range_device.h"
@@ -921,8 +922,10 @@ int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipS
   const bool colour = (s->cfg.voxelType == ITM_VOXEL_S_RGB || s->cfg.voxelType == ITM_VOXEL_F_RGB);
   if (colour && (!rgb || v->w_rgb <= 0 || v->h_rgb <= 0)) return set_error(ITM_ERR_INVALID, "colour voxels need an rgb image");
 
-  KernelTimer tk(s, ITM_TK_INTEGRATE, st);
+  // (the integration timer brackets the integration kernel alone; the small depth-tile launch of the dense path goes in front of it)
+  std::unique_ptr<KernelTimer> tk;
   if (s->cfg.indexType == ITM_INDEX_HASH) {
+    tk.reset(new KernelTimer(s, ITM_TK_INTEGRATE, st));
     // 2048 workgroups of 8 waves: more waves than the chip holds at once (768-1024 workgroups), so that the dispatcher evens out what
     // the static striding does not, but few enough that most waves have work -- a workgroup without any still holds a slot for ~1 us
     // (measured, configs[4] / configs[1]: 768-1024 workgroups 189 / 21.3 us, 1536: 177 / 19.9, 2048: 175 / 20.3, 4096: 170 / 20.4,
@@ -978,6 +981,7 @@ int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipS
           classify = g_debug_dense_classify == 2 ? 2 : g_debug_dense_classify == 3 ? 3 : 1;
         }
       }
+      tk.reset(new KernelTimer(s, ITM_TK_INTEGRATE, st));
 #define ITM_DENSE(P2, CU, CL) integrate_dense_s_x4_kernel<P2, CU, CL><<<grid, 256, 0, st>>>((uint4*)s->vba, v->depth, p, sz[0], sz[1], sz[2], of[0], of[1], of[2], lg, cc, gc)
       // the strip kernel: volumes whose rows are whole strips of 64 groups (debug key 17 keeps the launch shape of rounds 1-2)
       const bool strips = wantStrips && classify != 0;
@@ -995,6 +999,7 @@ int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipS
       else ITM_DENSE(false, 0, 0);
 #undef ITM_DENSE
     } else {
+      tk.reset(new KernelTimer(s, ITM_TK_INTEGRATE, st));
       int rc = dispatch_voxel(s->cfg.voxelType, [&](auto vx) {
         using VX = decltype(vx);
         integrate_dense_kernel<VX><<<256 * 32, 256, 0, st>>>(s->vba, v->depth, rgb, p, sz[0], sz[1], sz[2], of[0], of[1], of[2]);
