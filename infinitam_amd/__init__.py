@@ -19,7 +19,8 @@ _backend = None
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, LIB_NAME)
+    # ITM_LIB_OVERRIDE: a measurement build of the SAME library (tools/build_variant.sh) for A/B runs of bench.py and the tools
+    return os.environ.get("ITM_LIB_OVERRIDE") or os.path.join(_HERE, LIB_NAME)
 
 
 def build(verbose: bool = False) -> str:

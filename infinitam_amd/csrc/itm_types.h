@@ -227,9 +227,16 @@ struct AccelOrigin {
 
 // cube-relative block coordinates (each in [0, kDirSide) when the block is covered)
 __host__ __device__ inline bool dir_covers(uint32_t ux, uint32_t uy, uint32_t uz) { return ((ux | uy | uz) >> kDirBits) == 0u; }
+#ifndef ITM_DIR_LINEAR
+#define ITM_DIR_LINEAR 0
+#endif
 __host__ __device__ inline uint32_t dir_cell(uint32_t ux, uint32_t uy, uint32_t uz) {
+#if ITM_DIR_LINEAR
+  return (uz << (2 * kDirBits)) | (uy << kDirBits) | ux;
+#else
   const uint32_t brick = ((uz >> 2) << (2 * (kDirBits - 2))) | ((uy >> 2) << (kDirBits - 2)) | (ux >> 2);
   return (brick << 6) | ((uz & 3u) << 4) | ((uy & 3u) << 2) | (ux & 3u);
+#endif
 }
 // records an allocated block (device side; called by the allocation sweep and the rebuild kernel)
 // (dirSlot: the same cells holding the TABLE SLOT of the block instead of its voxel-block index -- what the allocation request
@@ -275,9 +282,19 @@ template <> struct MirrorCodec<false> {
   __device__ static T of(float rawSdf) { return __float_as_uint(rawSdf); }
 };
 __host__ __device__ inline bool mirror_covers(uint32_t ux, uint32_t uy, uint32_t uz) { return ((ux | uy | uz) >> kMirrorBits) == 0u; }
-__host__ __device__ inline uint32_t mirror_cell(uint32_t ux, uint32_t uy, uint32_t uz) {   // brick-major like the directory
+// plain x-fastest order of the blocks: a block's 512 values are a kilobyte of their own, so -- unlike the directory's 4-byte cells --
+// nothing is gained by keeping neighbouring blocks in one brick, and the brick-major index cost ~24 vector instructions of the ~90
+// a ray step issues (the march is bound by its instruction chain, profiles/r3_raycast_notes.md)
+#ifndef ITM_MIRROR_LINEAR
+#define ITM_MIRROR_LINEAR 1
+#endif
+__host__ __device__ inline uint32_t mirror_cell(uint32_t ux, uint32_t uy, uint32_t uz) {
+#if ITM_MIRROR_LINEAR
+  return (uz << (2 * kMirrorBits)) | (uy << kMirrorBits) | ux;
+#else
   const uint32_t brick = ((uz >> 2) << (2 * (kMirrorBits - 2))) | ((uy >> 2) << (kMirrorBits - 2)) | (ux >> 2);
   return (brick << 6) | ((uz & 3u) << 4) | ((uy & 3u) << 2) | (ux & 3u);
+#endif
 }
 // mirror index of the voxel at integer point (px, py, pz); false when its block lies outside the mirrored cube
 __host__ __device__ inline bool mirror_index(const AccelOrigin& org, int px, int py, int pz, size_t& idx) {
