@@ -287,7 +287,8 @@ int ITM_FN(process_frame)(itm_scene* scene, const itm_view* view, itm_render_sta
  * table as this frame's allocation leaves it -- ride in this frame's last launch, beside the ICP maps; the next frame then starts with
  * its visible-list launch (4 launches per frame instead of 5).  Results are identical to itm_process_frame, frame by frame.  Contract:
  * the next allocation on this render state (itm_process_frame[_ahead] or itm_allocate_scene_from_depth) must be for exactly that view
- * (same depth pointer, size, pose, intrinsics), else it returns ITM_ERR_INVALID. */
+ * (same depth pointer, size, pose, intrinsics), and the scene must not be reset or have its table uploaded in between, else that
+ * allocation returns ITM_ERR_INVALID (the render state's visible types then hold the marks of the abandoned requests: recreate it). */
 int ITM_FN(process_frame_ahead)(itm_scene* scene, const itm_view* view, const itm_view* next, itm_render_state* rs,
                                 float* points, float* normals, itm_stream stream);
 

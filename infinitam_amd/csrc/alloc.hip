@@ -565,6 +565,8 @@ int launch_request_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, 
     // the requests of this frame rode in the previous frame's last launch (itm_process_frame_ahead)
     if (onlyVisible || !same_view(rs, v))
       return set_error(ITM_ERR_INVALID, "the block requests of another view were issued ahead (itm_process_frame_ahead): the next allocation must be for that view");
+    if (rs->ahead.tableEpoch != s->tableEpoch)
+      return set_error(ITM_ERR_INVALID, "the scene was reset or its table replaced while the block requests of the next view were pending (itm_process_frame_ahead)");
     rs->ahead.valid = false;
     rs->lazyThisFrame = rs->ahead.lazy;
     return ITM_OK;

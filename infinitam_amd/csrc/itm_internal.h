@@ -88,6 +88,7 @@ struct itm_scene {
   // swapping (scenes with cfg.useSwapping; swapping.hip): ITMHashSwapState per entry on the device, the ITMGlobalCache in host memory
   uint8_t* swapStates = nullptr;           // uchar[noTotalEntries]
   struct SwapHost* swapHost = nullptr;
+  unsigned tableEpoch = 0;                 // bumped whenever the table is reset or replaced (requests issued ahead are then void)
   bool countedLive = false;       // this scene is in the per-device count of live hash scenes
   bool orgPlaced = false;         // false until the first frame (or an upload) has placed the cubes
   long long accelMoves = 0;       // times the cubes were re-placed (itm_scene_accel_info)
@@ -131,7 +132,7 @@ struct itm_render_state {
   hipEvent_t listReady = nullptr, projectionDone = nullptr;
   // itm_process_frame_ahead: the block requests of the NEXT frame were issued beside this frame's ICP maps; the next allocation
   // must be for exactly this view and skips its request launch
-  struct { bool valid = false; const float* depth = nullptr; int w = 0, h = 0; float M_d[16] = {}, intr_d[4] = {}; bool lazy = false; } ahead;
+  struct { bool valid = false; const float* depth = nullptr; int w = 0, h = 0; float M_d[16] = {}, intr_d[4] = {}; bool lazy = false; unsigned tableEpoch = 0; } ahead;
 };
 
 namespace itm {

@@ -571,6 +571,7 @@ int itm_reset_scene(itm_scene* s, itm_stream stream) {
     // the next frame places them around its camera
     { int rc = accel_unfill(s, st); if (rc) return rc; }
     s->orgPlaced = false;
+    ++s->tableEpoch;
     reset_hash_kernel<<<1024, 256, 0, st>>>(s->hash, s->noTotalEntries, s->excessList, s->cfg.excessNum, s->allocList,
                                             s->cfg.localBlockNum, s->allocKey, s->headBits, (s->cfg.bucketNum + 31) / 32, s->chunkReq, s->numChunks * 4, s->counters);
   } else {
@@ -738,7 +739,7 @@ int itm_upload(itm_scene* s, itm_render_state* rs, int which, const void* src, s
   size_t b; void* p = buffer_of(s, rs, which, &b);
   if (!p || !src || bytes > b) return set_error(ITM_ERR_INVALID, "bad buffer / size");
   hipStream_t st = as_stream(stream);
-  if (which == ITM_BUF_HASH_ENTRIES) { int rc = accel_unfill(s, st); if (rc) return rc; }      // while the table still holds what filled the cubes
+  if (which == ITM_BUF_HASH_ENTRIES) { int rc = accel_unfill(s, st); if (rc) return rc; ++s->tableEpoch; }      // while the table still holds what filled the cubes
   ITM_HIP(hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, st));
   if (which == ITM_BUF_HASH_ENTRIES) {
     if (bytes < b) {          // a partial upload: the rest of the table stays; place by the whole table as it now is

@@ -168,14 +168,16 @@ __global__ void __launch_bounds__(512) swap_combine_kernel(const int32_t* __rest
 template <class VX>
 __global__ void __launch_bounds__(512) swap_out_kernel(const int32_t* __restrict__ ids, void* __restrict__ xfer, uint4* __restrict__ hash, void* __restrict__ vba,
                                                        uint8_t* __restrict__ states, int32_t* __restrict__ allocList, const SceneCounters* __restrict__ counters,
-                                                       int bucketNum, int32_t* __restrict__ dirPtr, int32_t* __restrict__ dirSlot, void* __restrict__ mirror, AccelOrigin org) {
+                                                       int bucketNum, int localBlockNum, int32_t* __restrict__ dirPtr, int32_t* __restrict__ dirSlot, void* __restrict__ mirror, AccelOrigin org) {
   const int i = blockIdx.x, id = ids[i], t = threadIdx.x;
   const uint4 raw = hash[id];
   const HashEntry he = unpack_entry(raw);
   const size_t vi = (size_t)he.ptr * kBlockVoxels + t;
   VX::store(xfer, (size_t)i * kBlockVoxels + t, VX::load(vba, vi));
   const int vbaIdx = counters->lastFreeBlockId + i;
-  const bool release = vbaIdx < bucketNum - 1;
+  // (the second bound never binds in a consistent scene -- freed blocks were allocated before -- it keeps an uploaded, inconsistent
+  // counter from writing past the list, where the reference would)
+  const bool release = vbaIdx < bucketNum - 1 && vbaIdx + 1 < localBlockNum;
   if (release) {
     VX::store(vba, vi, VX::init());
     using MC = MirrorCodec<VX::kShort>;
@@ -192,9 +194,9 @@ __global__ void __launch_bounds__(512) swap_out_kernel(const int32_t* __restrict
     }
   }
 }
-__global__ void swap_out_commit_kernel(SceneCounters* __restrict__ counters, const int32_t* __restrict__ ids, int cap, int bucketNum) {
+__global__ void swap_out_commit_kernel(SceneCounters* __restrict__ counters, const int32_t* __restrict__ ids, int cap, int bucketNum, int localBlockNum) {
   const int L = counters->lastFreeBlockId, n = ids[cap];
-  int room = bucketNum - 1 - L;
+  int room = (bucketNum - 1 < localBlockNum - 1 ? bucketNum - 1 : localBlockNum - 1) - L;
   room = room < 0 ? 0 : room;
   counters->lastFreeBlockId = L + (n < room ? n : room);
 }
@@ -292,12 +294,12 @@ int itm_swap_save_to_global_memory(itm_scene* s, itm_render_state* rs, itm_strea
   if (n <= 0) return ITM_OK;
   int rc = dispatch_voxel(s->cfg.voxelType, [&](auto vx) {
     using VX = decltype(vx);
-    swap_out_kernel<VX><<<n, 512, 0, st>>>(h->xferIdsDev, h->xferBlocksDev, s->hash, s->vba, s->swapStates, s->allocList, s->counters, s->cfg.bucketNum,
+    swap_out_kernel<VX><<<n, 512, 0, st>>>(h->xferIdsDev, h->xferBlocksDev, s->hash, s->vba, s->swapStates, s->allocList, s->counters, s->cfg.bucketNum, s->cfg.localBlockNum,
                                            s->dirPtr, s->dirSlot, s->sdfMirror, s->org);
     return ITM_OK;
   });
   if (rc) return rc;
-  swap_out_commit_kernel<<<1, 1, 0, st>>>(s->counters, h->xferIdsDev, h->cap, s->cfg.bucketNum);
+  swap_out_commit_kernel<<<1, 1, 0, st>>>(s->counters, h->xferIdsDev, h->cap, s->cfg.bucketNum, s->cfg.localBlockNum);
   ITM_LAUNCH_CHECK();
   ITM_HIP(hipMemcpyAsync(h->xferBlocksHost, h->xferBlocksDev, (size_t)n * blockBytes, hipMemcpyDeviceToHost, st));
   ITM_HIP(hipStreamSynchronize(st));

@@ -537,6 +537,7 @@ int launch_icp_maps(const itm_scene* s, const itm_view* v, itm_render_state* rs,
   KernelTimer tk(s, ITM_TK_ICP_MAPS, st);
   if (issueAhead) {
     icp_maps_init_next_kernel<<<grid, 256, 0, st>>>(rs->raycast, points, normals, rs->image, p, rs->range, rs->counters);
+    rs->ahead.tableEpoch = sceneForNext->tableEpoch;
     rs->ahead.valid = true; rs->ahead.depth = next->depth; rs->ahead.w = next->w; rs->ahead.h = next->h; rs->ahead.lazy = true;
     memcpy(rs->ahead.M_d, next->M_d, 64); memcpy(rs->ahead.intr_d, next->intr_d, 16);
   } else {

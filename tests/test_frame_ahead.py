@@ -72,5 +72,8 @@ def test_a_frame_other_than_the_announced_one_is_refused(hip):
     with pytest.raises(capi.ItmError):
         ses.scene.process_frame(v[2], ses.rs, ses.points, ses.normals)           # not the announced view
     ses.scene.process_frame(v[1], ses.rs, ses.points, ses.normals)               # the announced one goes through
-    ses.scene.process_frame(v[2], ses.rs, ses.points, ses.normals)
+    ses.scene.process_frame_ahead(v[2], v[0], ses.rs, ses.points, ses.normals)
+    ses.scene.reco.ResetScene()                                                  # the table the requests were made against is gone
+    with pytest.raises(capi.ItmError):
+        ses.scene.process_frame(v[0], ses.rs, ses.points, ses.normals)
     ses.close()
