@@ -228,7 +228,8 @@ Stats g_stats;
 #define ITMO_PARALLEL_FOR
 #define ITMO_PARALLEL_FOR_STATIC
 #endif
-int* g_rayTrace = nullptr;  // optional per-ray (steps, band steps, not-found steps) dump, width in g_rayTraceW
+int* g_rayTrace = nullptr;  // optional per-ray census, 8 ints: steps, band (trilinear) steps, not-found steps, unit steps on a single-voxel value,
+                            // unit steps on a trilinear value, steps on a value of exactly 1, longest not-found run, steps after that run; width in g_rayTraceW
 int g_rayTraceW = 0;
 
 inline int floor_div8(int p) { return ((p < 0) ? p - 7 : p) / 8; }
@@ -843,22 +844,27 @@ bool cast_ray(V4f& out, int x, int y, const Reader<V>& rd, const float* invM, fl
   bool found;
   float step;
   long long steps = 0;
-  int bandSteps = 0, missSteps = 0;
+  int bandSteps = 0, missSteps = 0, unitNear = 0, unitBand = 0, farSteps = 0, missRun = 0, longestMissRun = 0, afterRun = 0;
   while (total < totalMax) {
     ++steps;
     sdf = rd.nearest(pt, found, cache);
     if (!found) {
       step = (float)ITM_SDF_BLOCK_SIZE; ++missSteps;
+      if (++missRun > longestMissRun) { longestMissRun = missRun; afterRun = 0; }
     } else {
-      if ((sdf <= 0.1f) && (sdf >= -0.5f)) { sdf = rd.trilinear(pt, found, cache); ++bandSteps; }
+      missRun = 0; ++afterRun;
+      bool band = false;
+      if (sdf == 1.0f) ++farSteps;
+      if ((sdf <= 0.1f) && (sdf >= -0.5f)) { sdf = rd.trilinear(pt, found, cache); ++bandSteps; band = true; }
       if (sdf <= 0.0f) break;
       step = fmax_ref(sdf * stepScale, 1.0f);
+      if (step == 1.0f) { if (band) ++unitBand; else ++unitNear; }
     }
     pt.x += step * dir.x; pt.y += step * dir.y; pt.z += step * dir.z;
     total += step;
   }
   ITMO_STAT(++g_stats.rays); ITMO_STAT(g_stats.ray_steps += steps);
-  if (g_rayTrace) { int* r = g_rayTrace + 3 * (x + y * g_rayTraceW); r[0] = (int)steps; r[1] = bandSteps; r[2] = missSteps; }
+  if (g_rayTrace) { int* r = g_rayTrace + 8 * (x + y * g_rayTraceW); r[0] = (int)steps; r[1] = bandSteps; r[2] = missSteps; r[3] = unitNear; r[4] = unitBand; r[5] = farSteps; r[6] = longestMissRun; r[7] = afterRun; }
   ITMO_STAT(g_stats.max_ray_steps = (steps > g_stats.max_ray_steps) ? steps : g_stats.max_ray_steps);
   bool hit;
   if (sdf <= 0.0f) {
