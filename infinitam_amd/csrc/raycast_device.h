@@ -7,6 +7,7 @@
 #pragma once
 
 #include "itm_types.h"
+#include <type_traits>
 
 #ifndef ITM_EXP_WAVE_TIMING
 #define ITM_EXP_WAVE_TIMING 0  // measurement build: per-wave cycle accounting of cast_ray (tools/wave_stats.py)
@@ -174,10 +175,28 @@ struct Corners {
         // outside the mirrored cube takes the general path as a whole: both give the same values)
         using MC = MirrorCodec<VX::kShort>;
         if (vol.sdfMirror) {
+#if ITM_MIRROR_LINEAR
+          // The eight mirror_index() values from ONE: with the blocks in plain x-fastest order the +1 neighbour along an axis is one
+          // voxel further inside the block, or -- from the block's last voxel -- the first voxel of the next block, a fixed distance
+          // either way.  (Taken when the blocks of (ix, iy, iz) and of (ix, iy, iz) + 8 per axis both lie in the cube: one block more than
+          // the neighbourhood needs at the cube's upper faces, where the general path gives the same values.)  ~35 vector instructions
+          // for the eight addresses instead of ~140 -- half of what a trilinear read issued.
+          const uint32_t mx = (uint32_t)((ix >> 3) - vol.org.mx), my = (uint32_t)((iy >> 3) - vol.org.my), mz = (uint32_t)((iz >> 3) - vol.org.mz);
+          const bool all = mirror_covers(mx, my, mz) && mirror_covers(mx + 1u, my + 1u, mz + 1u);
+          const int kx = ix & 7, ky = iy & 7, kz = iz & 7;
+          const size_t base = (size_t)mirror_cell(mx, my, mz) * 512u + (size_t)(kx + (ky << 3) + (kz << 6));
+          const uint32_t ox = (kx == 7) ? 512u - 7u : 1u;
+          const uint32_t oy = (ky == 7) ? (512u << kMirrorBits) - 56u : 8u;
+          const uint32_t oz = (kz == 7) ? (512u << (2 * kMirrorBits)) - 448u : 64u;
+          size_t mi[8];
+#pragma unroll
+          for (int c = 0; c < 8; ++c) mi[c] = base + (size_t)(((c & 1) ? ox : 0u) + ((c & 2) ? oy : 0u) + ((c & 4) ? oz : 0u));
+#else
           size_t mi[8];
           bool all = true;
 #pragma unroll
           for (int c = 0; c < 8; ++c) all &= mirror_index(vol.org, ix + (c & 1), iy + ((c >> 1) & 1), iz + (c >> 2), mi[c]);
+#endif
           if (__all(all)) {
             typename MC::T m[8];
 #pragma unroll
@@ -376,6 +395,24 @@ __device__ inline float4 cast_ray_plain(int x, int y, const VolumeView& vol, con
 #define ITM_RAY_PARKED_LOOKAHEAD 6   // directory cells fetched together per round trip by a parked ray's empty-space run (4: 55 us, 6: 53, 8: 53)
 #endif
 
+#ifndef ITM_RAY_PROBE_AT
+// phase 1: "not found" steps in a row after which a ray counts as inside a run for the wave-wide look-ahead (0 cells: never)
+#define ITM_RAY_PROBE_AT 2
+#endif
+#ifndef ITM_RAY_PROBE_CELLS
+#define ITM_RAY_PROBE_CELLS 10
+#endif
+
+#ifndef ITM_RAY_FLAT_STEP
+#define ITM_RAY_FLAT_STEP 1
+#endif
+#ifndef ITM_RAY_FAR_CELLS
+#define ITM_RAY_FAR_CELLS 0     // hash index with the mirror: positions a ray looks ahead after a single-voxel read of exactly 1 (0: never)
+#endif
+#ifndef ITM_RAY_FAR_ALL
+#define ITM_RAY_FAR_ALL 1       // 1: only when every marching lane of the wave has just read exactly 1; 0: when any has
+#endif
+
 #ifndef ITM_RAY_DENSE_LOOKAHEAD
 // Dense volumes: voxels fetched together by a ray that is crossing free space.  BASELINE configs[2] starts every ray 0.2 m in front
 // of the camera and the surface is 1.3-2.3 m away: ~65-115 steps of mu / voxelSize voxels through voxels that read exactly 1 (free
@@ -457,6 +494,70 @@ __device__ inline float4 march_ray(int x, int y, const VolumeView& vol, const Ra
     if (next != REFINE) { total += step; if (!(total < totalMax)) next = DONE; }
     return next;
   };
+  // One look-ahead round of an empty-space run (hash index with the block directory): the directory cells of the positions q0 = pt,
+  // q1 = pt + 8 dir, ... -- computed with the reference's own additions -- are fetched together (cell 0 / no use for lanes that are not
+  // runners) and the ray advances over as many of them as are empty, each the reference's step for a position without a block, with
+  // its length update and range test; it stops in front of the first position that holds a block (or lies outside the directory),
+  // which the regular loop then reads.  Returns the number of steps taken.
+  auto miss_run = [&](auto kc, bool runner) -> int {
+    constexpr int K = decltype(kc)::value;
+    const float sx = (float)kBlockSide * dx, sy = (float)kBlockSide * dy, sz = (float)kBlockSide * dz;   // exact products
+    int ahead[K];
+    {
+      float qx = px, qy = py, qz = pz;
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        const uint32_t ux = (uint32_t)(((int)round_ref(qx) >> 3) - vol.org.dx), uy = (uint32_t)(((int)round_ref(qy) >> 3) - vol.org.dy),
+                       uz = (uint32_t)(((int)round_ref(qz) >> 3) - vol.org.dz);
+        const bool use = runner && dir_covers(ux, uy, uz);
+        const int v = vol.dirPtr[use ? dir_cell(ux, uy, uz) : 0u];
+        ahead[j] = use ? v : 0;                               // 0 = "cannot tell / a block": stops the run
+        qx += sx; qy += sy; qz += sz;
+      }
+    }
+    int taken = 0;
+    if (runner) {
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        if (ahead[j] >= 0) break;                             // q_j holds a block (or lies outside the directory): regular read next
+        px += sx; py += sy; pz += sz; total += (float)kBlockSide;   // the reference's step for a position without a block
+        ++taken;
+        if (!(total < totalMax)) { st = DONE; break; }
+      }
+    }
+    return taken;
+  };
+  // One look-ahead round of a run through voxels that were allocated but never observed (hash index with the sdf mirror): a ray whose
+  // single-voxel read returned exactly 1 steps by max(1 * stepScale, 1) voxels; the mirror values of the next K positions -- each
+  // computed with the reference's own operations -- are fetched together and the ray advances over as many of them as read exactly 1.
+  auto far_run_mirror = [&](auto kc, bool runner) {
+    constexpr int K = decltype(kc)::value;
+    using MC = MirrorCodec<VX::kShort>;
+    const float one = 1.0f * stepScale;                       // sdf * stepScale with sdf == 1
+    const float step = (one < 1.0f) ? 1.0f : one;
+    const float sx = step * dx, sy = step * dy, sz = step * dz;
+    typename MC::T val[K];
+    bool ok[K];
+    {
+      float qx = px, qy = py, qz = pz;
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        size_t mi = 0;
+        const bool use = mirror_index(vol.org, (int)round_ref(qx), (int)round_ref(qy), (int)round_ref(qz), mi) && runner;
+        val[j] = ((const typename MC::T*)vol.sdfMirror)[use ? mi : (size_t)0];
+        ok[j] = use;
+        qx += sx; qy += sy; qz += sz;
+      }
+    }
+    if (runner) {
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        if (!ok[j] || MC::absent(val[j]) || VX::to_float(MC::raw(val[j])) != 1.0f) break;     // something else: regular read next
+        px += sx; py += sy; pz += sz; total += step;
+        if (!(total < totalMax)) { st = DONE; break; }
+      }
+    }
+  };
   ITM_WT(const unsigned long long wtStart = wt_clock(); unsigned wtOuter = 0;)
   bool missed = false;      // DENSE: the last single-voxel read found no voxel
   while (st != DONE) {
@@ -492,8 +593,24 @@ __device__ inline float4 march_ray(int x, int y, const VolumeView& vol, const Ra
       --budget;
       ITM_WT(++wtInner;)
       const float sdf = sdf_nearest<VX, DENSE>(vol, px, py, pz, found, cache);
+#if ITM_RAY_FLAT_STEP
+      {
+        // the step as selects rather than branches (the same operations on the same values as advance(); a lone wave pays every
+        // taken or skipped branch of a step with issue bubbles, profiles/r3_raycast_notes.md)
+        const bool band = found && (sdf <= 0.1f) && (sdf >= -0.5f);       // the position is kept for the trilinear read
+        const bool crossed = found && (sdf <= 0.0f);                      // (below the band) first refinement move, no length update
+        const float s = sdf * stepScale;
+        const float fwd = (s < 1.0f) ? 1.0f : s;
+        const float step = found ? (crossed ? s : fwd) : (float)kBlockSide;
+        const float nx = px + step * dx, ny = py + step * dy, nz = pz + step * dz, nt = total + step;
+        px = band ? px : nx; py = band ? py : ny; pz = band ? pz : nz;
+        total = (band || crossed) ? total : nt;
+        st = band ? TRI : crossed ? REFINE : (total < totalMax) ? MARCH : DONE;
+      }
+#else
       if (found && (sdf <= 0.1f) && (sdf >= -0.5f)) st = TRI;      // the position is kept for the trilinear read
       else st = advance(found, sdf);
+#endif
       if constexpr (DENSE) missed = !found;
       if constexpr (DENSE && LOOKAHEAD > 0) {
         const bool far = st == MARCH && found && sdf == 1.0f;      // SDF_valueToFloat(32767) is exactly 1
@@ -504,36 +621,26 @@ __device__ inline float4 march_ray(int x, int y, const VolumeView& vol, const Ra
         }
       }
       if constexpr (!DENSE && (PARK || LOOKAHEAD > 0)) missStreak = found ? 0 : missStreak + 1;
+      if constexpr (!DENSE && ITM_RAY_FAR_CELLS > 0) {
+        const bool far = st == MARCH && found && sdf == 1.0f;      // SDF_valueToFloat(32767) is exactly 1
+        if (vol.sdfMirror && (ITM_RAY_FAR_ALL ? (__all(st != MARCH || far) && __any(far)) : __any(far)))
+          far_run_mirror(std::integral_constant<int, (ITM_RAY_FAR_CELLS > 0 ? ITM_RAY_FAR_CELLS : 1)>(), far);
+      }
+      if constexpr (!DENSE && PARK && ITM_RAY_PROBE_CELLS > 0) {
+        // phase 1, once the wave has nothing left to march but rays inside "not found" runs (the other lanes are done or wait for their
+        // trilinear read): those rays look ITM_RAY_PROBE_CELLS positions ahead together, one round trip for the whole wave
+        const bool runner = st == MARCH && missStreak >= ITM_RAY_PROBE_AT;
+        if (vol.dirPtr && __all(st != MARCH || runner) && __any(runner)) {
+          const int adv = miss_run(std::integral_constant<int, ITM_RAY_PROBE_CELLS>(), runner);
+          if (runner) missStreak += adv;
+        }
+      }
       if constexpr (!DENSE && PARK) {
         if (st == MARCH && missStreak >= ITM_RAY_PARK_STREAK) { parked = true; st = DONE; }
       }
       if constexpr (!DENSE && LOOKAHEAD > 0) {
-        if (vol.dirPtr && __any(missStreak >= ITM_RAY_PARK_STREAK && st == MARCH)) {
-          // directory cells of the positions q0 = pt, q1 = pt + 8 dir, ... (cell 0 / no use for lanes that are not in an empty run)
-          const bool runner = missStreak >= ITM_RAY_PARK_STREAK && st == MARCH;
-          const float sx = (float)kBlockSide * dx, sy = (float)kBlockSide * dy, sz = (float)kBlockSide * dz;   // exact products
-          int ahead[LOOKAHEAD > 0 ? LOOKAHEAD : 1];
-          {
-            float qx = px, qy = py, qz = pz;
-#pragma unroll
-            for (int j = 0; j < LOOKAHEAD; ++j) {
-              const uint32_t ux = (uint32_t)(((int)round_ref(qx) >> 3) - vol.org.dx), uy = (uint32_t)(((int)round_ref(qy) >> 3) - vol.org.dy),
-                             uz = (uint32_t)(((int)round_ref(qz) >> 3) - vol.org.dz);
-              const bool use = runner && dir_covers(ux, uy, uz);
-              const int v = vol.dirPtr[use ? dir_cell(ux, uy, uz) : 0u];
-              ahead[j] = use ? v : 0;                               // 0 = "cannot tell / a block": stops the run
-              qx += sx; qy += sy; qz += sz;
-            }
-          }
-          if (runner) {
-#pragma unroll
-            for (int j = 0; j < LOOKAHEAD; ++j) {
-              if (ahead[j] >= 0) break;                             // q_j holds a block (or lies outside the directory): regular read next
-              px += sx; py += sy; pz += sz; total += (float)kBlockSide;   // the reference's step for a position without a block
-              if (!(total < totalMax)) { st = DONE; break; }
-            }
-          }
-        }
+        if (vol.dirPtr && __any(missStreak >= ITM_RAY_PARK_STREAK && st == MARCH))
+          (void)miss_run(std::integral_constant<int, (LOOKAHEAD > 0 ? LOOKAHEAD : 1)>(), missStreak >= ITM_RAY_PARK_STREAK && st == MARCH);
       }
     }
     ITM_WT(const unsigned long long wtA = wt_clock(); const unsigned wtTriLanes = __popcll(__ballot(st == TRI || st == REFINE)); wtInner = (unsigned)wt_wave_max(wtInner);)

@@ -10,5 +10,5 @@ ITM_LIB_OVERRIDE=$PWD/gpurun_variants/lib_$V.so $B > $O/bench_${V}_$rep.json 2>$
 done
 done
 python bench.py --config 5 --no-cpu-baseline --no-extra-legs > $O/bench_c5_new.json 2>$O/e.err
-ITM_LIB_OVERRIDE=$PWD/gpurun_variants/lib_noprobe.so python bench.py --config 5 --no-cpu-baseline --no-extra-legs > $O/bench_c5_noprobe.json 2>$O/e.err
+ITM_LIB_OVERRIDE=$PWD/gpurun_variants/lib_nofar.so python bench.py --config 5 --no-cpu-baseline --no-extra-legs > $O/bench_c5_nofar.json 2>$O/e.err
 for f in $O/bench_*.json; do echo "$f $(python -c "import json,sys; d=json.load(open('$f')); print(d['value'], d['ms_per_step'], (d.get('roofline') or {}).get('avg_kernel_us'))" 2>&1 | tail -1)"; done
