@@ -76,6 +76,7 @@ def parse():
                     help="feed the k streams of --streams-per-gpu from one host thread instead of one thread per stream")
     ap.add_argument("--timer-every", type=int, default=8,
                     help="bracket the roofline kernel with HIP events on every n-th frame of the timed region")
+    ap.add_argument("--raw-serial", action="store_true", help="raw-depth legs: the upload on the frame's own stream instead of the library's stager (A/B)")
     ap.add_argument("--raw-depth", action="store_true",
                     help="SURVEY 8d second figure as the run's value: each step uploads the 16-bit raw frame from pinned host memory "
                          "(w*h*2 bytes over PCIe) and converts it with itm_update_view inside the timed region (never the headline)")
@@ -143,7 +144,7 @@ class Stream:
     def __init__(self, be, capi, synth, torch, wl, stream_id, device, hip_stream, offset=(0.0, 0.0, 0.0), raw=False):
         import numpy as np
         w, h = wl["w"], wl["h"]
-        self.w, self.h, self.torch = w, h, torch
+        self.w, self.h, self.torch, self.be = w, h, torch, be
         vox = {"s": capi.VOXEL_S, "f_rgb": capi.VOXEL_F_RGB}[wl["voxel"]]
         idx = capi.INDEX_HASH if wl["index"] == "hash" else capi.INDEX_DENSE
         params = capi.default_params(voxelSize=wl["voxelSize"], mu=wl["mu"], stopIntegratingAtMaxW=wl["stopAtMax"])
@@ -186,7 +187,15 @@ class Stream:
         self.raw_host = torch.from_numpy(raws)
         if self.device != "cpu":
             self.raw_host = self.raw_host.pin_memory()
-        self.raw_dev = torch.empty((2, h, w), dtype=torch.int16, device=self.device)      # two upload slots
+        self.raw_ptrs = [self.raw_host[i].data_ptr() for i in range(self.nd)]
+        self.raw_dev = torch.empty((2, h, w), dtype=torch.int16, device=self.device)      # two upload slots (CPU shims; --raw-serial)
+        # the product uploads through the library's stager: a copy stream of its own, one frame ahead of the frame being fused
+        self.stager, self.staged = None, -1
+        if self.device != "cpu" and "depth_stager_create" in self.be.fn and self.be.prefix == "itm_":
+            g = C.c_void_p()
+            self.ahead = max(1, int(os.environ.get("ITM_BENCH_RAW_AHEAD", "1")))
+            self.be.check(self.be.fn["depth_stager_create"](w, h, self.ahead + 2, C.byref(g)), "depth_stager_create")
+            self.stager = g
         self.depth_conv = torch.empty((h, w), dtype=torch.float32, device=self.device)
         self.scratch = torch.empty((h, w), dtype=torch.float32, device=self.device)
         self.raw_views = [self.capi.View(self.depth_conv.data_ptr(), w, h, M_d=self.poses[i], intr_d=self.intr,
@@ -324,18 +333,33 @@ def worker(args) -> int:
         i = k % s.nd
         if mode["raw"]:
             # the frame as the sensor delivers it: 16-bit raw over PCIe from pinned memory, convertDepthAffineToFloat on the device,
-            # all on the frame's stream (two upload slots: the copy of frame k+1 may not overtake the conversion of frame k-1 -- it
-            # cannot, one stream -- the second slot only keeps the copy engine's writes away from the conversion's reads)
-            slot = s.raw_dev[k & 1]
-            if on_gpu:
-                with torch.cuda.stream(s.hip_stream):
-                    slot.copy_(s.raw_host[i], non_blocking=True)
+            # the upload through the library's stager (copy stream, one frame ahead); conversion and fusion on the frame's stream
+            raw_ptr = None
+            if s.stager is not None and not args.raw_serial:
+                def upload(step):
+                    be.check(be.fn["depth_stager_upload"](s.stager, C.c_void_p(s.raw_ptrs[step % s.nd])), "depth_stager_upload")
+                    s.staged = step
+                if s.staged < k or s.staged > k + s.ahead:
+                    s.staged = k - 1                # first frame of a leg (nothing of it is in flight)
+                while s.staged < k + (0 if last else s.ahead):
+                    upload(s.staged + 1)            # the next frames travel while this one is fused
+                dev = C.c_void_p()
+                be.check(be.fn["depth_stager_acquire"](s.stager, s.sp, C.byref(dev)), "depth_stager_acquire")
+                raw_ptr = dev
             else:
-                slot.copy_(s.raw_host[i])
-            rc = fn_view(C.c_void_p(slot.data_ptr()), s.w, s.h, 1, 0.001, 0.0, s.intr_c, 0, 0, C.c_void_p(s.depth_conv.data_ptr()),
+                slot = s.raw_dev[k & 1]
+                if on_gpu:
+                    with torch.cuda.stream(s.hip_stream):
+                        slot.copy_(s.raw_host[i], non_blocking=True)
+                else:
+                    slot.copy_(s.raw_host[i])
+                raw_ptr = C.c_void_p(slot.data_ptr())
+            rc = fn_view(raw_ptr, s.w, s.h, 1, 0.001, 0.0, s.intr_c, 0, 0, C.c_void_p(s.depth_conv.data_ptr()),
                          C.c_void_p(s.scratch.data_ptr()), None, None, s.sp)
             if rc:
                 be.check(rc, "update_view")
+            if s.stager is not None and not args.raw_serial:
+                be.check(be.fn["depth_stager_release"](s.stager, s.sp), "depth_stager_release")      # (the conversion is what read the slot)
             rc = fn(s.sh, C.byref(s.raw_views[i]), s.rh, s.pp, s.np_, s.sp)
         elif fn_ahead is not None:
             # the last frame of a run() names no successor: the next leg may start anywhere
@@ -448,7 +472,7 @@ def worker(args) -> int:
         dt = time.perf_counter() - t1
         mode["raw"] = False
         extra["with_h2d_raw_depth"] = {"value": round(n2 / dt, 2), "unit": "frames/s", "steps": n2,
-                                       "what": f"per frame {wl['w'] * wl['h'] * 2} bytes of raw short depth from pinned host memory over PCIe + itm_update_view (affine conversion) + the same fused frame"}
+                                       "what": f"per frame {wl['w'] * wl['h'] * 2} bytes of raw short depth from pinned host memory over PCIe (itm_depth_stager: a copy stream, one frame ahead) + itm_update_view (affine conversion) + the same fused frame"}
         # (2) the same roofline kernel when the acceleration structures (block directory, sdf mirror) do not answer -- blocks whose
         #     cells are owned by other blocks, or a device without room for them -- i.e. on the reference's own table walk
         if wl["index"] == "hash":

@@ -317,6 +317,20 @@ int ITM_FN(update_view)(const int16_t* raw, int w, int h, int calibType, float c
                         int useBilateralFilter, int modelSensorNoise, float* depth_out, float* scratch,
                         float* normals, float* sigmaZ, itm_stream stream);
 
+/* ---- raw frames from the host: the first statement of ITMViewBuilder_CUDA::UpdateView, shortImage->SetFrom(rawDepthImage, CPU_TO_CUDA)
+ * (Engine/DeviceSpecific/CUDA/ITMViewBuilder_CUDA.cu:53), a synchronous copy there.  A stager owns `slots` device images of w x h
+ * shorts and a copy stream: itm_depth_stager_upload puts a frame (PINNED host memory) on the copy stream and returns at once -- up to
+ * slots - 1 frames ahead of the one being fused --, itm_depth_stager_acquire makes the frame's stream wait for the OLDEST uploaded frame
+ * and returns its device image (the `raw` argument of itm_update_view), itm_depth_stager_release says that everything submitted to
+ * that stream so far is what read it: the slot is overwritten only behind that work.  One acquire / release pair at a time, frames leave
+ * in the order they were uploaded.  Host-side object, not thread safe. */
+typedef struct itm_depth_stager itm_depth_stager;
+int ITM_FN(depth_stager_create)(int w, int h, int slots, itm_depth_stager** out);
+int ITM_FN(depth_stager_destroy)(itm_depth_stager* g);
+int ITM_FN(depth_stager_upload)(itm_depth_stager* g, const int16_t* pinned_host);
+int ITM_FN(depth_stager_acquire)(itm_depth_stager* g, itm_stream stream, const int16_t** device_image);
+int ITM_FN(depth_stager_release)(itm_depth_stager* g, itm_stream stream);
+
 /* ---- on-disk input formats of the view builder's sources (host memory, no device work) -------------------------
  * Depth: PGM "P5" (or ASCII "P2") with maxval > 256: 16-bit samples stored BIG-endian, swapped on load
  * (Utils/FileUtils.cpp:377-421); colour: PPM "P6" / "P3" -> RGBA with alpha 255 (:324-375); writers :251-322

@@ -232,6 +232,11 @@ _HOST_IO_SIGS = {
     "swap_save_to_global_memory": (C.c_int, [_P, _P, _P]),
     "global_cache_get": (C.c_int, [_P, C.c_int, _P, C.POINTER(C.c_int)]),
     "global_cache_flags": (C.c_int, [_P, _P, C.c_size_t]),
+    "depth_stager_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "depth_stager_destroy": (C.c_int, [_P]),
+    "depth_stager_upload": (C.c_int, [_P, _P]),
+    "depth_stager_acquire": (C.c_int, [_P, _P, C.POINTER(_P)]),
+    "depth_stager_release": (C.c_int, [_P, _P]),
     "stream_create": (C.c_int, [C.POINTER(_P)]),
     "stream_destroy": (C.c_int, [_P]),
     # multi-stream exchange issued from the library (RCCL); the CPU shims exchange through torch.distributed (streams.py)

@@ -7,6 +7,11 @@
 // Arithmetic follows the reference operation for operation (no contraction); the only non-IEEE functions are
 // exp (filter weights) and acos (uncertainty), for which the device library and the host libm may differ in the last
 // place -- parity tolerance 1e-6 relative for the filtered depth, exact for everything else that does not depend on them.
+#include <atomic>
+#include <memory>
+#include <new>
+#include <vector>
+
 #include "itm_internal.h"
 
 namespace itm {
@@ -138,6 +143,119 @@ int itm_update_view(const int16_t* raw, int w, int h, int calibType, float c0, f
     ITM_HIP(hipMemcpyAsync(depth_out, scratch, (size_t)w * h * 4, hipMemcpyDeviceToDevice, as_stream(stream)));
   }
   if (modelSensorNoise) return itm_compute_normal_and_weights(depth_out, normals, sigmaZ, w, h, intr_d, stream);
+  return ITM_OK;
+}
+
+}  // extern "C"
+namespace itm {
+__global__ void __launch_bounds__(256) stage_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+}  // namespace itm
+extern "C" {
+
+// ---- raw frames from the host --------------------------------------------------------------------------------------------------
+// The reference's UpdateView starts with a synchronous copy of the raw image to the device (shortImage->SetFrom(rawDepthImage,
+// CPU_TO_CUDA), DeviceSpecific/CUDA/ITMViewBuilder_CUDA.cu:53).  Here the uploads ride on a stream of their own, up to slots - 1
+// frames ahead of the frame being fused, into a ring of device buffers; events tie the two streams together both ways: a slot is handed
+// to the frame's stream only behind its copy, and overwritten only behind the work that read it.
+struct itm_depth_stager {
+  int w = 0, h = 0, slots = 0;
+  int device = 0;
+  hipStream_t copy = nullptr;
+  std::vector<int16_t*> buf;
+  std::vector<hipEvent_t> uploaded, consumed;
+  // one thread may upload while another acquires / releases (a producer beside the frame loop): the counters both sides read are atomic
+  std::unique_ptr<std::atomic<char>[]> consumedRecorded;
+  std::atomic<unsigned long long> head{0}, tail{0};      // frames released / uploaded so far
+  bool held = false;                          // a frame has been acquired and not yet released (consumer side only)
+};
+
+static void free_stager(itm_depth_stager* g) {
+  if (!g) return;
+  if (g->copy) { (void)hipStreamSynchronize(g->copy); (void)hipStreamDestroy(g->copy); }
+  for (auto e : g->uploaded) if (e) (void)hipEventDestroy(e);
+  for (auto e : g->consumed) if (e) (void)hipEventDestroy(e);
+  for (auto b : g->buf) if (b) (void)hipFree(b);
+  delete g;
+}
+
+int itm_depth_stager_create(int w, int h, int slots, itm_depth_stager** out) {
+  if (!out || w <= 0 || h <= 0 || slots < 2 || slots > 64) return set_error(ITM_ERR_INVALID, "bad argument");
+  itm_depth_stager* g = new (std::nothrow) itm_depth_stager();
+  if (!g) return set_error(ITM_ERR_DEVICE, "out of host memory");
+  g->w = w; g->h = h; g->slots = slots;
+  g->buf.assign(slots, nullptr); g->uploaded.assign(slots, nullptr); g->consumed.assign(slots, nullptr);
+  g->consumedRecorded.reset(new (std::nothrow) std::atomic<char>[slots]);
+  if (!g->consumedRecorded) { delete g; return set_error(ITM_ERR_DEVICE, "out of host memory"); }
+  for (int i = 0; i < slots; ++i) g->consumedRecorded[i].store(0);
+  hipError_t e = hipGetDevice(&g->device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->copy, hipStreamNonBlocking);
+  for (int i = 0; i < slots && e == hipSuccess; ++i) {
+    e = hipMalloc((void**)&g->buf[i], (size_t)w * h * sizeof(int16_t));
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&g->uploaded[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&g->consumed[i], hipEventDisableTiming);
+  }
+  if (e != hipSuccess) { free_stager(g); return hip_fail(e, "depth stager", __FILE__, __LINE__); }
+  *out = g;
+  return ITM_OK;
+}
+
+int itm_depth_stager_destroy(itm_depth_stager* g) { free_stager(g); return ITM_OK; }
+
+int itm_depth_stager_upload(itm_depth_stager* g, const int16_t* host) {
+  if (!g || !host) return set_error(ITM_ERR_INVALID, "null argument");
+  const unsigned long long tail = g->tail.load(std::memory_order_relaxed);
+  if (tail - g->head.load(std::memory_order_acquire) >= (unsigned long long)g->slots) return set_error(ITM_ERR_INVALID, "every slot of the stager holds a frame that has not been released");
+  const int b = (int)(tail % (unsigned long long)g->slots);
+  if (g->consumedRecorded[b].load(std::memory_order_acquire)) {
+    // the work that read the slot's previous frame: with the uploads a frame or two ahead it finished long ago, and a wait the copy
+    // stream need not make is worth avoiding (a copy queued behind another queue's event costs the CALL ~100 us on this runtime)
+    const hipError_t q = hipEventQuery(g->consumed[b]);
+    if (q == hipErrorNotReady) ITM_HIP(hipStreamWaitEvent(g->copy, g->consumed[b], 0));
+    else if (q != hipSuccess) return hip_fail(q, "hipEventQuery(slot consumed)", __FILE__, __LINE__);
+    else g->consumedRecorded[b].store(0, std::memory_order_relaxed);
+  }
+  // Pinned host memory is mapped into the device's address space: a kernel on the copy stream reads the frame over PCIe itself.  (The
+  // runtime's own asynchronous copy goes through the SDMA engine on a stream that runs nothing else -- measured on this box: ~100 us
+  // per 600 KB frame, in the CALL when the queue is full -- and through a blit kernel only on a stream that is busy with kernels.)
+  const size_t bytes = (size_t)g->w * g->h * sizeof(int16_t);
+  void* mapped = nullptr;
+  if (hipHostGetDevicePointer(&mapped, (void*)host, 0) == hipSuccess && mapped && (bytes % 16) == 0 && ((uintptr_t)mapped % 16) == 0) {
+    const size_t n = bytes / 16;
+    stage_copy_kernel<<<(unsigned)((n + 255) / 256), 256, 0, g->copy>>>((const uint4*)mapped, (uint4*)g->buf[b], n);
+    ITM_LAUNCH_CHECK();
+  } else {
+    (void)hipGetLastError();                  // pageable memory: the runtime's staged copy
+    ITM_HIP(hipMemcpyAsync(g->buf[b], host, bytes, hipMemcpyHostToDevice, g->copy));
+  }
+  ITM_HIP(hipEventRecord(g->uploaded[b], g->copy));
+  g->tail.store(tail + 1, std::memory_order_release);
+  return ITM_OK;
+}
+
+int itm_depth_stager_acquire(itm_depth_stager* g, itm_stream stream, const int16_t** dev) {
+  if (!g || !dev) return set_error(ITM_ERR_INVALID, "null argument");
+  if (g->held) return set_error(ITM_ERR_INVALID, "the previous frame has not been released");
+  const unsigned long long head = g->head.load(std::memory_order_relaxed);
+  if (head == g->tail.load(std::memory_order_acquire)) return set_error(ITM_ERR_INVALID, "no uploaded frame is waiting");
+  const int b = (int)(head % (unsigned long long)g->slots);
+  ITM_HIP(hipStreamWaitEvent(as_stream(stream), g->uploaded[b], 0));
+  *dev = g->buf[b];
+  g->held = true;
+  return ITM_OK;
+}
+
+int itm_depth_stager_release(itm_depth_stager* g, itm_stream stream) {
+  if (!g) return set_error(ITM_ERR_INVALID, "null argument");
+  if (!g->held) return set_error(ITM_ERR_INVALID, "no frame is held");
+  const unsigned long long head = g->head.load(std::memory_order_relaxed);
+  const int b = (int)(head % (unsigned long long)g->slots);
+  ITM_HIP(hipEventRecord(g->consumed[b], as_stream(stream)));
+  g->consumedRecorded[b].store(1, std::memory_order_release);
+  g->held = false;
+  g->head.store(head + 1, std::memory_order_release);
   return ITM_OK;
 }
 
