@@ -160,6 +160,9 @@ size_t ITM_FN(voxel_size_bytes)(int voxelType);
 /* ---- device memory helpers (so a C / ctypes caller needs no other runtime) ---------------- */
 int ITM_FN(dev_malloc)(void** ptr, size_t bytes);
 int ITM_FN(dev_free)(void* ptr);
+/* page-locked host memory (hipHostMalloc): the source of asynchronous uploads, see itm_depth_stager */
+int ITM_FN(host_malloc)(void** ptr, size_t bytes);
+int ITM_FN(host_free)(void* ptr);
 int ITM_FN(memcpy_h2d)(void* dst_dev, const void* src_host, size_t bytes, itm_stream stream);
 int ITM_FN(memcpy_d2h)(void* dst_host, const void* src_dev, size_t bytes, itm_stream stream);
 int ITM_FN(stream_synchronize)(itm_stream stream);

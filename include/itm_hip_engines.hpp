@@ -298,6 +298,30 @@ class ITMViewBuilder_HIP {
                           modelSensorNoise ? 1 : 0, depth, scratch, depthNormal, depthUncertainty, stream), "UpdateView");
     view->depth = depth;
   }
+  // The reference's UpdateView takes HOST images and opens with a synchronous copy (shortImage->SetFrom(rawDepthImage, CPU_TO_CUDA),
+  // DeviceSpecific/CUDA/ITMViewBuilder_CUDA.cu:53).  Here a raw frame in pinned host memory travels on the stager's copy stream;
+  // Prefetch(next frame) while the current one is fused hides the transfer altogether.
+  void Prefetch(const int16_t* rawDepthHost, Vector2i size) {
+    if (!stager) check(itm_depth_stager_create(size.x, size.y, 3, &stager), "depth stager");
+    check(itm_depth_stager_upload(stager, rawDepthHost), "Prefetch");
+    prefetched = rawDepthHost;
+  }
+  void UpdateViewFromHost(ITMView* view, const int16_t* rawDepthHost, float* depth, float* scratch, bool useBilateralFilter,
+                          bool modelSensorNoise = false, float* depthNormal = nullptr, float* depthUncertainty = nullptr) {
+    if (prefetched != rawDepthHost) Prefetch(rawDepthHost, view->depthSize);
+    prefetched = nullptr;
+    const int16_t* raw = nullptr;
+    check(itm_depth_stager_acquire(stager, stream, &raw), "UpdateView (acquire)");
+    UpdateView(view, raw, depth, scratch, useBilateralFilter, modelSensorNoise, depthNormal, depthUncertainty);
+    check(itm_depth_stager_release(stager, stream), "UpdateView (release)");
+  }
+  ~ITMViewBuilder_HIP() { if (stager) itm_depth_stager_destroy(stager); }
+  ITMViewBuilder_HIP(const ITMViewBuilder_HIP&) = delete;
+  ITMViewBuilder_HIP& operator=(const ITMViewBuilder_HIP&) = delete;
+
+ private:
+  itm_depth_stager* stager = nullptr;
+  const int16_t* prefetched = nullptr;
 };
 
 // ITMDepthTracker (Engine/ITMDepthTracker.h): TrackCamera refines trackingState->pose_d against the ICP maps
@@ -464,6 +488,20 @@ class ITMMainEngine_HIP {
     view.rgb = rgbImage;
     viewBuilder->UpdateView(&view, rawDepthImage, (float*)depthBuf, (float*)scratchBuf, settings.useBilateralFilter, settings.modelSensorNoise,
                             (float*)normalBuf, (float*)sigmaBuf);
+    ProcessView();
+  }
+  // The reference's own signature takes the raw frame in HOST memory (Engine/ITMMainEngine.cpp:111): rawDepthHost in page-locked memory
+  // (itm_host_malloc); nextRawDepthHost, when the image source already has it, is uploaded while this frame is tracked and fused.
+  void ProcessFrameFromHost(const uint8_t* rgbImage, const int16_t* rawDepthHost, const int16_t* nextRawDepthHost = nullptr) {
+    view.rgb = rgbImage;
+    viewBuilder->UpdateViewFromHost(&view, rawDepthHost, (float*)depthBuf, (float*)scratchBuf, settings.useBilateralFilter, settings.modelSensorNoise,
+                                    (float*)normalBuf, (float*)sigmaBuf);
+    if (nextRawDepthHost) viewBuilder->Prefetch(nextRawDepthHost, view.depthSize);
+    ProcessView();
+  }
+
+ private:
+  void ProcessView() {
     if (!mainProcessingActive) return;
     // tracking
     trackingController->Track(&trackingState, &view);
@@ -472,6 +510,8 @@ class ITMMainEngine_HIP {
     // raycast to renderState_live for tracking and free visualisation
     trackingController->Prepare(&trackingState, &view, renderState_live);
   }
+
+ public:
   void turnOnIntegration() { fusionActive = true; }
   void turnOffIntegration() { fusionActive = false; }
   void turnOnMainProcessing() { mainProcessingActive = true; }

@@ -232,6 +232,8 @@ _HOST_IO_SIGS = {
     "swap_save_to_global_memory": (C.c_int, [_P, _P, _P]),
     "global_cache_get": (C.c_int, [_P, C.c_int, _P, C.POINTER(C.c_int)]),
     "global_cache_flags": (C.c_int, [_P, _P, C.c_size_t]),
+    "host_malloc": (C.c_int, [C.POINTER(_P), C.c_size_t]),
+    "host_free": (C.c_int, [_P]),
     "depth_stager_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "depth_stager_destroy": (C.c_int, [_P]),
     "depth_stager_upload": (C.c_int, [_P, _P]),

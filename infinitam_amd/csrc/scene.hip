@@ -418,6 +418,13 @@ int itm_dev_malloc(void** p, size_t n) {
   return ITM_OK;
 }
 int itm_dev_free(void* p) { ITM_HIP(hipFree(p)); return ITM_OK; }
+// page-locked host memory, mapped into the device's address space: what asynchronous uploads (itm_depth_stager) need
+int itm_host_malloc(void** p, size_t n) {
+  if (!p) return set_error(ITM_ERR_INVALID, "null pointer");
+  ITM_HIP(hipHostMalloc(p, n ? n : 1, hipHostMallocDefault));
+  return ITM_OK;
+}
+int itm_host_free(void* p) { ITM_HIP(hipHostFree(p)); return ITM_OK; }
 int itm_memcpy_h2d(void* d, const void* s, size_t n, itm_stream st) {
   ITM_HIP(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, as_stream(st)));
   return ITM_OK;

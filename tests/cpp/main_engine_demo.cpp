@@ -5,6 +5,8 @@
 // the same sequence run on the reference's objects.
 //   main_engine_demo <sequence file>          parity run
 //   main_engine_demo --bench <frames>         closed tracking + mapping loop on the 640x480 bench scene, frames/s
+//   main_engine_demo --bench-host <frames>    the same with every raw frame arriving from page-locked host memory (ProcessFrameFromHost,
+//                                             the next frame uploaded while the current one is tracked and fused)
 // sequence file: int32 {w, h, n, trackerType, useApproximateRaycast, skipPoints, hasPoses}, float intr[4], int16 raw[n*h*w],
 //                float poses[n*16] (if hasPoses), uint8 fusion[n], uint8 mainProcessing[n]
 #include <chrono>
@@ -35,7 +37,7 @@ static ITMLibSettings settings_for(int trackerType, bool approx, bool skip) {
   return st;
 }
 
-static int bench(int frames) {
+static int bench(int frames, bool fromHost) {
   // the bench scene: sphere of radius 0.5 m at (0, 0, 1.5) in front of a wall at 2.5 m, triangle-wave trajectory
   const int W = 640, H = 480, P = W * H, distinct = 100;
   std::vector<int16_t> raw((size_t)distinct * P);
@@ -56,23 +58,31 @@ static int bench(int frames) {
   ITMSceneParams params(0.02f, 100, 0.004f, 0.35f, 3.0f, false);
   ITMRGBDCalib calib;
   ITMMainEngine_HIP<V, I> engine(st, params, calib, Vector2i{W, H}, Vector2i{W, H}, 1, 0.001f, 0.0f, 0x40000);
-  for (int k = 0; k < 5; ++k) engine.ProcessFrame(nullptr, (const int16_t*)dRaw + (size_t)(k % distinct) * P);
+  void* hRaw = nullptr;
+  if (fromHost) { check(itm_host_malloc(&hRaw, raw.size() * 2), "host malloc"); memcpy(hRaw, raw.data(), raw.size() * 2); }
+  auto frame = [&](int k, bool more) {
+    if (!fromHost) { engine.ProcessFrame(nullptr, (const int16_t*)dRaw + (size_t)(k % distinct) * P); return; }
+    engine.ProcessFrameFromHost(nullptr, (const int16_t*)hRaw + (size_t)(k % distinct) * P, more ? (const int16_t*)hRaw + (size_t)((k + 1) % distinct) * P : nullptr);
+  };
+  for (int k = 0; k < 5; ++k) frame(k, true);
   check(itm_stream_synchronize(nullptr), "sync");
   const auto t0 = std::chrono::steady_clock::now();
-  for (int k = 5; k < 5 + frames; ++k) engine.ProcessFrame(nullptr, (const int16_t*)dRaw + (size_t)(k % distinct) * P);
+  for (int k = 5; k < 5 + frames; ++k) frame(k, k + 1 < 5 + frames);
   check(itm_stream_synchronize(nullptr), "sync");
   const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   const float* M = engine.GetTrackingState()->pose_d.GetM();
   const int last = 4 + frames;
   const float ex = -0.004f * (float)tri(last), ey = -0.002f * (float)tri(2 * last);
-  printf("{\"frames\": %d, \"fps\": %.1f, \"ms_per_frame\": %.4f, \"final_translation_error_m\": %.5f}\n", frames, frames / dt, 1e3 * dt / frames,
+  printf("{\"frames\": %d, \"raw_frames_from\": \"%s\", \"pose\": [%.9g, %.9g, %.9g], \"fps\": %.1f, \"ms_per_frame\": %.4f, \"final_translation_error_m\": %.5f}\n", frames, fromHost ? "pinned host memory (stager)" : "device memory", M[12], M[13], M[14], frames / dt, 1e3 * dt / frames,
          std::fmax(std::fabs(M[12] - ex), std::fmax(std::fabs(M[13] - ey), std::fabs(M[14]))));
   itm_dev_free(dRaw);
+  if (hRaw) itm_host_free(hRaw);
   return 0;
 }
 
 int main(int argc, char** argv) {
-  if (argc >= 3 && !strcmp(argv[1], "--bench")) return bench(atoi(argv[2]));
+  if (argc >= 3 && !strcmp(argv[1], "--bench")) return bench(atoi(argv[2]), false);
+  if (argc >= 3 && !strcmp(argv[1], "--bench-host")) return bench(atoi(argv[2]), true);
   if (argc < 2) { fprintf(stderr, "usage: %s <sequence file> | --bench <frames>\n", argv[0]); return 2; }
   FILE* f = fopen(argv[1], "rb");
   if (!f) { perror(argv[1]); return 2; }

@@ -122,3 +122,19 @@ def test_main_engine_on_hip_equals_the_reference_objects(kind, tmp_path):
         else:
             assert np.array_equal(gp, wp), g["k"]
             assert g["digest"] == w["digest"], (kind, g["k"], g["digest"], w["digest"])
+
+
+@pytest.mark.gpu
+def test_frames_from_pinned_host_memory_give_the_frames_from_device_memory():
+    """ITMMainEngine_HIP::ProcessFrameFromHost -- the reference's signature takes host images (Engine/ITMMainEngine.cpp:111) and its view
+    builder copies them synchronously (ITMViewBuilder_CUDA.cu:53); here they travel on the stager's copy stream, the next frame while
+    the current one is tracked and fused -- must end where ProcessFrame ends on the same frames resident in device memory."""
+    build_demo()
+    out = {}
+    for mode in ("--bench", "--bench-host"):
+        r = subprocess.run([EXE, mode, "40"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[mode] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["--bench-host"]["raw_frames_from"].startswith("pinned host")
+    assert out["--bench"]["pose"] == out["--bench-host"]["pose"], out
+    assert out["--bench"]["final_translation_error_m"] < 2e-3
