@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Census of the ray cast's dependent chains on the bench workload (CPU oracle, test infrastructure: the reference's castRay with per-ray
 counters): how many steps of which kind a ray takes, per 16x16-pixel tile the longest chain.  A step is one dependent round trip on
-the GPU (two when the value is in the band: single-voxel read, then trilinear read).  usage: python tools/ray_census.py [frames=30]"""
+the GPU (two when the value is in the band: single-voxel read, then trilinear read).  usage: python tests/golden/ray_census.py [frames=30]"""
 import ctypes as C
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from infinitam_amd import capi, synth  # noqa: E402
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""More seeds of tests/test_random_stress.py than the suite runs (HIP vs oracle, bit-exact): usage: python tools/stress_sweep.py [first=1000] [count=100]"""
+"""More seeds of tests/test_random_stress.py than the suite runs (HIP vs oracle, bit-exact): usage: python tests/stress_sweep.py [first=1000] [count=100]"""
 import os
 import sys
 
