@@ -296,7 +296,7 @@ def worker(args) -> int:
                 def make_exchange(uid=uid, box=box):
                     try:
                         if on_gpu:
-                            torch.cuda.set_device(device)
+                            torch.cuda.set_device(local_rank)
                         box["ex"] = NativeExchange(be, world, rank, MAX_IDS, batch=max(1, args.exchange_batch), unique_id=uid)
                     except Exception as e:      # noqa: BLE001
                         box["err"] = e
