@@ -7,7 +7,7 @@
 // frames the records of the batch are all-gathered with RCCL on a SIDE stream that waits for the last copy.  The batch buffers form
 // a ring of eight; before a buffer is written again the HOST checks that the collective which last read it has finished (it used the
 // buffer eight batches earlier: the check returns at once unless the host runs that far ahead of the GPU) -- the frame stream itself
-// never waits for a collective.  The one event recorded on the frame stream per batch uses a DEVICE-scope release: the default
+// never waits for a collective, and the frame THREAD does not issue one: a thread of the exchange's own does (below).  The one event recorded on the frame stream per batch uses a DEVICE-scope release: the default
 // system-scope release of hipEventRecord writes back the L2s, and the next frame's kernels then start on cold caches (measured:
 // per-frame exchange 8.0 k frames/s against 11.2 k without exchange, whoever performed the collective).  RCCL has no all-gather-v, hence the fixed
 // record size.  xGMI is point-to-point, so one 64 KB x batch all-gather per GPU is latency bound; batching trades record age
@@ -19,11 +19,16 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>              // types and prototypes only: the entry points are resolved with dlsym, nothing links against RCCL
 
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <new>
+#include <string>
+#include <thread>
 
 #include "itm_internal.h"
 
@@ -80,8 +85,23 @@ struct itm_exchange {
   int32_t* gathered = nullptr;            // world x batch records: rank-major, then frame of the batch
   hipStream_t side = nullptr;
   hipEvent_t copied[kRing] = {}, released[kRing] = {};
-  bool inFlight[kRing] = {};
+  // a batch buffer is FREE, then QUEUED (its last record's event is recorded, the issuer has been told), then ISSUED (the collective and
+  // its release event are on the side stream), then FREE again once the frame thread has seen that event complete
+  enum : int { kFree = 0, kQueued = 1, kIssued = 2 };
+  std::atomic<int> state[kRing];
   long long frame = 0;
+  // The collectives are issued by a thread of the exchange's own: putting an all-gather on a stream costs the host 60-80 us (RCCL's
+  // launch path), more than submitting a whole frame (16 us).  The frame thread records the event behind the record's copy and hands
+  // the buffer over; ITM_EXCHANGE_INLINE=1 issues from the frame thread as rounds 2-3 did (A/B).
+  bool threaded = true;
+  int device = 0;
+  std::thread issuer;
+  std::mutex m;
+  std::condition_variable cv;
+  std::deque<int> queue;
+  bool stop = false;
+  std::atomic<int> issuerFailed{0};
+  std::string issuerMessage;
   int experiment = 0;                     // ITM_EXCHANGE_EXPERIMENT (measurement hook, tools/exchange_cost.py): how much of a batch's hand-off is issued
 };
 
@@ -89,6 +109,11 @@ using namespace itm;
 
 static void free_exchange(itm_exchange* x) {
   if (!x) return;
+  if (x->issuer.joinable()) {
+    { std::lock_guard<std::mutex> g(x->m); x->stop = true; }
+    x->cv.notify_all();
+    x->issuer.join();
+  }
   if (x->side) (void)hipStreamSynchronize(x->side);
   if (x->comm) rccl().CommDestroy(x->comm);
   for (int b = 0; b < itm_exchange::kRing; ++b) {
@@ -99,6 +124,41 @@ static void free_exchange(itm_exchange* x) {
   if (x->gathered) (void)hipFree(x->gathered);
   if (x->side) (void)hipStreamDestroy(x->side);
   delete x;
+}
+
+// the collective of batch buffer b and its release event, on the side stream behind the event of the batch's last record
+static int issue_collective(itm_exchange* x, int b) {
+  const size_t count = x->words * (size_t)x->batch;
+  ITM_HIP(hipStreamWaitEvent(x->side, x->copied[b], 0));
+  if (x->experiment == 3) return ITM_OK;
+  if (x->comm) {
+    const ncclResult_t nrc = rccl().AllGather(x->buffers[b], x->gathered, count, ncclInt32, x->comm, x->side);
+    if (nrc) return rccl_fail(nrc, "ncclAllGather");
+  } else {
+    ITM_HIP(hipMemcpyAsync(x->gathered, x->buffers[b], count * 4, hipMemcpyDeviceToDevice, x->side));
+  }
+  if (x->experiment == 4) return ITM_OK;
+  ITM_HIP(hipEventRecord(x->released[b], x->side));
+  return ITM_OK;
+}
+
+static void issuer_main(itm_exchange* x) {
+  (void)hipSetDevice(x->device);
+  for (;;) {
+    int b;
+    {
+      std::unique_lock<std::mutex> lk(x->m);
+      x->cv.wait(lk, [&] { return x->stop || !x->queue.empty(); });
+      if (x->queue.empty()) return;                 // (stop: whatever was queued has been issued)
+      b = x->queue.front(); x->queue.pop_front();
+    }
+    if (issue_collective(x, b) != ITM_OK && !x->issuerFailed.load()) {
+      const char* msg = itm_last_error();
+      x->issuerMessage = msg ? msg : "exchange: the collective could not be issued";
+      x->issuerFailed.store(1, std::memory_order_release);
+    }
+    x->state[b].store(itm_exchange::kIssued, std::memory_order_release);
+  }
 }
 
 extern "C" {
@@ -120,6 +180,8 @@ int itm_exchange_create(int world, int rank, const unsigned char id[128], int ma
   if (!x) return set_error(ITM_ERR_DEVICE, "out of host memory");
   x->world = world; x->rank = rank; x->maxIds = max_ids; x->batch = batch;
   x->words = (size_t)kRecordHeader + (size_t)max_ids;
+  for (int b = 0; b < itm_exchange::kRing; ++b) x->state[b].store(itm_exchange::kFree);
+  (void)hipGetDevice(&x->device);
   const size_t batchBytes = x->words * (size_t)batch * 4;
   hipError_t e = hipStreamCreateWithFlags(&x->side, hipStreamNonBlocking);
   const char* sys = getenv("ITM_EXCHANGE_SYSTEM_SCOPE_EVENTS");       // A/B: the default (system-scope) release of hipEventRecord
@@ -150,6 +212,9 @@ int itm_exchange_create(int world, int rank, const unsigned char id[128], int ma
     const ncclResult_t rc = rccl().CommInitRank(&x->comm, world, u, rank);
     if (rc) { x->comm = nullptr; free_exchange(x); return rccl_fail(rc, "ncclCommInitRank"); }
   }
+  const char* inl = getenv("ITM_EXCHANGE_INLINE");
+  x->threaded = !(inl && inl[0] == '1') && x->experiment == 0;
+  if (x->threaded) x->issuer = std::thread(issuer_main, x);
   *out = x;
   return ITM_OK;
 }
@@ -161,27 +226,31 @@ int itm_exchange_step(itm_exchange* x, const itm_render_state* rs, const float M
   hipStream_t fs = as_stream(frame_stream);
   const int slot = (int)(x->frame % x->batch);
   const int b = (int)((x->frame / x->batch) % itm_exchange::kRing);
-  if (slot == 0 && x->inFlight[b]) {
-    // polled, not hipEventSynchronize: the blocking wait of the runtime was measured at ~60 ms per call in a process whose other
-    // threads keep the cores busy (bench.py with a gloo control plane: 33 frames/s), a query is a load
+  if (x->issuerFailed.load(std::memory_order_acquire)) return set_error(ITM_ERR_DEVICE, x->issuerMessage);
+  if (slot == 0 && x->state[b].load(std::memory_order_acquire) != itm_exchange::kFree) {
+    // the collective that read this buffer eight batches ago must have let go of it.  Polled, not hipEventSynchronize: the blocking
+    // wait of the runtime was measured at ~60 ms per call in a process whose other threads keep the cores busy (bench.py with a gloo
+    // control plane: 33 frames/s), a query is a load.  The wait returns at once unless the host runs that far ahead of the GPU.
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 0;; ++spins) {
-      const hipError_t q = hipEventQuery(x->released[b]);
-      if (q == hipSuccess) break;
-      if (q != hipErrorNotReady) return hip_fail(q, "exchange: collective", __FILE__, __LINE__);
+      if (x->state[b].load(std::memory_order_acquire) == itm_exchange::kIssued) {
+        const hipError_t q = (x->experiment == 3 || x->experiment == 4) ? hipSuccess : hipEventQuery(x->released[b]);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) return hip_fail(q, "exchange: collective", __FILE__, __LINE__);
+      }
       if ((spins & 0x3ffu) == 0x3ffu && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0)
         return set_error(ITM_ERR_DEVICE, "exchange: the collective that used this buffer eight batches ago has not finished");
       __builtin_ia32_pause();
     }
-    x->inFlight[b] = false;
-  }   // host-side: the collective eight batches ago has let go of this buffer
+    x->state[b].store(itm_exchange::kFree, std::memory_order_relaxed);
+  }
   int rc = itm_export_visible_record(rs, M_d, x->maxIds, x->buffers[b] + (size_t)slot * x->words, frame_stream);
   if (rc) return rc;
   if (slot == x->batch - 1 && x->experiment != 1) {
     // experiments (measurement only, the table is then not valid): 1 = record copy only; 2 = + event on the frame stream;
     // 3 = + the side stream waits for it; 4 = + the collective, but no release event; 5 = the collective on the FRAME stream, no events
-    const size_t count = x->words * (size_t)x->batch;
     if (x->experiment == 5) {
+      const size_t count = x->words * (size_t)x->batch;
       const ncclResult_t nrc = x->comm ? rccl().AllGather(x->buffers[b], x->gathered, count, ncclInt32, x->comm, fs) : ncclSuccess;
       if (nrc) return rccl_fail(nrc, "ncclAllGather");
       ++x->frame;
@@ -189,17 +258,15 @@ int itm_exchange_step(itm_exchange* x, const itm_render_state* rs, const float M
     }
     ITM_HIP(hipEventRecord(x->copied[b], fs));
     if (x->experiment == 2) { ++x->frame; return ITM_OK; }
-    ITM_HIP(hipStreamWaitEvent(x->side, x->copied[b], 0));
-    if (x->experiment == 3) { ++x->frame; return ITM_OK; }
-    if (x->comm) {
-      const ncclResult_t nrc = rccl().AllGather(x->buffers[b], x->gathered, count, ncclInt32, x->comm, x->side);
-      if (nrc) return rccl_fail(nrc, "ncclAllGather");
+    if (x->threaded) {
+      x->state[b].store(itm_exchange::kQueued, std::memory_order_release);
+      { std::lock_guard<std::mutex> g(x->m); x->queue.push_back(b); }
+      x->cv.notify_one();
     } else {
-      ITM_HIP(hipMemcpyAsync(x->gathered, x->buffers[b], count * 4, hipMemcpyDeviceToDevice, x->side));
+      rc = issue_collective(x, b);
+      if (rc) return rc;
+      x->state[b].store(itm_exchange::kIssued, std::memory_order_release);
     }
-    if (x->experiment == 4) { ++x->frame; return ITM_OK; }
-    ITM_HIP(hipEventRecord(x->released[b], x->side));
-    x->inFlight[b] = true;
   }
   ++x->frame;
   return ITM_OK;
@@ -219,6 +286,10 @@ int itm_exchange_table(itm_exchange* x, int32_t* dst_host, size_t words) {
   if (!x || !dst_host) return set_error(ITM_ERR_INVALID, "null argument");
   const size_t all = x->words * (size_t)x->batch * (size_t)x->world;
   if (words < all) return set_error(ITM_ERR_INVALID, "destination too small for world x batch records");
+  // every queued collective must have been put on the side stream before it is drained
+  for (int b = 0; b < itm_exchange::kRing; ++b)
+    while (x->state[b].load(std::memory_order_acquire) == itm_exchange::kQueued) std::this_thread::yield();
+  if (x->issuerFailed.load(std::memory_order_acquire)) return set_error(ITM_ERR_DEVICE, x->issuerMessage);
   ITM_HIP(hipStreamSynchronize(x->side));     // the table is written by the collectives on the side stream
   ITM_HIP(hipMemcpy(dst_host, x->gathered, all * 4, hipMemcpyDeviceToHost));
   return ITM_OK;
