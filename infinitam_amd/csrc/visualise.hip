@@ -255,16 +255,17 @@ struct RangeFuse {
 __device__ inline void reduce_own_cells(const RangeFuse& f, int tx, int ty, int W, float2* cellRange) {
   const int tid = threadIdx.x;
   const int nCells = f.RW * f.RH;
+  // 4 cells x kRangeParts partials: one load per lane (kRangeParts 32: waves 0 and 1, min / max over each 32-lane half; 64: all
+  // four waves, one cell per wave).  Requested before the counter that decides whether they are used: one round trip, not two, at the
+  // head of every tile
+  const int c = tid / kRangeParts, part = tid % kRangeParts;
+  const int cx = tx * 2 + (c & 1), cy = ty * 2 + (c >> 1);
+  const bool inside = tid < 4 * kRangeParts && cx < f.RW && cy < f.RH;
+  uint2 v = make_uint2(0xffffffffu, 0u);
+  if (inside) v = f.partials[(size_t)part * nCells + cx + cy * f.RW];
   const int total = f.rc->noRenderingBlocks;
   if (total < f.maxBlocks) {
-    // 4 cells x kRangeParts partials: one load per lane (kRangeParts 32: waves 0 and 1, min / max over each 32-lane half; 64: all
-    // four waves, one cell per wave)
     if (tid < 4 * kRangeParts) {
-      const int c = tid / kRangeParts, part = tid % kRangeParts;
-      const int cx = tx * 2 + (c & 1), cy = ty * 2 + (c >> 1);
-      const bool inside = cx < f.RW && cy < f.RH;
-      uint2 v = make_uint2(0xffffffffu, 0u);
-      if (inside) v = f.partials[(size_t)part * nCells + cx + cy * f.RW];
 #pragma unroll
       for (int o = kRangeParts / 2; o > 0; o >>= 1) {
         const uint32_t lo = __shfl_xor(v.x, o, 64), hi = __shfl_xor(v.y, o, 64);
