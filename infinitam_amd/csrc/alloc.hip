@@ -368,6 +368,26 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
       before += (int)(uint32_t)g;
     }
   };
+  // An ordered-region chunk's visible types and the entries its count re-tests do not depend on its own sweep (the sweep fills EMPTY
+  // slots whose types the request stage has set, the re-tested entries are those of the previous frame's list): they are requested
+  // here, ahead of the sweep's chain of dependent rounds, and have arrived when the count needs them -- for the chunk with the most
+  // requests, which every later chunk's look-back waits for, two round trips less behind its sweep.
+  const bool early = SWEEP && !excessRegion && slot0 < p.noTotalEntries;
+  uint2 rawEarly = make_uint2(0u, 0u);
+  uint4 entryEarly[kSlotsPerThread];
+  if (early) {
+    rawEarly = *(const uint2*)(visT + slot0);
+    if (rawEarly.x | rawEarly.y) {
+      uint32_t retest = 0;
+#pragma unroll
+      for (int k = 0; k < kSlotsPerThread; ++k) {
+        const uint32_t t = ((k < 4 ? rawEarly.x : rawEarly.y) >> ((k & 3) * 8)) & 0xffu;
+        if (!(LAZY && (t & 0x80u)) && (LAZY ? (t != 0u) : (t == 3u))) retest |= 1u << k;
+      }
+#pragma unroll
+      for (int k = 0; k < kSlotsPerThread; ++k) entryEarly[k] = hash[slot0 + ((retest >> k) & 1u ? k : 0)];
+    }
+  }
   if constexpr (SWEEP) {
     sweep_chunk<true>(sweepLds, sw.allocKey, chunkReq, sw.chunkReqNext, numChunks, hash, sw.excessList, sw.allocList, visT, counters, sw.headBits,
                       sw.dirPtr, sw.dirSlot, sw.sdfMirror, sw.depth, sw.lazy, p);
@@ -401,6 +421,8 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
     if (excessRegion) {
       const unsigned long long q = __hip_atomic_load((const unsigned long long*)(visT + slot0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       raw = make_uint2((uint32_t)q, (uint32_t)(q >> 32));
+    } else if (early) {
+      raw = rawEarly;
     } else {
       raw = *(const uint2*)(visT + slot0);
     }
@@ -416,8 +438,13 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
         if (!(LAZY && (t & 0x80u)) && (LAZY ? (t != 0u) : (t == 3u))) retest |= 1u << k;
       }
       uint4 entry[kSlotsPerThread];
+      if (early) {
 #pragma unroll
-      for (int k = 0; k < kSlotsPerThread; ++k) entry[k] = hash[slot0 + ((retest >> k) & 1u ? k : 0)];
+        for (int k = 0; k < kSlotsPerThread; ++k) entry[k] = entryEarly[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < kSlotsPerThread; ++k) entry[k] = hash[slot0 + ((retest >> k) & 1u ? k : 0)];
+      }
 #pragma unroll
       for (int k = 0; k < kSlotsPerThread; ++k) {
         uint32_t t = (w[k >> 2] >> ((k & 3) * 8)) & 0xffu;
