@@ -127,7 +127,12 @@ typedef struct itm_counters {
   int32_t noTotalPoints;
   int32_t noRenderingBlocks;   /* numRenderingBlocks of the last CreateExpectedDepths */
   int32_t noAllocRequests;     /* blocks requested by the last AllocateSceneFromDepth */
-  int32_t statusFlags;         /* bit0: alloc key overflow (too many ray steps); bit1: one-pass visible list gave up waiting */
+  int32_t statusFlags;         /* FATAL conditions: the scene is no longer what the reference would hold.  bit0: a depth pixel needed more ray
+                                  steps than the allocation key can number (mu / voxelSize beyond ~2 000), blocks were not requested;
+                                  bit1: a bounded wait between workgroups of the visible-list launch expired (a device that does not
+                                  run what it was given), the frame was not fused.  Once raised, every call that names the scene
+                                  returns ITM_ERR_DEVICE (itm_last_error says which) until itm_reset_scene; itm_get_counters still
+                                  fills its output before it returns the error.  Never raised by a healthy frame. */
 } itm_counters;
 
 /* buffers addressable by itm_download / itm_upload (parity dumps, checkpoints) */
@@ -192,6 +197,8 @@ int ITM_FN(set_device)(int device);
 #define ITM_DEBUG_DENSE_CLASSIFY 16            /* dense integration: 0 = 4-voxel groups classified against the depth tiles before the fetch (default), 1 = no classification, 2 = classified after the fetch, 3 = check mode (itm_debug_dense_classify_check) */
 #define ITM_DEBUG_DENSE_NO_STRIPS 17           /* dense integration: the launch shape of rounds 1-2 (four groups per lane, 131 072 short waves) instead of the strip kernel */
 #define ITM_DEBUG_TRACKER_SESSION_UNUSABLE 18  /* TrackCamera: the resident evaluation kernel reports itself unusable at the n-th evaluation of a handle (n = value): the call must finish through one launch per evaluation with the same pose */
+#define ITM_DEBUG_NO_DEFERRED_FUSION 19         /* the four per-frame engine calls launch at once, one by one, instead of being recorded and fused (see "the four calls" below) */
+#define ITM_DEBUG_FORCE_LIST_STUCK 20           /* AllocateSceneFromDepth, one-launch visible list: chunk n - 1 behaves as if its bounded wait for another workgroup had expired (0 = off): the scene must raise statusFlags bit 1 and refuse further calls */
 int ITM_FN(debug_set)(int key, int value);
 /* dense integration, check mode of key 16: {free groups, shadow groups, mixed groups, violations}; reset != 0 clears */
 int ITM_FN(debug_dense_classify_check)(int32_t out[4], int reset);
@@ -226,6 +233,19 @@ int ITM_FN(reset_scene)(itm_scene* scene, itm_stream stream);
  * range image with (vf_min, vf_max), Objects/ITMRenderState.h:51-75) */
 int ITM_FN(render_state_create)(const itm_scene* scene, int w, int h, itm_render_state** out);
 int ITM_FN(render_state_destroy)(itm_render_state* rs);
+
+/* ---- the four calls of a frame ----------------------------------------------------------------------------------------------
+ * ITMMainEngine::ProcessFrame reaches the engines as AllocateSceneFromDepth -> IntegrateIntoScene (Engine/ITMDenseMapper.cpp:50-57)
+ * -> CreateExpectedDepths -> CreateICPMaps (Engine/ITMTrackingController.cpp:30-46).  For hash scenes the first three of the entry
+ * points below RECORD their arguments (after checking everything they could be refused for) and return; itm_create_icp_maps for the
+ * same view, pose and stream completes the sequence and launches the fused frame of itm_process_frame (5 launches instead of 8).
+ * Any other call that names the scene or the render state, any copy / view-builder call of this library that writes an image the
+ * recorded view reads, itm_stream_synchronize on the recording stream and itm_flush launch what was recorded first, call by call.
+ * Results are identical either way.  What a host must know: the images of the view are read when the sequence is launched -- a host
+ * that overwrites them with its OWN kernels or copies between AllocateSceneFromDepth and CreateICPMaps calls itm_flush first (the
+ * reference's callers build the view before the tracker runs and never do).  ITM_NO_DEFERRED_FUSION=1 in the environment launches
+ * every call at once. */
+int ITM_FN(flush)(itm_scene* scene, itm_render_state* rs, itm_stream stream);   /* scene == rs == NULL: everything recorded on `stream` */
 
 /* ITMSceneReconstructionEngine::AllocateSceneFromDepth(scene, view, trackingState, renderState,
  * onlyUpdateVisibleList)                               Engine/ITMSceneReconstructionEngine.h:40
@@ -294,6 +314,12 @@ int ITM_FN(process_frame)(itm_scene* scene, const itm_view* view, itm_render_sta
  * allocation returns ITM_ERR_INVALID (the render state's visible types then hold the marks of the abandoned requests: recreate it). */
 int ITM_FN(process_frame_ahead)(itm_scene* scene, const itm_view* view, const itm_view* next, itm_render_state* rs,
                                 float* points, float* normals, itm_stream stream);
+/* While the requests of `next` are pending the render state's visible types carry their marks and the scene's request keys are in
+ * use: a download / upload / save of the visible list, itm_find_visible_blocks on that render state and an allocation through ANOTHER
+ * render state of the scene return ITM_ERR_INVALID.  itm_cancel_ahead abandons the requests: keys and counters return to "no
+ * request", the marks are cleared and the entries of the visible list read 3 -- the state of the reference's AllocateSceneFromDepth
+ * right after its "previous list -> 3" loop (CPU :160-161) -- so that any allocation may follow.  itm_reset_scene cancels by itself. */
+int ITM_FN(cancel_ahead)(itm_scene* scene, itm_render_state* rs, itm_stream stream);
 
 /* ---- view builder (the step before the path) -------------------------------- */
 /* convertDepthAffineToFloat  DeviceAgnostic/ITMViewBuilder.h:22-28 */
@@ -332,6 +358,10 @@ int ITM_FN(depth_stager_create)(int w, int h, int slots, itm_depth_stager** out)
 int ITM_FN(depth_stager_destroy)(itm_depth_stager* g);
 int ITM_FN(depth_stager_upload)(itm_depth_stager* g, const int16_t* pinned_host);
 int ITM_FN(depth_stager_acquire)(itm_depth_stager* g, itm_stream stream, const int16_t** device_image);
+/* itm_depth_stager_upload returns BEFORE the copy stream has read the host buffer: a pinned buffer may be rewritten only once
+ * *busy == 0 here (no upload still in flight; a query, never a wait), or after its frame has been acquired and the acquiring stream
+ * synchronised.  *waiting = uploaded frames not acquired yet.  Either pointer may be NULL. */
+int ITM_FN(depth_stager_pending)(itm_depth_stager* g, int* waiting, int* busy);
 int ITM_FN(depth_stager_release)(itm_depth_stager* g, itm_stream stream);
 
 /* ---- on-disk input formats of the view builder's sources (host memory, no device work) -------------------------

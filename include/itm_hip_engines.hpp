@@ -308,6 +308,17 @@ class ITMViewBuilder_HIP {
   }
   void UpdateViewFromHost(ITMView* view, const int16_t* rawDepthHost, float* depth, float* scratch, bool useBilateralFilter,
                           bool modelSensorNoise = false, float* depthNormal = nullptr, float* depthUncertainty = nullptr) {
+    if (stager && prefetched != rawDepthHost) {
+      // frames uploaded ahead that are not the one asked for (the image source changed its mind): taken off the ring unread, else the
+      // stager -- strictly first in, first out -- would hand the stale frame to this call and stay one frame behind from then on
+      int waiting = 0;
+      check(itm_depth_stager_pending(stager, &waiting, nullptr), "UpdateView (pending)");
+      for (; waiting > 0; --waiting) {
+        const int16_t* stale = nullptr;
+        check(itm_depth_stager_acquire(stager, stream, &stale), "UpdateView (discard)");
+        check(itm_depth_stager_release(stager, stream), "UpdateView (discard)");
+      }
+    }
     if (prefetched != rawDepthHost) Prefetch(rawDepthHost, view->depthSize);
     prefetched = nullptr;
     const int16_t* raw = nullptr;
@@ -503,11 +514,11 @@ class ITMMainEngine_HIP {
  private:
   void ProcessView() {
     if (!mainProcessingActive) return;
-    // tracking
+    // pose of this frame against the maps of the last ray cast
     trackingController->Track(&trackingState, &view);
-    // fusion
+    // allocate + integrate (the library records both; they launch with the two calls of Prepare as ONE fused frame, pending.hip)
     if (fusionActive) denseMapper.ProcessFrame(&view, &trackingState, &scene, renderState_live);
-    // raycast to renderState_live for tracking and free visualisation
+    // expected depths + ICP maps (or the forward projection) from the new pose: what the next Track call and the UI read
     trackingController->Prepare(&trackingState, &view, renderState_live);
   }
 

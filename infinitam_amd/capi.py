@@ -175,6 +175,8 @@ _SIGS = {
     "forward_render": (C.c_int, [_P, C.POINTER(ViewStruct), _P, _P]),
     "process_frame": (C.c_int, [_P, C.POINTER(ViewStruct), _P, _P, _P, _P]),
     "process_frame_ahead": (C.c_int, [_P, C.POINTER(ViewStruct), C.POINTER(ViewStruct), _P, _P, _P, _P]),
+    "flush": (C.c_int, [_P, _P, _P]),
+    "cancel_ahead": (C.c_int, [_P, _P, _P]),
     "convert_depth_affine": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_float, C.c_float, _P]),
     "convert_disparity": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, _P]),
     "filter_depth": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
@@ -239,6 +241,7 @@ _HOST_IO_SIGS = {
     "depth_stager_upload": (C.c_int, [_P, _P]),
     "depth_stager_acquire": (C.c_int, [_P, _P, C.POINTER(_P)]),
     "depth_stager_release": (C.c_int, [_P, _P]),
+    "depth_stager_pending": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "stream_create": (C.c_int, [C.POINTER(_P)]),
     "stream_destroy": (C.c_int, [_P]),
     # multi-stream exchange issued from the library (RCCL); the CPU shims exchange through torch.distributed (streams.py)
@@ -513,6 +516,14 @@ class Scene:
         ns = None if next_view is None else (next_view if isinstance(next_view, ViewStruct) else next_view.struct())
         self.be.check(self.be.fn["process_frame_ahead"](_P(self.h), C.byref(vs), (C.byref(ns) if ns is not None else None), _P(rs.h), _P(points.ptr), _P(normals.ptr),
                                                         _P(stream)), "process_frame_ahead")
+
+    def flush(self, rs: "RenderState" = None, stream=None):
+        """Launches the engine calls the library has recorded for this scene / render state (itm_flush)."""
+        self.be.check(self.be.fn["flush"](_P(self.h), _P(rs.h if rs is not None else None), _P(stream)), "flush")
+
+    def cancel_ahead(self, rs: "RenderState", stream=None):
+        """Abandons the block requests itm_process_frame_ahead issued for the next view (itm_cancel_ahead)."""
+        self.be.check(self.be.fn["cancel_ahead"](_P(self.h), _P(rs.h), _P(stream)), "cancel_ahead")
 
     def close(self):
         if self.h:

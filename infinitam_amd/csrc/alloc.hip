@@ -40,6 +40,7 @@ namespace itm {
 int g_debug_explicit_mark = 0;   // test hook: always run the explicit mark-previous launch
 int g_debug_two_pass_visible_list = 0;   // test hook: count and compact as two launches
 int g_debug_separate_sweep = 0;          // test hook (key 13): the allocation sweep as its own launch
+int g_debug_force_list_stuck = 0;        // test hook (key 20): chunk n - 1 of the one-launch list behaves as if its bounded wait had expired
 
 __global__ void __launch_bounds__(256) mark_previous_kernel(const int32_t* __restrict__ ids, RenderCounters* __restrict__ rc,
                                                             uint8_t* __restrict__ visT) {
@@ -74,14 +75,13 @@ constexpr int kSlotsPerThread = kSweepChunk / 256;  // 8
 // list is built by the same launch (visible_list_kernel<.., SWEEP>) the workgroup of that chunk reads it there, so it is written
 // with a device-scope store that bypasses the non-coherent L2s.
 template <bool ACROSS>
-__device__ inline void sweep_chunk(int* lds, uint32_t* __restrict__ allocKey, const int2* __restrict__ chunkReq,
+__device__ inline void sweep_chunk(const int chunk, int* lds, uint32_t* __restrict__ allocKey, const int2* __restrict__ chunkReq,
                                    int2* __restrict__ chunkReqNext, int numChunks, uint4* __restrict__ hash,
                                    const int32_t* __restrict__ excessList, const int32_t* __restrict__ allocList,
                                    uint8_t* __restrict__ visT, const SceneCounters* __restrict__ counters,
                                    uint32_t* __restrict__ headBits, int32_t* __restrict__ dirPtr, int32_t* __restrict__ dirSlot, void* __restrict__ sdfMirror,
                                    const float* __restrict__ depth, int lazy, const AllocParams& p) {
 
-  const int chunk = blockIdx.x;
   const int tid = threadIdx.x;
   if (tid == 0) chunkReqNext[chunk] = make_int2(0, 0);
   const int2 mine = chunkReq[chunk];
@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(256) allocate_sweep_kernel(uint32_t* __restric
                                                              uint32_t* __restrict__ headBits, int32_t* __restrict__ dirPtr, int32_t* __restrict__ dirSlot, void* __restrict__ sdfMirror,
                                                              const float* __restrict__ depth, int lazy, AllocParams p) {
   __shared__ int lds[8];
-  sweep_chunk<false>(lds, allocKey, chunkReq, chunkReqNext, numChunks, hash, excessList, allocList, visT, counters, headBits, dirPtr, dirSlot, sdfMirror, depth, lazy, p);
+  sweep_chunk<false>((int)blockIdx.x, lds, allocKey, chunkReq, chunkReqNext, numChunks, hash, excessList, allocList, visT, counters, headBits, dirPtr, dirSlot, sdfMirror, depth, lazy, p);
 }
 
 // checkBlockVisibility<false>: corners are reached by incremental +-f updates in a fixed order.
@@ -330,6 +330,9 @@ struct SweepArgs {
   uint32_t* allocKey; int2* chunkReqNext; const int32_t* excessList; const int32_t* allocList; uint32_t* headBits;
   int32_t* dirPtr; int32_t* dirSlot; void* sdfMirror; const float* depth; int lazy;
   uint32_t* sweepDone;     // per chunk: the epoch of the launch whose sweep has placed the chunk's excess allocations
+  int early;               // workgroups at the head of the grid that only sweep an excess-region chunk (below)
+  int32_t* fatalDev;       // the scene's host-visible status word (alloc_device.h: raise_fatal)
+  int forceStuck;          // test hook (debug key 20): chunk whose wait is treated as expired, or -1
 };
 
 #ifndef ITM_EXP_LIST_STAMPS
@@ -343,6 +346,16 @@ extern "C" int itm_debug_read_list_stamps(unsigned long long* dst, int n) { retu
 #define ITM_LS(k)
 #endif
 
+// WHO WAITS FOR WHOM.  A workgroup of this launch may only wait for workgroups with a LOWER index: workgroups are dispatched in index
+// order, so everything a waiting workgroup depends on is resident (or done) whatever share of the device the launch gets -- masked
+// compute units, other processes, time-sliced queues -- and the waiting cannot deadlock.  The look-back has that shape by itself
+// (chunk c waits for chunks < c).  The stamps did not: an excess-region chunk waits for the sweep of EVERY chunk with excess requests,
+// and such a chunk may lie behind it in the excess region (a request whose chain tail is an excess entry).  With SWEEP the grid
+// therefore starts with sw.early workgroups -- one per chunk of the excess region -- that do nothing but sweep "their" excess-region
+// chunk (nearly always: one load, no requests, gone); workgroup early + c is chunk c as before, and only sweeps c itself when c lies
+// in the ordered region.  Every stamp an excess-region chunk waits for is then written by a workgroup in front of it.  The waits stay
+// bounded all the same; one that does expire means a device that no longer runs what it was given, and is fatal for the scene
+// (statusFlags bit 1, ITM_ERR_DEVICE at the next call; the frame's list is marked invalid and the integration fuses nothing through it).
 template <bool COMMIT_ALLOC, bool LAZY, bool SWEEP>
 __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__ visT, uint4* __restrict__ hash,
                                                            unsigned long long* __restrict__ chunkGran, uint32_t epoch,
@@ -350,12 +363,32 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
                                                            int32_t* __restrict__ ids, int capIds, RenderCounters* __restrict__ rc, AllocParams p, SweepArgs sw) {
   __shared__ int lds[12];
   __shared__ int sweepLds[8];
-  const int chunk = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
+  // the chunk's stores must have COMPLETED before its stamp may follow: on gfx950 a workgroup-scope release fence is only
+  // s_waitcnt lgkmcnt(0) -- it does not wait for vector stores -- so the wait is spelled out (loads and stores share vmcnt);
+  // the type bytes and entries were stored with device scope (write-through), nothing is left to write back
+  auto stamp_sweep = [&](int c) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();                                         // ... all of the chunk's have: say that its excess allocations are in place
+    if (tid == 0) __hip_atomic_store(&sw.sweepDone[c], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  if constexpr (SWEEP) {
+    if ((int)blockIdx.x < sw.early) {
+      // ---- an early workgroup: the sweep of one excess-region chunk, nothing else ----
+      const int c = numChunks - sw.early + (int)blockIdx.x;
+      sweep_chunk<true>(c, sweepLds, sw.allocKey, chunkReq, sw.chunkReqNext, numChunks, hash, sw.excessList, sw.allocList, visT, counters, sw.headBits,
+                        sw.dirPtr, sw.dirSlot, sw.sdfMirror, sw.depth, sw.lazy, p);
+      if (chunkReq[c].y > 0) stamp_sweep(c);                   // (uniform; every request in the excess region is an excess request)
+      return;
+    }
+  }
+  const int chunk = (int)blockIdx.x - (SWEEP ? sw.early : 0);
   const int slot0 = chunk * kSweepChunk + tid * kSlotsPerThread;
   const bool excessRegion = SWEEP && slot0 - tid * kSlotsPerThread >= p.bucketNum;      // uniform: bucketNum is a multiple of the chunk size (host)
   ITM_LS(0)
   int before = 0;
-  bool stuck = false;
+  bool stuck = SWEEP && chunk == sw.forceStuck;
   // sums the granules of the chunks before this one, waiting for each to carry this launch's epoch
   auto look_back = [&]() {
     for (int j = tid; j < chunk; j += 256) {
@@ -389,22 +422,15 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
     }
   }
   if constexpr (SWEEP) {
-    sweep_chunk<true>(sweepLds, sw.allocKey, chunkReq, sw.chunkReqNext, numChunks, hash, sw.excessList, sw.allocList, visT, counters, sw.headBits,
-                      sw.dirPtr, sw.dirSlot, sw.sdfMirror, sw.depth, sw.lazy, p);
-    const bool wroteAcross = chunkReq[chunk].y > 0;            // (uniform) only excess allocations are read by other workgroups of this launch
-    if (wroteAcross) {
-      // this thread's stores must have COMPLETED before the stamp may follow: on gfx950 a workgroup-scope release fence is only
-      // s_waitcnt lgkmcnt(0) -- it does not wait for vector stores -- so the wait is spelled out (loads and stores share vmcnt);
-      // the type bytes and entries were stored with device scope (write-through), nothing is left to write back
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __syncthreads();                                         // ... all of the chunk's have: say that its excess allocations are in place
-      if (tid == 0) __hip_atomic_store(&sw.sweepDone[chunk], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (excessRegion) {
-      // every chunk that had excess requests (any index: no sweep waits for anything, so this cannot cycle) must be through
+    if (!excessRegion) {
+      sweep_chunk<true>(chunk, sweepLds, sw.allocKey, chunkReq, sw.chunkReqNext, numChunks, hash, sw.excessList, sw.allocList, visT, counters, sw.headBits,
+                        sw.dirPtr, sw.dirSlot, sw.sdfMirror, sw.depth, sw.lazy, p);
+      if (chunkReq[chunk].y > 0) stamp_sweep(chunk);           // (uniform) only excess allocations are read by other workgroups of this launch
+    } else {
+      // every chunk that had excess requests must be through: chunks of the ordered region (workgroups early + j, j < chunk) and of the
+      // excess region (the early workgroups) -- all in front of this workgroup
       for (int j = tid; j < numChunks; j += 256) {
-        if (chunkReq[j].y <= 0 || j == chunk) continue;
+        if (chunkReq[j].y <= 0) continue;
         for (int spin = 0; __hip_atomic_load(&sw.sweepDone[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch; ++spin) {
           if (spin > (1 << 22)) { stuck = true; break; }
           __builtin_amdgcn_s_sleep(1);
@@ -470,7 +496,7 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
   // base = visible slots in all earlier chunks
   look_back();
   ITM_LS(3)
-  if (stuck) { atomicOr(&counters->statusFlags, 2); rc->listInvalid = 1; }      // sticky for the host; the frame is not fused (integrate.hip)
+  if (stuck) { raise_fatal(counters, sw.fatalDev, 2); rc->listInvalid = 1; }    // fatal for the scene (see above); the frame is not fused (integrate.hip)
   const int base = block_reduce_sum<4>(before, lds + 4);
   if (COMMIT_ALLOC && chunk == (SWEEP ? numChunks - 1 : 0)) {
     // (with SWEEP every sweep has read the pool counters by now: all granules are in)
@@ -574,7 +600,7 @@ int prepare_request_stage(itm_scene* s, const itm_view* v, itm_render_state* rs,
   p.org = s->org;
   int2* reqCur = (int2*)s->chunkReq + (size_t)(s->frameParity & 1u) * s->numChunks;
   lazy = rs->listCoherent && !g_debug_explicit_mark;
-  ra = RequestArgs{v->depth, s->hash, rs->visibleType, s->allocKey, reqCur, s->counters, rs->range, rs->counters, g_debug_no_directory ? nullptr : s->dirSlot};
+  ra = RequestArgs{v->depth, s->hash, rs->visibleType, s->allocKey, reqCur, s->counters, rs->range, rs->counters, g_debug_no_directory ? nullptr : s->dirSlot, s->fatalDev};
   return ITM_OK;
 }
 
@@ -587,14 +613,30 @@ static bool same_view(const itm_render_state* rs, const itm_view* v) {
 // Stage 1: per-pixel block requests.  When the visible list and the visible types are known to be
 // coherent (always, unless the caller rewrote one of them) the "mark previous list as type 3" launch is
 // skipped and folded into the type encoding (LAZY, see request_kernel).
-int launch_request_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, bool onlyVisible, bool fuseRangeInit, hipStream_t st) {
+// What an allocation for view `v` would be refused for, checked without side effects (the entry point records the call, pending.hip,
+// and must report these at once): a pose without inverse, an image too large for the request key, block requests of ANOTHER view
+// issued ahead on this render state -- or of any view on another render state of the scene (the request keys belong to the scene).
+int validate_allocate(const itm_scene* s, const itm_view* v, const itm_render_state* rs, bool onlyVisible) {
+  float inv[16];
+  if (!invert4(v->M_d, inv)) return set_error(ITM_ERR_INVALID, "pose matrix is singular");
+  if ((long long)v->w * v->h > (1ll << 27)) return set_error(ITM_ERR_INVALID, "depth image too large for the allocation key");
+  if (s->aheadRs && s->aheadRs != rs)
+    return set_error(ITM_ERR_INVALID, "the scene holds the block requests of a frame issued ahead on another render state (itm_process_frame_ahead): fuse that frame or itm_cancel_ahead first");
   if (rs->ahead.valid) {
-    // the requests of this frame rode in the previous frame's last launch (itm_process_frame_ahead)
     if (onlyVisible || !same_view(rs, v))
       return set_error(ITM_ERR_INVALID, "the block requests of another view were issued ahead (itm_process_frame_ahead): the next allocation must be for that view");
     if (rs->ahead.tableEpoch != s->tableEpoch)
       return set_error(ITM_ERR_INVALID, "the scene was reset or its table replaced while the block requests of the next view were pending (itm_process_frame_ahead)");
+  }
+  return ITM_OK;
+}
+
+int launch_request_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, bool onlyVisible, bool fuseRangeInit, hipStream_t st) {
+  { const int rc = validate_allocate(s, v, rs, onlyVisible); if (rc) return rc; }
+  if (rs->ahead.valid) {
+    // the requests of this frame rode in the previous frame's last launch (itm_process_frame_ahead)
     rs->ahead.valid = false;
+    if (s->aheadRs == rs) s->aheadRs = nullptr;
     rs->lazyThisFrame = rs->ahead.lazy;
     return ITM_OK;
   }
@@ -649,8 +691,11 @@ int launch_sweep_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, bo
   KernelTimer tv(s, ITM_TK_VISIBLE_LIST, st);
   if (onePass) {
     const uint32_t epoch = ++s->listEpoch;
-    const SweepArgs sw{s->allocKey, reqNext, s->excessList, s->allocList, s->headBits, s->dirPtr, s->dirSlot, s->sdfMirror, v->depth, lazy ? 1 : 0, s->chunkSweepDone};
-#define ITM_VL(CM, LZ, SW) visible_list_kernel<CM, LZ, SW><<<nChunks, 256, 0, st>>>(rs->visibleType, s->hash, s->chunkGran, epoch, reqCur, nChunks, s->counters, rs->visibleIds, rs->capIds, rs->counters, p, sw)
+    // (the early workgroups: one per chunk of the excess region, see visible_list_kernel)
+    const int earlyWgs = fusedSweep ? nChunks - s->cfg.bucketNum / kSweepChunk : 0;
+    const SweepArgs sw{s->allocKey, reqNext, s->excessList, s->allocList, s->headBits, s->dirPtr, s->dirSlot, s->sdfMirror, v->depth, lazy ? 1 : 0, s->chunkSweepDone,
+                       earlyWgs, s->fatalDev, fusedSweep ? g_debug_force_list_stuck - 1 : -1};
+#define ITM_VL(CM, LZ, SW) visible_list_kernel<CM, LZ, SW><<<nChunks + earlyWgs, 256, 0, st>>>(rs->visibleType, s->hash, s->chunkGran, epoch, reqCur, nChunks, s->counters, rs->visibleIds, rs->capIds, rs->counters, p, sw)
     if (onlyVisible) { if (lazy) ITM_VL(false, true, false); else ITM_VL(false, false, false); }
     else if (fusedSweep) { if (lazy) ITM_VL(true, true, true); else ITM_VL(true, false, true); }
     else { if (lazy) ITM_VL(true, true, false); else ITM_VL(true, false, false); }
@@ -699,24 +744,42 @@ int launch_find_visible(const itm_scene* s, const float* M, const float* intr, i
   return ITM_OK;
 }
 
+// Abandons the block requests issued ahead on `rs` (itm_process_frame_ahead): the request keys and counters return to "no request",
+// every visible type the requests marked is cleared and the entries of the visible list read 3 -- the state of the reference's
+// AllocateSceneFromDepth right after its "previous list -> 3" loop (_CPU.cpp:160-161), from which any allocation may follow.
+__global__ void __launch_bounds__(256) cancel_requests_kernel(uint8_t* __restrict__ visT, uint32_t* __restrict__ allocKey, int n) {
+  const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;                                           // n is a multiple of 8
+  uint32_t t = *(const uint32_t*)(visT + i);
+  const uint32_t marked = t & 0x80808080u;
+  if (marked) { t &= ~((marked >> 7) * 0xffu); *(uint32_t*)(visT + i) = t; }
+  *(uint4*)(allocKey + i) = make_uint4(0u, 0u, 0u, 0u);
+}
+int cancel_ahead(itm_scene* s, itm_render_state* rs, hipStream_t st) {
+  if (!rs->ahead.valid) return ITM_OK;
+  const int n = s->noTotalEntries;
+  cancel_requests_kernel<<<(n / 4 + 255) / 256, 256, 0, st>>>(rs->visibleType, s->allocKey, n);
+  mark_previous_kernel<<<64, 256, 0, st>>>(rs->visibleIds, rs->counters, rs->visibleType);
+  ITM_LAUNCH_CHECK();
+  ITM_HIP(hipMemsetAsync((int2*)s->chunkReq + (size_t)(s->frameParity & 1u) * s->numChunks, 0, (size_t)s->numChunks * sizeof(int2), st));
+  rs->ahead.valid = false;
+  if (s->aheadRs == rs) s->aheadRs = nullptr;
+  rs->listCoherent = true;       // list == the non-zero types
+  return ITM_OK;
+}
+
 }  // namespace itm
 
 using namespace itm;
 
 extern "C" {
 
-int itm_allocate_scene_from_depth(itm_scene* s, const itm_view* v, itm_render_state* rs, int onlyUpdateVisibleList, itm_stream stream) {
-  if (!s || !v || !rs) return set_error(ITM_ERR_INVALID, "null argument");
-  if (s->cfg.indexType == ITM_INDEX_DENSE) return ITM_OK;  // _CPU.cpp:314-317
-  if (!v->depth) return set_error(ITM_ERR_INVALID, "null depth image");
-  if (rs->scene != s || v->w != rs->w || v->h != rs->h) return set_error(ITM_ERR_INVALID, "view / render state mismatch");
-  return launch_allocate(s, v, rs, onlyUpdateVisibleList != 0, false, as_stream(stream));
-}
-
 int itm_find_visible_blocks(const itm_scene* s, const float M[16], const float intr[4], itm_render_state* rs, itm_stream stream) {
   if (!s || !M || !intr || !rs) return set_error(ITM_ERR_INVALID, "null argument");
   if (s->cfg.indexType == ITM_INDEX_DENSE) return ITM_OK;  // ITMVisualisationEngine_CPU.cpp:34-37
   if (rs->scene != s) return set_error(ITM_ERR_INVALID, "render state belongs to another scene");
+  { const int rc = enter_scene(s, rs); if (rc) return rc; }
+  if (refuse_while_ahead(s, rs, "FindVisibleBlocks")) return ITM_ERR_INVALID;
   return launch_find_visible(s, M, intr, rs, as_stream(stream));
 }
 

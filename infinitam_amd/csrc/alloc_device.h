@@ -57,7 +57,15 @@ __device__ inline bool make_block_ray(float d, int x, int y, const AllocParams& 
 struct RequestArgs {
   const float* depth; const uint4* hash; uint8_t* visT; uint32_t* allocKey; int2* chunkReq; SceneCounters* counters;
   float2* range; RenderCounters* rcnt; const int32_t* dirSlot;
+  int32_t* fatalDev;     // the scene's status word in page-locked host memory (itm_internal.h), or nullptr
 };
+
+// A condition after which the scene is not what the reference would hold: recorded in the device-side counters (itm_get_counters) and
+// in the host-visible word every entry point checks (a system-scope atomic: it crosses PCIe; never on the path of a healthy frame).
+__device__ inline void raise_fatal(SceneCounters* __restrict__ counters, int32_t* __restrict__ fatalDev, int bits) {
+  atomicOr(&counters->statusFlags, bits);
+  if (fatalDev) __hip_atomic_fetch_or(fatalDev, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // The work of one 16x16-pixel tile (tx, ty) by a workgroup of 256 lanes, one wave = 16x4 pixels.
 template <bool ONLY_VISIBLE, bool FUSE_RANGE_INIT, bool LAZY>
@@ -81,7 +89,9 @@ __device__ inline void request_tile(int tx, int ty, const RequestArgs& a, const 
   BlockRay r;
   if (!make_block_ray(depth[loc], x, y, p, r)) return;
   if (!ONLY_VISIBLE && r.noSteps > (1 << p.stepBits)) {
-    atomicOr(&counters->statusFlags, 1);
+    // more steps than the request key can number (a band of thousands of blocks: mu / voxelSize beyond 2 000): the reference would walk
+    // them all; the frame is not the reference's any more and the scene says so (statusFlags bit 0 -> ITM_ERR_DEVICE at the next call)
+    raise_fatal(counters, a.fatalDev, 1);
     r.noSteps = 1 << p.stepBits;
   }
   for (int i = 0; i < r.noSteps; ++i) {

@@ -223,6 +223,7 @@ int itm_exchange_destroy(itm_exchange* x) { free_exchange(x); return ITM_OK; }
 
 int itm_exchange_step(itm_exchange* x, const itm_render_state* rs, const float M_d[16], itm_stream frame_stream) {
   if (!x || !rs || !M_d) return set_error(ITM_ERR_INVALID, "null argument");
+  { const int rc = enter_scene(rs->scene, rs); if (rc) return rc; }       // engine calls recorded on the render state are launched first (pending.hip)
   hipStream_t fs = as_stream(frame_stream);
   const int slot = (int)(x->frame % x->batch);
   const int b = (int)((x->frame / x->batch) % itm_exchange::kRing);

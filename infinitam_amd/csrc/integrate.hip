@@ -901,6 +901,13 @@ static bool make_column_cull(const FuseParams& p, const int* size, const int* of
 
 // `fuseProjection`: also run the projection half of CreateExpectedDepths (hash scenes whose sub-sampled range image
 // fits four times in LDS; the caller checked can_fuse_projection and launches range_reduce afterwards).
+// what an integration of view `v` would be refused for (checked at once by the entry point that records the call, pending.hip)
+int validate_integrate(const itm_scene* s, const itm_view* v) {
+  const bool colour = (s->cfg.voxelType == ITM_VOXEL_S_RGB || s->cfg.voxelType == ITM_VOXEL_F_RGB);
+  if (colour && (!v->rgb || v->w_rgb <= 0 || v->h_rgb <= 0)) return set_error(ITM_ERR_INVALID, "colour voxels need an rgb image");
+  return ITM_OK;
+}
+
 int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipStream_t st, bool fuseProjection) {
   FuseParams p;
   memcpy(p.M_d.m, v->M_d, 64);
@@ -919,8 +926,7 @@ int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipS
   p.stopAtMax = s->prm.stopIntegratingAtMaxW;
   p.org = s->org;
   const uchar4* rgb = (const uchar4*)v->rgb;
-  const bool colour = (s->cfg.voxelType == ITM_VOXEL_S_RGB || s->cfg.voxelType == ITM_VOXEL_F_RGB);
-  if (colour && (!rgb || v->w_rgb <= 0 || v->h_rgb <= 0)) return set_error(ITM_ERR_INVALID, "colour voxels need an rgb image");
+  { const int rc = validate_integrate(s, v); if (rc) return rc; }
 
   // (the integration timer brackets the integration kernel alone; the small depth-tile launch of the dense path goes in front of it)
   std::unique_ptr<KernelTimer> tk;
@@ -1043,9 +1049,3 @@ extern "C" int itm_debug_dense_classify_check(int32_t out[4], int reset) {
   return ITM_OK;
 }
 
-extern "C" int itm_integrate_into_scene(itm_scene* s, const itm_view* v, itm_render_state* rs, itm_stream stream) {
-  if (!s || !v || !rs) return set_error(ITM_ERR_INVALID, "null argument");
-  if (!v->depth) return set_error(ITM_ERR_INVALID, "null depth image");
-  if (rs->scene != s) return set_error(ITM_ERR_INVALID, "render state belongs to another scene");
-  return launch_integrate(s, v, rs, as_stream(stream), false);
-}

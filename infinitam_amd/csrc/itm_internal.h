@@ -97,6 +97,15 @@ struct itm_scene {
   float2* depthTiles = nullptr;
   size_t depthTilesCap = 0;
   itm::Profiler* prof = nullptr;
+  // engine calls recorded but not yet launched (pending.hip): the render state that holds them, or nullptr
+  mutable itm_render_state* deferredRs = nullptr;
+  // itm_process_frame_ahead: the render state whose NEXT frame's block requests are in the table's request keys (one per scene)
+  itm_render_state* aheadRs = nullptr;
+  // Conditions after which the scene is no longer what the reference would hold (itm_counters::statusFlags): kernels raise them in
+  // device memory AND in this word of page-locked host memory, which every entry point reads (a plain host load): the next call on
+  // the scene fails with ITM_ERR_DEVICE instead of going on with a state the reference can never be in.  Cleared by ResetScene.
+  volatile int32_t* fatalHost = nullptr;   // hipHostMalloc (mapped)
+  int32_t* fatalDev = nullptr;             // the same word as the device sees it
 };
 
 struct itm_render_state {
@@ -133,6 +142,10 @@ struct itm_render_state {
   // itm_process_frame_ahead: the block requests of the NEXT frame were issued beside this frame's ICP maps; the next allocation
   // must be for exactly this view and skips its request launch
   struct { bool valid = false; const float* depth = nullptr; int w = 0, h = 0; float M_d[16] = {}, intr_d[4] = {}; bool lazy = false; unsigned tableEpoch = 0; } ahead;
+  // Deferred fusion (pending.hip): AllocateSceneFromDepth -> IntegrateIntoScene -> CreateExpectedDepths recorded here; CreateICPMaps
+  // for the same view then launches the fused frame of itm_process_frame, anything else launches what was recorded one by one.
+  // stage: 0 nothing, 1 allocation recorded, 2 + integration, 3 + expected depths
+  struct { int stage = 0; itm_view view = {}; hipStream_t st = nullptr; } deferred;
 };
 
 namespace itm {
@@ -181,6 +194,21 @@ inline int dispatch_voxel(int voxelType, F&& f) {
   return set_error(ITM_ERR_INVALID, "unknown voxel type");
 }
 
+// ---- pending work of the entry points (pending.hip) --------------------------------------------------------------------------------
+// Launches, unfused and in call order, what the render state has recorded (no-op when nothing is).
+int flush_deferred(itm_render_state* rs);
+// The prologue of every entry point that reads or writes a scene / render state: fails with ITM_ERR_DEVICE once the scene has raised a
+// fatal status, then launches recorded calls of the scene (whichever render state holds them) and of `rs`.
+int enter_scene(const itm_scene* s, const itm_render_state* rs);
+// Entry points without a handle that write device memory (copies, the view builder) or wait for a stream: recorded calls that read
+// [p, p + bytes) -- or, p == nullptr, that were recorded on `st` -- are launched first.
+int flush_overlapping(const void* p, size_t bytes, hipStream_t st);
+void forget_deferred(itm_render_state* rs);      // the render state is going away
+extern int g_debug_no_deferred_fusion;
+extern int g_debug_force_list_stuck;
+// true when rs holds the block requests of a frame issued ahead (itm_process_frame_ahead): `what` is refused with ITM_ERR_INVALID
+int refuse_while_ahead(const itm_scene* s, const itm_render_state* rs, const char* what);
+
 // entry points implemented per translation unit
 extern int g_debug_explicit_mark;
 extern int g_debug_two_pass_visible_list;
@@ -206,6 +234,9 @@ extern int g_debug_no_directory;
 int launch_request_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, bool onlyVisible, bool fuseRangeInit, hipStream_t st);
 int launch_sweep_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, bool onlyVisible, hipStream_t st);
 int launch_allocate(itm_scene* s, const itm_view* v, itm_render_state* rs, bool onlyVisible, bool fuseRangeInit, hipStream_t st);
+int validate_allocate(const itm_scene* s, const itm_view* v, const itm_render_state* rs, bool onlyVisible);
+int validate_integrate(const itm_scene* s, const itm_view* v);
+int cancel_ahead(itm_scene* s, itm_render_state* rs, hipStream_t st);
 int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipStream_t st, bool fuseProjection = false);
 bool can_fuse_projection(const itm_scene* s, const itm_render_state* rs);
 int launch_find_visible(const itm_scene* s, const float* M, const float* intr, itm_render_state* rs, hipStream_t st);

@@ -263,6 +263,7 @@ int itm_mesh_destroy(itm_mesh* m) { free_mesh(m); return ITM_OK; }
 int itm_mesh_scene(const itm_scene* s, itm_mesh* m, itm_stream stream) {
   if (!s || !m) return set_error(ITM_ERR_INVALID, "null argument");
   if (m->scene != s) return set_error(ITM_ERR_INVALID, "mesh belongs to another scene");
+  { const int rc = enter_scene(s, nullptr); if (rc) return rc; }
   hipStream_t st = as_stream(stream);
   // mesh->triangles->Clear()
   ITM_HIP(hipMemsetAsync(m->triangles, 0, (size_t)m->maxTriangles * 36, st));

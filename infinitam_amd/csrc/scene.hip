@@ -374,6 +374,9 @@ int live_hash_scenes(int device) { return (device >= 0 && device < 64) ? g_liveH
 
 static void free_scene(itm_scene* s) {
   if (!s) return;
+  if (s->deferredRs) forget_deferred(s->deferredRs);      // the scene they were recorded for is going away
+  if (s->aheadRs) { s->aheadRs->ahead.valid = false; s->aheadRs = nullptr; }
+  if (s->fatalHost) (void)hipHostFree((void*)s->fatalHost);
   if (s->countedLive && s->device >= 0 && s->device < 64) g_liveHashScenes[s->device].fetch_sub(1);
   free_swap_state(s);
   if (s->prof) { s->prof->flush(); for (hipEvent_t e : s->prof->pool) (void)hipEventDestroy(e); delete s->prof; }
@@ -384,6 +387,8 @@ static void free_scene(itm_scene* s) {
 }
 static void free_rs(itm_render_state* r) {
   if (!r) return;
+  (void)flush_deferred(r);                                // calls recorded on it still happen (pending.hip)
+  if (r->scene && r->scene->aheadRs == r) const_cast<itm_scene*>(r->scene)->aheadRs = nullptr;
   (void)hipFree(r->range); (void)hipFree(r->raycast); (void)hipFree(r->fwdProj); (void)hipFree(r->missing);
   (void)hipFree(r->image); (void)hipFree(r->visibleIds); (void)hipFree(r->visibleType); (void)hipFree(r->counters);
   (void)hipFree(r->projBuf); (void)hipFree(r->rangePartials); (void)hipFree(r->pixScratch); (void)hipFree(r->pixChunk); (void)hipFree(r->viewFlags); (void)hipFree(r->viewChunkVis);
@@ -426,6 +431,7 @@ int itm_host_malloc(void** p, size_t n) {
 }
 int itm_host_free(void* p) { ITM_HIP(hipHostFree(p)); return ITM_OK; }
 int itm_memcpy_h2d(void* d, const void* s, size_t n, itm_stream st) {
+  { const int rc = flush_overlapping(d, n, as_stream(st)); if (rc) return rc; }     // recorded engine calls that read the target (pending.hip)
   ITM_HIP(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, as_stream(st)));
   return ITM_OK;
 }
@@ -433,7 +439,11 @@ int itm_memcpy_d2h(void* d, const void* s, size_t n, itm_stream st) {
   ITM_HIP(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, as_stream(st)));
   return ITM_OK;
 }
-int itm_stream_synchronize(itm_stream st) { ITM_HIP(hipStreamSynchronize(as_stream(st))); return ITM_OK; }
+int itm_stream_synchronize(itm_stream st) {
+  { const int rc = flush_overlapping(nullptr, 0, as_stream(st)); if (rc) return rc; }   // engine calls recorded on this stream are launched first
+  ITM_HIP(hipStreamSynchronize(as_stream(st)));
+  return ITM_OK;
+}
 int itm_set_device(int d) { ITM_HIP(hipSetDevice(d)); return ITM_OK; }
 
 int itm_scene_create(const itm_scene_config* cfg_in, const itm_scene_params* prm, itm_scene** out) {
@@ -519,6 +529,14 @@ int itm_scene_create(const itm_scene_config* cfg_in, const itm_scene_params* prm
     const int rc = create_swap_state(s);
     if (rc) { free_scene(s); return rc; }
   }
+  // the host-visible status word (itm_internal.h); a device that cannot map host memory runs without it
+  {
+    void* h = nullptr; void* d = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+      memset(h, 0, 64);
+      s->fatalHost = (volatile int32_t*)h; s->fatalDev = (int32_t*)d;
+    } else { if (h) (void)hipHostFree(h); (void)hipGetLastError(); }
+  }
   *out = s;
   return ITM_OK;
 }
@@ -561,6 +579,10 @@ int itm_scene_get_config(const itm_scene* s, itm_scene_config* c, itm_scene_para
 int itm_reset_scene(itm_scene* s, itm_stream stream) {
   if (!s) return set_error(ITM_ERR_INVALID, "null scene");
   hipStream_t st = as_stream(stream);
+  // (no fatal-status check: this is the call that clears it)
+  if (s->deferredRs) { const int rc = flush_deferred(s->deferredRs); if (rc) return rc; }
+  if (s->aheadRs) { const int rc = cancel_ahead(s, s->aheadRs, st); if (rc) return rc; }     // requests issued ahead die with the table
+  if (s->fatalHost && *s->fatalHost) { ITM_HIP(hipStreamSynchronize(st)); *s->fatalHost = 0; }   // nothing still running may raise it again
   const int grid = 2048;
   if (s->cfg.voxelType == ITM_VOXEL_S && (s->numVoxels % 4) == 0) {
     reset_voxels_s_x4_kernel<<<grid, 256, 0, st>>>((uint4*)s->vba, s->numVoxels / 4);
@@ -648,6 +670,7 @@ int itm_debug_divide(int mode, const float* a, const float* b, const float* r, f
 int itm_convert_depth_affine(const int16_t* raw, float* out, int w, int h, float a, float b, itm_stream st) {
   if (!raw || !out || w <= 0 || h <= 0) return set_error(ITM_ERR_INVALID, "bad argument");
   int n = w * h;
+  { const int rc = flush_overlapping(out, (size_t)n * 4, as_stream(st)); if (rc) return rc; }
   depth_affine_kernel<<<(n + 255) / 256, 256, 0, as_stream(st)>>>(raw, out, n, a, b);
   ITM_LAUNCH_CHECK();
   return ITM_OK;
@@ -655,6 +678,7 @@ int itm_convert_depth_affine(const int16_t* raw, float* out, int w, int h, float
 int itm_convert_disparity(const int16_t* raw, float* out, int w, int h, float c0, float c1, float fx, itm_stream st) {
   if (!raw || !out || w <= 0 || h <= 0) return set_error(ITM_ERR_INVALID, "bad argument");
   int n = w * h;
+  { const int rc = flush_overlapping(out, (size_t)n * 4, as_stream(st)); if (rc) return rc; }
   depth_disparity_kernel<<<(n + 255) / 256, 256, 0, as_stream(st)>>>(raw, out, n, c0, c1, fx);
   ITM_LAUNCH_CHECK();
   return ITM_OK;
@@ -687,6 +711,9 @@ int itm_get_counters(const itm_scene* s, const itm_render_state* rs, itm_counter
   if (!out) return set_error(ITM_ERR_INVALID, "null argument");
   memset(out, 0, sizeof *out);
   hipStream_t st = as_stream(stream);
+  // recorded calls first; a fatal status is reported AFTER the counters have been read (they say what happened)
+  if (s && s->deferredRs) { const int frc = flush_deferred(s->deferredRs); if (frc) return frc; }
+  if (rs && rs->deferred.stage) { const int frc = flush_deferred(const_cast<itm_render_state*>(rs)); if (frc) return frc; }
   SceneCounters sc{}; RenderCounters rc{};
   if (s) ITM_HIP(hipMemcpyAsync(&sc, s->counters, sizeof sc, hipMemcpyDeviceToHost, st));
   if (rs) ITM_HIP(hipMemcpyAsync(&rc, rs->counters, sizeof rc, hipMemcpyDeviceToHost, st));
@@ -699,11 +726,12 @@ int itm_get_counters(const itm_scene* s, const itm_render_state* rs, itm_counter
   out->noFwdProjMissingPoints = rc.noFwdProjMissingPoints;
   out->noTotalPoints = rc.noTotalPoints;
   out->noRenderingBlocks = (rc.renderingBlocksAccepted >= 0) ? rc.renderingBlocksAccepted : rc.noRenderingBlocks;
-  return ITM_OK;
+  return enter_scene(s ? s : (rs ? rs->scene : nullptr), nullptr);          // ITM_ERR_DEVICE once the scene has raised a fatal status
 }
 
 int itm_set_counters(itm_scene* s, itm_render_state* rs, const itm_counters* in, itm_stream stream) {
   if (!in) return set_error(ITM_ERR_INVALID, "null argument");
+  { const int rc = enter_scene(s, rs); if (rc) return rc; }
   if (rs) rs->denseRangeReady = false;
   hipStream_t st = as_stream(stream);
   if (s) {
@@ -731,20 +759,25 @@ size_t itm_buffer_bytes(const itm_scene* s, const itm_render_state* rs, int whic
   size_t b; buffer_of(s, rs, which, &b); return b;
 }
 void* itm_buffer_ptr(const itm_scene* s, const itm_render_state* rs, int which) {
+  if (enter_scene(s, rs)) return nullptr;       // (what is recorded now is launched; calls recorded LATER are the holder's to itm_flush)
   size_t b; return buffer_of(s, rs, which, &b);
 }
 int itm_download(const itm_scene* s, const itm_render_state* rs, int which, void* dst, size_t bytes, itm_stream stream) {
   size_t b; void* p = buffer_of(s, rs, which, &b);
   if (!p && bytes == 0) return ITM_OK;
   if (!p || !dst || bytes > b) return set_error(ITM_ERR_INVALID, "bad buffer / size");
+  { const int rc = enter_scene(s, rs); if (rc) return rc; }
+  if (which == ITM_BUF_VISIBLE_TYPE && refuse_while_ahead(s, rs, "download of the visible types")) return ITM_ERR_INVALID;
   hipStream_t st = as_stream(stream);
   ITM_HIP(hipMemcpyAsync(dst, p, bytes, hipMemcpyDeviceToHost, st));
   ITM_HIP(hipStreamSynchronize(st));
-  return ITM_OK;
+  return enter_scene(s, rs);           // a fatal status raised by the work that has just drained
 }
 int itm_upload(itm_scene* s, itm_render_state* rs, int which, const void* src, size_t bytes, itm_stream stream) {
   size_t b; void* p = buffer_of(s, rs, which, &b);
   if (!p || !src || bytes > b) return set_error(ITM_ERR_INVALID, "bad buffer / size");
+  { const int rc = enter_scene(s, rs); if (rc) return rc; }
+  if ((which == ITM_BUF_VISIBLE_IDS || which == ITM_BUF_VISIBLE_TYPE) && refuse_while_ahead(s, rs, "upload of the visible list")) return ITM_ERR_INVALID;
   hipStream_t st = as_stream(stream);
   if (which == ITM_BUF_HASH_ENTRIES) { int rc = accel_unfill(s, st); if (rc) return rc; ++s->tableEpoch; }      // while the table still holds what filled the cubes
   ITM_HIP(hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, st));
@@ -766,6 +799,7 @@ int itm_upload(itm_scene* s, itm_render_state* rs, int which, const void* src, s
 
 int itm_export_visible_record(const itm_render_state* rs, const float M_d[16], int max_ids, void* dst, itm_stream stream) {
   if (!rs || !rs->hash || !dst || !M_d || max_ids < 0) return set_error(ITM_ERR_INVALID, "bad argument");
+  { const int rc = enter_scene(rs->scene, rs); if (rc) return rc; }
   Mat4 M; memcpy(M.m, M_d, 64);
   int n = (max_ids > 17 ? max_ids : 17);
   export_record_kernel<<<(n + 255) / 256, 256, 0, as_stream(stream)>>>(rs->visibleIds, rs->counters, M, max_ids, (int32_t*)dst);

@@ -166,15 +166,25 @@ __global__ void __launch_bounds__(512) swap_combine_kernel(const int32_t* __rest
 // entry's ptr becomes -1, the block is reset and its cells are emptied.  Successes are a prefix of the candidates (the bound is on a
 // counter that only the successes advance), so candidate i succeeds iff lastFree + i < bucketNum - 1.
 template <class VX>
-__global__ void __launch_bounds__(512) swap_out_kernel(const int32_t* __restrict__ ids, void* __restrict__ xfer, uint4* __restrict__ hash, void* __restrict__ vba,
+__global__ void __launch_bounds__(512) swap_out_kernel(const int32_t* __restrict__ ids, void* __restrict__ xfer, uint4* hash, void* __restrict__ vba,
                                                        uint8_t* __restrict__ states, int32_t* __restrict__ allocList, const SceneCounters* __restrict__ counters,
                                                        int bucketNum, int localBlockNum, int32_t* __restrict__ dirPtr, int32_t* __restrict__ dirSlot, void* __restrict__ mirror, AccelOrigin org) {
   const int i = blockIdx.x, id = ids[i], t = threadIdx.x;
-  const uint4 raw = hash[id];
+  // the entry is read by ONE thread and handed to the others through LDS: thread 0 rewrites hash[id] below, and nothing else would
+  // order that store after a late wave's load of the same entry
+  __shared__ uint4 rawShared;
+  if (t == 0) rawShared = hash[id];
+  __syncthreads();
+  const uint4 raw = rawShared;
   const HashEntry he = unpack_entry(raw);
   const size_t vi = (size_t)he.ptr * kBlockVoxels + t;
   VX::store(xfer, (size_t)i * kBlockVoxels + t, VX::load(vba, vi));
-  const int vbaIdx = counters->lastFreeBlockId + i;
+  // An exhausted pool leaves lastFreeBlockId BELOW -1 (the allocation sweep keeps decrementing it for every request it cannot serve,
+  // _CPU.cpp:189,206), where the reference's `voxelAllocationList[vbaIdx + 1]` is an access in front of the list.  Here (and in the
+  // oracle) such a counter counts as -1 = "list empty": the first freed block becomes allocationList[0] and the counter goes to 0,
+  // so the blocks a swap-out frees are handed out again -- which is what swapping exists for.
+  const int lastFree = counters->lastFreeBlockId < -1 ? -1 : counters->lastFreeBlockId;
+  const int vbaIdx = lastFree + i;
   // (the second bound never binds in a consistent scene -- freed blocks were allocated before -- it keeps an uploaded, inconsistent
   // counter from writing past the list, where the reference would)
   const bool release = vbaIdx < bucketNum - 1 && vbaIdx + 1 < localBlockNum;
@@ -195,7 +205,7 @@ __global__ void __launch_bounds__(512) swap_out_kernel(const int32_t* __restrict
   }
 }
 __global__ void swap_out_commit_kernel(SceneCounters* __restrict__ counters, const int32_t* __restrict__ ids, int cap, int bucketNum, int localBlockNum) {
-  const int L = counters->lastFreeBlockId, n = ids[cap];
+  const int L = counters->lastFreeBlockId < -1 ? -1 : counters->lastFreeBlockId, n = ids[cap];      // (as in swap_out_kernel)
   int room = (bucketNum - 1 < localBlockNum - 1 ? bucketNum - 1 : localBlockNum - 1) - L;
   room = room < 0 ? 0 : room;
   counters->lastFreeBlockId = L + (n < room ? n : room);
@@ -251,6 +261,7 @@ extern "C" {
 int itm_swap_integrate_global_into_local(itm_scene* s, itm_render_state* rs, itm_stream stream) {
   if (!s || !rs || !s->swapHost) return set_error(ITM_ERR_INVALID, "scene without swapping");
   if (rs->scene != s) return set_error(ITM_ERR_INVALID, "render state belongs to another scene");
+  { const int rc = enter_scene(s, rs); if (rc) return rc; }
   SwapHost* h = s->swapHost;
   hipStream_t st = as_stream(stream);
   const size_t blockBytes = (size_t)kBlockVoxels * s->voxBytes;
@@ -283,6 +294,7 @@ int itm_swap_integrate_global_into_local(itm_scene* s, itm_render_state* rs, itm
 int itm_swap_save_to_global_memory(itm_scene* s, itm_render_state* rs, itm_stream stream) {
   if (!s || !rs || !s->swapHost) return set_error(ITM_ERR_INVALID, "scene without swapping");
   if (rs->scene != s) return set_error(ITM_ERR_INVALID, "render state belongs to another scene");
+  { const int rc = enter_scene(s, rs); if (rc) return rc; }
   SwapHost* h = s->swapHost;
   hipStream_t st = as_stream(stream);
   const size_t blockBytes = (size_t)kBlockVoxels * s->voxBytes;

@@ -110,6 +110,7 @@ extern "C" {
 
 int itm_filter_depth(const float* in, float* out, int w, int h, itm_stream stream) {
   if (!in || !out || in == out || w <= 0 || h <= 0) return set_error(ITM_ERR_INVALID, "bad argument");
+  { const int rc = flush_overlapping(out, (size_t)w * h * 4, as_stream(stream)); if (rc) return rc; }
   const dim3 grid((w + 15) / 16, (h + 15) / 16);
   filter_depth_kernel<<<grid, 256, 0, as_stream(stream)>>>(in, out, w, h);
   ITM_LAUNCH_CHECK();
@@ -232,6 +233,23 @@ int itm_depth_stager_upload(itm_depth_stager* g, const int16_t* host) {
   }
   ITM_HIP(hipEventRecord(g->uploaded[b], g->copy));
   g->tail.store(tail + 1, std::memory_order_release);
+  return ITM_OK;
+}
+
+// How many uploaded frames have not been acquired yet, and whether the copy stream still has to READ a host buffer: *busy == 0 means
+// every pinned buffer handed to itm_depth_stager_upload so far may be rewritten (hipEventQuery of the newest upload, no waiting).
+int itm_depth_stager_pending(itm_depth_stager* g, int* waiting, int* busy) {
+  if (!g) return set_error(ITM_ERR_INVALID, "null argument");
+  const unsigned long long tail = g->tail.load(std::memory_order_acquire), head = g->head.load(std::memory_order_acquire);
+  if (waiting) *waiting = (int)(tail - head) - (g->held ? 1 : 0);
+  if (busy) {
+    *busy = 0;
+    if (tail > 0) {
+      const hipError_t q = hipEventQuery(g->uploaded[(int)((tail - 1) % (unsigned long long)g->slots)]);
+      if (q == hipErrorNotReady) *busy = 1;
+      else if (q != hipSuccess) return hip_fail(q, "hipEventQuery(upload)", __FILE__, __LINE__);
+    }
+  }
   return ITM_OK;
 }
 

@@ -539,6 +539,7 @@ int launch_icp_maps(const itm_scene* s, const itm_view* v, itm_render_state* rs,
   if (issueAhead) {
     icp_maps_init_next_kernel<<<grid, 256, 0, st>>>(rs->raycast, points, normals, rs->image, p, rs->range, rs->counters);
     rs->ahead.tableEpoch = sceneForNext->tableEpoch;
+    sceneForNext->aheadRs = rs;
     rs->ahead.valid = true; rs->ahead.depth = next->depth; rs->ahead.w = next->w; rs->ahead.h = next->h; rs->ahead.lazy = true;
     memcpy(rs->ahead.M_d, next->M_d, 64); memcpy(rs->ahead.intr_d, next->intr_d, 16);
   } else {
@@ -625,32 +626,24 @@ int itm_debug_set(int key, int value) {
   if (key == ITM_DEBUG_DENSE_CLASSIFY) { g_debug_dense_classify = value; return ITM_OK; }
   if (key == ITM_DEBUG_TRACKER_SESSION_UNUSABLE) { g_debug_tracker_session_unusable = value; return ITM_OK; }
   if (key == ITM_DEBUG_DENSE_NO_STRIPS) { g_debug_dense_no_strips = value; return ITM_OK; }
+  if (key == ITM_DEBUG_NO_DEFERRED_FUSION) { g_debug_no_deferred_fusion = value; return ITM_OK; }
+  if (key == ITM_DEBUG_FORCE_LIST_STUCK) { g_debug_force_list_stuck = value; return ITM_OK; }
   return set_error(ITM_ERR_INVALID, "unknown debug key");
-}
-
-int itm_create_expected_depths(const itm_scene* s, const float M[16], const float intr[4], itm_render_state* rs, itm_stream stream) {
-  if (!s || !M || !intr || !rs) return set_error(ITM_ERR_INVALID, "null argument");
-  if (rs->scene != s) return set_error(ITM_ERR_INVALID, "render state belongs to another scene");
-  return launch_expected_depths(s, M, intr, rs, false, as_stream(stream), false);
 }
 
 int itm_find_surface(const itm_scene* s, const float M[16], const float intr[4], itm_render_state* rs, itm_stream stream) {
   if (!s || !M || !intr || !rs) return set_error(ITM_ERR_INVALID, "null argument");
   if (rs->scene != s) return set_error(ITM_ERR_INVALID, "render state belongs to another scene");
+  { const int rc = enter_scene(s, rs); if (rc) return rc; }
   float invM[16];
   if (!invert4(M, invM)) return set_error(ITM_ERR_INVALID, "pose matrix is singular");
   return launch_raycast(s, invM, intr, rs, rs->raycast, as_stream(stream));
 }
 
-int itm_create_icp_maps(const itm_scene* s, const itm_view* v, itm_render_state* rs, float* points, float* normals, itm_stream stream) {
-  if (!s || !v || !rs || !points || !normals) return set_error(ITM_ERR_INVALID, "null argument");
-  if (rs->scene != s) return set_error(ITM_ERR_INVALID, "render state belongs to another scene");
-  return launch_icp_maps(s, v, rs, (float4*)points, (float4*)normals, as_stream(stream));
-}
-
 int itm_render_image(const itm_scene* s, const float M[16], const float intr[4], itm_render_state* rs, uint8_t* out, int type, itm_stream stream) {
   if (!s || !M || !intr || !rs) return set_error(ITM_ERR_INVALID, "null argument");
   if (rs->scene != s) return set_error(ITM_ERR_INVALID, "render state belongs to another scene");
+  { const int rc = enter_scene(s, rs); if (rc) return rc; }
   return launch_render_image(s, M, intr, rs, out ? (uchar4*)out : rs->image, type, as_stream(stream));
 }
 
@@ -670,6 +663,7 @@ int itm_process_frame_ahead(itm_scene* s, const itm_view* v, const itm_view* nex
   if (rs->scene != s || v->w != rs->w || v->h != rs->h) return set_error(ITM_ERR_INVALID, "view / render state mismatch");
   hipStream_t st = as_stream(stream);
   int rc;
+  if ((rc = enter_scene(s, rs))) return rc;
   const bool hashScene = s->cfg.indexType == ITM_INDEX_HASH;
   if (hashScene && (rc = launch_allocate(s, v, rs, false, true, st))) return rc;
   const bool fuse = hashScene && can_fuse_projection(s, rs);

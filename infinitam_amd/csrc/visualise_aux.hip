@@ -226,12 +226,14 @@ int itm_forward_render(const itm_scene* s, const itm_view* v, itm_render_state* 
   if (!s || !v || !rs) return set_error(ITM_ERR_INVALID, "null argument");
   if (!v->depth) return set_error(ITM_ERR_INVALID, "null depth image");
   if (rs->scene != s || v->w != rs->w || v->h != rs->h) return set_error(ITM_ERR_INVALID, "view / render state mismatch");
+  { const int rc = enter_scene(s, rs); if (rc) return rc; }
   return launch_forward_render(s, v, rs, as_stream(stream));
 }
 
 int itm_create_point_cloud(const itm_scene* s, const itm_view* v, itm_render_state* rs, int skipPoints, float* locations, float* colours, itm_stream stream) {
   if (!s || !v || !rs || !locations || !colours) return set_error(ITM_ERR_INVALID, "null argument");
   if (rs->scene != s) return set_error(ITM_ERR_INVALID, "render state belongs to another scene");
+  { const int rc = enter_scene(s, rs); if (rc) return rc; }
   return launch_point_cloud(s, v, rs, skipPoints != 0, (float4*)locations, (float4*)colours, as_stream(stream));
 }
 

@@ -709,6 +709,8 @@ template <class V>
 void swap_save_t(itm_scene* s, itm_render_state* rs) {
   const int N = s->noTotalEntries, cap = s->transferBlockNum();
   V* vba = (V*)s->vba.data();
+  // (an exhausted pool leaves the counter below -1, where the reference writes in front of the list: counted as -1 = "list empty",
+  // as the product does -- outside the reference's defined behaviour)
   int noNeeded = 0, noAllocated = s->lastFreeBlockId;
   for (int e = 0; e < N; ++e) {
     if (noNeeded >= cap) break;
@@ -718,8 +720,9 @@ void swap_save_t(itm_scene* s, itm_render_state* rs) {
       s->hasStoredData[e] = 1;
       std::memcpy(s->storedBlocks + (size_t)e * 512 * sizeof(V), loc, 512 * sizeof(V));
       s->swapStates[e] = 0;
+      if (noAllocated < -1) noAllocated = -1;                    // (a call without candidates leaves the counter as it found it)
       const int vbaIdx = noAllocated;
-      if (vbaIdx < s->cfg.bucketNum - 1) {                       // (sic: SDF_BUCKET_NUM, ITMSwappingEngine_CPU.cpp:146)
+      if (vbaIdx < s->cfg.bucketNum - 1 && vbaIdx + 1 < s->cfg.localBlockNum) {   // (sic: SDF_BUCKET_NUM, ITMSwappingEngine_CPU.cpp:146; the second bound only guards an inconsistent uploaded counter)
         noAllocated++;
         s->allocList[vbaIdx + 1] = localPtr;
         s->hash[e].ptr = -1;
@@ -1413,6 +1416,9 @@ int itmo_process_frame(itm_scene* s, const itm_view* v, itm_render_state* rs, fl
 int itmo_process_frame_ahead(itm_scene* s, const itm_view* v, const itm_view*, itm_render_state* rs, float* pts, float* nrm, itm_stream st) {
   return itmo_process_frame(s, v, rs, pts, nrm, st);
 }
+// (recording calls and requests issued ahead are launch-level matters of the product: nothing is ever pending here)
+int itmo_flush(itm_scene*, itm_render_state*, itm_stream) { return ITM_OK; }
+int itmo_cancel_ahead(itm_scene*, itm_render_state*, itm_stream) { return ITM_OK; }
 
 // convertDepthAffineToFloat / convertDisparityToDepth  DeviceAgnostic/ITMViewBuilder.h:7-28
 int itmo_convert_depth_affine(const int16_t* raw, float* out, int w, int h, float a, float b, itm_stream) {

@@ -374,6 +374,8 @@ int itmr_process_frame(itm_scene* s, const itm_view* v, itm_render_state* r, flo
 int itmr_process_frame_ahead(itm_scene* s, const itm_view* v, const itm_view*, itm_render_state* r, float* pts, float* nrm, itm_stream st) {
   return itmr_process_frame(s, v, r, pts, nrm, st);
 }
+int itmr_flush(itm_scene*, itm_render_state*, itm_stream) { return ITM_OK; }          // (nothing is ever recorded or issued ahead here)
+int itmr_cancel_ahead(itm_scene*, itm_render_state*, itm_stream) { return ITM_OK; }
 
 // ---- meshing: the reference's ITMMesh + ITMMeshingEngine_CPU ----------------------------------------------------------------
 struct itm_mesh { const itm_scene* scene; ITMMesh* mesh; };

@@ -178,14 +178,21 @@ class Session:
                     w_rgb=sc.w, h_rgb=sc.h, intr_rgb=sc.intr())
 
     def frame(self, k, fused=False) -> View:
+        """fused=True: itm_process_frame.  fused=False: the four engine calls, each LAUNCHED before the next is made (itm_flush in
+        between: the separate kernels of every call).  fused="four": the four calls back to back, as ITMMainEngine::ProcessFrame
+        issues them -- the product records the first three and launches the fused frame at the fourth (pending.hip)."""
         v = self.view(k)
         s, rs = self.scene, self.rs
-        if fused:
+        if fused is True:
             s.process_frame(v, rs, self.points, self.normals)
         else:
+            sep = fused is False
             s.reco.AllocateSceneFromDepth(v, rs)
+            if sep: s.flush(rs)
             s.reco.IntegrateIntoScene(v, rs)
+            if sep: s.flush(rs)
             s.vis.CreateExpectedDepths(v.M_d, v.intr_d, rs)
+            if sep: s.flush(rs)
             s.vis.CreateICPMaps(v, rs, self.points, self.normals)
         return v
 

@@ -64,6 +64,13 @@ def test_the_stager_refuses_what_would_lose_or_reorder_a_frame(hip):
         hip.check(hip.fn["depth_stager_release"](g, None), "release")
         hip.check(hip.fn["depth_stager_upload"](g, raws[2].ctypes.data_as(C.c_void_p)), "upload")
         hip.sync()
+        # the upload-done query: two frames wait to be acquired; once the copy stream has drained no host buffer is still being read
+        waiting, busy = C.c_int(-1), C.c_int(-1)
+        for _ in range(2000):
+            hip.check(hip.fn["depth_stager_pending"](g, C.byref(waiting), C.byref(busy)), "pending")
+            if busy.value == 0:
+                break
+        assert waiting.value == 2 and busy.value == 0
         assert hip.fn["depth_stager_create"](W, H, 1, C.byref(dev)) == capi.ERR_INVALID
     finally:
         hip.check(hip.fn["depth_stager_destroy"](g), "destroy")

@@ -73,7 +73,45 @@ def test_a_frame_other_than_the_announced_one_is_refused(hip):
         ses.scene.process_frame(v[2], ses.rs, ses.points, ses.normals)           # not the announced view
     ses.scene.process_frame(v[1], ses.rs, ses.points, ses.normals)               # the announced one goes through
     ses.scene.process_frame_ahead(v[2], v[0], ses.rs, ses.points, ses.normals)
-    ses.scene.reco.ResetScene()                                                  # the table the requests were made against is gone
-    with pytest.raises(capi.ItmError):
-        ses.scene.process_frame(v[0], ses.rs, ses.points, ses.normals)
+    # while the requests are pending the visible types carry their marks: the list cannot be read, saved, rewritten or rebuilt,
+    # and no other render state of the scene may allocate
+    with pytest.raises(capi.ItmError, match="issued ahead"):
+        ses.scene.download(capi.BUF_VISIBLE_TYPE, ses.rs)
+    with pytest.raises(capi.ItmError, match="issued ahead"):
+        ses.scene.vis.FindVisibleBlocks(sc.pose(0), sc.intr(), ses.rs)
+    with pytest.raises(capi.ItmError, match="issued ahead"):
+        ses.scene.upload(capi.BUF_VISIBLE_IDS, np.zeros(16, np.int32), ses.rs)
+    other = ses.scene.vis.CreateRenderState((sc.w, sc.h))
+    with pytest.raises(capi.ItmError, match="another render state"):
+        ses.scene.reco.AllocateSceneFromDepth(v[0], other)
+        ses.scene.flush(other)
+    other.close()
+    ses.scene.reco.ResetScene()                                                  # the table the requests were made against is gone, and so are they
+    ses.scene.process_frame(v[1], ses.rs, ses.points, ses.normals)               # any view may follow
+    assert ses.scene.counters(ses.rs)["noVisibleEntries"] > 0
     ses.close()
+
+
+@pytest.mark.gpu
+def test_cancelled_requests_leave_no_trace(hip, oracle):
+    """itm_cancel_ahead: the frames after it -- for ANOTHER view than the announced one, through the four separate calls -- equal the
+    oracle's, and the visible types read like the reference's after its "previous list -> 3" loop."""
+    sc = T.Scenario(name="ahead_cancel", voxelSize=0.005, frames=6, trajectory="bench")
+    ses, ref = T.Session(hip, sc), T.Session(oracle, sc)
+    d = [hip.to_backend(sc.depth(k)) for k in range(sc.frames)]
+    v = [capi.View(d[k], sc.w, sc.h, M_d=sc.pose(k), intr_d=sc.intr()) for k in range(sc.frames)]
+    ses.scene.process_frame_ahead(v[0], v[1], ses.rs, ses.points, ses.normals)
+    ses.scene.process_frame_ahead(v[1], v[2], ses.rs, ses.points, ses.normals)
+    ses.scene.cancel_ahead(ses.rs)
+    types = ses.scene.download(capi.BUF_VISIBLE_TYPE, ses.rs)
+    ref.frame(0); ref.frame(1)
+    want = np.where(ref.scene.download(capi.BUF_VISIBLE_TYPE, ref.rs) > 0, 3, 0).astype(np.uint8)
+    assert np.array_equal(types, want), "types after the cancellation"
+    for k in (4, 5, 3):                                                          # not the announced frame 2
+        ses.view = lambda kk, _v=v: _v[kk]
+        ses.frame(k, fused=(k == 5))
+        ref.frame(k)
+    a, b = ses.snapshot(), ref.snapshot()
+    a.counters = [ses.scene.counters(ses.rs)]; b.counters = [ref.scene.counters(ref.rs)]
+    T.compare_results(a, b, sc, what="after itm_cancel_ahead")
+    ses.close(); ref.close()

@@ -30,9 +30,9 @@ def poses_and_depths():
     return intr, seq
 
 
-def run(be, voxel=capi.VOXEL_S, colour=False, frames=None):
+def run(be, voxel=capi.VOXEL_S, colour=False, frames=None, localBlockNum=0):
     intr, seq = poses_and_depths()
-    s = be.create_scene(voxel, capi.INDEX_HASH, capi.default_params(voxelSize=0.005), useSwapping=True)
+    s = be.create_scene(voxel, capi.INDEX_HASH, capi.default_params(voxelSize=0.005), useSwapping=True, localBlockNum=localBlockNum)
     s.reco.ResetScene()
     rs = s.vis.CreateRenderState((W, H))
     P = W * H
@@ -112,3 +112,39 @@ def test_hip_swapping_equals_the_oracle(hip, oracle, voxel, colour):
     a, b = run(hip, voxel, colour), run(oracle, voxel, colour)
     compare(a, b, "hip vs oracle")
     sanity(a)
+
+
+# ---- a pool that runs dry before the camera turns away ------------------------------------------------------------------------------
+# The allocation sweep keeps decrementing lastFreeBlockId for every request it cannot serve (_CPU.cpp:189,206), so an exhausted pool
+# leaves the counter BELOW -1; the reference's SaveToGlobalMemory then writes voxelAllocationList[vbaIdx + 1] in front of the list
+# (undefined).  Product and oracle count such a counter as -1: the blocks a swap-out frees go back on the list from index 0 and are
+# handed out again -- the situation swapping exists for.
+SMALL_POOL = 0x800
+
+
+def sanity_small_pool(frames):
+    assert min(f["counters"]["lastFreeBlockId"] for f in frames[:3]) < -1, "the pool never ran dry"
+    assert int(np.count_nonzero(frames[2]["hash"]["ptr"] >= 0)) == SMALL_POOL, "every block of the pool is in use before the camera turns"
+    away = frames[3:7]
+    assert max(f["counters"]["lastFreeBlockId"] for f in away) >= 0, "the swap-out put no block back on the list"
+    assert any(int(np.count_nonzero(f["hash"]["ptr"] == -1)) > 0 for f in away)
+    for f in frames:
+        n = f["counters"]["lastFreeBlockId"] + 1
+        free = f["alloc"][:max(n, 0)]
+        assert len(np.unique(free)) == len(free) and (free >= 0).all() and (free < SMALL_POOL).all(), "free list corrupt"
+        used = f["hash"]["ptr"][f["hash"]["ptr"] >= 0]
+        assert len(np.unique(used)) == len(used), "a voxel block is owned by two entries"
+        assert not np.intersect1d(used, free).size, "a voxel block is both free and in use"
+    # the blocks that came back were allocated again
+    assert int(np.count_nonzero(frames[-1]["hash"]["ptr"] >= 0)) > SMALL_POOL // 2
+
+
+def test_oracle_swapping_with_an_exhausted_pool_recycles_the_freed_blocks(oracle):
+    sanity_small_pool(run(oracle, localBlockNum=SMALL_POOL))
+
+
+@pytest.mark.gpu
+def test_hip_swapping_with_an_exhausted_pool_equals_the_oracle(hip, oracle):
+    a, b = run(hip, localBlockNum=SMALL_POOL), run(oracle, localBlockNum=SMALL_POOL)
+    compare(a, b, "hip vs oracle (small pool)")
+    sanity_small_pool(a)
