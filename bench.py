@@ -2,9 +2,17 @@
 """bench.py -- fused depth frames/s of the TSDF hot path on MI355X (BASELINE.json metric).
 
 One "step" = one depth frame through the per-frame call sequence of ITMMainEngine::ProcessFrame after the
-view is built (reference Engine/ITMMainEngine.cpp:123-126): AllocateSceneFromDepth + IntegrateIntoScene +
-CreateExpectedDepths + CreateICPMaps, issued through the C-ABI (itm_process_frame) with the float depth
-frames already resident in HBM.
+view is built (reference Engine/ITMMainEngine.cpp:123-126): AllocateSceneFromDepth + IntegrateIntoScene
+(Engine/ITMDenseMapper.cpp:50-57) + CreateExpectedDepths + CreateICPMaps (Engine/ITMTrackingController.cpp:30-46),
+issued as those FOUR calls through the C-ABI -- what a drop-in back-end is called with -- with the float depth
+frames already resident in HBM.  `value` is that figure.  Beside it, never as `value`: the same frames through the
+single entry point itm_process_frame and through itm_process_frame_ahead (which needs the NEXT frame's pose before
+this frame is done: fine for an offline sequence, impossible for a closed tracking loop).
+
+Short runs: with --steps < 100 the timed region (exactly --steps frames between two barriers) is repeated until at
+least 0.25 s have been measured; `value` / `ms_per_step` are those of the MEDIAN repetition, `repetitions` says how
+many there were.  The roofline kernel is never timed inside the timed region: one extra, untimed repetition brackets
+EVERY launch of it (and of the integration and the visible-list launch) with HIP events, at least 64 samples.
 
 Workloads (--config, names in config.workload):
   2 (default, the headline): BASELINE configs[1] -- synthetic 640x480 depth (sphere + wall, SURVEY 8d bench
@@ -74,8 +82,12 @@ def parse():
                     help="independent scenes co-scheduled on one GPU, each on its own HIP stream (separate figure; headline is 1)")
     ap.add_argument("--no-host-threads", dest="host_threads", action="store_false",
                     help="feed the k streams of --streams-per-gpu from one host thread instead of one thread per stream")
-    ap.add_argument("--timer-every", type=int, default=8,
-                    help="bracket the roofline kernel with HIP events on every n-th frame of the timed region")
+    ap.add_argument("--timer-frames", type=int, default=0,
+                    help="frames of the extra, untimed repetition in which every launch of the roofline kernel is bracketed by HIP events (0 = max(--steps, 64))")
+    ap.add_argument("--frame-call", choices=["four", "process_frame", "ahead"], default="four",
+                    help="how the timed region issues a frame: the reference's four engine calls (default, the headline), itm_process_frame, or "
+                         "itm_process_frame_ahead (a marked line: the next frame's pose is handed over before this frame is done)")
+    ap.add_argument("--min-measured-s", type=float, default=0.25, help="runs with --steps < 100 repeat the timed region until this much has been measured")
     ap.add_argument("--raw-serial", action="store_true", help="raw-depth legs: the upload on the frame's own stream instead of the library's stager (A/B)")
     ap.add_argument("--raw-depth", action="store_true",
                     help="SURVEY 8d second figure as the run's value: each step uploads the 16-bit raw frame from pinned host memory "
@@ -83,9 +95,6 @@ def parse():
     ap.add_argument("--origin-offset", default="0,0,0",
                     help="X,Y,Z metres added to every camera position (scene and trajectory translated together: same depth images, "
                          "block coordinates far from the world origin)")
-    ap.add_argument("--no-lookahead", action="store_true",
-                    help="itm_process_frame instead of itm_process_frame_ahead (the next frame's block requests beside this frame's ICP maps; "
-                         "the frames are resident, so the next view is always known)")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the secondary measurements of the default run (PCIe-inclusive rate, table-walk ray cast, stream-copy peak)")
     ap.add_argument("--lib", default=None, help="alternative shared library exporting the same C-ABI (tests: a host-memory backend)")
@@ -264,7 +273,9 @@ def worker(args) -> int:
             hs = torch.cuda.current_stream() if k_streams == 1 else torch.cuda.Stream()
         streams.append(Stream(be, capi, synth, torch, wl, rank * k_streams + j, device, hs, offset=offset, raw=args.raw_depth))
     fn = be.fn["process_frame"]
-    fn_ahead = be.fn["process_frame_ahead"] if (product and wl["index"] == "hash" and not args.no_lookahead) else None
+    fn_ahead = be.fn["process_frame_ahead"]
+    fn_alloc, fn_integrate, fn_expected, fn_icp = (be.fn[n] for n in ("allocate_scene_from_depth", "integrate_into_scene", "create_expected_depths", "create_icp_maps"))
+    can_ahead = product and wl["index"] == "hash"
     fn_view = be.fn["update_view"]
 
     exchange = (world > 1 and not args.no_exchange) or args.force_exchange
@@ -326,7 +337,19 @@ def worker(args) -> int:
         from infinitam_amd.streams import VisibleListExchange
         exs = [VisibleListExchange(be, world, rank, MAX_IDS, device=device, batch=max(1, args.exchange_batch)) for _ in streams]
 
-    mode = {"raw": args.raw_depth}
+    # "call": how a frame is issued -- "four" = the reference's four engine calls (the library records three and launches the fused
+    # frame at the fourth, infinitam_amd/csrc/pending.hip), "process_frame" = the single entry point, "ahead" = itm_process_frame_ahead
+    mode = {"raw": args.raw_depth, "call": (args.frame_call if (args.frame_call != "ahead" or can_ahead) else "process_frame")}
+
+    def issue(s, v, view, nxt):
+        """One frame of stream s for view struct `view` (a ViewStruct); nxt = the view that follows, or None."""
+        c = mode["call"]
+        if c == "four":
+            return (fn_alloc(s.sh, v, s.rh, 0, s.sp) or fn_integrate(s.sh, v, s.rh, s.sp) or fn_expected(s.sh, view.M_d, view.intr_d, s.rh, s.sp)
+                    or fn_icp(s.sh, v, s.rh, s.pp, s.np_, s.sp))
+        if c == "ahead":
+            return fn_ahead(s.sh, v, (C.byref(nxt) if nxt is not None else None), s.rh, s.pp, s.np_, s.sp)
+        return fn(s.sh, v, s.rh, s.pp, s.np_, s.sp)
 
     def step_stream(j, k, last=False):
         s = streams[j]
@@ -360,14 +383,12 @@ def worker(args) -> int:
                 be.check(rc, "update_view")
             if s.stager is not None and not args.raw_serial:
                 be.check(be.fn["depth_stager_release"](s.stager, s.sp), "depth_stager_release")      # (the conversion is what read the slot)
-            rc = fn(s.sh, C.byref(s.raw_views[i]), s.rh, s.pp, s.np_, s.sp)
-        elif fn_ahead is not None:
-            # the last frame of a run() names no successor: the next leg may start anywhere
-            rc = fn_ahead(s.sh, C.byref(s.views[i]), (None if last else C.byref(s.views[(k + 1) % s.nd])), s.rh, s.pp, s.np_, s.sp)
+            rc = issue(s, C.byref(s.raw_views[i]), s.raw_views[i], None)       # (the converted image is ONE buffer: no frame can be announced ahead)
         else:
-            rc = fn(s.sh, C.byref(s.views[i]), s.rh, s.pp, s.np_, s.sp)
+            # the last frame of a run() names no successor: the next leg may start anywhere
+            rc = issue(s, C.byref(s.views[i]), s.views[i], (None if last else s.views[(k + 1) % s.nd]))
         if rc:
-            be.check(rc, "process_frame")
+            be.check(rc, "frame (" + mode["call"] + ")")
         if exchange:
             # record copy on the frame stream, all-gather on a side stream (off the critical path)
             exs[j].step(s.rs.h, s.poses_c[i], s.hip_stream)
@@ -416,24 +437,58 @@ def worker(args) -> int:
     run(0, args.warmup)
     barrier()
     timed_kernel = TK[wl["kernel"]]
-    if rank == 0 and product:
-        streams[0].scene.profile_read(reset=True)
-        streams[0].scene.profile_enable(1 << timed_kernel)   # a hipEventRecord pair around the roofline kernel,
-        streams[0].scene.profile_sample(args.timer_every)    # on every timer_every-th frame
-    t0 = time.perf_counter()
-    run(args.warmup, args.warmup + args.steps)
-    barrier()
-    elapsed_local = time.perf_counter() - t0
-    elapsed = elapsed_local
+
+    def timed_region(first):
+        """EXACTLY --steps frames between two barriers; returns the MAX over ranks of the elapsed time (and this rank's own)."""
+        barrier()
+        t0 = time.perf_counter()
+        run(first, first + args.steps)
+        barrier()
+        mine = time.perf_counter() - t0
+        if world == 1:
+            return mine, mine
+        tt = torch.tensor([mine], dtype=torch.float64, device=ctl_device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item()), mine
+
+    # Short runs are repeated: 20 frames are 1.7 ms, less than the jitter of one host wake-up.  The number of repetitions follows from
+    # the first one (the same on every rank: it is computed from the all-reduced time), the MEDIAN repetition is the one reported.
+    reps = [timed_region(args.warmup)]
+    if args.steps < 100 and args.min_measured_s > 0:
+        want = int(min(2000, max(0, -(-args.min_measured_s // max(reps[0][0], 1e-6)) - 1)))
+        for r in range(want):
+            reps.append(timed_region(args.warmup + (r + 1) * args.steps))
+    order = sorted(range(len(reps)), key=lambda r: reps[r][0])
+    med = order[len(order) // 2]
+    elapsed, elapsed_local = reps[med]
     fps_minmax = None
     if world > 1:
-        tt = torch.tensor([elapsed_local], dtype=torch.float64, device=ctl_device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
         tn = torch.tensor([elapsed_local], dtype=torch.float64, device=ctl_device)
         dist.all_reduce(tn, op=dist.ReduceOp.MIN)
         per = k_streams * args.steps
         fps_minmax = [round(per / elapsed, 1), round(per / float(tn.item()), 1)]
+    rep_stats = {"count": len(reps), "measured_s": round(sum(t for t, _ in reps), 4),
+                 "fps_min_median_max": [round(world * k_streams * args.steps / reps[order[-1]][0], 1), round(world * k_streams * args.steps / elapsed, 1),
+                                        round(world * k_streams * args.steps / reps[order[0]][0], 1)]}
+
+    # ---- the roofline kernel: one extra, UNTIMED repetition with an event pair around EVERY launch of it (and of the integration and
+    # the visible-list launch), then empty brackets on the same stream for what an event pair itself adds to an interval ----
+    kernel_times = None
+    if rank == 0 and product and on_gpu:
+        s0 = streams[0]
+        nt = args.timer_frames if args.timer_frames > 0 else max(args.steps, 64)
+        timed_set = sorted({timed_kernel, TK["integrate"], TK["visible_list"], TK["raycast"]} if wl["index"] == "hash" else {timed_kernel, TK["raycast"]})
+        s0.scene.profile_read(reset=True)
+        s0.scene.profile_enable(sum(1 << t for t in timed_set))
+        s0.scene.profile_sample(1)
+        run(args.warmup, args.warmup + nt)
+        sync()
+        s0.scene.profile_calibrate(64, s0.hip_stream.cuda_stream if s0.hip_stream is not None else None)
+        sync()
+        kernel_times = s0.scene.profile_read(reset=True)
+        s0.scene.profile_enable(0)
+    if world > 1:
+        barrier()
 
     # what the exchange costs THIS run: the same frames once more without it (every rank, no collective involved)
     exchange_cost = None
@@ -453,15 +508,35 @@ def worker(args) -> int:
 
     counters = streams[0].scene.counters(streams[0].rs)
     roofline = None
-    if rank == 0 and product:
-        roofline = read_roofline(args.config, wl, streams[0].scene, counters, args.timer_every)
-        streams[0].scene.profile_enable(0)
+    if rank == 0 and product and kernel_times is not None:
+        roofline = read_roofline(args.config, wl, kernel_times, counters, streams[0].scene)
 
     # ---- secondary figures of the default single-GPU run (after the timed region; none of them is `value`) --------------------
     extra = {}
     if rank == 0 and world == 1 and product and k_streams == 1 and on_gpu and not exchange and not args.no_extra_legs and not args.raw_depth:
         s0 = streams[0]
-        n2 = args.steps
+        n2 = max(args.steps, 100)
+
+        def leg(call):
+            """The same frames through another entry point: warm-up, then n2 frames between two synchronisations."""
+            was = mode["call"]
+            mode["call"] = call
+            run(0, min(args.warmup, 20)); sync()
+            t1 = time.perf_counter()
+            run(args.warmup, args.warmup + n2); sync()
+            dt = time.perf_counter() - t1
+            mode["call"] = was
+            return round(n2 / dt, 2)
+        # (0) the same frames through the library's own single entry point, and with the next frame announced ahead.  Neither is a call
+        #     the reference makes: the first shows what the four-call path costs over it, the second needs the NEXT frame's pose before
+        #     this frame is done (an offline sequence has it, a closed tracking loop cannot)
+        if mode["call"] == "four":
+            extra["process_frame_entry_point"] = {"value": leg("process_frame"), "unit": "frames/s", "steps": n2,
+                                                  "what": "itm_process_frame: one call per frame instead of the reference's four (same launches)"}
+            if can_ahead:
+                extra["with_lookahead"] = {"value": leg("ahead"), "unit": "frames/s", "steps": n2,
+                                           "what": "itm_process_frame_ahead: the next resident frame's block requests ride in this frame's ray-cast launch (4 launches per frame); "
+                                                   "needs the next frame's pose before this frame is done -- never the headline"}
         # (1) SURVEY 8d's second figure: the frame arrives as 16-bit raw depth in pinned host memory; H2D copy + itm_update_view
         #     (convertDepthAffineToFloat) inside the timed region
         s0.enable_raw()
@@ -507,6 +582,7 @@ def worker(args) -> int:
             "metric": "fused depth frames/sec (640x480, hash TSDF)" if args.config == 2 else f"fused depth frames/sec (config {args.config})",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "repetitions": rep_stats,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" if product else "synthetic; ALTERNATIVE BACKEND (--lib) -- control-flow check, not a measurement of the product",
             "config": {"workload": wl["name"], "streams": world * k_streams, "streams_per_gpu": k_streams,
@@ -520,11 +596,13 @@ def worker(args) -> int:
                        "visible_blocks_last_frame": counters["noVisibleEntries"],
                        **({"acceleration_structures": streams[0].scene.accel_info()} if (product and wl["index"] == "hash") else {}),
                        "origin_offset_m": list(offset),
-                       "frame_call": ("itm_process_frame_ahead (the next resident frame's block requests ride in this frame's last launch)" if fn_ahead is not None
-                                      else "itm_process_frame"),
+                       "frame_call": {"four": "the reference's four engine calls per frame: itm_allocate_scene_from_depth, itm_integrate_into_scene, itm_create_expected_depths, "
+                                              "itm_create_icp_maps (recorded and launched as one fused frame by the library)",
+                                      "process_frame": "itm_process_frame (NOT the headline call sequence)",
+                                      "ahead": "itm_process_frame_ahead (NOT the headline: the next frame's pose is handed over before this frame is done)"}[mode["call"]],
                        "input": ("16-bit raw depth from pinned host memory: H2D + itm_update_view inside the timed region" if args.raw_depth
                                  else "float depth frames resident in HBM"),
-                       "timing_note": f"value includes a hipEventRecord pair around the roofline kernel on every {args.timer_every}-th frame of rank 0",
+                       "timing_note": "no event timers inside the timed region; kernels are timed in one extra, untimed repetition (roofline.launches_timed)",
                        **({"debug_keys": args.debug_keys} if args.debug_keys else {}),
                        "backend": be.version()},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
@@ -572,20 +650,37 @@ def algorithmic_bytes(config, wl, counters):
     return 512 ** 3 * 4 + 4 * P
 
 
-def read_roofline(config, wl, scene, counters, timer_every=1):
-    """Average duration of the roofline kernel from hipEvents recorded around every --timer-every-th launch inside the timed
-    region (an event pair costs about 5 us of stream time: 10.4k vs 11.0k frames/s at every launch vs every 8th), on the
-    stream the kernel runs on (itm_profile_enable / itm_profile_read).  `traffic` = HBM bytes per launch from the PMC
-    counters of a separate rocprofv3 pass (profiles/traffic_r02.json, stamped with the commit it was collected on)."""
-    prof = scene.profile_read(reset=True)
+def algorithmic_bytes_secondary(config, wl, counters, which, n_entries):
+    """Algorithmic bytes of the two other large launches of a hash frame:
+    integrate: Nv*(512*V*2 + E + 4) + 4*P (+ 4*P_rgb)  -- every visible block read and written once, its entry and list id, the depth image;
+    visible_list: T + (E + 4)*Nv  -- one type byte per table slot (the reference's own sweep, _CPU.cpp:229-269, visits every slot), the
+      entry of every re-tested block and the id written for it.  A latency-bound sweep: its fraction is tiny by construction."""
+    P = wl["w"] * wl["h"]
+    V = {"s": 4, "f_rgb": 12}[wl["voxel"]]
+    nv = counters["noVisibleEntries"]
+    if which == "integrate":
+        return nv * (512 * V * 2 + 16 + 4) + 4 * P + (4 * P if wl["colour"] else 0)
+    return n_entries + (16 + 4) * nv
+
+
+def read_roofline(config, wl, prof, counters, scene):
+    """Average duration of the roofline kernel from HIP events around EVERY launch of it in one extra, untimed repetition (at least 64
+    launches, steady state: no synchronisation in front of any of them), on the stream the kernel runs on.  `event_pair_us` is what an
+    event pair measures with NOTHING between the two records on the same stream (64 empty brackets): the part of every bracketed
+    interval that is not the kernel; `avg_kernel_us` = bracket - empty bracket, which is what rocprofv3 reports for the kernel
+    (profiles/r4_*_kernel_stats.csv), `avg_bracket_us` the raw figure.  `traffic` = HBM bytes per launch from the PMC counters of a
+    separate rocprofv3 pass (profiles/traffic_r0N.json, stamped with the commit it was collected on)."""
     r = prof[wl["kernel"]]
     if not r["calls"]:
         return None
-    avg_s = r["total_ms"] * 1e-3 / r["calls"]
+    empty = prof.get("empty", {"calls": 0, "total_ms": 0.0})
+    pair_s = (empty["total_ms"] * 1e-3 / empty["calls"]) if empty["calls"] else 0.0
+    raw_s = r["total_ms"] * 1e-3 / r["calls"]
+    avg_s = max(raw_s - pair_s, 1e-9)
     alg = algorithmic_bytes(config, wl, counters)
     achieved = alg / avg_s / 1e9
     traffic, traffic_src = None, None
-    for tname in ("traffic_r03.json", "traffic_r02.json"):        # the newest PMC collection that has this config
+    for tname in ("traffic_r04.json", "traffic_r03.json", "traffic_r02.json"):        # the newest PMC collection that has this config
         tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath):
             with open(tpath) as f:
@@ -594,12 +689,29 @@ def read_roofline(config, wl, scene, counters, timer_every=1):
                 traffic, traffic_src = t.get("hbm_bytes_per_launch"), t.get("source")
                 break
     kname = {2: "raycast_kernel<VoxelS,hash>", 3: "integrate_dense_strip_kernel", 5: "integrate_hash_kernel<VoxelFRgb>"}[config]
-    return {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-            # the same fraction on the bytes the kernel really moved (PMC counters of a separate pass) instead of the reference algorithm's
-            "frac_traffic": (round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
-            "algorithmic_bytes_per_launch": round(alg), "avg_kernel_us": round(avg_s * 1e6, 2),
-            "launches_timed": r["calls"], "timer_every": timer_every}
+    out = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+           # the same fraction on the bytes the kernel really moved (PMC counters of a separate pass) instead of the reference algorithm's
+           "frac_traffic": (round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
+           "algorithmic_bytes_per_launch": round(alg), "avg_kernel_us": round(avg_s * 1e6, 2), "avg_bracket_us": round(raw_s * 1e6, 2),
+           "event_pair_us": round(pair_s * 1e6, 2), "launches_timed": r["calls"],
+           "timed_in": "an extra untimed repetition, every launch bracketed (no sampling, no synchronisation between frames)"}
+    if wl["index"] == "hash":
+        other = {}
+        n_entries = scene.be.fn["buffer_bytes"](C.c_void_p(scene.h), None, 0) // 16
+        for which in ("integrate", "visible_list"):
+            q = prof[which]
+            if which == wl["kernel"] or not q["calls"]:
+                continue
+            t = max(q["total_ms"] * 1e-3 / q["calls"] - pair_s, 1e-9)
+            ab = algorithmic_bytes_secondary(config, wl, counters, which, n_entries)
+            other[which] = {"avg_kernel_us": round(t * 1e6, 2), "algorithmic_bytes_per_launch": int(ab), "achieved": round(ab / t / 1e9, 1),
+                            "frac": round(ab / t / 1e9 / HBM_PEAK_GBS, 4), "launches_timed": q["calls"]}
+        if wl["kernel"] != "raycast" and prof["raycast"]["calls"]:
+            q = prof["raycast"]
+            other["raycast"] = {"avg_kernel_us": round((q["total_ms"] * 1e-3 / q["calls"] - pair_s) * 1e6, 2), "launches_timed": q["calls"]}
+        out["other_kernels"] = other
+    return out
 
 
 def measured_stream_peak():

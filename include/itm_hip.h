@@ -512,6 +512,11 @@ int ITM_FN(exchange_step)(itm_exchange* exchange, const itm_render_state* rs, co
 int ITM_FN(exchange_info)(const itm_exchange* exchange, int* world, int* rank, int* max_ids, int* batch, const void** gathered_device);
 /* host copy of the gathered table, world x batch records of (17 + max_ids) int32 words, rank-major; synchronises the side stream */
 int ITM_FN(exchange_table)(itm_exchange* exchange, int32_t* dst_host, size_t words);
+/* Self-check, on by default at every world size (ITM_EXCHANGE_SELF_CHECK=0 in the environment switches it off): behind each collective,
+ * on the side stream, this rank's own block of the gathered table is compared with the batch buffer it sent; words that differ make the
+ * next itm_exchange_step / itm_exchange_table return ITM_ERR_DEVICE.  Here: collectives checked so far (-1 = self-check off) and words
+ * found different; synchronises the side stream. */
+int ITM_FN(exchange_self_check)(itm_exchange* exchange, int* collectives_checked, int* mismatched_words);
 
 /* ---- swapping (Engine/ITMSwappingEngine.h:19-36, DeviceSpecific/CPU/ITMSwappingEngine_CPU.cpp, Objects/ITMGlobalCache.h) ----
  * Scenes created with useSwapping keep an ITMGlobalCache in HOST memory (one block slot + one `hasStoredData` flag per table entry) and
@@ -559,6 +564,7 @@ enum itm_timed_kernel {
   ITM_TK_RANGE = 4,         /* CreateExpectedDepths kernels                                */
   ITM_TK_RAYCAST = 5,       /* GenericRaycast kernel                                       */
   ITM_TK_ICP_MAPS = 6,      /* processPixelICP kernel                                      */
+  ITM_TK_EMPTY = 7,         /* itm_profile_calibrate: event pairs with nothing between them          */
   ITM_TK_COUNT = 7
 };
 typedef struct itm_profile {
@@ -572,6 +578,9 @@ int ITM_FN(profile_enable)(itm_scene* scene, uint32_t kernel_mask);
  * event pair costs a few microseconds of stream time, which a throughput run should not pay on
  * every frame.  The average launch duration is over the sampled launches. */
 int ITM_FN(profile_sample)(itm_scene* scene, int every);
+/* Records n EMPTY brackets on `stream` (slot ITM_TK_EMPTY of itm_profile): the interval an event pair measures when nothing lies
+ * between the two records, i.e. what the pair itself adds to every timed kernel's figure on this machine. */
+int ITM_FN(profile_calibrate)(itm_scene* scene, int n, itm_stream stream);
 /* Waits for the recorded events, accumulates and returns the totals; reset != 0 clears them. */
 int ITM_FN(profile_read)(itm_scene* scene, itm_profile* out, int reset);
 

@@ -75,7 +75,7 @@ class Profile(C.Structure):
     _fields_ = [("calls", C.c_int32 * 8), ("total_ms", C.c_double * 8)]
 
 
-TIMED_KERNELS = ["request", "alloc_sweep", "visible_list", "integrate", "range", "raycast", "icp_maps"]
+TIMED_KERNELS = ["request", "alloc_sweep", "visible_list", "integrate", "range", "raycast", "icp_maps", "empty"]
 
 
 class TrackerConfig(C.Structure):
@@ -197,6 +197,7 @@ _SIGS = {
     "debug_divide": (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_int, _P]),
     "profile_enable": (C.c_int, [_P, C.c_uint32]),
     "profile_sample": (C.c_int, [_P, C.c_int]),
+    "profile_calibrate": (C.c_int, [_P, C.c_int, _P]),
     "profile_read": (C.c_int, [_P, C.POINTER(Profile), C.c_int]),
     "export_visible_record": (C.c_int, [_P, C.POINTER(C.c_float), C.c_int, _P, _P]),
     "mesh_create": (C.c_int, [_P, C.c_uint32, C.POINTER(_P)]),
@@ -251,6 +252,7 @@ _HOST_IO_SIGS = {
     "exchange_step": (C.c_int, [_P, _P, C.POINTER(C.c_float), _P]),
     "exchange_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_P)]),
     "exchange_table": (C.c_int, [_P, _P, C.c_size_t]),
+    "exchange_self_check": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 }
 
 
@@ -455,6 +457,9 @@ class Scene:
 
     def profile_sample(self, every: int):
         self.be.check(self.be.fn["profile_sample"](_P(self.h), every), "profile_sample")
+
+    def profile_calibrate(self, n: int, stream=None):
+        self.be.check(self.be.fn["profile_calibrate"](_P(self.h), int(n), _P(stream)), "profile_calibrate")
 
     def profile_read(self, reset=True) -> dict:
         p = Profile()

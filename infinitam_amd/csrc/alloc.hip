@@ -678,7 +678,7 @@ int launch_sweep_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, bo
   // process drives more hardware queues than the device runs at once (GPU_MAX_HW_QUEUES=8, 6 scenes) the queues are time-sliced and
   // the waits collapse the frame rate (492 frames/s against 19.2 k).  No frame of a multi-scene process contains a wait between
   // workgroups.
-  const bool onePass = !g_debug_two_pass_visible_list && one_pass_list_is_safe(s);
+  const bool onePass = !g_debug_two_pass_visible_list && (one_pass_list_is_safe(s) || g_debug_force_list_stuck != 0);      // (the test hook needs the launch that can get stuck)
   const bool fusedSweep = !onlyVisible && onePass && !g_debug_separate_sweep && (s->cfg.bucketNum % kSweepChunk) == 0;
   if (!onlyVisible) {
     if (!fusedSweep) {

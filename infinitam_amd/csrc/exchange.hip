@@ -68,6 +68,26 @@ static void load_rccl(Rccl& r) {
   r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.GetErrorString;
 }
 
+// SELF-CHECK (every world size; ITM_EXCHANGE_SELF_CHECK=0 switches it off): behind every collective, on the side stream, the block
+// of the gathered table that belongs to THIS rank is compared with the batch buffer this rank sent.  Whatever the other ranks'
+// blocks hold cannot be known here, but a communicator that was built with the wrong rank order, a count that disagrees between
+// ranks, a buffer reused too early or a collective that did not run all show up in the own block -- so the first run on hardware
+// this library has never seen (the pool offers one GPU per box: no collective with more than one rank has ever executed) reports
+// corruption instead of numbers.  The words that differ are counted in page-locked host memory, which the frame thread reads at
+// the next step: ITM_ERR_DEVICE.  Off the frame stream; one 64 KB compare per collective.
+struct SelfCheck { int32_t collectives, mismatchedWords, firstBadWord, pad; };
+__global__ void __launch_bounds__(256) exchange_self_check_kernel(const int32_t* __restrict__ sent, const int32_t* __restrict__ gatheredOwn, size_t count,
+                                                                  SelfCheck* __restrict__ out, int corruptWord) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) __hip_atomic_fetch_add(&out->collectives, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (i >= count) return;
+  int32_t got = gatheredOwn[i];
+  if ((long long)i == (long long)corruptWord) got ^= 0x5a5a5a5a;          // test hook: ITM_EXCHANGE_SELF_CHECK_CORRUPT=<word>
+  if (got != sent[i]) {
+    if (__hip_atomic_fetch_add(&out->mismatchedWords, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) out->firstBadWord = (int32_t)i;
+  }
+}
+
 static int rccl_fail(ncclResult_t code, const char* what) {
   char msg[256];
   snprintf(msg, sizeof msg, "%s: %s", what, rccl().GetErrorString ? rccl().GetErrorString(code) : "RCCL error");
@@ -102,6 +122,9 @@ struct itm_exchange {
   bool stop = false;
   std::atomic<int> issuerFailed{0};
   std::string issuerMessage;
+  itm::SelfCheck* check = nullptr;        // page-locked host memory (mapped); null = self-check off
+  itm::SelfCheck* checkDev = nullptr;
+  int corruptWord = -1;                   // ITM_EXCHANGE_SELF_CHECK_CORRUPT (test hook)
   int experiment = 0;                     // ITM_EXCHANGE_EXPERIMENT (measurement hook, tools/exchange_cost.py): how much of a batch's hand-off is issued
 };
 
@@ -122,6 +145,7 @@ static void free_exchange(itm_exchange* x) {
     if (x->released[b]) (void)hipEventDestroy(x->released[b]);
   }
   if (x->gathered) (void)hipFree(x->gathered);
+  if (x->check) (void)hipHostFree(x->check);
   if (x->side) (void)hipStreamDestroy(x->side);
   delete x;
 }
@@ -138,6 +162,10 @@ static int issue_collective(itm_exchange* x, int b) {
     ITM_HIP(hipMemcpyAsync(x->gathered, x->buffers[b], count * 4, hipMemcpyDeviceToDevice, x->side));
   }
   if (x->experiment == 4) return ITM_OK;
+  if (x->checkDev) {
+    exchange_self_check_kernel<<<(unsigned)((count + 255) / 256), 256, 0, x->side>>>(x->buffers[b], x->gathered + (size_t)x->rank * count, count, x->checkDev, x->corruptWord);
+    ITM_LAUNCH_CHECK();
+  }
   ITM_HIP(hipEventRecord(x->released[b], x->side));
   return ITM_OK;
 }
@@ -159,6 +187,14 @@ static void issuer_main(itm_exchange* x) {
     }
     x->state[b].store(itm_exchange::kIssued, std::memory_order_release);
   }
+}
+
+static int self_check_error(const itm_exchange* x) {
+  const volatile SelfCheck* c = x->check;
+  char msg[320];
+  snprintf(msg, sizeof msg, "exchange self-check: after a collective, %d word(s) of rank %d's own block of the gathered table differ from the records the rank sent "
+           "(first at word %d; %d collective(s) checked, world %d): the table cannot be trusted", (int)c->mismatchedWords, x->rank, (int)c->firstBadWord, (int)c->collectives, x->world);
+  return set_error(ITM_ERR_DEVICE, msg);
 }
 
 extern "C" {
@@ -212,6 +248,17 @@ int itm_exchange_create(int world, int rank, const unsigned char id[128], int ma
     const ncclResult_t rc = rccl().CommInitRank(&x->comm, world, u, rank);
     if (rc) { x->comm = nullptr; free_exchange(x); return rccl_fail(rc, "ncclCommInitRank"); }
   }
+  {
+    const char* sc = getenv("ITM_EXCHANGE_SELF_CHECK");
+    if (!(sc && sc[0] == '0') && x->experiment == 0) {
+      void* h = nullptr; void* d = nullptr;
+      if (hipHostMalloc(&h, sizeof(SelfCheck), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+        memset(h, 0, sizeof(SelfCheck));
+        x->check = (SelfCheck*)h; x->checkDev = (SelfCheck*)d;
+      } else { if (h) (void)hipHostFree(h); (void)hipGetLastError(); }
+    }
+    if (const char* c = getenv("ITM_EXCHANGE_SELF_CHECK_CORRUPT")) x->corruptWord = atoi(c);
+  }
   const char* inl = getenv("ITM_EXCHANGE_INLINE");
   x->threaded = !(inl && inl[0] == '1') && x->experiment == 0;
   if (x->threaded) x->issuer = std::thread(issuer_main, x);
@@ -228,6 +275,7 @@ int itm_exchange_step(itm_exchange* x, const itm_render_state* rs, const float M
   const int slot = (int)(x->frame % x->batch);
   const int b = (int)((x->frame / x->batch) % itm_exchange::kRing);
   if (x->issuerFailed.load(std::memory_order_acquire)) return set_error(ITM_ERR_DEVICE, x->issuerMessage);
+  if (x->check && ((volatile SelfCheck*)x->check)->mismatchedWords) return self_check_error(x);
   if (slot == 0 && x->state[b].load(std::memory_order_acquire) != itm_exchange::kFree) {
     // the collective that read this buffer eight batches ago must have let go of it.  Polled, not hipEventSynchronize: the blocking
     // wait of the runtime was measured at ~60 ms per call in a process whose other threads keep the cores busy (bench.py with a gloo
@@ -293,6 +341,19 @@ int itm_exchange_table(itm_exchange* x, int32_t* dst_host, size_t words) {
   if (x->issuerFailed.load(std::memory_order_acquire)) return set_error(ITM_ERR_DEVICE, x->issuerMessage);
   ITM_HIP(hipStreamSynchronize(x->side));     // the table is written by the collectives on the side stream
   ITM_HIP(hipMemcpy(dst_host, x->gathered, all * 4, hipMemcpyDeviceToHost));
+  if (x->check && ((volatile SelfCheck*)x->check)->mismatchedWords) return self_check_error(x);
+  return ITM_OK;
+}
+
+// {collectives checked, words of the own block that differed}; synchronises the side stream.  checked == 0 with the self-check
+// enabled means no collective has completed yet.
+int itm_exchange_self_check(itm_exchange* x, int* collectives_checked, int* mismatched_words) {
+  if (!x) return set_error(ITM_ERR_INVALID, "null argument");
+  for (int b = 0; b < itm_exchange::kRing; ++b)
+    while (x->state[b].load(std::memory_order_acquire) == itm_exchange::kQueued) std::this_thread::yield();
+  ITM_HIP(hipStreamSynchronize(x->side));
+  if (collectives_checked) *collectives_checked = x->check ? (int)((volatile SelfCheck*)x->check)->collectives : -1;
+  if (mismatched_words) *mismatched_words = x->check ? (int)((volatile SelfCheck*)x->check)->mismatchedWords : 0;
   return ITM_OK;
 }
 

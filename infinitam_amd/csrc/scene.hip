@@ -697,6 +697,18 @@ int itm_profile_sample(itm_scene* s, int every) {
   for (int i = 0; i < 8; ++i) s->prof->tick[i] = 0;
   return ITM_OK;
 }
+// n empty brackets (an event pair with nothing between) on `stream`, accumulated in slot ITM_TK_EMPTY: what an event pair adds to
+// the interval it brackets on this machine and queue -- the part of a timed kernel's figure that is not the kernel
+int itm_profile_calibrate(itm_scene* s, int n, itm_stream stream) {
+  if (!s || n < 1) return set_error(ITM_ERR_INVALID, "profile_calibrate: null scene or n < 1");
+  if (!s->prof) s->prof = new Profiler();
+  Profiler* p = s->prof;
+  const uint32_t mask = p->mask; const int every = p->every;
+  p->mask |= 1u << ITM_TK_EMPTY; p->every = 1;
+  for (int i = 0; i < n; ++i) { KernelTimer tk(s, ITM_TK_EMPTY, as_stream(stream)); }
+  p->mask = mask; p->every = every;
+  return ITM_OK;
+}
 int itm_profile_read(itm_scene* s, itm_profile* out, int reset) {
   if (!s || !out) return set_error(ITM_ERR_INVALID, "null argument");
   memset(out, 0, sizeof *out);

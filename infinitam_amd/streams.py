@@ -166,6 +166,12 @@ class NativeExchange:
         self.be.check(self.be.fn["exchange_table"](self.h, g.ctypes.data_as(C.c_void_p), g.size), "exchange_table")
         return g.reshape(self.world, self.batch, self.words)
 
+    def self_check(self) -> Tuple[int, int]:
+        """(collectives checked, words of this rank's own block that differed from what it sent); -1 checked = self-check off."""
+        a, b = C.c_int(), C.c_int()
+        self.be.check(self.be.fn["exchange_self_check"](self.h, C.byref(a), C.byref(b)), "exchange_self_check")
+        return a.value, b.value
+
     def close(self):
         if self.h:
             self.be.fn["exchange_destroy"](self.h)

@@ -1256,6 +1256,7 @@ int itmo_debug_divide(int mode, const float* a, const float* b, const float*, fl
 int itmo_debug_div32767(const float* in, float* out, int n, itm_stream) { for (int i = 0; i < n; ++i) out[i] = in[i] / 32767.0f; return ITM_OK; }
 int itmo_profile_enable(itm_scene*, uint32_t) { return ITM_OK; }
 int itmo_profile_sample(itm_scene*, int) { return ITM_OK; }
+int itmo_profile_calibrate(itm_scene*, int, itm_stream) { return ITM_OK; }
 int itmo_profile_read(itm_scene*, itm_profile* out, int) { if (out) std::memset(out, 0, sizeof *out); return ITM_OK; }
 
 int itmo_scene_create(const itm_scene_config* cfg_in, const itm_scene_params* prm, itm_scene** out) {

@@ -1,0 +1,76 @@
+"""BASELINE configs[3]: 8 independent 640x480 streams, one per GPU, each publishing {pose, visible-block list} per frame (SURVEY 8e,
+8d config 4: stream g adds (0, 0.05 g, 0) to the trajectory).  The pool offers ONE GPU per box, so what can be executed is
+
+  * every rank's WORKLOAD on the HIP path: streams g = 0 .. 7 at config-2 size (4 mm voxels, pool 0x40000, bench trajectory) against the
+    oracle, bit for bit, each stream publishing through the library's exchange (a real one-rank RCCL communicator and ncclAllGather,
+    every collective self-checked) and decoding its own record from the gathered table;
+  * the N-rank CONTROL FLOW of bench.py with the product library: `bench.py --gpus 2` with both ranks on the one GPU
+    (ITM_BENCH_SHARED_GPU=1: gloo control plane, two HIP processes), asserting the line the driver will read.
+
+What remains untested on hardware is only a collective among more than one RCCL rank."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import itm_testlib as T
+from infinitam_amd import capi
+from infinitam_amd.streams import NativeExchange
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MAX_IDS = 16384
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("g", range(8))
+def test_stream_g_of_the_eight_stream_config_equals_the_oracle(hip, oracle, g):
+    sc = T.Scenario(name="config4_stream%d" % g, w=640, h=480, voxelSize=0.004, localBlockNum=0x40000, frames=3, trajectory="bench", stream=g)
+    ses, ref = T.Session(hip, sc), T.Session(oracle, sc)
+    ex = NativeExchange(hip, 1, 0, max_ids=MAX_IDS, batch=1)
+    try:
+        counters = [[], []]
+        for k in range(sc.frames):
+            v = ses.frame(k, fused="four")                   # the reference's four calls, as every rank's frame loop issues them
+            ex.step(ses.rs.h, v.M_d, None)
+            ref.frame(k)
+            counters[0].append(ses.scene.counters(ses.rs)); counters[1].append(ref.scene.counters(ref.rs))
+            (M, ids), = ex.table()                            # the stream decodes its own record from the gathered table
+            nv = counters[1][-1]["noVisibleEntries"]
+            want = ref.scene.download(capi.BUF_VISIBLE_IDS, ref.rs)[:nv]
+            assert np.array_equal(M, np.asarray(sc.pose(k), np.float32).reshape(16)), "pose in the record of frame %d" % k
+            assert nv > 5000 and np.array_equal(ids, want[:MAX_IDS]), "visible list in the record of frame %d" % k
+        assert ex.self_check() == (sc.frames, 0)
+        a, b = ses.snapshot(), ref.snapshot()
+        a.counters, b.counters = counters
+        T.compare_results(a, b, sc, what=sc.name)
+        if g:
+            # the streams really differ: the y offset moves the camera 5 cm per stream
+            assert abs(float(np.asarray(sc.pose(0)).reshape(16)[13]) + np.float32(0.05) * g - float(np.asarray(T.Scenario(trajectory="bench").pose(0)).reshape(16)[13])) < 1e-6
+    finally:
+        ex.close(); ses.close(); ref.close()
+
+
+@pytest.mark.gpu
+def test_bench_with_two_ranks_sharing_the_gpu():
+    """`python bench.py --gpus 2` spawns two rank processes of the PRODUCT on one GPU (gloo control plane): n_gpus, both ranks' frame
+    rates, the exchange and exactly one JSON line."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    env["ITM_BENCH_SHARED_GPU"] = "1"
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "10", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["streams"] == 2 and out["config"]["world_size_seen"] == 2 and out["scaling"] == "weak"
+    assert out["steps"] == 40 and out["warmup"] == 10 and out["repetitions"]["count"] >= 1
+    assert out["config"]["collective_backend"] == "gloo" and "all_gather" in out["config"]["exchange"]
+    lo, hi = out["config"]["per_rank_fps_min_max"]
+    assert 100 < lo <= hi, out["config"]["per_rank_fps_min_max"]           # both ranks ran frames, on the GPU
+    assert out["value"] >= lo and out["data"] == "synthetic" and "four engine calls" in out["config"]["frame_call"]
+    assert out["config"]["visible_blocks_last_frame"] > 5000

@@ -15,7 +15,7 @@ def test_exchange_entry_points_are_exported():
     be = capi.Backend(infinitam_amd.lib_path(), "itm_") if T.os.path.exists(infinitam_amd.lib_path()) else None
     if be is None:
         pytest.skip("library not built")
-    for name in ("exchange_unique_id", "exchange_create", "exchange_destroy", "exchange_step", "exchange_info", "exchange_table"):
+    for name in ("exchange_unique_id", "exchange_create", "exchange_destroy", "exchange_step", "exchange_info", "exchange_table", "exchange_self_check"):
         assert name in be.fn
 
 
@@ -90,3 +90,41 @@ def test_one_rank_collective_equals_the_device_copy(hip, monkeypatch):
             ex.close()
             ses.close()
     assert np.array_equal(tables[0], tables[1]) and (tables[0][0, :, 16] > 100).all()
+
+
+@pytest.mark.gpu
+def test_every_collective_is_self_checked_and_corruption_is_loud(hip, monkeypatch):
+    """Behind each collective the rank's own block of the gathered table is compared with what it sent (on the side stream): a healthy
+    run counts the checks and no mismatch; a word corrupted on the way (test hook) makes the next step and the table read fail."""
+    sc = T.Scenario(name="ex_check", w=160, h=120, voxelSize=0.01, frames=9)
+    ses = T.Session(hip, sc)
+    ex = NativeExchange(hip, 1, 0, max_ids=512, batch=3)
+    try:
+        for k in range(sc.frames):
+            v = ses.frame(k, fused="four")
+            ex.step(ses.rs.h, v.M_d, None)
+        assert ex.self_check() == (3, 0)
+        ex.table()
+    finally:
+        ex.close()
+    monkeypatch.setenv("ITM_EXCHANGE_SELF_CHECK_CORRUPT", "40")
+    ex = NativeExchange(hip, 1, 0, max_ids=512, batch=3)
+    try:
+        with pytest.raises(capi.ItmError, match="self-check"):
+            for k in range(sc.frames):
+                v = ses.frame(k, fused=True)
+                ex.step(ses.rs.h, v.M_d, None)
+                if (k + 1) % 3 == 0:
+                    assert ex.self_check()[1] > 0                # (waits for the side stream: the check has run)
+        with pytest.raises(capi.ItmError, match="self-check"):
+            ex.table()
+    finally:
+        ex.close()
+    monkeypatch.delenv("ITM_EXCHANGE_SELF_CHECK_CORRUPT")
+    monkeypatch.setenv("ITM_EXCHANGE_SELF_CHECK", "0")
+    ex = NativeExchange(hip, 1, 0, max_ids=512, batch=3)
+    try:
+        assert ex.self_check() == (-1, 0)
+    finally:
+        ex.close()
+        ses.close()
