@@ -481,7 +481,9 @@ def worker(args) -> int:
         s0.scene.profile_read(reset=True)
         s0.scene.profile_enable(sum(1 << t for t in timed_set))
         s0.scene.profile_sample(1)
+        was, exchange = exchange, False         # rank 0 alone: no collective may be issued here (the other ranks wait at the barrier below)
         run(args.warmup, args.warmup + nt)
+        exchange = was
         sync()
         s0.scene.profile_calibrate(64, s0.hip_stream.cuda_stream if s0.hip_stream is not None else None)
         sync()
@@ -666,15 +668,19 @@ def algorithmic_bytes_secondary(config, wl, counters, which, n_entries):
 def read_roofline(config, wl, prof, counters, scene):
     """Average duration of the roofline kernel from HIP events around EVERY launch of it in one extra, untimed repetition (at least 64
     launches, steady state: no synchronisation in front of any of them), on the stream the kernel runs on.  `event_pair_us` is what an
-    event pair measures with NOTHING between the two records on the same stream (64 empty brackets): the part of every bracketed
-    interval that is not the kernel; `avg_kernel_us` = bracket - empty bracket, which is what rocprofv3 reports for the kernel
+    event pair adds to an interval (half of what 64 EMPTY brackets on the same stream measure, see below): the part of every bracketed
+    interval that is not the kernel; `avg_kernel_us` = bracket - that, which is what rocprofv3 reports for the kernel
     (profiles/r4_*_kernel_stats.csv), `avg_bracket_us` the raw figure.  `traffic` = HBM bytes per launch from the PMC counters of a
     separate rocprofv3 pass (profiles/traffic_r0N.json, stamped with the commit it was collected on)."""
     r = prof[wl["kernel"]]
     if not r["calls"]:
         return None
     empty = prof.get("empty", {"calls": 0, "total_ms": 0.0})
-    pair_s = (empty["total_ms"] * 1e-3 / empty["calls"]) if empty["calls"] else 0.0
+    # An EMPTY bracket is two marker packets back to back: it measures two marker latencies.  A bracket around a kernel contains ONE of
+    # them (the first marker's stamp is taken when it retires, the kernel starts right behind it; the second marker's own latency follows
+    # the kernel).  Half the empty bracket is therefore what the pair adds -- measured: bracket 40.8 us, empty 4.9 us, rocprofv3 of the
+    # same build 38.5 us (profiles/r4_config2_kernel_stats.csv) = bracket - 2.3.
+    pair_s = 0.5 * ((empty["total_ms"] * 1e-3 / empty["calls"]) if empty["calls"] else 0.0)
     raw_s = r["total_ms"] * 1e-3 / r["calls"]
     avg_s = max(raw_s - pair_s, 1e-9)
     alg = algorithmic_bytes(config, wl, counters)

@@ -148,7 +148,8 @@ enum itm_buffer {
   ITM_BUF_RAYCAST_IMAGE = 8,    /* Vector4u[h*w]  renderState->raycastImage         */
   ITM_BUF_FORWARD_PROJECTION = 9, /* Vector4f[h*w] renderState->forwardProjection   */
   ITM_BUF_MISSING_POINTS = 10,  /* int[h*w]       renderState->fwdProjMissingPoints */
-  ITM_BUF_SWAP_STATES = 11      /* uchar[noTotalEntries] globalCache->GetSwapStates(): ITMHashSwapState::state (scenes with useSwapping) */
+  ITM_BUF_SWAP_STATES = 11,     /* uchar[noTotalEntries] globalCache->GetSwapStates(): ITMHashSwapState::state (scenes with useSwapping) */
+  ITM_BUF_NEAR_BITS = 12        /* uchar[256^3], download only: the near bits of the mirror's cube (itm_accel_info; not part of the reference's state) */
 };
 
 typedef struct itm_scene itm_scene;               /* ITMScene<TVoxel,TIndex> + engine scratch */
@@ -199,6 +200,8 @@ int ITM_FN(set_device)(int device);
 #define ITM_DEBUG_TRACKER_SESSION_UNUSABLE 18  /* TrackCamera: the resident evaluation kernel reports itself unusable at the n-th evaluation of a handle (n = value): the call must finish through one launch per evaluation with the same pose */
 #define ITM_DEBUG_NO_DEFERRED_FUSION 19         /* the four per-frame engine calls launch at once, one by one, instead of being recorded and fused (see "the four calls" below) */
 #define ITM_DEBUG_FORCE_LIST_STUCK 20           /* AllocateSceneFromDepth, one-launch visible list: chunk n - 1 behaves as if its bounded wait for another workgroup had expired (0 = off): the scene must raise statusFlags bit 1 and refuse further calls */
+#define ITM_DEBUG_NO_NEAR_BITS 21               /* ray casting: every position is read although the near bits prove some empty; set before itm_scene_create: none are allocated */
+#define ITM_DEBUG_INTEGRATE_SLICES 22           /* hash integration: one voxel per lane, four z-slices per wave (rounds 2-3) instead of 16 bytes per lane, a block per wave */
 int ITM_FN(debug_set)(int key, int value);
 /* dense integration, check mode of key 16: {free groups, shadow groups, mixed groups, violations}; reset != 0 clears */
 int ITM_FN(debug_dense_classify_check)(int32_t out[4], int reset);
@@ -548,6 +551,8 @@ typedef struct itm_accel_info {
   int32_t origin_directory[3], origin_mirror[3];
   int32_t placed;
   int64_t moves;
+  int64_t near_bits_bytes;     /* one byte per cell of the mirror's cube: which distances (0 .. 7 blocks) hold an allocated block -- rays cross
+                                  proven-empty space on arithmetic alone (0 = absent) */
 } itm_accel_info;
 int ITM_FN(scene_accel_info)(const itm_scene* scene, itm_accel_info* out);
 

@@ -42,8 +42,15 @@ int g_debug_two_pass_visible_list = 0;   // test hook: count and compact as two 
 int g_debug_separate_sweep = 0;          // test hook (key 13): the allocation sweep as its own launch
 int g_debug_force_list_stuck = 0;        // test hook (key 20): chunk n - 1 of the one-launch list behaves as if its bounded wait had expired
 
+// (When the last list build found more visible slots than the list holds -- the reference then writes past its list, SURVEY section 7
+// trap 6; list and count are clamped here -- every slot that was visible counts as "visible in the previous frame", listed or not:
+// the rule the folded form of this pass, request_kernel<.., LAZY>, applies by construction, and the oracle's.)
 __global__ void __launch_bounds__(256) mark_previous_kernel(const int32_t* __restrict__ ids, RenderCounters* __restrict__ rc,
-                                                            uint8_t* __restrict__ visT) {
+                                                            uint8_t* __restrict__ visT, int noTotalEntries, int capIds) {
+  if (rc->rawVisibleCount > capIds) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < noTotalEntries; i += gridDim.x * blockDim.x) if (visT[i]) visT[i] = 3;
+    return;
+  }
   const int nv = rc->noVisibleEntries;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += gridDim.x * blockDim.x) visT[ids[i]] = 3;
 }
@@ -69,6 +76,15 @@ __device__ inline void replay_block_pos(uint32_t key, float d, const AllocParams
 
 constexpr int kSlotsPerThread = kSweepChunk / 256;  // 8
 
+// The blocks a chunk's sweep has just allocated, queued in LDS: their near bits (itm_types.h: 15 x 15 x 15 cells each) are set by the
+// whole workgroup once the chunk's count is out -- off the path the later chunks' look-backs wait for.
+struct NewBlocks { short4 block[kSweepChunk]; int count; };
+// (to be called by every thread of the workgroup, behind a barrier that follows the sweep)
+__device__ inline void splat_new_blocks(const NewBlocks* fresh, uint32_t* __restrict__ nearWords, const AccelOrigin& org) {
+  const int n = fresh->count;
+  for (int k = 0; k < n; ++k) near_bits_splat(nearWords, org, fresh->block[k].x, fresh->block[k].y, fresh->block[k].z, (int)threadIdx.x, 256);
+}
+
 // Ascending-slot allocation sweep (_CPU.cpp:175-227).  chunkReq holds, per 2048-slot chunk, the
 // number of requested slots and of excess-list requests; next-frame counters are zeroed here.
 // The sweep of ONE chunk by its workgroup.  ACROSS: the visible type of a new excess entry lies in another chunk; when the visible
@@ -80,12 +96,13 @@ __device__ inline void sweep_chunk(const int chunk, int* lds, uint32_t* __restri
                                    const int32_t* __restrict__ excessList, const int32_t* __restrict__ allocList,
                                    uint8_t* __restrict__ visT, const SceneCounters* __restrict__ counters,
                                    uint32_t* __restrict__ headBits, int32_t* __restrict__ dirPtr, int32_t* __restrict__ dirSlot, void* __restrict__ sdfMirror,
-                                   const float* __restrict__ depth, int lazy, const AllocParams& p) {
+                                   const float* __restrict__ depth, int lazy, const AllocParams& p, NewBlocks* fresh) {
 
   const int tid = threadIdx.x;
   if (tid == 0) chunkReqNext[chunk] = make_int2(0, 0);
   const int2 mine = chunkReq[chunk];
   if (mine.x == 0) return;  // nothing requested in this chunk (uniform per workgroup)
+  if (fresh && tid == 0) fresh->count = 0;      // (the barriers of the scans below order this before the first append)
 
   // The sweep of a chunk with requests is a chain of dependent loads (keys -> entry / depth pixel -> free-list slot), and the
   // whole visible-list launch waits for the slowest such chunk (per-workgroup timeline, tools/list_timeline.py: 8.9 us for it, 1 us
@@ -156,6 +173,7 @@ __device__ inline void sweep_chunk(const int chunk, int* lds, uint32_t* __restri
         else visT[p.bucketNum + off] = lazy ? 0x81 : 1;
         directory_insert(dirPtr, dirSlot, p.org, bx, by, bz, ptr, p.bucketNum + off);
         mirror_init_block(sdfMirror, p.mirrorFloat != 0, p.org, bx, by, bz);
+        if (fresh) fresh->block[atomicAdd(&fresh->count, 1)] = make_short4((short)bx, (short)by, (short)bz, 0);
       }
     } else if (vbaIdx[k] >= 0) {
       int bx, by, bz;
@@ -165,6 +183,7 @@ __device__ inline void sweep_chunk(const int chunk, int* lds, uint32_t* __restri
       atomicOr(&headBits[slot >> 5], 1u << (slot & 31));
       directory_insert(dirPtr, dirSlot, p.org, bx, by, bz, ptr, slot);
       mirror_init_block(sdfMirror, p.mirrorFloat != 0, p.org, bx, by, bz);
+      if (fresh) fresh->block[atomicAdd(&fresh->count, 1)] = make_short4((short)bx, (short)by, (short)bz, 0);
     }
     allocKey[slot] = 0u;
   }
@@ -175,9 +194,15 @@ __global__ void __launch_bounds__(256) allocate_sweep_kernel(uint32_t* __restric
                                                              const int32_t* __restrict__ excessList, const int32_t* __restrict__ allocList,
                                                              uint8_t* __restrict__ visT, const SceneCounters* __restrict__ counters,
                                                              uint32_t* __restrict__ headBits, int32_t* __restrict__ dirPtr, int32_t* __restrict__ dirSlot, void* __restrict__ sdfMirror,
-                                                             const float* __restrict__ depth, int lazy, AllocParams p) {
+                                                             const float* __restrict__ depth, int lazy, AllocParams p, uint32_t* __restrict__ nearWords) {
   __shared__ int lds[8];
-  sweep_chunk<false>((int)blockIdx.x, lds, allocKey, chunkReq, chunkReqNext, numChunks, hash, excessList, allocList, visT, counters, headBits, dirPtr, dirSlot, sdfMirror, depth, lazy, p);
+  __shared__ NewBlocks fresh;
+  sweep_chunk<false>((int)blockIdx.x, lds, allocKey, chunkReq, chunkReqNext, numChunks, hash, excessList, allocList, visT, counters, headBits, dirPtr, dirSlot, sdfMirror, depth, lazy, p,
+                     nearWords ? &fresh : nullptr);
+  if (nearWords && chunkReq[blockIdx.x].x > 0) {      // (uniform)
+    __syncthreads();
+    splat_new_blocks(&fresh, nearWords, p.org);
+  }
 }
 
 // checkBlockVisibility<false>: corners are reached by incremental +-f updates in a fixed order.
@@ -326,6 +351,9 @@ __global__ void __launch_bounds__(256) visible_compact_kernel(const uint8_t* __r
 // device-scope load (the sweep wrote them with one).  No sweep waits for anything, so the waiting cannot cycle; in a frame without
 // excess requests -- almost all of them -- nobody waits.  The pool counters, which every sweep reads, are committed by the LAST
 // chunk after its look-back (all granules in = all sweeps done) instead of by chunk 0.
+#ifndef ITM_LIST_EARLY_SWEEPS
+#define ITM_LIST_EARLY_SWEEPS 1     // 0 (measurement builds only): excess-region chunks sweep themselves and wait for each other, as in round 3
+#endif
 struct SweepArgs {
   uint32_t* allocKey; int2* chunkReqNext; const int32_t* excessList; const int32_t* allocList; uint32_t* headBits;
   int32_t* dirPtr; int32_t* dirSlot; void* sdfMirror; const float* depth; int lazy;
@@ -333,6 +361,7 @@ struct SweepArgs {
   int early;               // workgroups at the head of the grid that only sweep an excess-region chunk (below)
   int32_t* fatalDev;       // the scene's host-visible status word (alloc_device.h: raise_fatal)
   int forceStuck;          // test hook (debug key 20): chunk whose wait is treated as expired, or -1
+  uint32_t* nearWords;     // near bits of the mirror's cube (itm_types.h), or nullptr
 };
 
 #ifndef ITM_EXP_LIST_STAMPS
@@ -363,6 +392,8 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
                                                            int32_t* __restrict__ ids, int capIds, RenderCounters* __restrict__ rc, AllocParams p, SweepArgs sw) {
   __shared__ int lds[12];
   __shared__ int sweepLds[8];
+  __shared__ NewBlocks fresh;
+  NewBlocks* const freshPtr = (SWEEP && sw.nearWords) ? &fresh : nullptr;
   const int tid = threadIdx.x;
   // the chunk's stores must have COMPLETED before its stamp may follow: on gfx950 a workgroup-scope release fence is only
   // s_waitcnt lgkmcnt(0) -- it does not wait for vector stores -- so the wait is spelled out (loads and stores share vmcnt);
@@ -378,8 +409,11 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
       // ---- an early workgroup: the sweep of one excess-region chunk, nothing else ----
       const int c = numChunks - sw.early + (int)blockIdx.x;
       sweep_chunk<true>(c, sweepLds, sw.allocKey, chunkReq, sw.chunkReqNext, numChunks, hash, sw.excessList, sw.allocList, visT, counters, sw.headBits,
-                        sw.dirPtr, sw.dirSlot, sw.sdfMirror, sw.depth, sw.lazy, p);
-      if (chunkReq[c].y > 0) stamp_sweep(c);                   // (uniform; every request in the excess region is an excess request)
+                        sw.dirPtr, sw.dirSlot, sw.sdfMirror, sw.depth, sw.lazy, p, freshPtr);
+      if (chunkReq[c].y > 0) {                                 // (uniform; every request in the excess region is an excess request)
+        stamp_sweep(c);
+        if (freshPtr) splat_new_blocks(freshPtr, sw.nearWords, p.org);      // (stamp_sweep ended with a barrier)
+      }
       return;
     }
   }
@@ -422,15 +456,16 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
     }
   }
   if constexpr (SWEEP) {
-    if (!excessRegion) {
+    if (!excessRegion || !ITM_LIST_EARLY_SWEEPS) {
       sweep_chunk<true>(chunk, sweepLds, sw.allocKey, chunkReq, sw.chunkReqNext, numChunks, hash, sw.excessList, sw.allocList, visT, counters, sw.headBits,
-                        sw.dirPtr, sw.dirSlot, sw.sdfMirror, sw.depth, sw.lazy, p);
+                        sw.dirPtr, sw.dirSlot, sw.sdfMirror, sw.depth, sw.lazy, p, freshPtr);
       if (chunkReq[chunk].y > 0) stamp_sweep(chunk);           // (uniform) only excess allocations are read by other workgroups of this launch
-    } else {
+    }
+    if (excessRegion) {
       // every chunk that had excess requests must be through: chunks of the ordered region (workgroups early + j, j < chunk) and of the
       // excess region (the early workgroups) -- all in front of this workgroup
       for (int j = tid; j < numChunks; j += 256) {
-        if (chunkReq[j].y <= 0) continue;
+        if (chunkReq[j].y <= 0 || (!ITM_LIST_EARLY_SWEEPS && j == chunk)) continue;
         for (int spin = 0; __hip_atomic_load(&sw.sweepDone[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch; ++spin) {
           if (spin > (1 << 22)) { stuck = true; break; }
           __builtin_amdgcn_s_sleep(1);
@@ -493,6 +528,11 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
   if (tid == 0)
     __hip_atomic_store(&chunkGran[chunk], ((unsigned long long)epoch << 32) | (unsigned long long)(uint32_t)mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   ITM_LS(2)
+  if constexpr (SWEEP) {
+    // the chunk's count is out: the near bits of the blocks its sweep allocated, while the look-back would only wait (block_exclusive_scan
+    // above was the barrier behind the sweep)
+    if (freshPtr && (!excessRegion || !ITM_LIST_EARLY_SWEEPS) && chunkReq[chunk].x > 0) splat_new_blocks(freshPtr, sw.nearWords, p.org);
+  }
   // base = visible slots in all earlier chunks
   look_back();
   ITM_LS(3)
@@ -644,7 +684,7 @@ int launch_request_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, 
   int rc = prepare_request_stage(s, v, rs, st, p, ra, lazy);
   if (rc) return rc;
   rs->lazyThisFrame = lazy;
-  if (!lazy) mark_previous_kernel<<<64, 256, 0, st>>>(rs->visibleIds, rs->counters, rs->visibleType);
+  if (!lazy) mark_previous_kernel<<<64, 256, 0, st>>>(rs->visibleIds, rs->counters, rs->visibleType, s->noTotalEntries, rs->capIds);
   dim3 grid((v->w + 15) / 16, (v->h + 15) / 16);
   KernelTimer tq(s, ITM_TK_REQUEST, st);
 #define ITM_REQ(OV, FU, LZ) request_kernel<OV, FU, LZ><<<grid, 256, 0, st>>>(ra, p)
@@ -684,7 +724,7 @@ int launch_sweep_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, bo
     if (!fusedSweep) {
       KernelTimer ts(s, ITM_TK_ALLOC_SWEEP, st);
       allocate_sweep_kernel<<<nChunks, 256, 0, st>>>(s->allocKey, reqCur, reqNext, nChunks, s->hash, s->excessList, s->allocList,
-                                                     rs->visibleType, s->counters, s->headBits, s->dirPtr, s->dirSlot, s->sdfMirror, v->depth, lazy ? 1 : 0, p);
+                                                     rs->visibleType, s->counters, s->headBits, s->dirPtr, s->dirSlot, s->sdfMirror, v->depth, lazy ? 1 : 0, p, s->nearBits);
     }
     s->frameParity++;
   }
@@ -692,9 +732,9 @@ int launch_sweep_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, bo
   if (onePass) {
     const uint32_t epoch = ++s->listEpoch;
     // (the early workgroups: one per chunk of the excess region, see visible_list_kernel)
-    const int earlyWgs = fusedSweep ? nChunks - s->cfg.bucketNum / kSweepChunk : 0;
+    const int earlyWgs = (fusedSweep && ITM_LIST_EARLY_SWEEPS) ? nChunks - s->cfg.bucketNum / kSweepChunk : 0;
     const SweepArgs sw{s->allocKey, reqNext, s->excessList, s->allocList, s->headBits, s->dirPtr, s->dirSlot, s->sdfMirror, v->depth, lazy ? 1 : 0, s->chunkSweepDone,
-                       earlyWgs, s->fatalDev, fusedSweep ? g_debug_force_list_stuck - 1 : -1};
+                       earlyWgs, s->fatalDev, fusedSweep ? g_debug_force_list_stuck - 1 : -1, s->nearBits};
 #define ITM_VL(CM, LZ, SW) visible_list_kernel<CM, LZ, SW><<<nChunks + earlyWgs, 256, 0, st>>>(rs->visibleType, s->hash, s->chunkGran, epoch, reqCur, nChunks, s->counters, rs->visibleIds, rs->capIds, rs->counters, p, sw)
     if (onlyVisible) { if (lazy) ITM_VL(false, true, false); else ITM_VL(false, false, false); }
     else if (fusedSweep) { if (lazy) ITM_VL(true, true, true); else ITM_VL(true, false, true); }
@@ -759,7 +799,7 @@ int cancel_ahead(itm_scene* s, itm_render_state* rs, hipStream_t st) {
   if (!rs->ahead.valid) return ITM_OK;
   const int n = s->noTotalEntries;
   cancel_requests_kernel<<<(n / 4 + 255) / 256, 256, 0, st>>>(rs->visibleType, s->allocKey, n);
-  mark_previous_kernel<<<64, 256, 0, st>>>(rs->visibleIds, rs->counters, rs->visibleType);
+  mark_previous_kernel<<<64, 256, 0, st>>>(rs->visibleIds, rs->counters, rs->visibleType, s->noTotalEntries, rs->capIds);
   ITM_LAUNCH_CHECK();
   ITM_HIP(hipMemsetAsync((int2*)s->chunkReq + (size_t)(s->frameParity & 1u) * s->numChunks, 0, (size_t)s->numChunks * sizeof(int2), st));
   rs->ahead.valid = false;

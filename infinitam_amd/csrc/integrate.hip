@@ -28,6 +28,7 @@ namespace itm {
 #define ITM_PROJECTION_PRIORITY 1
 #endif
 int g_debug_integrate_wgs = 0;
+int g_debug_integrate_slices = 0;   // debug key 22: the hash integration of rounds 2-3 (one voxel per lane, four z-slices per wave) instead of a block per wave
 int g_debug_no_fused_projection = 0;
 int g_debug_dense_group_cull = 0;   // debug key 9: per-group frustum test instead of the per-column row interval
 int g_debug_dense_no_strips = 0;    // debug key 17: the launch shape of rounds 1-2 (four groups per lane) instead of the strip kernel
@@ -315,6 +316,150 @@ __device__ inline void integrate_hash_body(int wgIdx, int wgCount, const int32_t
   }
 }
 
+// ---- 16 bytes per lane (round 4) ----------------------------------------------------------------------------------------------
+// Work item = a WHOLE block by one wave: lane l owns the four x-consecutive voxels [4 l, 4 l + 4) of each half of the block (a block
+// is x + 8 y + 64 z: lane l <-> x0 = 4 (l & 1), y = (l >> 1) & 7, z = (l >> 4) + 4 half), moved with 128-bit accesses -- for
+// ITMVoxel_s one dwordx4 per half (the wave's load instruction covers 1 KB, where one voxel per lane covered 256 B: a quarter of the
+// memory instructions, twice the bytes in flight per wave), for the 8-byte types two, for ITMVoxel_f_rgb three.  A group is stored
+// back whole when any of its voxels changed (nobody else writes the block), the mirror gets the group's four sdf values as one store.
+// Per voxel the arithmetic is the slice kernel's, operation for operation (fuse_depth_project / fuse_depth_update / fuse_colour).
+template <class VX> struct Group;      // four consecutive voxels as the registers they arrive in
+template <> struct Group<VoxelS> {
+  uint4 q;
+  __device__ void load(const void* vba, size_t g) { q = ((const uint4*)vba)[g]; }
+  __device__ void store(void* vba, size_t g) const { ((uint4*)vba)[g] = q; }
+  __device__ VoxelS::Reg get(int k) const { return k == 0 ? q.x : k == 1 ? q.y : k == 2 ? q.z : q.w; }
+  __device__ void set(int k, VoxelS::Reg r) { if (k == 0) q.x = r; else if (k == 1) q.y = r; else if (k == 2) q.z = r; else q.w = r; }
+};
+template <class VX8> struct Group8 {   // the 8-byte voxel types: two voxels per dwordx4
+  uint4 q[2];
+  __device__ void load(const void* vba, size_t g) { q[0] = ((const uint4*)vba)[2 * g]; q[1] = ((const uint4*)vba)[2 * g + 1]; }
+  __device__ void store(void* vba, size_t g) const { ((uint4*)vba)[2 * g] = q[0]; ((uint4*)vba)[2 * g + 1] = q[1]; }
+  __device__ uint2 get(int k) const { const uint4& v = q[k >> 1]; return (k & 1) ? make_uint2(v.z, v.w) : make_uint2(v.x, v.y); }
+  __device__ void set(int k, uint2 r) { uint4& v = q[k >> 1]; if (k & 1) { v.z = r.x; v.w = r.y; } else { v.x = r.x; v.y = r.y; } }
+};
+template <> struct Group<VoxelF> : Group8<VoxelF> {};
+template <> struct Group<VoxelSRgb> : Group8<VoxelSRgb> {};
+template <> struct Group<VoxelFRgb> {  // 12-byte voxels: four of them are three dwordx4
+  uint32_t w[12];
+  __device__ void load(const void* vba, size_t g) {
+    const uint4* p = (const uint4*)vba + 3 * g;
+    const uint4 a = p[0], b = p[1], c = p[2];
+    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w; w[8] = c.x; w[9] = c.y; w[10] = c.z; w[11] = c.w;
+  }
+  __device__ void store(void* vba, size_t g) const {
+    uint4* p = (uint4*)vba + 3 * g;
+    p[0] = make_uint4(w[0], w[1], w[2], w[3]); p[1] = make_uint4(w[4], w[5], w[6], w[7]); p[2] = make_uint4(w[8], w[9], w[10], w[11]);
+  }
+  __device__ VoxelFRgb::Reg get(int k) const { VoxelFRgb::Reg r; r.a = w[3 * k]; r.b = w[3 * k + 1]; r.c = w[3 * k + 2]; return r; }
+  __device__ void set(int k, VoxelFRgb::Reg r) { w[3 * k] = r.a; w[3 * k + 1] = r.b; w[3 * k + 2] = r.c; }
+};
+
+template <class VX>
+__device__ inline void integrate_block_x4(const HashEntry& he, int lane, Group<VX> grp[2], void* __restrict__ vba, void* __restrict__ sdfMirror,
+                                          const float* __restrict__ depth, const uchar4* __restrict__ rgb, const FuseParams& p) {
+  const bool present = he.ptr >= 0;
+  const int x0 = (lane & 1) * 4, y = (lane >> 1) & 7, zl = lane >> 4;
+  const size_t g0 = (size_t)(present ? he.ptr : 0) * (kBlockVoxels / 4) + lane;      // group index of the first half; + 64 for the second
+  const float my = (float)(he.py * kBlockSide + y) * p.voxelSize;
+  using MC = MirrorCodec<VX::kShort>;
+  size_t mbase = 0;
+  typename MC::T* mirror = nullptr;
+  if (sdfMirror && mirror_index(p.org, he.px * kBlockSide, he.py * kBlockSide, he.pz * kBlockSide, mbase)) mirror = (typename MC::T*)sdfMirror;
+  // stage 1: project the eight voxels; stage 2: their depth pixels together; stage 3: update (+ colour), store the groups that changed
+  int pix[8];
+  float pcz[8], mx[4], mz[2];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) mx[k] = (float)(he.px * kBlockSide + x0 + k) * p.voxelSize;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    mz[h] = (float)(he.pz * kBlockSide + zl + 4 * h) * p.voxelSize;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int j = 4 * h + k;
+      pix[j] = -2;                                                            // -2: voxel skipped altogether (no block / stopIntegratingAtMaxW)
+      if (!present || (p.stopAtMax && VX::w_depth(grp[h].get(k)) == p.maxW)) continue;
+      pix[j] = fuse_depth_project(mx[k], my, mz[h], p, pcz[j]);
+    }
+  }
+  float dm[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) dm[j] = depth[pix[j] >= 0 ? pix[j] : 0];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int j = 4 * h + k;
+      if (pix[j] == -2) continue;
+      typename VX::Reg r = grp[h].get(k);
+      bool touched = false;
+      const float eta = (pix[j] >= 0) ? fuse_depth_update<VX>(r, dm[j], pcz[j], p, touched) : -1.0f;
+      if constexpr (VX::kColor) {
+        if (!((eta > p.mu) || (fabsf(eta / p.mu) > 0.25f))) {
+          fuse_colour<VX>(r, mx[k], my, mz[h], rgb, p);
+          touched = true;
+        }
+      }
+      if (touched) { grp[h].set(k, r); any = true; }
+    }
+    if (any) {
+      grp[h].store(vba, g0 + 64 * h);
+      if (mirror) {
+        // the group's four sdf values as one store (8 bytes for the short types, 16 for the float ones): a voxel that did not change
+        // is rewritten with the value it holds
+        const size_t mi = mbase + (size_t)(4 * lane + 256 * h);
+        if constexpr (VX::kShort) {
+          const uint32_t a = (uint32_t)(uint16_t)MC::of(VX::raw_sdf(grp[h].get(0))) | ((uint32_t)(uint16_t)MC::of(VX::raw_sdf(grp[h].get(1))) << 16);
+          const uint32_t b = (uint32_t)(uint16_t)MC::of(VX::raw_sdf(grp[h].get(2))) | ((uint32_t)(uint16_t)MC::of(VX::raw_sdf(grp[h].get(3))) << 16);
+          *(uint2*)(mirror + mi) = make_uint2(a, b);
+        } else {
+          *(uint4*)(mirror + mi) = make_uint4(MC::of(VX::raw_sdf(grp[h].get(0))), MC::of(VX::raw_sdf(grp[h].get(1))), MC::of(VX::raw_sdf(grp[h].get(2))), MC::of(VX::raw_sdf(grp[h].get(3))));
+        }
+      }
+    }
+  }
+}
+
+template <class VX>
+__device__ inline void load_block_x4(const HashEntry& he, int lane, const void* __restrict__ vba, Group<VX> grp[2]) {
+  const size_t g0 = (size_t)(he.ptr < 0 ? 0 : he.ptr) * (kBlockVoxels / 4) + lane;      // block 0 is always there
+  grp[0].load(vba, g0);
+  grp[1].load(vba, g0 + 64);
+}
+
+template <class VX>
+__device__ inline void integrate_hash_body_x4(int wgIdx, int wgCount, const int32_t* __restrict__ visibleIds, RenderCounters* __restrict__ rc,
+                                              const uint4* __restrict__ hash, void* __restrict__ vba, void* __restrict__ sdfMirror,
+                                              const float* __restrict__ depth, const uchar4* __restrict__ rgb, const FuseParams& p) {
+  if (rc->listInvalid) return;                        // the list of this frame is not the reference's: fuse nothing (alloc.hip, statusFlags bit 1)
+  const int nItems = rc->noVisibleEntries;
+  const int lane = threadIdx.x & 63;
+  const int waves = wgCount * (int)(blockDim.x >> 6);
+  int i = __builtin_amdgcn_readfirstlane(wgIdx * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6));
+  if (i >= nItems) return;
+  HashEntry cur = unpack_entry(hash[visibleIds[i]]);
+  Group<VX> grp[2];
+  load_block_x4<VX>(cur, lane, vba, grp);
+  for (;;) {
+    const int nxt = i + waves;
+    const bool more = nxt < nItems;
+    HashEntry ahead = cur;
+    if (more) ahead = unpack_entry(hash[visibleIds[nxt]]);       // the entry of the NEXT item travels while this one is fused
+    integrate_block_x4<VX>(cur, lane, grp, vba, sdfMirror, depth, rgb, p);
+    if (!more) break;
+    load_block_x4<VX>(ahead, lane, vba, grp);
+    cur = ahead; i = nxt;
+  }
+}
+
+template <class VX>
+__global__ void __launch_bounds__(512) integrate_hash_x4_kernel(const int32_t* __restrict__ visibleIds, RenderCounters* __restrict__ rc,
+                                                                const uint4* __restrict__ hash, void* __restrict__ vba, void* __restrict__ sdfMirror,
+                                                                const float* __restrict__ depth, const uchar4* __restrict__ rgb, FuseParams p) {
+  integrate_hash_body_x4<VX>(blockIdx.x, gridDim.x, visibleIds, rc, hash, vba, sdfMirror, depth, rgb, p);
+}
+
 template <class VX>
 __global__ void __launch_bounds__(512) integrate_hash_kernel(const int32_t* __restrict__ visibleIds, RenderCounters* __restrict__ rc,
                                                              const uint4* __restrict__ hash, void* __restrict__ vba, void* __restrict__ sdfMirror,
@@ -333,7 +478,7 @@ __device__ unsigned long long g_fusedStamps[8192 * 2];
 #else
 #define ITM_FS(...)
 #endif
-template <class VX>
+template <class VX, bool X4 = false>
 __global__ void __launch_bounds__(512) integrate_project_kernel(const int32_t* __restrict__ visibleIds, RenderCounters* __restrict__ rc,
                                                                 const uint4* __restrict__ hash, void* __restrict__ vba, void* __restrict__ sdfMirror,
                                                                 const float* __restrict__ depth, const uchar4* __restrict__ rgb, FuseParams p,
@@ -351,7 +496,8 @@ __global__ void __launch_bounds__(512) integrate_project_kernel(const int32_t* _
     ITM_FS(__syncthreads(); if (threadIdx.x == 0) g_fusedStamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();)
     return;
   }
-  integrate_hash_body<VX>(blockIdx.x - kRangeParts, gridDim.x - kRangeParts, visibleIds, rc, hash, vba, sdfMirror, depth, rgb, p);
+  if constexpr (X4) integrate_hash_body_x4<VX>(blockIdx.x - kRangeParts, gridDim.x - kRangeParts, visibleIds, rc, hash, vba, sdfMirror, depth, rgb, p);
+  else integrate_hash_body<VX>(blockIdx.x - kRangeParts, gridDim.x - kRangeParts, visibleIds, rc, hash, vba, sdfMirror, depth, rgb, p);
   ITM_FS(__syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 8192) g_fusedStamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();)
 }
 #if ITM_EXP_FUSED_STAMPS
@@ -946,11 +1092,14 @@ int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipS
     }
     int rc = dispatch_voxel(s->cfg.voxelType, [&](auto vx) {
       using VX = decltype(vx);
-      if (fuseProjection)
-        integrate_project_kernel<VX><<<grid, 512, (size_t)RW * RH * sizeof(uint2), st>>>(rs->visibleIds, rs->counters, s->hash, s->vba, s->sdfMirror, v->depth, rgb, p,
-                                                                                       rs->range, rs->projBuf, rs->rangePartials, pp, RW, RH);
-      else
-        integrate_hash_kernel<VX><<<grid, 512, 0, st>>>(rs->visibleIds, rs->counters, s->hash, s->vba, s->sdfMirror, v->depth, rgb, p);
+      const bool x4 = !g_debug_integrate_slices;            // 16 bytes per lane, a block per wave (debug key 22: the slice kernel of rounds 2-3)
+      if (fuseProjection) {
+        if (x4) integrate_project_kernel<VX, true><<<grid, 512, (size_t)RW * RH * sizeof(uint2), st>>>(rs->visibleIds, rs->counters, s->hash, s->vba, s->sdfMirror, v->depth, rgb, p,
+                                                                                                     rs->range, rs->projBuf, rs->rangePartials, pp, RW, RH);
+        else integrate_project_kernel<VX, false><<<grid, 512, (size_t)RW * RH * sizeof(uint2), st>>>(rs->visibleIds, rs->counters, s->hash, s->vba, s->sdfMirror, v->depth, rgb, p,
+                                                                                                   rs->range, rs->projBuf, rs->rangePartials, pp, RW, RH);
+      } else if (x4) integrate_hash_x4_kernel<VX><<<grid, 512, 0, st>>>(rs->visibleIds, rs->counters, s->hash, s->vba, s->sdfMirror, v->depth, rgb, p);
+      else integrate_hash_kernel<VX><<<grid, 512, 0, st>>>(rs->visibleIds, rs->counters, s->hash, s->vba, s->sdfMirror, v->depth, rgb, p);
       return ITM_OK;
     });
     if (rc) return rc;

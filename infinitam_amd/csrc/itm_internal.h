@@ -81,6 +81,7 @@ struct itm_scene {
   int32_t* dirPtr = nullptr;      // int32[kDirCells]  (512 MB)
   int32_t* dirSlot = nullptr;     // int32[kDirCells]  (512 MB): table slot of the block at that position or -1 (request kernel)
   void* sdfMirror = nullptr;      // int16 / uint32 [kMirrorCells * 512]  (17 / 34 GB; hash scenes, itm_types.h) or nullptr
+  uint32_t* nearBits = nullptr;   // uint8[kMirrorCells] as words (16 MB; scenes with a mirror): per cell, which distances hold an allocated block (itm_types.h)
   // Where the two cubes lie (scene.hip, accel_place): re-placed around the camera when the view leaves them.  Invariant: the only
   // non-empty cells of dirPtr / dirSlot / sdfMirror are those of table entries with ptr >= 0 at `org` -- every path that replaces
   // the table or moves the origin empties exactly those cells first (O(allocated blocks), no 18 GB memset)
@@ -213,6 +214,7 @@ int refuse_while_ahead(const itm_scene* s, const itm_render_state* rs, const cha
 extern int g_debug_explicit_mark;
 extern int g_debug_two_pass_visible_list;
 extern int g_debug_integrate_wgs;
+extern int g_debug_integrate_slices;
 extern int g_debug_dense_group_cull;
 extern int g_debug_dense_classify;
 extern int g_debug_dense_no_strips;
@@ -222,6 +224,8 @@ extern int g_debug_tracker_session_unusable;
 extern int g_debug_no_sdf_mirror;
 extern int g_debug_separate_sweep;
 int rebuild_sdf_mirror(itm_scene* s, hipStream_t st);
+int near_bits_rebuild(itm_scene* s, hipStream_t st);      // cleared, then set again from the table (scene.hip)
+extern int g_debug_no_near_bits;
 int launch_swap_after_allocation(itm_scene* s, itm_render_state* rs, hipStream_t st);   // swapping.hip
 void free_swap_state(itm_scene* s);
 int create_swap_state(itm_scene* s);

@@ -319,6 +319,42 @@ __device__ inline void mirror_init_block(void* __restrict__ mirror, bool floatSd
   }
 }
 
+// ---- near bits ----------------------------------------------------------------------------------
+// One byte per cell of the mirror's cube (256^3 cells = 16 MB, x fastest like the mirror): bit k is set iff a voxel block has been
+// allocated at Chebyshev distance <= k (in blocks) from the cell, k = 0 .. 7.  The lowest set bit m of a cell says that every block
+// closer than m to it is unallocated (no bit set: closer than 8).  What the ray caster does with it (raycast_device.h): the reference's
+// step at a position without a block is 8 voxels along a unit direction (DeviceAgnostic/ITMVisualisationEngine.h:129-130,139), so
+// after k such steps the rounded position lies at most k + 1 blocks from the cell of the first one on every axis -- the positions of
+// the next m - 2 reads provably hold no block either, and the ray takes those steps on arithmetic alone: the same additions, the
+// same length test, no load.  Bits are only ever SET: by the allocation sweep for every block it allocates (also blocks outside the
+// cube, clipped), and again from the table after the cube has moved or the table was replaced.  A block that leaves (swapping)
+// keeps its bits: a distance that is too small only costs reads.
+constexpr int kNearReach = 7;
+// the near bits of the (up to 15 x 15 x 15) cells around block (bx, by, bz), by `nthreads` threads of which this is number `tid`
+__device__ inline void near_bits_splat(uint32_t* __restrict__ nearWords, const AccelOrigin& org, int bx, int by, int bz, int tid, int nthreads) {
+  const int cx = bx - org.mx, cy = by - org.my, cz = bz - org.mz;
+  if (cx < -kNearReach || cx >= kMirrorSide + kNearReach || cy < -kNearReach || cy >= kMirrorSide + kNearReach || cz < -kNearReach || cz >= kMirrorSide + kNearReach) return;
+  constexpr int kSpan = 2 * kNearReach + 1;            // 15 rows per axis
+  const int w0 = (cx - kNearReach) >> 2;               // first word of a row (arithmetic shift: may be negative)
+  constexpr int kWords = 5;                            // 15 cells touch at most 5 words of four
+  for (int task = tid; task < kSpan * kSpan * kWords; task += nthreads) {
+    const int wi = task % kWords, row = task / kWords;
+    const int dy = row % kSpan - kNearReach, dz = row / kSpan - kNearReach;
+    const int y = cy + dy, z = cz + dz, w = w0 + wi;
+    if ((unsigned)y >= (unsigned)kMirrorSide || (unsigned)z >= (unsigned)kMirrorSide || (unsigned)w >= (unsigned)(kMirrorSide / 4)) continue;
+    const int dyz = max(abs(dy), abs(dz));
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int d = max(abs(w * 4 + k - cx), dyz);
+      if (d <= kNearReach) m |= ((0xffu << d) & 0xffu) << (8 * k);
+    }
+    if (!m) continue;
+    uint32_t* word = nearWords + (((size_t)z << (2 * kMirrorBits - 2)) | ((size_t)y << (kMirrorBits - 2)) | (size_t)w);
+    if ((__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & m) != m) atomicOr(word, m);     // (bits only ever get set: a stale read costs an atomic, nothing else)
+  }
+}
+
 // 4x4 column-major matrix passed to kernels by value
 struct Mat4 { float m[16]; };
 

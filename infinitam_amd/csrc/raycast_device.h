@@ -45,6 +45,7 @@ struct VolumeView {
   int bucketNum;
   const int32_t* dirPtr;    // block directory (itm_types.h); nullptr = walk the table (hash index only)
   const void* sdfMirror;    // sdf by position (itm_types.h); nullptr = none (hash index only)
+  const uint8_t* nearBits;  // per cell of the mirror's cube: distances at which a block is allocated (itm_types.h); nullptr = none
   AccelOrigin org;          // where the directory / mirror cubes lie
   int sx, sy, sz;      // dense size
   int ox, oy, oz;      // dense offset
@@ -411,6 +412,12 @@ __device__ inline float4 cast_ray_plain(int x, int y, const VolumeView& vol, con
 #ifndef ITM_RAY_FLAT_STEP
 #define ITM_RAY_FLAT_STEP 1
 #endif
+#ifndef ITM_RAY_NEAR_SKIP
+// 1: after a mirror read that found no block, the near bits of that cell (itm_types.h) say how many of the following reads provably
+// find none either; the ray takes those steps without reading.  2: the byte is requested together with the mirror value at every step
+// (one round trip per hop instead of two, one more load per step for every lane).  0: off.
+#define ITM_RAY_NEAR_SKIP 1
+#endif
 #ifndef ITM_RAY_FAR_CELLS
 #define ITM_RAY_FAR_CELLS 0     // hash index with the mirror: positions a ray looks ahead after a single-voxel read of exactly 1 (0: never)
 #endif
@@ -597,6 +604,7 @@ __device__ inline float4 march_ray(int x, int y, const VolumeView& vol, const Ra
     while (st == MARCH && budget > 0) {
       --budget;
       ITM_WT(++wtInner;)
+      const float readX = px, readY = py, readZ = pz;          // where this read is made (the near-bit skip below needs the cell)
       const float sdf = sdf_nearest<VX, DENSE>(vol, px, py, pz, found, cache);
 #if ITM_RAY_FLAT_STEP
       {
@@ -626,6 +634,32 @@ __device__ inline float4 march_ray(int x, int y, const VolumeView& vol, const Ra
         }
       }
       if constexpr (!DENSE && (PARK || LOOKAHEAD > 0)) missStreak = found ? 0 : missStreak + 1;
+#if ITM_RAY_NEAR_SKIP
+      if constexpr (!DENSE) {
+        // Proven-empty space on arithmetic alone.  The read at `readX/Y/Z` (the position before this step) found no block; if its cell
+        // lies in the mirror's cube, the lowest set near bit m of the cell says that no block closer than m is allocated, and after k
+        // further steps of 8 voxels along a unit direction the rounded position is at most k + 1 blocks away on every axis (8 k + 1
+        // voxels: the step, plus half a voxel of rounding at either end; the accumulated float error of 7 additions at these magnitudes
+        // is below 0.2) -- so the reads of the next m - 2 positions find nothing, and each of them would be answered by exactly the step
+        // taken here: pt += 8 dir, total += 8, the range test (DeviceAgnostic/ITMVisualisationEngine.h:129-130,139-141).
+        const bool lost = !found && st == MARCH;
+        if (vol.nearBits && __any(lost)) {
+          const int cxr = ((int)round_ref(readX) >> 3) - vol.org.mx, cyr = ((int)round_ref(readY) >> 3) - vol.org.my, czr = ((int)round_ref(readZ) >> 3) - vol.org.mz;
+          const bool use = lost && mirror_covers((uint32_t)cxr, (uint32_t)cyr, (uint32_t)czr);
+          const uint32_t nb = vol.nearBits[use ? mirror_cell((uint32_t)cxr, (uint32_t)cyr, (uint32_t)czr) : 0u];
+          int skip = use ? (nb ? __builtin_ctz(nb) : 8) - 2 : 0;
+          const float sx = (float)kBlockSide * dx, sy = (float)kBlockSide * dy, sz = (float)kBlockSide * dz;      // exact products, as in the step above
+          int taken = 0;
+          while (skip > 0) {
+            --skip;
+            px += sx; py += sy; pz += sz; total += (float)kBlockSide;
+            ++taken;
+            if (!(total < totalMax)) { st = DONE; break; }
+          }
+          if constexpr (PARK || LOOKAHEAD > 0) missStreak += taken;
+        }
+      }
+#endif
       if constexpr (!DENSE && ITM_RAY_FAR_CELLS > 0) {
         const bool far = st == MARCH && found && sdf == 1.0f;      // SDF_valueToFloat(32767) is exactly 1
         if (vol.sdfMirror && (ITM_RAY_FAR_ALL ? (__all(st != MARCH || far) && __any(far)) : __any(far)))

@@ -180,6 +180,7 @@ struct itm_render_state {
   int w, h;
   bool hash;
   int capIds;
+  int rawVisible = 0;      // visible slots found by the last list build, before the clamp to capIds
   std::vector<V2f> range;        // renderingRangeImage
   std::vector<V4f> raycast;      // raycastResult
   std::vector<V4f> fwdProj;      // forwardProjection
@@ -536,7 +537,11 @@ void allocate_hash(itm_scene* s, const itm_view* view, itm_render_state* rs, boo
 
   int lastFreeVBA = s->lastFreeBlockId, lastFreeExcess = s->lastFreeExcessListId;
   std::memset(allocT, 0, (size_t)s->noTotalEntries);
-  for (int i = 0; i < rs->noVisibleEntries; ++i) visT[rs->visibleIds[i]] = 3;
+  // (_CPU.cpp:160-161 marks the previous LIST.  When more slots were visible than the list holds the reference has written past its
+  // list, SURVEY section 7 trap 6; product and oracle clamp list and count, and then every slot that was visible -- listed or not --
+  // counts as "visible in the previous frame": outside the reference's defined behaviour, the same rule on both sides)
+  if (rs->rawVisible > rs->capIds) { for (int t = 0; t < s->noTotalEntries; ++t) if (visT[t]) visT[t] = 3; }
+  else for (int i = 0; i < rs->noVisibleEntries; ++i) visT[rs->visibleIds[i]] = 3;
 
   ITMO_PARALLEL_FOR
   for (int loc = 0; loc < W * H; ++loc) {
@@ -648,6 +653,7 @@ void allocate_hash(itm_scene* s, const itm_view* view, itm_render_state* rs, boo
     }
   }
   rs->noVisibleEntries = (nv < rs->capIds) ? nv : rs->capIds;
+  rs->rawVisible = nv;
   s->lastFreeBlockId = lastFreeVBA;
   s->lastFreeExcessListId = lastFreeExcess;
 }
@@ -744,6 +750,7 @@ void find_visible_hash(const itm_scene* s, const float* M, const float* intr, it
     if (vis) { if (nv < rs->capIds) rs->visibleIds[nv] = t; nv++; }
   }
   rs->noVisibleEntries = (nv < rs->capIds) ? nv : rs->capIds;
+  rs->rawVisible = nv;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1509,7 +1516,7 @@ int itmo_get_counters(const itm_scene* s, const itm_render_state* rs, itm_counte
 int itmo_set_counters(itm_scene* s, itm_render_state* rs, const itm_counters* c, itm_stream) {
   if (!c) return fail(ITM_ERR_INVALID, "null argument");
   if (s) { s->lastFreeBlockId = c->lastFreeBlockId; s->lastFreeExcessListId = c->lastFreeExcessListId; }
-  if (rs) rs->noVisibleEntries = c->noVisibleEntries;
+  if (rs) { rs->noVisibleEntries = c->noVisibleEntries; rs->rawVisible = c->noVisibleEntries; }
   return ITM_OK;
 }
 

@@ -9,6 +9,7 @@ import pytest
 
 import itm_testlib as T
 from itm_testlib import Scenario
+from infinitam_amd import capi
 
 pytestmark = pytest.mark.gpu
 
@@ -370,3 +371,23 @@ def test_directory_is_rebuilt_after_table_upload(hip, oracle):
     assert np.array_equal(ra[..., 3], rb[..., 3])
     hit = ra[..., 3] > 0
     assert hit.sum() > 1000 and np.array_equal(ra[hit], rb[hit])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("voxel,colour", [(capi.VOXEL_S, False), (capi.VOXEL_F, False), (capi.VOXEL_S_RGB, True), (capi.VOXEL_F_RGB, True)])
+def test_hash_integration_a_block_per_wave_and_the_slice_kernel(hip, oracle, voxel, colour):
+    """The hash integration moves 16 bytes per lane, a whole block per wave (integrate_block_x4); ITM_DEBUG_INTEGRATE_SLICES (22) selects
+    the kernel of rounds 2-3 (one voxel per lane, four z-slices per wave).  Both against the oracle for every voxel type, fused with the
+    projection (four calls back to back) and as their own launch, with weights that saturate (maxW 3) and stopIntegratingAtMaxW."""
+    for stop in (False, True):
+        sc = Scenario(name="x4_%d_%d" % (voxel, stop), voxelType=voxel, colour=colour, w=320, h=240, voxelSize=0.006, frames=5, maxW=3,
+                      stopIntegratingAtMaxW=stop, trajectory="bench", noise_seed=11)
+        b = T.run_scenario(oracle, sc)
+        for key in (0, 1):
+            hip.check(hip.fn["debug_set"](22, key), "debug_set")
+            try:
+                for fused in ("four", False):
+                    a = T.run_scenario(hip, sc, fused=fused)
+                    T.compare_results(a, b, sc, what="%s/%s/%s" % (sc.name, "slices" if key else "block per wave", fused))
+            finally:
+                hip.check(hip.fn["debug_set"](22, 0), "debug_set")
