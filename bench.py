@@ -121,6 +121,10 @@ def launch_ranks(args) -> int:
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
                     "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "ITM_BENCH_SPAWNED": "1"})
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if env.get("ITM_BENCH_SHARED_GPU") == "1":
+            # several PROCESSES on one GPU: each library sees one scene and would pick the one-launch visible list, whose workgroups wait
+            # for each other -- between processes the queues are time-sliced and those waits collapse the frame rate (36 frames/s measured)
+            env.setdefault("ITM_ONE_PASS_LIST", "0")
         out = subprocess.PIPE if r == 0 else subprocess.DEVNULL
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
     text = procs[0].communicate()[0].decode(errors="replace")

@@ -201,7 +201,7 @@ int ITM_FN(set_device)(int device);
 #define ITM_DEBUG_NO_DEFERRED_FUSION 19         /* the four per-frame engine calls launch at once, one by one, instead of being recorded and fused (see "the four calls" below) */
 #define ITM_DEBUG_FORCE_LIST_STUCK 20           /* AllocateSceneFromDepth, one-launch visible list: chunk n - 1 behaves as if its bounded wait for another workgroup had expired (0 = off): the scene must raise statusFlags bit 1 and refuse further calls */
 #define ITM_DEBUG_NO_NEAR_BITS 21               /* ray casting: every position is read although the near bits prove some empty; set before itm_scene_create: none are allocated */
-#define ITM_DEBUG_INTEGRATE_SLICES 22           /* hash integration: one voxel per lane, four z-slices per wave (rounds 2-3) instead of 16 bytes per lane, a block per wave */
+#define ITM_DEBUG_INTEGRATE_BLOCK_PER_WAVE 22   /* hash integration: 16 bytes per lane, a whole block per wave, instead of one voxel per lane and four z-slices per wave (measured slower on every configuration, profiles/r4_integrate_notes.md; kept with its parity test) */
 int ITM_FN(debug_set)(int key, int value);
 /* dense integration, check mode of key 16: {free groups, shadow groups, mixed groups, violations}; reset != 0 clears */
 int ITM_FN(debug_dense_classify_check)(int32_t out[4], int reset);
@@ -551,8 +551,9 @@ typedef struct itm_accel_info {
   int32_t origin_directory[3], origin_mirror[3];
   int32_t placed;
   int64_t moves;
-  int64_t near_bits_bytes;     /* one byte per cell of the mirror's cube: which distances (0 .. 7 blocks) hold an allocated block -- rays cross
-                                  proven-empty space on arithmetic alone (0 = absent) */
+  int64_t near_bits_bytes;     /* measurement feature (ITM_NEAR_BITS=1 in the environment at scene creation; 0 = absent, the default): one byte per
+                                  cell of the mirror's cube saying which distances (0 .. 7 blocks) hold an allocated block, so that rays could
+                                  cross proven-empty space on arithmetic alone -- built, bit-exact, slower (profiles/r4_raycast_notes.md) */
 } itm_accel_info;
 int ITM_FN(scene_accel_info)(const itm_scene* scene, itm_accel_info* out);
 

@@ -351,14 +351,11 @@ __global__ void __launch_bounds__(256) visible_compact_kernel(const uint8_t* __r
 // device-scope load (the sweep wrote them with one).  No sweep waits for anything, so the waiting cannot cycle; in a frame without
 // excess requests -- almost all of them -- nobody waits.  The pool counters, which every sweep reads, are committed by the LAST
 // chunk after its look-back (all granules in = all sweeps done) instead of by chunk 0.
-#ifndef ITM_LIST_EARLY_SWEEPS
-#define ITM_LIST_EARLY_SWEEPS 1     // 0 (measurement builds only): excess-region chunks sweep themselves and wait for each other, as in round 3
-#endif
 struct SweepArgs {
   uint32_t* allocKey; int2* chunkReqNext; const int32_t* excessList; const int32_t* allocList; uint32_t* headBits;
   int32_t* dirPtr; int32_t* dirSlot; void* sdfMirror; const float* depth; int lazy;
   uint32_t* sweepDone;     // per chunk: the epoch of the launch whose sweep has placed the chunk's excess allocations
-  int early;               // workgroups at the head of the grid that only sweep an excess-region chunk (below)
+  uint32_t* sweepClaim;    // per chunk of the excess region: the epoch of the launch in which a workgroup took on the chunk's sweep (below)
   int32_t* fatalDev;       // the scene's host-visible status word (alloc_device.h: raise_fatal)
   int forceStuck;          // test hook (debug key 20): chunk whose wait is treated as expired, or -1
   uint32_t* nearWords;     // near bits of the mirror's cube (itm_types.h), or nullptr
@@ -375,16 +372,19 @@ extern "C" int itm_debug_read_list_stamps(unsigned long long* dst, int n) { retu
 #define ITM_LS(k)
 #endif
 
-// WHO WAITS FOR WHOM.  A workgroup of this launch may only wait for workgroups with a LOWER index: workgroups are dispatched in index
-// order, so everything a waiting workgroup depends on is resident (or done) whatever share of the device the launch gets -- masked
-// compute units, other processes, time-sliced queues -- and the waiting cannot deadlock.  The look-back has that shape by itself
-// (chunk c waits for chunks < c).  The stamps did not: an excess-region chunk waits for the sweep of EVERY chunk with excess requests,
-// and such a chunk may lie behind it in the excess region (a request whose chain tail is an excess entry).  With SWEEP the grid
-// therefore starts with sw.early workgroups -- one per chunk of the excess region -- that do nothing but sweep "their" excess-region
-// chunk (nearly always: one load, no requests, gone); workgroup early + c is chunk c as before, and only sweeps c itself when c lies
-// in the ordered region.  Every stamp an excess-region chunk waits for is then written by a workgroup in front of it.  The waits stay
-// bounded all the same; one that does expire means a device that no longer runs what it was given, and is fatal for the scene
-// (statusFlags bit 1, ITM_ERR_DEVICE at the next call; the frame's list is marked invalid and the integration fuses nothing through it).
+// WHO WAITS FOR WHOM.  A workgroup of this launch may only wait for work that a RUNNING workgroup has taken on: then nothing it
+// waits for can be stuck behind it, whatever share of the device the launch gets (masked compute units, other processes, time-sliced
+// queues) -- workgroups are dispatched in index order and a dispatched workgroup runs to its end.  The look-back has that shape by
+// itself: chunk c waits for chunks < c.  So do the stamps of ordered-region chunks, which only excess-region chunks -- all behind
+// them -- wait for.  The stamps of EXCESS-region chunks did not: excess-region chunk c waits for the sweep of every chunk with excess
+// requests, and such a chunk may lie behind c (a request whose chain tail is an excess entry).  Therefore the sweep of an
+// excess-region chunk is not tied to "its" workgroup: whoever needs it first CLAIMS it (an atomic exchange of the launch's epoch into
+// sweepClaim[j]) and does it -- its own workgroup when that gets there first, which is the usual case and costs one atomic per chunk
+// with requests; an excess-region workgroup that finds another excess-region chunk with requests unclaimed sweeps that chunk too
+// instead of waiting for a workgroup that may not have been dispatched.  A stamp is then only ever awaited from a workgroup that is
+// running.  The waits stay bounded all the same; one that does expire means a device that no longer runs what it was given, and is
+// fatal for the scene (statusFlags bit 1, ITM_ERR_DEVICE at the next call; the frame's list is marked invalid and the integration
+// fuses nothing through it).
 template <bool COMMIT_ALLOC, bool LAZY, bool SWEEP>
 __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__ visT, uint4* __restrict__ hash,
                                                            unsigned long long* __restrict__ chunkGran, uint32_t epoch,
@@ -404,20 +404,7 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
     __syncthreads();                                         // ... all of the chunk's have: say that its excess allocations are in place
     if (tid == 0) __hip_atomic_store(&sw.sweepDone[c], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
-  if constexpr (SWEEP) {
-    if ((int)blockIdx.x < sw.early) {
-      // ---- an early workgroup: the sweep of one excess-region chunk, nothing else ----
-      const int c = numChunks - sw.early + (int)blockIdx.x;
-      sweep_chunk<true>(c, sweepLds, sw.allocKey, chunkReq, sw.chunkReqNext, numChunks, hash, sw.excessList, sw.allocList, visT, counters, sw.headBits,
-                        sw.dirPtr, sw.dirSlot, sw.sdfMirror, sw.depth, sw.lazy, p, freshPtr);
-      if (chunkReq[c].y > 0) {                                 // (uniform; every request in the excess region is an excess request)
-        stamp_sweep(c);
-        if (freshPtr) splat_new_blocks(freshPtr, sw.nearWords, p.org);      // (stamp_sweep ended with a barrier)
-      }
-      return;
-    }
-  }
-  const int chunk = (int)blockIdx.x - (SWEEP ? sw.early : 0);
+  const int chunk = (int)blockIdx.x;
   const int slot0 = chunk * kSweepChunk + tid * kSlotsPerThread;
   const bool excessRegion = SWEEP && slot0 - tid * kSlotsPerThread >= p.bucketNum;      // uniform: bucketNum is a multiple of the chunk size (host)
   ITM_LS(0)
@@ -456,16 +443,31 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
     }
   }
   if constexpr (SWEEP) {
-    if (!excessRegion || !ITM_LIST_EARLY_SWEEPS) {
+    __shared__ int claimWon;
+    if (!excessRegion) {
       sweep_chunk<true>(chunk, sweepLds, sw.allocKey, chunkReq, sw.chunkReqNext, numChunks, hash, sw.excessList, sw.allocList, visT, counters, sw.headBits,
                         sw.dirPtr, sw.dirSlot, sw.sdfMirror, sw.depth, sw.lazy, p, freshPtr);
       if (chunkReq[chunk].y > 0) stamp_sweep(chunk);           // (uniform) only excess allocations are read by other workgroups of this launch
-    }
-    if (excessRegion) {
-      // every chunk that had excess requests must be through: chunks of the ordered region (workgroups early + j, j < chunk) and of the
-      // excess region (the early workgroups) -- all in front of this workgroup
+    } else {
+      // the sweeps of the excess region: this workgroup's own chunk first, then any other that still has no taker (see above)
+      const int firstExcess = p.bucketNum / kSweepChunk;
+      for (int r = 0; r < numChunks - firstExcess; ++r) {
+        const int j = (r == 0) ? chunk : firstExcess + r - 1 + ((firstExcess + r - 1 >= chunk) ? 1 : 0);      // chunk, then the others in order
+        if (r > 0 && chunkReq[j].y <= 0) continue;             // (uniform; every request in the excess region is an excess request)
+        if (r == 0 && chunkReq[j].x <= 0) { if (tid == 0) sw.chunkReqNext[j] = make_int2(0, 0); continue; }
+        __syncthreads();
+        if (tid == 0) claimWon = atomicExch(&sw.sweepClaim[j], epoch) != epoch;
+        __syncthreads();
+        if (!claimWon) continue;
+        sweep_chunk<true>(j, sweepLds, sw.allocKey, chunkReq, sw.chunkReqNext, numChunks, hash, sw.excessList, sw.allocList, visT, counters, sw.headBits,
+                          sw.dirPtr, sw.dirSlot, sw.sdfMirror, sw.depth, sw.lazy, p, freshPtr);
+        stamp_sweep(j);
+        if (freshPtr) splat_new_blocks(freshPtr, sw.nearWords, p.org);      // (stamp_sweep ended with a barrier; the queue is reused by the next sweep)
+      }
+      // every chunk that had excess requests must be through: the ordered-region ones run in front of this workgroup, the excess-region
+      // ones have all been claimed by now -- by a workgroup that is running
       for (int j = tid; j < numChunks; j += 256) {
-        if (chunkReq[j].y <= 0 || (!ITM_LIST_EARLY_SWEEPS && j == chunk)) continue;
+        if (chunkReq[j].y <= 0) continue;
         for (int spin = 0; __hip_atomic_load(&sw.sweepDone[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch; ++spin) {
           if (spin > (1 << 22)) { stuck = true; break; }
           __builtin_amdgcn_s_sleep(1);
@@ -531,7 +533,7 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
   if constexpr (SWEEP) {
     // the chunk's count is out: the near bits of the blocks its sweep allocated, while the look-back would only wait (block_exclusive_scan
     // above was the barrier behind the sweep)
-    if (freshPtr && (!excessRegion || !ITM_LIST_EARLY_SWEEPS) && chunkReq[chunk].x > 0) splat_new_blocks(freshPtr, sw.nearWords, p.org);
+    if (freshPtr && !excessRegion && chunkReq[chunk].x > 0) splat_new_blocks(freshPtr, sw.nearWords, p.org);
   }
   // base = visible slots in all earlier chunks
   look_back();
@@ -557,6 +559,7 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
     rc->noVisibleEntries = total < capIds ? total : capIds;
   }
   ITM_LS(4)
+  ITM_LS(5)
   if (n == 0) return;
   int pos = base + pos0;
 #pragma unroll
@@ -731,11 +734,9 @@ int launch_sweep_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, bo
   KernelTimer tv(s, ITM_TK_VISIBLE_LIST, st);
   if (onePass) {
     const uint32_t epoch = ++s->listEpoch;
-    // (the early workgroups: one per chunk of the excess region, see visible_list_kernel)
-    const int earlyWgs = (fusedSweep && ITM_LIST_EARLY_SWEEPS) ? nChunks - s->cfg.bucketNum / kSweepChunk : 0;
     const SweepArgs sw{s->allocKey, reqNext, s->excessList, s->allocList, s->headBits, s->dirPtr, s->dirSlot, s->sdfMirror, v->depth, lazy ? 1 : 0, s->chunkSweepDone,
-                       earlyWgs, s->fatalDev, fusedSweep ? g_debug_force_list_stuck - 1 : -1, s->nearBits};
-#define ITM_VL(CM, LZ, SW) visible_list_kernel<CM, LZ, SW><<<nChunks + earlyWgs, 256, 0, st>>>(rs->visibleType, s->hash, s->chunkGran, epoch, reqCur, nChunks, s->counters, rs->visibleIds, rs->capIds, rs->counters, p, sw)
+                       s->chunkSweepClaim, s->fatalDev, fusedSweep ? g_debug_force_list_stuck - 1 : -1, s->nearBits};
+#define ITM_VL(CM, LZ, SW) visible_list_kernel<CM, LZ, SW><<<nChunks, 256, 0, st>>>(rs->visibleType, s->hash, s->chunkGran, epoch, reqCur, nChunks, s->counters, rs->visibleIds, rs->capIds, rs->counters, p, sw)
     if (onlyVisible) { if (lazy) ITM_VL(false, true, false); else ITM_VL(false, false, false); }
     else if (fusedSweep) { if (lazy) ITM_VL(true, true, true); else ITM_VL(true, false, true); }
     else { if (lazy) ITM_VL(true, true, false); else ITM_VL(true, false, false); }

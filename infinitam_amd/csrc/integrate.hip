@@ -28,7 +28,7 @@ namespace itm {
 #define ITM_PROJECTION_PRIORITY 1
 #endif
 int g_debug_integrate_wgs = 0;
-int g_debug_integrate_slices = 0;   // debug key 22: the hash integration of rounds 2-3 (one voxel per lane, four z-slices per wave) instead of a block per wave
+int g_debug_integrate_block_per_wave = 0;   // debug key 22: the hash integration with 16 bytes per lane, a whole block per wave (integrate_block_x4)
 int g_debug_no_fused_projection = 0;
 int g_debug_dense_group_cull = 0;   // debug key 9: per-group frustum test instead of the per-column row interval
 int g_debug_dense_no_strips = 0;    // debug key 17: the launch shape of rounds 1-2 (four groups per lane) instead of the strip kernel
@@ -1092,7 +1092,7 @@ int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipS
     }
     int rc = dispatch_voxel(s->cfg.voxelType, [&](auto vx) {
       using VX = decltype(vx);
-      const bool x4 = !g_debug_integrate_slices;            // 16 bytes per lane, a block per wave (debug key 22: the slice kernel of rounds 2-3)
+      const bool x4 = g_debug_integrate_block_per_wave != 0;  // debug key 22: 16 bytes per lane, a block per wave (measured slower, profiles/r4_integrate_notes.md)
       if (fuseProjection) {
         if (x4) integrate_project_kernel<VX, true><<<grid, 512, (size_t)RW * RH * sizeof(uint2), st>>>(rs->visibleIds, rs->counters, s->hash, s->vba, s->sdfMirror, v->depth, rgb, p,
                                                                                                      rs->range, rs->projBuf, rs->rangePartials, pp, RW, RH);

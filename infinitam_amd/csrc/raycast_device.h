@@ -104,8 +104,10 @@ __device__ inline long long locate_voxel(const VolumeView& vol, int px, int py, 
 }
 
 // raw (unconverted) sdf of the voxel at an integer point; the default voxel when absent
-template <class VX, bool DENSE>
-__device__ inline float read_raw_sdf(const VolumeView& vol, int px, int py, int pz, bool& found, BlockCache& cache) {
+// skipLane: this lane wants no value (its answer comes from the near bits): it reads cell 0 and reports "no block"
+template <class VX, bool DENSE, bool NEAR = false>
+__device__ inline float read_raw_sdf(const VolumeView& vol, int px, int py, int pz, bool& found, BlockCache& cache, uint32_t* nearByte = nullptr, bool skipLane = false) {
+  if constexpr (NEAR) *nearByte = 0xffu;      // "a block right here": nothing may be skipped
   if constexpr (!DENSE) {
     // sdf mirror: one load, address from the position alone (same value and same "found" as the walk below: the mirror holds
     // exactly the voxels of the allocated blocks inside its cube)
@@ -115,8 +117,13 @@ __device__ inline float read_raw_sdf(const VolumeView& vol, int px, int py, int 
       // every lane was served: no exec-mask bracket around the common case (ray cast 42.1 -> 41.7 us)
       size_t mi = 0;
       const bool covered = mirror_index(vol.org, px, py, pz, mi);
-      const typename MC::T v = ((const typename MC::T*)vol.sdfMirror)[covered ? mi : (size_t)0];
-      const bool present = covered && !MC::absent(v);
+      const typename MC::T v = ((const typename MC::T*)vol.sdfMirror)[(covered && !skipLane) ? mi : (size_t)0];
+      if constexpr (NEAR) {
+        // the cell's near bits travel with the value (same cell index, an independent load): no second round trip after a miss
+        const uint32_t nb = vol.nearBits[covered ? (mi >> 9) : (size_t)0];
+        if (covered) *nearByte = nb;
+      }
+      const bool present = covered && !skipLane && !MC::absent(v);
       const float value = present ? MC::raw(v) : (VX::kShort ? 32767.0f : 1.0f);
       if (__all(covered)) { found = present; return value; }
       if (covered) { found = present; return value; }
@@ -131,6 +138,10 @@ __device__ inline float read_raw_sdf(const VolumeView& vol, int px, int py, int 
 template <class VX, bool DENSE>
 __device__ inline float sdf_nearest(const VolumeView& vol, float x, float y, float z, bool& found, BlockCache& cache) {
   return VX::to_float(read_raw_sdf<VX, DENSE>(vol, (int)round_ref(x), (int)round_ref(y), (int)round_ref(z), found, cache));
+}
+template <class VX>
+__device__ inline float sdf_nearest_near(const VolumeView& vol, float x, float y, float z, bool& found, BlockCache& cache, uint32_t& nearByte) {
+  return VX::to_float(read_raw_sdf<VX, false, true>(vol, (int)round_ref(x), (int)round_ref(y), (int)round_ref(z), found, cache, &nearByte));
 }
 
 // Walks the excess chain starting from an already loaded head entry; block base or -1.
@@ -416,7 +427,10 @@ __device__ inline float4 cast_ray_plain(int x, int y, const VolumeView& vol, con
 // 1: after a mirror read that found no block, the near bits of that cell (itm_types.h) say how many of the following reads provably
 // find none either; the ray takes those steps without reading.  2: the byte is requested together with the mirror value at every step
 // (one round trip per hop instead of two, one more load per step for every lane).  0: off.
-#define ITM_RAY_NEAR_SKIP 1
+// MEASURED (MI355X, BASELINE configs[1], ray cast in frame, profiles/r4_raycast_notes.md): 0: 38.3 us; 1: 44.3; 2: 42.3-43.3; 3 (near bits
+// FIRST inside a run, below): 44.3-45.1 -- every form loses: the march is bound by the instructions a step issues.  Default 0; scenes
+// only carry near bits when ITM_NEAR_BITS=1 is in the environment.
+#define ITM_RAY_NEAR_SKIP 0
 #endif
 #ifndef ITM_RAY_FAR_CELLS
 #define ITM_RAY_FAR_CELLS 0     // hash index with the mirror: positions a ray looks ahead after a single-voxel read of exactly 1 (0: never)
@@ -489,6 +503,9 @@ __device__ inline float4 march_ray(int x, int y, const VolumeView& vol, const Ra
   float px = r.px, py = r.py, pz = r.pz, total = r.total;
   const float dx = r.dx, dy = r.dy, dz = r.dz, totalMax = r.totalMax;
   int missStreak = 0;
+#if ITM_RAY_NEAR_SKIP == 3
+  bool confirm = false;
+#endif
   if (resume) { px = resume->px; py = resume->py; pz = resume->pz; total = resume->total; missStreak = ITM_RAY_PARK_STREAK; }
   BlockCache cache;
   bool found;
@@ -605,7 +622,33 @@ __device__ inline float4 march_ray(int x, int y, const VolumeView& vol, const Ra
       --budget;
       ITM_WT(++wtInner;)
       const float readX = px, readY = py, readZ = pz;          // where this read is made (the near-bit skip below needs the cell)
+#if ITM_RAY_NEAR_SKIP == 3
+      // NEAR FIRST inside a run.  A ray whose last read found no block asks the near bits of its position BEFORE (instead of) the
+      // mirror: the 16 MB of near bits are cache resident, the mirror's line of an empty cell is a cold kilobyte of HBM that says
+      // nothing else.  Bit 0 clear: no block here -- the read is answered, and the lowest set bit m grants m - 2 further steps.  Bit 0
+      // set: a block is (or was) here: the mirror is read at the same position in the wave's next iteration (`confirm`).
+      uint32_t nearByte = 0xffu;
+      bool nearFirst = false, stay = false;
+      float sdf;
+      if constexpr (!DENSE) {
+        if (vol.nearBits) {
+          const uint32_t ux = (uint32_t)(((int)round_ref(px) >> 3) - vol.org.mx), uy = (uint32_t)(((int)round_ref(py) >> 3) - vol.org.my), uz = (uint32_t)(((int)round_ref(pz) >> 3) - vol.org.mz);
+          nearFirst = missStreak >= 1 && !confirm && mirror_covers(ux, uy, uz);
+          nearByte = vol.nearBits[nearFirst ? mirror_cell(ux, uy, uz) : 0u];
+          sdf = VX::to_float(read_raw_sdf<VX, false, false>(vol, (int)round_ref(px), (int)round_ref(py), (int)round_ref(pz), found, cache, nullptr, nearFirst));
+          stay = nearFirst && (nearByte & 1u);
+          confirm = stay;
+        } else sdf = sdf_nearest<VX, DENSE>(vol, px, py, pz, found, cache);
+      } else sdf = sdf_nearest<VX, DENSE>(vol, px, py, pz, found, cache);
+      const float keepX = px, keepY = py, keepZ = pz, keepT = total;
+#elif ITM_RAY_NEAR_SKIP == 2
+      uint32_t nearByte = 0xffu;
+      float sdf;
+      if constexpr (!DENSE) { if (vol.nearBits) sdf = sdf_nearest_near<VX>(vol, px, py, pz, found, cache, nearByte); else sdf = sdf_nearest<VX, DENSE>(vol, px, py, pz, found, cache); }
+      else sdf = sdf_nearest<VX, DENSE>(vol, px, py, pz, found, cache);
+#else
       const float sdf = sdf_nearest<VX, DENSE>(vol, px, py, pz, found, cache);
+#endif
 #if ITM_RAY_FLAT_STEP
       {
         // the step as selects rather than branches (the same operations on the same values as advance(); a lone wave pays every
@@ -624,6 +667,9 @@ __device__ inline float4 march_ray(int x, int y, const VolumeView& vol, const Ra
       if (found && (sdf <= 0.1f) && (sdf >= -0.5f)) st = TRI;      // the position is kept for the trilinear read
       else st = advance(found, sdf);
 #endif
+#if ITM_RAY_NEAR_SKIP == 3
+      if (stay) { px = keepX; py = keepY; pz = keepZ; total = keepT; st = MARCH; }      // nothing was learnt but "read the mirror here"
+#endif
       if constexpr (DENSE) missed = !found;
       if constexpr (DENSE && LOOKAHEAD > 0) {
         const bool far = st == MARCH && found && sdf == 1.0f;      // SDF_valueToFloat(32767) is exactly 1
@@ -633,7 +679,11 @@ __device__ inline float4 march_ray(int x, int y, const VolumeView& vol, const Ra
           if (ended) st = DONE;
         }
       }
+#if ITM_RAY_NEAR_SKIP == 3
+      if constexpr (!DENSE) { if (!stay) missStreak = found ? 0 : missStreak + 1; }
+#else
       if constexpr (!DENSE && (PARK || LOOKAHEAD > 0)) missStreak = found ? 0 : missStreak + 1;
+#endif
 #if ITM_RAY_NEAR_SKIP
       if constexpr (!DENSE) {
         // Proven-empty space on arithmetic alone.  The read at `readX/Y/Z` (the position before this step) found no block; if its cell
@@ -644,10 +694,20 @@ __device__ inline float4 march_ray(int x, int y, const VolumeView& vol, const Ra
         // taken here: pt += 8 dir, total += 8, the range test (DeviceAgnostic/ITMVisualisationEngine.h:129-130,139-141).
         const bool lost = !found && st == MARCH;
         if (vol.nearBits && __any(lost)) {
+#if ITM_RAY_NEAR_SKIP == 3
+          (void)readX; (void)readY; (void)readZ;
+          const uint32_t nb = nearByte;
+          int skip = (lost && nearFirst && !stay) ? (nb ? __builtin_ctz(nb) : 8) - 2 : 0;
+#elif ITM_RAY_NEAR_SKIP == 2
+          (void)readX; (void)readY; (void)readZ;
+          const uint32_t nb = nearByte;             // (0xff unless the read went through the mirror)
+          int skip = lost ? (nb ? __builtin_ctz(nb) : 8) - 2 : 0;
+#else
           const int cxr = ((int)round_ref(readX) >> 3) - vol.org.mx, cyr = ((int)round_ref(readY) >> 3) - vol.org.my, czr = ((int)round_ref(readZ) >> 3) - vol.org.mz;
           const bool use = lost && mirror_covers((uint32_t)cxr, (uint32_t)cyr, (uint32_t)czr);
           const uint32_t nb = vol.nearBits[use ? mirror_cell((uint32_t)cxr, (uint32_t)cyr, (uint32_t)czr) : 0u];
           int skip = use ? (nb ? __builtin_ctz(nb) : 8) - 2 : 0;
+#endif
           const float sx = (float)kBlockSide * dx, sy = (float)kBlockSide * dy, sz = (float)kBlockSide * dz;      // exact products, as in the step above
           int taken = 0;
           while (skip > 0) {

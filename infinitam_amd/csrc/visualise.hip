@@ -626,7 +626,7 @@ int itm_debug_set(int key, int value) {
   if (key == ITM_DEBUG_DENSE_CLASSIFY) { g_debug_dense_classify = value; return ITM_OK; }
   if (key == ITM_DEBUG_TRACKER_SESSION_UNUSABLE) { g_debug_tracker_session_unusable = value; return ITM_OK; }
   if (key == ITM_DEBUG_DENSE_NO_STRIPS) { g_debug_dense_no_strips = value; return ITM_OK; }
-  if (key == ITM_DEBUG_INTEGRATE_SLICES) { g_debug_integrate_slices = value; return ITM_OK; }
+  if (key == ITM_DEBUG_INTEGRATE_BLOCK_PER_WAVE) { g_debug_integrate_block_per_wave = value; return ITM_OK; }
   if (key == ITM_DEBUG_NO_NEAR_BITS) { g_debug_no_near_bits = value; return ITM_OK; }
   if (key == ITM_DEBUG_NO_DEFERRED_FUSION) { g_debug_no_deferred_fusion = value; return ITM_OK; }
   if (key == ITM_DEBUG_FORCE_LIST_STUCK) { g_debug_force_list_stuck = value; return ITM_OK; }

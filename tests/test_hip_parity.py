@@ -376,8 +376,9 @@ def test_directory_is_rebuilt_after_table_upload(hip, oracle):
 @pytest.mark.gpu
 @pytest.mark.parametrize("voxel,colour", [(capi.VOXEL_S, False), (capi.VOXEL_F, False), (capi.VOXEL_S_RGB, True), (capi.VOXEL_F_RGB, True)])
 def test_hash_integration_a_block_per_wave_and_the_slice_kernel(hip, oracle, voxel, colour):
-    """The hash integration moves 16 bytes per lane, a whole block per wave (integrate_block_x4); ITM_DEBUG_INTEGRATE_SLICES (22) selects
-    the kernel of rounds 2-3 (one voxel per lane, four z-slices per wave).  Both against the oracle for every voxel type, fused with the
+    """The hash integration gives four z-slices of a block to a wave, one voxel per lane; ITM_DEBUG_INTEGRATE_BLOCK_PER_WAVE (22) selects
+    the kernel that moves 16 bytes per lane, a whole block per wave (integrate_block_x4: built for VERDICT r3 item 5, measured slower,
+    profiles/r4_integrate_notes.md).  Both against the oracle for every voxel type, fused with the
     projection (four calls back to back) and as their own launch, with weights that saturate (maxW 3) and stopIntegratingAtMaxW."""
     for stop in (False, True):
         sc = Scenario(name="x4_%d_%d" % (voxel, stop), voxelType=voxel, colour=colour, w=320, h=240, voxelSize=0.006, frames=5, maxW=3,
@@ -388,6 +389,6 @@ def test_hash_integration_a_block_per_wave_and_the_slice_kernel(hip, oracle, vox
             try:
                 for fused in ("four", False):
                     a = T.run_scenario(hip, sc, fused=fused)
-                    T.compare_results(a, b, sc, what="%s/%s/%s" % (sc.name, "slices" if key else "block per wave", fused))
+                    T.compare_results(a, b, sc, what="%s/%s/%s" % (sc.name, "block per wave" if key else "slices", fused))
             finally:
                 hip.check(hip.fn["debug_set"](22, 0), "debug_set")
