@@ -443,32 +443,56 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
     }
   }
   if constexpr (SWEEP) {
+    // ONE call site of sweep_chunk (a second inlined copy doubles the kernel's registers: 122 -> 200 VGPRs plus spills, and the 576
+    // workgroups are no longer resident together): a loop whose first round is the workgroup's own chunk and whose further rounds --
+    // excess-region workgroups only, and nearly never -- are other excess-region chunks that have requests and no taker yet.
     __shared__ int claimWon;
-    if (!excessRegion) {
-      sweep_chunk<true>(chunk, sweepLds, sw.allocKey, chunkReq, sw.chunkReqNext, numChunks, hash, sw.excessList, sw.allocList, visT, counters, sw.headBits,
-                        sw.dirPtr, sw.dirSlot, sw.sdfMirror, sw.depth, sw.lazy, p, freshPtr);
-      if (chunkReq[chunk].y > 0) stamp_sweep(chunk);           // (uniform) only excess allocations are read by other workgroups of this launch
-    } else {
-      // the sweeps of the excess region: this workgroup's own chunk first, then any other that still has no taker (see above)
-      const int firstExcess = p.bucketNum / kSweepChunk;
-      for (int r = 0; r < numChunks - firstExcess; ++r) {
-        const int j = (r == 0) ? chunk : firstExcess + r - 1 + ((firstExcess + r - 1 >= chunk) ? 1 : 0);      // chunk, then the others in order
-        if (r > 0 && chunkReq[j].y <= 0) continue;             // (uniform; every request in the excess region is an excess request)
-        if (r == 0 && chunkReq[j].x <= 0) { if (tid == 0) sw.chunkReqNext[j] = make_int2(0, 0); continue; }
+    __shared__ unsigned long long wanted;
+    const int firstExcess = p.bucketNum / kSweepChunk;
+    int j = chunk, j0 = firstExcess - 64;
+    unsigned long long left = 0;
+    for (bool own = true;; own = false) {
+      bool go = own ? chunkReq[chunk].x > 0 : true;            // (uniform)
+      if (own && !go && tid == 0) sw.chunkReqNext[chunk] = make_int2(0, 0);
+      if (go && excessRegion) {
+        // the sweep of an excess-region chunk belongs to whoever claims it first (see above)
         __syncthreads();
         if (tid == 0) claimWon = atomicExch(&sw.sweepClaim[j], epoch) != epoch;
         __syncthreads();
-        if (!claimWon) continue;
+        go = claimWon != 0;
+      }
+      if (go) {
         sweep_chunk<true>(j, sweepLds, sw.allocKey, chunkReq, sw.chunkReqNext, numChunks, hash, sw.excessList, sw.allocList, visT, counters, sw.headBits,
                           sw.dirPtr, sw.dirSlot, sw.sdfMirror, sw.depth, sw.lazy, p, freshPtr);
-        stamp_sweep(j);
-        if (freshPtr) splat_new_blocks(freshPtr, sw.nearWords, p.org);      // (stamp_sweep ended with a barrier; the queue is reused by the next sweep)
+        if (chunkReq[j].y > 0) {                               // (uniform) only excess allocations are read by other workgroups of this launch
+          stamp_sweep(j);
+          if (excessRegion && freshPtr) splat_new_blocks(freshPtr, sw.nearWords, p.org);      // (behind the stamp's barrier; the queue is reused by the next round)
+        }
       }
+      if (!excessRegion) break;
+      // the next excess-region chunk with requests, other than this workgroup's own: one load per lane, 64 chunks per look
+      while (!left) {
+        j0 += 64;
+        if (j0 >= numChunks) break;
+        __syncthreads();
+        if (tid < 64) {
+          const int c = j0 + tid;
+          const unsigned long long m = __ballot(c < numChunks && c != chunk && chunkReq[c < numChunks ? c : chunk].y > 0);
+          if (tid == 0) wanted = m;
+        }
+        __syncthreads();
+        left = wanted;
+      }
+      if (!left) break;
+      j = j0 + (int)__builtin_ctzll(left);
+      left &= left - 1;
+    }
+    if (excessRegion) {
       // every chunk that had excess requests must be through: the ordered-region ones run in front of this workgroup, the excess-region
       // ones have all been claimed by now -- by a workgroup that is running
-      for (int j = tid; j < numChunks; j += 256) {
-        if (chunkReq[j].y <= 0) continue;
-        for (int spin = 0; __hip_atomic_load(&sw.sweepDone[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch; ++spin) {
+      for (int c = tid; c < numChunks; c += 256) {
+        if (chunkReq[c].y <= 0) continue;
+        for (int spin = 0; __hip_atomic_load(&sw.sweepDone[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch; ++spin) {
           if (spin > (1 << 22)) { stuck = true; break; }
           __builtin_amdgcn_s_sleep(1);
         }
