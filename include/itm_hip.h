@@ -551,6 +551,7 @@ typedef struct itm_accel_info {
   int32_t origin_directory[3], origin_mirror[3];
   int32_t placed;
   int64_t moves;
+  int32_t mirror_pages, mirror_pages_mapped;   /* the mirror's pool: 64 KB pages (4 x 4 x 4 blocks of int16 sdf) it holds / has handed out (reading this synchronises the device) */
   int64_t near_bits_bytes;     /* measurement feature (ITM_NEAR_BITS=1 in the environment at scene creation; 0 = absent, the default): one byte per
                                   cell of the mirror's cube saying which distances (0 .. 7 blocks) hold an allocated block, so that rays could
                                   cross proven-empty space on arithmetic alone -- built, bit-exact, slower (profiles/r4_raycast_notes.md) */

@@ -140,7 +140,7 @@ class AccelInfo(C.Structure):
     """itm_accel_info (include/itm_hip.h)."""
     _fields_ = [("directory_bytes", C.c_int64), ("slot_directory_bytes", C.c_int64), ("mirror_bytes", C.c_int64),
                 ("origin_directory", C.c_int32 * 3), ("origin_mirror", C.c_int32 * 3), ("placed", C.c_int32), ("moves", C.c_int64),
-                ("near_bits_bytes", C.c_int64)]
+                ("mirror_pages", C.c_int32), ("mirror_pages_mapped", C.c_int32), ("near_bits_bytes", C.c_int64)]
 
 
 class ItmError(RuntimeError):
@@ -509,7 +509,7 @@ class Scene:
         a = AccelInfo()
         self.be.check(self.be.fn["scene_accel_info"](_P(self.h), C.byref(a)), "scene_accel_info")
         return {"directory_bytes": a.directory_bytes, "slot_directory_bytes": a.slot_directory_bytes, "mirror_bytes": a.mirror_bytes,
-                "near_bits_bytes": a.near_bits_bytes, "origin_directory": list(a.origin_directory), "origin_mirror": list(a.origin_mirror), "placed": bool(a.placed), "moves": a.moves}
+                "near_bits_bytes": a.near_bits_bytes, "mirror_pages": a.mirror_pages, "mirror_pages_mapped": a.mirror_pages_mapped, "origin_directory": list(a.origin_directory), "origin_mirror": list(a.origin_mirror), "placed": bool(a.placed), "moves": a.moves}
 
     def process_frame(self, view: View, rs: "RenderState", points: DevBuffer, normals: DevBuffer, stream=None):
         """ITMDenseMapper::ProcessFrame + ITMTrackingController::Prepare (Engine/ITMMainEngine.cpp:123-126)."""

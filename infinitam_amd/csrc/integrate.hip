@@ -250,7 +250,8 @@ __device__ inline void integrate_item(const HashEntry& he, int z0, int lane, typ
   using MC = MirrorCodec<VX::kShort>;
   size_t mbase = 0;
   typename MC::T* mirror = nullptr;
-  if (sdfMirror && mirror_index(p.org, he.px * kBlockSide, he.py * kBlockSide, he.pz * kBlockSide, mbase)) mirror = (typename MC::T*)sdfMirror;
+  // (the block's page was mapped when the block was allocated; the table entry is requested here, beside the voxels, and used at the end)
+  if (sdfMirror && mirror_block_base<false>(p.org, he.px, he.py, he.pz, mbase)) mirror = (typename MC::T*)sdfMirror;
   // stage 1: project every slice's voxel; stage 2: all depth pixels together; stage 3: update (+ colour), store what changed
   int pix[kSlices];
   float pcz[kSlices], mz[kSlices];
@@ -365,7 +366,8 @@ __device__ inline void integrate_block_x4(const HashEntry& he, int lane, Group<V
   using MC = MirrorCodec<VX::kShort>;
   size_t mbase = 0;
   typename MC::T* mirror = nullptr;
-  if (sdfMirror && mirror_index(p.org, he.px * kBlockSide, he.py * kBlockSide, he.pz * kBlockSide, mbase)) mirror = (typename MC::T*)sdfMirror;
+  // (the block's page was mapped when the block was allocated; the table entry is requested here, beside the voxels, and used at the end)
+  if (sdfMirror && mirror_block_base<false>(p.org, he.px, he.py, he.pz, mbase)) mirror = (typename MC::T*)sdfMirror;
   // stage 1: project the eight voxels; stage 2: their depth pixels together; stage 3: update (+ colour), store the groups that changed
   int pix[8];
   float pcz[8], mx[4], mz[2];

@@ -81,12 +81,14 @@ struct itm_scene {
   // order.  Maintained by the allocation sweep, rebuilt after uploads; an exact mirror of the table entries with ptr >= 0.
   int32_t* dirPtr = nullptr;      // int32[kDirCells]  (512 MB)
   int32_t* dirSlot = nullptr;     // int32[kDirCells]  (512 MB): table slot of the block at that position or -1 (request kernel)
-  void* sdfMirror = nullptr;      // int16 / uint32 [kMirrorCells * 512]  (17 / 34 GB; hash scenes, itm_types.h) or nullptr
+  void* sdfMirror = nullptr;      // the mirror's page pool: int16 / uint32 [mirrorPages * 64 * 512] (512 MB; hash scenes, itm_types.h) or nullptr;
+                                  // its page table and page counter travel to the kernels inside `org` (AccelOrigin::mTable / mPages / mMaxPages)
+  int mirrorPages = 0;
   uint32_t* nearBits = nullptr;   // uint8[kMirrorCells] as words (16 MB; scenes with a mirror): per cell, which distances hold an allocated block (itm_types.h)
   // Where the two cubes lie (scene.hip, accel_place): re-placed around the camera when the view leaves them.  Invariant: the only
   // non-empty cells of dirPtr / dirSlot / sdfMirror are those of table entries with ptr >= 0 at `org` -- every path that replaces
   // the table or moves the origin empties exactly those cells first (O(allocated blocks), no 18 GB memset)
-  itm::AccelOrigin org = {-itm::kDirHalf, -itm::kDirHalf, -itm::kDirHalf, -itm::kMirrorHalf, -itm::kMirrorHalf, -itm::kMirrorHalf + itm::kMirrorShift};
+  itm::AccelOrigin org = {-itm::kDirHalf, -itm::kDirHalf, -itm::kDirHalf, -itm::kMirrorHalf, -itm::kMirrorHalf, -itm::kMirrorHalf + itm::kMirrorShift, nullptr, nullptr, 0};
   // swapping (scenes with cfg.useSwapping; swapping.hip): ITMHashSwapState per entry on the device, the ITMGlobalCache in host memory
   uint8_t* swapStates = nullptr;           // uchar[noTotalEntries]
   struct SwapHost* swapHost = nullptr;

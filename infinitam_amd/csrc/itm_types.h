@@ -223,6 +223,10 @@ constexpr size_t kDirCells = (size_t)kDirSide * kDirSide * kDirSide;
 struct AccelOrigin {
   int32_t dx, dy, dz;
   int32_t mx, my, mz;
+  // the mirror's page table, the pool's page counter and size (sdf mirror below); nullptr / 0 for a scene without a mirror
+  int32_t* mTable;
+  int32_t* mPages;
+  int32_t mMaxPages;
 };
 
 // cube-relative block coordinates (each in [0, kDirSide) when the block is covered)
@@ -251,15 +255,25 @@ __device__ inline void directory_insert(int32_t* __restrict__ dirPtr, int32_t* _
 }
 
 // ---- sdf mirror -------------------------------------------------------------------------------
-// A second copy of the sdf of every voxel, addressed by POSITION instead of through the block pointer:
-//   sdfMirror[mirror_cell(block) * 512 + voxel-in-block]   the voxel's raw sdf (int16 for the short voxel types, the float's bits
-//                                                          for the float types), or an "absent" pattern where no block is allocated
-// over a cube of 256^3 blocks placed in front of the camera (AccelOrigin: centred kMirrorShift blocks along the viewing direction
-// of the frame that placed it, moved when the view leaves it), i.e. 256^3 cells x 1 KB = 17 GB (short) / 2 KB = 34 GB (float) of the 288 GB.  The pointer chase of a ray step -- directory cell,
-// then voxel, two dependent round trips -- becomes one load whose address follows from the position alone, and the eight reads of a
-// trilinear sample are independent of any look-up.  "Absent": -32768 cannot be a stored short sdf ((short)(f * 32767) with f in
-// [-1, 1]); 0xFFFFFFFF is a NaN no arithmetic produces.  Written wherever voxels are written: at allocation (the initial value),
-// by the integration, and rebuilt from the table after an upload; blocks outside the cube use the directory.
+// A second copy of the sdf of every voxel of every allocated block, addressed by POSITION instead of through the block pointer, over a
+// cube of 256^3 blocks placed in front of the camera (AccelOrigin: centred kMirrorShift blocks along the viewing direction of the frame
+// that placed it, moved when the view leaves it).  Rounds 2-3 stored the cube densely -- 256^3 cells x 1 KB = 17 GB per scene whatever
+// it held.  Round 4: the cube is PAGED.  A page is 4 x 4 x 4 blocks (64 KB of int16 sdf, 128 KB of float bits); a table of 64^3
+// entries (1 MB) says for every page of the cube
+//     >= 0   the page's index in the pool: value of voxel v of block b = pool[(page * 64 + block-in-page) * 512 + v]
+//     -1     no block was ever allocated in the page: every position in it reads "no block" WITHOUT a second load
+//     -3     the pool had run dry when a block of the page was allocated: the page says nothing, readers use the block directory
+//     (-2    a thread is taking a page from the pool right now; only ever seen inside the kernel that allocates)
+// and pages are handed out by whoever allocates the first block in them (mirror_claim_page).  Memory is O(touched pages): the bench
+// scene (sphere + wall, 60 k blocks allocated over the trajectory) maps ~1 100 pages = 70 MB of a 512 MB pool.  What a ray step costs:
+// the table entry (1 MB, cache resident; kept per lane while the ray stays inside the page -- a page is 32 voxels wide, a step at most
+// 8) and then ONE load whose address follows from the position, as before; in empty space the table alone answers, where the dense
+// cube answered with a cold kilobyte of HBM per cell.  "Absent" inside a mapped page: -32768 cannot be a stored short sdf
+// ((short)(f * 32767) with f in [-1, 1]); 0xFFFFFFFF is a NaN no arithmetic produces.  Written wherever voxels are written: at
+// allocation (the initial value), by the integration, by the swapping engine, and again from the table after the cube has moved or
+// the table was replaced.  Invariant: the only cells of mapped pages that are not "absent" are those of table entries with ptr >= 0 --
+// so emptying the mirror is a pass over the table that writes "absent" into exactly those cells, after which EVERY page of the pool
+// is clean again, the page table returns to -1 and the pool's counter to 0.
 #ifndef ITM_MIRROR_BITS
 #define ITM_MIRROR_BITS 8
 #endif
@@ -268,6 +282,10 @@ constexpr int kMirrorSide = 1 << kMirrorBits;
 constexpr int kMirrorHalf = kMirrorSide / 2;
 constexpr int kMirrorShift = kMirrorSide / 4;      // the cube is centred kMirrorShift blocks in front of the camera that placed it
 constexpr size_t kMirrorCells = (size_t)kMirrorSide * kMirrorSide * kMirrorSide;
+constexpr int kPageBits = 2;                        // a page is 4 x 4 x 4 blocks
+constexpr int kPageBlocks = 1 << (3 * kPageBits);   // 64
+constexpr size_t kMirrorTableCells = kMirrorCells >> (3 * kPageBits);      // 64^3
+constexpr int kPageNone = -1, kPageClaiming = -2, kPageUnmappable = -3;
 template <bool SHORT> struct MirrorCodec;
 template <> struct MirrorCodec<true> {
   using T = int16_t;
@@ -282,32 +300,52 @@ template <> struct MirrorCodec<false> {
   __device__ static T of(float rawSdf) { return __float_as_uint(rawSdf); }
 };
 __host__ __device__ inline bool mirror_covers(uint32_t ux, uint32_t uy, uint32_t uz) { return ((ux | uy | uz) >> kMirrorBits) == 0u; }
-// plain x-fastest order of the blocks: a block's 512 values are a kilobyte of their own, so -- unlike the directory's 4-byte cells --
-// nothing is gained by keeping neighbouring blocks in one brick, and the brick-major index cost ~24 vector instructions of the ~90
-// a ray step issues (the march is bound by its instruction chain, profiles/r3_raycast_notes.md)
-#ifndef ITM_MIRROR_LINEAR
-#define ITM_MIRROR_LINEAR 1
-#endif
-__host__ __device__ inline uint32_t mirror_cell(uint32_t ux, uint32_t uy, uint32_t uz) {
-#if ITM_MIRROR_LINEAR
-  return (uz << (2 * kMirrorBits)) | (uy << kMirrorBits) | ux;
-#else
-  const uint32_t brick = ((uz >> 2) << (2 * (kMirrorBits - 2))) | ((uy >> 2) << (kMirrorBits - 2)) | (ux >> 2);
-  return (brick << 6) | ((uz & 3u) << 4) | ((uy & 3u) << 2) | (ux & 3u);
-#endif
+// the cells of the cube in plain x-fastest order (the near bits, one byte per cell)
+__host__ __device__ inline uint32_t mirror_cell(uint32_t ux, uint32_t uy, uint32_t uz) { return (uz << (2 * kMirrorBits)) | (uy << kMirrorBits) | ux; }
+// page-table entry of the page that holds cube-relative block (ux, uy, uz), and the block's place inside its page
+__host__ __device__ inline uint32_t mirror_table_index(uint32_t ux, uint32_t uy, uint32_t uz) {
+  return ((uz >> kPageBits) << (2 * (kMirrorBits - kPageBits))) | ((uy >> kPageBits) << (kMirrorBits - kPageBits)) | (ux >> kPageBits);
 }
-// mirror index of the voxel at integer point (px, py, pz); false when its block lies outside the mirrored cube
-__host__ __device__ inline bool mirror_index(const AccelOrigin& org, int px, int py, int pz, size_t& idx) {
-  const uint32_t ux = (uint32_t)((px >> 3) - org.mx), uy = (uint32_t)((py >> 3) - org.my), uz = (uint32_t)((pz >> 3) - org.mz);
-  if (!mirror_covers(ux, uy, uz)) return false;
-  idx = (size_t)mirror_cell(ux, uy, uz) * 512u + (size_t)((px & 7) + ((py & 7) << 3) + ((pz & 7) << 6));
+__host__ __device__ inline uint32_t mirror_block_in_page(uint32_t ux, uint32_t uy, uint32_t uz) {
+  return ((uz & 3u) << (2 * kPageBits)) | ((uy & 3u) << kPageBits) | (ux & 3u);
+}
+// pool index of voxel `lin` of block-in-page `blk` of page `page`
+__host__ __device__ inline size_t mirror_element(int page, uint32_t blk, uint32_t lin) { return ((size_t)page * kPageBlocks + blk) * 512u + lin; }
+
+// The page of a table entry, taking one from the pool if the page has none yet (allocation paths only).  Safe between the lanes of
+// one wave as well: whoever wins the exchange publishes the page before it leaves the loop body, nobody waits inside the loop for a
+// lane of its own wave.  Returns the page index, or kPageUnmappable.
+__device__ inline int mirror_claim_page(const AccelOrigin& org, uint32_t tIdx) {
+  int v = __hip_atomic_load(&org.mTable[tIdx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  while (v == kPageNone || v == kPageClaiming) {
+    if (v == kPageNone) {
+      const int old = atomicCAS(&org.mTable[tIdx], kPageNone, kPageClaiming);
+      if (old == kPageNone) {
+        const int pg = atomicAdd(org.mPages, 1);
+        v = pg < org.mMaxPages ? pg : kPageUnmappable;          // (a page of the pool is all "absent" until it is handed out: see the invariant above)
+        __hip_atomic_store(&org.mTable[tIdx], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else v = old;
+    } else v = __hip_atomic_load(&org.mTable[tIdx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return v;
+}
+// Pool index of voxel 0 of block (bx, by, bz); false when the block has no place in the mirror (outside the cube, page not mapped).
+// CLAIM: map the page if it is not (allocation paths); otherwise a plain read of the table.
+template <bool CLAIM>
+__device__ inline bool mirror_block_base(const AccelOrigin& org, int bx, int by, int bz, size_t& base) {
+  const uint32_t ux = (uint32_t)(bx - org.mx), uy = (uint32_t)(by - org.my), uz = (uint32_t)(bz - org.mz);
+  if (!org.mTable || !mirror_covers(ux, uy, uz)) return false;
+  const uint32_t tIdx = mirror_table_index(ux, uy, uz);
+  const int page = CLAIM ? mirror_claim_page(org, tIdx) : org.mTable[tIdx];
+  if (page < 0) return false;
+  base = mirror_element(page, mirror_block_in_page(ux, uy, uz), 0u);
   return true;
 }
 
 // a block has just been allocated: its voxels hold the initial value (sdf 32767 / 1.0f); called by one thread (the allocation sweep)
 __device__ inline void mirror_init_block(void* __restrict__ mirror, bool floatSdf, const AccelOrigin& org, int bx, int by, int bz) {
   size_t base;
-  if (!mirror || !mirror_index(org, bx * 8, by * 8, bz * 8, base)) return;
+  if (!mirror || !mirror_block_base<true>(org, bx, by, bz, base)) return;
   if (floatSdf) {
     uint4* q = (uint4*)((uint32_t*)mirror + base);         // 2 KB, 16-byte aligned
     const uint4 init = make_uint4(0x3f800000u, 0x3f800000u, 0x3f800000u, 0x3f800000u);

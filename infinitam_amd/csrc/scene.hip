@@ -161,9 +161,14 @@ __global__ void __launch_bounds__(256) mirror_fill_kernel(const uint4* __restric
   for (int i = blockIdx.x; i < nEntries; i += gridDim.x) {
     const HashEntry e = unpack_entry(hash[i]);
     if (e.ptr < 0) continue;
-    size_t base;
-    if (!mirror_index(org, e.px * kBlockSide, e.py * kBlockSide, e.pz * kBlockSide, base)) continue;
     if (FILL && (size_t)e.ptr * kBlockVoxels + kBlockVoxels > numVoxels) continue;      // an uploaded table may hold anything
+    // (FILL maps the block's page if need be: one thread asks, the workgroup hears the answer)
+    __shared__ size_t baseShared; __shared__ int okShared;
+    __syncthreads();
+    if (threadIdx.x == 0) { size_t b0 = 0; okShared = mirror_block_base<FILL>(org, e.px, e.py, e.pz, b0) ? 1 : 0; baseShared = b0; }
+    __syncthreads();
+    if (!okShared) continue;
+    const size_t base = baseShared;
     for (int t = threadIdx.x; t < kBlockVoxels; t += 256) {
       typename MC::T v;
       if constexpr (FILL) v = MC::of(VX::load_raw_sdf(vba, (size_t)e.ptr * kBlockVoxels + t));
@@ -178,10 +183,13 @@ __global__ void __launch_bounds__(256) mirror_fill_kernel(const uint4* __restric
 #define ITM_MIRROR_FLOAT_TYPES 0
 #endif
 static bool mirror_is_float(const itm_scene* s) { return s->cfg.voxelType == ITM_VOXEL_F || s->cfg.voxelType == ITM_VOXEL_F_RGB; }
-// every cell "no block here": -32768 per short, all ones per float (scene creation only)
+// every voxel of every page of the pool "no block here" (-32768 per short, all ones per float), no page handed out (scene creation only)
 static hipError_t mirror_clear(itm_scene* s, hipStream_t st) {
-  if (mirror_is_float(s)) return hipMemsetAsync(s->sdfMirror, 0xff, kMirrorCells * 512 * 4, st);
-  return hipMemsetD16Async((unsigned short*)s->sdfMirror, (unsigned short)0x8000, kMirrorCells * 512, st);
+  const size_t voxels = (size_t)s->mirrorPages * kPageBlocks * 512;
+  hipError_t e = mirror_is_float(s) ? hipMemsetAsync(s->sdfMirror, 0xff, voxels * 4, st) : hipMemsetD16Async((unsigned short*)s->sdfMirror, (unsigned short)0x8000, voxels, st);
+  if (e == hipSuccess) e = hipMemsetAsync(s->org.mTable, 0xff, kMirrorTableCells * 4, st);
+  if (e == hipSuccess) e = hipMemsetAsync(s->org.mPages, 0, 4, st);
+  return e;
 }
 
 template <bool FILL>
@@ -194,6 +202,11 @@ static int mirror_pass(itm_scene* s, hipStream_t st) {
   });
   if (rc) return rc;
   ITM_LAUNCH_CHECK();
+  if (!FILL) {
+    // every mapped page is all "absent" again (the invariant of itm_types.h): the pool is as good as new
+    ITM_HIP(hipMemsetAsync(s->org.mTable, 0xff, kMirrorTableCells * 4, st));
+    ITM_HIP(hipMemsetAsync(s->org.mPages, 0, 4, st));
+  }
   return ITM_OK;
 }
 template <bool FILL>
@@ -313,7 +326,8 @@ static void accel_place_for_table(itm_scene* s, const HashEntry* entries, size_t
   }
   if (!any) { s->orgPlaced = false; return; }
   const int c[3] = {round4((lo[0] + hi[0]) * 0.5), round4((lo[1] + hi[1]) * 0.5), round4((lo[2] + hi[2]) * 0.5)};
-  s->org = {c[0] - kDirHalf, c[1] - kDirHalf, c[2] - kDirHalf, c[0] - kMirrorHalf, c[1] - kMirrorHalf, c[2] - kMirrorHalf};
+  s->org.dx = c[0] - kDirHalf; s->org.dy = c[1] - kDirHalf; s->org.dz = c[2] - kDirHalf;
+  s->org.mx = c[0] - kMirrorHalf; s->org.my = c[1] - kMirrorHalf; s->org.mz = c[2] - kMirrorHalf;
   s->orgPlaced = true;
 }
 
@@ -413,7 +427,7 @@ static void free_scene(itm_scene* s) {
   if (s->prof) { s->prof->flush(); for (hipEvent_t e : s->prof->pool) (void)hipEventDestroy(e); delete s->prof; }
   (void)hipFree(s->hash); (void)hipFree(s->excessList); (void)hipFree(s->vba); (void)hipFree(s->allocList);
   (void)hipFree(s->counters); (void)hipFree(s->headBits); (void)hipFree(s->allocKey); (void)hipFree(s->chunkReq); (void)hipFree(s->chunkVis); (void)hipFree(s->chunkGran); (void)hipFree(s->chunkSweepDone); (void)hipFree(s->chunkSweepClaim);
-  (void)hipFree(s->dirPtr); (void)hipFree(s->dirSlot); (void)hipFree(s->sdfMirror); (void)hipFree(s->nearBits); (void)hipFree(s->depthTiles);
+  (void)hipFree(s->dirPtr); (void)hipFree(s->dirSlot); (void)hipFree(s->sdfMirror); (void)hipFree(s->org.mTable); (void)hipFree(s->org.mPages); (void)hipFree(s->nearBits); (void)hipFree(s->depthTiles);
   delete s;
 }
 static void free_rs(itm_render_state* r) {
@@ -535,15 +549,24 @@ int itm_scene_create(const itm_scene_config* cfg_in, const itm_scene_params* prm
     if (hipMalloc((void**)&s->dirPtr, kDirCells * 4) != hipSuccess) { s->dirPtr = nullptr; (void)hipGetLastError(); }
     else if (hipMalloc((void**)&s->dirSlot, kDirCells * 4) != hipSuccess) { (void)hipFree(s->dirPtr); s->dirPtr = nullptr; s->dirSlot = nullptr; (void)hipGetLastError(); }
   }
-  // The sdf mirror is an accelerator: taken when the device has room to spare, silently left out otherwise -- and only for the short
-  // voxel types.  For the float types (34 GB) it was measured on BASELINE configs[4]: ray cast 119 -> 106 us, but the integration pays
-  // 175 -> 189 us for the extra 4-byte stores: 2 609 -> 2 560 frames/s.  (ITM_MIRROR_FLOAT_TYPES=1 builds it in.)
+  // The sdf mirror is an accelerator: taken when the device has room for its pool (512 MB: 8 192 pages of 64 KB for the short voxel
+  // types; the table says which pages of the cube are mapped, itm_types.h), silently left out otherwise -- and only for the short voxel
+  // types.  For the float types it was measured on BASELINE configs[4]: the ray cast gains less than the integration pays for the extra
+  // 4-byte stores (ITM_MIRROR_FLOAT_TYPES=1 builds it in).  ITM_MIRROR_PAGES in the environment sizes the pool.
   if (cfg.indexType == ITM_INDEX_HASH && s->dirPtr && !g_debug_no_sdf_mirror && (ITM_MIRROR_FLOAT_TYPES || !mirror_is_float(s))) {
+    int pages = mirror_is_float(s) ? 4096 : 8192;
+    if (const char* e = getenv("ITM_MIRROR_PAGES")) { const int v = atoi(e); if (v > 0) pages = v; }
     size_t freeB = 0, totalB = 0;
-    const size_t bytes = kMirrorCells * 512 * (mirror_is_float(s) ? 4 : 2);
+    const size_t bytes = (size_t)pages * kPageBlocks * 512 * (mirror_is_float(s) ? 4 : 2);
     if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB > 3 * bytes) {
-      if (hipMalloc(&s->sdfMirror, bytes) != hipSuccess) { s->sdfMirror = nullptr; (void)hipGetLastError(); }
-      else if (mirror_clear(s, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) { (void)hipFree(s->sdfMirror); s->sdfMirror = nullptr; (void)hipGetLastError(); }
+      s->mirrorPages = pages;
+      s->org.mMaxPages = pages;
+      if (hipMalloc(&s->sdfMirror, bytes) != hipSuccess || hipMalloc((void**)&s->org.mTable, kMirrorTableCells * 4) != hipSuccess ||
+          hipMalloc((void**)&s->org.mPages, 4) != hipSuccess || mirror_clear(s, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(s->sdfMirror); (void)hipFree(s->org.mTable); (void)hipFree(s->org.mPages);
+        s->sdfMirror = nullptr; s->org.mTable = nullptr; s->org.mPages = nullptr; s->org.mMaxPages = 0; s->mirrorPages = 0;
+      }
     }
   }
   // near bits (itm_types.h): MEASUREMENT FEATURE, off unless ITM_NEAR_BITS=1 is in the environment when the scene is created.  Built for
@@ -605,7 +628,10 @@ int itm_scene_accel_info(const itm_scene* s, itm_accel_info* out) {
   out->directory_bytes = s->dirPtr ? (int64_t)(kDirCells * 4) : 0;
   out->slot_directory_bytes = s->dirSlot ? (int64_t)(kDirCells * 4) : 0;
   out->near_bits_bytes = s->nearBits ? (int64_t)kMirrorCells : 0;
-  out->mirror_bytes = s->sdfMirror ? (int64_t)(kMirrorCells * 512 * (s->cfg.voxelType == ITM_VOXEL_F || s->cfg.voxelType == ITM_VOXEL_F_RGB ? 4 : 2)) : 0;
+  out->mirror_bytes = s->sdfMirror ? (int64_t)((size_t)s->mirrorPages * kPageBlocks * 512 * (mirror_is_float(s) ? 4 : 2) + kMirrorTableCells * 4) : 0;
+  out->mirror_pages = s->mirrorPages;
+  out->mirror_pages_mapped = 0;
+  if (s->sdfMirror) { int n = 0; if (hipMemcpy(&n, s->org.mPages, 4, hipMemcpyDeviceToHost) == hipSuccess) out->mirror_pages_mapped = n < s->mirrorPages ? n : s->mirrorPages; else (void)hipGetLastError(); }
   out->origin_directory[0] = s->org.dx; out->origin_directory[1] = s->org.dy; out->origin_directory[2] = s->org.dz;
   out->origin_mirror[0] = s->org.mx; out->origin_mirror[1] = s->org.my; out->origin_mirror[2] = s->org.mz;
   out->placed = s->orgPlaced ? 1 : 0;
