@@ -279,7 +279,7 @@ __device__ inline void integrate_item(const HashEntry& he, int z0, int lane, typ
     }
     if (touched) {
       VX::store(vba, vi + 64 * k, r[k]);
-      if (mirror) mirror[mbase + (size_t)(z0 + k) * 64 + lane] = MC::of(VX::raw_sdf(r[k]));   // sdf mirror (itm_types.h)
+      if (mirror) mirror[mbase + mirror_block_voxel((uint32_t)x, (uint32_t)y, (uint32_t)(z0 + k))] = MC::of(VX::raw_sdf(r[k]));   // sdf mirror (itm_types.h): rows of 8 lanes are 16 contiguous bytes
     }
   }
 }
@@ -410,7 +410,7 @@ __device__ inline void integrate_block_x4(const HashEntry& he, int lane, Group<V
       if (mirror) {
         // the group's four sdf values as one store (8 bytes for the short types, 16 for the float ones): a voxel that did not change
         // is rewritten with the value it holds
-        const size_t mi = mbase + (size_t)(4 * lane + 256 * h);
+        const size_t mi = mbase + mirror_block_voxel((uint32_t)x0, (uint32_t)y, (uint32_t)(zl + 4 * h));
         if constexpr (VX::kShort) {
           const uint32_t a = (uint32_t)(uint16_t)MC::of(VX::raw_sdf(grp[h].get(0))) | ((uint32_t)(uint16_t)MC::of(VX::raw_sdf(grp[h].get(1))) << 16);
           const uint32_t b = (uint32_t)(uint16_t)MC::of(VX::raw_sdf(grp[h].get(2))) | ((uint32_t)(uint16_t)MC::of(VX::raw_sdf(grp[h].get(3))) << 16);

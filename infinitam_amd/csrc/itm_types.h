@@ -258,9 +258,12 @@ __device__ inline void directory_insert(int32_t* __restrict__ dirPtr, int32_t* _
 // A second copy of the sdf of every voxel of every allocated block, addressed by POSITION instead of through the block pointer, over a
 // cube of 256^3 blocks placed in front of the camera (AccelOrigin: centred kMirrorShift blocks along the viewing direction of the frame
 // that placed it, moved when the view leaves it).  Rounds 2-3 stored the cube densely -- 256^3 cells x 1 KB = 17 GB per scene whatever
-// it held.  Round 4: the cube is PAGED.  A page is 4 x 4 x 4 blocks (64 KB of int16 sdf, 128 KB of float bits); a table of 64^3
-// entries (1 MB) says for every page of the cube
-//     >= 0   the page's index in the pool: value of voxel v of block b = pool[(page * 64 + block-in-page) * 512 + v]
+// it held.  Round 4: the cube is PAGED.  A page is 32 x 32 x 32 VOXELS (4 x 4 x 4 blocks; 64 KB of int16 sdf, 128 KB of float bits) in
+// plain x-fastest voxel order -- no block structure inside a page: the voxel at cube-relative (vx, vy, vz) lies at
+// (vz & 31) << 10 | (vy & 31) << 5 | (vx & 31), its +1 neighbours at fixed distances 1 / 32 / 1024 wherever it sits in its block
+// (five instructions for an address, where the dense cube's block-major cells took ten and a trilinear read thirty-five).  A table of
+// 64^3 entries (1 MB) says for every page of the cube
+//     >= 0   the page's index in the pool: value = pool[page << 15 | place in the page]
 //     -1     no block was ever allocated in the page: every position in it reads "no block" WITHOUT a second load
 //     -3     the pool had run dry when a block of the page was allocated: the page says nothing, readers use the block directory
 //     (-2    a thread is taking a page from the pool right now; only ever seen inside the kernel that allocates)
@@ -284,6 +287,9 @@ constexpr int kMirrorShift = kMirrorSide / 4;      // the cube is centred kMirro
 constexpr size_t kMirrorCells = (size_t)kMirrorSide * kMirrorSide * kMirrorSide;
 constexpr int kPageBits = 2;                        // a page is 4 x 4 x 4 blocks
 constexpr int kPageBlocks = 1 << (3 * kPageBits);   // 64
+constexpr int kPageVoxBits = kPageBits + 3;         // ... = 32 x 32 x 32 voxels
+constexpr uint32_t kPageVoxMask = (1u << kPageVoxBits) - 1u;
+constexpr uint32_t kMirrorVoxels = (uint32_t)kMirrorSide * 8u;      // voxels per side of the cube
 constexpr size_t kMirrorTableCells = kMirrorCells >> (3 * kPageBits);      // 64^3
 constexpr int kPageNone = -1, kPageClaiming = -2, kPageUnmappable = -3;
 template <bool SHORT> struct MirrorCodec;
@@ -306,11 +312,19 @@ __host__ __device__ inline uint32_t mirror_cell(uint32_t ux, uint32_t uy, uint32
 __host__ __device__ inline uint32_t mirror_table_index(uint32_t ux, uint32_t uy, uint32_t uz) {
   return ((uz >> kPageBits) << (2 * (kMirrorBits - kPageBits))) | ((uy >> kPageBits) << (kMirrorBits - kPageBits)) | (ux >> kPageBits);
 }
-__host__ __device__ inline uint32_t mirror_block_in_page(uint32_t ux, uint32_t uy, uint32_t uz) {
-  return ((uz & 3u) << (2 * kPageBits)) | ((uy & 3u) << kPageBits) | (ux & 3u);
+// the same from cube-relative VOXEL coordinates (each below kMirrorVoxels when the voxel is covered), and the voxel's place in its page
+__host__ __device__ inline bool mirror_covers_voxel(uint32_t vx, uint32_t vy, uint32_t vz) { return ((vx | vy | vz) >> (kMirrorBits + 3)) == 0u; }
+__host__ __device__ inline uint32_t mirror_table_index_voxel(uint32_t vx, uint32_t vy, uint32_t vz) {
+  return ((vz >> kPageVoxBits) << (2 * (kMirrorBits - kPageBits))) | ((vy >> kPageVoxBits) << (kMirrorBits - kPageBits)) | (vx >> kPageVoxBits);
 }
-// pool index of voxel `lin` of block-in-page `blk` of page `page`
-__host__ __device__ inline size_t mirror_element(int page, uint32_t blk, uint32_t lin) { return ((size_t)page * kPageBlocks + blk) * 512u + lin; }
+__host__ __device__ inline uint32_t mirror_in_page(uint32_t vx, uint32_t vy, uint32_t vz) {
+  return ((vz & kPageVoxMask) << (2 * kPageVoxBits)) | ((vy & kPageVoxMask) << kPageVoxBits) | (vx & kPageVoxMask);
+}
+// pool index of the voxel at place `at` of page `page`
+__host__ __device__ inline size_t mirror_element(int page, uint32_t at) { return ((size_t)page << (3 * kPageVoxBits)) | at; }
+// place in its page of voxel (x, y, z) of a block, relative to the block's voxel (0, 0, 0): rows of 8 along x, 32 apart along y, 1 024 along z
+__host__ __device__ inline uint32_t mirror_block_voxel(uint32_t x, uint32_t y, uint32_t z) { return (z << (2 * kPageVoxBits)) | (y << kPageVoxBits) | x; }
+__host__ __device__ inline uint32_t mirror_block_lin(uint32_t lin) { return mirror_block_voxel(lin & 7u, (lin >> 3) & 7u, lin >> 6); }
 
 // The page of a table entry, taking one from the pool if the page has none yet (allocation paths only).  Safe between the lanes of
 // one wave as well: whoever wins the exchange publishes the page before it leaves the loop body, nobody waits inside the loop for a
@@ -329,7 +343,8 @@ __device__ inline int mirror_claim_page(const AccelOrigin& org, uint32_t tIdx) {
   }
   return v;
 }
-// Pool index of voxel 0 of block (bx, by, bz); false when the block has no place in the mirror (outside the cube, page not mapped).
+// Pool index of voxel (0, 0, 0) of block (bx, by, bz) -- voxel (x, y, z) of the block lies mirror_block_voxel(x, y, z) further --; false
+// when the block has no place in the mirror (outside the cube, page not mapped).
 // CLAIM: map the page if it is not (allocation paths); otherwise a plain read of the table.
 template <bool CLAIM>
 __device__ inline bool mirror_block_base(const AccelOrigin& org, int bx, int by, int bz, size_t& base) {
@@ -338,7 +353,7 @@ __device__ inline bool mirror_block_base(const AccelOrigin& org, int bx, int by,
   const uint32_t tIdx = mirror_table_index(ux, uy, uz);
   const int page = CLAIM ? mirror_claim_page(org, tIdx) : org.mTable[tIdx];
   if (page < 0) return false;
-  base = mirror_element(page, mirror_block_in_page(ux, uy, uz), 0u);
+  base = mirror_element(page, mirror_in_page(ux << 3, uy << 3, uz << 3));
   return true;
 }
 
@@ -346,14 +361,13 @@ __device__ inline bool mirror_block_base(const AccelOrigin& org, int bx, int by,
 __device__ inline void mirror_init_block(void* __restrict__ mirror, bool floatSdf, const AccelOrigin& org, int bx, int by, int bz) {
   size_t base;
   if (!mirror || !mirror_block_base<true>(org, bx, by, bz, base)) return;
+  // 64 rows (y, z) of 8 voxels: 16 bytes of shorts / 2 x 16 bytes of float bits each
   if (floatSdf) {
-    uint4* q = (uint4*)((uint32_t*)mirror + base);         // 2 KB, 16-byte aligned
     const uint4 init = make_uint4(0x3f800000u, 0x3f800000u, 0x3f800000u, 0x3f800000u);
-    for (int i = 0; i < 128; ++i) q[i] = init;
+    for (int r = 0; r < 64; ++r) { uint4* q = (uint4*)((uint32_t*)mirror + base + mirror_block_voxel(0u, (uint32_t)(r & 7), (uint32_t)(r >> 3))); q[0] = init; q[1] = init; }
   } else {
-    uint4* q = (uint4*)((int16_t*)mirror + base);          // 1 KB
     const uint4 init = make_uint4(0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu);
-    for (int i = 0; i < 64; ++i) q[i] = init;
+    for (int r = 0; r < 64; ++r) *(uint4*)((int16_t*)mirror + base + mirror_block_voxel(0u, (uint32_t)(r & 7), (uint32_t)(r >> 3))) = init;
   }
 }
 

@@ -62,10 +62,9 @@ struct BlockCache {
   __device__ BlockCache() : bx(0x7fffffff), by(0x7fffffff), bz(0x7fffffff), base(-1), pageIdx(0xffffffffu), page(kPageNone) {}
 };
 
-// The mirror page of cube-relative block (ux, uy, uz), through the per-lane cache.  The table is read by a wave only when one of its
-// lanes has left its page (uniform branch; a lane that keeps its page reads entry 0 and drops it).
-__device__ inline int mirror_page_of(const VolumeView& vol, bool inCube, uint32_t ux, uint32_t uy, uint32_t uz, BlockCache& cache) {
-  const uint32_t tIdx = mirror_table_index(ux, uy, uz);
+// The mirror page with table index tIdx, through the per-lane cache.  The table is read by a wave only when one of its lanes has left
+// its page (uniform branch; a lane that keeps its page reads entry 0 and drops it).
+__device__ inline int mirror_page_of(const VolumeView& vol, bool inCube, uint32_t tIdx, BlockCache& cache) {
   const bool need = inCube && tIdx != cache.pageIdx;
   if (__any(need)) {
     const int v = vol.org.mTable[need ? tIdx : 0u];
@@ -131,21 +130,21 @@ __device__ inline float read_raw_sdf(const VolumeView& vol, int px, int py, int 
     if (vol.sdfMirror) {
       // the load is unconditional (cell 0 for a lane outside the cube) and the general path below is skipped by a UNIFORM branch when
       // every lane was served: no exec-mask bracket around the common case (ray cast 42.1 -> 41.7 us)
-      const uint32_t ux = (uint32_t)((px >> 3) - vol.org.mx), uy = (uint32_t)((py >> 3) - vol.org.my), uz = (uint32_t)((pz >> 3) - vol.org.mz);
-      const bool inCube = mirror_covers(ux, uy, uz);
-      const int page = mirror_page_of(vol, inCube, ux, uy, uz, cache);
+      const uint32_t vx = (uint32_t)(px - (vol.org.mx << 3)), vy = (uint32_t)(py - (vol.org.my << 3)), vz = (uint32_t)(pz - (vol.org.mz << 3));      // cube-relative voxel
+      const bool inCube = mirror_covers_voxel(vx, vy, vz);
+      const int page = mirror_page_of(vol, inCube, mirror_table_index_voxel(vx, vy, vz), cache);
       // the page answers: with a value, or -- no block was ever allocated in it -- with "no block" and no further load
       const bool covered = inCube && page != kPageUnmappable;
       const bool mapped = covered && page >= 0 && !skipLane;
       typename MC::T v = VX::kShort ? (typename MC::T)-32768 : (typename MC::T)0xffffffffu;
       if (__any(mapped)) {
-        const size_t mi = mapped ? mirror_element(page, mirror_block_in_page(ux, uy, uz), (uint32_t)((px & 7) + ((py & 7) << 3) + ((pz & 7) << 6))) : (size_t)0;
+        const size_t mi = mapped ? mirror_element(page, mirror_in_page(vx, vy, vz)) : (size_t)0;
         const typename MC::T got = ((const typename MC::T*)vol.sdfMirror)[mi];
         if (mapped) v = got;
       }
       if constexpr (NEAR) {
         // the cell's near bits travel with the value (an independent load): no second round trip after a miss
-        const uint32_t nb = vol.nearBits[covered ? mirror_cell(ux, uy, uz) : 0u];
+        const uint32_t nb = vol.nearBits[covered ? mirror_cell(vx >> 3, vy >> 3, vz >> 3) : 0u];
         if (covered) *nearByte = nb;
       }
       const bool present = mapped && !MC::absent(v);
@@ -217,31 +216,26 @@ struct Corners {
         // outside the mirrored cube takes the general path as a whole: both give the same values)
         using MC = MirrorCodec<VX::kShort>;
         if (vol.sdfMirror) {
-          // The eight addresses from ONE: inside a page the blocks lie x-fastest at a kilobyte each, so the +1 neighbour along an axis is one
-          // voxel further inside the block or -- from the block's last voxel -- the first voxel of the next block of the page, a fixed
-          // distance either way (~35 vector instructions for the eight addresses instead of ~140).  That holds while the neighbourhood
-          // stays inside ONE page (31 of 32 positions per axis); a wave with a lane whose neighbourhood straddles pages looks up the page of
-          // each of the eight corner blocks instead (eight independent table reads, then the eight values).
-          const uint32_t mx = (uint32_t)((ix >> 3) - vol.org.mx), my = (uint32_t)((iy >> 3) - vol.org.my), mz = (uint32_t)((iz >> 3) - vol.org.mz);
-          const bool inCube = mirror_covers(mx, my, mz) && mirror_covers(mx + 1u, my + 1u, mz + 1u);
-          const int kx = ix & 7, ky = iy & 7, kz = iz & 7;
-          const bool onePage = !((kx == 7 && (mx & 3u) == 3u) || (ky == 7 && (my & 3u) == 3u) || (kz == 7 && (mz & 3u) == 3u));
-          const uint32_t lin0 = (uint32_t)(kx + (ky << 3) + (kz << 6));
+          // The eight addresses from ONE: a page is 32^3 voxels in plain x-fastest order, so the +1 neighbours lie 1 / 32 / 1 024 elements
+          // further wherever the voxel sits in its block -- as long as the neighbourhood stays inside ONE page (31 of 32 positions per
+          // axis).  A wave with a lane whose neighbourhood straddles pages looks up the page of each of the eight voxels instead (eight
+          // independent table reads, then the eight values).
+          const uint32_t vx = (uint32_t)(ix - (vol.org.mx << 3)), vy = (uint32_t)(iy - (vol.org.my << 3)), vz = (uint32_t)(iz - (vol.org.mz << 3));
+          const bool inCube = mirror_covers_voxel(vx, vy, vz) && mirror_covers_voxel(vx + 1u, vy + 1u, vz + 1u);
+          const bool onePage = ((vx & kPageVoxMask) != kPageVoxMask) && ((vy & kPageVoxMask) != kPageVoxMask) && ((vz & kPageVoxMask) != kPageVoxMask);
+          const typename MC::T none = VX::kShort ? (typename MC::T)-32768 : (typename MC::T)0xffffffffu;
           if (__all(inCube && onePage)) {
-            const int page = mirror_page_of(vol, inCube, mx, my, mz, cache);
+            const int page = mirror_page_of(vol, inCube, mirror_table_index_voxel(vx, vy, vz), cache);
             if (__all(page != kPageUnmappable)) {
               const bool mapped = page >= 0;
               typename MC::T m[8];
 #pragma unroll
-              for (int c = 0; c < 8; ++c) m[c] = VX::kShort ? (typename MC::T)-32768 : (typename MC::T)0xffffffffu;
+              for (int c = 0; c < 8; ++c) m[c] = none;
               if (__any(mapped)) {
-                const size_t base = mapped ? mirror_element(page, mirror_block_in_page(mx, my, mz), lin0) : (size_t)0;
-                const uint32_t ox = (kx == 7) ? 512u - 7u : 1u;
-                const uint32_t oy = (ky == 7) ? (512u << kPageBits) - 56u : 8u;
-                const uint32_t oz = (kz == 7) ? (512u << (2 * kPageBits)) - 448u : 64u;
+                const size_t base = mapped ? mirror_element(page, mirror_in_page(vx, vy, vz)) : (size_t)0;
                 typename MC::T got[8];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) got[c] = ((const typename MC::T*)vol.sdfMirror)[mapped ? base + (size_t)(((c & 1) ? ox : 0u) + ((c & 2) ? oy : 0u) + ((c & 4) ? oz : 0u)) : (size_t)0];
+                for (int c = 0; c < 8; ++c) got[c] = ((const typename MC::T*)vol.sdfMirror)[mapped ? base + (size_t)mirror_block_voxel((uint32_t)(c & 1), (uint32_t)((c >> 1) & 1), (uint32_t)(c >> 2)) : (size_t)0];
 #pragma unroll
                 for (int c = 0; c < 8; ++c) if (mapped) m[c] = got[c];
               }
@@ -250,29 +244,21 @@ struct Corners {
               return;
             }
           } else if (__all(inCube)) {
-            // a neighbourhood that straddles pages: the page of every corner's block
-            const int cross = (kx == 7 ? 1 : 0) | (ky == 7 ? 2 : 0) | (kz == 7 ? 4 : 0);
+            // a neighbourhood that straddles pages: the page of every corner's voxel
             int pg[8];
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-              const int t = s & cross;                                     // the block of corner pattern s
-              pg[s] = vol.org.mTable[mirror_table_index(mx + (uint32_t)(t & 1), my + (uint32_t)((t >> 1) & 1), mz + (uint32_t)(t >> 2))];
-            }
+            for (int c = 0; c < 8; ++c) pg[c] = vol.org.mTable[mirror_table_index_voxel(vx + (uint32_t)(c & 1), vy + (uint32_t)((c >> 1) & 1), vz + (uint32_t)(c >> 2))];
             bool usable = true;
 #pragma unroll
-            for (int s = 0; s < 8; ++s) usable &= pg[s] != kPageUnmappable;
+            for (int c = 0; c < 8; ++c) usable &= pg[c] != kPageUnmappable;
             if (__all(usable)) {
               typename MC::T got[8];
 #pragma unroll
-              for (int c = 0; c < 8; ++c) {
-                const int t = c & cross;
-                const uint32_t bxx = mx + (uint32_t)(t & 1), byy = my + (uint32_t)((t >> 1) & 1), bzz = mz + (uint32_t)(t >> 2);
-                const uint32_t lin = (uint32_t)(((kx + (c & 1)) & 7) + (((ky + ((c >> 1) & 1)) & 7) << 3) + (((kz + (c >> 2)) & 7) << 6));
-                got[c] = ((const typename MC::T*)vol.sdfMirror)[pg[c] >= 0 ? mirror_element(pg[c], mirror_block_in_page(bxx, byy, bzz), lin) : (size_t)0];
-              }
+              for (int c = 0; c < 8; ++c)
+                got[c] = ((const typename MC::T*)vol.sdfMirror)[pg[c] >= 0 ? mirror_element(pg[c], mirror_in_page(vx + (uint32_t)(c & 1), vy + (uint32_t)((c >> 1) & 1), vz + (uint32_t)(c >> 2))) : (size_t)0];
 #pragma unroll
               for (int c = 0; c < 8; ++c) {
-                const typename MC::T mv = pg[c] >= 0 ? got[c] : (VX::kShort ? (typename MC::T)-32768 : (typename MC::T)0xffffffffu);
+                const typename MC::T mv = pg[c] >= 0 ? got[c] : none;
                 present[c] = !MC::absent(mv); v[c] = present[c] ? MC::raw(mv) : dflt;
               }
               return;
@@ -627,12 +613,11 @@ __device__ inline float4 march_ray(int x, int y, const VolumeView& vol, const Ra
       float qx = px, qy = py, qz = pz;
 #pragma unroll
       for (int j = 0; j < K; ++j) {
-        const int jx = (int)round_ref(qx), jy = (int)round_ref(qy), jz = (int)round_ref(qz);
-        const uint32_t ux = (uint32_t)((jx >> 3) - vol.org.mx), uy = (uint32_t)((jy >> 3) - vol.org.my), uz = (uint32_t)((jz >> 3) - vol.org.mz);
-        const bool in = runner && mirror_covers(ux, uy, uz);
-        const int pg = vol.org.mTable[in ? mirror_table_index(ux, uy, uz) : 0u];
+        const uint32_t vx = (uint32_t)((int)round_ref(qx) - (vol.org.mx << 3)), vy = (uint32_t)((int)round_ref(qy) - (vol.org.my << 3)), vz = (uint32_t)((int)round_ref(qz) - (vol.org.mz << 3));
+        const bool in = runner && mirror_covers_voxel(vx, vy, vz);
+        const int pg = vol.org.mTable[in ? mirror_table_index_voxel(vx, vy, vz) : 0u];
         const bool use = in && pg >= 0;
-        val[j] = ((const typename MC::T*)vol.sdfMirror)[use ? mirror_element(pg, mirror_block_in_page(ux, uy, uz), (uint32_t)((jx & 7) + ((jy & 7) << 3) + ((jz & 7) << 6))) : (size_t)0];
+        val[j] = ((const typename MC::T*)vol.sdfMirror)[use ? mirror_element(pg, mirror_in_page(vx, vy, vz)) : (size_t)0];
         ok[j] = use;
         qx += sx; qy += sy; qz += sz;
       }

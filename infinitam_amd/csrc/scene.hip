@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(256) mirror_fill_kernel(const uint4* __restric
       if constexpr (FILL) v = MC::of(VX::load_raw_sdf(vba, (size_t)e.ptr * kBlockVoxels + t));
       else if constexpr (VX::kShort) v = (typename MC::T)-32768;
       else v = (typename MC::T)0xffffffffu;
-      ((typename MC::T*)mirror)[base + t] = v;
+      ((typename MC::T*)mirror)[base + mirror_block_lin((uint32_t)t)] = v;
     }
   }
 }

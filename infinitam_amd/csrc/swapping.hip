@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(512) swap_combine_kernel(const int32_t* __rest
     VX::store(vba, vi, r);
     using MC = MirrorCodec<VX::kShort>;
     size_t mbase;
-    if (mirror && mirror_block_base<false>(org, he.px, he.py, he.pz, mbase)) ((typename MC::T*)mirror)[mbase + t] = MC::of(VX::raw_sdf(r));
+    if (mirror && mirror_block_base<false>(org, he.px, he.py, he.pz, mbase)) ((typename MC::T*)mirror)[mbase + mirror_block_lin((uint32_t)t)] = MC::of(VX::raw_sdf(r));
   }
   if (t == 0) states[id] = 2;
 }
@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(512) swap_out_kernel(const int32_t* __restrict
     using MC = MirrorCodec<VX::kShort>;
     size_t mbase;
     if (mirror && mirror_block_base<false>(org, he.px, he.py, he.pz, mbase))
-      ((typename MC::T*)mirror)[mbase + t] = VX::kShort ? (typename MC::T)-32768 : (typename MC::T)0xffffffffu;
+      ((typename MC::T*)mirror)[mbase + mirror_block_lin((uint32_t)t)] = VX::kShort ? (typename MC::T)-32768 : (typename MC::T)0xffffffffu;
   }
   if (t == 0) {
     states[id] = 0;

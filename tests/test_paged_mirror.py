@@ -34,9 +34,9 @@ def test_mirror_memory_follows_the_scene_not_the_cube(hip, oracle):
     ses.close(); ref.close()
 
 
-@pytest.mark.parametrize("pages", [1, 24, 300])
+@pytest.mark.parametrize("pages", [1, 24, 150])
 def test_a_pool_that_runs_dry_costs_speed_not_results(hip, oracle, monkeypatch, pages):
-    """ITM_MIRROR_PAGES (read when the scene is created): with 1, 24 or 300 pages most, many or some of the scene's pages cannot be
+    """ITM_MIRROR_PAGES (read when the scene is created): with 1, 24 or 150 pages most, many or some of the scene's pages cannot be
     mapped; their table entries say "unmappable", rays through them read the block directory.  Five frames of a turning camera, the
     free-view entry points from another pose, then a cube move (everything unmapped and mapped again at the new origin)."""
     monkeypatch.setenv("ITM_MIRROR_PAGES", str(pages))
@@ -48,7 +48,7 @@ def test_a_pool_that_runs_dry_costs_speed_not_results(hip, oracle, monkeypatch, 
     for k in range(2):
         ses.frame(k, fused=True)
     info = ses.scene.accel_info()
-    assert info["mirror_pages"] == pages and info["mirror_pages_mapped"] == pages, info      # (the scene wants ~500)
+    assert info["mirror_pages"] == pages and info["mirror_pages_mapped"] == pages, info      # (the scene wants ~270)
     ses.close()
 
 
