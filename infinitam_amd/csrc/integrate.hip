@@ -27,6 +27,9 @@ namespace itm {
 #ifndef ITM_PROJECTION_PRIORITY
 #define ITM_PROJECTION_PRIORITY 1
 #endif
+#ifndef ITM_MIRROR_FLOAT_TYPES
+#define ITM_MIRROR_FLOAT_TYPES 0     // (scene.hip decides whether a float scene gets a mirror; the same switch must be given to both files)
+#endif
 int g_debug_integrate_wgs = 0;
 int g_debug_integrate_block_per_wave = 0;   // debug key 22: the hash integration with 16 bytes per lane, a whole block per wave (integrate_block_x4)
 int g_debug_no_fused_projection = 0;
@@ -250,8 +253,12 @@ __device__ inline void integrate_item(const HashEntry& he, int z0, int lane, typ
   using MC = MirrorCodec<VX::kShort>;
   size_t mbase = 0;
   typename MC::T* mirror = nullptr;
-  // (the block's page was mapped when the block was allocated; the table entry is requested here, beside the voxels, and used at the end)
-  if (sdfMirror && mirror_block_base<false>(p.org, he.px, he.py, he.pz, mbase)) mirror = (typename MC::T*)sdfMirror;
+  // (the block's page was mapped when the block was allocated; the table entry is requested here, beside the voxels, and used at the end.
+  // The float voxel types carry no mirror unless built with ITM_MIRROR_FLOAT_TYPES: their kernels do not carry its code either -- two
+  // registers more and ITMVoxel_f_rgb drops from six waves per SIMD to five, 180 -> 203 us on BASELINE configs[4])
+  if constexpr (VX::kShort || ITM_MIRROR_FLOAT_TYPES) {
+    if (sdfMirror && mirror_block_base<false>(p.org, he.px, he.py, he.pz, mbase)) mirror = (typename MC::T*)sdfMirror;
+  }
   // stage 1: project every slice's voxel; stage 2: all depth pixels together; stage 3: update (+ colour), store what changed
   int pix[kSlices];
   float pcz[kSlices], mz[kSlices];
@@ -366,8 +373,12 @@ __device__ inline void integrate_block_x4(const HashEntry& he, int lane, Group<V
   using MC = MirrorCodec<VX::kShort>;
   size_t mbase = 0;
   typename MC::T* mirror = nullptr;
-  // (the block's page was mapped when the block was allocated; the table entry is requested here, beside the voxels, and used at the end)
-  if (sdfMirror && mirror_block_base<false>(p.org, he.px, he.py, he.pz, mbase)) mirror = (typename MC::T*)sdfMirror;
+  // (the block's page was mapped when the block was allocated; the table entry is requested here, beside the voxels, and used at the end.
+  // The float voxel types carry no mirror unless built with ITM_MIRROR_FLOAT_TYPES: their kernels do not carry its code either -- two
+  // registers more and ITMVoxel_f_rgb drops from six waves per SIMD to five, 180 -> 203 us on BASELINE configs[4])
+  if constexpr (VX::kShort || ITM_MIRROR_FLOAT_TYPES) {
+    if (sdfMirror && mirror_block_base<false>(p.org, he.px, he.py, he.pz, mbase)) mirror = (typename MC::T*)sdfMirror;
+  }
   // stage 1: project the eight voxels; stage 2: their depth pixels together; stage 3: update (+ colour), store the groups that changed
   int pix[8];
   float pcz[8], mx[4], mz[2];

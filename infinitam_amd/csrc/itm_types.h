@@ -258,20 +258,20 @@ __device__ inline void directory_insert(int32_t* __restrict__ dirPtr, int32_t* _
 // A second copy of the sdf of every voxel of every allocated block, addressed by POSITION instead of through the block pointer, over a
 // cube of 256^3 blocks placed in front of the camera (AccelOrigin: centred kMirrorShift blocks along the viewing direction of the frame
 // that placed it, moved when the view leaves it).  Rounds 2-3 stored the cube densely -- 256^3 cells x 1 KB = 17 GB per scene whatever
-// it held.  Round 4: the cube is PAGED.  A page is 32 x 32 x 32 VOXELS (4 x 4 x 4 blocks; 64 KB of int16 sdf, 128 KB of float bits) in
+// it held.  Round 4: the cube is PAGED.  A page is 128 x 128 x 128 VOXELS (16 x 16 x 16 blocks; 4 MB of int16 sdf, 8 MB of float bits) in
 // plain x-fastest voxel order -- no block structure inside a page: the voxel at cube-relative (vx, vy, vz) lies at
-// (vz & 31) << 10 | (vy & 31) << 5 | (vx & 31), its +1 neighbours at fixed distances 1 / 32 / 1024 wherever it sits in its block
+// (vz & 127) << 14 | (vy & 127) << 7 | (vx & 127), its +1 neighbours at fixed distances 1 / 128 / 16 384 wherever it sits in its block
 // (five instructions for an address, where the dense cube's block-major cells took ten and a trilinear read thirty-five).  A table of
-// 64^3 entries (1 MB) says for every page of the cube
-//     >= 0   the page's index in the pool: value = pool[page << 15 | place in the page]
+// 16^3 entries (16 KB: every ray-cast workgroup keeps a copy in LDS) says for every page of the cube
+//     >= 0   the page's index in the pool: value = pool[page << 21 | place in the page]
 //     -1     no block was ever allocated in the page: every position in it reads "no block" WITHOUT a second load
 //     -3     the pool had run dry when a block of the page was allocated: the page says nothing, readers use the block directory
 //     (-2    a thread is taking a page from the pool right now; only ever seen inside the kernel that allocates)
 // and pages are handed out by whoever allocates the first block in them (mirror_claim_page).  Memory is O(touched pages): the bench
-// scene (sphere + wall, 60 k blocks allocated over the trajectory) maps ~1 100 pages = 70 MB of a 512 MB pool.  What a ray step costs:
-// the table entry (1 MB, cache resident; kept per lane while the ray stays inside the page -- a page is 32 voxels wide, a step at most
-// 8) and then ONE load whose address follows from the position, as before; in empty space the table alone answers, where the dense
-// cube answered with a cold kilobyte of HBM per cell.  "Absent" inside a mapped page: -32768 cannot be a stored short sdf
+// scene (sphere + wall, 60 k blocks allocated over the trajectory) maps a few dozen pages of a 768 MB pool.  What a ray step costs: the
+// table entry (kept per lane while the ray stays inside the page -- a page is 128 voxels wide, a step at most 8 -- and otherwise read
+// from LDS) and then ONE load whose address follows from the position, as before; in empty space the table alone answers, where the
+// dense cube answered with a cold kilobyte of HBM per cell.  "Absent" inside a mapped page: -32768 cannot be a stored short sdf
 // ((short)(f * 32767) with f in [-1, 1]); 0xFFFFFFFF is a NaN no arithmetic produces.  Written wherever voxels are written: at
 // allocation (the initial value), by the integration, by the swapping engine, and again from the table after the cube has moved or
 // the table was replaced.  Invariant: the only cells of mapped pages that are not "absent" are those of table entries with ptr >= 0 --
@@ -285,12 +285,19 @@ constexpr int kMirrorSide = 1 << kMirrorBits;
 constexpr int kMirrorHalf = kMirrorSide / 2;
 constexpr int kMirrorShift = kMirrorSide / 4;      // the cube is centred kMirrorShift blocks in front of the camera that placed it
 constexpr size_t kMirrorCells = (size_t)kMirrorSide * kMirrorSide * kMirrorSide;
-constexpr int kPageBits = 2;                        // a page is 4 x 4 x 4 blocks
-constexpr int kPageBlocks = 1 << (3 * kPageBits);   // 64
-constexpr int kPageVoxBits = kPageBits + 3;         // ... = 32 x 32 x 32 voxels
+#ifndef ITM_MIRROR_PAGE_BITS
+// log2 of a page's side in blocks.  Measured (ray cast in frame, BASELINE configs[1], dense cube 38.3 us): 2 (32^3 voxels, 64 KB pages,
+// a 1 MB table read from memory) 43.4-44.9 us in either layout -- the table entry is a second DEPENDENT load in nearly every iteration
+// of a wave, because with pages 32 voxels wide some lane of the 64 has always just crossed into another page; 4 (128^3 voxels, 4 MB
+// pages, a 16 KB table that every ray-cast workgroup keeps in LDS): see profiles/r4_raycast_notes.md.
+#define ITM_MIRROR_PAGE_BITS 4
+#endif
+constexpr int kPageBits = ITM_MIRROR_PAGE_BITS;     // a page is 16 x 16 x 16 blocks
+constexpr int kPageBlocks = 1 << (3 * kPageBits);   // 4 096
+constexpr int kPageVoxBits = kPageBits + 3;         // ... = 128 x 128 x 128 voxels
 constexpr uint32_t kPageVoxMask = (1u << kPageVoxBits) - 1u;
 constexpr uint32_t kMirrorVoxels = (uint32_t)kMirrorSide * 8u;      // voxels per side of the cube
-constexpr size_t kMirrorTableCells = kMirrorCells >> (3 * kPageBits);      // 64^3
+constexpr size_t kMirrorTableCells = kMirrorCells >> (3 * kPageBits);      // 16^3
 constexpr int kPageNone = -1, kPageClaiming = -2, kPageUnmappable = -3;
 template <bool SHORT> struct MirrorCodec;
 template <> struct MirrorCodec<true> {

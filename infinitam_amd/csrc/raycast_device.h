@@ -46,6 +46,7 @@ struct VolumeView {
   const int32_t* dirPtr;    // block directory (itm_types.h); nullptr = walk the table (hash index only)
   const void* sdfMirror;    // sdf by position (itm_types.h); nullptr = none (hash index only)
   const uint8_t* nearBits;  // per cell of the mirror's cube: distances at which a block is allocated (itm_types.h); nullptr = none
+  const int32_t* pageTable; // the mirror's page table as THIS kernel reads it: the scene's (memory) or the workgroup's copy in LDS (raycast_kernel)
   AccelOrigin org;          // where the directory / mirror cubes lie
   int sx, sy, sz;      // dense size
   int ox, oy, oz;      // dense offset
@@ -67,7 +68,7 @@ struct BlockCache {
 __device__ inline int mirror_page_of(const VolumeView& vol, bool inCube, uint32_t tIdx, BlockCache& cache) {
   const bool need = inCube && tIdx != cache.pageIdx;
   if (__any(need)) {
-    const int v = vol.org.mTable[need ? tIdx : 0u];
+    const int v = vol.pageTable[need ? tIdx : 0u];
     if (need) { cache.pageIdx = tIdx; cache.page = v; }
   }
   return cache.page;
@@ -247,7 +248,7 @@ struct Corners {
             // a neighbourhood that straddles pages: the page of every corner's voxel
             int pg[8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) pg[c] = vol.org.mTable[mirror_table_index_voxel(vx + (uint32_t)(c & 1), vy + (uint32_t)((c >> 1) & 1), vz + (uint32_t)(c >> 2))];
+            for (int c = 0; c < 8; ++c) pg[c] = vol.pageTable[mirror_table_index_voxel(vx + (uint32_t)(c & 1), vy + (uint32_t)((c >> 1) & 1), vz + (uint32_t)(c >> 2))];
             bool usable = true;
 #pragma unroll
             for (int c = 0; c < 8; ++c) usable &= pg[c] != kPageUnmappable;
@@ -615,7 +616,7 @@ __device__ inline float4 march_ray(int x, int y, const VolumeView& vol, const Ra
       for (int j = 0; j < K; ++j) {
         const uint32_t vx = (uint32_t)((int)round_ref(qx) - (vol.org.mx << 3)), vy = (uint32_t)((int)round_ref(qy) - (vol.org.my << 3)), vz = (uint32_t)((int)round_ref(qz) - (vol.org.mz << 3));
         const bool in = runner && mirror_covers_voxel(vx, vy, vz);
-        const int pg = vol.org.mTable[in ? mirror_table_index_voxel(vx, vy, vz) : 0u];
+        const int pg = vol.pageTable[in ? mirror_table_index_voxel(vx, vy, vz) : 0u];
         const bool use = in && pg >= 0;
         val[j] = ((const typename MC::T*)vol.sdfMirror)[use ? mirror_element(pg, mirror_in_page(vx, vy, vz)) : (size_t)0];
         ok[j] = use;

@@ -549,15 +549,16 @@ int itm_scene_create(const itm_scene_config* cfg_in, const itm_scene_params* prm
     if (hipMalloc((void**)&s->dirPtr, kDirCells * 4) != hipSuccess) { s->dirPtr = nullptr; (void)hipGetLastError(); }
     else if (hipMalloc((void**)&s->dirSlot, kDirCells * 4) != hipSuccess) { (void)hipFree(s->dirPtr); s->dirPtr = nullptr; s->dirSlot = nullptr; (void)hipGetLastError(); }
   }
-  // The sdf mirror is an accelerator: taken when the device has room for its pool (512 MB: 8 192 pages of 64 KB for the short voxel
+  // The sdf mirror is an accelerator: taken when the device has room for its pool (768 MB: 192 pages of 4 MB for the short voxel
   // types; the table says which pages of the cube are mapped, itm_types.h), silently left out otherwise -- and only for the short voxel
   // types.  For the float types it was measured on BASELINE configs[4]: the ray cast gains less than the integration pays for the extra
   // 4-byte stores (ITM_MIRROR_FLOAT_TYPES=1 builds it in).  ITM_MIRROR_PAGES in the environment sizes the pool.
   if (cfg.indexType == ITM_INDEX_HASH && s->dirPtr && !g_debug_no_sdf_mirror && (ITM_MIRROR_FLOAT_TYPES || !mirror_is_float(s))) {
-    int pages = mirror_is_float(s) ? 4096 : 8192;
+    const size_t pageBytes = (size_t)kPageBlocks * 512 * (mirror_is_float(s) ? 4 : 2);
+    int pages = (int)(((size_t)768 << 20) / pageBytes);
     if (const char* e = getenv("ITM_MIRROR_PAGES")) { const int v = atoi(e); if (v > 0) pages = v; }
     size_t freeB = 0, totalB = 0;
-    const size_t bytes = (size_t)pages * kPageBlocks * 512 * (mirror_is_float(s) ? 4 : 2);
+    const size_t bytes = (size_t)pages * pageBytes;
     if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB > 3 * bytes) {
       s->mirrorPages = pages;
       s->org.mMaxPages = pages;

@@ -18,6 +18,7 @@ static inline VolumeView make_volume(const itm_scene* s) {
   v.dirPtr = g_debug_no_directory ? nullptr : s->dirPtr;
   v.sdfMirror = (g_debug_no_directory || g_debug_no_sdf_mirror) ? nullptr : s->sdfMirror;
   v.nearBits = (v.sdfMirror && !g_debug_no_near_bits) ? (const uint8_t*)s->nearBits : nullptr;
+  v.pageTable = s->org.mTable;
   v.org = s->org;
   v.mask = (uint32_t)s->cfg.bucketNum - 1u; v.bucketNum = s->cfg.bucketNum;
   v.sx = s->cfg.denseSize[0]; v.sy = s->cfg.denseSize[1]; v.sz = s->cfg.denseSize[2];

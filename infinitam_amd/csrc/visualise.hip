@@ -342,12 +342,23 @@ __device__ unsigned long long g_rayStamps[8192 * 4];   // per wave: start, after
 struct AheadRequest { RequestArgs ra; AllocParams ap; int rayTiles, reqTilesX; };
 
 template <class VX, bool DENSE, bool REDUCE, bool PARK, bool AHEAD = false>
-__global__ void __launch_bounds__(256) raycast_kernel(VolumeView vol, const float2* __restrict__ range, float4* __restrict__ out, RayParams p, RangeFuse fuse, AheadRequest ahead) {
+__global__ void __launch_bounds__(256) raycast_kernel(VolumeView volIn, const float2* __restrict__ range, float4* __restrict__ out, RayParams p, RangeFuse fuse, AheadRequest ahead) {
   if constexpr (AHEAD) {
     if ((int)blockIdx.x >= ahead.rayTiles) {
       const int r = (int)blockIdx.x - ahead.rayTiles;
       request_tile<false, false, true>(r % ahead.reqTilesX, r / ahead.reqTilesX, ahead.ra, ahead.ap);
       return;
+    }
+  }
+  // The mirror's page table (itm_types.h: 16^3 entries) in LDS: requested first, so that it travels beside the prologue's own loads; the
+  // barrier of the prologue below is the one behind which it is read
+  constexpr bool kStageTable = !DENSE && kMirrorTableCells <= 4096;
+  __shared__ int32_t pageLds[kStageTable ? kMirrorTableCells : 1];
+  VolumeView vol = volIn;
+  if constexpr (kStageTable) {
+    if (volIn.sdfMirror) {
+      for (int i = threadIdx.x; i < (int)kMirrorTableCells; i += 256) pageLds[i] = volIn.pageTable[i];
+      vol.pageTable = pageLds;
     }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -371,7 +382,7 @@ __global__ void __launch_bounds__(256) raycast_kernel(VolumeView vol, const floa
     __syncthreads();
     if (inside) mm = cellRange[((lane & 15) >> 3) + 2 * (wave >> 1)];
   } else {
-    if (PARK) __syncthreads();
+    if (PARK || kStageTable) __syncthreads();
     if (inside) mm = range[(x >> 3) + (y >> 3) * p.W];  // floor(x/8) + floor(y/8)*W  (_CPU.cpp:174)
   }
   ITM_RS(if (lane == 0) stamp[1] = __builtin_amdgcn_s_memrealtime();)
