@@ -573,6 +573,38 @@ def worker(args) -> int:
             extra["table_walk_fallback"] = {"value": round(n2 / dt, 2), "unit": "frames/s", "steps": n2,
                                             "kernel_us": round(prof["total_ms"] * 1e3 / max(1, prof["calls"]), 2),
                                             "what": "block directory and sdf mirror switched off: every look-up walks the hash table as the reference does (event pair on every launch)"}
+        # (3) the same frames on a scene whose sdf mirror is PAGED (a 768 MB pool behind a page table instead of the dense 17 GB cube:
+        #     what every scene gets once the device no longer has 3 x 17 GB to spare, or with ITM_MIRROR=paged)
+        if wl["index"] == "hash" and wl["voxel"] == "s" and s0.scene.accel_info()["mirror_pages"] == 0 and s0.scene.accel_info()["mirror_bytes"] > 0:
+            os.environ["ITM_MIRROR"] = "paged"
+            try:
+                sp = Stream(be, capi, synth, torch, wl, rank * k_streams, device, s0.hip_stream, offset=offset)
+            finally:
+                del os.environ["ITM_MIRROR"]
+            streams.append(sp)
+            keep, streams[0] = streams[0], sp
+
+            def run_paged(a, b):
+                for k in range(a, b):
+                    step_stream(0, k, k == b - 1)
+            run_paged(0, args.warmup); sync()
+            t1 = time.perf_counter()
+            run_paged(args.warmup, args.warmup + n2); sync()
+            dt = time.perf_counter() - t1
+            sp.scene.profile_read(reset=True)
+            sp.scene.profile_enable(1 << timed_kernel); sp.scene.profile_sample(1)
+            run_paged(args.warmup, args.warmup + 64); sync()
+            sp.scene.profile_calibrate(64, sp.hip_stream.cuda_stream if sp.hip_stream is not None else None); sync()
+            pr = sp.scene.profile_read(reset=True)
+            sp.scene.profile_enable(0)
+            ai = sp.scene.accel_info()
+            half_pair = 0.5 * pr["empty"]["total_ms"] / max(1, pr["empty"]["calls"])
+            extra["paged_mirror"] = {"value": round(n2 / dt, 2), "unit": "frames/s", "steps": n2,
+                                     "kernel_us": round((pr[wl["kernel"]]["total_ms"] / max(1, pr[wl["kernel"]]["calls"]) - half_pair) * 1e3, 2),
+                                     "mirror_bytes": ai["mirror_bytes"], "mirror_pages_mapped": ai["mirror_pages_mapped"], "mirror_pages": ai["mirror_pages"],
+                                     "what": "the sdf mirror as 4 MB pages from a 768 MB pool behind a 16 KB table instead of the dense 17 GB cube of the headline scene"}
+            streams[0] = keep
+            streams.pop()
     if rank == 0 and world == 1 and product and on_gpu and roofline is not None and not args.no_extra_legs:
         roofline["peak_measured"] = measured_stream_peak()
 

@@ -551,7 +551,9 @@ typedef struct itm_accel_info {
   int32_t origin_directory[3], origin_mirror[3];
   int32_t placed;
   int64_t moves;
-  int32_t mirror_pages, mirror_pages_mapped;   /* the mirror's pool: 64 KB pages (4 x 4 x 4 blocks of int16 sdf) it holds / has handed out (reading this synchronises the device) */
+  int32_t mirror_pages, mirror_pages_mapped;   /* PAGED mirror (ITM_MIRROR=paged in the environment, or a device without 3 x 17 GB to spare): 4 MB pages (16 x 16 x 16 blocks of
+                                                  int16 sdf) the pool holds / has handed out (reading this synchronises the device); both 0 for the DENSE form, whose
+                                                  mirror_bytes are the whole cube's 17 GB */
   int64_t near_bits_bytes;     /* measurement feature (ITM_NEAR_BITS=1 in the environment at scene creation; 0 = absent, the default): one byte per
                                   cell of the mirror's cube saying which distances (0 .. 7 blocks) hold an allocated block, so that rays could
                                   cross proven-empty space on arithmetic alone -- built, bit-exact, slower (profiles/r4_raycast_notes.md) */

@@ -286,7 +286,7 @@ __device__ inline void integrate_item(const HashEntry& he, int z0, int lane, typ
     }
     if (touched) {
       VX::store(vba, vi + 64 * k, r[k]);
-      if (mirror) mirror[mbase + mirror_block_voxel((uint32_t)x, (uint32_t)y, (uint32_t)(z0 + k))] = MC::of(VX::raw_sdf(r[k]));   // sdf mirror (itm_types.h): rows of 8 lanes are 16 contiguous bytes
+      if (mirror) mirror[mbase + mirror_block_voxel((uint32_t)x, (uint32_t)y, (uint32_t)(z0 + k))] = MC::of(VX::raw_sdf(r[k]));   // sdf mirror (itm_types.h)
     }
   }
 }

@@ -223,7 +223,8 @@ constexpr size_t kDirCells = (size_t)kDirSide * kDirSide * kDirSide;
 struct AccelOrigin {
   int32_t dx, dy, dz;
   int32_t mx, my, mz;
-  // the mirror's page table, the pool's page counter and size (sdf mirror below); nullptr / 0 for a scene without a mirror
+  // the sdf mirror (below).  mMaxPages > 0: PAGED -- the page table, the pool's page counter and size; mMaxPages < 0: DENSE -- the whole
+  // cube is stored, no table (mTable / mPages are nullptr); 0: the scene has no mirror
   int32_t* mTable;
   int32_t* mPages;
   int32_t mMaxPages;
@@ -258,10 +259,8 @@ __device__ inline void directory_insert(int32_t* __restrict__ dirPtr, int32_t* _
 // A second copy of the sdf of every voxel of every allocated block, addressed by POSITION instead of through the block pointer, over a
 // cube of 256^3 blocks placed in front of the camera (AccelOrigin: centred kMirrorShift blocks along the viewing direction of the frame
 // that placed it, moved when the view leaves it).  Rounds 2-3 stored the cube densely -- 256^3 cells x 1 KB = 17 GB per scene whatever
-// it held.  Round 4: the cube is PAGED.  A page is 128 x 128 x 128 VOXELS (16 x 16 x 16 blocks; 4 MB of int16 sdf, 8 MB of float bits) in
-// plain x-fastest voxel order -- no block structure inside a page: the voxel at cube-relative (vx, vy, vz) lies at
-// (vz & 127) << 14 | (vy & 127) << 7 | (vx & 127), its +1 neighbours at fixed distances 1 / 128 / 16 384 wherever it sits in its block
-// (five instructions for an address, where the dense cube's block-major cells took ten and a trilinear read thirty-five).  A table of
+// it held.  Round 4: the cube is PAGED.  A page is 16 x 16 x 16 blocks (4 MB of int16 sdf, 8 MB of float bits), its blocks
+// x-fastest at a kilobyte each, a block's voxels in the block's own order (mirror_in_page).  A table of
 // 16^3 entries (16 KB: every ray-cast workgroup keeps a copy in LDS) says for every page of the cube
 //     >= 0   the page's index in the pool: value = pool[page << 21 | place in the page]
 //     -1     no block was ever allocated in the page: every position in it reads "no block" WITHOUT a second load
@@ -271,7 +270,11 @@ __device__ inline void directory_insert(int32_t* __restrict__ dirPtr, int32_t* _
 // scene (sphere + wall, 60 k blocks allocated over the trajectory) maps a few dozen pages of a 768 MB pool.  What a ray step costs: the
 // table entry (kept per lane while the ray stays inside the page -- a page is 128 voxels wide, a step at most 8 -- and otherwise read
 // from LDS) and then ONE load whose address follows from the position, as before; in empty space the table alone answers, where the
-// dense cube answered with a cold kilobyte of HBM per cell.  "Absent" inside a mapped page: -32768 cannot be a stored short sdf
+// dense cube answered with a cold kilobyte of HBM per cell.
+// BOTH forms exist at run time (AccelOrigin::mMaxPages): the dense cube is the faster one -- ray cast 38.3 us against 42.8-43.4 paged on
+// BASELINE configs[1]: a page's address takes ~12 more vector instructions per step and the table entry is one more dependent load
+// whenever a lane changes page (profiles/r4_raycast_notes.md) -- and is taken while the device has three times its 17 GB to spare;
+// every further scene, and every scene created with ITM_MIRROR=paged in the environment, gets the paged form.  "Absent" inside a mapped page: -32768 cannot be a stored short sdf
 // ((short)(f * 32767) with f in [-1, 1]); 0xFFFFFFFF is a NaN no arithmetic produces.  Written wherever voxels are written: at
 // allocation (the initial value), by the integration, by the swapping engine, and again from the table after the cube has moved or
 // the table was replaced.  Invariant: the only cells of mapped pages that are not "absent" are those of table entries with ptr >= 0 --
@@ -324,19 +327,29 @@ __host__ __device__ inline bool mirror_covers_voxel(uint32_t vx, uint32_t vy, ui
 __host__ __device__ inline uint32_t mirror_table_index_voxel(uint32_t vx, uint32_t vy, uint32_t vz) {
   return ((vz >> kPageVoxBits) << (2 * (kMirrorBits - kPageBits))) | ((vy >> kPageVoxBits) << (kMirrorBits - kPageBits)) | (vx >> kPageVoxBits);
 }
+// BLOCK-MAJOR inside the page: the page's blocks x-fastest, a kilobyte (512 voxels, x + 8 y + 64 z) each -- the voxels rays of one wave
+// read together lie in a handful of cache lines.  (Plain voxel order over the whole page -- five instructions for an address, fixed
+// neighbour distances -- was measured: 38.3 -> 42.2 us even WITHOUT any table look-up, a trilinear read then touches four lines
+// instead of two and neighbouring rays' voxels spread over many more: profiles/r4_raycast_notes.md.)
 __host__ __device__ inline uint32_t mirror_in_page(uint32_t vx, uint32_t vy, uint32_t vz) {
-  return ((vz & kPageVoxMask) << (2 * kPageVoxBits)) | ((vy & kPageVoxMask) << kPageVoxBits) | (vx & kPageVoxMask);
+  constexpr uint32_t m = (1u << kPageBits) - 1u;
+  const uint32_t blk = ((((vz >> 3) & m) << kPageBits | ((vy >> 3) & m)) << kPageBits) | ((vx >> 3) & m);
+  return (blk << 9) | ((vz & 7u) << 6) | ((vy & 7u) << 3) | (vx & 7u);
 }
 // pool index of the voxel at place `at` of page `page`
 __host__ __device__ inline size_t mirror_element(int page, uint32_t at) { return ((size_t)page << (3 * kPageVoxBits)) | at; }
-// place in its page of voxel (x, y, z) of a block, relative to the block's voxel (0, 0, 0): rows of 8 along x, 32 apart along y, 1 024 along z
-__host__ __device__ inline uint32_t mirror_block_voxel(uint32_t x, uint32_t y, uint32_t z) { return (z << (2 * kPageVoxBits)) | (y << kPageVoxBits) | x; }
-__host__ __device__ inline uint32_t mirror_block_lin(uint32_t lin) { return mirror_block_voxel(lin & 7u, (lin >> 3) & 7u, lin >> 6); }
+// place of voxel (x, y, z) of a block relative to the block's voxel (0, 0, 0): the block's own order, x + 8 y + 64 z
+__host__ __device__ inline uint32_t mirror_block_voxel(uint32_t x, uint32_t y, uint32_t z) { return (z << 6) | (y << 3) | x; }
+__host__ __device__ inline uint32_t mirror_block_lin(uint32_t lin) { return lin; }
 
 // The page of a table entry, taking one from the pool if the page has none yet (allocation paths only).  Safe between the lanes of
 // one wave as well: whoever wins the exchange publishes the page before it leaves the loop body, nobody waits inside the loop for a
 // lane of its own wave.  Returns the page index, or kPageUnmappable.
 __device__ inline int mirror_claim_page(const AccelOrigin& org, uint32_t tIdx) {
+  if (org.mMaxPages >= (int)kMirrorTableCells) {      // a pool with a page for every page of the cube (measurement set-up: ITM_MIRROR_PAGES=4096): mapped 1:1
+    if (org.mTable[tIdx] != (int)tIdx) __hip_atomic_store(&org.mTable[tIdx], (int)tIdx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (int)tIdx;
+  }
   int v = __hip_atomic_load(&org.mTable[tIdx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   while (v == kPageNone || v == kPageClaiming) {
     if (v == kPageNone) {
@@ -356,7 +369,8 @@ __device__ inline int mirror_claim_page(const AccelOrigin& org, uint32_t tIdx) {
 template <bool CLAIM>
 __device__ inline bool mirror_block_base(const AccelOrigin& org, int bx, int by, int bz, size_t& base) {
   const uint32_t ux = (uint32_t)(bx - org.mx), uy = (uint32_t)(by - org.my), uz = (uint32_t)(bz - org.mz);
-  if (!org.mTable || !mirror_covers(ux, uy, uz)) return false;
+  if (org.mMaxPages == 0 || !mirror_covers(ux, uy, uz)) return false;
+  if (org.mMaxPages < 0) { base = (size_t)mirror_cell(ux, uy, uz) << 9; return true; }      // dense: the cube's blocks x-fastest, a kilobyte each
   const uint32_t tIdx = mirror_table_index(ux, uy, uz);
   const int page = CLAIM ? mirror_claim_page(org, tIdx) : org.mTable[tIdx];
   if (page < 0) return false;
@@ -368,13 +382,14 @@ __device__ inline bool mirror_block_base(const AccelOrigin& org, int bx, int by,
 __device__ inline void mirror_init_block(void* __restrict__ mirror, bool floatSdf, const AccelOrigin& org, int bx, int by, int bz) {
   size_t base;
   if (!mirror || !mirror_block_base<true>(org, bx, by, bz, base)) return;
-  // 64 rows (y, z) of 8 voxels: 16 bytes of shorts / 2 x 16 bytes of float bits each
   if (floatSdf) {
+    uint4* q = (uint4*)((uint32_t*)mirror + base);         // 2 KB, 16-byte aligned
     const uint4 init = make_uint4(0x3f800000u, 0x3f800000u, 0x3f800000u, 0x3f800000u);
-    for (int r = 0; r < 64; ++r) { uint4* q = (uint4*)((uint32_t*)mirror + base + mirror_block_voxel(0u, (uint32_t)(r & 7), (uint32_t)(r >> 3))); q[0] = init; q[1] = init; }
+    for (int i = 0; i < 128; ++i) q[i] = init;
   } else {
+    uint4* q = (uint4*)((int16_t*)mirror + base);          // 1 KB
     const uint4 init = make_uint4(0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu);
-    for (int r = 0; r < 64; ++r) *(uint4*)((int16_t*)mirror + base + mirror_block_voxel(0u, (uint32_t)(r & 7), (uint32_t)(r >> 3))) = init;
+    for (int i = 0; i < 64; ++i) q[i] = init;
   }
 }
 

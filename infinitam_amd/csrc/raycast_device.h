@@ -50,7 +50,19 @@ struct VolumeView {
   AccelOrigin org;          // where the directory / mirror cubes lie
   int sx, sy, sz;      // dense size
   int ox, oy, oz;      // dense offset
+  // which form of the sdf mirror the code reading through this view is compiled for: -1 = decided at run time from org.mMaxPages
+  // (both forms compiled in: the free-view and helper kernels), see VolumeViewM
+  static constexpr int kMirror = -1;
 };
+// The same view for a kernel that is compiled for ONE form of the mirror (0 none, 1 dense cube, 2 paged: itm_types.h): the ray-cast
+// kernel needs every tile of the image resident at once -- 4 800 waves, five per SIMD, at most 96 vector registers -- and with both
+// forms' address arithmetic alive it takes 104.  Every function below takes the view as a template parameter and folds the other form away.
+template <int M> struct VolumeViewM : VolumeView {
+  static constexpr int kMirror = M;
+  __device__ VolumeViewM(const VolumeView& v) : VolumeView(v) {}
+};
+template <class VOL> __device__ inline bool mirror_is_dense(const VOL& vol) { return VOL::kMirror == 1 || (VOL::kMirror < 0 && vol.org.mMaxPages < 0); }
+template <class VOL> __device__ inline bool mirror_is_paged(const VOL& vol) { return VOL::kMirror == 2 || (VOL::kMirror < 0 && vol.org.mMaxPages > 0); }
 
 // per-ray block cache: ITMVoxelBlockHash::IndexCache (Objects/ITMVoxelBlockHash.h:27-33)
 struct BlockCache {
@@ -66,6 +78,10 @@ struct BlockCache {
 // The mirror page with table index tIdx, through the per-lane cache.  The table is read by a wave only when one of its lanes has left
 // its page (uniform branch; a lane that keeps its page reads entry 0 and drops it).
 __device__ inline int mirror_page_of(const VolumeView& vol, bool inCube, uint32_t tIdx, BlockCache& cache) {
+#if ITM_EXP_MIRROR_IDENTITY
+  (void)vol; (void)cache; (void)inCube;
+  return (int)tIdx;          // measurement build: every page of the cube has its own pool page (scene created with ITM_MIRROR_PAGES=4096 and mapped 1:1)
+#endif
   const bool need = inCube && tIdx != cache.pageIdx;
   if (__any(need)) {
     const int v = vol.pageTable[need ? tIdx : 0u];
@@ -121,16 +137,30 @@ __device__ inline long long locate_voxel(const VolumeView& vol, int px, int py, 
 
 // raw (unconverted) sdf of the voxel at an integer point; the default voxel when absent
 // skipLane: this lane wants no value (its answer comes from the near bits): it reads cell 0 and reports "no block"
-template <class VX, bool DENSE, bool NEAR = false>
-__device__ inline float read_raw_sdf(const VolumeView& vol, int px, int py, int pz, bool& found, BlockCache& cache, uint32_t* nearByte = nullptr, bool skipLane = false) {
+template <class VX, bool DENSE, bool NEAR = false, class VOL = VolumeView>
+__device__ inline float read_raw_sdf(const VOL& vol, int px, int py, int pz, bool& found, BlockCache& cache, uint32_t* nearByte = nullptr, bool skipLane = false) {
   if constexpr (NEAR) *nearByte = 0xffu;      // "a block right here": nothing may be skipped
   if constexpr (!DENSE) {
     // sdf mirror: one load, address from the position alone (same value and same "found" as the walk below: the mirror holds
     // exactly the voxels of the allocated blocks inside its cube)
     using MC = MirrorCodec<VX::kShort>;
-    if (vol.sdfMirror) {
-      // the load is unconditional (cell 0 for a lane outside the cube) and the general path below is skipped by a UNIFORM branch when
-      // every lane was served: no exec-mask bracket around the common case (ray cast 42.1 -> 41.7 us)
+    if (vol.sdfMirror && mirror_is_dense(vol)) {
+      // DENSE cube (itm_types.h): the load is unconditional (cell 0 for a lane outside the cube) and the general path below is skipped by
+      // a UNIFORM branch when every lane was served: no exec-mask bracket around the common case (ray cast 42.1 -> 41.7 us)
+      const uint32_t ux = (uint32_t)((px >> 3) - vol.org.mx), uy = (uint32_t)((py >> 3) - vol.org.my), uz = (uint32_t)((pz >> 3) - vol.org.mz);
+      const bool covered = mirror_covers(ux, uy, uz);
+      const size_t mi = ((size_t)mirror_cell(ux, uy, uz) << 9) | (size_t)((px & 7) + ((py & 7) << 3) + ((pz & 7) << 6));
+      const typename MC::T v = ((const typename MC::T*)vol.sdfMirror)[(covered && !skipLane) ? mi : (size_t)0];
+      if constexpr (NEAR) {
+        const uint32_t nb = vol.nearBits[covered ? (mi >> 9) : (size_t)0];
+        if (covered) *nearByte = nb;
+      }
+      const bool present = covered && !skipLane && !MC::absent(v);
+      const float value = present ? MC::raw(v) : (VX::kShort ? 32767.0f : 1.0f);
+      if (__all(covered)) { found = present; return value; }
+      if (covered) { found = present; return value; }
+    } else if (vol.sdfMirror && mirror_is_paged(vol)) {
+      // PAGED cube: the page's table entry (per-lane cache, else one read), then the one load that follows from the position
       const uint32_t vx = (uint32_t)(px - (vol.org.mx << 3)), vy = (uint32_t)(py - (vol.org.my << 3)), vz = (uint32_t)(pz - (vol.org.mz << 3));      // cube-relative voxel
       const bool inCube = mirror_covers_voxel(vx, vy, vz);
       const int page = mirror_page_of(vol, inCube, mirror_table_index_voxel(vx, vy, vz), cache);
@@ -160,12 +190,12 @@ __device__ inline float read_raw_sdf(const VolumeView& vol, int px, int py, int 
   return VX::load_raw_sdf(vol.vba, (size_t)a);
 }
 
-template <class VX, bool DENSE>
-__device__ inline float sdf_nearest(const VolumeView& vol, float x, float y, float z, bool& found, BlockCache& cache) {
+template <class VX, bool DENSE, class VOL = VolumeView>
+__device__ inline float sdf_nearest(const VOL& vol, float x, float y, float z, bool& found, BlockCache& cache) {
   return VX::to_float(read_raw_sdf<VX, DENSE>(vol, (int)round_ref(x), (int)round_ref(y), (int)round_ref(z), found, cache));
 }
-template <class VX>
-__device__ inline float sdf_nearest_near(const VolumeView& vol, float x, float y, float z, bool& found, BlockCache& cache, uint32_t& nearByte) {
+template <class VX, class VOL = VolumeView>
+__device__ inline float sdf_nearest_near(const VOL& vol, float x, float y, float z, bool& found, BlockCache& cache, uint32_t& nearByte) {
   return VX::to_float(read_raw_sdf<VX, false, true>(vol, (int)round_ref(x), (int)round_ref(y), (int)round_ref(z), found, cache, &nearByte));
 }
 
@@ -198,7 +228,8 @@ struct Corners {
   // reads voxel 0 / its own cell again and drops the value): a load inside an exec-masked branch forces the compiler to
   // wait for it inside that branch, which turned the eight voxel reads of a trilinear sample into eight serial round
   // trips (round 1's "4 500 cycles per trilinear step").  Unconditional, they are in flight together.
-  __device__ inline void fetch(const VolumeView& vol, float x, float y, float z, BlockCache& cache) {
+  template <class VOL>
+  __device__ inline void fetch(const VOL& vol, float x, float y, float z, BlockCache& cache) {
     const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
     cx = x - fx; cy = y - fy; cz = z - fz;
     ix = (int)fx; iy = (int)fy; iz = (int)fz;
@@ -216,11 +247,33 @@ struct Corners {
         // sdf mirror: eight independent loads.  Taken when every lane of the wave that is here can use it (a wave with a lane
         // outside the mirrored cube takes the general path as a whole: both give the same values)
         using MC = MirrorCodec<VX::kShort>;
-        if (vol.sdfMirror) {
-          // The eight addresses from ONE: a page is 32^3 voxels in plain x-fastest order, so the +1 neighbours lie 1 / 32 / 1 024 elements
-          // further wherever the voxel sits in its block -- as long as the neighbourhood stays inside ONE page (31 of 32 positions per
-          // axis).  A wave with a lane whose neighbourhood straddles pages looks up the page of each of the eight voxels instead (eight
-          // independent table reads, then the eight values).
+        if (vol.sdfMirror && mirror_is_dense(vol)) {
+          // DENSE cube.  The eight addresses from ONE: with the blocks in plain x-fastest order the +1 neighbour along an axis is one voxel
+          // further inside the block, or -- from the block's last voxel -- the first voxel of the next block, a fixed distance either
+          // way.  (Taken when the blocks of (ix, iy, iz) and of (ix, iy, iz) + 8 per axis both lie in the cube: one block more than the
+          // neighbourhood needs at the cube's upper faces, where the general path gives the same values.)  ~35 vector instructions for
+          // the eight addresses instead of ~140 -- half of what a trilinear read issued.
+          const uint32_t mx = (uint32_t)((ix >> 3) - vol.org.mx), my = (uint32_t)((iy >> 3) - vol.org.my), mz = (uint32_t)((iz >> 3) - vol.org.mz);
+          const bool all = mirror_covers(mx, my, mz) && mirror_covers(mx + 1u, my + 1u, mz + 1u);
+          const int kx = ix & 7, ky = iy & 7, kz = iz & 7;
+          const size_t base = ((size_t)mirror_cell(mx, my, mz) << 9) + (size_t)(kx + (ky << 3) + (kz << 6));
+          const uint32_t ox = (kx == 7) ? 512u - 7u : 1u;
+          const uint32_t oy = (ky == 7) ? (512u << kMirrorBits) - 56u : 8u;
+          const uint32_t oz = (kz == 7) ? (512u << (2 * kMirrorBits)) - 448u : 64u;
+          if (__all(all)) {
+            typename MC::T m[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) m[c] = ((const typename MC::T*)vol.sdfMirror)[base + (size_t)(((c & 1) ? ox : 0u) + ((c & 2) ? oy : 0u) + ((c & 4) ? oz : 0u))];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { present[c] = !MC::absent(m[c]); v[c] = present[c] ? MC::raw(m[c]) : dflt; }
+            return;
+          }
+        } else if (vol.sdfMirror && mirror_is_paged(vol)) {
+          // PAGED cube.  The eight addresses from ONE: inside a page the blocks lie x-fastest at a kilobyte each, so the +1 neighbour along an axis is one
+          // voxel further inside the block or -- from the block's last voxel -- the first voxel of the next block of the page, a fixed
+          // distance either way (~35 vector instructions for the eight addresses instead of ~140).  That holds while the neighbourhood
+          // stays inside ONE page (127 of 128 positions per axis); a wave with a lane whose neighbourhood straddles pages looks up the page
+          // of each of the eight voxels instead (eight independent table reads, then the eight values).
           const uint32_t vx = (uint32_t)(ix - (vol.org.mx << 3)), vy = (uint32_t)(iy - (vol.org.my << 3)), vz = (uint32_t)(iz - (vol.org.mz << 3));
           const bool inCube = mirror_covers_voxel(vx, vy, vz) && mirror_covers_voxel(vx + 1u, vy + 1u, vz + 1u);
           const bool onePage = ((vx & kPageVoxMask) != kPageVoxMask) && ((vy & kPageVoxMask) != kPageVoxMask) && ((vz & kPageVoxMask) != kPageVoxMask);
@@ -234,9 +287,12 @@ struct Corners {
               for (int c = 0; c < 8; ++c) m[c] = none;
               if (__any(mapped)) {
                 const size_t base = mapped ? mirror_element(page, mirror_in_page(vx, vy, vz)) : (size_t)0;
+                const uint32_t ox = ((vx & 7u) == 7u) ? 512u - 7u : 1u;
+                const uint32_t oy = ((vy & 7u) == 7u) ? (512u << kPageBits) - 56u : 8u;
+                const uint32_t oz = ((vz & 7u) == 7u) ? (512u << (2 * kPageBits)) - 448u : 64u;
                 typename MC::T got[8];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) got[c] = ((const typename MC::T*)vol.sdfMirror)[mapped ? base + (size_t)mirror_block_voxel((uint32_t)(c & 1), (uint32_t)((c >> 1) & 1), (uint32_t)(c >> 2)) : (size_t)0];
+                for (int c = 0; c < 8; ++c) got[c] = ((const typename MC::T*)vol.sdfMirror)[mapped ? base + (size_t)(((c & 1) ? ox : 0u) + ((c & 2) ? oy : 0u) + ((c & 4) ? oz : 0u)) : (size_t)0];
 #pragma unroll
                 for (int c = 0; c < 8; ++c) if (mapped) m[c] = got[c];
               }
@@ -353,8 +409,8 @@ struct Corners {
   }
 };
 
-template <class VX, bool DENSE>
-__device__ inline float sdf_trilinear(const VolumeView& vol, float x, float y, float z, bool& found, BlockCache& cache) {
+template <class VX, bool DENSE, class VOL = VolumeView>
+__device__ inline float sdf_trilinear(const VOL& vol, float x, float y, float z, bool& found, BlockCache& cache) {
   Corners<VX, DENSE> cn;
   cn.fetch(vol, x, y, z, cache);
   found = true;
@@ -396,8 +452,8 @@ __device__ inline RaySetup ray_setup(int x, int y, const RayParams& p, float2 mm
 
 // castRay in the reference's own order (DeviceAgnostic/ITMVisualisationEngine.h:92-158): baseline for measurements
 // (ITM_RAY_WHILE_WHILE=0, 69 us vs 62 us for the restructured loop below on config 2).
-template <class VX, bool DENSE>
-__device__ inline float4 cast_ray_plain(int x, int y, const VolumeView& vol, const RayParams& p, float2 mm) {
+template <class VX, bool DENSE, class VOL = VolumeView>
+__device__ inline float4 cast_ray_plain(int x, int y, const VOL& vol, const RayParams& p, float2 mm) {
   const float stepScale = p.mu * p.oneOverVoxel;
   RaySetup r = ray_setup(x, y, p, mm);
   float px = r.px, py = r.py, pz = r.pz, total = r.total;
@@ -463,6 +519,9 @@ __device__ inline float4 cast_ray_plain(int x, int y, const VolumeView& vol, con
 #define ITM_RAY_PROBE_CELLS 10
 #endif
 
+#ifndef ITM_EXP_MIRROR_IDENTITY
+#define ITM_EXP_MIRROR_IDENTITY 0
+#endif
 #ifndef ITM_RAY_FLAT_STEP
 #define ITM_RAY_FLAT_STEP 1
 #endif
@@ -536,8 +595,8 @@ struct RayResume { float px, py, pz, total; };
 //   PARK: the ray stops (parked = true, returns its position and length in xyz / w) once it has taken ITM_RAY_PARK_STREAK
 //     "not found" steps in a row; the caller appends it to the queue of the second pass.
 // Per ray the sequence of positions, reads and float operations is that of the reference, whatever the pass structure.
-template <class VX, bool DENSE, int LOOKAHEAD, bool PARK>
-__device__ inline float4 march_ray(int x, int y, const VolumeView& vol, const RayParams& p, float2 mm, const RayResume* resume, bool& parked) {
+template <class VX, bool DENSE, int LOOKAHEAD, bool PARK, class VOL = VolumeView>
+__device__ inline float4 march_ray(int x, int y, const VOL& vol, const RayParams& p, float2 mm, const RayResume* resume, bool& parked) {
   // MARCH: next read is a single voxel; TRI: a single-voxel read found the band, the trilinear read of the same position is
   // due; REFINE: the surface was crossed
   enum : int { MARCH = 0, TRI = 1, REFINE = 2, DONE = 4 };
@@ -616,9 +675,11 @@ __device__ inline float4 march_ray(int x, int y, const VolumeView& vol, const Ra
       for (int j = 0; j < K; ++j) {
         const uint32_t vx = (uint32_t)((int)round_ref(qx) - (vol.org.mx << 3)), vy = (uint32_t)((int)round_ref(qy) - (vol.org.my << 3)), vz = (uint32_t)((int)round_ref(qz) - (vol.org.mz << 3));
         const bool in = runner && mirror_covers_voxel(vx, vy, vz);
-        const int pg = vol.pageTable[in ? mirror_table_index_voxel(vx, vy, vz) : 0u];
+        const bool dense = mirror_is_dense(vol);
+        const int pg = dense ? 0 : vol.pageTable[in ? mirror_table_index_voxel(vx, vy, vz) : 0u];
         const bool use = in && pg >= 0;
-        val[j] = ((const typename MC::T*)vol.sdfMirror)[use ? mirror_element(pg, mirror_in_page(vx, vy, vz)) : (size_t)0];
+        const size_t at = dense ? (((size_t)mirror_cell(vx >> 3, vy >> 3, vz >> 3) << 9) | (size_t)((vx & 7u) | ((vy & 7u) << 3) | ((vz & 7u) << 6))) : mirror_element(pg, mirror_in_page(vx, vy, vz));
+        val[j] = ((const typename MC::T*)vol.sdfMirror)[use ? at : (size_t)0];
         ok[j] = use;
         qx += sx; qy += sy; qz += sz;
       }
@@ -826,8 +887,8 @@ __device__ inline float4 march_ray(int x, int y, const VolumeView& vol, const Ra
 }
 
 // castRay for callers that want one ray start to finish
-template <class VX, bool DENSE>
-__device__ inline float4 cast_ray(int x, int y, const VolumeView& vol, const RayParams& p, float2 mm) {
+template <class VX, bool DENSE, class VOL = VolumeView>
+__device__ inline float4 cast_ray(int x, int y, const VOL& vol, const RayParams& p, float2 mm) {
 #if !ITM_RAY_WHILE_WHILE
   return cast_ray_plain<VX, DENSE>(x, y, vol, p, mm);
 #else

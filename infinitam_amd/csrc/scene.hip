@@ -185,10 +185,10 @@ __global__ void __launch_bounds__(256) mirror_fill_kernel(const uint4* __restric
 static bool mirror_is_float(const itm_scene* s) { return s->cfg.voxelType == ITM_VOXEL_F || s->cfg.voxelType == ITM_VOXEL_F_RGB; }
 // every voxel of every page of the pool "no block here" (-32768 per short, all ones per float), no page handed out (scene creation only)
 static hipError_t mirror_clear(itm_scene* s, hipStream_t st) {
-  const size_t voxels = (size_t)s->mirrorPages * kPageBlocks * 512;
+  const size_t voxels = s->org.mMaxPages < 0 ? kMirrorCells * 512 : (size_t)s->mirrorPages * kPageBlocks * 512;
   hipError_t e = mirror_is_float(s) ? hipMemsetAsync(s->sdfMirror, 0xff, voxels * 4, st) : hipMemsetD16Async((unsigned short*)s->sdfMirror, (unsigned short)0x8000, voxels, st);
-  if (e == hipSuccess) e = hipMemsetAsync(s->org.mTable, 0xff, kMirrorTableCells * 4, st);
-  if (e == hipSuccess) e = hipMemsetAsync(s->org.mPages, 0, 4, st);
+  if (e == hipSuccess && s->org.mTable) e = hipMemsetAsync(s->org.mTable, 0xff, kMirrorTableCells * 4, st);
+  if (e == hipSuccess && s->org.mPages) e = hipMemsetAsync(s->org.mPages, 0, 4, st);
   return e;
 }
 
@@ -202,7 +202,7 @@ static int mirror_pass(itm_scene* s, hipStream_t st) {
   });
   if (rc) return rc;
   ITM_LAUNCH_CHECK();
-  if (!FILL) {
+  if (!FILL && s->org.mTable) {
     // every mapped page is all "absent" again (the invariant of itm_types.h): the pool is as good as new
     ITM_HIP(hipMemsetAsync(s->org.mTable, 0xff, kMirrorTableCells * 4, st));
     ITM_HIP(hipMemsetAsync(s->org.mPages, 0, 4, st));
@@ -549,25 +549,37 @@ int itm_scene_create(const itm_scene_config* cfg_in, const itm_scene_params* prm
     if (hipMalloc((void**)&s->dirPtr, kDirCells * 4) != hipSuccess) { s->dirPtr = nullptr; (void)hipGetLastError(); }
     else if (hipMalloc((void**)&s->dirSlot, kDirCells * 4) != hipSuccess) { (void)hipFree(s->dirPtr); s->dirPtr = nullptr; s->dirSlot = nullptr; (void)hipGetLastError(); }
   }
-  // The sdf mirror is an accelerator: taken when the device has room for its pool (768 MB: 192 pages of 4 MB for the short voxel
-  // types; the table says which pages of the cube are mapped, itm_types.h), silently left out otherwise -- and only for the short voxel
-  // types.  For the float types it was measured on BASELINE configs[4]: the ray cast gains less than the integration pays for the extra
-  // 4-byte stores (ITM_MIRROR_FLOAT_TYPES=1 builds it in).  ITM_MIRROR_PAGES in the environment sizes the pool.
+  // The sdf mirror is an accelerator, in one of two forms (itm_types.h): DENSE -- the whole cube of 256^3 blocks, 17 GB, the faster one
+  // (ray cast 38.3 us against 42.8-43.4 on BASELINE configs[1]) -- while the device has three times that to spare, i.e. for the first
+  // handful of scenes of a 288 GB device; PAGED -- a 768 MB pool of 4 MB pages behind a 16 KB table, O(touched pages) -- for every
+  // scene after that, and whenever ITM_MIRROR=paged is in the environment (ITM_MIRROR=dense insists on the cube, =off on none;
+  // ITM_MIRROR_PAGES sizes the pool).  Silently left out when not even the pool fits -- and only for the short voxel types: for the
+  // float types it was measured on BASELINE configs[4], the ray cast gains less than the integration pays for the extra 4-byte stores
+  // (ITM_MIRROR_FLOAT_TYPES=1 builds it in).
   if (cfg.indexType == ITM_INDEX_HASH && s->dirPtr && !g_debug_no_sdf_mirror && (ITM_MIRROR_FLOAT_TYPES || !mirror_is_float(s))) {
-    const size_t pageBytes = (size_t)kPageBlocks * 512 * (mirror_is_float(s) ? 4 : 2);
+    const char* mode = getenv("ITM_MIRROR");
+    const size_t voxBytes = mirror_is_float(s) ? 4 : 2;
+    const size_t pageBytes = (size_t)kPageBlocks * 512 * voxBytes, denseBytes = kMirrorCells * 512 * voxBytes;
     int pages = (int)(((size_t)768 << 20) / pageBytes);
     if (const char* e = getenv("ITM_MIRROR_PAGES")) { const int v = atoi(e); if (v > 0) pages = v; }
     size_t freeB = 0, totalB = 0;
-    const size_t bytes = (size_t)pages * pageBytes;
-    if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB > 3 * bytes) {
+    const bool haveInfo = hipMemGetInfo(&freeB, &totalB) == hipSuccess;
+    const bool off = mode && !strcmp(mode, "off");
+    bool dense = !off && haveInfo && ((mode && !strcmp(mode, "dense")) ? freeB > denseBytes + ((size_t)1 << 30) : (!(mode && !strcmp(mode, "paged")) && freeB > 3 * denseBytes));
+    const bool paged = !off && !dense && haveInfo && freeB > 3 * (size_t)pages * pageBytes;
+    auto drop = [&]() {
+      (void)hipGetLastError();
+      (void)hipFree(s->sdfMirror); (void)hipFree(s->org.mTable); (void)hipFree(s->org.mPages);
+      s->sdfMirror = nullptr; s->org.mTable = nullptr; s->org.mPages = nullptr; s->org.mMaxPages = 0; s->mirrorPages = 0;
+    };
+    if (dense) {
+      s->org.mMaxPages = -1;
+      if (hipMalloc(&s->sdfMirror, denseBytes) != hipSuccess || mirror_clear(s, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) drop();
+    } else if (paged) {
       s->mirrorPages = pages;
       s->org.mMaxPages = pages;
-      if (hipMalloc(&s->sdfMirror, bytes) != hipSuccess || hipMalloc((void**)&s->org.mTable, kMirrorTableCells * 4) != hipSuccess ||
-          hipMalloc((void**)&s->org.mPages, 4) != hipSuccess || mirror_clear(s, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
-        (void)hipGetLastError();
-        (void)hipFree(s->sdfMirror); (void)hipFree(s->org.mTable); (void)hipFree(s->org.mPages);
-        s->sdfMirror = nullptr; s->org.mTable = nullptr; s->org.mPages = nullptr; s->org.mMaxPages = 0; s->mirrorPages = 0;
-      }
+      if (hipMalloc(&s->sdfMirror, (size_t)pages * pageBytes) != hipSuccess || hipMalloc((void**)&s->org.mTable, kMirrorTableCells * 4) != hipSuccess ||
+          hipMalloc((void**)&s->org.mPages, 4) != hipSuccess || mirror_clear(s, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) drop();
     }
   }
   // near bits (itm_types.h): MEASUREMENT FEATURE, off unless ITM_NEAR_BITS=1 is in the environment when the scene is created.  Built for
@@ -629,10 +641,11 @@ int itm_scene_accel_info(const itm_scene* s, itm_accel_info* out) {
   out->directory_bytes = s->dirPtr ? (int64_t)(kDirCells * 4) : 0;
   out->slot_directory_bytes = s->dirSlot ? (int64_t)(kDirCells * 4) : 0;
   out->near_bits_bytes = s->nearBits ? (int64_t)kMirrorCells : 0;
-  out->mirror_bytes = s->sdfMirror ? (int64_t)((size_t)s->mirrorPages * kPageBlocks * 512 * (mirror_is_float(s) ? 4 : 2) + kMirrorTableCells * 4) : 0;
-  out->mirror_pages = s->mirrorPages;
+  out->mirror_bytes = !s->sdfMirror ? 0 : s->org.mMaxPages < 0 ? (int64_t)(kMirrorCells * 512 * (mirror_is_float(s) ? 4 : 2))
+                                                                  : (int64_t)((size_t)s->mirrorPages * kPageBlocks * 512 * (mirror_is_float(s) ? 4 : 2) + kMirrorTableCells * 4);
+  out->mirror_pages = s->mirrorPages;          // 0 for the dense form
   out->mirror_pages_mapped = 0;
-  if (s->sdfMirror) { int n = 0; if (hipMemcpy(&n, s->org.mPages, 4, hipMemcpyDeviceToHost) == hipSuccess) out->mirror_pages_mapped = n < s->mirrorPages ? n : s->mirrorPages; else (void)hipGetLastError(); }
+  if (s->sdfMirror && s->org.mPages) { int n = 0; if (hipMemcpy(&n, s->org.mPages, 4, hipMemcpyDeviceToHost) == hipSuccess) out->mirror_pages_mapped = n < s->mirrorPages ? n : s->mirrorPages; else (void)hipGetLastError(); }
   out->origin_directory[0] = s->org.dx; out->origin_directory[1] = s->org.dy; out->origin_directory[2] = s->org.dz;
   out->origin_mirror[0] = s->org.mx; out->origin_mirror[1] = s->org.my; out->origin_mirror[2] = s->org.mz;
   out->placed = s->orgPlaced ? 1 : 0;

@@ -30,6 +30,12 @@
 
 namespace itm {
 
+#ifndef ITM_MIRROR_FLOAT_TYPES
+#define ITM_MIRROR_FLOAT_TYPES 0     // (scene.hip decides whether a float scene gets a mirror; the same switch must be given to every file)
+#endif
+#ifndef ITM_MIRROR_STAGE_TABLE
+#define ITM_MIRROR_STAGE_TABLE 0     // 1: every ray-cast workgroup copies the mirror's page table (16 KB) to LDS in its prologue
+#endif
 #ifndef ITM_NT_STORES
 #define ITM_NT_STORES 1
 #endif
@@ -341,7 +347,8 @@ __device__ unsigned long long g_rayStamps[8192 * 4];   // per wave: start, after
 // slot directory / next depth image and writes request keys, visible types and request counters, none of which a ray touches.
 struct AheadRequest { RequestArgs ra; AllocParams ap; int rayTiles, reqTilesX; };
 
-template <class VX, bool DENSE, bool REDUCE, bool PARK, bool AHEAD = false>
+// MIRROR: the form of the sdf mirror this instance is compiled for (raycast_device.h, VolumeViewM): 0 none, 1 dense cube, 2 paged
+template <class VX, bool DENSE, bool REDUCE, bool PARK, bool AHEAD = false, int MIRROR = 0>
 __global__ void __launch_bounds__(256) raycast_kernel(VolumeView volIn, const float2* __restrict__ range, float4* __restrict__ out, RayParams p, RangeFuse fuse, AheadRequest ahead) {
   if constexpr (AHEAD) {
     if ((int)blockIdx.x >= ahead.rayTiles) {
@@ -352,11 +359,12 @@ __global__ void __launch_bounds__(256) raycast_kernel(VolumeView volIn, const fl
   }
   // The mirror's page table (itm_types.h: 16^3 entries) in LDS: requested first, so that it travels beside the prologue's own loads; the
   // barrier of the prologue below is the one behind which it is read
-  constexpr bool kStageTable = !DENSE && kMirrorTableCells <= 4096;
+  constexpr bool kStageTable = !DENSE && MIRROR == 2 && kMirrorTableCells <= 4096 && ITM_MIRROR_STAGE_TABLE;
   __shared__ int32_t pageLds[kStageTable ? kMirrorTableCells : 1];
-  VolumeView vol = volIn;
+  VolumeViewM<MIRROR> vol(volIn);
+  if constexpr (MIRROR == 0) vol.sdfMirror = nullptr;
   if constexpr (kStageTable) {
-    if (volIn.sdfMirror) {
+    if (volIn.sdfMirror && volIn.pageTable) {
       for (int i = threadIdx.x; i < (int)kMirrorTableCells; i += 256) pageLds[i] = volIn.pageTable[i];
       vol.pageTable = pageLds;
     }
@@ -440,21 +448,25 @@ int launch_raycast(const itm_scene* s, const float* invM, const float* intr, itm
   if (aheadIn && !dense) { ahead = *aheadIn; ahead.rayTiles = rayTiles; reqTiles = ahead.reqTilesX * ((ahead.ap.H + 15) / 16); }
   const dim3 grid(rayTiles + reqTiles);
   KernelTimer tk(s, ITM_TK_RAYCAST, st);
+  // the mirror's form picks the kernel (one form's address arithmetic per instance, see VolumeViewM); scenes without the block directory
+  // (no parked rays) have no mirror either
+  const int mirrorForm = (!vol.sdfMirror || !park) ? 0 : (vol.org.mMaxPages < 0 ? 1 : 2);
   int rc = dispatch_voxel(s->cfg.voxelType, [&](auto vx) {
     using VX = decltype(vx);
+    constexpr bool kMayMirror = VX::kShort || ITM_MIRROR_FLOAT_TYPES;
+#define ITM_RC(RED, PRK, AHD, MIR) raycast_kernel<VX, false, RED, PRK, AHD, MIR><<<grid, 256, 0, st>>>(vol, rs->range, dst, p, fuse, ahead)
+#define ITM_RC_MIRROR(RED, AHD) do { if (kMayMirror && mirrorForm == 1) ITM_RC(RED, true, AHD, (kMayMirror ? 1 : 0)); else if (kMayMirror && mirrorForm == 2) ITM_RC(RED, true, AHD, (kMayMirror ? 2 : 0)); else ITM_RC(RED, true, AHD, 0); } while (0)
     if (dense) raycast_kernel<VX, true, false, false><<<grid, 256, 0, st>>>(vol, rs->range, dst, p, fuse, ahead);
     else if (reqTiles) {
-      if (park) { if (reduceRange) raycast_kernel<VX, false, true, true, true><<<grid, 256, 0, st>>>(vol, rs->range, dst, p, fuse, ahead);
-                  else raycast_kernel<VX, false, false, true, true><<<grid, 256, 0, st>>>(vol, rs->range, dst, p, fuse, ahead); }
-      else if (reduceRange) raycast_kernel<VX, false, true, false, true><<<grid, 256, 0, st>>>(vol, rs->range, dst, p, fuse, ahead);
-      else raycast_kernel<VX, false, false, false, true><<<grid, 256, 0, st>>>(vol, rs->range, dst, p, fuse, ahead);
+      if (park) { if (reduceRange) ITM_RC_MIRROR(true, true); else ITM_RC_MIRROR(false, true); }
+      else if (reduceRange) ITM_RC(true, false, true, 0);
+      else ITM_RC(false, false, true, 0);
     }
-    else if (park) {
-      if (reduceRange) raycast_kernel<VX, false, true, true><<<grid, 256, 0, st>>>(vol, rs->range, dst, p, fuse, ahead);
-      else raycast_kernel<VX, false, false, true><<<grid, 256, 0, st>>>(vol, rs->range, dst, p, fuse, ahead);
-    }
-    else if (reduceRange) raycast_kernel<VX, false, true, false><<<grid, 256, 0, st>>>(vol, rs->range, dst, p, fuse, ahead);
-    else raycast_kernel<VX, false, false, false><<<grid, 256, 0, st>>>(vol, rs->range, dst, p, fuse, ahead);
+    else if (park) { if (reduceRange) ITM_RC_MIRROR(true, false); else ITM_RC_MIRROR(false, false); }
+    else if (reduceRange) ITM_RC(true, false, false, 0);
+    else ITM_RC(false, false, false, 0);
+#undef ITM_RC_MIRROR
+#undef ITM_RC
     return ITM_OK;
   });
   if (rc) return rc;

@@ -2,7 +2,7 @@
 16 x 16 x 16-block pages hold blocks; pages (4 MB of int16 sdf) come from a pool as blocks are allocated.  The reference's footprint is O(pool)
 (ITMLib/Objects/ITMLocalVBA.h:18-59); the mirror's now is too (rounds 2-3: 17 GB per scene whatever it held).
 
-Here: the footprint on the bench scene, a pool too small for the scene (pages that could not be mapped say nothing: their rays use
+Here: (the dense cube remains the default while the device has 3 x 17 GB to spare: it is the faster form, ray cast 38.3 us against 42.8-43.4.)  The footprint on the bench scene, a pool too small for the scene (pages that could not be mapped say nothing: their rays use
 the block directory, same results), and pages returning to the pool when the cube moves or the scene is reset."""
 import numpy as np
 import pytest
@@ -11,6 +11,12 @@ import itm_testlib as T
 from infinitam_amd import capi
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def paged(monkeypatch):
+    """The paged form is what these tests are about (a device with 3 x 17 GB to spare would pick the dense cube)."""
+    monkeypatch.setenv("ITM_MIRROR", "paged")
 
 PAGE = 16          # blocks per side of a page (ITM_MIRROR_PAGE_BITS = 4)
 
@@ -83,4 +89,4 @@ def test_pages_return_to_the_pool_when_the_cube_moves(hip, oracle):
             assert ses.scene.accel_info()["moves"] >= 3
         ses.close()
     T.compare_results(res[0], res[1], sc, what="paged mirror across cube moves")
-    assert max(mapped) < 192 and min(mapped) > 0
+    assert max(mapped) <= 192 and min(mapped) > 0
