@@ -132,6 +132,7 @@ struct itm_render_state {
   // scratch
   uint4* projBuf = nullptr;    // per visible entry: projected bounding box + z range (2 x uint4)
   uint2* rangePartials = nullptr;  // [32][ceil(w/8)*ceil(h/8)] partial range images (LDS path)
+  uint8_t* rayClass = nullptr;    // uchar[h*w]: reads the last ray cast took per pixel (255: parked); deals the next cast's rays to waves (visualise.hip)
   int32_t* pixScratch = nullptr;  // int[h*w] (forward projection winners, ordered compaction flags)
   int32_t* pixChunk = nullptr;    // int[ceil(h*w / kSweepChunk)]
   uint8_t* viewFlags = nullptr;   // FindVisibleBlocks: per-slot flags (uchar[numChunks * kSweepChunk]), allocated on first use

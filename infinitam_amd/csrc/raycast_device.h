@@ -423,6 +423,9 @@ struct RayParams {
   float oneOverVoxel, mu, voxelSize;
   float lx, ly, lz;         // light source = -(invM column 2)
   int W, H;
+  // per pixel, how many reads the LAST ray cast through this render state took for it (0 .. 254; 255: the ray was parked) -- what the
+  // next ray cast deals its rays to waves by (raycast_kernel); nullptr: rays are dealt in image order
+  uint8_t* rayClass;
 };
 
 // Ray set-up shared by both loops: start point, direction and the [total, totalMax) range in voxel units.
@@ -596,7 +599,8 @@ struct RayResume { float px, py, pz, total; };
 //     "not found" steps in a row; the caller appends it to the queue of the second pass.
 // Per ray the sequence of positions, reads and float operations is that of the reference, whatever the pass structure.
 template <class VX, bool DENSE, int LOOKAHEAD, bool PARK, class VOL = VolumeView>
-__device__ inline float4 march_ray(int x, int y, const VOL& vol, const RayParams& p, float2 mm, const RayResume* resume, bool& parked) {
+__device__ inline float4 march_ray(int x, int y, const VOL& vol, const RayParams& p, float2 mm, const RayResume* resume, bool& parked, int* readsOut = nullptr) {
+  int reads = 0;            // single-voxel and trilinear reads of this call (the ray's length as the next frame's dealing sees it)
   // MARCH: next read is a single voxel; TRI: a single-voxel read found the band, the trilinear read of the same position is
   // due; REFINE: the surface was crossed
   enum : int { MARCH = 0, TRI = 1, REFINE = 2, DONE = 4 };
@@ -726,6 +730,7 @@ __device__ inline float4 march_ray(int x, int y, const VOL& vol, const RayParams
     int budget = ITM_RAY_MARCH_BURST;
     while (st == MARCH && budget > 0) {
       --budget;
+      ++reads;
       ITM_WT(++wtInner;)
       const float readX = px, readY = py, readZ = pz;          // where this read is made (the near-bit skip below needs the cell)
 #if ITM_RAY_NEAR_SKIP == 3
@@ -851,6 +856,7 @@ __device__ inline float4 march_ray(int x, int y, const VOL& vol, const RayParams
     ITM_WT(const unsigned long long wtA = wt_clock(); const unsigned wtTriLanes = __popcll(__ballot(st == TRI || st == REFINE)); wtInner = (unsigned)wt_wave_max(wtInner);)
     // ---- expensive phase: one 2x2x2 fetch for every lane that waits for one ---------------------------------------------
     if (st == TRI || st == REFINE) {
+      ++reads;
       Corners<VX, DENSE> cn;
       cn.fetch(vol, px, py, pz, cache);
       if (st == REFINE) {
@@ -882,6 +888,7 @@ __device__ inline float4 march_ray(int x, int y, const VOL& vol, const RayParams
     if ((threadIdx.x & 63) == 0 && wv < 8192) { unsigned long long* o = g_waveStats + (size_t)wv * 12; o[0] = wtEnd - wtStart; o[1] = mOuter; }
   }
 #endif
+  if (readsOut) *readsOut = reads;
   if (PARK && parked) return make_float4(px, py, pz, total);
   return make_float4(px, py, pz, w);
 }

@@ -436,7 +436,7 @@ static void free_rs(itm_render_state* r) {
   if (r->scene && r->scene->aheadRs == r) const_cast<itm_scene*>(r->scene)->aheadRs = nullptr;
   (void)hipFree(r->range); (void)hipFree(r->raycast); (void)hipFree(r->fwdProj); (void)hipFree(r->missing);
   (void)hipFree(r->image); (void)hipFree(r->visibleIds); (void)hipFree(r->visibleType); (void)hipFree(r->counters);
-  (void)hipFree(r->projBuf); (void)hipFree(r->rangePartials); (void)hipFree(r->pixScratch); (void)hipFree(r->pixChunk); (void)hipFree(r->viewFlags); (void)hipFree(r->viewChunkVis);
+  (void)hipFree(r->projBuf); (void)hipFree(r->rangePartials); (void)hipFree(r->pixScratch); (void)hipFree(r->rayClass); (void)hipFree(r->pixChunk); (void)hipFree(r->viewFlags); (void)hipFree(r->viewChunkVis);
   if (r->sideStream) { (void)hipStreamSynchronize(r->sideStream); (void)hipStreamDestroy(r->sideStream); }
   if (r->listReady) (void)hipEventDestroy(r->listReady);
   if (r->projectionDone) (void)hipEventDestroy(r->projectionDone);
@@ -712,6 +712,7 @@ int itm_render_state_create(const itm_scene* s, int w, int h, itm_render_state**
   alloc((void**)&r->image, P * 4);
   alloc((void**)&r->counters, sizeof(RenderCounters));
   alloc((void**)&r->pixScratch, P * 4);
+  alloc((void**)&r->rayClass, P);
   alloc((void**)&r->pixChunk, ((P + kSweepChunk - 1) / kSweepChunk) * 4 + 16);
   if (r->hash) {
     alloc((void**)&r->visibleIds, (size_t)r->capIds * 4);
@@ -726,6 +727,7 @@ int itm_render_state_create(const itm_scene* s, int w, int h, itm_render_state**
   if (e == hipSuccess) e = hipMemset(r->fwdProj, 0, P * 16);
   if (e == hipSuccess) e = hipMemset(r->missing, 0, P * 4);
   if (e == hipSuccess) e = hipMemset(r->image, 0, P * 4);
+  if (e == hipSuccess) e = hipMemset(r->rayClass, 0, P);
   if (e == hipSuccess && r->hash) e = hipMemset(r->visibleIds, 0, (size_t)r->capIds * 4);
   if (e == hipSuccess && r->hash) e = hipMemset(r->visibleType, 0, (size_t)s->noTotalEntries);
   if (e != hipSuccess) { free_rs(r); return hip_fail(e, "hipMemset(render state)", __FILE__, __LINE__); }

@@ -33,6 +33,7 @@ static inline void make_ray_params(const itm_scene* s, const float* invM, const 
   p.mu = s->prm.mu; p.voxelSize = s->prm.voxelSize;
   p.lx = -invM[8]; p.ly = -invM[9]; p.lz = -invM[10];
   p.W = W; p.H = H;
+  p.rayClass = nullptr;
 }
 
 __device__ inline uchar4 grey_pixel(float angle) {  // drawPixelGrey

@@ -33,6 +33,9 @@ namespace itm {
 #ifndef ITM_MIRROR_FLOAT_TYPES
 #define ITM_MIRROR_FLOAT_TYPES 0     // (scene.hip decides whether a float scene gets a mirror; the same switch must be given to every file)
 #endif
+#ifndef ITM_RAY_SORT_LONG
+#define ITM_RAY_SORT_LONG 9          // reads of the previous frame's ray (in a pixel's 5 x 5 neighbourhood) from which a ray counts as long when the tile's rays are dealt to its waves
+#endif
 #ifndef ITM_MIRROR_STAGE_TABLE
 #define ITM_MIRROR_STAGE_TABLE 0     // 1: every ray-cast workgroup copies the mirror's page table (16 KB) to LDS in its prologue
 #endif
@@ -47,6 +50,7 @@ int g_debug_no_fused_range_reduce = 0;
 int g_debug_single_pass_raycast = 0;
 int g_debug_no_side_projection = 0;
 int g_debug_dense_range_refill = 0;
+int g_debug_no_ray_sort = 0;         // debug key 23: rays are dealt to the waves in image order although the render state has the previous cast's lengths
 
 // ---------------------------------------------------------------------------------------------
 // expected depth range
@@ -375,8 +379,45 @@ __global__ void __launch_bounds__(256) raycast_kernel(VolumeView volIn, const fl
   // pixel waves change nothing.  Both measured)
   const int tilesX = (p.W + 15) / 16;
   const int tx = blockIdx.x % tilesX, ty = blockIdx.x / tilesX;
-  const int x = tx * 16 + (lane & 15);
-  const int y = ty * 16 + wave * 4 + (lane >> 4);
+  // DEALING THE RAYS TO THE WAVES (round 4).  In image order every wave of a silhouette tile holds a few long rays -- past the rim, through
+  // the empty stretch, to the wall -- among its short ones, and lasts as long as they do while its other lanes idle; the launch lasts as
+  // long as those waves.  The previous ray cast through this render state left, per pixel, the number of reads its ray took (p.rayClass;
+  // the camera moves a pixel or two per frame).  A tile's pixels whose 5 x 5 neighbourhood held a long ray then are dealt out FIRST: the
+  // tile's long rays fill its first wave(s), where every lane is in the same phase of its march (the wave-wide look-ahead applies from
+  // the start, no trilinear read of a short neighbour interrupts), and the other waves hold short rays only and are gone early.  Which
+  // lane casts which ray changes nothing about the ray: same positions, same reads, same result, written to the ray's own pixel.
+  int lx = lane & 15, ly = wave * 4 + (lane >> 4);
+  __shared__ uint8_t prevClass[20 * 20];
+  __shared__ uint8_t dealt[256];
+  __shared__ int longInWave[4];
+  const bool sortRays = p.rayClass != nullptr;
+  if (sortRays) {
+    for (int i = threadIdx.x; i < 400; i += 256) {
+      const int gx = tx * 16 - 2 + i % 20, gy = ty * 16 - 2 + i / 20;
+      prevClass[i] = (gx >= 0 && gx < p.W && gy >= 0 && gy < p.H) ? p.rayClass[gx + gy * p.W] : (uint8_t)0;
+    }
+    __syncthreads();
+    int worst = 0;
+#pragma unroll
+    for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 5; ++dx) worst = max(worst, (int)prevClass[(ly + dy) * 20 + lx + dx]);
+    const bool isLong = worst >= ITM_RAY_SORT_LONG && tx * 16 + lx < p.W && ty * 16 + ly < p.H;
+    const unsigned long long b = __ballot(isLong);
+    if (lane == 0) longInWave[wave] = __popcll(b);
+    __syncthreads();
+    int longBefore = 0, longAll = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { const int c = longInWave[w]; longAll += c; if (w < wave) longBefore += c; }
+    const int below = __popcll(b & ((1ull << lane) - 1ull));
+    const int pos = isLong ? longBefore + below : longAll + (wave * 64 - longBefore) + (lane - below);
+    dealt[pos] = (uint8_t)(ly * 16 + lx);
+    __syncthreads();
+    const int mine = dealt[threadIdx.x];
+    lx = mine & 15; ly = mine >> 4;
+  }
+  const int x = tx * 16 + lx;
+  const int y = ty * 16 + ly;
   const bool inside = x < p.W && y < p.H;
   __shared__ float2 cellRange[4];
   __shared__ float4 parkState[PARK ? 256 : 1];   // (px, py, pz, total) of a parked ray
@@ -388,7 +429,7 @@ __global__ void __launch_bounds__(256) raycast_kernel(VolumeView volIn, const fl
   if constexpr (REDUCE) {
     reduce_own_cells(fuse, tx, ty, p.W, cellRange);
     __syncthreads();
-    if (inside) mm = cellRange[((lane & 15) >> 3) + 2 * (wave >> 1)];
+    if (inside) mm = cellRange[(lx >> 3) + 2 * (ly >> 3)];
   } else {
     if (PARK || kStageTable) __syncthreads();
     if (inside) mm = range[(x >> 3) + (y >> 3) * p.W];  // floor(x/8) + floor(y/8)*W  (_CPU.cpp:174)
@@ -402,13 +443,15 @@ __global__ void __launch_bounds__(256) raycast_kernel(VolumeView volIn, const fl
   // ---- phase 1: every ray of the tile; rays that turn out to be crossing empty space are parked ----
   bool parked = false;
   if (inside) {
-    const float4 r = march_ray<VX, DENSE, DENSE ? ITM_RAY_DENSE_LOOKAHEAD : 0, PARK>(x, y, vol, p, mm, nullptr, parked);
+    int reads = 0;
+    const float4 r = march_ray<VX, DENSE, DENSE ? ITM_RAY_DENSE_LOOKAHEAD : 0, PARK>(x, y, vol, p, mm, nullptr, parked, &reads);
     if (!parked) out[x + y * p.W] = r;
     else if constexpr (PARK) {
       const int slot = atomicAdd(&parkCount, 1);
       parkState[slot] = r;
-      parkSource[slot] = (int)threadIdx.x;
+      parkSource[slot] = ly * 16 + lx;           // the pixel of the tile the ray belongs to
     }
+    if (sortRays) p.rayClass[x + y * p.W] = (uint8_t)(parked ? 255 : min(reads, 254));
   }
   ITM_RS(if (lane == 0) { stamp[2] = __builtin_amdgcn_s_memrealtime(); stamp[3] = 0; })
   if constexpr (PARK) {
@@ -418,10 +461,9 @@ __global__ void __launch_bounds__(256) raycast_kernel(VolumeView volIn, const fl
     if ((int)threadIdx.x < n) {
       const float4 q = parkState[threadIdx.x];
       const int src = parkSource[threadIdx.x];
-      const int sl = src & 63, sw = src >> 6;
-      const int qx = tx * 16 + (sl & 15), qy = ty * 16 + sw * 4 + (sl >> 4);
+      const int qx = tx * 16 + (src & 15), qy = ty * 16 + (src >> 4);
       float2 m2;
-      if constexpr (REDUCE) m2 = cellRange[((sl & 15) >> 3) + 2 * (sw >> 1)];
+      if constexpr (REDUCE) m2 = cellRange[((src & 15) >> 3) + 2 * (src >> 7)];
       else m2 = range[(qx >> 3) + (qy >> 3) * p.W];
       const RayResume rr{q.x, q.y, q.z, q.w};
       bool again;
@@ -436,6 +478,7 @@ extern "C" int itm_debug_read_raycast_stamps(unsigned long long* dst, int n) { r
 
 int launch_raycast(const itm_scene* s, const float* invM, const float* intr, itm_render_state* rs, float4* dst, hipStream_t st, bool reduceRange, const AheadRequest* aheadIn) {
   RayParams p; make_ray_params(s, invM, intr, rs->w, rs->h, p);
+  p.rayClass = g_debug_no_ray_sort ? nullptr : rs->rayClass;
   const VolumeView vol = make_volume(s);
   const int rayTiles = ((rs->w + 15) / 16) * ((rs->h + 15) / 16);
   const bool dense = s->cfg.indexType == ITM_INDEX_DENSE;
@@ -649,6 +692,7 @@ int itm_debug_set(int key, int value) {
   if (key == ITM_DEBUG_DENSE_CLASSIFY) { g_debug_dense_classify = value; return ITM_OK; }
   if (key == ITM_DEBUG_TRACKER_SESSION_UNUSABLE) { g_debug_tracker_session_unusable = value; return ITM_OK; }
   if (key == ITM_DEBUG_DENSE_NO_STRIPS) { g_debug_dense_no_strips = value; return ITM_OK; }
+  if (key == ITM_DEBUG_NO_RAY_SORT) { g_debug_no_ray_sort = value; return ITM_OK; }
   if (key == ITM_DEBUG_INTEGRATE_BLOCK_PER_WAVE) { g_debug_integrate_block_per_wave = value; return ITM_OK; }
   if (key == ITM_DEBUG_NO_NEAR_BITS) { g_debug_no_near_bits = value; return ITM_OK; }
   if (key == ITM_DEBUG_NO_DEFERRED_FUSION) { g_debug_no_deferred_fusion = value; return ITM_OK; }

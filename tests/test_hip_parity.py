@@ -392,3 +392,22 @@ def test_hash_integration_a_block_per_wave_and_the_slice_kernel(hip, oracle, vox
                     T.compare_results(a, b, sc, what="%s/%s/%s" % (sc.name, "block per wave" if key else "slices", fused))
             finally:
                 hip.check(hip.fn["debug_set"](22, 0), "debug_set")
+
+
+@pytest.mark.parametrize("sc", [Scenario(name="deal_bench", voxelSize=0.004, localBlockNum=0x40000, frames=5, trajectory="bench"),
+                                Scenario(name="deal_yaw_ragged", w=333, h=211, voxelSize=0.006, frames=5, trajectory="yaw"),
+                                Scenario(name="deal_dense", indexType=capi.INDEX_DENSE, denseSize=(128, 128, 128), denseOffset=(-64, -64, 100), voxelSize=0.01, w=320, h=240, frames=4)],
+                         ids=lambda s: s.name)
+def test_rays_dealt_by_the_previous_casts_lengths_or_in_image_order(hip, oracle, sc):
+    """The ray cast deals a tile's rays to its waves long rays first, by the number of reads the previous cast through the render state
+    took per pixel (raycast_kernel); ITM_DEBUG_NO_RAY_SORT (23) deals them in image order.  Which lane casts a ray changes nothing
+    about the ray: both against the oracle, over several frames (the first frame has no history), ragged image sizes included."""
+    b = T.run_scenario(oracle, sc)
+    a = T.run_scenario(hip, sc, fused="four")
+    T.compare_results(a, b, sc, what=sc.name + "/long rays first")
+    hip.check(hip.fn["debug_set"](23, 1), "debug_set")
+    try:
+        a = T.run_scenario(hip, sc, fused="four")
+    finally:
+        hip.check(hip.fn["debug_set"](23, 0), "debug_set")
+    T.compare_results(a, b, sc, what=sc.name + "/image order")

@@ -64,7 +64,7 @@ def expected_near_bits(hash_entries, origin, reach=7, side=256):
 
 def check_bits(scene, what):
     info = scene.accel_info()
-    assert info["near_bits_bytes"] == 256 ** 3 and info["mirror_pages_mapped"] > 0, info
+    assert info["near_bits_bytes"] == 256 ** 3 and info["mirror_bytes"] > 0, info
     got = scene.download(capi.BUF_NEAR_BITS).reshape(256, 256, 256)
     want = expected_near_bits(scene.download(capi.BUF_HASH_ENTRIES), info["origin_mirror"])
     bad = np.argwhere(got != want)
