@@ -202,7 +202,7 @@ int ITM_FN(set_device)(int device);
 #define ITM_DEBUG_FORCE_LIST_STUCK 20           /* AllocateSceneFromDepth, one-launch visible list: chunk n - 1 behaves as if its bounded wait for another workgroup had expired (0 = off): the scene must raise statusFlags bit 1 and refuse further calls */
 #define ITM_DEBUG_NO_NEAR_BITS 21               /* ray casting: every position is read although the near bits prove some empty; set before itm_scene_create: none are allocated */
 #define ITM_DEBUG_INTEGRATE_BLOCK_PER_WAVE 22   /* hash integration: 16 bytes per lane, a whole block per wave, instead of one voxel per lane and four z-slices per wave (measured slower on every configuration, profiles/r4_integrate_notes.md; kept with its parity test) */
-#define ITM_DEBUG_NO_RAY_SORT 23                /* ray casting: a tile's rays are dealt to its waves in image order, not long rays first (the lengths are still recorded) */
+#define ITM_DEBUG_NO_RAY_SORT 23                /* measurement builds with -DITM_RAY_SORT=1 only (a tile's rays dealt to its waves long rays first, by the previous cast's read counts: slower, off): deal in image order */
 int ITM_FN(debug_set)(int key, int value);
 /* dense integration, check mode of key 16: {free groups, shadow groups, mixed groups, violations}; reset != 0 clears */
 int ITM_FN(debug_dense_classify_check)(int32_t out[4], int reset);

@@ -33,6 +33,9 @@ namespace itm {
 #ifndef ITM_MIRROR_FLOAT_TYPES
 #define ITM_MIRROR_FLOAT_TYPES 0     // (scene.hip decides whether a float scene gets a mirror; the same switch must be given to every file)
 #endif
+#ifndef ITM_RAY_SORT
+#define ITM_RAY_SORT 0
+#endif
 #ifndef ITM_RAY_SORT_LONG
 #define ITM_RAY_SORT_LONG 9          // reads of the previous frame's ray (in a pixel's 5 x 5 neighbourhood) from which a ray counts as long when the tile's rays are dealt to its waves
 #endif
@@ -379,7 +382,10 @@ __global__ void __launch_bounds__(256) raycast_kernel(VolumeView volIn, const fl
   // pixel waves change nothing.  Both measured)
   const int tilesX = (p.W + 15) / 16;
   const int tx = blockIdx.x % tilesX, ty = blockIdx.x / tilesX;
-  // DEALING THE RAYS TO THE WAVES (round 4).  In image order every wave of a silhouette tile holds a few long rays -- past the rim, through
+  // DEALING THE RAYS TO THE WAVES (round 4; MEASUREMENT BUILDS ONLY, -DITM_RAY_SORT=1: bit-exact, and slower -- BASELINE configs[1]
+  // 37.8-39.3 -> 40.3-40.4 us, configs[4] 123.6 -> 129.7, configs[2] +-0, profiles/r4_raycast_notes.md section 3: the long rays'
+  // chains are as long in a wave of their own, the short waves lose their image-order locality, and the prologue is paid by every tile).
+  // In image order every wave of a silhouette tile holds a few long rays -- past the rim, through
   // the empty stretch, to the wall -- among its short ones, and lasts as long as they do while its other lanes idle; the launch lasts as
   // long as those waves.  The previous ray cast through this render state left, per pixel, the number of reads its ray took (p.rayClass;
   // the camera moves a pixel or two per frame).  A tile's pixels whose 5 x 5 neighbourhood held a long ray then are dealt out FIRST: the
@@ -390,7 +396,7 @@ __global__ void __launch_bounds__(256) raycast_kernel(VolumeView volIn, const fl
   __shared__ uint8_t prevClass[20 * 20];
   __shared__ uint8_t dealt[256];
   __shared__ int longInWave[4];
-  const bool sortRays = p.rayClass != nullptr;
+  const bool sortRays = ITM_RAY_SORT && p.rayClass != nullptr;
   if (sortRays) {
     for (int i = threadIdx.x; i < 400; i += 256) {
       const int gx = tx * 16 - 2 + i % 20, gy = ty * 16 - 2 + i / 20;
@@ -478,7 +484,7 @@ extern "C" int itm_debug_read_raycast_stamps(unsigned long long* dst, int n) { r
 
 int launch_raycast(const itm_scene* s, const float* invM, const float* intr, itm_render_state* rs, float4* dst, hipStream_t st, bool reduceRange, const AheadRequest* aheadIn) {
   RayParams p; make_ray_params(s, invM, intr, rs->w, rs->h, p);
-  p.rayClass = g_debug_no_ray_sort ? nullptr : rs->rayClass;
+  p.rayClass = (ITM_RAY_SORT && !g_debug_no_ray_sort) ? rs->rayClass : nullptr;
   const VolumeView vol = make_volume(s);
   const int rayTiles = ((rs->w + 15) / 16) * ((rs->h + 15) / 16);
   const bool dense = s->cfg.indexType == ITM_INDEX_DENSE;

@@ -399,9 +399,11 @@ def test_hash_integration_a_block_per_wave_and_the_slice_kernel(hip, oracle, vox
                                 Scenario(name="deal_dense", indexType=capi.INDEX_DENSE, denseSize=(128, 128, 128), denseOffset=(-64, -64, 100), voxelSize=0.01, w=320, h=240, frames=4)],
                          ids=lambda s: s.name)
 def test_rays_dealt_by_the_previous_casts_lengths_or_in_image_order(hip, oracle, sc):
-    """The ray cast deals a tile's rays to its waves long rays first, by the number of reads the previous cast through the render state
-    took per pixel (raycast_kernel); ITM_DEBUG_NO_RAY_SORT (23) deals them in image order.  Which lane casts a ray changes nothing
-    about the ray: both against the oracle, over several frames (the first frame has no history), ragged image sizes included."""
+    """A measurement build (-DITM_RAY_SORT=1, ITM_TEST_LIB=...) deals a tile's rays to its waves long rays first, by the number of reads the
+    previous cast through the render state took per pixel (raycast_kernel); ITM_DEBUG_NO_RAY_SORT (23) deals them in image order.  Which
+    lane casts a ray changes nothing about the ray: both against the oracle, over several frames (the first frame has no history), ragged
+    image sizes included.  (Green on the GPU with the dealing compiled in; it was slower and is compiled out of the product, where both
+    runs below cast in image order.)"""
     b = T.run_scenario(oracle, sc)
     a = T.run_scenario(hip, sc, fused="four")
     T.compare_results(a, b, sc, what=sc.name + "/long rays first")
