@@ -196,6 +196,7 @@ __global__ void __launch_bounds__(256) allocate_sweep_kernel(uint32_t* __restric
                                                              uint32_t* __restrict__ headBits, int32_t* __restrict__ dirPtr, int32_t* __restrict__ dirSlot, void* __restrict__ sdfMirror,
                                                              const float* __restrict__ depth, int lazy, AllocParams p, uint32_t* __restrict__ nearWords) {
   __shared__ int lds[8];
+#if ITM_NEAR_BITS
   __shared__ NewBlocks fresh;
   sweep_chunk<false>((int)blockIdx.x, lds, allocKey, chunkReq, chunkReqNext, numChunks, hash, excessList, allocList, visT, counters, headBits, dirPtr, dirSlot, sdfMirror, depth, lazy, p,
                      nearWords ? &fresh : nullptr);
@@ -203,6 +204,10 @@ __global__ void __launch_bounds__(256) allocate_sweep_kernel(uint32_t* __restric
     __syncthreads();
     splat_new_blocks(&fresh, nearWords, p.org);
   }
+#else
+  (void)nearWords;
+  sweep_chunk<false>((int)blockIdx.x, lds, allocKey, chunkReq, chunkReqNext, numChunks, hash, excessList, allocList, visT, counters, headBits, dirPtr, dirSlot, sdfMirror, depth, lazy, p, nullptr);
+#endif
 }
 
 // checkBlockVisibility<false>: corners are reached by incremental +-f updates in a fixed order.
@@ -355,7 +360,6 @@ struct SweepArgs {
   uint32_t* allocKey; int2* chunkReqNext; const int32_t* excessList; const int32_t* allocList; uint32_t* headBits;
   int32_t* dirPtr; int32_t* dirSlot; void* sdfMirror; const float* depth; int lazy;
   uint32_t* sweepDone;     // per chunk: the epoch of the launch whose sweep has placed the chunk's excess allocations
-  uint32_t* sweepClaim;    // per chunk of the excess region: the epoch of the launch in which a workgroup took on the chunk's sweep (below)
   int32_t* fatalDev;       // the scene's host-visible status word (alloc_device.h: raise_fatal)
   int forceStuck;          // test hook (debug key 20): chunk whose wait is treated as expired, or -1
   uint32_t* nearWords;     // near bits of the mirror's cube (itm_types.h), or nullptr
@@ -372,19 +376,19 @@ extern "C" int itm_debug_read_list_stamps(unsigned long long* dst, int n) { retu
 #define ITM_LS(k)
 #endif
 
-// WHO WAITS FOR WHOM.  A workgroup of this launch may only wait for work that a RUNNING workgroup has taken on: then nothing it
-// waits for can be stuck behind it, whatever share of the device the launch gets (masked compute units, other processes, time-sliced
-// queues) -- workgroups are dispatched in index order and a dispatched workgroup runs to its end.  The look-back has that shape by
-// itself: chunk c waits for chunks < c.  So do the stamps of ordered-region chunks, which only excess-region chunks -- all behind
-// them -- wait for.  The stamps of EXCESS-region chunks did not: excess-region chunk c waits for the sweep of every chunk with excess
-// requests, and such a chunk may lie behind c (a request whose chain tail is an excess entry).  Therefore the sweep of an
-// excess-region chunk is not tied to "its" workgroup: whoever needs it first CLAIMS it (an atomic exchange of the launch's epoch into
-// sweepClaim[j]) and does it -- its own workgroup when that gets there first, which is the usual case and costs one atomic per chunk
-// with requests; an excess-region workgroup that finds another excess-region chunk with requests unclaimed sweeps that chunk too
-// instead of waiting for a workgroup that may not have been dispatched.  A stamp is then only ever awaited from a workgroup that is
-// running.  The waits stay bounded all the same; one that does expire means a device that no longer runs what it was given, and is
-// fatal for the scene (statusFlags bit 1, ITM_ERR_DEVICE at the next call; the frame's list is marked invalid and the integration
-// fuses nothing through it).
+// WHO WAITS FOR WHOM, AND WHEN THAT IS SAFE.  The look-back waits for lower-numbered chunks only; workgroups are dispatched in index order
+// and run to their end, so that wait cannot be stuck behind the waiter.  The stamps are different: an excess-region chunk waits for the
+// sweep of EVERY chunk with excess requests, and such a chunk may lie behind it in the excess region (a request whose chain tail is an
+// excess entry) -- safe only while all workgroups of the launch are resident TOGETHER.  That is a property of the device, and it is
+// checked, not assumed: one_pass_list_is_safe() asks the runtime how many workgroups of this kernel a compute unit holds
+// (hipOccupancyMaxActiveBlocksPerMultiprocessor) and takes this launch only if units x that covers the grid -- a partitioned or masked
+// device gets the launches that never wait (separate sweep, count, compaction), like a device shared by several scenes.  The waits
+// stay bounded all the same; one that does expire (another PROCESS holding the compute units) is fatal for the scene: statusFlags
+// bit 1, ITM_ERR_DEVICE at the next call, the frame's list marked invalid and nothing fused through it -- never a silently dropped frame.
+// (Round 4 also built the two shapes that make every wait target running work by construction -- 64 extra workgroups at the head of the
+// grid that sweep the excess region, and sweeps of the excess region CLAIMED by whoever needs them first -- and measured them at
+// +1.5 us and +5.5 us per frame on BASELINE configs[1]: the loop around the sweep that the claim needs makes the compiler drain the
+// early loads before it, 13.2 -> 19.3 us.  profiles/r4_integrate_notes.md.)
 template <bool COMMIT_ALLOC, bool LAZY, bool SWEEP>
 __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__ visT, uint4* __restrict__ hash,
                                                            unsigned long long* __restrict__ chunkGran, uint32_t epoch,
@@ -392,8 +396,12 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
                                                            int32_t* __restrict__ ids, int capIds, RenderCounters* __restrict__ rc, AllocParams p, SweepArgs sw) {
   __shared__ int lds[12];
   __shared__ int sweepLds[8];
+#if ITM_NEAR_BITS
   __shared__ NewBlocks fresh;
   NewBlocks* const freshPtr = (SWEEP && sw.nearWords) ? &fresh : nullptr;
+#else
+  NewBlocks* const freshPtr = nullptr;       // (builds without near bits, the default: no 16 KB queue in LDS)
+#endif
   const int tid = threadIdx.x;
   // the chunk's stores must have COMPLETED before its stamp may follow: on gfx950 a workgroup-scope release fence is only
   // s_waitcnt lgkmcnt(0) -- it does not wait for vector stores -- so the wait is spelled out (loads and stores share vmcnt);
@@ -443,56 +451,14 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
     }
   }
   if constexpr (SWEEP) {
-    // ONE call site of sweep_chunk (a second inlined copy doubles the kernel's registers: 122 -> 200 VGPRs plus spills, and the 576
-    // workgroups are no longer resident together): a loop whose first round is the workgroup's own chunk and whose further rounds --
-    // excess-region workgroups only, and nearly never -- are other excess-region chunks that have requests and no taker yet.
-    __shared__ int claimWon;
-    __shared__ unsigned long long wanted;
-    const int firstExcess = p.bucketNum / kSweepChunk;
-    int j = chunk, j0 = firstExcess - 64;
-    unsigned long long left = 0;
-    for (bool own = true;; own = false) {
-      bool go = own ? chunkReq[chunk].x > 0 : true;            // (uniform)
-      if (own && !go && tid == 0) sw.chunkReqNext[chunk] = make_int2(0, 0);
-      if (go && excessRegion) {
-        // the sweep of an excess-region chunk belongs to whoever claims it first (see above)
-        __syncthreads();
-        if (tid == 0) claimWon = atomicExch(&sw.sweepClaim[j], epoch) != epoch;
-        __syncthreads();
-        go = claimWon != 0;
-      }
-      if (go) {
-        sweep_chunk<true>(j, sweepLds, sw.allocKey, chunkReq, sw.chunkReqNext, numChunks, hash, sw.excessList, sw.allocList, visT, counters, sw.headBits,
-                          sw.dirPtr, sw.dirSlot, sw.sdfMirror, sw.depth, sw.lazy, p, freshPtr);
-        if (chunkReq[j].y > 0) {                               // (uniform) only excess allocations are read by other workgroups of this launch
-          stamp_sweep(j);
-          if (excessRegion && freshPtr) splat_new_blocks(freshPtr, sw.nearWords, p.org);      // (behind the stamp's barrier; the queue is reused by the next round)
-        }
-      }
-      if (!excessRegion) break;
-      // the next excess-region chunk with requests, other than this workgroup's own: one load per lane, 64 chunks per look
-      while (!left) {
-        j0 += 64;
-        if (j0 >= numChunks) break;
-        __syncthreads();
-        if (tid < 64) {
-          const int c = j0 + tid;
-          const unsigned long long m = __ballot(c < numChunks && c != chunk && chunkReq[c < numChunks ? c : chunk].y > 0);
-          if (tid == 0) wanted = m;
-        }
-        __syncthreads();
-        left = wanted;
-      }
-      if (!left) break;
-      j = j0 + (int)__builtin_ctzll(left);
-      left &= left - 1;
-    }
+    sweep_chunk<true>(chunk, sweepLds, sw.allocKey, chunkReq, sw.chunkReqNext, numChunks, hash, sw.excessList, sw.allocList, visT, counters, sw.headBits,
+                      sw.dirPtr, sw.dirSlot, sw.sdfMirror, sw.depth, sw.lazy, p, freshPtr);
+    if (chunkReq[chunk].y > 0) stamp_sweep(chunk);           // (uniform) only excess allocations are read by other workgroups of this launch
     if (excessRegion) {
-      // every chunk that had excess requests must be through: the ordered-region ones run in front of this workgroup, the excess-region
-      // ones have all been claimed by now -- by a workgroup that is running
-      for (int c = tid; c < numChunks; c += 256) {
-        if (chunkReq[c].y <= 0) continue;
-        for (int spin = 0; __hip_atomic_load(&sw.sweepDone[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch; ++spin) {
+      // every chunk that had excess requests (any index: no sweep waits for anything, so this cannot cycle) must be through
+      for (int j = tid; j < numChunks; j += 256) {
+        if (chunkReq[j].y <= 0 || j == chunk) continue;
+        for (int spin = 0; __hip_atomic_load(&sw.sweepDone[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch; ++spin) {
           if (spin > (1 << 22)) { stuck = true; break; }
           __builtin_amdgcn_s_sleep(1);
         }
@@ -557,7 +523,7 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
   if constexpr (SWEEP) {
     // the chunk's count is out: the near bits of the blocks its sweep allocated, while the look-back would only wait (block_exclusive_scan
     // above was the barrier behind the sweep)
-    if (freshPtr && !excessRegion && chunkReq[chunk].x > 0) splat_new_blocks(freshPtr, sw.nearWords, p.org);
+    if (freshPtr && chunkReq[chunk].x > 0) splat_new_blocks(freshPtr, sw.nearWords, p.org);
   }
   // base = visible slots in all earlier chunks
   look_back();
@@ -618,11 +584,24 @@ __global__ void __launch_bounds__(256) freeview_flag_kernel(const uint4* __restr
 }
 
 // Is this scene alone on its device?  (scene.hip keeps the count of live hash scenes.)
+// ... and can all workgroups of the one-launch list be resident on it together?  (Asked of the runtime once per device and grid size:
+// workgroups a compute unit holds of visible_list_kernel<true, true, true> x compute units >= the grid.)
+static bool list_grid_is_resident(const itm_scene* s) {
+  static int answer[64] = {};                  // per device: 0 unknown, chunks + 1 that fit
+  const int dev = (s->device >= 0 && s->device < 64) ? s->device : 0;
+  if (!answer[dev]) {
+    int perCu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, (const void*)visible_list_kernel<true, true, true>, 256, 0) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); perCu = 0; cus = 0; }
+    answer[dev] = perCu * cus + 1;
+  }
+  return answer[dev] - 1 >= s->numChunks;
+}
 static bool one_pass_list_is_safe(const itm_scene* s) {
   static const int forced = [] { const char* e = getenv("ITM_ONE_PASS_LIST"); return e ? atoi(e) : -1; }();      // A/B: 1 = always, 0 = never
   if (s->cfg.useSwapping) return false;        // the swapping hooks live in the separate launches
   if (forced >= 0) return forced != 0;
-  return live_hash_scenes(s->device) <= 1;
+  return live_hash_scenes(s->device) <= 1 && list_grid_is_resident(s);
 }
 
 static int fill_params(const itm_scene* s, const float* M, const float* intr, int W, int H, int capIds, AllocParams& p) {
@@ -759,7 +738,7 @@ int launch_sweep_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, bo
   if (onePass) {
     const uint32_t epoch = ++s->listEpoch;
     const SweepArgs sw{s->allocKey, reqNext, s->excessList, s->allocList, s->headBits, s->dirPtr, s->dirSlot, s->sdfMirror, v->depth, lazy ? 1 : 0, s->chunkSweepDone,
-                       s->chunkSweepClaim, s->fatalDev, fusedSweep ? g_debug_force_list_stuck - 1 : -1, s->nearBits};
+                       s->fatalDev, fusedSweep ? g_debug_force_list_stuck - 1 : -1, s->nearBits};
 #define ITM_VL(CM, LZ, SW) visible_list_kernel<CM, LZ, SW><<<nChunks, 256, 0, st>>>(rs->visibleType, s->hash, s->chunkGran, epoch, reqCur, nChunks, s->counters, rs->visibleIds, rs->capIds, rs->counters, p, sw)
     if (onlyVisible) { if (lazy) ITM_VL(false, true, false); else ITM_VL(false, false, false); }
     else if (fusedSweep) { if (lazy) ITM_VL(true, true, true); else ITM_VL(true, false, true); }

@@ -394,6 +394,11 @@ __device__ inline void mirror_init_block(void* __restrict__ mirror, bool floatSd
 }
 
 // ---- near bits ----------------------------------------------------------------------------------
+// (MEASUREMENT BUILDS ONLY: the whole library built with -DITM_NEAR_BITS=1, tools/build_full_variant.sh, and ITM_NEAR_BITS=1 in the environment
+// when the scene is created.  Built for VERDICT r3 item 4, bit-exact, slower in every form: profiles/r4_raycast_notes.md section 1.)
+#ifndef ITM_NEAR_BITS
+#define ITM_NEAR_BITS 0
+#endif
 // One byte per cell of the mirror's cube (256^3 cells = 16 MB, x fastest like the mirror): bit k is set iff a voxel block has been
 // allocated at Chebyshev distance <= k (in blocks) from the cell, k = 0 .. 7.  The lowest set bit m of a cell says that every block
 // closer than m to it is unallocated (no bit set: closer than 8).  What the ray caster does with it (raycast_device.h): the reference's

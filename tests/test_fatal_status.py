@@ -1,9 +1,9 @@
 """Conditions after which a scene is not what the reference would hold are FATAL, and loud.
 
 The reference never drops a frame (DeviceSpecific/CPU/ITMSceneReconstructionEngine_CPU.cpp:229-290 always builds its list, :47-114
-always fuses through it).  The product's one-launch visible list hands counts from workgroup to workgroup; its waits only ever target
-workgroups with a lower index (dispatched earlier, hence resident or done: alloc.hip) and are bounded all the same.  A wait that does
-expire -- or a depth pixel with more ray steps than the allocation key can number -- raises itm_counters::statusFlags in device memory
+always fuses through it).  The product's one-launch visible list hands counts from workgroup to workgroup; it is only taken on a device
+that holds all its workgroups at once (asked of the runtime: alloc.hip, one_pass_list_is_safe) and its waits are bounded all the same.  A
+wait that does expire -- or a depth pixel with more ray steps than the allocation key can number -- raises itm_counters::statusFlags in device memory
 AND in a word of page-locked host memory every entry point reads: from then on every call that names the scene fails with
 ITM_ERR_DEVICE until ResetScene, instead of silently continuing with a scene the reference can never be in."""
 import numpy as np
@@ -64,9 +64,9 @@ def test_more_ray_steps_than_the_key_can_number_is_fatal(hip):
 @pytest.mark.parametrize("sc", [T.Scenario(name="early_sweeps_tiny_table", frames=5, bucketNum=0x1000, excessNum=0x1000, w=320, h=240, voxelSize=0.01, trajectory="yaw"),
                                 T.Scenario(name="early_sweeps_chains_of_chains", frames=4, bucketNum=0x800, excessNum=0x4000, w=320, h=240, voxelSize=0.008, trajectory="yaw")],
                          ids=lambda s: s.name)
-def test_excess_region_chunks_are_swept_by_the_workgroups_in_front(hip, oracle, sc):
-    """Tables so small that most requests hang off excess entries (chain tails IN the excess region): the sweeps of the excess-region
-    chunks run in the early workgroups of the visible-list launch, every stamp a chunk waits for is written in front of it."""
+def test_excess_region_chunks_wait_for_each_others_sweeps(hip, oracle, sc):
+    """Tables so small that most requests hang off excess entries (chain tails IN the excess region): the workgroups of the excess region
+    wait for the stamps of each other's sweeps -- the one wait of the launch that is not a look-back."""
     a = T.run_scenario(hip, sc, fused="four")
     b = T.run_scenario(oracle, sc)
     T.compare_results(a, b, sc, what=sc.name)

@@ -76,6 +76,13 @@ def check_bits(scene, what):
 def near_bits_on(monkeypatch):
     """Scenes only carry near bits when asked to (a measurement feature: the skip lost, profiles/r4_raycast_notes.md)."""
     monkeypatch.setenv("ITM_NEAR_BITS", "1")
+    import itm_testlib
+    be = itm_testlib.hip_backend()
+    s = be.create_scene(capi.VOXEL_S, capi.INDEX_HASH, capi.default_params())
+    have = s.accel_info()["near_bits_bytes"] > 0
+    s.close()
+    if not have:
+        pytest.skip("library built without near bits (the default: -DITM_NEAR_BITS=1 is a measurement build, tools/build_full_variant.sh)")
 
 
 @pytest.mark.gpu
