@@ -530,11 +530,18 @@ def worker(args) -> int:
         s0 = streams[0]
         n2 = max(args.steps, 100)
 
+        def fresh():
+            """Every leg starts where the timed region started: a reset scene + the same warm-up (what a frame costs depends on the
+            scene's state -- config 3's dense integration gets cheaper once weights saturate and stop integrating)."""
+            for s_ in streams:
+                s_.scene.reco.ResetScene(stream=(s_.hip_stream.cuda_stream if s_.hip_stream is not None else None))
+
         def leg(call):
-            """The same frames through another entry point: warm-up, then n2 frames between two synchronisations."""
+            """The same frames through another entry point: reset, warm-up, then n2 frames between two synchronisations."""
             was = mode["call"]
             mode["call"] = call
-            run(0, min(args.warmup, 20)); sync()
+            fresh()
+            run(0, args.warmup); sync()
             t1 = time.perf_counter()
             run(args.warmup, args.warmup + n2); sync()
             dt = time.perf_counter() - t1
@@ -554,6 +561,7 @@ def worker(args) -> int:
         #     (convertDepthAffineToFloat) inside the timed region
         s0.enable_raw()
         mode["raw"] = True
+        fresh()
         run(0, args.warmup); sync()
         t1 = time.perf_counter()
         run(args.warmup, args.warmup + n2); sync()
@@ -566,6 +574,7 @@ def worker(args) -> int:
         if wl["index"] == "hash":
             for key in (1, 2):                 # ITM_DEBUG_NO_DIRECTORY, ITM_DEBUG_NO_SDF_MIRROR
                 be.check(be.fn["debug_set"](DEBUG_KEYS_FALLBACK[key], 1), "debug_set")
+            fresh()
             run(0, args.warmup); sync()
             s0.scene.profile_read(reset=True)
             s0.scene.profile_enable(1 << timed_kernel)
