@@ -225,6 +225,10 @@ constexpr int kSlices = ITM_INTEGRATE_SLICES;
 constexpr int kItemsPerBlock = kBlockSide / kSlices;
 static_assert(kSlices == 1 || kSlices == 2 || kSlices == 4 || kSlices == 8, "slice groups tile the block");
 
+#ifndef ITM_INTEGRATE_NT
+// bit 0: the 4-byte voxels, bit 1: the mirror values are stored with the non-temporal hint (measurement switch)
+#define ITM_INTEGRATE_NT 0
+#endif
 #ifndef ITM_INTEGRATE_PREFETCH
 // 1: the voxel runs of the wave's NEXT item are requested right behind the depth gathers of the current one.  Measured: BASELINE
 // configs[4] 189 -> 198 us (the second register set costs a wave of occupancy, 76 -> 92 VGPRs), configs[1] +-0.  Off.
@@ -285,8 +289,19 @@ __device__ inline void integrate_item(const HashEntry& he, int z0, int lane, typ
       }
     }
     if (touched) {
+#if ITM_INTEGRATE_NT & 1
+      if constexpr (VX::kBytes == 4) __builtin_nontemporal_store(r[k], (uint32_t*)vba + vi + 64 * k); else VX::store(vba, vi + 64 * k, r[k]);
+#else
       VX::store(vba, vi + 64 * k, r[k]);
-      if (mirror) mirror[mbase + mirror_block_voxel((uint32_t)x, (uint32_t)y, (uint32_t)(z0 + k))] = MC::of(VX::raw_sdf(r[k]));   // sdf mirror (itm_types.h)
+#endif
+      if (mirror) {
+        typename MC::T* const at = mirror + mbase + mirror_block_voxel((uint32_t)x, (uint32_t)y, (uint32_t)(z0 + k));     // sdf mirror (itm_types.h)
+#if ITM_INTEGRATE_NT & 2
+        __builtin_nontemporal_store(MC::of(VX::raw_sdf(r[k])), at);
+#else
+        *at = MC::of(VX::raw_sdf(r[k]));
+#endif
+      }
     }
   }
 }

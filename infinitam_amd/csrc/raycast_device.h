@@ -19,7 +19,9 @@
 #define ITM_RAY_WHILE_WHILE 1   // 0: the plain loop in the reference's order (baseline for measurements)
 #endif
 #ifndef ITM_RAY_MARCH_BURST
-#define ITM_RAY_MARCH_BURST 4   // cheap steps a lane may take before the wave serves the lanes waiting for a trilinear read
+// cheap steps a lane may take before the wave serves the lanes waiting for a trilinear read.  Round 4 (final kernel, config 2 / 3 / 5 ray cast):
+// 1: 37.7-38.5 us, 2: 37.1-37.7 / c3 +2.6 % frames/s, 3: 38.1-38.3, 4 (rounds 2-3): 38.0-38.8, 6: 40.3
+#define ITM_RAY_MARCH_BURST 2
 #endif
 
 namespace itm {
@@ -511,7 +513,10 @@ __device__ inline float4 cast_ray_plain(int x, int y, const VOL& vol, const RayP
 #define ITM_RAY_PARK_STREAK 12
 #endif
 #ifndef ITM_RAY_PARKED_LOOKAHEAD
-#define ITM_RAY_PARKED_LOOKAHEAD 6   // directory cells fetched together per round trip by a parked ray's empty-space run (4: 55 us, 6: 53, 8: 53)
+// directory cells fetched together per round trip by a parked ray's empty-space run (round 2: 4: 55 us, 6: 53, 8: 53; round 4 with a march
+// burst of 2, config 2 / config 5 ray cast: 6: 37.2-37.7 / 116-118, 8: 35.8-36.9 / 114.7-114.9, 12: 35.5-36.7 / 112.8-113.1, 16: 40.2-40.6 / 119.6,
+// 20: 41.8 / 130, 24: 40.4-42.1 / 131)
+#define ITM_RAY_PARKED_LOOKAHEAD 12
 #endif
 
 #ifndef ITM_RAY_PROBE_AT
