@@ -286,7 +286,10 @@ def worker(args) -> int:
     exs = []
     # the exchange is issued by the library (RCCL called from C++, infinitam_amd/csrc/exchange.hip) whenever the product runs with one
     # GPU per rank; the torch.distributed path remains for the CPU / shared-GPU self-tests and for --exchange-impl torch
-    native = exchange and product and on_gpu and not shared and args.exchange_impl == "library"
+    # (shared-GPU self-test: RCCL refuses two ranks on one device, so the library's exchange runs there only over a stand-in transport
+    # named by ITM_RCCL_LIBRARY -- tests/cpp/rccl_standin.cpp -- which exercises this file's N-rank bootstrap and the library's N-rank code)
+    standin = os.environ.get("ITM_RCCL_LIBRARY") if shared else None
+    native = exchange and product and on_gpu and (not shared or bool(standin)) and args.exchange_impl == "library"
     if exchange and native:
         from infinitam_amd.streams import NativeExchange
         for _ in streams:
@@ -643,7 +646,7 @@ def worker(args) -> int:
                        "host_threads": (k_streams if (k_streams > 1 and args.host_threads and not exchange) else 1),
                        "world_size_seen": (dist.get_world_size() if dist.is_initialized() else 1), "collective_backend": backend_name,
                        "exchange": (f"all_gather of {17 + MAX_IDS}-word visible-block records, {max(1, args.exchange_batch)} frame(s) per collective, side stream, "
-                                    + ("issued by the library (RCCL from C++)" if native else "issued through torch.distributed")
+                                    + (("issued by the library over the STAND-IN transport of the shared-GPU self-test (not RCCL)" if standin else "issued by the library (RCCL from C++)") if native else "issued through torch.distributed")
                                     if exchange else "none"),
                        "exchange_cost_measured": exchange_cost,
                        "per_rank_fps_min_max": fps_minmax,

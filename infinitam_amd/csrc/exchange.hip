@@ -57,8 +57,12 @@ static Rccl& rccl() {
   return r;
 }
 static void load_rccl(Rccl& r) {
+  // ITM_RCCL_LIBRARY names the collective library to load instead (a site's own RCCL build; the tests' stand-in transport for several
+  // ranks on ONE GPU, tests/cpp/rccl_standin.cpp).  When it is set nothing else is tried: a path that does not load is an error.
+  const char* forced = getenv("ITM_RCCL_LIBRARY");
   const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
-  for (const char* n : names) { r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (r.lib) break; }
+  if (forced && forced[0]) r.lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+  else for (const char* n : names) { r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (r.lib) break; }
   if (!r.lib) return;
   r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
   r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");

@@ -53,8 +53,8 @@ def test_stream_g_of_the_eight_stream_config_equals_the_oracle(hip, oracle, g):
         ex.close(); ses.close(); ref.close()
 
 
-def _bench_two_ranks(extra):
-    env = dict(os.environ)
+def _bench_two_ranks(extra, extra_env=None):
+    env = dict(os.environ, **(extra_env or {}))
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     env["ITM_BENCH_SHARED_GPU"] = "1"
@@ -82,3 +82,18 @@ def test_bench_with_two_ranks_sharing_the_gpu():
     lo, hi = out["config"]["per_rank_fps_min_max"]
     assert out["n_gpus"] == 2 and 1000 < lo <= hi, out["config"]["per_rank_fps_min_max"]       # both ranks ran frames, on the GPU, side by side
     assert out["repetitions"]["count"] > 1 and abs(out["value"] - 2 * lo) / out["value"] < 0.2
+
+
+@pytest.mark.gpu
+def test_bench_with_two_ranks_and_the_library_exchange_over_the_standin_transport():
+    """The same launcher with the exchange issued by the LIBRARY at world 2: bench.py's bootstrap (unique id of rank 0 broadcast over the
+    control plane, communicator creation bounded by a thread, all-ranks-or-none agreement) and exchange.hip's N-rank code run end to end on
+    one GPU over tests/cpp/rccl_standin.cpp (RCCL itself refuses two ranks on one device).  Batched and per-frame; the self-check stays on."""
+    import test_native_exchange as X
+    lib = X.build_standin()
+    for batch in ("8", "1"):
+        out = _bench_two_ranks(["--steps", "24", "--warmup", "8", "--exchange-batch", batch], {"ITM_RCCL_LIBRARY": lib})
+        assert out["n_gpus"] == 2 and out["config"]["world_size_seen"] == 2
+        assert "issued by the library over the STAND-IN transport" in out["config"]["exchange"] and ("%s frame(s) per collective" % batch) in out["config"]["exchange"]
+        lo, hi = out["config"]["per_rank_fps_min_max"]
+        assert 50 < lo <= hi, out["config"]["per_rank_fps_min_max"]

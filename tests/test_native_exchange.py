@@ -128,3 +128,84 @@ def test_every_collective_is_self_checked_and_corruption_is_loud(hip, monkeypatc
     finally:
         ex.close()
         ses.close()
+
+
+# ---- world 2 on ONE GPU: the library's exchange through a stand-in transport ------------------------------------------------------
+# RCCL refuses two ranks on one device and the pool has one GPU per box, so the N > 1 code of exchange.hip (rank-major table, the
+# self-check's own-block offset, the ring of batch buffers with a peer at another pace, the bootstrap through the 128-byte id) runs
+# here over tests/cpp/rccl_standin.cpp -- a TEST DOUBLE loaded through ITM_RCCL_LIBRARY that stages the all-gather through shared
+# memory.  It says nothing about RCCL itself; it says the code around the collective is right for more than one rank.
+STANDIN_SRC = T.os.path.join(T.ROOT, "tests", "cpp", "rccl_standin.cpp")
+STANDIN = T.os.path.join(T.ROOT, "tests", "cpp", "librccl_standin.so")
+
+
+def build_standin():
+    import subprocess
+    if not T.os.path.exists(STANDIN) or T.os.path.getmtime(STANDIN) < T.os.path.getmtime(STANDIN_SRC):
+        subprocess.run(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "-O2", "-w", "-o", STANDIN, STANDIN_SRC, "-lrt"], check=True, capture_output=True)
+    return STANDIN
+
+
+def test_standin_transport_builds_and_exports_the_five_entry_points():
+    import ctypes
+    lib = ctypes.CDLL(build_standin())
+    for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclAllGather", "ncclGetErrorString"):
+        assert hasattr(lib, name)
+
+
+def run_world(tmp_path, world, extra_env=None, paces=None):
+    import json, subprocess, sys
+    env = dict(T.os.environ, ITM_RCCL_LIBRARY=build_standin(), **(extra_env or {}))
+    idfile = str(tmp_path / "uid.bin")
+    procs = []
+    for r in range(world):
+        cmd = [sys.executable, T.os.path.join(T.ROOT, "tests", "exchange_world2_worker.py"), str(r), str(world), idfile, str(tmp_path / ("rank%d.npz" % r))]
+        if paces:
+            cmd.append(str(paces[r]))
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o)
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    return [(np.load(str(tmp_path / ("rank%d.npz" % r))), json.load(open(str(tmp_path / ("rank%d.npz.json" % r))))) for r in range(world)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,paces", [(2, None), (2, (0, 15)), (3, (5, 0, 10))])
+def test_library_exchange_with_several_ranks_on_one_gpu(hip, tmp_path, world, paces):
+    """Every rank runs its own stream of BASELINE configs[3] (the reference's four calls per frame) and publishes through the library's
+    exchange; ranks run at different paces, the ring of eight batch buffers wraps.  Every rank must hold the same table, block r of it
+    must be what rank r sent (pose, count, ids, -1 padding), and every collective must have passed the own-block check."""
+    res = run_world(tmp_path, world, paces=paces)
+    for d, meta in res:
+        assert meta["error"] is None, meta
+        assert meta["self_check"] == [14, 0], meta                      # 3 + 11 batches, each collective checked, no word differed
+    t0, at = res[0][0]["tables"], res[0][0]["at"]
+    assert t0.shape == (4, world, 2, 17 + 1024) and list(at) == [1, 3, 5, 27]
+    for d, _ in res[1:]:
+        assert np.array_equal(d["tables"], t0) and np.array_equal(d["at"], at)
+    for r, (d, _) in enumerate(res):
+        for c, k_last in enumerate(at):
+            for slot in range(2):
+                k = int(k_last) - 1 + slot
+                rec = t0[c, r, slot]
+                assert np.array_equal(rec[:16].view(np.float32), d["own_M"][k])
+                assert rec[16] == d["own_n"][k] and d["own_n"][k] > 100
+                assert np.array_equal(rec[17:], d["own_ids"][k])
+    assert not np.array_equal(res[0][0]["own_ids"][5], res[1][0]["own_ids"][5])          # the streams differ: the comparison above says something
+
+
+@pytest.mark.gpu
+def test_a_table_in_the_wrong_rank_order_is_caught_at_world_two(hip, tmp_path):
+    """The transport files every rank's block one place further (what a communicator built with the wrong rank order would deliver):
+    both ranks' self-checks fire and the error is loud."""
+    res = run_world(tmp_path, 2, extra_env={"ITM_STANDIN_ROTATE_RANKS": "1", "ITM_STANDIN_TIMEOUT_S": "5"})
+    for d, meta in res:
+        assert meta["error"] and "self-check" in meta["error"], meta
