@@ -545,6 +545,9 @@ __device__ inline float4 cast_ray_plain(int x, int y, const VOL& vol, const RayP
 #ifndef ITM_RAY_FAR_CELLS
 #define ITM_RAY_FAR_CELLS 0     // hash index with the mirror: positions a ray looks ahead after a single-voxel read of exactly 1 (0: never)
 #endif
+#ifndef ITM_RAY_FAR_CELLS_PARKED
+#define ITM_RAY_FAR_CELLS_PARKED 0   // the same, but only in the second pass over the parked rays (0: never)
+#endif
 #ifndef ITM_RAY_FAR_ALL
 #define ITM_RAY_FAR_ALL 1       // 1: only when every marching lane of the wave has just read exactly 1; 0: when any has
 #endif
@@ -836,10 +839,13 @@ __device__ inline float4 march_ray(int x, int y, const VOL& vol, const RayParams
         }
       }
 #endif
-      if constexpr (!DENSE && ITM_RAY_FAR_CELLS > 0) {
+      if constexpr (!DENSE && (ITM_RAY_FAR_CELLS > 0 || (LOOKAHEAD > 0 && ITM_RAY_FAR_CELLS_PARKED > 0))) {
+        // (ITM_RAY_FAR_CELLS_PARKED: the same look-ahead in phase 2 only, where every lane of the wave is a parked ray that enters the
+        // never-observed shell of the far surface at about the same time)
+        constexpr int KF = (LOOKAHEAD > 0 && ITM_RAY_FAR_CELLS_PARKED > 0) ? ITM_RAY_FAR_CELLS_PARKED : (ITM_RAY_FAR_CELLS > 0 ? ITM_RAY_FAR_CELLS : 1);
         const bool far = st == MARCH && found && sdf == 1.0f;      // SDF_valueToFloat(32767) is exactly 1
         if (vol.sdfMirror && (ITM_RAY_FAR_ALL ? (__all(st != MARCH || far) && __any(far)) : __any(far)))
-          far_run_mirror(std::integral_constant<int, (ITM_RAY_FAR_CELLS > 0 ? ITM_RAY_FAR_CELLS : 1)>(), far);
+          far_run_mirror(std::integral_constant<int, KF>(), far);
       }
       if constexpr (!DENSE && PARK && ITM_RAY_PROBE_CELLS > 0) {
         // phase 1, once the wave has nothing left to march but rays inside "not found" runs (the other lanes are done or wait for their
