@@ -149,15 +149,19 @@ int itm_allocate_scene_from_depth(itm_scene* s, const itm_view* v, itm_render_st
 
 int itm_integrate_into_scene(itm_scene* s, const itm_view* v, itm_render_state* rs, itm_stream stream) {
   if (!s || !v || !rs) return set_error(ITM_ERR_INVALID, "null argument");
-  std::lock_guard<std::recursive_mutex> lock(g_pendingMutex);
   if (!v->depth) return set_error(ITM_ERR_INVALID, "null depth image");
   if (rs->scene != s) return set_error(ITM_ERR_INVALID, "render state belongs to another scene");
-  if (rs->deferred.stage == 1 && s->deferredRs == rs && rs->deferred.st == as_stream(stream) && same_images(rs->deferred.view, *v)) {
-    if (s->fatalHost && *s->fatalHost) return enter_scene(s, nullptr);
-    const int rc = validate_integrate(s, v);
-    if (rc) return rc;                       // (the recorded allocation stays recorded: the call that failed did nothing)
-    rs->deferred.stage = 2;
-    return ITM_OK;
+  {
+    // (the lock covers the bookkeeping only: kernels are launched outside it, so that the frames of several scenes submitted from
+    // several host threads do not queue up behind each other's launches)
+    std::lock_guard<std::recursive_mutex> lock(g_pendingMutex);
+    if (rs->deferred.stage == 1 && s->deferredRs == rs && rs->deferred.st == as_stream(stream) && same_images(rs->deferred.view, *v)) {
+      if (s->fatalHost && *s->fatalHost) return enter_scene(s, nullptr);
+      const int rc = validate_integrate(s, v);
+      if (rc) return rc;                       // (the recorded allocation stays recorded: the call that failed did nothing)
+      rs->deferred.stage = 2;
+      return ITM_OK;
+    }
   }
   const int rc = enter_scene(s, rs);
   if (rc) return rc;
@@ -166,13 +170,15 @@ int itm_integrate_into_scene(itm_scene* s, const itm_view* v, itm_render_state* 
 
 int itm_create_expected_depths(const itm_scene* s, const float M[16], const float intr[4], itm_render_state* rs, itm_stream stream) {
   if (!s || !M || !intr || !rs) return set_error(ITM_ERR_INVALID, "null argument");
-  std::lock_guard<std::recursive_mutex> lock(g_pendingMutex);
   if (rs->scene != s) return set_error(ITM_ERR_INVALID, "render state belongs to another scene");
-  if (rs->deferred.stage == 2 && s->deferredRs == rs && rs->deferred.st == as_stream(stream) &&
-      memcmp(M, rs->deferred.view.M_d, 64) == 0 && memcmp(intr, rs->deferred.view.intr_d, 16) == 0) {
-    if (s->fatalHost && *s->fatalHost) return enter_scene(s, nullptr);
-    rs->deferred.stage = 3;
-    return ITM_OK;
+  {
+    std::lock_guard<std::recursive_mutex> lock(g_pendingMutex);
+    if (rs->deferred.stage == 2 && s->deferredRs == rs && rs->deferred.st == as_stream(stream) &&
+        memcmp(M, rs->deferred.view.M_d, 64) == 0 && memcmp(intr, rs->deferred.view.intr_d, 16) == 0) {
+      if (s->fatalHost && *s->fatalHost) return enter_scene(s, nullptr);
+      rs->deferred.stage = 3;
+      return ITM_OK;
+    }
   }
   const int rc = enter_scene(s, rs);
   if (rc) return rc;
@@ -181,14 +187,19 @@ int itm_create_expected_depths(const itm_scene* s, const float M[16], const floa
 
 int itm_create_icp_maps(const itm_scene* s, const itm_view* v, itm_render_state* rs, float* points, float* normals, itm_stream stream) {
   if (!s || !v || !rs || !points || !normals) return set_error(ITM_ERR_INVALID, "null argument");
-  std::lock_guard<std::recursive_mutex> lock(g_pendingMutex);
   if (rs->scene != s) return set_error(ITM_ERR_INVALID, "render state belongs to another scene");
-  if (rs->deferred.stage == 3 && s->deferredRs == rs && rs->deferred.st == as_stream(stream) && same_images(rs->deferred.view, *v)) {
-    // the sequence is complete: the fused frame (visualise.hip)
-    const itm_view view = rs->deferred.view;
-    forget_deferred(rs);
-    return itm_process_frame_ahead(const_cast<itm_scene*>(s), &view, nullptr, rs, points, normals, stream);
+  bool complete = false;
+  itm_view view;
+  {
+    std::lock_guard<std::recursive_mutex> lock(g_pendingMutex);
+    if (rs->deferred.stage == 3 && s->deferredRs == rs && rs->deferred.st == as_stream(stream) && same_images(rs->deferred.view, *v)) {
+      view = rs->deferred.view;
+      forget_deferred(rs);
+      complete = true;
+    }
   }
+  // the sequence is complete: the fused frame (visualise.hip), launched outside the lock
+  if (complete) return itm_process_frame_ahead(const_cast<itm_scene*>(s), &view, nullptr, rs, points, normals, stream);
   const int rc = enter_scene(s, rs);
   if (rc) return rc;
   return launch_icp_maps(s, v, rs, (float4*)points, (float4*)normals, as_stream(stream));

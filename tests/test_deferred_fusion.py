@@ -211,3 +211,38 @@ def test_refusals_are_reported_by_the_call_that_causes_them(hip):
     ses.scene.vis.CreateICPMaps(v, ses.rs, ses.points, ses.normals)
     assert ses.scene.counters(ses.rs)["noVisibleEntries"] > 0
     ses.close()
+
+
+def test_four_calls_from_several_host_threads(hip, oracle):
+    """Three scenes driven by three host threads at once (ctypes releases the interpreter lock inside every call): the recording of one
+    thread's calls, the flushes its uploads trigger and the fused launches -- made outside the library's lock -- must not disturb the
+    others.  Every scene equals the oracle's sequential run of the same frames."""
+    import threading
+    scs = [Scenario(name="thr%d" % g, w=320, h=240, voxelSize=0.008, frames=8, trajectory="bench", stream=g) for g in range(3)]
+    sessions = [T.Session(hip, sc) for sc in scs]
+    errors = []
+
+    def drive(ses):
+        try:
+            for k in range(ses.sc.frames):
+                ses.frame(k, fused="four")
+                if k % 3 == 2:
+                    ses.scene.counters(ses.rs)            # an observer now and then (flushes nothing: the frame is complete)
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=drive, args=(ses,)) for ses in sessions]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for ses, sc in zip(sessions, scs):
+        got = ses.snapshot()
+        ses.close()
+        ref = T.Session(oracle, sc)
+        for k in range(sc.frames):
+            ref.frame(k, fused="four")
+        want = ref.snapshot()
+        ref.close()
+        T.compare_results(got, want, sc, what=sc.name + "/threads")
