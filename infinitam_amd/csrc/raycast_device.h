@@ -548,6 +548,9 @@ __device__ inline float4 cast_ray_plain(int x, int y, const VOL& vol, const RayP
 #ifndef ITM_RAY_FAR_CELLS_PARKED
 #define ITM_RAY_FAR_CELLS_PARKED 0   // the same, but only in the second pass over the parked rays (0: never)
 #endif
+#ifndef ITM_RAY_FAR_GATE
+#define ITM_RAY_FAR_GATE 0      // > 0: the look-ahead over values of exactly 1 only for rays that have just read that many of them in a row
+#endif
 #ifndef ITM_RAY_FAR_ALL
 #define ITM_RAY_FAR_ALL 1       // 1: only when every marching lane of the wave has just read exactly 1; 0: when any has
 #endif
@@ -617,6 +620,9 @@ __device__ inline float4 march_ray(int x, int y, const VOL& vol, const RayParams
   float px = r.px, py = r.py, pz = r.pz, total = r.total;
   const float dx = r.dx, dy = r.dy, dz = r.dz, totalMax = r.totalMax;
   int missStreak = 0;
+#if ITM_RAY_FAR_GATE > 0
+  int farStreak = 0;
+#endif
 #if ITM_RAY_NEAR_SKIP == 3
   bool confirm = false;
 #endif
@@ -843,7 +849,13 @@ __device__ inline float4 march_ray(int x, int y, const VOL& vol, const RayParams
         // (ITM_RAY_FAR_CELLS_PARKED: the same look-ahead in phase 2 only, where every lane of the wave is a parked ray that enters the
         // never-observed shell of the far surface at about the same time)
         constexpr int KF = (LOOKAHEAD > 0 && ITM_RAY_FAR_CELLS_PARKED > 0) ? ITM_RAY_FAR_CELLS_PARKED : (ITM_RAY_FAR_CELLS > 0 ? ITM_RAY_FAR_CELLS : 1);
-        const bool far = st == MARCH && found && sdf == 1.0f;      // SDF_valueToFloat(32767) is exactly 1
+        const bool far1 = st == MARCH && found && sdf == 1.0f;      // SDF_valueToFloat(32767) is exactly 1
+#if ITM_RAY_FAR_GATE > 0
+        farStreak = far1 ? farStreak + 1 : 0;                       // (gate: only rays that have just taken ITM_RAY_FAR_GATE such steps in a row)
+        const bool far = far1 && farStreak >= ITM_RAY_FAR_GATE;
+#else
+        const bool far = far1;
+#endif
         if (vol.sdfMirror && (ITM_RAY_FAR_ALL ? (__all(st != MARCH || far) && __any(far)) : __any(far)))
           far_run_mirror(std::integral_constant<int, KF>(), far);
       }
