@@ -435,6 +435,12 @@ def worker(args) -> int:
             torch.cuda.synchronize()
 
     def barrier():
+        if exchange and native:
+            # every collective the library's issuer thread still holds is put on its stream and completes (the synchronisation below
+            # waits for streams, not for that thread's queue): no all-gather of the library's communicator is left to overlap -- in an
+            # order that could differ from rank to rank -- with the control plane's collective on the other communicator
+            for ex in exs:
+                ex.self_check()
         sync()
         if world > 1:
             dist.barrier()
