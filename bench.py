@@ -434,7 +434,7 @@ def worker(args) -> int:
         if on_gpu:
             torch.cuda.synchronize()
 
-    def barrier():
+    def drain():
         if exchange and native:
             # every collective the library's issuer thread still holds is put on its stream and completes (the synchronisation below
             # waits for streams, not for that thread's queue): no all-gather of the library's communicator is left to overlap -- in an
@@ -442,6 +442,9 @@ def worker(args) -> int:
             for ex in exs:
                 ex.self_check()
         sync()
+
+    def barrier():
+        drain()
         if world > 1:
             dist.barrier()
         sync()
@@ -452,12 +455,13 @@ def worker(args) -> int:
     timed_kernel = TK[wl["kernel"]]
 
     def timed_region(first):
-        """EXACTLY --steps frames between two barriers; returns the MAX over ranks of the elapsed time (and this rank's own)."""
+        """EXACTLY --steps frames: a barrier + synchronisation in front, each rank's own synchronisation (frames and exchange) behind; returns the MAX
+        over ranks of the elapsed times -- the job's time; the all-reduce that forms it is the closing barrier -- and this rank's own."""
         barrier()
         t0 = time.perf_counter()
         run(first, first + args.steps)
-        barrier()
-        mine = time.perf_counter() - t0
+        drain()                                   # this rank's frames AND its share of the exchange are done ...
+        mine = time.perf_counter() - t0           # ... at its own clock; the MAX over ranks below is the job's time (and the closing barrier)
         if world == 1:
             return mine, mine
         tt = torch.tensor([mine], dtype=torch.float64, device=ctl_device)
