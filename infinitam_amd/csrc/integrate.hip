@@ -221,9 +221,15 @@ __device__ inline bool fuse_voxel(typename VX::Reg& r, float mx, float my, float
 #ifndef ITM_INTEGRATE_SLICES
 #define ITM_INTEGRATE_SLICES 4
 #endif
-constexpr int kSlices = ITM_INTEGRATE_SLICES;
-constexpr int kItemsPerBlock = kBlockSide / kSlices;
-static_assert(kSlices == 1 || kSlices == 2 || kSlices == 4 || kSlices == 8, "slice groups tile the block");
+#ifndef ITM_INTEGRATE_SLICES_SHORT
+// ITMVoxel_s (4 bytes, 36 registers): the whole block per item -- eight runs in flight per wave.  Measured at the end of round 4 (BASELINE
+// configs[1], integration + projection launch): 2 slices 22.5-23.0 us, 4: 20.4-20.5, 8: 19.2-19.5; the 12-byte ITMVoxel_f_rgb loses with 8
+// (configs[4]: 178 -> 196 us, registers), so the other types keep ITM_INTEGRATE_SLICES.
+#define ITM_INTEGRATE_SLICES_SHORT 8
+#endif
+template <class VX> __host__ __device__ constexpr int slices_of() { return VX::kBytes == 4 ? ITM_INTEGRATE_SLICES_SHORT : ITM_INTEGRATE_SLICES; }
+static_assert(ITM_INTEGRATE_SLICES == 1 || ITM_INTEGRATE_SLICES == 2 || ITM_INTEGRATE_SLICES == 4 || ITM_INTEGRATE_SLICES == 8, "slice groups tile the block");
+static_assert(ITM_INTEGRATE_SLICES_SHORT == 1 || ITM_INTEGRATE_SLICES_SHORT == 2 || ITM_INTEGRATE_SLICES_SHORT == 4 || ITM_INTEGRATE_SLICES_SHORT == 8, "slice groups tile the block");
 
 #ifndef ITM_INTEGRATE_NT
 // bit 0: the 4-byte voxels, bit 1: the mirror values are stored with the non-temporal hint (measurement switch)
@@ -236,7 +242,8 @@ static_assert(kSlices == 1 || kSlices == 2 || kSlices == 4 || kSlices == 8, "sli
 #endif
 
 template <class VX>
-__device__ inline void load_item(const HashEntry& he, int z0, int lane, const void* __restrict__ vba, typename VX::Reg r[kSlices]) {
+__device__ inline void load_item(const HashEntry& he, int z0, int lane, const void* __restrict__ vba, typename VX::Reg r[slices_of<VX>()]) {
+  constexpr int kSlices = slices_of<VX>();
   const size_t vi = (size_t)(he.ptr < 0 ? 0 : he.ptr) * kBlockVoxels + (size_t)z0 * 64 + lane;      // block 0 is always there
 #pragma unroll
   for (int k = 0; k < kSlices; ++k) r[k] = VX::load(vba, vi + 64 * k);
@@ -246,9 +253,10 @@ __device__ inline void load_item(const HashEntry& he, int z0, int lane, const vo
 // behind the depth gathers -- the wave then waits for those gathers only (the memory counter retires in issue order), and the new
 // runs travel while this item is updated and stored.
 template <class VX>
-__device__ inline void integrate_item(const HashEntry& he, int z0, int lane, typename VX::Reg r[kSlices], void* __restrict__ vba, void* __restrict__ sdfMirror,
+__device__ inline void integrate_item(const HashEntry& he, int z0, int lane, typename VX::Reg r[slices_of<VX>()], void* __restrict__ vba, void* __restrict__ sdfMirror,
                                       const float* __restrict__ depth, const uchar4* __restrict__ rgb, const FuseParams& p,
-                                      bool hasNext, const HashEntry& next, int nextZ0, typename VX::Reg nextR[kSlices]) {
+                                      bool hasNext, const HashEntry& next, int nextZ0, typename VX::Reg nextR[slices_of<VX>()]) {
+  constexpr int kSlices = slices_of<VX>();
   const bool present = he.ptr >= 0;
   const int x = lane & 7, y = lane >> 3;
   const size_t vi = (size_t)(present ? he.ptr : 0) * kBlockVoxels + (size_t)z0 * 64 + lane;
@@ -310,6 +318,8 @@ template <class VX>
 __device__ inline void integrate_hash_body(int wgIdx, int wgCount, const int32_t* __restrict__ visibleIds, RenderCounters* __restrict__ rc,
                                            const uint4* __restrict__ hash, void* __restrict__ vba, void* __restrict__ sdfMirror,
                                            const float* __restrict__ depth, const uchar4* __restrict__ rgb, const FuseParams& p) {
+  constexpr int kSlices = slices_of<VX>();
+  constexpr int kItemsPerBlock = kBlockSide / kSlices;
   if (rc->listInvalid) return;                        // the list of this frame is not the reference's: fuse nothing (alloc.hip, statusFlags bit 1)
   const int nItems = rc->noVisibleEntries * kItemsPerBlock;
   const int lane = threadIdx.x & 63;
@@ -1110,7 +1120,11 @@ int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipS
     // the static striding does not, but few enough that most waves have work -- a workgroup without any still holds a slot for ~1 us
     // (measured, configs[4] / configs[1]: 768-1024 workgroups 189 / 21.3 us, 1536: 177 / 19.9, 2048: 175 / 20.3, 4096: 170 / 20.4,
     // where the last workgroup of configs[1] only STARTS after 15 us)
-    const int grid = g_debug_integrate_wgs > 0 ? g_debug_integrate_wgs : 2048;
+    // re-measured at the end of round 4 on the final kernels (ITMVoxel_s with a whole block per item): 640 x 480 (9.6 k visible blocks)
+    // 1024: 19.5-19.8 us, 1536: 19.4-19.8, 2048: 19.0-19.5, 3072: 18.9-19.8, 8192: 18.2-19.6; 1280 x 960 colour (55.8 k blocks) 1024: 193 us,
+    // 2048: 178, 3072: 174, 4096: 173-174, 6144: 172-173, 8192: 171 -- the number of visible blocks is not known on the host (nothing is read
+    // back), the image size stands in for it
+    const int grid = g_debug_integrate_wgs > 0 ? g_debug_integrate_wgs : ((size_t)rs->w * rs->h > (size_t)640 * 480 ? 8192 : 2048);
     ProjParams pp;
     const int RW = (rs->w + 7) / 8, RH = (rs->h + 7) / 8;
     if (fuseProjection) {
