@@ -64,9 +64,12 @@ __device__ inline Projected project_block(const HashEntry& e, const ProjParams& 
 // reference clamps boxes to the FULL image size, a quirk that only touches cells no ray ever reads) go
 // through global atomics.
 #ifndef ITM_RANGE_PARTS
-#define ITM_RANGE_PARTS 32
+// (re-measured at the end of round 4, BASELINE configs[1] frames/s through the four calls / configs[4]: 4 parts 10.8-10.9 k / 2 800 -- the
+// projection becomes the integration launch's long pole, 31 us --, 8: 12.0 k / 2 902, 16: 12.46-12.54 k / 2 901-2 906, 32: 12.28-12.37 k /
+// 2 892-2 899, 64: 12.1-12.2 k / 2 857: every ray-cast workgroup reduces 4 cells x parts partial values in its prologue)
+#define ITM_RANGE_PARTS 16
 #endif
-constexpr int kRangeParts = ITM_RANGE_PARTS;   // 32 or 64 (the ray-cast prologue reduces 4 cells x kRangeParts partials with <= 256 lanes)
+constexpr int kRangeParts = ITM_RANGE_PARTS;   // 16, 32 or 64 (the ray-cast prologue reduces 4 cells x kRangeParts partials with <= 256 lanes)
 
 // Rendering-block cap of the reference reached (numRenderingBlocks >= MAX_RENDERING_BLOCKS): replays the sequential
 // accept / skip decisions and rebuilds the whole image from the accepted boxes.  One workgroup of `nthreads` lanes.

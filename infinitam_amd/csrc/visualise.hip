@@ -337,7 +337,13 @@ __device__ inline void reduce_own_cells(const RangeFuse& f, int tx, int ty, int 
 // the same workgroup re-packs the parked rays 64 per wave: all lanes are then in the same phase, and the look-ahead of
 // march_ray turns the ~45 dependent round trips of the run into ~8.  (As a second LAUNCH over a global queue the parked rays
 // took 52 us on their own -- one wave per SIMD, other XCDs' cold L2s -- against 34 us for the first pass; measured, dropped.)
-constexpr float kSilhouetteSpread = 0.3f;   // metres between the near and far bound of a tile's expected depths
+#ifndef ITM_RAY_SILHOUETTE_SPREAD
+#define ITM_RAY_SILHOUETTE_SPREAD 0.3f
+#endif
+#ifndef ITM_RAY_SILHOUETTE_PRIO
+#define ITM_RAY_SILHOUETTE_PRIO 3
+#endif
+constexpr float kSilhouetteSpread = ITM_RAY_SILHOUETTE_SPREAD;   // metres between the near and far bound of a tile's expected depths
 #ifndef ITM_EXP_RAYCAST_STAMPS
 #define ITM_EXP_RAYCAST_STAMPS 0   // measurement build: per-wave timeline of the ray-cast launch on the 100 MHz clock (tools/raycast_timeline.py)
 #endif
@@ -445,7 +451,7 @@ __global__ void __launch_bounds__(256) raycast_kernel(VolumeView volIn, const fl
   // (profiles/r2_raycast_timeline.txt), and while the other ~1 000 tiles are still resident they share each SIMD's issue slots with
   // four other waves.  Raised wave priority lets them issue first: 48.2 -> 46.1 us in frame (config 2; a threshold of 0.03 m, i.e.
   // nearly every tile, gives nothing; delaying the other tiles by 3-14 us instead: no gain, config 5 +4..20 us).
-  if (!DENSE && __any(inside && mm.y - mm.x > kSilhouetteSpread)) __builtin_amdgcn_s_setprio(3);
+  if (!DENSE && __any(inside && mm.y - mm.x > kSilhouetteSpread)) __builtin_amdgcn_s_setprio(ITM_RAY_SILHOUETTE_PRIO);
   // ---- phase 1: every ray of the tile; rays that turn out to be crossing empty space are parked ----
   bool parked = false;
   if (inside) {

@@ -6,7 +6,7 @@ name=$1; extra=$2
 obj=/tmp/itm_fullvariant_$name; mkdir -p $obj ../../gpurun_variants
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math $extra"
 objs=""
-for f in scene alloc integrate visualise visualise_aux tracker viewbuilder io meshing exchange swapping; do
+for f in scene alloc integrate visualise visualise_aux tracker viewbuilder io meshing exchange swapping pending; do
   /opt/rocm/bin/hipcc $FL -c $f.hip -o $obj/$f.o &
   objs="$objs $obj/$f.o"
 done
