@@ -365,6 +365,9 @@ struct SweepArgs {
   uint32_t* nearWords;     // near bits of the mirror's cube (itm_types.h), or nullptr
 };
 
+#ifndef ITM_LIST_SPIN_SLEEP
+#define ITM_LIST_SPIN_SLEEP 1        // s_sleep argument between two polls of a predecessor's granule in the look-back (x 64 cycles)
+#endif
 #ifndef ITM_EXP_LIST_STAMPS
 #define ITM_EXP_LIST_STAMPS 0     // measurement build: per-workgroup timeline of the visible-list launch (100 MHz clock)
 #endif
@@ -424,7 +427,7 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
       unsigned long long g = __hip_atomic_load(&chunkGran[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       for (int spin = 0; (uint32_t)(g >> 32) != epoch; ++spin) {
         if (spin > (1 << 22)) { stuck = true; break; }
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(ITM_LIST_SPIN_SLEEP);
         g = __hip_atomic_load(&chunkGran[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       before += (int)(uint32_t)g;
