@@ -548,6 +548,9 @@ __device__ inline float4 cast_ray_plain(int x, int y, const VOL& vol, const RayP
 #ifndef ITM_RAY_FAR_CELLS_PARKED
 #define ITM_RAY_FAR_CELLS_PARKED 0   // the same, but only in the second pass over the parked rays (0: never)
 #endif
+#ifndef ITM_RAY_PREFETCH_NEXT
+#define ITM_RAY_PREFETCH_NEXT 0   // 1: the mirror line of the position a repeated step would reach is requested beside every single-voxel read (measurement switch)
+#endif
 #ifndef ITM_RAY_FAR_GATE
 #define ITM_RAY_FAR_GATE 0      // > 0: the look-ahead over values of exactly 1 only for rays that have just read that many of them in a row
 #endif
@@ -620,6 +623,9 @@ __device__ inline float4 march_ray(int x, int y, const VOL& vol, const RayParams
   float px = r.px, py = r.py, pz = r.pz, total = r.total;
   const float dx = r.dx, dy = r.dy, dz = r.dz, totalMax = r.totalMax;
   int missStreak = 0;
+#if ITM_RAY_PREFETCH_NEXT
+  float lastStep = 0.0f;
+#endif
 #if ITM_RAY_FAR_GATE > 0
   int farStreak = 0;
 #endif
@@ -747,6 +753,22 @@ __device__ inline float4 march_ray(int x, int y, const VOL& vol, const RayParams
       ++reads;
       ITM_WT(++wtInner;)
       const float readX = px, readY = py, readZ = pz;          // where this read is made (the near-bit skip below needs the cell)
+#if ITM_RAY_PREFETCH_NEXT
+      // NON-BINDING PREFETCH (measurement switch): the mirror line of the position this ray reaches if it repeats its last step (runs
+      // through empty space and through never-observed voxels repeat it) is requested beside this position's own read; nothing looks at
+      // the value -- if the guess holds, the next read finds its line in the cache instead of making a round trip of its own.
+      [[maybe_unused]] uint32_t pfValue = 0;
+      if constexpr (!DENSE && VOL::kMirror == 1) {
+        if (vol.sdfMirror) {
+          const float qx = px + lastStep * dx, qy = py + lastStep * dy, qz = pz + lastStep * dz;
+          const uint32_t vx = (uint32_t)((int)round_ref(qx) - (vol.org.mx << 3)), vy = (uint32_t)((int)round_ref(qy) - (vol.org.my << 3)), vz = (uint32_t)((int)round_ref(qz) - (vol.org.mz << 3));
+          const bool in = mirror_covers_voxel(vx, vy, vz);
+          const size_t at = ((size_t)mirror_cell(vx >> 3, vy >> 3, vz >> 3) << 9) | (size_t)((vx & 7u) | ((vy & 7u) << 3) | ((vz & 7u) << 6));
+          pfValue = (uint32_t)((const typename MirrorCodec<VX::kShort>::T*)vol.sdfMirror)[in ? at : (size_t)0];
+        }
+      }
+      const float pfBeforeX = px, pfBeforeY = py, pfBeforeZ = pz, pfBeforeT = total;
+#endif
 #if ITM_RAY_NEAR_SKIP == 3
       // NEAR FIRST inside a run.  A ray whose last read found no block asks the near bits of its position BEFORE (instead of) the
       // mirror: the 16 MB of near bits are cache resident, the mirror's line of an empty cell is a cold kilobyte of HBM that says
@@ -794,6 +816,11 @@ __device__ inline float4 march_ray(int x, int y, const VOL& vol, const RayParams
 #endif
 #if ITM_RAY_NEAR_SKIP == 3
       if (stay) { px = keepX; py = keepY; pz = keepZ; total = keepT; st = MARCH; }      // nothing was learnt but "read the mirror here"
+#endif
+#if ITM_RAY_PREFETCH_NEXT
+      lastStep = (st == MARCH) ? total - pfBeforeT : 0.0f;      // (the step just taken; the guess for the next one)
+      (void)pfBeforeX; (void)pfBeforeY; (void)pfBeforeZ;
+      asm volatile("" :: "v"(pfValue));                          // the prefetched value is not used; the request must not be optimised away
 #endif
       if constexpr (DENSE) missed = !found;
       if constexpr (DENSE && LOOKAHEAD > 0) {
