@@ -548,6 +548,9 @@ __device__ inline float4 cast_ray_plain(int x, int y, const VOL& vol, const RayP
 #ifndef ITM_RAY_FAR_CELLS_PARKED
 #define ITM_RAY_FAR_CELLS_PARKED 0   // the same, but only in the second pass over the parked rays (0: never)
 #endif
+#ifndef ITM_RAY_UNROLL_BURST
+#define ITM_RAY_UNROLL_BURST 0    // 1: the burst of cheap steps unrolled (measurement switch)
+#endif
 #ifndef ITM_RAY_PREFETCH_NEXT
 #define ITM_RAY_PREFETCH_NEXT 0   // 1: the mirror line of the position a repeated step would reach is requested beside every single-voxel read (measurement switch)
 #endif
@@ -748,6 +751,9 @@ __device__ inline float4 march_ray(int x, int y, const VOL& vol, const RayParams
     ITM_WT(const unsigned long long wt0 = wt_clock(); unsigned wtInner = 0; const unsigned wtLanes0 = __popcll(__ballot(1)); const unsigned wtMarch0 = __popcll(__ballot(st == MARCH));)
     // ---- cheap phase: at most ITM_RAY_MARCH_BURST single-voxel steps, so that waiting lanes are served regularly ----
     int budget = ITM_RAY_MARCH_BURST;
+#if ITM_RAY_UNROLL_BURST
+#pragma unroll ITM_RAY_MARCH_BURST
+#endif
     while (st == MARCH && budget > 0) {
       --budget;
       ++reads;
