@@ -162,6 +162,9 @@ class Stream:
         idx = capi.INDEX_HASH if wl["index"] == "hash" else capi.INDEX_DENSE
         params = capi.default_params(voxelSize=wl["voxelSize"], mu=wl["mu"], stopIntegratingAtMaxW=wl["stopAtMax"])
         self.scene = be.create_scene(vox, idx, params, localBlockNum=wl["blocks"])
+        # the four-call path of the timed region relies on the library recording the first three calls (include/itm_hip.h,
+        # itm_scene_set_deferred_fusion): this host accepts that contract -- it never touches the stream between the four calls
+        self.scene.set_deferred_fusion(True)
         self.scene.reco.ResetScene()
         self.rs = self.scene.vis.CreateRenderState((w, h))
         intr = synth.intrinsics_for(w, h)
@@ -494,7 +497,7 @@ def worker(args) -> int:
     if rank == 0 and product and on_gpu:
         s0 = streams[0]
         nt = args.timer_frames if args.timer_frames > 0 else max(args.steps, 64)
-        timed_set = sorted({timed_kernel, TK["integrate"], TK["visible_list"], TK["raycast"]} if wl["index"] == "hash" else {timed_kernel, TK["raycast"]})
+        timed_set = sorted({timed_kernel, TK["request"], TK["integrate"], TK["visible_list"], TK["raycast"]} if wl["index"] == "hash" else {timed_kernel, TK["raycast"]})
         # the SAME frames on the SAME state as the timed region saw them: the scene is reset and warmed up again first (what a launch
         # costs depends on the scene -- BASELINE configs[2]'s dense integration gets cheaper as weights saturate: 83 us over frames
         # 20..219 of a fresh scene, 61 us when the same frames are fused a second time)
@@ -637,9 +640,9 @@ def worker(args) -> int:
     if rank == 0 and world == 1 and product and on_gpu and roofline is not None and not args.no_extra_legs:
         roofline["peak_measured"] = measured_stream_peak()
 
-    cpu_baseline = None
+    cpu_baseline, parity_check = None, None
     if rank == 0 and world == 1 and product and k_streams == 1 and not args.no_cpu_baseline:
-        cpu_baseline = run_cpu_baseline(args.config, wl, args.cpu_frames)
+        cpu_baseline, parity_check = run_cpu_baseline(args.config, wl, args.cpu_frames, on_gpu)
 
     out = None
     if rank == 0:
@@ -672,7 +675,7 @@ def worker(args) -> int:
                        "timing_note": "no event timers inside the timed region; kernels are timed in one extra, untimed repetition (roofline.launches_timed)",
                        **({"debug_keys": args.debug_keys} if args.debug_keys else {}),
                        "backend": be.version()},
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity_check": parity_check,
             **extra,
         }
     for ex in exs:                     # communicators of the library exchange go before the process group they were bootstrapped over
@@ -686,6 +689,9 @@ def worker(args) -> int:
         sys.stdout.flush()
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
+        if parity_check is not None and not parity_check["equal"]:
+            print(f"bench.py: PARITY CHECK FAILED: {parity_check}", file=sys.stderr)
+            return 4
     return 0
 
 
@@ -718,16 +724,28 @@ def algorithmic_bytes(config, wl, counters):
 
 
 def algorithmic_bytes_secondary(config, wl, counters, which, n_entries):
-    """Algorithmic bytes of the two other large launches of a hash frame:
-    integrate: Nv*(512*V*2 + E + 4) + 4*P (+ 4*P_rgb)  -- every visible block read and written once, its entry and list id, the depth image;
+    """Algorithmic bytes of the other large launches of a frame (SURVEY 8d formulas; work counts of the reference algorithm on this
+    workload from the CPU oracle's counters, tests/golden/algbytes_config<N>.json):
+    integrate (hash): Nv*(512*V*2 + E + 4) + 4*P (+ 4*P_rgb)  -- every visible block read and written once, its entry and list id, the depth image;
     visible_list: T + (E + 4)*Nv  -- one type byte per table slot (the reference's own sweep, _CPU.cpp:229-269, visits every slot), the
-      entry of every re-tested block and the id written for it.  A latency-bound sweep: its fraction is tiny by construction."""
+      entry of every re-tested block and the id written for it.  A latency-bound sweep: its fraction is tiny by construction;
+    raycast: 8*P/64 + V*(R_found + 8*R_t) + E*H + 16*P  -- V is the WHOLE voxel as the reference's readVoxel fetches it (the kernels
+      read only the sdf field: 2 of 4 bytes for ITMVoxel_s, 4 of 12 for ITMVoxel_f_rgb), H = 0 for a plain voxel array;
+    request: 4*P + E*S + 9*A  -- depth image, S hash probes of buildHashAllocAndVisibleTypePP, A allocation requests."""
     P = wl["w"] * wl["h"]
     V = {"s": 4, "f_rgb": 12}[wl["voxel"]]
     nv = counters["noVisibleEntries"]
     if which == "integrate":
         return nv * (512 * V * 2 + 16 + 4) + 4 * P + (4 * P if wl["colour"] else 0)
-    return n_entries + (16 + 4) * nv
+    if which == "visible_list":
+        return n_entries + (16 + 4) * nv
+    with open(os.path.join(ROOT, "tests", "golden", f"algbytes_config{config}.json")) as f:
+        c = json.load(f)
+    if which == "raycast":
+        return 8 * (P / 64) + V * ((c["nearest_reads"] - c["nearest_misses"]) + 8 * c["trilinear_reads"]) + 16 * c["hash_probes"] + 16 * P
+    if which == "request":
+        return 4 * P + 16 * c["alloc_probes"] + 9 * counters.get("noAllocRequests", 0)
+    raise KeyError(which)
 
 
 def read_roofline(config, wl, prof, counters, scene):
@@ -735,8 +753,9 @@ def read_roofline(config, wl, prof, counters, scene):
     launches, steady state: no synchronisation in front of any of them), on the stream the kernel runs on.  `event_pair_us` is what an
     event pair adds to an interval (half of what 64 EMPTY brackets on the same stream measure, see below): the part of every bracketed
     interval that is not the kernel; `avg_kernel_us` = bracket - that, which is what rocprofv3 reports for the kernel
-    (profiles/r4_*_kernel_stats.csv), `avg_bracket_us` the raw figure.  `traffic` = HBM bytes per launch from the PMC counters of a
-    separate rocprofv3 pass (profiles/traffic_r0N.json, stamped with the commit it was collected on)."""
+    (profiles/r5_*_kernel_stats.csv), `avg_bracket_us` the raw figure and `frac_raw_bracket` the fraction it would give.  `traffic` =
+    HBM bytes per launch from the PMC counters of a separate rocprofv3 pass (profiles/traffic_r0N.json, stamped with the commit it was
+    collected on).  `other_kernels`: every other launch that is a sizeable part of the frame, priced the same way."""
     r = prof[wl["kernel"]]
     if not r["calls"]:
         return None
@@ -744,44 +763,49 @@ def read_roofline(config, wl, prof, counters, scene):
     # An EMPTY bracket is two marker packets back to back: it measures two marker latencies.  A bracket around a kernel contains ONE of
     # them (the first marker's stamp is taken when it retires, the kernel starts right behind it; the second marker's own latency follows
     # the kernel).  Half the empty bracket is therefore what the pair adds -- measured: bracket 40.8 us, empty 4.9 us, rocprofv3 of the
-    # same build 38.5 us (profiles/r4_config2_kernel_stats.csv) = bracket - 2.3.
-    pair_s = 0.5 * ((empty["total_ms"] * 1e-3 / empty["calls"]) if empty["calls"] else 0.0)
+    # same build 38.5 us (profiles/r4_config2_kernel_stats.csv) = bracket - 2.3.  The correction is bounded: never more than 10 % of
+    # the bracket it is taken from (a calibration gone wrong must not buy a fraction).
     raw_s = r["total_ms"] * 1e-3 / r["calls"]
+    pair_s = min(0.5 * ((empty["total_ms"] * 1e-3 / empty["calls"]) if empty["calls"] else 0.0), 0.1 * raw_s)
     avg_s = max(raw_s - pair_s, 1e-9)
     alg = algorithmic_bytes(config, wl, counters)
     achieved = alg / avg_s / 1e9
-    traffic, traffic_src = None, None
-    for tname in ("traffic_r04.json", "traffic_r03.json", "traffic_r02.json"):        # the newest PMC collection that has this config
+    traffic_all = {}
+    for tname in ("traffic_r05.json", "traffic_r04.json", "traffic_r03.json", "traffic_r02.json"):        # the newest PMC collection that has this config
         tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath):
             with open(tpath) as f:
                 t = json.load(f).get(f"config{config}")
             if t:
-                traffic, traffic_src = t.get("hbm_bytes_per_launch"), t.get("source")
+                traffic_all = t
                 break
+    traffic, traffic_src = traffic_all.get("hbm_bytes_per_launch"), traffic_all.get("source")
     kname = {2: "raycast_kernel<VoxelS,hash>", 3: "integrate_dense_strip_kernel", 5: "integrate_hash_kernel<VoxelFRgb>"}[config]
     out = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
            # the same fraction on the bytes the kernel really moved (PMC counters of a separate pass) instead of the reference algorithm's
            "frac_traffic": (round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
+           "frac_raw_bracket": round(alg / raw_s / 1e9 / HBM_PEAK_GBS, 4),
            "algorithmic_bytes_per_launch": round(alg), "avg_kernel_us": round(avg_s * 1e6, 2), "avg_bracket_us": round(raw_s * 1e6, 2),
            "event_pair_us": round(pair_s * 1e6, 2), "launches_timed": r["calls"],
            "timed_in": "an extra untimed repetition, every launch bracketed (no sampling, no synchronisation between frames)"}
-    if wl["index"] == "hash":
-        other = {}
-        n_entries = scene.be.fn["buffer_bytes"](C.c_void_p(scene.h), None, 0) // 16
-        for which in ("integrate", "visible_list"):
-            q = prof[which]
-            if which == wl["kernel"] or not q["calls"]:
-                continue
-            t = max(q["total_ms"] * 1e-3 / q["calls"] - pair_s, 1e-9)
-            ab = algorithmic_bytes_secondary(config, wl, counters, which, n_entries)
-            other[which] = {"avg_kernel_us": round(t * 1e6, 2),      # (bracket - half a pair: within ~2 us of rocprofv3, which profiles/ holds) "algorithmic_bytes_per_launch": int(ab), "achieved": round(ab / t / 1e9, 1),
-                            "frac": round(ab / t / 1e9 / HBM_PEAK_GBS, 4), "launches_timed": q["calls"]}
-        if wl["kernel"] != "raycast" and prof["raycast"]["calls"]:
-            q = prof["raycast"]
-            other["raycast"] = {"avg_kernel_us": round((q["total_ms"] * 1e-3 / q["calls"] - pair_s) * 1e6, 2), "launches_timed": q["calls"]}
-        out["other_kernels"] = other
+    other = {}
+    n_entries = (scene.be.fn["buffer_bytes"](C.c_void_p(scene.h), None, 0) // 16) if wl["index"] == "hash" else 0
+    for which in (("request", "visible_list", "integrate", "raycast") if wl["index"] == "hash" else ("raycast",)):
+        q = prof[which]
+        if which == wl["kernel"] or not q["calls"]:
+            continue
+        qraw = q["total_ms"] * 1e-3 / q["calls"]
+        t = max(qraw - min(pair_s, 0.1 * qraw), 1e-9)
+        ab = algorithmic_bytes_secondary(config, wl, counters, which, n_entries)
+        # (bracket - half a pair: within ~2 us of rocprofv3, which profiles/ holds)
+        other[which] = {"avg_kernel_us": round(t * 1e6, 2), "algorithmic_bytes_per_launch": int(ab), "achieved": round(ab / t / 1e9, 1),
+                        "frac": round(ab / t / 1e9 / HBM_PEAK_GBS, 4), "launches_timed": q["calls"]}
+        tr = (traffic_all.get("other_kernels") or {}).get(which)
+        if tr:
+            other[which]["traffic"] = tr.get("hbm_bytes_per_launch")
+            other[which]["frac_traffic"] = round(tr["hbm_bytes_per_launch"] / t / 1e9 / HBM_PEAK_GBS, 4) if tr.get("hbm_bytes_per_launch") else None
+    out["other_kernels"] = other
     return out
 
 
@@ -803,7 +827,31 @@ def measured_stream_peak():
 # -------------------------------------------------------------------------------------------------------------
 # CPU baseline (checker code: the only place outside tests/ and smoke() that loads anything from oracle/)
 # -------------------------------------------------------------------------------------------------------------
-def _time_cpu(be, sc, nframes, T):
+def _state_digests(ses, sc):
+    """SHA-256 of everything a frame sequence leaves behind in a scene + render state: what the parity check compares."""
+    import hashlib
+    import numpy as np
+    from infinitam_amd import capi
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()     # noqa: E731
+    s, rs = ses.scene, ses.rs
+    c = s.counters(rs)
+    d = {"counters": {k: c[k] for k in ("lastFreeBlockId", "lastFreeExcessListId", "noVisibleEntries")}}
+    if s.is_hash:
+        d["hash_table"] = sha(s.download(capi.BUF_HASH_ENTRIES))
+        d["excess_list"] = sha(s.download(capi.BUF_EXCESS_LIST))
+        d["visible_ids"] = sha(s.download(capi.BUF_VISIBLE_IDS, rs)[: c["noVisibleEntries"]])
+        d["visible_types"] = sha(s.download(capi.BUF_VISIBLE_TYPE, rs))
+    d["allocation_list"] = sha(s.download(capi.BUF_ALLOCATION_LIST))
+    d["voxels"] = sha(s.download(capi.BUF_VOXEL_BLOCKS))
+    ray = s.download(capi.BUF_RAYCAST_RESULT, rs).copy()
+    ray[ray[..., 3] <= 0, :3] = 0          # a ray that found nothing keeps an unspecified position in the reference; its w is compared
+    d["raycast_result"] = sha(ray)
+    d["icp_points"], d["icp_normals"] = sha(ses.points.numpy()), sha(ses.normals.numpy())
+    d["raycast_image"] = sha(s.download(capi.BUF_RAYCAST_IMAGE, rs))
+    return d
+
+
+def _time_cpu(be, sc, nframes, T, digests=False):
     ses = T.Session(be, sc)
     depth = [be.to_backend(sc.depth(k)) for k in range(nframes)]
     rgb = ses.rgb
@@ -812,11 +860,31 @@ def _time_cpu(be, sc, nframes, T):
         v = T.View(depth[k], sc.w, sc.h, M_d=sc.pose(k), intr_d=sc.intr(), rgb=rgb, w_rgb=sc.w, h_rgb=sc.h, intr_rgb=sc.intr())
         ses.scene.process_frame(v, ses.rs, ses.points, ses.normals)
     dt = time.perf_counter() - t0
+    dig = _state_digests(ses, sc) if digests else None
     ses.close()
-    return nframes / dt
+    return (nframes / dt, dig) if digests else nframes / dt
 
 
-def run_cpu_baseline(config, wl, nframes):
+def run_parity_check(sc, nframes, oracle_digests, T):
+    """Outside every timed region: the first `nframes` frames of the workload on a FRESH scene of the product, through the headline
+    call sequence (the reference's four engine calls, recorded and launched as the fused frame), compared -- SHA-256 of every buffer --
+    with the oracle scene the cpu_baseline leg has just built on those same frames.  Every bench run thereby certifies that the
+    launches it timed do the reference's work; a mismatch makes the run fail."""
+    hip = T.hip_backend()
+    ses = T.Session(hip, sc)                 # (Session switches the recording on: itm_scene_set_deferred_fusion)
+    for k in range(nframes):
+        ses.frame(k, fused="four")
+    got = _state_digests(ses, sc)
+    status = ses.scene.counters(ses.rs)["statusFlags"]
+    ses.close()
+    differing = sorted(k for k in oracle_digests if got.get(k) != oracle_digests[k])
+    return {"frames": nframes, "equal": (not differing and status == 0), "what": sorted(oracle_digests),
+            "against": "oracle/libitm_oracle.so (bit-equal to the reference's CPU engines) on the same frames, same fresh scene",
+            "through": "itm_allocate_scene_from_depth + itm_integrate_into_scene + itm_create_expected_depths + itm_create_icp_maps per frame",
+            **({"differing": differing, "statusFlags": status} if (differing or status) else {})}
+
+
+def run_cpu_baseline(config, wl, nframes, on_gpu=True):
     """The CPU oracle (a port of the reference CPU engines, bit-equal to them) on the first `nframes` frames of the same
     workload: single thread, and with OpenMP on all host cores over the loops the reference parallelises
     (ITMSceneReconstructionEngine_CPU.cpp:80,164,348; ITMVisualisationEngine_CPU.cpp:168,211,283).  Beside it, where
@@ -835,9 +903,11 @@ def run_cpu_baseline(config, wl, nframes):
                                           stopIntegratingAtMaxW=wl["stopAtMax"], colour=wl["colour"], trajectory="bench", frames=n, **kw)
     ob = T.oracle_backend()
     _time_cpu(ob, mk("warm", 1, localBlockNum=wl["blocks"]), 1, T)
-    one = _time_cpu(ob, mk("bench_cpu", nframes, localBlockNum=wl["blocks"]), nframes, T)
+    sc_cpu = mk("bench_cpu", nframes, localBlockNum=wl["blocks"])
+    one, oracle_digests = _time_cpu(ob, sc_cpu, nframes, T, digests=True)
     out = {"value": round(one, 3), "unit": "frames/s", "cores": 1, "kind": "port",
            "sample": f"first {nframes} frames of the same workload, oracle/libitm_oracle.so single thread"}
+    parity = run_parity_check(sc_cpu, nframes, oracle_digests, T) if on_gpu else None
     omp = T.oracle_omp_backend()
     if omp is not None:
         n2 = nframes * 2
@@ -853,7 +923,7 @@ def run_cpu_baseline(config, wl, nframes):
             n2 = nframes * 2
             out["reference_engines_all_cores"] = {"value": round(_time_cpu(ro, mk("bench_ref_omp", n2), n2, T), 3), "unit": "frames/s", "cores": cores,
                                                   "kind": "reference", "note": "the same engines built with -fopenmp -DWITH_OPENMP (timing only: the reference's OpenMP allocation loop is racy)"}
-    return out
+    return out, parity
 
 
 def main() -> int:

@@ -240,15 +240,25 @@ int ITM_FN(render_state_destroy)(itm_render_state* rs);
 
 /* ---- the four calls of a frame ----------------------------------------------------------------------------------------------
  * ITMMainEngine::ProcessFrame reaches the engines as AllocateSceneFromDepth -> IntegrateIntoScene (Engine/ITMDenseMapper.cpp:50-57)
- * -> CreateExpectedDepths -> CreateICPMaps (Engine/ITMTrackingController.cpp:30-46).  For hash scenes the first three of the entry
- * points below RECORD their arguments (after checking everything they could be refused for) and return; itm_create_icp_maps for the
- * same view, pose and stream completes the sequence and launches the fused frame of itm_process_frame (5 launches instead of 8).
- * Any other call that names the scene or the render state, any copy / view-builder call of this library that writes an image the
- * recorded view reads, itm_stream_synchronize on the recording stream and itm_flush launch what was recorded first, call by call.
- * Results are identical either way.  What a host must know: the images of the view are read when the sequence is launched -- a host
- * that overwrites them with its OWN kernels or copies between AllocateSceneFromDepth and CreateICPMaps calls itm_flush first (the
- * reference's callers build the view before the tracker runs and never do).  ITM_NO_DEFERRED_FUSION=1 in the environment launches
- * every call at once. */
+ * -> CreateExpectedDepths -> CreateICPMaps (Engine/ITMTrackingController.cpp:30-46).  By DEFAULT each of the entry points below
+ * enqueues its kernels on `stream` before it returns (8 launches per frame), like the reference's CUDA engines on their stream.
+ *
+ * itm_scene_set_deferred_fusion(scene, 1) lets the library fuse the sequence (hash scenes): the first three calls then RECORD their
+ * arguments (after checking everything they could be refused for) and return with NOTHING enqueued; itm_create_icp_maps for the same
+ * view, pose and stream completes the sequence and launches the fused frame of itm_process_frame (5 launches instead of 8).  Any
+ * other call of this library that names the scene or the render state, any copy / view-builder call of this library that writes an
+ * image the recorded view reads, itm_stream_synchronize on the recording stream, itm_flush and itm_render_state_destroy launch what
+ * was recorded first, call by call.  Results are identical either way.  The contract a host accepts by switching it on:
+ *   - the images of the view are read when the sequence is LAUNCHED: they stay valid and unchanged until then -- a host that
+ *     overwrites them with its OWN kernels or copies between AllocateSceneFromDepth and CreateICPMaps calls itm_flush first;
+ *   - stream order only holds from the launching call on: before a hipEventRecord / hipStreamWaitEvent / kernel of the host's own
+ *     that is meant to run behind one of the first three calls, and before it uses a raw pointer from itm_buffer_ptr, the host calls
+ *     itm_flush;
+ *   - the four calls of one frame come from one thread (calls for different scenes may come from different threads).
+ * The reference's callers meet all three (the view is built before the tracker runs, Engine/ITMMainEngine.cpp:111-127, and results
+ * are read through the engines), so the adapters (include/itm_hip_engines.hpp, integration/ITMEngines_HIP.h) switch it on.
+ * Environment: ITM_DEFERRED_FUSION=1 switches it on for every new scene, ITM_NO_DEFERRED_FUSION=1 off whatever the host asked for. */
+int ITM_FN(scene_set_deferred_fusion)(itm_scene* scene, int on);
 int ITM_FN(flush)(itm_scene* scene, itm_render_state* rs, itm_stream stream);   /* scene == rs == NULL: everything recorded on `stream` */
 
 /* ITMSceneReconstructionEngine::AllocateSceneFromDepth(scene, view, trackingState, renderState,
@@ -575,11 +585,11 @@ enum itm_timed_kernel {
   ITM_TK_RAYCAST = 5,       /* GenericRaycast kernel                                       */
   ITM_TK_ICP_MAPS = 6,      /* processPixelICP kernel                                      */
   ITM_TK_EMPTY = 7,         /* itm_profile_calibrate: event pairs with nothing between them          */
-  ITM_TK_COUNT = 7
+  ITM_TK_COUNT = 8
 };
 typedef struct itm_profile {
-  int32_t calls[8];
-  double total_ms[8];
+  int32_t calls[ITM_TK_COUNT];
+  double total_ms[ITM_TK_COUNT];
 } itm_profile;
 /* kernel_mask: bit i enables timing of kernel i (0 disables everything).  Each timed launch costs
  * two hipEventRecord calls on the frame stream. */

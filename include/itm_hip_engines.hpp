@@ -137,6 +137,10 @@ class ITMScene {
     cfg.localBlockNum = localBlockNum; cfg.bucketNum = bucketNum; cfg.excessNum = excessNum;
     cfg.useSwapping = useSwapping ? 1 : 0;        // the scene then owns an ITMGlobalCache in host memory (Objects/ITMScene.h:37-43)
     check(itm_scene_create(&cfg, params, &handle), "itm_scene_create");
+    // the engines below are driven in the reference's call order by hosts that read results through the engines: the library may
+    // record AllocateSceneFromDepth / IntegrateIntoScene / CreateExpectedDepths and launch the fused frame at CreateICPMaps
+    // (include/itm_hip.h, "the four calls of a frame")
+    check(itm_scene_set_deferred_fusion(handle, 1), "itm_scene_set_deferred_fusion");
   }
   ~ITMScene() { itm_scene_destroy(handle); }
   ITMScene(const ITMScene&) = delete;

@@ -232,6 +232,7 @@ _HOST_IO_SIGS = {
                                          C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "debug_dense_classify_check": (C.c_int, [C.POINTER(C.c_int32), C.c_int]),
     "scene_accel_info": (C.c_int, [_P, C.POINTER(AccelInfo)]),
+    "scene_set_deferred_fusion": (C.c_int, [_P, C.c_int]),
     "swap_integrate_global_into_local": (C.c_int, [_P, _P, _P]),
     "swap_save_to_global_memory": (C.c_int, [_P, _P, _P]),
     "global_cache_get": (C.c_int, [_P, C.c_int, _P, C.POINTER(C.c_int)]),
@@ -522,6 +523,12 @@ class Scene:
         ns = None if next_view is None else (next_view if isinstance(next_view, ViewStruct) else next_view.struct())
         self.be.check(self.be.fn["process_frame_ahead"](_P(self.h), C.byref(vs), (C.byref(ns) if ns is not None else None), _P(rs.h), _P(points.ptr), _P(normals.ptr),
                                                         _P(stream)), "process_frame_ahead")
+
+    def set_deferred_fusion(self, on=True):
+        """itm_scene_set_deferred_fusion: the four per-frame engine calls may be recorded and launched as one fused frame (the host
+        accepts the contract in include/itm_hip.h).  A launch-level matter of the product: other implementations of the ABI ignore it."""
+        if "scene_set_deferred_fusion" in self.be.fn:
+            self.be.check(self.be.fn["scene_set_deferred_fusion"](_P(self.h), int(bool(on))), "scene_set_deferred_fusion")
 
     def flush(self, rs: "RenderState" = None, stream=None):
         """Launches the engine calls the library has recorded for this scene / render state (itm_flush)."""

@@ -35,12 +35,12 @@ struct RenderCounters {
 struct Profiler {
   uint32_t mask = 0;
   int every = 1;                 // time every `every`-th launch of an enabled kernel
-  uint32_t tick[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t tick[ITM_TK_COUNT] = {};
   struct Rec { int id; hipEvent_t a, b; };
   std::vector<Rec> pending;
   std::vector<hipEvent_t> pool;
-  double total_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  int32_t calls[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double total_ms[ITM_TK_COUNT] = {};
+  int32_t calls[ITM_TK_COUNT] = {};
   hipEvent_t get();
   void flush();
 };
@@ -102,6 +102,13 @@ struct itm_scene {
   itm::Profiler* prof = nullptr;
   // engine calls recorded but not yet launched (pending.hip): the render state that holds them, or nullptr
   mutable itm_render_state* deferredRs = nullptr;
+  // itm_scene_set_deferred_fusion: the four per-frame engine calls may be recorded and launched as one fused frame (pending.hip).
+  // Off unless the host asks for it (or ITM_DEFERRED_FUSION=1 in the environment at scene creation): a recorded call has enqueued
+  // nothing on its stream when it returns, which a host that orders its own work by stream must know about.
+  bool deferredFusion = false;
+  // every render state created for this scene and not yet destroyed (scene.hip): a scene that goes away first takes its render
+  // states' back pointers with it, so that destroying them afterwards does not touch freed memory
+  mutable std::vector<itm_render_state*> renderStates;
   // itm_process_frame_ahead: the render state whose NEXT frame's block requests are in the table's request keys (one per scene)
   itm_render_state* aheadRs = nullptr;
   // Conditions after which the scene is no longer what the reference would hold (itm_counters::statusFlags): kernels raise them in
@@ -209,6 +216,7 @@ int enter_scene(const itm_scene* s, const itm_render_state* rs);
 int flush_overlapping(const void* p, size_t bytes, hipStream_t st);
 void forget_deferred(itm_render_state* rs);      // the render state is going away
 extern int g_debug_no_deferred_fusion;
+bool deferred_fusion_default();               // ITM_DEFERRED_FUSION=1 in the environment: new scenes record without being asked
 extern int g_debug_force_list_stuck;
 // true when rs holds the block requests of a frame issued ahead (itm_process_frame_ahead): `what` is refused with ITM_ERR_INVALID
 int refuse_while_ahead(const itm_scene* s, const itm_render_state* rs, const char* what);

@@ -6,8 +6,9 @@
 // projection of the visible blocks in the integration launch, the range reduction in the ray cast).  A drop-in back-end is called
 // through the four virtuals, so the fusion has to happen BEHIND them:
 //
-//   * itm_allocate_scene_from_depth, itm_integrate_into_scene and itm_create_expected_depths RECORD their arguments in the render
-//     state (after checking everything they could be refused for) and launch nothing;
+//   * on a scene whose host has asked for it (itm_scene_set_deferred_fusion; never by default: a recorded call has put nothing on its
+//     stream when it returns) itm_allocate_scene_from_depth, itm_integrate_into_scene and itm_create_expected_depths RECORD their
+//     arguments in the render state (after checking everything they could be refused for) and launch nothing;
 //   * itm_create_icp_maps for the same view, pose and stream completes the sequence and launches the fused frame;
 //   * every other entry point that could observe or disturb the recorded calls -- any call naming the scene or the render state, a
 //     copy or a view-builder call that writes an image the recorded view reads, itm_stream_synchronize on the recording stream,
@@ -15,9 +16,12 @@
 //
 // Results are those of the four calls launched one by one, bit for bit (tests/test_deferred_fusion.py).  The contract this adds: the
 // images of the recorded view are read when the sequence is launched, so a host that overwrites them with its OWN kernels or copies
-// (not through this library) between AllocateSceneFromDepth and CreateICPMaps must call itm_flush first.  The reference's callers
-// never do (the view is built before the tracker runs, Engine/ITMMainEngine.cpp:111-127).  ITM_NO_DEFERRED_FUSION=1 in the
-// environment (or debug key 19) launches every call at once, as rounds 1-3 did.
+// (not through this library) between AllocateSceneFromDepth and CreateICPMaps, or orders its own work behind one of the first three
+// calls through the stream (an event, a kernel of its own, a raw pointer from itm_buffer_ptr), must call itm_flush first.  The
+// reference's callers never do (the view is built before the tracker runs, Engine/ITMMainEngine.cpp:111-127; the engines' results are
+// read through the engines), which is why the adapters switch the recording on and a bare C host has to ask for it.
+// ITM_NO_DEFERRED_FUSION=1 in the environment (or debug key 19) launches every call at once whatever the scene says;
+// ITM_DEFERRED_FUSION=1 makes new scenes record without being asked (a host that cannot be recompiled).
 //
 // Also here: the fatal-status check (a scene that raised statusFlags refuses further calls with ITM_ERR_DEVICE) and the guards of
 // itm_process_frame_ahead's pending requests.
@@ -78,14 +82,12 @@ static int fatal_error(const itm_scene* s) {
 int enter_scene(const itm_scene* s, const itm_render_state* rs) {
   if (!s && rs) s = rs->scene;
   if (fatal_raised(s)) return fatal_error(s);
-  if ((s && s->deferredRs) || (rs && rs->deferred.stage)) {
-    std::lock_guard<std::recursive_mutex> lock(g_pendingMutex);
-    int rc = ITM_OK;
-    if (s && s->deferredRs) rc = flush_deferred(s->deferredRs);
-    if (!rc && rs && rs->deferred.stage) rc = flush_deferred(const_cast<itm_render_state*>(rs));
-    return rc;
-  }
-  return ITM_OK;
+  // (the records are read under the lock: flush_overlapping may rewrite them from another thread)
+  std::lock_guard<std::recursive_mutex> lock(g_pendingMutex);
+  int rc = ITM_OK;
+  if (s && s->deferredRs) rc = flush_deferred(s->deferredRs);
+  if (!rc && rs && rs->deferred.stage) rc = flush_deferred(const_cast<itm_render_state*>(rs));
+  return rc;
 }
 
 int flush_overlapping(const void* p, size_t bytes, hipStream_t st) {
@@ -118,7 +120,12 @@ static bool deferral_enabled(const itm_scene* s) {
   static const bool off = [] { const char* e = getenv("ITM_NO_DEFERRED_FUSION"); return e && atoi(e) != 0; }();
   // dense scenes launch the same kernels either way; with swapping the mapper calls the swapping engine between the integration and
   // the ray cast (Engine/ITMDenseMapper.cpp:59-64), which would flush every frame
-  return !off && !g_debug_no_deferred_fusion && s->cfg.indexType == ITM_INDEX_HASH && !s->cfg.useSwapping;
+  return s->deferredFusion && !off && !g_debug_no_deferred_fusion && s->cfg.indexType == ITM_INDEX_HASH && !s->cfg.useSwapping;
+}
+
+bool deferred_fusion_default() {
+  static const bool on = [] { const char* e = getenv("ITM_DEFERRED_FUSION"); return e && atoi(e) != 0; }();
+  return on;
 }
 
 static bool same_images(const itm_view& a, const itm_view& b) { return memcmp(&a, &b, sizeof(itm_view)) == 0; }
@@ -203,6 +210,14 @@ int itm_create_icp_maps(const itm_scene* s, const itm_view* v, itm_render_state*
   const int rc = enter_scene(s, rs);
   if (rc) return rc;
   return launch_icp_maps(s, v, rs, (float4*)points, (float4*)normals, as_stream(stream));
+}
+
+int itm_scene_set_deferred_fusion(itm_scene* s, int on) {
+  if (!s) return set_error(ITM_ERR_INVALID, "null scene");
+  const int rc = enter_scene(s, nullptr);      // what was recorded under the old setting is launched under it
+  if (rc) return rc;
+  s->deferredFusion = on != 0;
+  return ITM_OK;
 }
 
 int itm_flush(itm_scene* s, itm_render_state* rs, itm_stream stream) {

@@ -5,6 +5,7 @@
 //   ITMRenderState(_VH)      Objects/ITMRenderState.h:51-75, Objects/ITMRenderState_VH.h:38-47
 //   view builder conversions DeviceAgnostic/ITMViewBuilder.h:7-28
 #include <atomic>
+#include <mutex>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -417,10 +418,20 @@ int g_debug_no_near_bits = 0;          // debug key 21: set before itm_scene_cre
 static std::atomic<int> g_liveHashScenes[64];
 int live_hash_scenes(int device) { return (device >= 0 && device < 64) ? g_liveHashScenes[device].load() : 2; }
 
+// Render states keep a back pointer to their scene and a scene keeps the list of its render states; either may be destroyed first
+// (hosts with garbage-collected handles destroy in any order).  The list is touched at creation / destruction only.
+static std::mutex g_rsRegistryMutex;
+
 static void free_scene(itm_scene* s) {
   if (!s) return;
   if (s->deferredRs) forget_deferred(s->deferredRs);      // the scene they were recorded for is going away
   if (s->aheadRs) { s->aheadRs->ahead.valid = false; s->aheadRs = nullptr; }
+  {
+    // render states that outlive the scene: nothing recorded or announced on them survives it, and they no longer point at it
+    std::lock_guard<std::mutex> lock(g_rsRegistryMutex);
+    for (itm_render_state* r : s->renderStates) { forget_deferred(r); r->ahead.valid = false; r->scene = nullptr; }
+    s->renderStates.clear();
+  }
   if (s->fatalHost) (void)hipHostFree((void*)s->fatalHost);
   if (s->countedLive && s->device >= 0 && s->device < 64) g_liveHashScenes[s->device].fetch_sub(1);
   free_swap_state(s);
@@ -432,8 +443,17 @@ static void free_scene(itm_scene* s) {
 }
 static void free_rs(itm_render_state* r) {
   if (!r) return;
-  (void)flush_deferred(r);                                // calls recorded on it still happen (pending.hip)
-  if (r->scene && r->scene->aheadRs == r) const_cast<itm_scene*>(r->scene)->aheadRs = nullptr;
+  // r->scene is null when the scene was destroyed first (free_scene above): then nothing is recorded on r any more and there is no
+  // scene to tell.  Otherwise calls recorded on it still happen (pending.hip: the host made them, the reference would have executed
+  // them; the recorded view's images must still be valid -- see itm_scene_set_deferred_fusion in the header).
+  if (r->scene) {
+    (void)flush_deferred(r);
+    std::lock_guard<std::mutex> lock(g_rsRegistryMutex);
+    itm_scene* s = const_cast<itm_scene*>(r->scene);
+    if (s->aheadRs == r) s->aheadRs = nullptr;
+    for (size_t i = 0; i < s->renderStates.size(); ++i)
+      if (s->renderStates[i] == r) { s->renderStates[i] = s->renderStates.back(); s->renderStates.pop_back(); break; }
+  } else forget_deferred(r);
   (void)hipFree(r->range); (void)hipFree(r->raycast); (void)hipFree(r->fwdProj); (void)hipFree(r->missing);
   (void)hipFree(r->image); (void)hipFree(r->visibleIds); (void)hipFree(r->visibleType); (void)hipFree(r->counters);
   (void)hipFree(r->projBuf); (void)hipFree(r->rangePartials); (void)hipFree(r->pixScratch); (void)hipFree(r->rayClass); (void)hipFree(r->pixChunk); (void)hipFree(r->viewFlags); (void)hipFree(r->viewChunkVis);
@@ -615,6 +635,7 @@ int itm_scene_create(const itm_scene_config* cfg_in, const itm_scene_params* prm
       s->fatalHost = (volatile int32_t*)h; s->fatalDev = (int32_t*)d;
     } else { if (h) (void)hipHostFree(h); (void)hipGetLastError(); }
   }
+  s->deferredFusion = deferred_fusion_default();
   *out = s;
   return ITM_OK;
 }
@@ -733,6 +754,7 @@ int itm_render_state_create(const itm_scene* s, int w, int h, itm_render_state**
   fill_range_kernel<<<256, 256, 0, 0>>>(r->range, (int)P, s->prm.viewFrustum_min, s->prm.viewFrustum_max);
   e = hipDeviceSynchronize();
   if (e != hipSuccess) { free_rs(r); return hip_fail(e, "init range image", __FILE__, __LINE__); }
+  { std::lock_guard<std::mutex> lock(g_rsRegistryMutex); s->renderStates.push_back(r); }
   *out = r;
   return ITM_OK;
 }
@@ -779,7 +801,7 @@ int itm_profile_sample(itm_scene* s, int every) {
   if (!s || every < 1) return set_error(ITM_ERR_INVALID, "profile_sample: null scene or every < 1");
   if (!s->prof) s->prof = new Profiler();
   s->prof->every = every;
-  for (int i = 0; i < 8; ++i) s->prof->tick[i] = 0;
+  for (int i = 0; i < ITM_TK_COUNT; ++i) s->prof->tick[i] = 0;
   return ITM_OK;
 }
 // n empty brackets (an event pair with nothing between) on `stream`, accumulated in slot ITM_TK_EMPTY: what an event pair adds to
@@ -799,8 +821,8 @@ int itm_profile_read(itm_scene* s, itm_profile* out, int reset) {
   memset(out, 0, sizeof *out);
   if (!s->prof) return ITM_OK;
   s->prof->flush();
-  for (int i = 0; i < 8; ++i) { out->calls[i] = s->prof->calls[i]; out->total_ms[i] = s->prof->total_ms[i]; }
-  if (reset) for (int i = 0; i < 8; ++i) { s->prof->calls[i] = 0; s->prof->total_ms[i] = 0; }
+  for (int i = 0; i < ITM_TK_COUNT; ++i) { out->calls[i] = s->prof->calls[i]; out->total_ms[i] = s->prof->total_ms[i]; }
+  if (reset) for (int i = 0; i < ITM_TK_COUNT; ++i) { s->prof->calls[i] = 0; s->prof->total_ms[i] = 0; }
   return ITM_OK;
 }
 

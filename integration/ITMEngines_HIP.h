@@ -101,6 +101,9 @@ itm_scene* HipSceneOf(const ITMScene<TVoxel, TIndex>* scene) {
   p.stopIntegratingAtMaxW = sp->stopIntegratingAtMaxW ? 1 : 0;
   itm_scene* dev = nullptr;
   HipCheck(itm_scene_create(&c, &p, &dev), "itm_scene_create");
+  // the reference's callers (ITMDenseMapper::ProcessFrame, ITMTrackingController::Prepare) issue the four per-frame calls back to
+  // back and read results through the engines: the library may record the first three and fuse the frame (include/itm_hip.h)
+  HipCheck(itm_scene_set_deferred_fusion(dev, 1), "itm_scene_set_deferred_fusion");
   r.scenes[scene] = dev;
   return dev;
 }

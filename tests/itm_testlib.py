@@ -106,6 +106,7 @@ class Scenario:
     colour: bool = False
     noise_seed: Optional[int] = None
     origin: tuple = (0.0, 0.0, 0.0)   # metres added to every camera position: the scene and its trajectory far from the world origin (same depth images)
+    frame_stride: int = 1             # frame k of the scenario is position k * frame_stride of its trajectory (bench.py's config 5 keeps every 4th pose)
 
     def params(self):
         return default_params(self.voxelSize, self.mu, self.maxW, 0.35, 3.0, self.stopIntegratingAtMaxW)
@@ -114,6 +115,7 @@ class Scenario:
         return synth.intrinsics_for(self.w, self.h)
 
     def position(self, k):
+        k = k * self.frame_stride
         if self.trajectory == "bench":
             return synth.bench_position(k, self.stream)
         return synth.parity_position(k, self.stream)
@@ -157,19 +159,26 @@ class RunResult:
 class Session:
     """A scene + render state + I/O buffers on one backend."""
 
-    def __init__(self, be: Backend, sc: Scenario):
+    def __init__(self, be: Backend, sc: Scenario, deferred_fusion=True):
         self.be, self.sc = be, sc
         self.scene = be.create_scene(sc.voxelType, sc.indexType, sc.params(), bucketNum=sc.bucketNum,
                                      excessNum=sc.excessNum, localBlockNum=sc.localBlockNum,
                                      denseSize=sc.denseSize, denseOffset=sc.denseOffset,
                                      maxRenderingBlocks=sc.maxRenderingBlocks)
         self.scene.reco.ResetScene()
+        # the sessions of the suite accept the recording contract (include/itm_hip.h, itm_scene_set_deferred_fusion): with fused=False
+        # every call is flushed before the next, with fused="four" the calls are recorded; tests/test_deferred_fusion.py covers a
+        # scene that never asked (the default)
+        self.enable_deferred_fusion(deferred_fusion)
         self.rs = self.scene.vis.CreateRenderState((sc.w, sc.h))
         P = sc.w * sc.h
         self.points = DevBuffer(be, P * 16, np.float32, (sc.h, sc.w, 4))
         self.normals = DevBuffer(be, P * 16, np.float32, (sc.h, sc.w, 4))
         self.rgb = be.to_backend(synth.rgb_frame(sc.w, sc.h)) if sc.colour else None
         self._depth = None
+
+    def enable_deferred_fusion(self, on=True):
+        self.scene.set_deferred_fusion(on)
 
     def view(self, k) -> View:
         sc = self.sc

@@ -55,6 +55,43 @@ def test_four_calls_take_the_fused_launches(hip):
         assert (prof["range"]["calls"] > 0) == separate, (mode, prof)
 
 
+def test_a_scene_that_never_asked_launches_every_call_at_once(hip, oracle):
+    """The default (no itm_scene_set_deferred_fusion): every call has enqueued its kernels when it returns -- the stream order a host
+    with its own events and kernels relies on -- so four calls back to back time the SEPARATE range launches; results are the same."""
+    sc = Scenario(name="not_asked", voxelSize=0.005, frames=3, trajectory="bench")
+    ses = T.Session(hip, sc, deferred_fusion=False)
+    ses.scene.profile_enable(0x7f)
+    for k in range(sc.frames):
+        ses.frame(k, fused="four")
+    prof = ses.scene.profile_read()
+    a = ses.snapshot()
+    ses.close()
+    assert prof["range"]["calls"] > 0 and prof["raycast"]["calls"] == sc.frames, prof
+    b = T.run_scenario(oracle, sc)
+    b.counters = b.counters[-1:]
+    T.compare_results(a, b, sc, what="never asked for the recording")
+
+
+def test_scene_destroyed_before_its_render_state(hip):
+    """Handles are destroyed in any order (garbage-collected hosts): a render state that outlives its scene -- with calls recorded on
+    it, and with requests issued ahead -- is destroyed without touching the scene's memory."""
+    sc = Scenario(name="order", voxelSize=0.01, w=160, h=120, frames=2)
+    for ahead in (False, True):
+        ses = T.Session(hip, sc)
+        v = ses.view(0)
+        if ahead:
+            ses.scene.process_frame_ahead(v, ses.view(1), ses.rs, ses.points, ses.normals)
+        else:
+            ses.scene.reco.AllocateSceneFromDepth(v, ses.rs)          # recorded, never launched
+        ses.scene.close()
+        ses.rs.close()
+        # the library is still healthy
+        b = T.Session(hip, sc)
+        b.frame(0, fused="four")
+        assert b.scene.counters(b.rs)["noVisibleEntries"] > 0
+        b.close()
+
+
 def test_observers_between_the_calls_see_what_the_reference_would(hip, oracle):
     """A read between two of the calls launches what was recorded: the table after the allocation alone, the voxels after the
     integration alone, the range image after CreateExpectedDepths alone -- all equal to the oracle's at that point."""
