@@ -26,7 +26,7 @@ INDEX_HASH, INDEX_DENSE = 0, 1
 RENDER_SHADED_GREYSCALE, RENDER_COLOUR_FROM_VOLUME, RENDER_COLOUR_FROM_NORMAL = 0, 1, 2
 (BUF_HASH_ENTRIES, BUF_EXCESS_LIST, BUF_VOXEL_BLOCKS, BUF_ALLOCATION_LIST, BUF_VISIBLE_IDS,
  BUF_VISIBLE_TYPE, BUF_RANGE_IMAGE, BUF_RAYCAST_RESULT, BUF_RAYCAST_IMAGE, BUF_FORWARD_PROJECTION,
- BUF_MISSING_POINTS, BUF_SWAP_STATES, BUF_NEAR_BITS) = range(13)
+ BUF_MISSING_POINTS, BUF_SWAP_STATES) = range(12)
 ERR_INVALID, ERR_DEVICE, ERR_UNSUPPORTED = -1, -2, -3
 
 VOXEL_NAMES = {VOXEL_S: "ITMVoxel_s", VOXEL_F: "ITMVoxel_f", VOXEL_S_RGB: "ITMVoxel_s_rgb",
@@ -129,9 +129,11 @@ def header_path() -> str:
 
 
 def declared_functions() -> list:
-    """Names declared through ITM_FN(...) in include/itm_hip.h."""
-    with open(header_path()) as f:
-        text = f.read()
+    """Names declared through ITM_FN(...) in include/itm_hip.h (the boundary) and include/itm_debug.h (the test hooks)."""
+    text = ""
+    for path in (header_path(), os.path.join(os.path.dirname(header_path()), "itm_debug.h")):
+        with open(path) as f:
+            text += f.read()
     names = re.findall(r"ITM_FN\((\w+)\)\s*\(", text)
     return sorted(set(n for n in names if n != "name"))
 
@@ -140,7 +142,7 @@ class AccelInfo(C.Structure):
     """itm_accel_info (include/itm_hip.h)."""
     _fields_ = [("directory_bytes", C.c_int64), ("slot_directory_bytes", C.c_int64), ("mirror_bytes", C.c_int64),
                 ("origin_directory", C.c_int32 * 3), ("origin_mirror", C.c_int32 * 3), ("placed", C.c_int32), ("moves", C.c_int64),
-                ("mirror_pages", C.c_int32), ("mirror_pages_mapped", C.c_int32), ("near_bits_bytes", C.c_int64)]
+                ("mirror_pages", C.c_int32), ("mirror_pages_mapped", C.c_int32)]
 
 
 class ItmError(RuntimeError):
@@ -452,7 +454,7 @@ class Scene:
                 BUF_VISIBLE_IDS: np.dtype("<i4"), BUF_VISIBLE_TYPE: np.dtype("u1"),
                 BUF_RANGE_IMAGE: np.dtype("<f4"), BUF_RAYCAST_RESULT: np.dtype("<f4"),
                 BUF_RAYCAST_IMAGE: np.dtype("u1"), BUF_FORWARD_PROJECTION: np.dtype("<f4"),
-                BUF_MISSING_POINTS: np.dtype("<i4"), BUF_SWAP_STATES: np.dtype("u1"), BUF_NEAR_BITS: np.dtype("u1")}[which]
+                BUF_MISSING_POINTS: np.dtype("<i4"), BUF_SWAP_STATES: np.dtype("u1")}[which]
 
     def profile_enable(self, mask: int):
         self.be.check(self.be.fn["profile_enable"](_P(self.h), mask), "profile_enable")
@@ -510,7 +512,7 @@ class Scene:
         a = AccelInfo()
         self.be.check(self.be.fn["scene_accel_info"](_P(self.h), C.byref(a)), "scene_accel_info")
         return {"directory_bytes": a.directory_bytes, "slot_directory_bytes": a.slot_directory_bytes, "mirror_bytes": a.mirror_bytes,
-                "near_bits_bytes": a.near_bits_bytes, "mirror_pages": a.mirror_pages, "mirror_pages_mapped": a.mirror_pages_mapped, "origin_directory": list(a.origin_directory), "origin_mirror": list(a.origin_mirror), "placed": bool(a.placed), "moves": a.moves}
+                "mirror_pages": a.mirror_pages, "mirror_pages_mapped": a.mirror_pages_mapped, "origin_directory": list(a.origin_directory), "origin_mirror": list(a.origin_mirror), "placed": bool(a.placed), "moves": a.moves}
 
     def process_frame(self, view: View, rs: "RenderState", points: DevBuffer, normals: DevBuffer, stream=None):
         """ITMDenseMapper::ProcessFrame + ITMTrackingController::Prepare (Engine/ITMMainEngine.cpp:123-126)."""

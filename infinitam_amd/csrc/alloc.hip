@@ -76,15 +76,6 @@ __device__ inline void replay_block_pos(uint32_t key, float d, const AllocParams
 
 constexpr int kSlotsPerThread = kSweepChunk / 256;  // 8
 
-// The blocks a chunk's sweep has just allocated, queued in LDS: their near bits (itm_types.h: 15 x 15 x 15 cells each) are set by the
-// whole workgroup once the chunk's count is out -- off the path the later chunks' look-backs wait for.
-struct NewBlocks { short4 block[kSweepChunk]; int count; };
-// (to be called by every thread of the workgroup, behind a barrier that follows the sweep)
-__device__ inline void splat_new_blocks(const NewBlocks* fresh, uint32_t* __restrict__ nearWords, const AccelOrigin& org) {
-  const int n = fresh->count;
-  for (int k = 0; k < n; ++k) near_bits_splat(nearWords, org, fresh->block[k].x, fresh->block[k].y, fresh->block[k].z, (int)threadIdx.x, 256);
-}
-
 // Ascending-slot allocation sweep (_CPU.cpp:175-227).  chunkReq holds, per 2048-slot chunk, the
 // number of requested slots and of excess-list requests; next-frame counters are zeroed here.
 // The sweep of ONE chunk by its workgroup.  ACROSS: the visible type of a new excess entry lies in another chunk; when the visible
@@ -96,13 +87,12 @@ __device__ inline void sweep_chunk(const int chunk, int* lds, uint32_t* __restri
                                    const int32_t* __restrict__ excessList, const int32_t* __restrict__ allocList,
                                    uint8_t* __restrict__ visT, const SceneCounters* __restrict__ counters,
                                    uint32_t* __restrict__ headBits, int32_t* __restrict__ dirPtr, int32_t* __restrict__ dirSlot, void* __restrict__ sdfMirror,
-                                   const float* __restrict__ depth, int lazy, const AllocParams& p, NewBlocks* fresh) {
+                                   const float* __restrict__ depth, int lazy, const AllocParams& p) {
 
   const int tid = threadIdx.x;
   if (tid == 0) chunkReqNext[chunk] = make_int2(0, 0);
   const int2 mine = chunkReq[chunk];
   if (mine.x == 0) return;  // nothing requested in this chunk (uniform per workgroup)
-  if (fresh && tid == 0) fresh->count = 0;      // (the barriers of the scans below order this before the first append)
 
   // The sweep of a chunk with requests is a chain of dependent loads (keys -> entry / depth pixel -> free-list slot), and the
   // whole visible-list launch waits for the slowest such chunk (per-workgroup timeline, tools/list_timeline.py: 8.9 us for it, 1 us
@@ -173,7 +163,6 @@ __device__ inline void sweep_chunk(const int chunk, int* lds, uint32_t* __restri
         else visT[p.bucketNum + off] = lazy ? 0x81 : 1;
         directory_insert(dirPtr, dirSlot, p.org, bx, by, bz, ptr, p.bucketNum + off);
         mirror_init_block(sdfMirror, p.mirrorFloat != 0, p.org, bx, by, bz);
-        if (fresh) fresh->block[atomicAdd(&fresh->count, 1)] = make_short4((short)bx, (short)by, (short)bz, 0);
       }
     } else if (vbaIdx[k] >= 0) {
       int bx, by, bz;
@@ -183,7 +172,6 @@ __device__ inline void sweep_chunk(const int chunk, int* lds, uint32_t* __restri
       atomicOr(&headBits[slot >> 5], 1u << (slot & 31));
       directory_insert(dirPtr, dirSlot, p.org, bx, by, bz, ptr, slot);
       mirror_init_block(sdfMirror, p.mirrorFloat != 0, p.org, bx, by, bz);
-      if (fresh) fresh->block[atomicAdd(&fresh->count, 1)] = make_short4((short)bx, (short)by, (short)bz, 0);
     }
     allocKey[slot] = 0u;
   }
@@ -194,20 +182,9 @@ __global__ void __launch_bounds__(256) allocate_sweep_kernel(uint32_t* __restric
                                                              const int32_t* __restrict__ excessList, const int32_t* __restrict__ allocList,
                                                              uint8_t* __restrict__ visT, const SceneCounters* __restrict__ counters,
                                                              uint32_t* __restrict__ headBits, int32_t* __restrict__ dirPtr, int32_t* __restrict__ dirSlot, void* __restrict__ sdfMirror,
-                                                             const float* __restrict__ depth, int lazy, AllocParams p, uint32_t* __restrict__ nearWords) {
+                                                             const float* __restrict__ depth, int lazy, AllocParams p) {
   __shared__ int lds[8];
-#if ITM_NEAR_BITS
-  __shared__ NewBlocks fresh;
-  sweep_chunk<false>((int)blockIdx.x, lds, allocKey, chunkReq, chunkReqNext, numChunks, hash, excessList, allocList, visT, counters, headBits, dirPtr, dirSlot, sdfMirror, depth, lazy, p,
-                     nearWords ? &fresh : nullptr);
-  if (nearWords && chunkReq[blockIdx.x].x > 0) {      // (uniform)
-    __syncthreads();
-    splat_new_blocks(&fresh, nearWords, p.org);
-  }
-#else
-  (void)nearWords;
-  sweep_chunk<false>((int)blockIdx.x, lds, allocKey, chunkReq, chunkReqNext, numChunks, hash, excessList, allocList, visT, counters, headBits, dirPtr, dirSlot, sdfMirror, depth, lazy, p, nullptr);
-#endif
+  sweep_chunk<false>((int)blockIdx.x, lds, allocKey, chunkReq, chunkReqNext, numChunks, hash, excessList, allocList, visT, counters, headBits, dirPtr, dirSlot, sdfMirror, depth, lazy, p);
 }
 
 // checkBlockVisibility<false>: corners are reached by incremental +-f updates in a fixed order.
@@ -362,12 +339,9 @@ struct SweepArgs {
   uint32_t* sweepDone;     // per chunk: the epoch of the launch whose sweep has placed the chunk's excess allocations
   int32_t* fatalDev;       // the scene's host-visible status word (alloc_device.h: raise_fatal)
   int forceStuck;          // test hook (debug key 20): chunk whose wait is treated as expired, or -1
-  uint32_t* nearWords;     // near bits of the mirror's cube (itm_types.h), or nullptr
 };
 
-#ifndef ITM_LIST_SPIN_SLEEP
-#define ITM_LIST_SPIN_SLEEP 1        // s_sleep argument between two polls of a predecessor's granule in the look-back (x 64 cycles)
-#endif
+constexpr int kListSpinSleep = 1;    // s_sleep argument between two polls of a predecessor's granule in the look-back (x 64 cycles)
 #ifndef ITM_EXP_LIST_STAMPS
 #define ITM_EXP_LIST_STAMPS 0     // measurement build: per-workgroup timeline of the visible-list launch (100 MHz clock)
 #endif
@@ -399,12 +373,6 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
                                                            int32_t* __restrict__ ids, int capIds, RenderCounters* __restrict__ rc, AllocParams p, SweepArgs sw) {
   __shared__ int lds[12];
   __shared__ int sweepLds[8];
-#if ITM_NEAR_BITS
-  __shared__ NewBlocks fresh;
-  NewBlocks* const freshPtr = (SWEEP && sw.nearWords) ? &fresh : nullptr;
-#else
-  NewBlocks* const freshPtr = nullptr;       // (builds without near bits, the default: no 16 KB queue in LDS)
-#endif
   const int tid = threadIdx.x;
   // the chunk's stores must have COMPLETED before its stamp may follow: on gfx950 a workgroup-scope release fence is only
   // s_waitcnt lgkmcnt(0) -- it does not wait for vector stores -- so the wait is spelled out (loads and stores share vmcnt);
@@ -427,7 +395,7 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
       unsigned long long g = __hip_atomic_load(&chunkGran[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       for (int spin = 0; (uint32_t)(g >> 32) != epoch; ++spin) {
         if (spin > (1 << 22)) { stuck = true; break; }
-        __builtin_amdgcn_s_sleep(ITM_LIST_SPIN_SLEEP);
+        __builtin_amdgcn_s_sleep(kListSpinSleep);
         g = __hip_atomic_load(&chunkGran[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       before += (int)(uint32_t)g;
@@ -455,7 +423,7 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
   }
   if constexpr (SWEEP) {
     sweep_chunk<true>(chunk, sweepLds, sw.allocKey, chunkReq, sw.chunkReqNext, numChunks, hash, sw.excessList, sw.allocList, visT, counters, sw.headBits,
-                      sw.dirPtr, sw.dirSlot, sw.sdfMirror, sw.depth, sw.lazy, p, freshPtr);
+                      sw.dirPtr, sw.dirSlot, sw.sdfMirror, sw.depth, sw.lazy, p);
     if (chunkReq[chunk].y > 0) stamp_sweep(chunk);           // (uniform) only excess allocations are read by other workgroups of this launch
     if (excessRegion) {
       // every chunk that had excess requests (any index: no sweep waits for anything, so this cannot cycle) must be through
@@ -523,11 +491,6 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
   if (tid == 0)
     __hip_atomic_store(&chunkGran[chunk], ((unsigned long long)epoch << 32) | (unsigned long long)(uint32_t)mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   ITM_LS(2)
-  if constexpr (SWEEP) {
-    // the chunk's count is out: the near bits of the blocks its sweep allocated, while the look-back would only wait (block_exclusive_scan
-    // above was the barrier behind the sweep)
-    if (freshPtr && chunkReq[chunk].x > 0) splat_new_blocks(freshPtr, sw.nearWords, p.org);
-  }
   // base = visible slots in all earlier chunks
   look_back();
   ITM_LS(3)
@@ -733,7 +696,7 @@ int launch_sweep_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, bo
     if (!fusedSweep) {
       KernelTimer ts(s, ITM_TK_ALLOC_SWEEP, st);
       allocate_sweep_kernel<<<nChunks, 256, 0, st>>>(s->allocKey, reqCur, reqNext, nChunks, s->hash, s->excessList, s->allocList,
-                                                     rs->visibleType, s->counters, s->headBits, s->dirPtr, s->dirSlot, s->sdfMirror, v->depth, lazy ? 1 : 0, p, s->nearBits);
+                                                     rs->visibleType, s->counters, s->headBits, s->dirPtr, s->dirSlot, s->sdfMirror, v->depth, lazy ? 1 : 0, p);
     }
     s->frameParity++;
   }
@@ -741,7 +704,7 @@ int launch_sweep_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, bo
   if (onePass) {
     const uint32_t epoch = ++s->listEpoch;
     const SweepArgs sw{s->allocKey, reqNext, s->excessList, s->allocList, s->headBits, s->dirPtr, s->dirSlot, s->sdfMirror, v->depth, lazy ? 1 : 0, s->chunkSweepDone,
-                       s->fatalDev, fusedSweep ? g_debug_force_list_stuck - 1 : -1, s->nearBits};
+                       s->fatalDev, fusedSweep ? g_debug_force_list_stuck - 1 : -1};
 #define ITM_VL(CM, LZ, SW) visible_list_kernel<CM, LZ, SW><<<nChunks, 256, 0, st>>>(rs->visibleType, s->hash, s->chunkGran, epoch, reqCur, nChunks, s->counters, rs->visibleIds, rs->capIds, rs->counters, p, sw)
     if (onlyVisible) { if (lazy) ITM_VL(false, true, false); else ITM_VL(false, false, false); }
     else if (fusedSweep) { if (lazy) ITM_VL(true, true, true); else ITM_VL(true, false, true); }

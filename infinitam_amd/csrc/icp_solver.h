@@ -6,6 +6,7 @@
 #include <cstring>
 
 #include "../../include/itm_hip.h"
+#include "../../include/itm_debug.h"      // itm_icp_evaluate_fn (the host-only test hook drives this solver)
 #include "se3.h"
 
 namespace itm {

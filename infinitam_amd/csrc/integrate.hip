@@ -24,14 +24,10 @@ namespace itm {
 #ifndef ITM_EXP_FUSED_STAMPS
 #define ITM_EXP_FUSED_STAMPS 0
 #endif
-#ifndef ITM_PROJECTION_PRIORITY
-#define ITM_PROJECTION_PRIORITY 1
-#endif
 #ifndef ITM_MIRROR_FLOAT_TYPES
 #define ITM_MIRROR_FLOAT_TYPES 0     // (scene.hip decides whether a float scene gets a mirror; the same switch must be given to both files)
 #endif
 int g_debug_integrate_wgs = 0;
-int g_debug_integrate_block_per_wave = 0;   // debug key 22: the hash integration with 16 bytes per lane, a whole block per wave (integrate_block_x4)
 int g_debug_no_fused_projection = 0;
 int g_debug_dense_group_cull = 0;   // debug key 9: per-group frustum test instead of the per-column row interval
 int g_debug_dense_no_strips = 0;    // debug key 17: the launch shape of rounds 1-2 (four groups per lane) instead of the strip kernel
@@ -218,28 +214,15 @@ __device__ inline bool fuse_voxel(typename VX::Reg& r, float mx, float my, float
 // requested before it starts on the current one, and the x / y partial sums of the projection are shared by the slices.
 // (Two x-neighbours per lane with packed fp32 arithmetic -- v_pk_mul / add / fma_f32, bit-exact -- was built and measured first:
 // -8 % VALU instructions, but +5 % time; the kernels are not VALU bound.)
-#ifndef ITM_INTEGRATE_SLICES
-#define ITM_INTEGRATE_SLICES 4
-#endif
-#ifndef ITM_INTEGRATE_SLICES_SHORT
-// ITMVoxel_s (4 bytes, 36 registers): the whole block per item -- eight runs in flight per wave.  Measured at the end of round 4 (BASELINE
-// configs[1], integration + projection launch): 2 slices 22.5-23.0 us, 4: 20.4-20.5, 8: 19.2-19.5; the 12-byte ITMVoxel_f_rgb loses with 8
-// (configs[4]: 178 -> 196 us, registers), so the other types keep ITM_INTEGRATE_SLICES.
-#define ITM_INTEGRATE_SLICES_SHORT 8
-#endif
-template <class VX> __host__ __device__ constexpr int slices_of() { return VX::kBytes == 4 ? ITM_INTEGRATE_SLICES_SHORT : ITM_INTEGRATE_SLICES; }
-static_assert(ITM_INTEGRATE_SLICES == 1 || ITM_INTEGRATE_SLICES == 2 || ITM_INTEGRATE_SLICES == 4 || ITM_INTEGRATE_SLICES == 8, "slice groups tile the block");
-static_assert(ITM_INTEGRATE_SLICES_SHORT == 1 || ITM_INTEGRATE_SLICES_SHORT == 2 || ITM_INTEGRATE_SLICES_SHORT == 4 || ITM_INTEGRATE_SLICES_SHORT == 8, "slice groups tile the block");
-
-#ifndef ITM_INTEGRATE_NT
-// bit 0: the 4-byte voxels, bit 1: the mirror values are stored with the non-temporal hint (measurement switch)
-#define ITM_INTEGRATE_NT 0
-#endif
-#ifndef ITM_INTEGRATE_PREFETCH
-// 1: the voxel runs of the wave's NEXT item are requested right behind the depth gathers of the current one.  Measured: BASELINE
-// configs[4] 189 -> 198 us (the second register set costs a wave of occupancy, 76 -> 92 VGPRs), configs[1] +-0.  Off.
-#define ITM_INTEGRATE_PREFETCH 0
-#endif
+// Slices per item: 4 (1 / 2 / 8: 243 / 211 / 195 us against 186 on BASELINE configs[4] when it was chosen).  ITMVoxel_s (4 bytes, 36 registers)
+// takes the whole block per item -- eight runs in flight per wave; end of round 4, BASELINE configs[1], integration + projection launch:
+// 2 slices 22.5-23.0 us, 4: 20.4-20.5, 8: 19.2-19.5; the 12-byte ITMVoxel_f_rgb loses with 8 (configs[4]: 178 -> 196 us, registers).
+// (Also measured and not kept, profiles/r4_integrate_notes.md: a whole block per wave with 16 bytes per lane, for all four voxel types --
+// configs[1] 19.9 -> 20.8-22.1 us, configs[4] 180 -> 264; the next item's voxel runs requested behind the depth gathers -- configs[4]
+// 189 -> 198 us, the second register set costs a wave of occupancy; non-temporal stores of the voxels or of the mirror values: +-0 / +2 us
+// on the ray cast that follows.)
+constexpr int kIntegrateSlices = 4, kIntegrateSlicesShort = 8;
+template <class VX> __host__ __device__ constexpr int slices_of() { return VX::kBytes == 4 ? kIntegrateSlicesShort : kIntegrateSlices; }
 
 template <class VX>
 __device__ inline void load_item(const HashEntry& he, int z0, int lane, const void* __restrict__ vba, typename VX::Reg r[slices_of<VX>()]) {
@@ -249,13 +232,10 @@ __device__ inline void load_item(const HashEntry& he, int z0, int lane, const vo
   for (int k = 0; k < kSlices; ++k) r[k] = VX::load(vba, vi + 64 * k);
 }
 
-// r: the item's voxels (already requested).  hasNext / next / nextR: the voxel runs of the following item are requested right
-// behind the depth gathers -- the wave then waits for those gathers only (the memory counter retires in issue order), and the new
-// runs travel while this item is updated and stored.
+// r: the item's voxels (already requested)
 template <class VX>
 __device__ inline void integrate_item(const HashEntry& he, int z0, int lane, typename VX::Reg r[slices_of<VX>()], void* __restrict__ vba, void* __restrict__ sdfMirror,
-                                      const float* __restrict__ depth, const uchar4* __restrict__ rgb, const FuseParams& p,
-                                      bool hasNext, const HashEntry& next, int nextZ0, typename VX::Reg nextR[slices_of<VX>()]) {
+                                      const float* __restrict__ depth, const uchar4* __restrict__ rgb, const FuseParams& p) {
   constexpr int kSlices = slices_of<VX>();
   const bool present = he.ptr >= 0;
   const int x = lane & 7, y = lane >> 3;
@@ -284,7 +264,6 @@ __device__ inline void integrate_item(const HashEntry& he, int z0, int lane, typ
   float dm[kSlices];
 #pragma unroll
   for (int k = 0; k < kSlices; ++k) dm[k] = depth[pix[k] >= 0 ? pix[k] : 0];
-  if (hasNext) load_item<VX>(next, nextZ0, lane, vba, nextR);
 #pragma unroll
   for (int k = 0; k < kSlices; ++k) {
     if (pix[k] == -2) continue;
@@ -297,19 +276,8 @@ __device__ inline void integrate_item(const HashEntry& he, int z0, int lane, typ
       }
     }
     if (touched) {
-#if ITM_INTEGRATE_NT & 1
-      if constexpr (VX::kBytes == 4) __builtin_nontemporal_store(r[k], (uint32_t*)vba + vi + 64 * k); else VX::store(vba, vi + 64 * k, r[k]);
-#else
       VX::store(vba, vi + 64 * k, r[k]);
-#endif
-      if (mirror) {
-        typename MC::T* const at = mirror + mbase + mirror_block_voxel((uint32_t)x, (uint32_t)y, (uint32_t)(z0 + k));     // sdf mirror (itm_types.h)
-#if ITM_INTEGRATE_NT & 2
-        __builtin_nontemporal_store(MC::of(VX::raw_sdf(r[k])), at);
-#else
-        *at = MC::of(VX::raw_sdf(r[k]));
-#endif
-      }
+      if (mirror) mirror[mbase + mirror_block_voxel((uint32_t)x, (uint32_t)y, (uint32_t)(z0 + k))] = MC::of(VX::raw_sdf(r[k]));     // sdf mirror (itm_types.h)
     }
   }
 }
@@ -327,7 +295,7 @@ __device__ inline void integrate_hash_body(int wgIdx, int wgCount, const int32_t
   int i = __builtin_amdgcn_readfirstlane(wgIdx * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6));
   if (i >= nItems) return;
   HashEntry cur = unpack_entry(hash[visibleIds[i / kItemsPerBlock]]);
-  typename VX::Reg r[kSlices], rn[kSlices];
+  typename VX::Reg r[kSlices];
   load_item<VX>(cur, (i % kItemsPerBlock) * kSlices, lane, vba, r);
   for (;;) {
     const int nxt = i + waves;
@@ -335,167 +303,11 @@ __device__ inline void integrate_hash_body(int wgIdx, int wgCount, const int32_t
     HashEntry ahead = cur;
     if (more) ahead = unpack_entry(hash[visibleIds[nxt / kItemsPerBlock]]);
     const int zn = (nxt % kItemsPerBlock) * kSlices;
-#if ITM_INTEGRATE_PREFETCH
-    integrate_item<VX>(cur, (i % kItemsPerBlock) * kSlices, lane, r, vba, sdfMirror, depth, rgb, p, more, ahead, zn, rn);
-    if (!more) break;
-#pragma unroll
-    for (int k = 0; k < kSlices; ++k) r[k] = rn[k];
-#else
-    integrate_item<VX>(cur, (i % kItemsPerBlock) * kSlices, lane, r, vba, sdfMirror, depth, rgb, p, false, ahead, 0, rn);
+    integrate_item<VX>(cur, (i % kItemsPerBlock) * kSlices, lane, r, vba, sdfMirror, depth, rgb, p);
     if (!more) break;
     load_item<VX>(ahead, zn, lane, vba, r);
-#endif
     cur = ahead; i = nxt;
   }
-}
-
-// ---- 16 bytes per lane (round 4) ----------------------------------------------------------------------------------------------
-// Work item = a WHOLE block by one wave: lane l owns the four x-consecutive voxels [4 l, 4 l + 4) of each half of the block (a block
-// is x + 8 y + 64 z: lane l <-> x0 = 4 (l & 1), y = (l >> 1) & 7, z = (l >> 4) + 4 half), moved with 128-bit accesses -- for
-// ITMVoxel_s one dwordx4 per half (the wave's load instruction covers 1 KB, where one voxel per lane covered 256 B: a quarter of the
-// memory instructions, twice the bytes in flight per wave), for the 8-byte types two, for ITMVoxel_f_rgb three.  A group is stored
-// back whole when any of its voxels changed (nobody else writes the block), the mirror gets the group's four sdf values as one store.
-// Per voxel the arithmetic is the slice kernel's, operation for operation (fuse_depth_project / fuse_depth_update / fuse_colour).
-template <class VX> struct Group;      // four consecutive voxels as the registers they arrive in
-template <> struct Group<VoxelS> {
-  uint4 q;
-  __device__ void load(const void* vba, size_t g) { q = ((const uint4*)vba)[g]; }
-  __device__ void store(void* vba, size_t g) const { ((uint4*)vba)[g] = q; }
-  __device__ VoxelS::Reg get(int k) const { return k == 0 ? q.x : k == 1 ? q.y : k == 2 ? q.z : q.w; }
-  __device__ void set(int k, VoxelS::Reg r) { if (k == 0) q.x = r; else if (k == 1) q.y = r; else if (k == 2) q.z = r; else q.w = r; }
-};
-template <class VX8> struct Group8 {   // the 8-byte voxel types: two voxels per dwordx4
-  uint4 q[2];
-  __device__ void load(const void* vba, size_t g) { q[0] = ((const uint4*)vba)[2 * g]; q[1] = ((const uint4*)vba)[2 * g + 1]; }
-  __device__ void store(void* vba, size_t g) const { ((uint4*)vba)[2 * g] = q[0]; ((uint4*)vba)[2 * g + 1] = q[1]; }
-  __device__ uint2 get(int k) const { const uint4& v = q[k >> 1]; return (k & 1) ? make_uint2(v.z, v.w) : make_uint2(v.x, v.y); }
-  __device__ void set(int k, uint2 r) { uint4& v = q[k >> 1]; if (k & 1) { v.z = r.x; v.w = r.y; } else { v.x = r.x; v.y = r.y; } }
-};
-template <> struct Group<VoxelF> : Group8<VoxelF> {};
-template <> struct Group<VoxelSRgb> : Group8<VoxelSRgb> {};
-template <> struct Group<VoxelFRgb> {  // 12-byte voxels: four of them are three dwordx4
-  uint32_t w[12];
-  __device__ void load(const void* vba, size_t g) {
-    const uint4* p = (const uint4*)vba + 3 * g;
-    const uint4 a = p[0], b = p[1], c = p[2];
-    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w; w[8] = c.x; w[9] = c.y; w[10] = c.z; w[11] = c.w;
-  }
-  __device__ void store(void* vba, size_t g) const {
-    uint4* p = (uint4*)vba + 3 * g;
-    p[0] = make_uint4(w[0], w[1], w[2], w[3]); p[1] = make_uint4(w[4], w[5], w[6], w[7]); p[2] = make_uint4(w[8], w[9], w[10], w[11]);
-  }
-  __device__ VoxelFRgb::Reg get(int k) const { VoxelFRgb::Reg r; r.a = w[3 * k]; r.b = w[3 * k + 1]; r.c = w[3 * k + 2]; return r; }
-  __device__ void set(int k, VoxelFRgb::Reg r) { w[3 * k] = r.a; w[3 * k + 1] = r.b; w[3 * k + 2] = r.c; }
-};
-
-template <class VX>
-__device__ inline void integrate_block_x4(const HashEntry& he, int lane, Group<VX> grp[2], void* __restrict__ vba, void* __restrict__ sdfMirror,
-                                          const float* __restrict__ depth, const uchar4* __restrict__ rgb, const FuseParams& p) {
-  const bool present = he.ptr >= 0;
-  const int x0 = (lane & 1) * 4, y = (lane >> 1) & 7, zl = lane >> 4;
-  const size_t g0 = (size_t)(present ? he.ptr : 0) * (kBlockVoxels / 4) + lane;      // group index of the first half; + 64 for the second
-  const float my = (float)(he.py * kBlockSide + y) * p.voxelSize;
-  using MC = MirrorCodec<VX::kShort>;
-  size_t mbase = 0;
-  typename MC::T* mirror = nullptr;
-  // (the block's page was mapped when the block was allocated; the table entry is requested here, beside the voxels, and used at the end.
-  // The float voxel types carry no mirror unless built with ITM_MIRROR_FLOAT_TYPES: their kernels do not carry its code either -- two
-  // registers more and ITMVoxel_f_rgb drops from six waves per SIMD to five, 180 -> 203 us on BASELINE configs[4])
-  if constexpr (VX::kShort || ITM_MIRROR_FLOAT_TYPES) {
-    if (sdfMirror && mirror_block_base<false>(p.org, he.px, he.py, he.pz, mbase)) mirror = (typename MC::T*)sdfMirror;
-  }
-  // stage 1: project the eight voxels; stage 2: their depth pixels together; stage 3: update (+ colour), store the groups that changed
-  int pix[8];
-  float pcz[8], mx[4], mz[2];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) mx[k] = (float)(he.px * kBlockSide + x0 + k) * p.voxelSize;
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    mz[h] = (float)(he.pz * kBlockSide + zl + 4 * h) * p.voxelSize;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int j = 4 * h + k;
-      pix[j] = -2;                                                            // -2: voxel skipped altogether (no block / stopIntegratingAtMaxW)
-      if (!present || (p.stopAtMax && VX::w_depth(grp[h].get(k)) == p.maxW)) continue;
-      pix[j] = fuse_depth_project(mx[k], my, mz[h], p, pcz[j]);
-    }
-  }
-  float dm[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) dm[j] = depth[pix[j] >= 0 ? pix[j] : 0];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    bool any = false;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int j = 4 * h + k;
-      if (pix[j] == -2) continue;
-      typename VX::Reg r = grp[h].get(k);
-      bool touched = false;
-      const float eta = (pix[j] >= 0) ? fuse_depth_update<VX>(r, dm[j], pcz[j], p, touched) : -1.0f;
-      if constexpr (VX::kColor) {
-        if (!((eta > p.mu) || (fabsf(eta / p.mu) > 0.25f))) {
-          fuse_colour<VX>(r, mx[k], my, mz[h], rgb, p);
-          touched = true;
-        }
-      }
-      if (touched) { grp[h].set(k, r); any = true; }
-    }
-    if (any) {
-      grp[h].store(vba, g0 + 64 * h);
-      if (mirror) {
-        // the group's four sdf values as one store (8 bytes for the short types, 16 for the float ones): a voxel that did not change
-        // is rewritten with the value it holds
-        const size_t mi = mbase + mirror_block_voxel((uint32_t)x0, (uint32_t)y, (uint32_t)(zl + 4 * h));
-        if constexpr (VX::kShort) {
-          const uint32_t a = (uint32_t)(uint16_t)MC::of(VX::raw_sdf(grp[h].get(0))) | ((uint32_t)(uint16_t)MC::of(VX::raw_sdf(grp[h].get(1))) << 16);
-          const uint32_t b = (uint32_t)(uint16_t)MC::of(VX::raw_sdf(grp[h].get(2))) | ((uint32_t)(uint16_t)MC::of(VX::raw_sdf(grp[h].get(3))) << 16);
-          *(uint2*)(mirror + mi) = make_uint2(a, b);
-        } else {
-          *(uint4*)(mirror + mi) = make_uint4(MC::of(VX::raw_sdf(grp[h].get(0))), MC::of(VX::raw_sdf(grp[h].get(1))), MC::of(VX::raw_sdf(grp[h].get(2))), MC::of(VX::raw_sdf(grp[h].get(3))));
-        }
-      }
-    }
-  }
-}
-
-template <class VX>
-__device__ inline void load_block_x4(const HashEntry& he, int lane, const void* __restrict__ vba, Group<VX> grp[2]) {
-  const size_t g0 = (size_t)(he.ptr < 0 ? 0 : he.ptr) * (kBlockVoxels / 4) + lane;      // block 0 is always there
-  grp[0].load(vba, g0);
-  grp[1].load(vba, g0 + 64);
-}
-
-template <class VX>
-__device__ inline void integrate_hash_body_x4(int wgIdx, int wgCount, const int32_t* __restrict__ visibleIds, RenderCounters* __restrict__ rc,
-                                              const uint4* __restrict__ hash, void* __restrict__ vba, void* __restrict__ sdfMirror,
-                                              const float* __restrict__ depth, const uchar4* __restrict__ rgb, const FuseParams& p) {
-  if (rc->listInvalid) return;                        // the list of this frame is not the reference's: fuse nothing (alloc.hip, statusFlags bit 1)
-  const int nItems = rc->noVisibleEntries;
-  const int lane = threadIdx.x & 63;
-  const int waves = wgCount * (int)(blockDim.x >> 6);
-  int i = __builtin_amdgcn_readfirstlane(wgIdx * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6));
-  if (i >= nItems) return;
-  HashEntry cur = unpack_entry(hash[visibleIds[i]]);
-  Group<VX> grp[2];
-  load_block_x4<VX>(cur, lane, vba, grp);
-  for (;;) {
-    const int nxt = i + waves;
-    const bool more = nxt < nItems;
-    HashEntry ahead = cur;
-    if (more) ahead = unpack_entry(hash[visibleIds[nxt]]);       // the entry of the NEXT item travels while this one is fused
-    integrate_block_x4<VX>(cur, lane, grp, vba, sdfMirror, depth, rgb, p);
-    if (!more) break;
-    load_block_x4<VX>(ahead, lane, vba, grp);
-    cur = ahead; i = nxt;
-  }
-}
-
-template <class VX>
-__global__ void __launch_bounds__(512) integrate_hash_x4_kernel(const int32_t* __restrict__ visibleIds, RenderCounters* __restrict__ rc,
-                                                                const uint4* __restrict__ hash, void* __restrict__ vba, void* __restrict__ sdfMirror,
-                                                                const float* __restrict__ depth, const uchar4* __restrict__ rgb, FuseParams p) {
-  integrate_hash_body_x4<VX>(blockIdx.x, gridDim.x, visibleIds, rc, hash, vba, sdfMirror, depth, rgb, p);
 }
 
 template <class VX>
@@ -516,7 +328,7 @@ __device__ unsigned long long g_fusedStamps[8192 * 2];
 #else
 #define ITM_FS(...)
 #endif
-template <class VX, bool X4 = false>
+template <class VX>
 __global__ void __launch_bounds__(512) integrate_project_kernel(const int32_t* __restrict__ visibleIds, RenderCounters* __restrict__ rc,
                                                                 const uint4* __restrict__ hash, void* __restrict__ vba, void* __restrict__ sdfMirror,
                                                                 const float* __restrict__ depth, const uchar4* __restrict__ rgb, FuseParams p,
@@ -527,15 +339,12 @@ __global__ void __launch_bounds__(512) integrate_project_kernel(const int32_t* _
   if (blockIdx.x < kRangeParts) {
     // the few projection workgroups share their CUs with integration workgroups and would otherwise be the last to finish
     // (21.8 us fused against 15.7 us for the integration alone): let their waves win the issue arbitration
-#if ITM_PROJECTION_PRIORITY
     __builtin_amdgcn_s_setprio(3);
-#endif
     project_partial_body(blockIdx.x, cells, visibleIds, rc, hash, range, projBuf, partials, pp, RW, RH);
     ITM_FS(__syncthreads(); if (threadIdx.x == 0) g_fusedStamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();)
     return;
   }
-  if constexpr (X4) integrate_hash_body_x4<VX>(blockIdx.x - kRangeParts, gridDim.x - kRangeParts, visibleIds, rc, hash, vba, sdfMirror, depth, rgb, p);
-  else integrate_hash_body<VX>(blockIdx.x - kRangeParts, gridDim.x - kRangeParts, visibleIds, rc, hash, vba, sdfMirror, depth, rgb, p);
+  integrate_hash_body<VX>(blockIdx.x - kRangeParts, gridDim.x - kRangeParts, visibleIds, rc, hash, vba, sdfMirror, depth, rgb, p);
   ITM_FS(__syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 8192) g_fusedStamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();)
 }
 #if ITM_EXP_FUSED_STAMPS
@@ -887,16 +696,10 @@ __global__ void __launch_bounds__(256) integrate_dense_s_x4_kernel(uint4* __rest
 // 290 us for a 512^3 launch, whatever the arithmetic: all of them at the same offset modulo the chunk at the same time); items go
 // round-robin over persistent waves, far slices first (a shared work counter was measured too: an atomic with a return value on
 // one address is ~16 ns, serialised at the memory side -- 350 us for the 24 k draws of a launch).
-#ifndef ITM_STRIP_PHASES
-#define ITM_STRIP_PHASES 16
-#endif
-#ifndef ITM_STRIP_OCC
-#define ITM_STRIP_OCC 1
-#endif
-constexpr int kStripPhases = ITM_STRIP_PHASES;   // work items per strip
+constexpr int kStripPhases = 16;                 // work items per strip
 constexpr int kStripQueue = 128;                 // queued groups per wave: fewer than 64 left over + at most 64 of one row
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITM_STRIP_OCC))) integrate_dense_strip_kernel(uint4* __restrict__ vba, const float* __restrict__ depth, FuseParams p,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1))) integrate_dense_strip_kernel(uint4* __restrict__ vba, const float* __restrict__ depth, FuseParams p,
                                                                     int sx, int sy, int sz, int ox, int oy, int oz, ColumnCull cc, GroupClassify gc) {
   __shared__ uint4 sQ[4][kStripQueue];
   __shared__ int sTag[4][kStripQueue];
@@ -1134,13 +937,9 @@ int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipS
     }
     int rc = dispatch_voxel(s->cfg.voxelType, [&](auto vx) {
       using VX = decltype(vx);
-      const bool x4 = g_debug_integrate_block_per_wave != 0;  // debug key 22: 16 bytes per lane, a block per wave (measured slower, profiles/r4_integrate_notes.md)
-      if (fuseProjection) {
-        if (x4) integrate_project_kernel<VX, true><<<grid, 512, (size_t)RW * RH * sizeof(uint2), st>>>(rs->visibleIds, rs->counters, s->hash, s->vba, s->sdfMirror, v->depth, rgb, p,
-                                                                                                     rs->range, rs->projBuf, rs->rangePartials, pp, RW, RH);
-        else integrate_project_kernel<VX, false><<<grid, 512, (size_t)RW * RH * sizeof(uint2), st>>>(rs->visibleIds, rs->counters, s->hash, s->vba, s->sdfMirror, v->depth, rgb, p,
-                                                                                                   rs->range, rs->projBuf, rs->rangePartials, pp, RW, RH);
-      } else if (x4) integrate_hash_x4_kernel<VX><<<grid, 512, 0, st>>>(rs->visibleIds, rs->counters, s->hash, s->vba, s->sdfMirror, v->depth, rgb, p);
+      if (fuseProjection)
+        integrate_project_kernel<VX><<<grid, 512, (size_t)RW * RH * sizeof(uint2), st>>>(rs->visibleIds, rs->counters, s->hash, s->vba, s->sdfMirror, v->depth, rgb, p,
+                                                                                         rs->range, rs->projBuf, rs->rangePartials, pp, RW, RH);
       else integrate_hash_kernel<VX><<<grid, 512, 0, st>>>(rs->visibleIds, rs->counters, s->hash, s->vba, s->sdfMirror, v->depth, rgb, p);
       return ITM_OK;
     });

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../include/itm_hip.h"
+#include "../../include/itm_debug.h"      // the library implements the test hooks; hosts never see them
 #include "itm_types.h"
 
 namespace itm {
@@ -83,7 +84,6 @@ struct itm_scene {
   void* sdfMirror = nullptr;      // the mirror's page pool: int16 / uint32 [mirrorPages * 64 * 512] (512 MB; hash scenes, itm_types.h) or nullptr;
                                   // its page table and page counter travel to the kernels inside `org` (AccelOrigin::mTable / mPages / mMaxPages)
   int mirrorPages = 0;
-  uint32_t* nearBits = nullptr;   // uint8[kMirrorCells] as words (16 MB; scenes with a mirror): per cell, which distances hold an allocated block (itm_types.h)
   // Where the two cubes lie (scene.hip, accel_place): re-placed around the camera when the view leaves them.  Invariant: the only
   // non-empty cells of dirPtr / dirSlot / sdfMirror are those of table entries with ptr >= 0 at `org` -- every path that replaces
   // the table or moves the origin empties exactly those cells first (O(allocated blocks), no 18 GB memset)
@@ -138,7 +138,6 @@ struct itm_render_state {
   // scratch
   uint4* projBuf = nullptr;    // per visible entry: projected bounding box + z range (2 x uint4)
   uint2* rangePartials = nullptr;  // [32][ceil(w/8)*ceil(h/8)] partial range images (LDS path)
-  uint8_t* rayClass = nullptr;    // uchar[h*w]: reads the last ray cast took per pixel (255: parked); deals the next cast's rays to waves (visualise.hip)
   int32_t* pixScratch = nullptr;  // int[h*w] (forward projection winners, ordered compaction flags)
   int32_t* pixChunk = nullptr;    // int[ceil(h*w / kSweepChunk)]
   uint8_t* viewFlags = nullptr;   // FindVisibleBlocks: per-slot flags (uchar[numChunks * kSweepChunk]), allocated on first use
@@ -225,7 +224,6 @@ int refuse_while_ahead(const itm_scene* s, const itm_render_state* rs, const cha
 extern int g_debug_explicit_mark;
 extern int g_debug_two_pass_visible_list;
 extern int g_debug_integrate_wgs;
-extern int g_debug_integrate_block_per_wave;
 extern int g_debug_dense_group_cull;
 extern int g_debug_dense_classify;
 extern int g_debug_dense_no_strips;
@@ -235,8 +233,6 @@ extern int g_debug_tracker_session_unusable;
 extern int g_debug_no_sdf_mirror;
 extern int g_debug_separate_sweep;
 int rebuild_sdf_mirror(itm_scene* s, hipStream_t st);
-int near_bits_rebuild(itm_scene* s, hipStream_t st);      // cleared, then set again from the table (scene.hip)
-extern int g_debug_no_near_bits;
 int launch_swap_after_allocation(itm_scene* s, itm_render_state* rs, hipStream_t st);   // swapping.hip
 void free_swap_state(itm_scene* s);
 int create_swap_state(itm_scene* s);

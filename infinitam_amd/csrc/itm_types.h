@@ -210,10 +210,7 @@ struct VoxelFRgb {  // ITMVoxel_f_rgb: {f32 sdf @0; u8 w_depth @4; u8 clr[3] @5;
 // bricks on arithmetic alone, with joint "runs" of the lanes of a wave and provably-safe multi-step advances -- was built
 // and measured: 83-104 us against 64 us for the plain directory; the classification arithmetic per step costs more than
 // the L1-resident load it saves and the extra loop structure de-synchronises the lanes.  Removed)
-#ifndef ITM_DIR_BITS
-#define ITM_DIR_BITS 9
-#endif
-constexpr int kDirBits = ITM_DIR_BITS;
+constexpr int kDirBits = 9;
 constexpr int kDirSide = 1 << kDirBits;        // 512 blocks per axis: +-8.2 m at 4 mm voxels, +-4.1 m at 2 mm
 constexpr int kDirHalf = kDirSide / 2;
 constexpr size_t kDirCells = (size_t)kDirSide * kDirSide * kDirSide;
@@ -232,16 +229,10 @@ struct AccelOrigin {
 
 // cube-relative block coordinates (each in [0, kDirSide) when the block is covered)
 __host__ __device__ inline bool dir_covers(uint32_t ux, uint32_t uy, uint32_t uz) { return ((ux | uy | uz) >> kDirBits) == 0u; }
-#ifndef ITM_DIR_LINEAR
-#define ITM_DIR_LINEAR 0
-#endif
+// brick-major: 4 x 4 x 4 blocks are 256 contiguous bytes (the 2 x 2 x 2 block neighbourhood of a trilinear read mostly lies in one)
 __host__ __device__ inline uint32_t dir_cell(uint32_t ux, uint32_t uy, uint32_t uz) {
-#if ITM_DIR_LINEAR
-  return (uz << (2 * kDirBits)) | (uy << kDirBits) | ux;
-#else
   const uint32_t brick = ((uz >> 2) << (2 * (kDirBits - 2))) | ((uy >> 2) << (kDirBits - 2)) | (ux >> 2);
   return (brick << 6) | ((uz & 3u) << 4) | ((uy & 3u) << 2) | (ux & 3u);
-#endif
 }
 // records an allocated block (device side; called by the allocation sweep and the rebuild kernel)
 // (dirSlot: the same cells holding the TABLE SLOT of the block instead of its voxel-block index -- what the allocation request
@@ -280,22 +271,16 @@ __device__ inline void directory_insert(int32_t* __restrict__ dirPtr, int32_t* _
 // the table was replaced.  Invariant: the only cells of mapped pages that are not "absent" are those of table entries with ptr >= 0 --
 // so emptying the mirror is a pass over the table that writes "absent" into exactly those cells, after which EVERY page of the pool
 // is clean again, the page table returns to -1 and the pool's counter to 0.
-#ifndef ITM_MIRROR_BITS
-#define ITM_MIRROR_BITS 8
-#endif
-constexpr int kMirrorBits = ITM_MIRROR_BITS;
+constexpr int kMirrorBits = 8;
 constexpr int kMirrorSide = 1 << kMirrorBits;
 constexpr int kMirrorHalf = kMirrorSide / 2;
 constexpr int kMirrorShift = kMirrorSide / 4;      // the cube is centred kMirrorShift blocks in front of the camera that placed it
 constexpr size_t kMirrorCells = (size_t)kMirrorSide * kMirrorSide * kMirrorSide;
-#ifndef ITM_MIRROR_PAGE_BITS
 // log2 of a page's side in blocks.  Measured (ray cast in frame, BASELINE configs[1], dense cube 38.3 us): 2 (32^3 voxels, 64 KB pages,
 // a 1 MB table read from memory) 43.4-44.9 us in either layout -- the table entry is a second DEPENDENT load in nearly every iteration
 // of a wave, because with pages 32 voxels wide some lane of the 64 has always just crossed into another page; 4 (128^3 voxels, 4 MB
-// pages, a 16 KB table that every ray-cast workgroup keeps in LDS): see profiles/r4_raycast_notes.md.
-#define ITM_MIRROR_PAGE_BITS 4
-#endif
-constexpr int kPageBits = ITM_MIRROR_PAGE_BITS;     // a page is 16 x 16 x 16 blocks
+// pages, a 16 KB table): see profiles/r4_raycast_notes.md.
+constexpr int kPageBits = 4;                        // a page is 16 x 16 x 16 blocks
 constexpr int kPageBlocks = 1 << (3 * kPageBits);   // 4 096
 constexpr int kPageVoxBits = kPageBits + 3;         // ... = 128 x 128 x 128 voxels
 constexpr uint32_t kPageVoxMask = (1u << kPageVoxBits) - 1u;
@@ -390,47 +375,6 @@ __device__ inline void mirror_init_block(void* __restrict__ mirror, bool floatSd
     uint4* q = (uint4*)((int16_t*)mirror + base);          // 1 KB
     const uint4 init = make_uint4(0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu);
     for (int i = 0; i < 64; ++i) q[i] = init;
-  }
-}
-
-// ---- near bits ----------------------------------------------------------------------------------
-// (MEASUREMENT BUILDS ONLY: the whole library built with -DITM_NEAR_BITS=1, tools/build_full_variant.sh, and ITM_NEAR_BITS=1 in the environment
-// when the scene is created.  Built for VERDICT r3 item 4, bit-exact, slower in every form: profiles/r4_raycast_notes.md section 1.)
-#ifndef ITM_NEAR_BITS
-#define ITM_NEAR_BITS 0
-#endif
-// One byte per cell of the mirror's cube (256^3 cells = 16 MB, x fastest like the mirror): bit k is set iff a voxel block has been
-// allocated at Chebyshev distance <= k (in blocks) from the cell, k = 0 .. 7.  The lowest set bit m of a cell says that every block
-// closer than m to it is unallocated (no bit set: closer than 8).  What the ray caster does with it (raycast_device.h): the reference's
-// step at a position without a block is 8 voxels along a unit direction (DeviceAgnostic/ITMVisualisationEngine.h:129-130,139), so
-// after k such steps the rounded position lies at most k + 1 blocks from the cell of the first one on every axis -- the positions of
-// the next m - 2 reads provably hold no block either, and the ray takes those steps on arithmetic alone: the same additions, the
-// same length test, no load.  Bits are only ever SET: by the allocation sweep for every block it allocates (also blocks outside the
-// cube, clipped), and again from the table after the cube has moved or the table was replaced.  A block that leaves (swapping)
-// keeps its bits: a distance that is too small only costs reads.
-constexpr int kNearReach = 7;
-// the near bits of the (up to 15 x 15 x 15) cells around block (bx, by, bz), by `nthreads` threads of which this is number `tid`
-__device__ inline void near_bits_splat(uint32_t* __restrict__ nearWords, const AccelOrigin& org, int bx, int by, int bz, int tid, int nthreads) {
-  const int cx = bx - org.mx, cy = by - org.my, cz = bz - org.mz;
-  if (cx < -kNearReach || cx >= kMirrorSide + kNearReach || cy < -kNearReach || cy >= kMirrorSide + kNearReach || cz < -kNearReach || cz >= kMirrorSide + kNearReach) return;
-  constexpr int kSpan = 2 * kNearReach + 1;            // 15 rows per axis
-  const int w0 = (cx - kNearReach) >> 2;               // first word of a row (arithmetic shift: may be negative)
-  constexpr int kWords = 5;                            // 15 cells touch at most 5 words of four
-  for (int task = tid; task < kSpan * kSpan * kWords; task += nthreads) {
-    const int wi = task % kWords, row = task / kWords;
-    const int dy = row % kSpan - kNearReach, dz = row / kSpan - kNearReach;
-    const int y = cy + dy, z = cz + dz, w = w0 + wi;
-    if ((unsigned)y >= (unsigned)kMirrorSide || (unsigned)z >= (unsigned)kMirrorSide || (unsigned)w >= (unsigned)(kMirrorSide / 4)) continue;
-    const int dyz = max(abs(dy), abs(dz));
-    uint32_t m = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int d = max(abs(w * 4 + k - cx), dyz);
-      if (d <= kNearReach) m |= ((0xffu << d) & 0xffu) << (8 * k);
-    }
-    if (!m) continue;
-    uint32_t* word = nearWords + (((size_t)z << (2 * kMirrorBits - 2)) | ((size_t)y << (kMirrorBits - 2)) | (size_t)w);
-    if ((__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & m) != m) atomicOr(word, m);     // (bits only ever get set: a stale read costs an atomic, nothing else)
   }
 }
 

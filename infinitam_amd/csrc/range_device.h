@@ -63,15 +63,12 @@ __device__ inline Projected project_block(const HashEntry& e, const ProjParams& 
 // writes that partial image to HBM (reduced by range_reduce_kernel).  Cells outside the region (the
 // reference clamps boxes to the FULL image size, a quirk that only touches cells no ray ever reads) go
 // through global atomics.
-#ifndef ITM_RANGE_PARTS
 // (re-measured at the end of round 4, BASELINE configs[1] frames/s through the four calls / configs[4]: 4 parts 10.8-10.9 k / 2 800 -- the
 // projection becomes the integration launch's long pole, 31 us --, 8: 12.0 k / 2 902, 16: 12.46-12.54 k / 2 901-2 906, 32: 12.28-12.37 k /
 // 2 892-2 899, 64: 12.1-12.2 k / 2 857: every ray-cast workgroup reduces 4 cells x parts partial values in its prologue.  With 5-12 times as
 // many visible blocks at 640 x 480 (2 mm / 1.5 mm voxels, tools/fine_voxel_bench.py) 16 parts are still no slower than 32: 4 765 / 2 867 against
 // 4 670 / 2 857 frames/s)
-#define ITM_RANGE_PARTS 16
-#endif
-constexpr int kRangeParts = ITM_RANGE_PARTS;   // 16, 32 or 64 (the ray-cast prologue reduces 4 cells x kRangeParts partials with <= 256 lanes)
+constexpr int kRangeParts = 16;   // 16, 32 or 64 (the ray-cast prologue reduces 4 cells x kRangeParts partials with <= 256 lanes)
 
 // Rendering-block cap of the reference reached (numRenderingBlocks >= MAX_RENDERING_BLOCKS): replays the sequential
 // accept / skip decisions and rebuilds the whole image from the accepted boxes.  One workgroup of `nthreads` lanes.

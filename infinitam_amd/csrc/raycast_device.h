@@ -12,19 +12,30 @@
 #ifndef ITM_EXP_WAVE_TIMING
 #define ITM_EXP_WAVE_TIMING 0  // measurement build: per-wave cycle accounting of cast_ray (tools/wave_stats.py)
 #endif
-#ifndef ITM_RAY_BITMAP_GUARD
-#define ITM_RAY_BITMAP_GUARD 1  // consult the occupancy bitmap before fetching a hash entry (single-voxel lookups)
-#endif
-#ifndef ITM_RAY_WHILE_WHILE
-#define ITM_RAY_WHILE_WHILE 1   // 0: the plain loop in the reference's order (baseline for measurements)
-#endif
-#ifndef ITM_RAY_MARCH_BURST
-// cheap steps a lane may take before the wave serves the lanes waiting for a trilinear read.  Round 4 (final kernel, config 2 / 3 / 5 ray cast):
-// 1: 37.7-38.5 us, 2: 37.1-37.7 / c3 +2.6 % frames/s, 3: 38.1-38.3, 4 (rounds 2-3): 38.0-38.8, 6: 40.3
-#define ITM_RAY_MARCH_BURST 2
-#endif
 
 namespace itm {
+
+// ---- launch constants of the march (each swept on the final kernels; the numbers are MI355X ray-cast times in frame) ----------------
+// cheap steps a lane may take before the wave serves the lanes waiting for a trilinear read.  Round 4 (config 2 / 3 / 5 ray cast):
+// 1: 37.7-38.5 us, 2: 37.1-37.7 / c3 +2.6 % frames/s, 3: 38.1-38.3, 4 (rounds 2-3): 38.0-38.8, 6: 40.3
+constexpr int kMarchBurst = 2;
+// a ray that has just taken this many "block not found" steps in a row is crossing empty space (a silhouette ray on its way from
+// the sphere to the wall): phase 1 of the ray-cast workgroup parks it, phase 2 marches the parked rays in waves of their own.
+// Config 2 / config 5, one-phase kernel 60.4 / 132.5 us: streak 4: 76 / 152, 6: 62, 8: 54 / 129, 10: 53 / 123, 12: 53 / 117,
+// 16: 55 / 118, 24: 58 / 120 -- parking too early also catches rays that only skip a few blocks.
+constexpr int kParkStreak = 12;
+// directory cells fetched together per round trip by a parked ray's empty-space run (round 2: 4: 55 us, 6: 53, 8: 53; round 4 with a march
+// burst of 2, config 2 / config 5 ray cast: 6: 37.2-37.7 / 116-118, 8: 35.8-36.9 / 114.7-114.9, 12: 35.5-36.7 / 112.8-113.1, 16: 40.2-40.6 / 119.6,
+// 20: 41.8 / 130, 24: 40.4-42.1 / 131)
+constexpr int kParkedLookahead = 12;
+// phase 1: "not found" steps in a row after which a ray counts as inside a run for the wave-wide look-ahead, and the cells it fetches
+constexpr int kProbeAt = 2;
+constexpr int kProbeCells = 10;
+// Dense volumes: voxels fetched together by a ray that is crossing free space.  BASELINE configs[2] starts every ray 0.2 m in front
+// of the camera and the surface is 1.3-2.3 m away: ~65-115 steps of mu / voxelSize voxels through voxels that read exactly 1 (free
+// or never seen), each a dependent round trip.  Measured (config 3 ray cast, event timers): none 90.6 us, 4 voxels 86.6, 8: 92.5,
+// 12: 94.0, 16: 103.7 -- the run is NOT what bounds the dense ray cast (its neighbouring rays read the same lines from L2); kept at 4.
+constexpr int kDenseLookahead = 4;
 
 #if ITM_EXP_WAVE_TIMING
 static __device__ unsigned long long g_waveStats[8192 * 12];
@@ -47,7 +58,6 @@ struct VolumeView {
   int bucketNum;
   const int32_t* dirPtr;    // block directory (itm_types.h); nullptr = walk the table (hash index only)
   const void* sdfMirror;    // sdf by position (itm_types.h); nullptr = none (hash index only)
-  const uint8_t* nearBits;  // per cell of the mirror's cube: distances at which a block is allocated (itm_types.h); nullptr = none
   const int32_t* pageTable; // the mirror's page table as THIS kernel reads it: the scene's (memory) or the workgroup's copy in LDS (raycast_kernel)
   AccelOrigin org;          // where the directory / mirror cubes lie
   int sx, sy, sz;      // dense size
@@ -80,10 +90,6 @@ struct BlockCache {
 // The mirror page with table index tIdx, through the per-lane cache.  The table is read by a wave only when one of its lanes has left
 // its page (uniform branch; a lane that keeps its page reads entry 0 and drops it).
 __device__ inline int mirror_page_of(const VolumeView& vol, bool inCube, uint32_t tIdx, BlockCache& cache) {
-#if ITM_EXP_MIRROR_IDENTITY
-  (void)vol; (void)cache; (void)inCube;
-  return (int)tIdx;          // measurement build: every page of the cube has its own pool page (scene created with ITM_MIRROR_PAGES=4096 and mapped 1:1)
-#endif
   const bool need = inCube && tIdx != cache.pageIdx;
   if (__any(need)) {
     const int v = vol.pageTable[need ? tIdx : 0u];
@@ -120,10 +126,8 @@ __device__ inline long long locate_voxel(const VolumeView& vol, int px, int py, 
       }
     }
     int idx = hash_index(bx, by, bz, vol.mask);
-#if ITM_RAY_BITMAP_GUARD
     // the 16-byte entry is only fetched when the occupancy bit says the bucket is in use
     if (!((vol.headBits[idx >> 5] >> (idx & 31)) & 1u)) return -1;
-#endif
     HashEntry e = unpack_entry(vol.hash[idx]);
     for (;;) {
       if (e.px == bx && e.py == by && e.pz == bz && e.ptr >= 0) {
@@ -138,10 +142,8 @@ __device__ inline long long locate_voxel(const VolumeView& vol, int px, int py, 
 }
 
 // raw (unconverted) sdf of the voxel at an integer point; the default voxel when absent
-// skipLane: this lane wants no value (its answer comes from the near bits): it reads cell 0 and reports "no block"
-template <class VX, bool DENSE, bool NEAR = false, class VOL = VolumeView>
-__device__ inline float read_raw_sdf(const VOL& vol, int px, int py, int pz, bool& found, BlockCache& cache, uint32_t* nearByte = nullptr, bool skipLane = false) {
-  if constexpr (NEAR) *nearByte = 0xffu;      // "a block right here": nothing may be skipped
+template <class VX, bool DENSE, class VOL = VolumeView>
+__device__ inline float read_raw_sdf(const VOL& vol, int px, int py, int pz, bool& found, BlockCache& cache) {
   if constexpr (!DENSE) {
     // sdf mirror: one load, address from the position alone (same value and same "found" as the walk below: the mirror holds
     // exactly the voxels of the allocated blocks inside its cube)
@@ -152,12 +154,8 @@ __device__ inline float read_raw_sdf(const VOL& vol, int px, int py, int pz, boo
       const uint32_t ux = (uint32_t)((px >> 3) - vol.org.mx), uy = (uint32_t)((py >> 3) - vol.org.my), uz = (uint32_t)((pz >> 3) - vol.org.mz);
       const bool covered = mirror_covers(ux, uy, uz);
       const size_t mi = ((size_t)mirror_cell(ux, uy, uz) << 9) | (size_t)((px & 7) + ((py & 7) << 3) + ((pz & 7) << 6));
-      const typename MC::T v = ((const typename MC::T*)vol.sdfMirror)[(covered && !skipLane) ? mi : (size_t)0];
-      if constexpr (NEAR) {
-        const uint32_t nb = vol.nearBits[covered ? (mi >> 9) : (size_t)0];
-        if (covered) *nearByte = nb;
-      }
-      const bool present = covered && !skipLane && !MC::absent(v);
+      const typename MC::T v = ((const typename MC::T*)vol.sdfMirror)[covered ? mi : (size_t)0];
+      const bool present = covered && !MC::absent(v);
       const float value = present ? MC::raw(v) : (VX::kShort ? 32767.0f : 1.0f);
       if (__all(covered)) { found = present; return value; }
       if (covered) { found = present; return value; }
@@ -168,17 +166,12 @@ __device__ inline float read_raw_sdf(const VOL& vol, int px, int py, int pz, boo
       const int page = mirror_page_of(vol, inCube, mirror_table_index_voxel(vx, vy, vz), cache);
       // the page answers: with a value, or -- no block was ever allocated in it -- with "no block" and no further load
       const bool covered = inCube && page != kPageUnmappable;
-      const bool mapped = covered && page >= 0 && !skipLane;
+      const bool mapped = covered && page >= 0;
       typename MC::T v = VX::kShort ? (typename MC::T)-32768 : (typename MC::T)0xffffffffu;
       if (__any(mapped)) {
         const size_t mi = mapped ? mirror_element(page, mirror_in_page(vx, vy, vz)) : (size_t)0;
         const typename MC::T got = ((const typename MC::T*)vol.sdfMirror)[mi];
         if (mapped) v = got;
-      }
-      if constexpr (NEAR) {
-        // the cell's near bits travel with the value (an independent load): no second round trip after a miss
-        const uint32_t nb = vol.nearBits[covered ? mirror_cell(vx >> 3, vy >> 3, vz >> 3) : 0u];
-        if (covered) *nearByte = nb;
       }
       const bool present = mapped && !MC::absent(v);
       const float value = present ? MC::raw(v) : (VX::kShort ? 32767.0f : 1.0f);
@@ -195,10 +188,6 @@ __device__ inline float read_raw_sdf(const VOL& vol, int px, int py, int pz, boo
 template <class VX, bool DENSE, class VOL = VolumeView>
 __device__ inline float sdf_nearest(const VOL& vol, float x, float y, float z, bool& found, BlockCache& cache) {
   return VX::to_float(read_raw_sdf<VX, DENSE>(vol, (int)round_ref(x), (int)round_ref(y), (int)round_ref(z), found, cache));
-}
-template <class VX, class VOL = VolumeView>
-__device__ inline float sdf_nearest_near(const VOL& vol, float x, float y, float z, bool& found, BlockCache& cache, uint32_t& nearByte) {
-  return VX::to_float(read_raw_sdf<VX, false, true>(vol, (int)round_ref(x), (int)round_ref(y), (int)round_ref(z), found, cache, &nearByte));
 }
 
 // Walks the excess chain starting from an already loaded head entry; block base or -1.
@@ -425,9 +414,6 @@ struct RayParams {
   float oneOverVoxel, mu, voxelSize;
   float lx, ly, lz;         // light source = -(invM column 2)
   int W, H;
-  // per pixel, how many reads the LAST ray cast through this render state took for it (0 .. 254; 255: the ray was parked) -- what the
-  // next ray cast deals its rays to waves by (raycast_kernel); nullptr: rays are dealt in image order
-  uint8_t* rayClass;
 };
 
 // Ray set-up shared by both loops: start point, direction and the [total, totalMax) range in voxel units.
@@ -455,120 +441,20 @@ __device__ inline RaySetup ray_setup(int x, int y, const RayParams& p, float2 mm
   return r;
 }
 
-// castRay in the reference's own order (DeviceAgnostic/ITMVisualisationEngine.h:92-158): baseline for measurements
-// (ITM_RAY_WHILE_WHILE=0, 69 us vs 62 us for the restructured loop below on config 2).
-template <class VX, bool DENSE, class VOL = VolumeView>
-__device__ inline float4 cast_ray_plain(int x, int y, const VOL& vol, const RayParams& p, float2 mm) {
-  const float stepScale = p.mu * p.oneOverVoxel;
-  RaySetup r = ray_setup(x, y, p, mm);
-  float px = r.px, py = r.py, pz = r.pz, total = r.total;
-  const float dx = r.dx, dy = r.dy, dz = r.dz, totalMax = r.totalMax;
-  BlockCache cache;
-  bool found;
-  float sdf = 1.0f, step;
-  while (total < totalMax) {
-    sdf = sdf_nearest<VX, DENSE>(vol, px, py, pz, found, cache);
-    if (!found) {
-      step = (float)kBlockSide;
-    } else {
-      if ((sdf <= 0.1f) && (sdf >= -0.5f)) sdf = sdf_trilinear<VX, DENSE>(vol, px, py, pz, found, cache);
-      if (sdf <= 0.0f) break;
-      const float s = sdf * stepScale;
-      step = (s < 1.0f) ? 1.0f : s;
-    }
-    px += step * dx; py += step * dy; pz += step * dz;
-    total += step;
-  }
-  float w = 0.0f;
-  if (sdf <= 0.0f) {
-    step = sdf * stepScale;
-    px += step * dx; py += step * dy; pz += step * dz;
-    sdf = sdf_trilinear<VX, DENSE>(vol, px, py, pz, found, cache);
-    step = sdf * stepScale;
-    px += step * dx; py += step * dy; pz += step * dz;
-    w = 1.0f;
-  }
-  return make_float4(px, py, pz, w);
-}
-
 // castRay restructured as two nested loops ("while-while"): the inner loop only does the cheap part of a
 // step (nearest-voxel read, empty-space / far-field advance) and a lane leaves it as soon as its value lies
 // inside the truncation band; the expensive trilinear read (band steps and the post-hit refinement alike)
 // sits after the inner loop.  SIMT reconvergence then does the scheduling: lanes that need a trilinear
-// read wait while the other lanes of the wave take up to ITM_RAY_MARCH_BURST cheap steps, then the
+// read wait while the other lanes of the wave take up to kMarchBurst cheap steps, then the
 // trilinear code runs once for all of them -- instead of once per iteration in which ANY lane happens to
 // be in the band.  Per ray the sequence of positions, reads and float operations is exactly that of
-// cast_ray_plain (and of the reference), so results are bit-identical.
+// the reference's loop (DeviceAgnostic/ITMVisualisationEngine.h:92-158), so results are bit-identical.
 //
 // Measured on MI355X (config 2, tools/wave_stats.py per-wave cycle traces): the kernel lasts as long as its
 // slowest wave (rays that pass the sphere and run ~45 empty-space steps to the wall); a cold voxel/hash
 // line costs ~2 000 cycles per dependent round trip, a trilinear step ~4 500.  Burst 1 (= the plain loop)
 // 69 us, 2: 65, 3: 64, 4: 62, 8: 66, unbounded: 95 (lanes then serialise each other's empty-space runs).
 // The other restructurings that were tried and dropped are listed with their numbers in DESIGN.md section 5.
-#ifndef ITM_RAY_PARK_STREAK
-// a ray that has just taken this many "block not found" steps in a row is crossing empty space (a silhouette ray on its way from
-// the sphere to the wall): phase 1 of the ray-cast workgroup parks it, phase 2 marches the parked rays in waves of their own.
-// Measured in-frame (MI355X; config 2 / config 5, one-phase kernel 60.4 / 132.5 us): streak 4: 76 / 152, 6: 62, 8: 54 / 129,
-// 10: 53 / 123, 12: 53 / 117, 16: 55 / 118, 24: 58 / 120 -- parking too early also catches rays that only skip a few blocks.
-#define ITM_RAY_PARK_STREAK 12
-#endif
-#ifndef ITM_RAY_PARKED_LOOKAHEAD
-// directory cells fetched together per round trip by a parked ray's empty-space run (round 2: 4: 55 us, 6: 53, 8: 53; round 4 with a march
-// burst of 2, config 2 / config 5 ray cast: 6: 37.2-37.7 / 116-118, 8: 35.8-36.9 / 114.7-114.9, 12: 35.5-36.7 / 112.8-113.1, 16: 40.2-40.6 / 119.6,
-// 20: 41.8 / 130, 24: 40.4-42.1 / 131)
-#define ITM_RAY_PARKED_LOOKAHEAD 12
-#endif
-
-#ifndef ITM_RAY_PROBE_AT
-// phase 1: "not found" steps in a row after which a ray counts as inside a run for the wave-wide look-ahead (0 cells: never)
-#define ITM_RAY_PROBE_AT 2
-#endif
-#ifndef ITM_RAY_PROBE_CELLS
-#define ITM_RAY_PROBE_CELLS 10
-#endif
-
-#ifndef ITM_EXP_MIRROR_IDENTITY
-#define ITM_EXP_MIRROR_IDENTITY 0
-#endif
-#ifndef ITM_RAY_FLAT_STEP
-#define ITM_RAY_FLAT_STEP 1
-#endif
-#ifndef ITM_RAY_NEAR_SKIP
-// 1: after a mirror read that found no block, the near bits of that cell (itm_types.h) say how many of the following reads provably
-// find none either; the ray takes those steps without reading.  2: the byte is requested together with the mirror value at every step
-// (one round trip per hop instead of two, one more load per step for every lane).  0: off.
-// MEASURED (MI355X, BASELINE configs[1], ray cast in frame, profiles/r4_raycast_notes.md): 0: 38.3 us; 1: 44.3; 2: 42.3-43.3; 3 (near bits
-// FIRST inside a run, below): 44.3-45.1 -- every form loses: the march is bound by the instructions a step issues.  Default 0; scenes
-// only carry near bits when ITM_NEAR_BITS=1 is in the environment.
-#define ITM_RAY_NEAR_SKIP 0
-#endif
-#ifndef ITM_RAY_FAR_CELLS
-#define ITM_RAY_FAR_CELLS 0     // hash index with the mirror: positions a ray looks ahead after a single-voxel read of exactly 1 (0: never)
-#endif
-#ifndef ITM_RAY_FAR_CELLS_PARKED
-#define ITM_RAY_FAR_CELLS_PARKED 0   // the same, but only in the second pass over the parked rays (0: never)
-#endif
-#ifndef ITM_RAY_UNROLL_BURST
-#define ITM_RAY_UNROLL_BURST 0    // 1: the burst of cheap steps unrolled (measurement switch)
-#endif
-#ifndef ITM_RAY_PREFETCH_NEXT
-#define ITM_RAY_PREFETCH_NEXT 0   // 1: the mirror line of the position a repeated step would reach is requested beside every single-voxel read (measurement switch)
-#endif
-#ifndef ITM_RAY_FAR_GATE
-#define ITM_RAY_FAR_GATE 0      // > 0: the look-ahead over values of exactly 1 only for rays that have just read that many of them in a row
-#endif
-#ifndef ITM_RAY_FAR_ALL
-#define ITM_RAY_FAR_ALL 1       // 1: only when every marching lane of the wave has just read exactly 1; 0: when any has
-#endif
-
-#ifndef ITM_RAY_DENSE_LOOKAHEAD
-// Dense volumes: voxels fetched together by a ray that is crossing free space.  BASELINE configs[2] starts every ray 0.2 m in front
-// of the camera and the surface is 1.3-2.3 m away: ~65-115 steps of mu / voxelSize voxels through voxels that read exactly 1 (free
-// or never seen), each a dependent round trip.  Measured (config 3 ray cast, event timers): none 90.6 us, 4 voxels 86.6, 8: 92.5,
-// 12: 94.0, 16: 103.7 -- the run is NOT what bounds the dense ray cast (its neighbouring rays read the same lines from L2); kept at 4.
-#define ITM_RAY_DENSE_LOOKAHEAD 4
-#endif
-
 // One look-ahead round of a far-field run in a DENSE volume.  A ray whose single-voxel read returned exactly 1 steps by
 // max(1 * stepScale, 1) voxels and, in free space, reads 1 again: the voxels of the next K positions -- q0 = pt, q1 = pt + step dir,
 // ..., each computed with the reference's own operations -- are fetched together and the ray advances over as many of them as
@@ -612,12 +498,11 @@ struct RayResume { float px, py, pz, total; };
 //     advances over as many of them as are empty: K dependent round trips become one.  In a wave where only SOME lanes cross
 //     empty space this loses (every lane pays the K classifications and loads: 61 -> 64 / 69 / 77 us for K = 3 / 6 / 10, gated or
 //     not); in a wave of nothing but such rays it is what makes their ~45-step runs cheap.
-//   PARK: the ray stops (parked = true, returns its position and length in xyz / w) once it has taken ITM_RAY_PARK_STREAK
+//   PARK: the ray stops (parked = true, returns its position and length in xyz / w) once it has taken kParkStreak
 //     "not found" steps in a row; the caller appends it to the queue of the second pass.
 // Per ray the sequence of positions, reads and float operations is that of the reference, whatever the pass structure.
 template <class VX, bool DENSE, int LOOKAHEAD, bool PARK, class VOL = VolumeView>
-__device__ inline float4 march_ray(int x, int y, const VOL& vol, const RayParams& p, float2 mm, const RayResume* resume, bool& parked, int* readsOut = nullptr) {
-  int reads = 0;            // single-voxel and trilinear reads of this call (the ray's length as the next frame's dealing sees it)
+__device__ inline float4 march_ray(int x, int y, const VOL& vol, const RayParams& p, float2 mm, const RayResume* resume, bool& parked) {
   // MARCH: next read is a single voxel; TRI: a single-voxel read found the band, the trilinear read of the same position is
   // due; REFINE: the surface was crossed
   enum : int { MARCH = 0, TRI = 1, REFINE = 2, DONE = 4 };
@@ -626,16 +511,7 @@ __device__ inline float4 march_ray(int x, int y, const VOL& vol, const RayParams
   float px = r.px, py = r.py, pz = r.pz, total = r.total;
   const float dx = r.dx, dy = r.dy, dz = r.dz, totalMax = r.totalMax;
   int missStreak = 0;
-#if ITM_RAY_PREFETCH_NEXT
-  float lastStep = 0.0f;
-#endif
-#if ITM_RAY_FAR_GATE > 0
-  int farStreak = 0;
-#endif
-#if ITM_RAY_NEAR_SKIP == 3
-  bool confirm = false;
-#endif
-  if (resume) { px = resume->px; py = resume->py; pz = resume->pz; total = resume->total; missStreak = ITM_RAY_PARK_STREAK; }
+  if (resume) { px = resume->px; py = resume->py; pz = resume->pz; total = resume->total; missStreak = kParkStreak; }
   BlockCache cache;
   bool found;
   float w = 0.0f;
@@ -685,41 +561,6 @@ __device__ inline float4 march_ray(int x, int y, const VOL& vol, const RayParams
     }
     return taken;
   };
-  // One look-ahead round of a run through voxels that were allocated but never observed (hash index with the sdf mirror): a ray whose
-  // single-voxel read returned exactly 1 steps by max(1 * stepScale, 1) voxels; the mirror values of the next K positions -- each
-  // computed with the reference's own operations -- are fetched together and the ray advances over as many of them as read exactly 1.
-  auto far_run_mirror = [&](auto kc, bool runner) {
-    constexpr int K = decltype(kc)::value;
-    using MC = MirrorCodec<VX::kShort>;
-    const float one = 1.0f * stepScale;                       // sdf * stepScale with sdf == 1
-    const float step = (one < 1.0f) ? 1.0f : one;
-    const float sx = step * dx, sy = step * dy, sz = step * dz;
-    typename MC::T val[K];
-    bool ok[K];
-    {
-      float qx = px, qy = py, qz = pz;
-#pragma unroll
-      for (int j = 0; j < K; ++j) {
-        const uint32_t vx = (uint32_t)((int)round_ref(qx) - (vol.org.mx << 3)), vy = (uint32_t)((int)round_ref(qy) - (vol.org.my << 3)), vz = (uint32_t)((int)round_ref(qz) - (vol.org.mz << 3));
-        const bool in = runner && mirror_covers_voxel(vx, vy, vz);
-        const bool dense = mirror_is_dense(vol);
-        const int pg = dense ? 0 : vol.pageTable[in ? mirror_table_index_voxel(vx, vy, vz) : 0u];
-        const bool use = in && pg >= 0;
-        const size_t at = dense ? (((size_t)mirror_cell(vx >> 3, vy >> 3, vz >> 3) << 9) | (size_t)((vx & 7u) | ((vy & 7u) << 3) | ((vz & 7u) << 6))) : mirror_element(pg, mirror_in_page(vx, vy, vz));
-        val[j] = ((const typename MC::T*)vol.sdfMirror)[use ? at : (size_t)0];
-        ok[j] = use;
-        qx += sx; qy += sy; qz += sz;
-      }
-    }
-    if (runner) {
-#pragma unroll
-      for (int j = 0; j < K; ++j) {
-        if (!ok[j] || MC::absent(val[j]) || VX::to_float(MC::raw(val[j])) != 1.0f) break;     // something else: regular read next
-        px += sx; py += sy; pz += sz; total += step;
-        if (!(total < totalMax)) { st = DONE; break; }
-      }
-    }
-  };
   ITM_WT(const unsigned long long wtStart = wt_clock(); unsigned wtOuter = 0;)
   bool missed = false;      // DENSE: the last single-voxel read found no voxel
   while (st != DONE) {
@@ -749,60 +590,12 @@ __device__ inline float4 march_ray(int x, int y, const VOL& vol, const RayParams
       }
     }
     ITM_WT(const unsigned long long wt0 = wt_clock(); unsigned wtInner = 0; const unsigned wtLanes0 = __popcll(__ballot(1)); const unsigned wtMarch0 = __popcll(__ballot(st == MARCH));)
-    // ---- cheap phase: at most ITM_RAY_MARCH_BURST single-voxel steps, so that waiting lanes are served regularly ----
-    int budget = ITM_RAY_MARCH_BURST;
-#if ITM_RAY_UNROLL_BURST
-#pragma unroll ITM_RAY_MARCH_BURST
-#endif
+    // ---- cheap phase: at most kMarchBurst single-voxel steps, so that waiting lanes are served regularly ----
+    int budget = kMarchBurst;
     while (st == MARCH && budget > 0) {
       --budget;
-      ++reads;
       ITM_WT(++wtInner;)
-      const float readX = px, readY = py, readZ = pz;          // where this read is made (the near-bit skip below needs the cell)
-#if ITM_RAY_PREFETCH_NEXT
-      // NON-BINDING PREFETCH (measurement switch): the mirror line of the position this ray reaches if it repeats its last step (runs
-      // through empty space and through never-observed voxels repeat it) is requested beside this position's own read; nothing looks at
-      // the value -- if the guess holds, the next read finds its line in the cache instead of making a round trip of its own.
-      [[maybe_unused]] uint32_t pfValue = 0;
-      if constexpr (!DENSE && VOL::kMirror == 1) {
-        if (vol.sdfMirror) {
-          const float qx = px + lastStep * dx, qy = py + lastStep * dy, qz = pz + lastStep * dz;
-          const uint32_t vx = (uint32_t)((int)round_ref(qx) - (vol.org.mx << 3)), vy = (uint32_t)((int)round_ref(qy) - (vol.org.my << 3)), vz = (uint32_t)((int)round_ref(qz) - (vol.org.mz << 3));
-          const bool in = mirror_covers_voxel(vx, vy, vz);
-          const size_t at = ((size_t)mirror_cell(vx >> 3, vy >> 3, vz >> 3) << 9) | (size_t)((vx & 7u) | ((vy & 7u) << 3) | ((vz & 7u) << 6));
-          pfValue = (uint32_t)((const typename MirrorCodec<VX::kShort>::T*)vol.sdfMirror)[in ? at : (size_t)0];
-        }
-      }
-      const float pfBeforeX = px, pfBeforeY = py, pfBeforeZ = pz, pfBeforeT = total;
-#endif
-#if ITM_RAY_NEAR_SKIP == 3
-      // NEAR FIRST inside a run.  A ray whose last read found no block asks the near bits of its position BEFORE (instead of) the
-      // mirror: the 16 MB of near bits are cache resident, the mirror's line of an empty cell is a cold kilobyte of HBM that says
-      // nothing else.  Bit 0 clear: no block here -- the read is answered, and the lowest set bit m grants m - 2 further steps.  Bit 0
-      // set: a block is (or was) here: the mirror is read at the same position in the wave's next iteration (`confirm`).
-      uint32_t nearByte = 0xffu;
-      bool nearFirst = false, stay = false;
-      float sdf;
-      if constexpr (!DENSE) {
-        if (vol.nearBits) {
-          const uint32_t ux = (uint32_t)(((int)round_ref(px) >> 3) - vol.org.mx), uy = (uint32_t)(((int)round_ref(py) >> 3) - vol.org.my), uz = (uint32_t)(((int)round_ref(pz) >> 3) - vol.org.mz);
-          nearFirst = missStreak >= 1 && !confirm && mirror_covers(ux, uy, uz);
-          nearByte = vol.nearBits[nearFirst ? mirror_cell(ux, uy, uz) : 0u];
-          sdf = VX::to_float(read_raw_sdf<VX, false, false>(vol, (int)round_ref(px), (int)round_ref(py), (int)round_ref(pz), found, cache, nullptr, nearFirst));
-          stay = nearFirst && (nearByte & 1u);
-          confirm = stay;
-        } else sdf = sdf_nearest<VX, DENSE>(vol, px, py, pz, found, cache);
-      } else sdf = sdf_nearest<VX, DENSE>(vol, px, py, pz, found, cache);
-      const float keepX = px, keepY = py, keepZ = pz, keepT = total;
-#elif ITM_RAY_NEAR_SKIP == 2
-      uint32_t nearByte = 0xffu;
-      float sdf;
-      if constexpr (!DENSE) { if (vol.nearBits) sdf = sdf_nearest_near<VX>(vol, px, py, pz, found, cache, nearByte); else sdf = sdf_nearest<VX, DENSE>(vol, px, py, pz, found, cache); }
-      else sdf = sdf_nearest<VX, DENSE>(vol, px, py, pz, found, cache);
-#else
       const float sdf = sdf_nearest<VX, DENSE>(vol, px, py, pz, found, cache);
-#endif
-#if ITM_RAY_FLAT_STEP
       {
         // the step as selects rather than branches (the same operations on the same values as advance(); a lone wave pays every
         // taken or skipped branch of a step with issue bubbles, profiles/r3_raycast_notes.md)
@@ -816,18 +609,6 @@ __device__ inline float4 march_ray(int x, int y, const VOL& vol, const RayParams
         total = (band || crossed) ? total : nt;
         st = band ? TRI : crossed ? REFINE : (total < totalMax) ? MARCH : DONE;
       }
-#else
-      if (found && (sdf <= 0.1f) && (sdf >= -0.5f)) st = TRI;      // the position is kept for the trilinear read
-      else st = advance(found, sdf);
-#endif
-#if ITM_RAY_NEAR_SKIP == 3
-      if (stay) { px = keepX; py = keepY; pz = keepZ; total = keepT; st = MARCH; }      // nothing was learnt but "read the mirror here"
-#endif
-#if ITM_RAY_PREFETCH_NEXT
-      lastStep = (st == MARCH) ? total - pfBeforeT : 0.0f;      // (the step just taken; the guess for the next one)
-      (void)pfBeforeX; (void)pfBeforeY; (void)pfBeforeZ;
-      asm volatile("" :: "v"(pfValue));                          // the prefetched value is not used; the request must not be optimised away
-#endif
       if constexpr (DENSE) missed = !found;
       if constexpr (DENSE && LOOKAHEAD > 0) {
         const bool far = st == MARCH && found && sdf == 1.0f;      // SDF_valueToFloat(32767) is exactly 1
@@ -837,82 +618,27 @@ __device__ inline float4 march_ray(int x, int y, const VOL& vol, const RayParams
           if (ended) st = DONE;
         }
       }
-#if ITM_RAY_NEAR_SKIP == 3
-      if constexpr (!DENSE) { if (!stay) missStreak = found ? 0 : missStreak + 1; }
-#else
       if constexpr (!DENSE && (PARK || LOOKAHEAD > 0)) missStreak = found ? 0 : missStreak + 1;
-#endif
-#if ITM_RAY_NEAR_SKIP
-      if constexpr (!DENSE) {
-        // Proven-empty space on arithmetic alone.  The read at `readX/Y/Z` (the position before this step) found no block; if its cell
-        // lies in the mirror's cube, the lowest set near bit m of the cell says that no block closer than m is allocated, and after k
-        // further steps of 8 voxels along a unit direction the rounded position is at most k + 1 blocks away on every axis (8 k + 1
-        // voxels: the step, plus half a voxel of rounding at either end; the accumulated float error of 7 additions at these magnitudes
-        // is below 0.2) -- so the reads of the next m - 2 positions find nothing, and each of them would be answered by exactly the step
-        // taken here: pt += 8 dir, total += 8, the range test (DeviceAgnostic/ITMVisualisationEngine.h:129-130,139-141).
-        const bool lost = !found && st == MARCH;
-        if (vol.nearBits && __any(lost)) {
-#if ITM_RAY_NEAR_SKIP == 3
-          (void)readX; (void)readY; (void)readZ;
-          const uint32_t nb = nearByte;
-          int skip = (lost && nearFirst && !stay) ? (nb ? __builtin_ctz(nb) : 8) - 2 : 0;
-#elif ITM_RAY_NEAR_SKIP == 2
-          (void)readX; (void)readY; (void)readZ;
-          const uint32_t nb = nearByte;             // (0xff unless the read went through the mirror)
-          int skip = lost ? (nb ? __builtin_ctz(nb) : 8) - 2 : 0;
-#else
-          const int cxr = ((int)round_ref(readX) >> 3) - vol.org.mx, cyr = ((int)round_ref(readY) >> 3) - vol.org.my, czr = ((int)round_ref(readZ) >> 3) - vol.org.mz;
-          const bool use = lost && mirror_covers((uint32_t)cxr, (uint32_t)cyr, (uint32_t)czr);
-          const uint32_t nb = vol.nearBits[use ? mirror_cell((uint32_t)cxr, (uint32_t)cyr, (uint32_t)czr) : 0u];
-          int skip = use ? (nb ? __builtin_ctz(nb) : 8) - 2 : 0;
-#endif
-          const float sx = (float)kBlockSide * dx, sy = (float)kBlockSide * dy, sz = (float)kBlockSide * dz;      // exact products, as in the step above
-          int taken = 0;
-          while (skip > 0) {
-            --skip;
-            px += sx; py += sy; pz += sz; total += (float)kBlockSide;
-            ++taken;
-            if (!(total < totalMax)) { st = DONE; break; }
-          }
-          if constexpr (PARK || LOOKAHEAD > 0) missStreak += taken;
-        }
-      }
-#endif
-      if constexpr (!DENSE && (ITM_RAY_FAR_CELLS > 0 || (LOOKAHEAD > 0 && ITM_RAY_FAR_CELLS_PARKED > 0))) {
-        // (ITM_RAY_FAR_CELLS_PARKED: the same look-ahead in phase 2 only, where every lane of the wave is a parked ray that enters the
-        // never-observed shell of the far surface at about the same time)
-        constexpr int KF = (LOOKAHEAD > 0 && ITM_RAY_FAR_CELLS_PARKED > 0) ? ITM_RAY_FAR_CELLS_PARKED : (ITM_RAY_FAR_CELLS > 0 ? ITM_RAY_FAR_CELLS : 1);
-        const bool far1 = st == MARCH && found && sdf == 1.0f;      // SDF_valueToFloat(32767) is exactly 1
-#if ITM_RAY_FAR_GATE > 0
-        farStreak = far1 ? farStreak + 1 : 0;                       // (gate: only rays that have just taken ITM_RAY_FAR_GATE such steps in a row)
-        const bool far = far1 && farStreak >= ITM_RAY_FAR_GATE;
-#else
-        const bool far = far1;
-#endif
-        if (vol.sdfMirror && (ITM_RAY_FAR_ALL ? (__all(st != MARCH || far) && __any(far)) : __any(far)))
-          far_run_mirror(std::integral_constant<int, KF>(), far);
-      }
-      if constexpr (!DENSE && PARK && ITM_RAY_PROBE_CELLS > 0) {
+      if constexpr (!DENSE && PARK && kProbeCells > 0) {
         // phase 1, once the wave has nothing left to march but rays inside "not found" runs (the other lanes are done or wait for their
-        // trilinear read): those rays look ITM_RAY_PROBE_CELLS positions ahead together, one round trip for the whole wave
-        const bool runner = st == MARCH && missStreak >= ITM_RAY_PROBE_AT;
+        // trilinear read): those rays look kProbeCells positions ahead together, one round trip for the whole wave
+        const bool runner = st == MARCH && missStreak >= kProbeAt;
         if (vol.dirPtr && __all(st != MARCH || runner) && __any(runner)) {
-          const int adv = miss_run(std::integral_constant<int, ITM_RAY_PROBE_CELLS>(), runner);
+          const int adv = miss_run(std::integral_constant<int, kProbeCells>(), runner);
           if (runner) missStreak += adv;
         }
       }
       if constexpr (!DENSE && PARK) {
-        if (st == MARCH && missStreak >= ITM_RAY_PARK_STREAK) { parked = true; st = DONE; }
+        if (st == MARCH && missStreak >= kParkStreak) { parked = true; st = DONE; }
       }
       if constexpr (!DENSE && LOOKAHEAD > 0) {
-        if (vol.dirPtr && __any(missStreak >= ITM_RAY_PARK_STREAK && st == MARCH))
-          (void)miss_run(std::integral_constant<int, (LOOKAHEAD > 0 ? LOOKAHEAD : 1)>(), missStreak >= ITM_RAY_PARK_STREAK && st == MARCH);
+        if (vol.dirPtr && __any(missStreak >= kParkStreak && st == MARCH))
+          (void)miss_run(std::integral_constant<int, (LOOKAHEAD > 0 ? LOOKAHEAD : 1)>(), missStreak >= kParkStreak && st == MARCH);
       }
     }
     ITM_WT(const unsigned long long wtA = wt_clock(); const unsigned wtTriLanes = __popcll(__ballot(st == TRI || st == REFINE)); wtInner = (unsigned)wt_wave_max(wtInner);)
     // ---- expensive phase: one 2x2x2 fetch for every lane that waits for one ---------------------------------------------
     if (st == TRI || st == REFINE) {
-      ++reads;
       Corners<VX, DENSE> cn;
       cn.fetch(vol, px, py, pz, cache);
       if (st == REFINE) {
@@ -944,7 +670,6 @@ __device__ inline float4 march_ray(int x, int y, const VOL& vol, const RayParams
     if ((threadIdx.x & 63) == 0 && wv < 8192) { unsigned long long* o = g_waveStats + (size_t)wv * 12; o[0] = wtEnd - wtStart; o[1] = mOuter; }
   }
 #endif
-  if (readsOut) *readsOut = reads;
   if (PARK && parked) return make_float4(px, py, pz, total);
   return make_float4(px, py, pz, w);
 }
@@ -952,12 +677,8 @@ __device__ inline float4 march_ray(int x, int y, const VOL& vol, const RayParams
 // castRay for callers that want one ray start to finish
 template <class VX, bool DENSE, class VOL = VolumeView>
 __device__ inline float4 cast_ray(int x, int y, const VOL& vol, const RayParams& p, float2 mm) {
-#if !ITM_RAY_WHILE_WHILE
-  return cast_ray_plain<VX, DENSE>(x, y, vol, p, mm);
-#else
   bool parked;
   return march_ray<VX, DENSE, 0, false>(x, y, vol, p, mm, nullptr, parked);
-#endif
 }
 
 }  // namespace itm

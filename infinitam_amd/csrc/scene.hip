@@ -218,32 +218,6 @@ static int directory_pass(itm_scene* s, hipStream_t st) {
   return ITM_OK;
 }
 
-// Near bits (itm_types.h) from the table: every entry that holds or may again hold a block (ptr >= -1: a swapped-out entry gets its
-// block back without passing through the allocation sweep).  One workgroup per 2048 table slots: the entries found are queued in LDS
-// and splatted by all 256 threads together.
-__global__ void __launch_bounds__(256) near_bits_fill_kernel(const uint4* __restrict__ hash, int nEntries, uint32_t* __restrict__ nearWords, AccelOrigin org) {
-  __shared__ short4 found[kSweepChunk];
-  __shared__ int count;
-  if (threadIdx.x == 0) count = 0;
-  __syncthreads();
-  const int base = blockIdx.x * kSweepChunk;
-  for (int i = threadIdx.x; i < kSweepChunk; i += 256) {
-    if (base + i >= nEntries) break;
-    const HashEntry e = unpack_entry(hash[base + i]);
-    if (e.ptr >= -1) found[atomicAdd(&count, 1)] = make_short4(e.px, e.py, e.pz, 0);
-  }
-  __syncthreads();
-  const int n = count;
-  for (int k = 0; k < n; ++k) near_bits_splat(nearWords, org, found[k].x, found[k].y, found[k].z, (int)threadIdx.x, 256);
-}
-int near_bits_rebuild(itm_scene* s, hipStream_t st) {
-  if (!s->nearBits) return ITM_OK;
-  ITM_HIP(hipMemsetAsync(s->nearBits, 0, kMirrorCells, st));
-  near_bits_fill_kernel<<<s->numChunks, 256, 0, st>>>(s->hash, s->noTotalEntries, s->nearBits, s->org);
-  ITM_LAUNCH_CHECK();
-  return ITM_OK;
-}
-
 // the mirror's values again from the pool (the voxels were replaced, the table was not)
 int rebuild_sdf_mirror(itm_scene* s, hipStream_t st) { return mirror_pass<true>(s, st); }
 
@@ -251,7 +225,6 @@ int rebuild_sdf_mirror(itm_scene* s, hipStream_t st) { return mirror_pass<true>(
 int accel_unfill(itm_scene* s, hipStream_t st) {
   int rc = directory_pass<false>(s, st);
   if (rc) return rc;
-  if (s->nearBits) ITM_HIP(hipMemsetAsync(s->nearBits, 0, kMirrorCells, st));      // (16 MB: the one structure cheap enough to clear whole)
   return mirror_pass<false>(s, st);
 }
 
@@ -263,7 +236,6 @@ int rebuild_head_bits(itm_scene* s, hipStream_t st) {
   ITM_LAUNCH_CHECK();
   int rc = directory_pass<true>(s, st);
   if (rc) return rc;
-  if ((rc = near_bits_rebuild(s, st))) return rc;
   return mirror_pass<true>(s, st);
 }
 
@@ -311,7 +283,6 @@ int accel_place(itm_scene* s, const float* invM, hipStream_t st) {
   ++s->accelMoves;
   if (moveDir) rc = directory_pass<true>(s, st);
   if (!rc && moveMir) rc = mirror_pass<true>(s, st);
-  if (!rc && moveMir) rc = near_bits_rebuild(s, st);
   return rc;
 }
 
@@ -396,7 +367,6 @@ static void* buffer_of(const itm_scene* s, const itm_render_state* rs, int which
     case ITM_BUF_VOXEL_BLOCKS: if (s) { *bytes = s->numVoxels * s->voxBytes; return s->vba; } break;
     case ITM_BUF_ALLOCATION_LIST: if (s) { *bytes = (hashScene ? (size_t)s->cfg.localBlockNum : 1) * 4; return s->allocList; } break;
     case ITM_BUF_SWAP_STATES: if (hashScene && s->swapStates) { *bytes = (size_t)s->noTotalEntries; return s->swapStates; } break;
-    case ITM_BUF_NEAR_BITS: if (hashScene && s->nearBits) { *bytes = kMirrorCells; return s->nearBits; } break;
     default: break;
   }
   if (!rs) return nullptr;
@@ -414,7 +384,6 @@ static void* buffer_of(const itm_scene* s, const itm_render_state* rs, int which
   return nullptr;
 }
 
-int g_debug_no_near_bits = 0;          // debug key 21: set before itm_scene_create, no near bits are allocated; at run time the ray caster ignores them
 static std::atomic<int> g_liveHashScenes[64];
 int live_hash_scenes(int device) { return (device >= 0 && device < 64) ? g_liveHashScenes[device].load() : 2; }
 
@@ -438,7 +407,7 @@ static void free_scene(itm_scene* s) {
   if (s->prof) { s->prof->flush(); for (hipEvent_t e : s->prof->pool) (void)hipEventDestroy(e); delete s->prof; }
   (void)hipFree(s->hash); (void)hipFree(s->excessList); (void)hipFree(s->vba); (void)hipFree(s->allocList);
   (void)hipFree(s->counters); (void)hipFree(s->headBits); (void)hipFree(s->allocKey); (void)hipFree(s->chunkReq); (void)hipFree(s->chunkVis); (void)hipFree(s->chunkGran); (void)hipFree(s->chunkSweepDone);
-  (void)hipFree(s->dirPtr); (void)hipFree(s->dirSlot); (void)hipFree(s->sdfMirror); (void)hipFree(s->org.mTable); (void)hipFree(s->org.mPages); (void)hipFree(s->nearBits); (void)hipFree(s->depthTiles);
+  (void)hipFree(s->dirPtr); (void)hipFree(s->dirSlot); (void)hipFree(s->sdfMirror); (void)hipFree(s->org.mTable); (void)hipFree(s->org.mPages); (void)hipFree(s->depthTiles);
   delete s;
 }
 static void free_rs(itm_render_state* r) {
@@ -456,7 +425,7 @@ static void free_rs(itm_render_state* r) {
   } else forget_deferred(r);
   (void)hipFree(r->range); (void)hipFree(r->raycast); (void)hipFree(r->fwdProj); (void)hipFree(r->missing);
   (void)hipFree(r->image); (void)hipFree(r->visibleIds); (void)hipFree(r->visibleType); (void)hipFree(r->counters);
-  (void)hipFree(r->projBuf); (void)hipFree(r->rangePartials); (void)hipFree(r->pixScratch); (void)hipFree(r->rayClass); (void)hipFree(r->pixChunk); (void)hipFree(r->viewFlags); (void)hipFree(r->viewChunkVis);
+  (void)hipFree(r->projBuf); (void)hipFree(r->rangePartials); (void)hipFree(r->pixScratch); (void)hipFree(r->pixChunk); (void)hipFree(r->viewFlags); (void)hipFree(r->viewChunkVis);
   if (r->sideStream) { (void)hipStreamSynchronize(r->sideStream); (void)hipStreamDestroy(r->sideStream); }
   if (r->listReady) (void)hipEventDestroy(r->listReady);
   if (r->projectionDone) (void)hipEventDestroy(r->projectionDone);
@@ -601,17 +570,6 @@ int itm_scene_create(const itm_scene_config* cfg_in, const itm_scene_params* prm
           hipMalloc((void**)&s->org.mPages, 4) != hipSuccess || mirror_clear(s, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) drop();
     }
   }
-  // near bits (itm_types.h): MEASUREMENT FEATURE, only in libraries built with -DITM_NEAR_BITS=1 and then off unless ITM_NEAR_BITS=1 is in the
-  // environment when the scene is created.  Built for
-  // VERDICT r3 item 4 -- steps through proven-empty space on arithmetic alone -- and measured slower in every form tried (ray cast
-  // 38.3 -> 42.3 .. 47.4 us, profiles/r4_raycast_notes.md): the march is bound by the instructions a step issues, not by its loads, and
-  // the bookkeeping of a skip costs more issue slots than the reads it saves.  The default library does not consult them either
-  // (ITM_RAY_NEAR_SKIP, raycast_device.h); the maintenance and its tests stay so that the experiment can be repeated.
-  if (ITM_NEAR_BITS && s->sdfMirror && !g_debug_no_near_bits && [] { const char* e = getenv("ITM_NEAR_BITS"); return e && e[0] == '1'; }()) {
-    if (hipMalloc((void**)&s->nearBits, kMirrorCells) != hipSuccess || hipMemset(s->nearBits, 0, kMirrorCells) != hipSuccess) {
-      (void)hipGetLastError(); (void)hipFree(s->nearBits); s->nearBits = nullptr;
-    }
-  }
   if (cfg.indexType == ITM_INDEX_HASH && s->device >= 0 && s->device < 64) { g_liveHashScenes[s->device].fetch_add(1); s->countedLive = true; }
   e = hipMemset(s->counters, 0, sizeof(SceneCounters));
   if (e == hipSuccess && s->allocKey) e = hipMemset(s->allocKey, 0, (size_t)s->noTotalEntries * 4);
@@ -660,7 +618,6 @@ int itm_scene_accel_info(const itm_scene* s, itm_accel_info* out) {
   memset(out, 0, sizeof *out);
   out->directory_bytes = s->dirPtr ? (int64_t)(kDirCells * 4) : 0;
   out->slot_directory_bytes = s->dirSlot ? (int64_t)(kDirCells * 4) : 0;
-  out->near_bits_bytes = s->nearBits ? (int64_t)kMirrorCells : 0;
   out->mirror_bytes = !s->sdfMirror ? 0 : s->org.mMaxPages < 0 ? (int64_t)(kMirrorCells * 512 * (mirror_is_float(s) ? 4 : 2))
                                                                   : (int64_t)((size_t)s->mirrorPages * kPageBlocks * 512 * (mirror_is_float(s) ? 4 : 2) + kMirrorTableCells * 4);
   out->mirror_pages = s->mirrorPages;          // 0 for the dense form
@@ -732,7 +689,6 @@ int itm_render_state_create(const itm_scene* s, int w, int h, itm_render_state**
   alloc((void**)&r->image, P * 4);
   alloc((void**)&r->counters, sizeof(RenderCounters));
   alloc((void**)&r->pixScratch, P * 4);
-  alloc((void**)&r->rayClass, P);
   alloc((void**)&r->pixChunk, ((P + kSweepChunk - 1) / kSweepChunk) * 4 + 16);
   if (r->hash) {
     alloc((void**)&r->visibleIds, (size_t)r->capIds * 4);
@@ -747,7 +703,6 @@ int itm_render_state_create(const itm_scene* s, int w, int h, itm_render_state**
   if (e == hipSuccess) e = hipMemset(r->fwdProj, 0, P * 16);
   if (e == hipSuccess) e = hipMemset(r->missing, 0, P * 4);
   if (e == hipSuccess) e = hipMemset(r->image, 0, P * 4);
-  if (e == hipSuccess) e = hipMemset(r->rayClass, 0, P);
   if (e == hipSuccess && r->hash) e = hipMemset(r->visibleIds, 0, (size_t)r->capIds * 4);
   if (e == hipSuccess && r->hash) e = hipMemset(r->visibleType, 0, (size_t)s->noTotalEntries);
   if (e != hipSuccess) { free_rs(r); return hip_fail(e, "hipMemset(render state)", __FILE__, __LINE__); }
@@ -898,7 +853,6 @@ int itm_upload(itm_scene* s, itm_render_state* rs, int which, const void* src, s
   if (!p || !src || bytes > b) return set_error(ITM_ERR_INVALID, "bad buffer / size");
   { const int rc = enter_scene(s, rs); if (rc) return rc; }
   if ((which == ITM_BUF_VISIBLE_IDS || which == ITM_BUF_VISIBLE_TYPE) && refuse_while_ahead(s, rs, "upload of the visible list")) return ITM_ERR_INVALID;
-  if (which == ITM_BUF_NEAR_BITS) return set_error(ITM_ERR_INVALID, "the near bits are derived from the table: download only");
   hipStream_t st = as_stream(stream);
   if (which == ITM_BUF_HASH_ENTRIES) { int rc = accel_unfill(s, st); if (rc) return rc; ++s->tableEpoch; }      // while the table still holds what filled the cubes
   ITM_HIP(hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, st));

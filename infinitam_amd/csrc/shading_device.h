@@ -17,7 +17,6 @@ static inline VolumeView make_volume(const itm_scene* s) {
   v.hash = s->hash; v.vba = s->vba; v.headBits = s->headBits;
   v.dirPtr = g_debug_no_directory ? nullptr : s->dirPtr;
   v.sdfMirror = (g_debug_no_directory || g_debug_no_sdf_mirror) ? nullptr : s->sdfMirror;
-  v.nearBits = (v.sdfMirror && !g_debug_no_near_bits) ? (const uint8_t*)s->nearBits : nullptr;
   v.pageTable = s->org.mTable;
   v.org = s->org;
   v.mask = (uint32_t)s->cfg.bucketNum - 1u; v.bucketNum = s->cfg.bucketNum;
@@ -33,7 +32,6 @@ static inline void make_ray_params(const itm_scene* s, const float* invM, const 
   p.mu = s->prm.mu; p.voxelSize = s->prm.voxelSize;
   p.lx = -invM[8]; p.ly = -invM[9]; p.lz = -invM[10];
   p.W = W; p.H = H;
-  p.rayClass = nullptr;
 }
 
 __device__ inline uchar4 grey_pixel(float angle) {  // drawPixelGrey

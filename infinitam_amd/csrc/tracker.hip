@@ -151,15 +151,9 @@ __device__ inline bool bilinear_holes(const float4* __restrict__ src, float px, 
 // registers (double), so a call delivers at most kGHGroups records to the host whatever the image size -- with one record per
 // tile, the 1 200 records (288 KB over PCIe, two system fences per workgroup) of a 640x480 level cost 113 us per evaluation
 // against 20 us for the 40x30 level (tools/tracker_bench.py).
-#ifndef ITM_GH_GROUPS
-#define ITM_GH_GROUPS 256
-#endif
-#ifndef ITM_GH_WAVES
-#define ITM_GH_WAVES 4           // waves per workgroup (measured per 640x480 evaluation: 4 waves 43 us, 8 waves 51 us, 16 waves 73 us)
-#endif
-constexpr int kGHGroups = ITM_GH_GROUPS;
+constexpr int kGHGroups = 256;
 constexpr int kSegs = (kGHGroups + kSegBlocks - 1) / kSegBlocks;
-constexpr int kGHWaves = ITM_GH_WAVES;
+constexpr int kGHWaves = 4;      // waves per workgroup (measured per 640x480 evaluation: 4 waves 43 us, 8 waves 51 us, 16 waves 73 us)
 static_assert(kSegBlocks % kGHWaves == 0, "a gathering workgroup splits its segment evenly over its waves");
 constexpr int kGHThreads = 64 * kGHWaves;
 constexpr int kGHTileH = kGHThreads / 16;      // a tile is 16 pixels wide and at most kGHTileH tall
@@ -358,13 +352,8 @@ __global__ void __launch_bounds__(kGHThreads) gh_partial_kernel(const float* __r
 // session gone starts another one at the pending sequence number (same stream: it begins when the old one has left entirely).
 constexpr unsigned int kSessionExit = 0xffffffffu;
 constexpr unsigned long long kSessionIdleTicks = 200000ull;   // 2 ms
-#ifndef ITM_SESSION_POLL_SLEEP
-#define ITM_SESSION_POLL_SLEEP 4      // s_sleep argument between two polls of the command granules (x64 clocks)
-#endif
-#ifndef ITM_SESSION_TO_HOST_BLOCKS
-#define ITM_SESSION_TO_HOST_BLOCKS 96
-#endif
-constexpr int kSessionToHostBlocks = ITM_SESSION_TO_HOST_BLOCKS;   // evaluations with at most this many workgroups answer with per-workgroup records
+constexpr int kSessionPollSleep = 4;       // s_sleep argument between two polls of the command granules (x64 clocks)
+constexpr int kSessionToHostBlocks = 96;   // evaluations with at most this many workgroups answer with per-workgroup records
 struct GHCommand {            // the payload words of the command granules
   GHParams p;
   const float* depth; const float4* points; const float4* normals;
@@ -431,9 +420,7 @@ __global__ void __launch_bounds__(kGHThreads) gh_session_kernel(const unsigned l
           s = kSessionExit;
           break;
         }
-#if ITM_SESSION_POLL_SLEEP > 0
-        __builtin_amdgcn_s_sleep(ITM_SESSION_POLL_SLEEP);
-#endif
+        __builtin_amdgcn_s_sleep(kSessionPollSleep);
       }
       if (lane == 0) { nextSeq = s; gatherFailed = 0; }
     }

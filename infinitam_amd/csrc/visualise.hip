@@ -33,18 +33,6 @@ namespace itm {
 #ifndef ITM_MIRROR_FLOAT_TYPES
 #define ITM_MIRROR_FLOAT_TYPES 0     // (scene.hip decides whether a float scene gets a mirror; the same switch must be given to every file)
 #endif
-#ifndef ITM_RAY_SORT
-#define ITM_RAY_SORT 0
-#endif
-#ifndef ITM_RAY_SORT_LONG
-#define ITM_RAY_SORT_LONG 9          // reads of the previous frame's ray (in a pixel's 5 x 5 neighbourhood) from which a ray counts as long when the tile's rays are dealt to its waves
-#endif
-#ifndef ITM_MIRROR_STAGE_TABLE
-#define ITM_MIRROR_STAGE_TABLE 0     // 1: every ray-cast workgroup copies the mirror's page table (16 KB) to LDS in its prologue
-#endif
-#ifndef ITM_NT_STORES
-#define ITM_NT_STORES 1
-#endif
 
 int g_debug_force_global_range = 0;
 int g_debug_no_directory = 0;
@@ -53,7 +41,6 @@ int g_debug_no_fused_range_reduce = 0;
 int g_debug_single_pass_raycast = 0;
 int g_debug_no_side_projection = 0;
 int g_debug_dense_range_refill = 0;
-int g_debug_no_ray_sort = 0;         // debug key 23: rays are dealt to the waves in image order although the render state has the previous cast's lengths
 
 // ---------------------------------------------------------------------------------------------
 // expected depth range
@@ -337,13 +324,8 @@ __device__ inline void reduce_own_cells(const RangeFuse& f, int tx, int ty, int 
 // the same workgroup re-packs the parked rays 64 per wave: all lanes are then in the same phase, and the look-ahead of
 // march_ray turns the ~45 dependent round trips of the run into ~8.  (As a second LAUNCH over a global queue the parked rays
 // took 52 us on their own -- one wave per SIMD, other XCDs' cold L2s -- against 34 us for the first pass; measured, dropped.)
-#ifndef ITM_RAY_SILHOUETTE_SPREAD
-#define ITM_RAY_SILHOUETTE_SPREAD 0.3f
-#endif
-#ifndef ITM_RAY_SILHOUETTE_PRIO
-#define ITM_RAY_SILHOUETTE_PRIO 3
-#endif
-constexpr float kSilhouetteSpread = ITM_RAY_SILHOUETTE_SPREAD;   // metres between the near and far bound of a tile's expected depths
+constexpr float kSilhouetteSpread = 0.3f;   // metres between the near and far bound of a tile's expected depths from which the tile counts as holding a silhouette
+constexpr int kSilhouettePrio = 3;          // s_setprio of such a tile's waves (0.03 m, i.e. nearly every tile: no gain; priority only in phase 2: no gain)
 #ifndef ITM_EXP_RAYCAST_STAMPS
 #define ITM_EXP_RAYCAST_STAMPS 0   // measurement build: per-wave timeline of the ray-cast launch on the 100 MHz clock (tools/raycast_timeline.py)
 #endif
@@ -370,64 +352,17 @@ __global__ void __launch_bounds__(256) raycast_kernel(VolumeView volIn, const fl
       return;
     }
   }
-  // The mirror's page table (itm_types.h: 16^3 entries) in LDS: requested first, so that it travels beside the prologue's own loads; the
-  // barrier of the prologue below is the one behind which it is read
-  constexpr bool kStageTable = !DENSE && MIRROR == 2 && kMirrorTableCells <= 4096 && ITM_MIRROR_STAGE_TABLE;
-  __shared__ int32_t pageLds[kStageTable ? kMirrorTableCells : 1];
   VolumeViewM<MIRROR> vol(volIn);
   if constexpr (MIRROR == 0) vol.sdfMirror = nullptr;
-  if constexpr (kStageTable) {
-    if (volIn.sdfMirror && volIn.pageTable) {
-      for (int i = threadIdx.x; i < (int)kMirrorTableCells; i += 256) pageLds[i] = volIn.pageTable[i];
-      vol.pageTable = pageLds;
-    }
-  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // (An XCD-affine order -- image band b ray-cast by XCD b, with integration placing the blocks of band b on XCD b --
   // recovers 5 of the ~17 us the rays lose to voxel lines written on other XCDs, but costs integration 10 us; and 8x8
   // pixel waves change nothing.  Both measured)
   const int tilesX = (p.W + 15) / 16;
   const int tx = blockIdx.x % tilesX, ty = blockIdx.x / tilesX;
-  // DEALING THE RAYS TO THE WAVES (round 4; MEASUREMENT BUILDS ONLY, -DITM_RAY_SORT=1: bit-exact, and slower -- BASELINE configs[1]
-  // 37.8-39.3 -> 40.3-40.4 us, configs[4] 123.6 -> 129.7, configs[2] +-0, profiles/r4_raycast_notes.md section 3: the long rays'
-  // chains are as long in a wave of their own, the short waves lose their image-order locality, and the prologue is paid by every tile).
-  // In image order every wave of a silhouette tile holds a few long rays -- past the rim, through
-  // the empty stretch, to the wall -- among its short ones, and lasts as long as they do while its other lanes idle; the launch lasts as
-  // long as those waves.  The previous ray cast through this render state left, per pixel, the number of reads its ray took (p.rayClass;
-  // the camera moves a pixel or two per frame).  A tile's pixels whose 5 x 5 neighbourhood held a long ray then are dealt out FIRST: the
-  // tile's long rays fill its first wave(s), where every lane is in the same phase of its march (the wave-wide look-ahead applies from
-  // the start, no trilinear read of a short neighbour interrupts), and the other waves hold short rays only and are gone early.  Which
-  // lane casts which ray changes nothing about the ray: same positions, same reads, same result, written to the ray's own pixel.
-  int lx = lane & 15, ly = wave * 4 + (lane >> 4);
-  __shared__ uint8_t prevClass[20 * 20];
-  __shared__ uint8_t dealt[256];
-  __shared__ int longInWave[4];
-  const bool sortRays = ITM_RAY_SORT && p.rayClass != nullptr;
-  if (sortRays) {
-    for (int i = threadIdx.x; i < 400; i += 256) {
-      const int gx = tx * 16 - 2 + i % 20, gy = ty * 16 - 2 + i / 20;
-      prevClass[i] = (gx >= 0 && gx < p.W && gy >= 0 && gy < p.H) ? p.rayClass[gx + gy * p.W] : (uint8_t)0;
-    }
-    __syncthreads();
-    int worst = 0;
-#pragma unroll
-    for (int dy = 0; dy < 5; ++dy)
-#pragma unroll
-      for (int dx = 0; dx < 5; ++dx) worst = max(worst, (int)prevClass[(ly + dy) * 20 + lx + dx]);
-    const bool isLong = worst >= ITM_RAY_SORT_LONG && tx * 16 + lx < p.W && ty * 16 + ly < p.H;
-    const unsigned long long b = __ballot(isLong);
-    if (lane == 0) longInWave[wave] = __popcll(b);
-    __syncthreads();
-    int longBefore = 0, longAll = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) { const int c = longInWave[w]; longAll += c; if (w < wave) longBefore += c; }
-    const int below = __popcll(b & ((1ull << lane) - 1ull));
-    const int pos = isLong ? longBefore + below : longAll + (wave * 64 - longBefore) + (lane - below);
-    dealt[pos] = (uint8_t)(ly * 16 + lx);
-    __syncthreads();
-    const int mine = dealt[threadIdx.x];
-    lx = mine & 15; ly = mine >> 4;
-  }
+  // (Dealing a tile's rays to its waves long rays first, by the previous cast's per-pixel read counts, was built and measured in round 4:
+  // bit-exact and slower, profiles/r4_raycast_notes.md section 3.)
+  const int lx = lane & 15, ly = wave * 4 + (lane >> 4);
   const int x = tx * 16 + lx;
   const int y = ty * 16 + ly;
   const bool inside = x < p.W && y < p.H;
@@ -443,7 +378,7 @@ __global__ void __launch_bounds__(256) raycast_kernel(VolumeView volIn, const fl
     __syncthreads();
     if (inside) mm = cellRange[(lx >> 3) + 2 * (ly >> 3)];
   } else {
-    if (PARK || kStageTable) __syncthreads();
+    if (PARK) __syncthreads();
     if (inside) mm = range[(x >> 3) + (y >> 3) * p.W];  // floor(x/8) + floor(y/8)*W  (_CPU.cpp:174)
   }
   ITM_RS(if (lane == 0) stamp[1] = __builtin_amdgcn_s_memrealtime();)
@@ -451,19 +386,17 @@ __global__ void __launch_bounds__(256) raycast_kernel(VolumeView volIn, const fl
   // (profiles/r2_raycast_timeline.txt), and while the other ~1 000 tiles are still resident they share each SIMD's issue slots with
   // four other waves.  Raised wave priority lets them issue first: 48.2 -> 46.1 us in frame (config 2; a threshold of 0.03 m, i.e.
   // nearly every tile, gives nothing; delaying the other tiles by 3-14 us instead: no gain, config 5 +4..20 us).
-  if (!DENSE && __any(inside && mm.y - mm.x > kSilhouetteSpread)) __builtin_amdgcn_s_setprio(ITM_RAY_SILHOUETTE_PRIO);
+  if (!DENSE && __any(inside && mm.y - mm.x > kSilhouetteSpread)) __builtin_amdgcn_s_setprio(kSilhouettePrio);
   // ---- phase 1: every ray of the tile; rays that turn out to be crossing empty space are parked ----
   bool parked = false;
   if (inside) {
-    int reads = 0;
-    const float4 r = march_ray<VX, DENSE, DENSE ? ITM_RAY_DENSE_LOOKAHEAD : 0, PARK>(x, y, vol, p, mm, nullptr, parked, &reads);
+    const float4 r = march_ray<VX, DENSE, DENSE ? kDenseLookahead : 0, PARK>(x, y, vol, p, mm, nullptr, parked);
     if (!parked) out[x + y * p.W] = r;
     else if constexpr (PARK) {
       const int slot = atomicAdd(&parkCount, 1);
       parkState[slot] = r;
       parkSource[slot] = ly * 16 + lx;           // the pixel of the tile the ray belongs to
     }
-    if (sortRays) p.rayClass[x + y * p.W] = (uint8_t)(parked ? 255 : min(reads, 254));
   }
   ITM_RS(if (lane == 0) { stamp[2] = __builtin_amdgcn_s_memrealtime(); stamp[3] = 0; })
   if constexpr (PARK) {
@@ -479,7 +412,7 @@ __global__ void __launch_bounds__(256) raycast_kernel(VolumeView volIn, const fl
       else m2 = range[(qx >> 3) + (qy >> 3) * p.W];
       const RayResume rr{q.x, q.y, q.z, q.w};
       bool again;
-      out[qx + qy * p.W] = march_ray<VX, DENSE, ITM_RAY_PARKED_LOOKAHEAD, false>(qx, qy, vol, p, m2, &rr, again);
+      out[qx + qy * p.W] = march_ray<VX, DENSE, kParkedLookahead, false>(qx, qy, vol, p, m2, &rr, again);
     }
     ITM_RS(if (lane == 0) stamp[3] = __builtin_amdgcn_s_memrealtime() | ((unsigned long long)(wave == 0 ? n : 0) << 52);)
   }
@@ -490,7 +423,6 @@ extern "C" int itm_debug_read_raycast_stamps(unsigned long long* dst, int n) { r
 
 int launch_raycast(const itm_scene* s, const float* invM, const float* intr, itm_render_state* rs, float4* dst, hipStream_t st, bool reduceRange, const AheadRequest* aheadIn) {
   RayParams p; make_ray_params(s, invM, intr, rs->w, rs->h, p);
-  p.rayClass = (ITM_RAY_SORT && !g_debug_no_ray_sort) ? rs->rayClass : nullptr;
   const VolumeView vol = make_volume(s);
   const int rayTiles = ((rs->w + 15) / 16) * ((rs->h + 15) / 16);
   const bool dense = s->cfg.indexType == ITM_INDEX_DENSE;
@@ -538,12 +470,8 @@ int launch_raycast(const itm_scene* s, const float* invM, const float* intr, itm
 // ---------------------------------------------------------------------------------------------
 // Streaming outputs (11 MB per frame that nothing on the GPU re-reads soon) are stored with the non-temporal hint so that
 // they do not wash the hash lines, occupancy words and voxel lines of the next kernels out of the 4 MB L2s.
-#if ITM_NT_STORES
 __device__ inline void nt_store(float4* p, float4 v) { __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y); __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w); }
 __device__ inline void nt_store(uchar4* p, uchar4 v) { __builtin_nontemporal_store(*(unsigned int*)&v, (unsigned int*)p); }
-#else
-template <class T> __device__ inline void nt_store(T* p, T v) { *p = v; }
-#endif
 
 __global__ void __launch_bounds__(256) icp_maps_kernel(const float4* __restrict__ rays, float4* __restrict__ points,
                                                        float4* __restrict__ normals, uchar4* __restrict__ image, RayParams p) {
@@ -704,9 +632,6 @@ int itm_debug_set(int key, int value) {
   if (key == ITM_DEBUG_DENSE_CLASSIFY) { g_debug_dense_classify = value; return ITM_OK; }
   if (key == ITM_DEBUG_TRACKER_SESSION_UNUSABLE) { g_debug_tracker_session_unusable = value; return ITM_OK; }
   if (key == ITM_DEBUG_DENSE_NO_STRIPS) { g_debug_dense_no_strips = value; return ITM_OK; }
-  if (key == ITM_DEBUG_NO_RAY_SORT) { g_debug_no_ray_sort = value; return ITM_OK; }
-  if (key == ITM_DEBUG_INTEGRATE_BLOCK_PER_WAVE) { g_debug_integrate_block_per_wave = value; return ITM_OK; }
-  if (key == ITM_DEBUG_NO_NEAR_BITS) { g_debug_no_near_bits = value; return ITM_OK; }
   if (key == ITM_DEBUG_NO_DEFERRED_FUSION) { g_debug_no_deferred_fusion = value; return ITM_OK; }
   if (key == ITM_DEBUG_FORCE_LIST_STUCK) { g_debug_force_list_stuck = value; return ITM_OK; }
   return set_error(ITM_ERR_INVALID, "unknown debug key");

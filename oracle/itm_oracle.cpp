@@ -21,6 +21,7 @@
 
 #define ITM_FN(name) itmo_##name
 #include "../include/itm_hip.h"
+#include "../include/itm_debug.h"
 
 #include <cmath>
 #include <cstdint>

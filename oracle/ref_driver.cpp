@@ -13,6 +13,7 @@
 
 #define ITM_FN(name) itmr_##name
 #include "../include/itm_hip.h"
+#include "../include/itm_debug.h"
 
 #include <cstring>
 #include <string>
