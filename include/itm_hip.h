@@ -168,6 +168,11 @@ int ITM_FN(dev_free)(void* ptr);
 /* page-locked host memory (hipHostMalloc): the source of asynchronous uploads, see itm_depth_stager */
 int ITM_FN(host_malloc)(void** ptr, size_t bytes);
 int ITM_FN(host_free)(void* ptr);
+/* Page-locks host memory the HOST owns (hipHostRegister): an image buffer of the reference (ORUtils::MemoryBlock allocates with `new`)
+ * becomes a source / target of asynchronous copies at PCIe speed -- from pageable memory itm_memcpy_h2d is staged through the runtime's
+ * bounce buffer and blocks the calling thread.  Registering a range twice is not an error.  Unregister before the memory is freed. */
+int ITM_FN(host_register)(void* ptr, size_t bytes);
+int ITM_FN(host_unregister)(void* ptr);
 int ITM_FN(memcpy_h2d)(void* dst_dev, const void* src_host, size_t bytes, itm_stream stream);
 int ITM_FN(memcpy_d2h)(void* dst_host, const void* src_dev, size_t bytes, itm_stream stream);
 int ITM_FN(stream_synchronize)(itm_stream stream);

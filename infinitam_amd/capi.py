@@ -241,6 +241,8 @@ _HOST_IO_SIGS = {
     "global_cache_flags": (C.c_int, [_P, _P, C.c_size_t]),
     "host_malloc": (C.c_int, [C.POINTER(_P), C.c_size_t]),
     "host_free": (C.c_int, [_P]),
+    "host_register": (C.c_int, [_P, C.c_size_t]),
+    "host_unregister": (C.c_int, [_P]),
     "depth_stager_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "depth_stager_destroy": (C.c_int, [_P]),
     "depth_stager_upload": (C.c_int, [_P, _P]),

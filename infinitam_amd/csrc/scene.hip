@@ -464,6 +464,19 @@ int itm_host_malloc(void** p, size_t n) {
   return ITM_OK;
 }
 int itm_host_free(void* p) { ITM_HIP(hipHostFree(p)); return ITM_OK; }
+int itm_host_register(void* p, size_t n) {
+  if (!p || !n) return set_error(ITM_ERR_INVALID, "null pointer / empty range");
+  const hipError_t e = hipHostRegister(p, n, hipHostRegisterDefault);
+  if (e == hipErrorHostMemoryAlreadyRegistered) { (void)hipGetLastError(); return ITM_OK; }
+  if (e != hipSuccess) return hip_fail(e, "hipHostRegister", __FILE__, __LINE__);
+  return ITM_OK;
+}
+int itm_host_unregister(void* p) {
+  if (!p) return ITM_OK;
+  const hipError_t e = hipHostUnregister(p);
+  if (e != hipSuccess) { (void)hipGetLastError(); return set_error(ITM_ERR_INVALID, "the range was not registered"); }
+  return ITM_OK;
+}
 int itm_memcpy_h2d(void* d, const void* s, size_t n, itm_stream st) {
   { const int rc = flush_overlapping(d, n, as_stream(st)); if (rc) return rc; }     // recorded engine calls that read the target (pending.hip)
   ITM_HIP(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, as_stream(st)));

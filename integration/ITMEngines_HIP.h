@@ -5,10 +5,21 @@
 // copied here -- the classes below are new code against its public interfaces.
 //
 // Memory model.  The scene lives in HBM inside libitmhip.so ("device twin" of an ITMScene object, created on first
-// use).  This adapter is written for a reference build WITHOUT CUDA, whose images only have host storage: the depth /
-// colour image of a view is staged into HBM on every call and the results the rest of InfiniTAM reads on the host
-// (visible list, range image, ray-cast result, ICP maps, renders, counters) are mirrored back after each call.  A
-// build whose MemoryBlocks have a device slot passes those pointers instead and drops the staging.
+// use).  This adapter is written for a reference build WITHOUT CUDA, whose images only have host storage:
+//   * a view's depth / colour image is staged into HBM ONCE per frame: HipMarkViewUpdated(view) -- called by
+//     ITMViewBuilder_HIP::UpdateView (ITMTrackers_HIP.h), or by whoever else fills the view -- starts a new generation of the
+//     view, and the engine calls of a frame (AllocateSceneFromDepth, IntegrateIntoScene, CreateICPMaps: ITMDenseMapper.cpp:50-57,
+//     ITMTrackingController.cpp:30-46) then hand the library byte-identical views, which is what lets it record the first
+//     three and launch the fused frame at the fourth (include/itm_hip.h, "the four calls of a frame").  A view nobody
+//     ever marked is staged on every call (always correct, never fused);
+//   * what the rest of InfiniTAM reads on the host (visible list, range image, ray-cast result, ICP maps, shaded image,
+//     counters) comes back under a POLICY: HIP_MIRROR_EAGER downloads after every call (a host that reads its images
+//     right after each engine call: today's ITMLib with a host tracker), HIP_MIRROR_ON_DEMAND leaves everything in HBM
+//     until HipSyncRenderStateToHost / HipSyncTrackingStateToHost / HipSyncViewToHost ask for it (a host whose next
+//     consumer is on the device too -- ITMDepthTracker_HIP takes the ICP maps straight from HBM -- or that only looks at
+//     results now and then: a UI, a mesh export).  Results are identical; ON_DEMAND is the one in which a frame is 5 launches
+//     and no synchronisation (measured by ref_hip_demo --bench).
+// A build whose MemoryBlocks have a device slot passes those pointers instead and drops the staging.
 // SyncSceneToHost() copies table + voxels into the reference's host scene on demand (saving, meshing, tests).
 #pragma once
 
@@ -35,6 +46,8 @@ inline int HipDownload(void* dst_host, const void* src_dev, size_t bytes, itm_st
   return rc != ITM_OK ? rc : itm_stream_synchronize(stream);
 }
 
+enum HipMirrorPolicy { HIP_MIRROR_EAGER = 0, HIP_MIRROR_ON_DEMAND = 1 };
+
 template <class TVoxel> struct HipVoxelTag;
 template <> struct HipVoxelTag<ITMVoxel_s> { enum { value = ITM_VOXEL_S }; };
 template <> struct HipVoxelTag<ITMVoxel_f> { enum { value = ITM_VOXEL_F }; };
@@ -44,6 +57,9 @@ template <> struct HipVoxelTag<ITMVoxel_f_rgb> { enum { value = ITM_VOXEL_F_RGB 
 // render-state shells that own their device twin (the reference deletes render states through the virtual destructor)
 struct HipRenderStateTwin {
   itm_render_state* dev = nullptr;
+  const itm_scene* devScene = nullptr;
+  // HIP_MIRROR_ON_DEMAND: parts of the host shell that are older than the device twin (HipSyncRenderStateToHost brings them back)
+  bool staleList = false, staleRange = false, staleRays = false, staleImage = false, staleForward = false;
   virtual ~HipRenderStateTwin() { itm_render_state_destroy(dev); }
 };
 struct ITMRenderState_VH_HIP : public ITMRenderState_VH, public HipRenderStateTwin {
@@ -76,15 +92,45 @@ template <> struct HipIndexTraits<ITMPlainVoxelArray> {
 
 // ---- device twins, keyed by the address of the reference object they shadow ------------------------------------
 struct HipRegistry {
+  HipMirrorPolicy policy = HIP_MIRROR_EAGER;
   std::map<const void*, itm_scene*> scenes;
-  struct Stage { void* depth = nullptr; void* rgb = nullptr; void* points = nullptr; void* normals = nullptr; size_t pixels = 0, rgbPixels = 0; };
+  // a view's images in HBM.  `generation` counts the times the host said the view has new content (HipMarkViewUpdated);
+  // `depthStaged` / `rgbStaged` say which generation the device copy holds.  hostDepthStale: the device copy is NEWER than the
+  // host image (ITMViewBuilder_HIP converted the raw frame in HBM and the policy did not ask for the host copy).
+  struct Stage {
+    void* depth = nullptr; void* rgb = nullptr; size_t pixels = 0, rgbPixels = 0;
+    bool tracked = false; unsigned long long generation = 0, depthStaged = ~0ull, rgbStaged = ~0ull;
+    bool hostDepthStale = false;
+    void* pinnedDepth = nullptr; void* pinnedRgb = nullptr;      // host ranges page-locked for asynchronous uploads
+  };
   std::map<const void*, Stage> views;
+  // the ICP maps / point cloud of a tracking state in HBM (trackingState->pointCloud->locations / ->colours)
+  struct Maps { void* points = nullptr; void* normals = nullptr; size_t pixels = 0, count = 0; bool hostStale = false; const void* locationsImage = nullptr; };      // count: elements the last call wrote
+  std::map<const void*, Maps> maps;
   static HipRegistry& Get() { static HipRegistry r; return r; }
+  static void Free(Stage& st) {
+    itm_dev_free(st.depth); itm_dev_free(st.rgb);
+    if (st.pinnedDepth) itm_host_unregister(st.pinnedDepth);
+    if (st.pinnedRgb) itm_host_unregister(st.pinnedRgb);
+    st = Stage();
+  }
+  static void Free(Maps& m) { itm_dev_free(m.points); itm_dev_free(m.normals); m = Maps(); }
   ~HipRegistry() {
     for (auto& kv : scenes) itm_scene_destroy(kv.second);
-    for (auto& kv : views) { itm_dev_free(kv.second.depth); itm_dev_free(kv.second.rgb); itm_dev_free(kv.second.points); itm_dev_free(kv.second.normals); }
+    for (auto& kv : views) Free(kv.second);
+    for (auto& kv : maps) Free(kv.second);
   }
 };
+inline void HipSetMirrorPolicy(HipMirrorPolicy p) { HipRegistry::Get().policy = p; }
+inline bool HipEager() { return HipRegistry::Get().policy == HIP_MIRROR_EAGER; }
+
+// "This view has new content": to be called once per frame by whoever fills the view's host images (ITMViewBuilder_HIP does;
+// a host that keeps the reference's CPU view builder adds this one line behind its UpdateView call).  From then on the view
+// is staged once per generation instead of on every engine call.
+inline void HipMarkViewUpdated(const ITMView* view) {
+  HipRegistry::Stage& st = HipRegistry::Get().views[view];
+  st.tracked = true; ++st.generation; st.hostDepthStale = false;
+}
 
 template <class TVoxel, class TIndex>
 itm_scene* HipSceneOf(const ITMScene<TVoxel, TIndex>* scene) {
@@ -117,30 +163,72 @@ inline void HipReleaseScene(const void* scene) {
 inline void HipReleaseView(const void* view) {
   auto it = HipRegistry::Get().views.find(view);
   if (it == HipRegistry::Get().views.end()) return;
-  itm_dev_free(it->second.depth); itm_dev_free(it->second.rgb); itm_dev_free(it->second.points); itm_dev_free(it->second.normals);
+  HipRegistry::Free(it->second);
   HipRegistry::Get().views.erase(it);
 }
-
-inline itm_render_state* HipRenderStateOf(const ITMRenderState* rs) {
-  const HipRenderStateTwin* t = dynamic_cast<const HipRenderStateTwin*>(rs);
-  if (!t || !t->dev) throw std::runtime_error("render state was not created by the HIP visualisation engine");
-  return t->dev;
+inline void HipReleaseTrackingState(const void* ts) {
+  auto it = HipRegistry::Get().maps.find(ts);
+  if (it == HipRegistry::Get().maps.end()) return;
+  HipRegistry::Free(it->second);
+  HipRegistry::Get().maps.erase(it);
 }
 
-// stages the host images of a view in HBM and fills the POD view of the C-ABI
-inline itm_view HipStageView(const ITMView* view, const ITMPose* pose_d, bool withRgb) {
+inline HipRenderStateTwin* HipTwinOf(const ITMRenderState* rs) {
+  HipRenderStateTwin* t = const_cast<HipRenderStateTwin*>(dynamic_cast<const HipRenderStateTwin*>(rs));
+  if (!t || !t->dev) throw std::runtime_error("render state was not created by the HIP visualisation engine");
+  return t;
+}
+inline itm_render_state* HipRenderStateOf(const ITMRenderState* rs) { return HipTwinOf(rs)->dev; }
+
+// the device images of a view, allocated on first use
+inline HipRegistry::Stage& HipStageOf(const ITMView* view) {
   HipRegistry::Stage& st = HipRegistry::Get().views[view];
   const Vector2i ds = view->depth->noDims, cs = view->rgb->noDims;
   const size_t px = (size_t)ds.x * ds.y, cpx = (size_t)cs.x * cs.y;
-  if (st.pixels != px) {
-    itm_dev_free(st.depth); itm_dev_free(st.points); itm_dev_free(st.normals);
-    HipCheck(itm_dev_malloc(&st.depth, px * 4), "dev_malloc"); HipCheck(itm_dev_malloc(&st.points, px * 16), "dev_malloc"); HipCheck(itm_dev_malloc(&st.normals, px * 16), "dev_malloc");
-    st.pixels = px;
+  if (st.pixels != px) { itm_dev_free(st.depth); HipCheck(itm_dev_malloc(&st.depth, px * 4), "dev_malloc"); st.pixels = px; st.depthStaged = ~0ull; }
+  if (st.rgbPixels != cpx) { itm_dev_free(st.rgb); HipCheck(itm_dev_malloc(&st.rgb, cpx * 4), "dev_malloc"); st.rgbPixels = cpx; st.rgbStaged = ~0ull; }
+  return st;
+}
+// the device maps of a tracking state, allocated on first use
+inline HipRegistry::Maps& HipMapsOf(const ITMTrackingState* ts) {
+  HipRegistry::Maps& m = HipRegistry::Get().maps[ts];
+  const Vector2i s = ts->pointCloud->locations->noDims;
+  const size_t px = (size_t)s.x * s.y;
+  if (m.pixels != px) {
+    itm_dev_free(m.points); itm_dev_free(m.normals);
+    HipCheck(itm_dev_malloc(&m.points, px * 16), "dev_malloc"); HipCheck(itm_dev_malloc(&m.normals, px * 16), "dev_malloc");
+    m.pixels = px; m.hostStale = false; m.count = 0;
   }
-  if (st.rgbPixels != cpx) { itm_dev_free(st.rgb); HipCheck(itm_dev_malloc(&st.rgb, cpx * 4), "dev_malloc"); st.rgbPixels = cpx; }
-  HipCheck(itm_memcpy_h2d(st.depth, view->depth->GetData(MEMORYDEVICE_CPU), px * 4, 0), "memcpy_h2d");
-  if (withRgb) HipCheck(itm_memcpy_h2d(st.rgb, view->rgb->GetData(MEMORYDEVICE_CPU), cpx * 4, 0), "memcpy_h2d");
+  m.locationsImage = ts->pointCloud->locations;
+  return m;
+}
+
+// page-locks a host image the first time it is uploaded from (the reference allocates its images with `new`; a pageable source
+// makes every upload a blocking, bounce-buffered copy).  Failure to lock is not an error: the copy is merely slower.
+inline void HipPin(void*& pinned, const void* host, size_t bytes) {
+  if (pinned == host) return;
+  if (pinned) itm_host_unregister(pinned);
+  pinned = (itm_host_register(const_cast<void*>(host), bytes) == ITM_OK) ? const_cast<void*>(host) : nullptr;
+}
+
+// stages the host images of a view in HBM -- once per generation for a tracked view -- and fills the POD view of the C-ABI
+inline itm_view HipStageView(const ITMView* view, const ITMPose* pose_d, bool withRgb) {
+  HipRegistry::Stage& st = HipStageOf(view);
+  if (!st.tracked || st.depthStaged != st.generation) {
+    const void* host = view->depth->GetData(MEMORYDEVICE_CPU);
+    if (st.tracked) HipPin(st.pinnedDepth, host, st.pixels * 4);
+    HipCheck(itm_memcpy_h2d(st.depth, host, st.pixels * 4, 0), "memcpy_h2d");
+    st.depthStaged = st.generation;
+  }
+  if (withRgb && (!st.tracked || st.rgbStaged != st.generation)) {
+    const void* host = view->rgb->GetData(MEMORYDEVICE_CPU);
+    if (st.tracked) HipPin(st.pinnedRgb, host, st.rgbPixels * 4);
+    HipCheck(itm_memcpy_h2d(st.rgb, host, st.rgbPixels * 4, 0), "memcpy_h2d");
+    st.rgbStaged = st.generation;
+  }
+  const Vector2i ds = view->depth->noDims, cs = view->rgb->noDims;
   itm_view v; std::memset(&v, 0, sizeof v);
+  // (the rgb pointer is handed over whether or not this call uploaded it: the calls of one frame must name the same view)
   v.depth = (const float*)st.depth; v.rgb = (const uint8_t*)st.rgb;
   v.w = ds.x; v.h = ds.y; v.w_rgb = cs.x; v.h_rgb = cs.y;
   std::memcpy(v.M_d, pose_d->GetM().m, 64);
@@ -151,7 +239,8 @@ inline itm_view HipStageView(const ITMView* view, const ITMPose* pose_d, bool wi
   return v;
 }
 
-template <class TIndex> struct HipMirror;   // copies the index-specific part of a render state back to the host shell
+// ---- bringing results back to the host shells (every call under HIP_MIRROR_EAGER, on request under HIP_MIRROR_ON_DEMAND) ----
+template <class TIndex> struct HipMirror;   // the index-specific part of a render state
 template <> struct HipMirror<ITMVoxelBlockHash> {
   static void VisibleList(const itm_scene* dev, ITMRenderState* rs) {
     ITMRenderState_VH* vh = (ITMRenderState_VH*)rs;
@@ -164,6 +253,49 @@ template <> struct HipMirror<ITMVoxelBlockHash> {
 };
 template <> struct HipMirror<ITMPlainVoxelArray> { static void VisibleList(const itm_scene*, ITMRenderState*) {} };
 
+inline void HipMirrorImages(const itm_scene* dev, ITMRenderState* rs, bool range, bool rays, bool image) {
+  itm_render_state* d = HipRenderStateOf(rs);
+  const size_t px = (size_t)rs->raycastResult->noDims.x * rs->raycastResult->noDims.y;
+  if (range) HipCheck(itm_download(dev, d, ITM_BUF_RANGE_IMAGE, rs->renderingRangeImage->GetData(MEMORYDEVICE_CPU), px * 8, 0), "download range image");
+  if (rays) HipCheck(itm_download(dev, d, ITM_BUF_RAYCAST_RESULT, rs->raycastResult->GetData(MEMORYDEVICE_CPU), px * 16, 0), "download raycast result");
+  if (image) HipCheck(itm_download(dev, d, ITM_BUF_RAYCAST_IMAGE, rs->raycastImage->GetData(MEMORYDEVICE_CPU), px * 4, 0), "download raycast image");
+}
+inline void HipMirrorForward(const itm_scene* dev, ITMRenderState* rs) {
+  itm_render_state* d = HipRenderStateOf(rs);
+  const size_t px = (size_t)rs->forwardProjection->noDims.x * rs->forwardProjection->noDims.y;
+  HipCheck(itm_download(dev, d, ITM_BUF_FORWARD_PROJECTION, rs->forwardProjection->GetData(MEMORYDEVICE_CPU), px * 16, 0), "download");
+  HipCheck(itm_download(dev, d, ITM_BUF_MISSING_POINTS, rs->fwdProjMissingPoints->GetData(MEMORYDEVICE_CPU), px * 4, 0), "download");
+  itm_counters c; HipCheck(itm_get_counters(dev, d, &c, 0), "get_counters");
+  rs->noFwdProjMissingPoints = c.noFwdProjMissingPoints;
+}
+
+// HIP_MIRROR_ON_DEMAND: everything of the render state's host shell that is older than its device twin.  TIndex picks the
+// visible-list part (ITMRenderState_VH for the hash index).
+template <class TIndex>
+inline void HipSyncRenderStateToHost(ITMRenderState* rs) {
+  HipRenderStateTwin* t = HipTwinOf(rs);
+  if (t->staleList) HipMirror<TIndex>::VisibleList(t->devScene, rs);
+  HipMirrorImages(t->devScene, rs, t->staleRange, t->staleRays, t->staleImage);
+  if (t->staleForward) HipMirrorForward(t->devScene, rs);
+  t->staleList = t->staleRange = t->staleRays = t->staleImage = t->staleForward = false;
+}
+// ... of a tracking state's point cloud (the ICP maps CreateICPMaps wrote, or the points of CreatePointCloud)
+inline void HipSyncTrackingStateToHost(ITMTrackingState* ts) {
+  HipRegistry::Maps& m = HipMapsOf(ts);
+  if (!m.hostStale) return;
+  const size_t n = m.count * 16;
+  HipCheck(itm_memcpy_d2h(ts->pointCloud->locations->GetData(MEMORYDEVICE_CPU), m.points, n, 0), "memcpy_d2h");
+  HipCheck(HipDownload(ts->pointCloud->colours->GetData(MEMORYDEVICE_CPU), m.normals, n, 0), "memcpy_d2h");
+  m.hostStale = false;
+}
+// ... of a view whose float depth was produced in HBM (ITMViewBuilder_HIP)
+inline void HipSyncViewToHost(ITMView* view) {
+  HipRegistry::Stage& st = HipStageOf(view);
+  if (!st.hostDepthStale) return;
+  HipCheck(HipDownload(view->depth->GetData(MEMORYDEVICE_CPU), st.depth, st.pixels * 4, 0), "memcpy_d2h");
+  st.hostDepthStale = false;
+}
+
 // ---- ITMSceneReconstructionEngine ---------------------------------------------------------------------------
 template <class TVoxel, class TIndex>
 class ITMSceneReconstructionEngine_HIP : public ITMSceneReconstructionEngine<TVoxel, TIndex> {
@@ -172,12 +304,14 @@ class ITMSceneReconstructionEngine_HIP : public ITMSceneReconstructionEngine<TVo
  public:
   void ResetScene(ITMScene<TVoxel, TIndex>* scene) { HipCheck(itm_reset_scene(HipSceneOf(scene), 0), "ResetScene"); }
 
+  // (colour scenes stage the rgb image with the first call of the frame, so that all calls of the frame name the same view)
   void AllocateSceneFromDepth(ITMScene<TVoxel, TIndex>* scene, const ITMView* view, const ITMTrackingState* trackingState,
                               const ITMRenderState* renderState, bool onlyUpdateVisibleList = false) {
     itm_scene* dev = HipSceneOf(scene);
-    itm_view v = HipStageView(view, trackingState->pose_d, false);
+    itm_view v = HipStageView(view, trackingState->pose_d, Colour());
     HipCheck(itm_allocate_scene_from_depth(dev, &v, HipRenderStateOf(renderState), onlyUpdateVisibleList ? 1 : 0, 0), "AllocateSceneFromDepth");
-    HipMirror<TIndex>::VisibleList(dev, const_cast<ITMRenderState*>(renderState));
+    if (HipEager()) HipMirror<TIndex>::VisibleList(dev, const_cast<ITMRenderState*>(renderState));
+    else HipTwinOf(renderState)->staleList = true;
   }
 
   void IntegrateIntoScene(ITMScene<TVoxel, TIndex>* scene, const ITMView* view, const ITMTrackingState* trackingState,
@@ -214,13 +348,13 @@ void ITMSceneReconstructionEngine_HIP<TVoxel, TIndex>::SyncSceneToHost(ITMScene<
 // ---- ITMVisualisationEngine ---------------------------------------------------------------------------------
 template <class TVoxel, class TIndex>
 class ITMVisualisationEngine_HIP : public ITMVisualisationEngine<TVoxel, TIndex> {
+  static bool Colour() { return HipVoxelTag<TVoxel>::value == ITM_VOXEL_S_RGB || HipVoxelTag<TVoxel>::value == ITM_VOXEL_F_RGB; }
   itm_scene* Dev() const { return HipSceneOf(this->scene); }
-  void MirrorImages(ITMRenderState* rs, bool range, bool rays, bool image) const {
-    itm_render_state* d = HipRenderStateOf(rs);
-    const size_t px = (size_t)rs->raycastResult->noDims.x * rs->raycastResult->noDims.y;
-    if (range) HipCheck(itm_download(Dev(), d, ITM_BUF_RANGE_IMAGE, rs->renderingRangeImage->GetData(MEMORYDEVICE_CPU), px * 8, 0), "download range image");
-    if (rays) HipCheck(itm_download(Dev(), d, ITM_BUF_RAYCAST_RESULT, rs->raycastResult->GetData(MEMORYDEVICE_CPU), px * 16, 0), "download raycast result");
-    if (image) HipCheck(itm_download(Dev(), d, ITM_BUF_RAYCAST_IMAGE, rs->raycastImage->GetData(MEMORYDEVICE_CPU), px * 4, 0), "download raycast image");
+  // after a call that wrote parts of the render state: back to the host now, or marked for HipSyncRenderStateToHost
+  void Mirror(ITMRenderState* rs, bool range, bool rays, bool image) const {
+    if (HipEager()) { HipMirrorImages(Dev(), rs, range, rays, image); return; }
+    HipRenderStateTwin* t = HipTwinOf(rs);
+    t->staleRange |= range; t->staleRays |= rays; t->staleImage |= image;
   }
 
  public:
@@ -231,17 +365,20 @@ class ITMVisualisationEngine_HIP : public ITMVisualisationEngine<TVoxel, TIndex>
     auto* rs =
         HipIndexTraits<TIndex>::NewRenderState(imgSize, this->scene->sceneParams->viewFrustum_min, this->scene->sceneParams->viewFrustum_max);
     HipCheck(itm_render_state_create(Dev(), imgSize.x, imgSize.y, &rs->dev), "CreateRenderState");
+    rs->devScene = Dev();
     return rs;
   }
 
   void FindVisibleBlocks(const ITMPose* pose, const ITMIntrinsics* intrinsics, ITMRenderState* renderState) const {
     HipCheck(itm_find_visible_blocks(Dev(), pose->GetM().m, &intrinsics->projectionParamsSimple.all.x, HipRenderStateOf(renderState), 0), "FindVisibleBlocks");
-    HipMirror<TIndex>::VisibleList(Dev(), renderState);
+    if (HipEager()) HipMirror<TIndex>::VisibleList(Dev(), renderState);
+    else HipTwinOf(renderState)->staleList = true;
   }
   void CreateExpectedDepths(const ITMPose* pose, const ITMIntrinsics* intrinsics, ITMRenderState* renderState) const {
     HipCheck(itm_create_expected_depths(Dev(), pose->GetM().m, &intrinsics->projectionParamsSimple.all.x, HipRenderStateOf(renderState), 0), "CreateExpectedDepths");
-    MirrorImages(renderState, true, false, false);
+    Mirror(renderState, true, false, false);
   }
+  // (the caller reads outputImage as soon as this returns: a synchronous download under either policy)
   void RenderImage(const ITMPose* pose, const ITMIntrinsics* intrinsics, const ITMRenderState* renderState, ITMUChar4Image* outputImage,
                    IITMVisualisationEngine::RenderImageType type = IITMVisualisationEngine::RENDER_SHADED_GREYSCALE) const {
     const size_t px = (size_t)outputImage->noDims.x * outputImage->noDims.y;
@@ -254,40 +391,38 @@ class ITMVisualisationEngine_HIP : public ITMVisualisationEngine<TVoxel, TIndex>
     if (rc == ITM_OK) rc = HipDownload(outputImage->GetData(MEMORYDEVICE_CPU), out, px * 4, 0);
     itm_dev_free(out);
     HipCheck(rc, "RenderImage");
-    MirrorImages(const_cast<ITMRenderState*>(renderState), false, true, false);
+    Mirror(const_cast<ITMRenderState*>(renderState), false, true, false);
   }
   void FindSurface(const ITMPose* pose, const ITMIntrinsics* intrinsics, const ITMRenderState* renderState) const {
     HipCheck(itm_find_surface(Dev(), pose->GetM().m, &intrinsics->projectionParamsSimple.all.x, HipRenderStateOf(renderState), 0), "FindSurface");
-    MirrorImages(const_cast<ITMRenderState*>(renderState), false, true, false);
+    Mirror(const_cast<ITMRenderState*>(renderState), false, true, false);
   }
+  // (noTotalPoints is a host member the colour tracker sizes its loops with: read back under either policy)
   void CreatePointCloud(const ITMView* view, ITMTrackingState* trackingState, ITMRenderState* renderState, bool skipPoints) const {
-    itm_view v = HipStageView(view, trackingState->pose_d, false);
-    HipRegistry::Stage& st = HipRegistry::Get().views[view];
-    HipCheck(itm_create_point_cloud(Dev(), &v, HipRenderStateOf(renderState), skipPoints ? 1 : 0, (float*)st.points, (float*)st.normals, 0), "CreatePointCloud");
+    itm_view v = HipStageView(view, trackingState->pose_d, Colour());
+    HipRegistry::Maps& m = HipMapsOf(trackingState);
+    HipCheck(itm_create_point_cloud(Dev(), &v, HipRenderStateOf(renderState), skipPoints ? 1 : 0, (float*)m.points, (float*)m.normals, 0), "CreatePointCloud");
     itm_counters c; HipCheck(itm_get_counters(Dev(), HipRenderStateOf(renderState), &c, 0), "get_counters");
     trackingState->pointCloud->noTotalPoints = c.noTotalPoints;
-    HipCheck(HipDownload(trackingState->pointCloud->locations->GetData(MEMORYDEVICE_CPU), st.points, (size_t)c.noTotalPoints * 16, 0), "memcpy_d2h");
-    HipCheck(HipDownload(trackingState->pointCloud->colours->GetData(MEMORYDEVICE_CPU), st.normals, (size_t)c.noTotalPoints * 16, 0), "memcpy_d2h");
+    m.count = (size_t)c.noTotalPoints; m.hostStale = true;
+    if (HipEager()) HipSyncTrackingStateToHost(trackingState);
     trackingState->pose_pointCloud->SetFrom(trackingState->pose_d);
+    Mirror(renderState, false, true, false);
   }
   void CreateICPMaps(const ITMView* view, ITMTrackingState* trackingState, ITMRenderState* renderState) const {
-    itm_view v = HipStageView(view, trackingState->pose_d, false);
-    HipRegistry::Stage& st = HipRegistry::Get().views[view];
-    HipCheck(itm_create_icp_maps(Dev(), &v, HipRenderStateOf(renderState), (float*)st.points, (float*)st.normals, 0), "CreateICPMaps");
-    HipCheck(HipDownload(trackingState->pointCloud->locations->GetData(MEMORYDEVICE_CPU), st.points, st.pixels * 16, 0), "memcpy_d2h");
-    HipCheck(HipDownload(trackingState->pointCloud->colours->GetData(MEMORYDEVICE_CPU), st.normals, st.pixels * 16, 0), "memcpy_d2h");
+    itm_view v = HipStageView(view, trackingState->pose_d, Colour());
+    HipRegistry::Maps& m = HipMapsOf(trackingState);
+    HipCheck(itm_create_icp_maps(Dev(), &v, HipRenderStateOf(renderState), (float*)m.points, (float*)m.normals, 0), "CreateICPMaps");
+    m.count = m.pixels; m.hostStale = true;
+    if (HipEager()) HipSyncTrackingStateToHost(trackingState);
     trackingState->pose_pointCloud->SetFrom(trackingState->pose_d);   // ITMVisualisationEngine_CPU.cpp CreateICPMaps
-    MirrorImages(renderState, false, true, true);
+    Mirror(renderState, false, true, true);
   }
   void ForwardRender(const ITMView* view, ITMTrackingState* trackingState, ITMRenderState* renderState) const {
-    itm_view v = HipStageView(view, trackingState->pose_d, false);
-    itm_render_state* d = HipRenderStateOf(renderState);
-    HipCheck(itm_forward_render(Dev(), &v, d, 0), "ForwardRender");
-    const size_t px = (size_t)renderState->forwardProjection->noDims.x * renderState->forwardProjection->noDims.y;
-    HipCheck(itm_download(Dev(), d, ITM_BUF_FORWARD_PROJECTION, renderState->forwardProjection->GetData(MEMORYDEVICE_CPU), px * 16, 0), "download");
-    HipCheck(itm_download(Dev(), d, ITM_BUF_MISSING_POINTS, renderState->fwdProjMissingPoints->GetData(MEMORYDEVICE_CPU), px * 4, 0), "download");
-    itm_counters c; HipCheck(itm_get_counters(Dev(), d, &c, 0), "get_counters");
-    renderState->noFwdProjMissingPoints = c.noFwdProjMissingPoints;
+    itm_view v = HipStageView(view, trackingState->pose_d, Colour());
+    HipCheck(itm_forward_render(Dev(), &v, HipRenderStateOf(renderState), 0), "ForwardRender");
+    if (HipEager()) HipMirrorForward(Dev(), renderState);
+    else HipTwinOf(renderState)->staleForward = true;
   }
 };
 

@@ -17,6 +17,7 @@ namespace Engine {
 
 class ITMDepthTracker_HIP : public ITMDepthTracker {
   void* devPoints = nullptr; void* devNormals = nullptr; void* devDepth = nullptr;
+  const void* mapPoints = nullptr; const void* mapNormals = nullptr;      // the maps of this call: the registry's (written by CreateICPMaps) or the staged copies
   size_t mapPixels = 0, depthPixels = 0;
   const void* stagedDepth = nullptr; int lastLevel = -1;
 
@@ -30,10 +31,18 @@ class ITMDepthTracker_HIP : public ITMDepthTracker {
     }
     if (dp > depthPixels) { itm_dev_free(devDepth); HipCheck(itm_dev_malloc(&devDepth, dp * 4), "dev_malloc"); depthPixels = dp; stagedDepth = nullptr; }
     // TrackCamera walks the levels from coarse (high id) to fine: a level id above the previous one means a new call,
-    // i.e. new ICP maps
+    // i.e. new ICP maps.  When CreateICPMaps of the HIP visualisation engine wrote them, they are still in HBM (whole maps): taken
+    // from there, nothing is uploaded
     if (levelId > lastLevel) {
-      HipCheck(itm_memcpy_h2d(devPoints, sceneHierarchyLevel->pointsMap->GetData(MEMORYDEVICE_CPU), mp * 16, 0), "memcpy_h2d");
-      HipCheck(itm_memcpy_h2d(devNormals, sceneHierarchyLevel->normalsMap->GetData(MEMORYDEVICE_CPU), mp * 16, 0), "memcpy_h2d");
+      mapPoints = devPoints; mapNormals = devNormals;
+      const HipRegistry::Maps* fresh = nullptr;
+      for (auto& kv : HipRegistry::Get().maps)
+        if (kv.second.locationsImage == (const void*)sceneHierarchyLevel->pointsMap && kv.second.pixels == mp && kv.second.count == mp) fresh = &kv.second;
+      if (fresh) { mapPoints = fresh->points; mapNormals = fresh->normals; }
+      else {
+        HipCheck(itm_memcpy_h2d(devPoints, sceneHierarchyLevel->pointsMap->GetData(MEMORYDEVICE_CPU), mp * 16, 0), "memcpy_h2d");
+        HipCheck(itm_memcpy_h2d(devNormals, sceneHierarchyLevel->normalsMap->GetData(MEMORYDEVICE_CPU), mp * 16, 0), "memcpy_h2d");
+      }
       stagedDepth = nullptr;
     }
     const float* hostDepth = viewHierarchyLevel->depth->GetData(MEMORYDEVICE_CPU);
@@ -52,8 +61,8 @@ class ITMDepthTracker_HIP : public ITMDepthTracker {
     const int it = iterationType == TRACKER_ITERATION_ROTATION ? ITM_TRACKER_ITERATION_ROTATION
                    : iterationType == TRACKER_ITERATION_TRANSLATION ? ITM_TRACKER_ITERATION_TRANSLATION : ITM_TRACKER_ITERATION_BOTH;
     itm_tracker_gh gh;
-    HipCheck(itm_tracker_compute_g_and_h((const float*)devDepth, ds.x, ds.y, &viewHierarchyLevel->intrinsics.x, (const float*)devPoints,
-                                         (const float*)devNormals, ss.x, ss.y, &sceneHierarchyLevel->intrinsics.x, approxInvPose.m, scenePose.m,
+    HipCheck(itm_tracker_compute_g_and_h((const float*)devDepth, ds.x, ds.y, &viewHierarchyLevel->intrinsics.x, (const float*)mapPoints,
+                                         (const float*)mapNormals, ss.x, ss.y, &sceneHierarchyLevel->intrinsics.x, approxInvPose.m, scenePose.m,
                                          distThresh[levelId], it, &gh, 0), "ComputeGandH");
     const int noPara = (it == ITM_TRACKER_ITERATION_BOTH) ? 6 : 3;
     for (int r = 0; r < noPara; ++r) for (int c = 0; c < noPara; ++c) hessian[r + c * 6] = gh.hessian[r + c * 6];
@@ -67,10 +76,18 @@ class ITMDepthTracker_HIP : public ITMDepthTracker {
                       float terminationThreshold, const ITMLowLevelEngine* lowLevelEngine)
       : ITMDepthTracker(imgSize, trackingRegime, noHierarchyLevels, noICPRunTillLevel, distThresh, terminationThreshold, lowLevelEngine, MEMORYDEVICE_CPU) {}
   ~ITMDepthTracker_HIP() { itm_dev_free(devPoints); itm_dev_free(devNormals); itm_dev_free(devDepth); }
+
+  // the reference's own TrackCamera builds its depth pyramid on the HOST from view->depth: under HIP_MIRROR_ON_DEMAND a view whose
+  // float depth was produced in HBM comes back first
+  void TrackCamera(ITMTrackingState* trackingState, const ITMView* view) {
+    HipSyncViewToHost(const_cast<ITMView*>(view));
+    ITMDepthTracker::TrackCamera(trackingState, view);
+  }
 };
 
 class ITMViewBuilder_HIP : public ITMViewBuilder {
   void* devRaw = nullptr; void* devA = nullptr; void* devB = nullptr; void* devN = nullptr; void* devS = nullptr;
+  void* pinnedRaw = nullptr;
   size_t pixels = 0;
   void Ensure(size_t px) {
     if (px == pixels) return;
@@ -82,7 +99,7 @@ class ITMViewBuilder_HIP : public ITMViewBuilder {
 
  public:
   explicit ITMViewBuilder_HIP(const ITMRGBDCalib* calib) : ITMViewBuilder(calib) {}
-  ~ITMViewBuilder_HIP() { itm_dev_free(devRaw); itm_dev_free(devA); itm_dev_free(devB); itm_dev_free(devN); itm_dev_free(devS); }
+  ~ITMViewBuilder_HIP() { if (pinnedRaw) itm_host_unregister(pinnedRaw); itm_dev_free(devRaw); itm_dev_free(devA); itm_dev_free(devB); itm_dev_free(devN); itm_dev_free(devS); }
 
   void ConvertDisparityToDepth(ITMFloatImage* depth_out, const ITMShortImage* disp_in, const ITMIntrinsics* depthIntrinsics, Vector2f disparityCalibParams) {
     const size_t px = (size_t)disp_in->noDims.x * disp_in->noDims.y; Ensure(px);
@@ -127,16 +144,22 @@ class ITMViewBuilder_HIP : public ITMViewBuilder {
     view->rgb->SetFrom(rgbImage, ORUtils::MemoryBlock<Vector4u>::CPU_TO_CPU);
     const int w = rawDepthImage->noDims.x, h = rawDepthImage->noDims.y;
     const size_t px = (size_t)w * h; Ensure(px);
+    HipPin(pinnedRaw, rawDepthImage->GetData(MEMORYDEVICE_CPU), px * 2);      // (the source engines reuse one raw image for every frame)
     HipCheck(itm_memcpy_h2d(devRaw, rawDepthImage->GetData(MEMORYDEVICE_CPU), px * 2, 0), "memcpy_h2d");
     if (modelSensorNoise) {
       HipCheck(itm_memcpy_h2d(devN, view->depthNormal->GetData(MEMORYDEVICE_CPU), px * 16, 0), "memcpy_h2d");
       HipCheck(itm_memcpy_h2d(devS, view->depthUncertainty->GetData(MEMORYDEVICE_CPU), px * 4, 0), "memcpy_h2d");
     }
     const ITMDisparityCalib& dc = view->calib->disparityCalib;
+    // the float depth is written straight into the view's device stage: the engine calls of this frame find it there (no float
+    // image crosses PCIe towards the device), the host image follows now or on request (HipSyncViewToHost)
+    HipRegistry::Stage& st = HipStageOf(view);
     HipCheck(itm_update_view((const int16_t*)devRaw, w, h, dc.type == ITMDisparityCalib::TRAFO_KINECT ? 0 : 1, dc.params.x, dc.params.y,
                              &view->calib->intrinsics_d.projectionParamsSimple.all.x, useBilateralFilter ? 1 : 0, modelSensorNoise ? 1 : 0,
-                             (float*)devA, (float*)devB, (float*)devN, (float*)devS, 0), "UpdateView");
-    HipCheck(HipDownload(view->depth->GetData(MEMORYDEVICE_CPU), devA, px * 4, 0), "memcpy_d2h");
+                             (float*)st.depth, (float*)devB, (float*)devN, (float*)devS, 0), "UpdateView");
+    HipMarkViewUpdated(view);
+    st.depthStaged = st.generation; st.hostDepthStale = true;
+    if (HipEager()) HipSyncViewToHost(view);
     if (modelSensorNoise) {
       HipCheck(HipDownload(view->depthNormal->GetData(MEMORYDEVICE_CPU), devN, px * 16, 0), "memcpy_d2h");
       HipCheck(HipDownload(view->depthUncertainty->GetData(MEMORYDEVICE_CPU), devS, px * 4, 0), "memcpy_d2h");
@@ -145,6 +168,7 @@ class ITMViewBuilder_HIP : public ITMViewBuilder {
   void UpdateView(ITMView** view_ptr, ITMUChar4Image* rgbImage, ITMFloatImage* depthImage) {
     if (*view_ptr == NULL) *view_ptr = new ITMView(calib, rgbImage->noDims, depthImage->noDims, false);
     // host build: the caller already wrote the float depth into the view (ITMViewBuilder_CPU.cpp:65-74)
+    HipMarkViewUpdated(*view_ptr);
   }
   void UpdateView(ITMView** view_ptr, ITMUChar4Image* rgbImage, ITMShortImage* depthImage, bool useBilateralFilter, ITMIMUMeasurement* imuMeasurement) {
     if (*view_ptr == NULL) *view_ptr = new ITMViewIMU(calib, rgbImage->noDims, depthImage->noDims, false);

@@ -2,10 +2,23 @@
 // reference's CPU engines, once with the HIP adapters of ITMEngines_HIP.h (libitmhip.so behind them), on the same
 // synthetic frames, and compares everything the rest of InfiniTAM would read -- bit for bit.
 //
+// Every configuration runs under BOTH mirror policies of the adapter (ITMEngines_HIP.h): HIP_MIRROR_EAGER (results back on the host
+// after every call) and HIP_MIRROR_ON_DEMAND (results stay in HBM until asked for) -- and checks, with the library's per-kernel
+// timers, that under ON_DEMAND the reference's four per-frame calls really ran as the fused frame (no separate expected-depth
+// launches), under EAGER they did not.
+//
+//   ref_hip_demo             parity at 160 x 120 (hash, colour hash, dense), view builder, tracker
+//   ref_hip_demo --bench N   BASELINE configs[1] through the reference's classes: 640 x 480, ITMVoxel_s, hash, 4 mm, bench trajectory;
+//                            parity over 5 frames at that size, then N timed frames per policy in the reference's call order
+//                            (ITMDenseMapper.cpp:50-57 + ITMTrackingController.cpp:30-46), the depth image uploaded from the
+//                            reference's host ITMView every frame
+//
 // Built only where the reference tree exists (oracle/Makefile target `hipdemo` -> oracle/_ref/ref_hip_demo, g++ only;
 // the binary travels to the GPU box).  Prints one JSON line per configuration; exit code 0 iff all are equal.
+#include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -29,11 +42,11 @@ template class ITMLib::Engine::ITMMeshingEngine_CPU<ITMVoxel_s, ITMPlainVoxelArr
 template class ITMLib::Engine::ITMSceneReconstructionEngine_CPU<ITMVoxel_s, ITMPlainVoxelArray>;
 template class ITMLib::Engine::ITMVisualisationEngine_CPU<ITMVoxel_s, ITMPlainVoxelArray>;
 
-static const int W = 160, H = 120;
+static int W = 160, H = 120;      // (--bench switches to 640 x 480)
 
 // sphere (r 0.5 m at z 1.5 m) in front of a wall at 2.5 m, camera at t, fp32 without contraction
 static void make_depth(float* d, float tx, float ty) {
-  const float fx = 145.0f, fy = 145.0f, cx = 80.0f, cy = 60.0f;
+  const float fx = 145.0f * (float)W / 160.0f, fy = fx, cx = 0.5f * (float)W, cy = 0.5f * (float)H;
   for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {
     const float dx = ((float)x - cx) / fx, dy = ((float)y - cy) / fy;
     const float ox = tx, oy = ty, oz = 0.0f - 1.5f;
@@ -75,8 +88,15 @@ template <> struct VisibleCmp<ITMPlainVoxelArray> {
   }
 };
 
+static void set_calib(ITMRGBDCalib& calib) {
+  const float f = 145.0f * (float)W / 160.0f;
+  calib.intrinsics_d.SetFrom(f, f, 0.5f * (float)W, 0.5f * (float)H, W, H); calib.intrinsics_rgb.SetFrom(f, f, 0.5f * (float)W, 0.5f * (float)H, W, H);
+}
+
 template <class TVoxel, class TIndex>
-static bool run(const char* name, float voxelSize, int frames) {
+static bool run(const char* name, float voxelSize, int frames, HipMirrorPolicy policy) {
+  HipSetMirrorPolicy(policy);
+  const bool onDemand = policy == HIP_MIRROR_ON_DEMAND;
   ITMSceneParams sp(0.02f, 100, voxelSize, 0.2f, 3.0f, false);
   ITMScene<TVoxel, TIndex> sceneA(&sp, false, MEMORYDEVICE_CPU), sceneB(&sp, false, MEMORYDEVICE_CPU);
   VisibleCmp<TIndex>::Configure(sceneA.index); VisibleCmp<TIndex>::Configure(sceneB.index);
@@ -85,7 +105,7 @@ static bool run(const char* name, float voxelSize, int frames) {
   ITMVisualisationEngine<TVoxel, TIndex>* vis[2] = {new ITMVisualisationEngine_CPU<TVoxel, TIndex>(&sceneA), new ITMVisualisationEngine_HIP<TVoxel, TIndex>(&sceneB)};
   ITMScene<TVoxel, TIndex>* scene[2] = {&sceneA, &sceneB};
   ITMRGBDCalib calib;
-  calib.intrinsics_d.SetFrom(145, 145, 80, 60, W, H); calib.intrinsics_rgb.SetFrom(145, 145, 80, 60, W, H);
+  set_calib(calib);
   ITMRenderState* rs[2]; ITMView* view[2]; ITMTrackingState* ts[2];
   for (int e = 0; e < 2; ++e) {
     reco[e]->ResetScene(scene[e]);
@@ -93,6 +113,9 @@ static bool run(const char* name, float voxelSize, int frames) {
     view[e] = new ITMView(&calib, Vector2i(W, H), Vector2i(W, H), false);
     ts[e] = new ITMTrackingState(Vector2i(W, H), MEMORYDEVICE_CPU);
   }
+  // the library's per-kernel timers say which launches the calls became: range = the separate CreateExpectedDepths launches
+  itm_scene* dev = HipSceneOf(&sceneB);
+  HipCheck(itm_profile_enable(dev, (1u << ITM_TK_RANGE) | (1u << ITM_TK_RAYCAST)), "profile_enable");
   std::string why; bool ok = true;
   ITMUChar4Image img[2] = {ITMUChar4Image(Vector2i(W, H), true, false), ITMUChar4Image(Vector2i(W, H), true, false)};
   for (int k = 0; k < frames && ok; ++k) {
@@ -103,6 +126,7 @@ static bool run(const char* name, float voxelSize, int frames) {
       Vector4u* c = view[e]->rgb->GetData(MEMORYDEVICE_CPU);
       for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) c[x + y * W] = Vector4u((uchar)(x & 255), (uchar)(y & 255), (uchar)((x ^ y) & 255), 255);
       ts[e]->pose_d->SetM(M);
+      if (e == 1) HipMarkViewUpdated(view[e]);      // what ITMViewBuilder_HIP::UpdateView does: the view has new content
       // ITMDenseMapper::ProcessFrame + ITMTrackingController::Prepare, then a free-view render
       reco[e]->AllocateSceneFromDepth(scene[e], view[e], ts[e], rs[e]);
       reco[e]->IntegrateIntoScene(scene[e], view[e], ts[e], rs[e]);
@@ -110,6 +134,7 @@ static bool run(const char* name, float voxelSize, int frames) {
       vis[e]->CreateICPMaps(view[e], ts[e], rs[e]);
       vis[e]->RenderImage(ts[e]->pose_d, &view[e]->calib->intrinsics_d, rs[e], &img[e], IITMVisualisationEngine::RENDER_COLOUR_FROM_NORMAL);
     }
+    if (onDemand) { HipSyncRenderStateToHost<TIndex>(rs[1]); HipSyncTrackingStateToHost(ts[1]); }      // what a host does before it reads
     const size_t px = (size_t)W * H;
     if (!VisibleCmp<TIndex>::Equal(rs[0], rs[1], why)) ok = false;
     // the range image is only defined on the sub-sampled region the rays read
@@ -123,6 +148,16 @@ static bool run(const char* name, float voxelSize, int frames) {
     if (!ok) why += " (frame " + std::to_string(k) + ")";
   }
   long long hits = 0;
+  itm_profile prof; std::memset(&prof, 0, sizeof prof);
+  HipCheck(itm_profile_read(dev, &prof, 1), "profile_read");
+  HipCheck(itm_profile_enable(dev, 0), "profile_enable");
+  if (ok && HipIndexTraits<TIndex>::value == ITM_INDEX_HASH) {
+    // ON_DEMAND: the four calls of every frame formed the fused frame (the free-view render adds one ray cast per frame, no range launch
+    // of the tracked view); EAGER: the downloads between the calls launched them one by one
+    const int rangeLaunches = prof.calls[ITM_TK_RANGE];
+    if (onDemand && rangeLaunches != 0) { ok = false; why = "ON_DEMAND: " + std::to_string(rangeLaunches) + " separate expected-depth launches -- the frame was not fused"; }
+    if (!onDemand && rangeLaunches == 0) { ok = false; why = "EAGER: no separate expected-depth launch although every call was mirrored"; }
+  }
   if (ok) {
     ITMSceneReconstructionEngine_HIP<TVoxel, TIndex>::SyncSceneToHost(&sceneB);
     if (!VisibleCmp<TIndex>::SceneEqual(sceneA.index, sceneB.index, why)) ok = false;
@@ -142,10 +177,84 @@ static bool run(const char* name, float voxelSize, int frames) {
     else if (!same(mesh[0]->triangles->GetData(MEMORYDEVICE_CPU), mesh[1]->triangles->GetData(MEMORYDEVICE_CPU), (size_t)mesh[0]->noTotalTriangles)) { ok = false; why = "mesh triangles"; }
     for (int e = 0; e < 2; ++e) { delete mesh[e]; delete mesher[e]; }
   }
-  std::printf("{\"config\": \"%s\", \"frames\": %d, \"equal\": %s, \"icp_points\": %lld, \"lastFreeBlockId\": %d, \"triangles\": %lld, \"mismatch\": \"%s\"}\n", name, frames,
-              ok ? "true" : "false", hits, sceneB.localVBA.lastFreeBlockId, triangles, why.c_str());
+  std::printf("{\"config\": \"%s\", \"policy\": \"%s\", \"frames\": %d, \"equal\": %s, \"icp_points\": %lld, \"lastFreeBlockId\": %d, \"triangles\": %lld, "
+              "\"range_launches\": %d, \"raycast_launches\": %d, \"mismatch\": \"%s\"}\n", name, onDemand ? "on_demand" : "eager", frames,
+              ok ? "true" : "false", hits, sceneB.localVBA.lastFreeBlockId, triangles, (int)prof.calls[ITM_TK_RANGE], (int)prof.calls[ITM_TK_RAYCAST], why.c_str());
   // teardown in the reference's order: render states, then engines (the HIP visualisation engine releases the scene twin)
-  for (int e = 0; e < 2; ++e) { HipReleaseView(view[e]); delete rs[e]; delete view[e]; delete ts[e]; delete reco[e]; delete vis[e]; }
+  for (int e = 0; e < 2; ++e) { HipReleaseView(view[e]); HipReleaseTrackingState(ts[e]); delete rs[e]; delete view[e]; delete ts[e]; delete reco[e]; delete vis[e]; }
+  HipSetMirrorPolicy(HIP_MIRROR_EAGER);
+  return ok;
+}
+
+// ---- --bench: BASELINE configs[1] through the reference's own classes --------------------------------------------------------------
+static int tri(int k) { return std::abs(((k + 25) % 100) - 50) - 25; }      // the bench trajectory: bounded triangle waves, period 100
+
+// `frames` timed frames (after 20 of warm-up) of: view has new content -> AllocateSceneFromDepth -> IntegrateIntoScene (ITMDenseMapper::
+// ProcessFrame) -> CreateExpectedDepths -> CreateICPMaps (ITMTrackingController::Prepare), every call through the reference's base-class
+// pointers; the 100 distinct frames of the trajectory live in 100 host ITMViews and are uploaded again every time they come round
+static double time_frames(ITMScene<ITMVoxel_s, ITMVoxelBlockHash>* scene, ITMSceneReconstructionEngine<ITMVoxel_s, ITMVoxelBlockHash>* reco,
+                          ITMVisualisationEngine<ITMVoxel_s, ITMVoxelBlockHash>* vis, std::vector<ITMView*>& views, ITMTrackingState* ts, ITMRenderState* rs,
+                          int frames, bool hip) {
+  reco->ResetScene(scene);
+  const int warm = hip ? 20 : 1;
+  std::chrono::steady_clock::time_point t0;
+  for (int k = 0; k < warm + frames; ++k) {
+    if (k == warm) { if (hip) HipCheck(itm_stream_synchronize(0), "sync"); t0 = std::chrono::steady_clock::now(); }
+    ITMView* v = views[(size_t)k % views.size()];
+    Matrix4f M; M.setIdentity(); M.m[12] = -(0.004f * (float)tri(k)); M.m[13] = -(0.002f * (float)tri(2 * k));
+    ts->pose_d->SetM(M);
+    if (hip) HipMarkViewUpdated(v);
+    reco->AllocateSceneFromDepth(scene, v, ts, rs);
+    reco->IntegrateIntoScene(scene, v, ts, rs);
+    vis->CreateExpectedDepths(ts->pose_d, &v->calib->intrinsics_d, rs);
+    vis->CreateICPMaps(v, ts, rs);
+  }
+  if (hip) HipCheck(itm_stream_synchronize(0), "sync");
+  return (double)frames / std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+static bool run_bench(int frames) {
+  W = 640; H = 480;
+  bool ok = true;
+  ok &= run<ITMVoxel_s, ITMVoxelBlockHash>("BASELINE configs[1] size: hash ITMVoxel_s 4 mm 640x480", 0.004f, 5, HIP_MIRROR_EAGER);
+  ok &= run<ITMVoxel_s, ITMVoxelBlockHash>("BASELINE configs[1] size: hash ITMVoxel_s 4 mm 640x480", 0.004f, 5, HIP_MIRROR_ON_DEMAND);
+  ITMSceneParams sp(0.02f, 100, 0.004f, 0.35f, 3.0f, false);
+  ITMRGBDCalib calib; set_calib(calib);
+  std::vector<ITMView*> views;
+  for (int k = 0; k < 100; ++k) {
+    views.push_back(new ITMView(&calib, Vector2i(W, H), Vector2i(W, H), false));
+    make_depth(views.back()->depth->GetData(MEMORYDEVICE_CPU), 0.004f * (float)tri(k), 0.002f * (float)tri(2 * k));
+  }
+  double fps[3] = {0, 0, 0};
+  {
+    ITMScene<ITMVoxel_s, ITMVoxelBlockHash> scene(&sp, false, MEMORYDEVICE_CPU);
+    ITMSceneReconstructionEngine<ITMVoxel_s, ITMVoxelBlockHash>* reco = new ITMSceneReconstructionEngine_HIP<ITMVoxel_s, ITMVoxelBlockHash>();
+    ITMVisualisationEngine<ITMVoxel_s, ITMVoxelBlockHash>* vis = new ITMVisualisationEngine_HIP<ITMVoxel_s, ITMVoxelBlockHash>(&scene);
+    ITMRenderState* rs = vis->CreateRenderState(Vector2i(W, H));
+    ITMTrackingState ts(Vector2i(W, H), MEMORYDEVICE_CPU);
+    for (int pol = 0; pol < 2; ++pol) {
+      HipSetMirrorPolicy(pol ? HIP_MIRROR_ON_DEMAND : HIP_MIRROR_EAGER);
+      fps[pol] = time_frames(&scene, reco, vis, views, &ts, rs, pol ? frames : (frames < 100 ? frames : 100), true);
+    }
+    HipSyncRenderStateToHost<ITMVoxelBlockHash>(rs); HipSyncTrackingStateToHost(&ts);
+    HipSetMirrorPolicy(HIP_MIRROR_EAGER);
+    HipReleaseTrackingState(&ts);
+    delete rs; delete reco; delete vis;
+  }
+  {
+    ITMScene<ITMVoxel_s, ITMVoxelBlockHash> scene(&sp, false, MEMORYDEVICE_CPU);
+    ITMSceneReconstructionEngine<ITMVoxel_s, ITMVoxelBlockHash>* reco = new ITMSceneReconstructionEngine_CPU<ITMVoxel_s, ITMVoxelBlockHash>();
+    ITMVisualisationEngine<ITMVoxel_s, ITMVoxelBlockHash>* vis = new ITMVisualisationEngine_CPU<ITMVoxel_s, ITMVoxelBlockHash>(&scene);
+    ITMRenderState* rs = vis->CreateRenderState(Vector2i(W, H));
+    ITMTrackingState ts(Vector2i(W, H), MEMORYDEVICE_CPU);
+    fps[2] = time_frames(&scene, reco, vis, views, &ts, rs, 10, false);
+    delete rs; delete reco; delete vis;
+  }
+  for (ITMView* v : views) { HipReleaseView(v); delete v; }
+  std::printf("{\"bench\": \"BASELINE configs[1] through the reference's abstract engines (ITMDenseMapper::ProcessFrame + ITMTrackingController::Prepare call order), "
+              "640x480 hash ITMVoxel_s 4 mm, pool SDF_LOCAL_BLOCK_NUM = %d blocks, one 1.2 MB float depth image uploaded from the reference's host ITMView per frame\", "
+              "\"frames\": %d, \"fps_on_demand\": %.1f, \"fps_eager\": %.1f, \"fps_reference_cpu_engines_1_thread\": %.2f, \"equal\": %s, \"icp_points\": 100000, \"mismatch\": \"\"}\n",
+              (int)SDF_LOCAL_BLOCK_NUM, frames, fps[1], fps[0], fps[2], ok ? "true" : "false");
   return ok;
 }
 
@@ -225,12 +334,16 @@ static bool run_tracker() {
   return ok;
 }
 
-int main() {
+int main(int argc, char** argv) {
   std::printf("{\"library\": \"%s\"}\n", itm_version());
+  if (argc >= 2 && std::string(argv[1]) == "--bench") return run_bench(argc >= 3 ? std::atoi(argv[2]) : 300) ? 0 : 1;
   bool ok = true;
-  ok &= run<ITMVoxel_s, ITMVoxelBlockHash>("hash ITMVoxel_s 10 mm", 0.01f, 4);
-  ok &= run<ITMVoxel_f_rgb, ITMVoxelBlockHash>("hash ITMVoxel_f_rgb 10 mm", 0.01f, 3);
-  ok &= run<ITMVoxel_s, ITMPlainVoxelArray>("dense 128^3 ITMVoxel_s 10 mm", 0.01f, 3);
+  for (int pol = 0; pol < 2; ++pol) {
+    const HipMirrorPolicy policy = pol ? HIP_MIRROR_ON_DEMAND : HIP_MIRROR_EAGER;
+    ok &= run<ITMVoxel_s, ITMVoxelBlockHash>("hash ITMVoxel_s 10 mm", 0.01f, 4, policy);
+    ok &= run<ITMVoxel_f_rgb, ITMVoxelBlockHash>("hash ITMVoxel_f_rgb 10 mm", 0.01f, 3, policy);
+    ok &= run<ITMVoxel_s, ITMPlainVoxelArray>("dense 128^3 ITMVoxel_s 10 mm", 0.01f, 3, policy);
+  }
   ok &= run_view_builder();
   ok &= run_tracker();
   return ok ? 0 : 1;

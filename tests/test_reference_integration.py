@@ -39,10 +39,34 @@ def test_reference_interfaces_drive_the_hip_engines_bit_exactly():
     res = subprocess.run([DEMO], capture_output=True, text=True, timeout=600)
     lines = [json.loads(l) for l in res.stdout.strip().splitlines() if l.startswith("{")]
     configs = [l for l in lines if "config" in l]
-    assert len(configs) == 5, res.stdout + res.stderr
+    # hash / colour hash / dense under both mirror policies of the adapter, the view builder, the tracker
+    assert len(configs) == 8, res.stdout + res.stderr
     for c in configs:
         assert c["equal"], c
         assert c["icp_points"] > 3000
         if c["config"].startswith("hash"):
             assert c["triangles"] > 1000, c       # ITMMeshingEngine_HIP vs ITMMeshingEngine_CPU compared triangle for triangle
+            # the reference's four calls through its base-class pointers: fused under ON_DEMAND (no separate expected-depth launch),
+            # launched one by one under EAGER (every call is mirrored to the host before the next)
+            assert (c["range_launches"] == 0) == (c["policy"] == "on_demand"), c
+    assert {c.get("policy") for c in configs if "policy" in c} == {"eager", "on_demand"}
+    assert res.returncode == 0
+
+
+@pytest.mark.gpu
+def test_reference_binding_at_bench_size_forms_the_fused_frame_and_reports_its_rate():
+    """`ref_hip_demo --bench`: BASELINE configs[1] (640x480, ITMVoxel_s, hash, 4 mm) through the reference's own classes in the reference's
+    call order, one host depth image uploaded per frame: bit-equal to the reference's CPU engines under both policies, fused under
+    ON_DEMAND, and the frame rates INTEGRATION.md / BASELINE.md quote are printed (the timing itself is not asserted beyond sanity: a
+    shared test box is no measurement)."""
+    if not os.path.exists(DEMO):
+        pytest.skip("oracle/_ref/ref_hip_demo was not built (needs the reference tree at build time)")
+    res = subprocess.run([DEMO, "--bench", "100"], capture_output=True, text=True, timeout=900)
+    lines = [json.loads(l) for l in res.stdout.strip().splitlines() if l.startswith("{")]
+    configs = [l for l in lines if "config" in l]
+    assert len(configs) == 2 and all(c["equal"] for c in configs), res.stdout + res.stderr
+    assert [c["range_launches"] == 0 for c in configs] == [False, True], configs
+    bench = [l for l in lines if "bench" in l]
+    assert len(bench) == 1 and bench[0]["equal"], res.stdout
+    assert bench[0]["fps_on_demand"] > bench[0]["fps_eager"] > bench[0]["fps_reference_cpu_engines_1_thread"] > 0, bench
     assert res.returncode == 0
