@@ -35,6 +35,7 @@ constexpr int kProbeCells = 10;
 // of the camera and the surface is 1.3-2.3 m away: ~65-115 steps of mu / voxelSize voxels through voxels that read exactly 1 (free
 // or never seen), each a dependent round trip.  Measured (config 3 ray cast, event timers): none 90.6 us, 4 voxels 86.6, 8: 92.5,
 // 12: 94.0, 16: 103.7 -- the run is NOT what bounds the dense ray cast (its neighbouring rays read the same lines from L2); kept at 4.
+// Round 5, with all loads of a look-ahead really in flight together (far_run): 4: 70.7-71.3 us, 6: > 75, 8: 75.3-75.7.
 constexpr int kDenseLookahead = 4;
 
 #if ITM_EXP_WAVE_TIMING
@@ -107,9 +108,11 @@ __device__ inline float round_ref(float x) { return x + __builtin_copysignf(0.5f
 template <bool DENSE>
 __device__ inline long long locate_voxel(const VolumeView& vol, int px, int py, int pz, BlockCache& cache) {
   if (DENSE) {
-    const int qx = px - vol.ox, qy = py - vol.oy, qz = pz - vol.oz;
-    if (qx < 0 || qx >= vol.sx || qy < 0 || qy >= vol.sy || qz < 0 || qz >= vol.sz) return -1;
-    return (long long)(qx + qy * vol.sx + qz * vol.sx * vol.sy);
+    // (unsigned: 0 <= q < size in one comparison per axis; `&`, not `&&`: three compares and two ANDs instead of a ladder of
+    // exec-masked branches)
+    const uint32_t qx = (uint32_t)(px - vol.ox), qy = (uint32_t)(py - vol.oy), qz = (uint32_t)(pz - vol.oz);
+    const bool in = (qx < (uint32_t)vol.sx) & (qy < (uint32_t)vol.sy) & (qz < (uint32_t)vol.sz);
+    return in ? (long long)(qx + qy * (uint32_t)vol.sx + qz * (uint32_t)(vol.sx * vol.sy)) : -1ll;
   } else {
     const int bx = px >> 3, by = py >> 3, bz = pz >> 3;                       // floor(p / 8): arithmetic shift
     const int lin = (px & 7) + ((py & 7) << 3) + ((pz & 7) << 6);             // (p - 8 b) per axis
@@ -181,6 +184,11 @@ __device__ inline float read_raw_sdf(const VOL& vol, int px, int py, int pz, boo
   }
   const long long a = locate_voxel<DENSE>(vol, px, py, pz, cache);
   found = a >= 0;
+  if constexpr (DENSE) {
+    // the load is unconditional (voxel 0 for a position outside the volume): inside an exec-masked branch the compiler waits for it there
+    const float v = VX::load_raw_sdf(vol.vba, found ? (size_t)a : (size_t)0);
+    return found ? v : (VX::kShort ? 32767.0f : 1.0f);
+  }
   if (!found) return VX::kShort ? 32767.0f : 1.0f;
   return VX::load_raw_sdf(vol.vba, (size_t)a);
 }
@@ -460,33 +468,46 @@ __device__ inline RaySetup ray_setup(int x, int y, const RayParams& p, float2 mm
 // ..., each computed with the reference's own operations -- are fetched together and the ray advances over as many of them as
 // read exactly 1 (the reference's step for such a value, with its length update and range test); it stops in front of the first
 // other value (or position outside the volume), which the regular loop then reads again.  K dependent round trips become one.
+// Returns the number of steps taken.
 template <class VX, int K>
-__device__ inline void far_run(const VolumeView& vol, bool runner, float& px, float& py, float& pz, float& total, float dx, float dy, float dz,
-                               float stepScale, float totalMax, bool& ended) {
+__device__ inline int far_run(const VolumeView& vol, bool runner, float& px, float& py, float& pz, float& total, float dx, float dy, float dz,
+                              float stepScale, float totalMax, bool& ended) {
   const float one = 1.0f * stepScale;                       // sdf * stepScale with sdf == 1
   const float step = (one < 1.0f) ? 1.0f : one;
   const float sx = step * dx, sy = step * dy, sz = step * dz;
   const float farRaw = VX::kShort ? 32767.0f : 1.0f;
-  float raw[K];
+  // bit j set: q_j holds something else than exactly 1 (or lies outside the volume, or the lane is no runner): the run stops in front of it.
+  // EVERY value goes into the mask, so all K loads are in flight together: with the values consumed one by one in an accept / break
+  // chain the compiler sinks the last load into the chain (it is only needed when all others were accepted), i.e. one more dependent
+  // round trip in exactly the common case of a run through free space (found in the ISA, round 5).
+  uint32_t stop = 0;
   {
     float qx = px, qy = py, qz = pz;
+    uint32_t at[K];
+    float raw[K];
+    // (all addresses first, then all loads: interleaved, the register allocator reused a load's destination inside the next address's
+    // 64-bit multiply-add and the wave waited for the load there)
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-      const int ix = (int)round_ref(qx) - vol.ox, iy = (int)round_ref(qy) - vol.oy, iz = (int)round_ref(qz) - vol.oz;
-      const bool use = runner && ix >= 0 && ix < vol.sx && iy >= 0 && iy < vol.sy && iz >= 0 && iz < vol.sz;
-      const float v = VX::load_raw_sdf(vol.vba, use ? (size_t)(ix + iy * vol.sx + iz * vol.sx * vol.sy) : (size_t)0);   // voxel 0 / no use for the others
-      raw[j] = use ? v : 0.0f;                              // 0 = "something else": stops the run
+      const uint32_t ix = (uint32_t)((int)round_ref(qx) - vol.ox), iy = (uint32_t)((int)round_ref(qy) - vol.oy), iz = (uint32_t)((int)round_ref(qz) - vol.oz);
+      const bool use = runner & (ix < (uint32_t)vol.sx) & (iy < (uint32_t)vol.sy) & (iz < (uint32_t)vol.sz);      // (unsigned: 0 <= i < size in one comparison)
+      at[j] = use ? (ix + iy * (uint32_t)vol.sx + iz * (uint32_t)(vol.sx * vol.sy)) : 0xffffffffu;
       qx += sx; qy += sy; qz += sz;
     }
-  }
-  if (runner) {
+    asm volatile("" ::: "memory");
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
-      if (raw[j] != farRaw) break;
-      px += sx; py += sy; pz += sz; total += step;
-      if (!(total < totalMax)) { ended = true; break; }
-    }
+    for (int j = 0; j < K; ++j) raw[j] = VX::load_raw_sdf(vol.vba, at[j] != 0xffffffffu ? (size_t)at[j] : (size_t)0);   // voxel 0 / no use for the others
+#pragma unroll
+    for (int j = 0; j < K; ++j) stop |= (((raw[j] != farRaw) | (at[j] == 0xffffffffu)) ? 1u : 0u) << j;      // outside the volume / no runner: stops the run
   }
+  const int n = runner ? __builtin_ctz(stop | (1u << K)) : 0;      // positions that read exactly 1, counted from the first
+  int taken = 0;
+  while (taken < n) {
+    px += sx; py += sy; pz += sz; total += step;               // the reference's step for a value of exactly 1, with its length update ...
+    ++taken;
+    if (!(total < totalMax)) { ended = true; break; }         // ... and its range test
+  }
+  return taken;
 }
 
 // a parked ray: where it stands and how far it has come; direction, end of range etc. are recomputed from the pixel
@@ -536,6 +557,10 @@ __device__ inline float4 march_ray(int x, int y, const VOL& vol, const RayParams
   auto miss_run = [&](auto kc, bool runner) -> int {
     constexpr int K = decltype(kc)::value;
     const float sx = (float)kBlockSide * dx, sy = (float)kBlockSide * dy, sz = (float)kBlockSide * dz;   // exact products
+    // (Round 5: with every cell folded into one mask -- all K loads awaited together, the count taken with a find-first-bit -- the hash
+    // ray cast got SLOWER, configs[1] 36.5 -> 37.3 us, configs[4] 111.5 -> 119 us: the chain below consumes the cells as they arrive and
+    // leaves at the first block, and the compiler's habit of issuing the last cell's load only when all others were empty costs less
+    // than waiting for all of them every time.  profiles/r5_raycast_notes.md)
     int ahead[K];
     {
       float qx = px, qy = py, qz = pz;
@@ -611,10 +636,13 @@ __device__ inline float4 march_ray(int x, int y, const VOL& vol, const RayParams
       }
       if constexpr (DENSE) missed = !found;
       if constexpr (DENSE && LOOKAHEAD > 0) {
+        // (Several look-aheads back to back while all of their positions read exactly 1 -- no single-voxel read in between -- were
+        // measured in round 5: config 3's ray cast 71 us with one, 79 with two, 95 with four, 120 with eight: the lanes of the wave that
+        // are near the surface wait through the others' runs.  profiles/r5_raycast_notes.md)
         const bool far = st == MARCH && found && sdf == 1.0f;      // SDF_valueToFloat(32767) is exactly 1
         if (__any(far)) {
           bool ended = false;
-          far_run<VX, LOOKAHEAD>(vol, far, px, py, pz, total, dx, dy, dz, stepScale, totalMax, ended);
+          (void)far_run<VX, LOOKAHEAD>(vol, far, px, py, pz, total, dx, dy, dz, stepScale, totalMax, ended);
           if (ended) st = DONE;
         }
       }
