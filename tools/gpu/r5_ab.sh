@@ -3,6 +3,8 @@
 cd "$(dirname "$0")/../.."
 O=gpurun_out/r5ab; rm -rf $O; mkdir -p $O
 if [ -n "$TESTS" ]; then timeout 1800 python -m pytest $TESTS -m gpu -q -x > $O/pytest.log 2>&1; grep -E "passed|failed|FAILED|Error" $O/pytest.log | tail -8; fi
+# parity of measurement builds (TEST_LIBS) on the tests of VTESTS
+for V in $TEST_LIBS; do echo "== parity of lib_$V"; ITM_TEST_LIB=$PWD/gpurun_variants/lib_$V.so timeout 1800 python -m pytest $VTESTS -m gpu -q -x > $O/pytest_$V.log 2>&1; grep -E "passed|failed|FAILED|Error" $O/pytest_$V.log | tail -5; done
 B="python bench.py --no-cpu-baseline --no-extra-legs --steps ${STEPS:-400} --warmup 40"
 for rep in 1 2; do
   for c in ${CONFIGS:-2 3 5}; do
