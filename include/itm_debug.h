@@ -34,7 +34,13 @@ extern "C" {
 #define ITM_DEBUG_TRACKER_SESSION_UNUSABLE 18  /* TrackCamera: the resident evaluation kernel reports itself unusable at the n-th evaluation of a handle (n = value): the call must finish through one launch per evaluation with the same pose */
 #define ITM_DEBUG_NO_DEFERRED_FUSION 19         /* the four per-frame engine calls launch at once, one by one, instead of being recorded and fused (see "the four calls" below) */
 #define ITM_DEBUG_FORCE_LIST_STUCK 20           /* AllocateSceneFromDepth, one-launch visible list: chunk n - 1 behaves as if its bounded wait for another workgroup had expired (0 = off): the scene must raise statusFlags bit 1 and refuse further calls */
+#define ITM_DEBUG_EXCHANGE_DEVICE_COPY 24        /* exchanges created while it is set: a ONE-rank exchange performs its collective as a device copy instead of ncclAllGather (a test pins both to the same table) */
+#define ITM_DEBUG_EXCHANGE_CORRUPT_WORD 25       /* exchanges created while it is >= 0: the self-check behind every collective sees this word of the rank's own block flipped (the check must fire); -1 = off */
 int ITM_FN(debug_set)(int key, int value);
+/* A stand-in for a device-side consumer of the exchange's table (tests of itm_exchange_acquire): dst[0] = sum over `rounds` passes of a
+ * position-weighted checksum of src[0 .. words), computed by ONE workgroup on `stream` -- slow on purpose, so that collectives of later
+ * batches run while it reads. */
+int ITM_FN(debug_checksum)(const int32_t* src, size_t words, int rounds, unsigned long long* dst, itm_stream stream);
 /* dense integration, check mode of key 16: {free groups, shadow groups, mixed groups, violations}; reset != 0 clears */
 int ITM_FN(debug_dense_classify_check)(int32_t out[4], int reset);
 /* Test hook (host only): rows [rlo, rhi] of the column of 4-voxel groups (x0 .. x0 + 3, slice z) that the dense integration visits for

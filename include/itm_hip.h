@@ -472,9 +472,9 @@ int ITM_FN(mesh_write_stl)(const itm_mesh* mesh, const char* path, itm_stream st
  * ({M_d[16], noVisibleEntries, ids[max_ids]}); every `batch` frames the records are all-gathered with RCCL on a side stream owned by
  * the exchange, so that each rank holds the pose and the live block list of every stream (input of a shared-map merger).  The frame
  * stream never waits for a collective of the current batch, and the collectives are put on the side stream by a thread the exchange owns
- * (enqueueing an all-gather costs a host thread 60-80 us; ITM_EXCHANGE_INLINE=1 issues from the calling thread).  RCCL is loaded on first use (dlopen).  Every world size, one rank
- * included, gets an RCCL communicator and runs ncclAllGather (ITM_EXCHANGE_DEVICE_COPY=1 in the environment replaces the ONE-rank
- * collective by a device copy, for A/B measurements).  Bootstrap: rank 0 calls itm_exchange_unique_id, the host hands the 128 bytes
+ * (enqueueing an all-gather costs a host thread 60-80 us).  RCCL is loaded on first use (dlopen; ITM_RCCL_LIBRARY in the environment
+ * names another collective library -- a site's own build, the tests' stand-in for several ranks on one GPU -- and says so on stderr).
+ * Every world size, one rank included, gets an RCCL communicator and runs ncclAllGather.  Bootstrap: rank 0 calls itm_exchange_unique_id, the host hands the 128 bytes
  * to every rank; `id` may be NULL for world == 1 (the library then makes the id itself). */
 typedef struct itm_exchange itm_exchange;
 int ITM_FN(exchange_unique_id)(unsigned char id[128]);
@@ -483,6 +483,15 @@ int ITM_FN(exchange_destroy)(itm_exchange* exchange);
 /* frame f of this rank's stream: record copy on `frame_stream`; on the last frame of a batch also the collective (side stream) */
 int ITM_FN(exchange_step)(itm_exchange* exchange, const itm_render_state* rs, const float M_d[16], itm_stream frame_stream);
 int ITM_FN(exchange_info)(const itm_exchange* exchange, int* world, int* rank, int* max_ids, int* batch, const void** gathered_device);
+/* Hand-off of a gathered table to a DEVICE-side consumer (the per-GPU global visibility table of SURVEY 8e; a shared-map merger's kernel).
+ * Every slot of the exchange's ring of eight has its own table.  itm_exchange_acquire makes `consumer_stream` wait for the newest
+ * collective issued so far and returns its table (world x batch records, rank-major; *first_frame = the frame number of the batch's
+ * first record; NULL / -1 before the first collective).  The table belongs to the consumer until itm_exchange_release -- or the next
+ * itm_exchange_acquire, which releases first -- both given the stream the consumer's reads were put on: the ring skips a held slot,
+ * and the collective that next writes a released slot waits (on the exchange's side stream) behind those reads.  One holder at a time.
+ * Frames and collectives go on meanwhile; nothing here blocks the host. */
+int ITM_FN(exchange_acquire)(itm_exchange* exchange, itm_stream consumer_stream, const int32_t** table, long long* first_frame);
+int ITM_FN(exchange_release)(itm_exchange* exchange, itm_stream consumer_stream);
 /* host copy of the gathered table, world x batch records of (17 + max_ids) int32 words, rank-major; synchronises the side stream */
 int ITM_FN(exchange_table)(itm_exchange* exchange, int32_t* dst_host, size_t words);
 /* Self-check, on by default at every world size (ITM_EXCHANGE_SELF_CHECK=0 in the environment switches it off): behind each collective,

@@ -259,6 +259,9 @@ _HOST_IO_SIGS = {
     "exchange_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_P)]),
     "exchange_table": (C.c_int, [_P, _P, C.c_size_t]),
     "exchange_self_check": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "exchange_acquire": (C.c_int, [_P, _P, C.POINTER(_P), C.POINTER(C.c_longlong)]),
+    "exchange_release": (C.c_int, [_P, _P]),
+    "debug_checksum": (C.c_int, [_P, C.c_size_t, C.c_int, _P, _P]),
 }
 
 

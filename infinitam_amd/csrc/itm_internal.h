@@ -217,6 +217,7 @@ void forget_deferred(itm_render_state* rs);      // the render state is going aw
 extern int g_debug_no_deferred_fusion;
 bool deferred_fusion_default();               // ITM_DEFERRED_FUSION=1 in the environment: new scenes record without being asked
 extern int g_debug_force_list_stuck;
+extern int g_debug_exchange_device_copy, g_debug_exchange_corrupt_word;      // exchange.hip
 // true when rs holds the block requests of a frame issued ahead (itm_process_frame_ahead): `what` is refused with ITM_ERR_INVALID
 int refuse_while_ahead(const itm_scene* s, const itm_render_state* rs, const char* what);
 

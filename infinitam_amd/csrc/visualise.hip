@@ -634,6 +634,8 @@ int itm_debug_set(int key, int value) {
   if (key == ITM_DEBUG_DENSE_NO_STRIPS) { g_debug_dense_no_strips = value; return ITM_OK; }
   if (key == ITM_DEBUG_NO_DEFERRED_FUSION) { g_debug_no_deferred_fusion = value; return ITM_OK; }
   if (key == ITM_DEBUG_FORCE_LIST_STUCK) { g_debug_force_list_stuck = value; return ITM_OK; }
+  if (key == ITM_DEBUG_EXCHANGE_DEVICE_COPY) { g_debug_exchange_device_copy = value; return ITM_OK; }
+  if (key == ITM_DEBUG_EXCHANGE_CORRUPT_WORD) { g_debug_exchange_corrupt_word = value; return ITM_OK; }
   return set_error(ITM_ERR_INVALID, "unknown debug key");
 }
 

@@ -166,6 +166,16 @@ class NativeExchange:
         self.be.check(self.be.fn["exchange_table"](self.h, g.ctypes.data_as(C.c_void_p), g.size), "exchange_table")
         return g.reshape(self.world, self.batch, self.words)
 
+    def acquire(self, consumer_stream=None):
+        """itm_exchange_acquire: (device pointer of the newest table, number of the first frame in it); (0, -1) before the first collective.
+        The table is the caller's until release() / the next acquire(); `consumer_stream` (an int handle or None) is made to wait for it."""
+        t, f = C.c_void_p(), C.c_longlong()
+        self.be.check(self.be.fn["exchange_acquire"](self.h, C.c_void_p(consumer_stream), C.byref(t), C.byref(f)), "exchange_acquire")
+        return (t.value or 0), f.value
+
+    def release(self, consumer_stream=None):
+        self.be.check(self.be.fn["exchange_release"](self.h, C.c_void_p(consumer_stream)), "exchange_release")
+
     def self_check(self) -> Tuple[int, int]:
         """(collectives checked, words of this rank's own block that differed from what it sent); -1 checked = self-check off."""
         a, b = C.c_int(), C.c_int()

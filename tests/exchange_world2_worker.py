@@ -38,6 +38,10 @@ def main():
     ses = T.Session(hip, sc)
     out = {"rank": rank, "error": None}
     own_M, own_n, own_ids, tables, at = [], [], [], [], []
+    import ctypes as C
+    stream = C.c_void_p()
+    hip.check(hip.fn["stream_create"](C.byref(stream)), "stream_create")
+    sums = capi.DevBuffer(hip, 8, np.uint64, (1,))
     try:
         ex = NativeExchange(hip, world, rank, max_ids=MAX_IDS, batch=BATCH, unique_id=uid)
         try:
@@ -52,8 +56,17 @@ def main():
                 batch_no = (k + 1) // BATCH
                 if (k + 1) % BATCH == 0 and (batch_no <= CHECKED_BATCHES or k == frames - 1):
                     tables.append(ex.raw_table().copy()); at.append(k)
+                if k + 1 == BATCH * CHECKED_BATCHES:
+                    # a device-side consumer: the newest table is acquired on a stream of its own and read by a SLOW kernel while the
+                    # 11 batches that follow are stepped and collected (the ring of eight wraps around the held slot)
+                    table, first = ex.acquire(stream.value)
+                    out["consumer_first_frame"] = int(first)
+                    hip.check(hip.fn["debug_checksum"](C.c_void_p(table), world * BATCH * (17 + MAX_IDS), 300, C.c_void_p(sums.ptr), stream), "debug_checksum")
                 if pace:
                     time.sleep(pace)
+            ex.release(stream.value)
+            hip.check(hip.fn["stream_synchronize"](stream), "stream_synchronize")
+            out["consumer_checksum"] = int(sums.numpy()[0])
             out["self_check"] = list(ex.self_check())
         finally:
             ex.close()

@@ -15,7 +15,8 @@ def test_exchange_entry_points_are_exported():
     be = capi.Backend(infinitam_amd.lib_path(), "itm_") if T.os.path.exists(infinitam_amd.lib_path()) else None
     if be is None:
         pytest.skip("library not built")
-    for name in ("exchange_unique_id", "exchange_create", "exchange_destroy", "exchange_step", "exchange_info", "exchange_table", "exchange_self_check"):
+    for name in ("exchange_unique_id", "exchange_create", "exchange_destroy", "exchange_step", "exchange_info", "exchange_table", "exchange_self_check",
+                 "exchange_acquire", "exchange_release"):
         assert name in be.fn
 
 
@@ -73,14 +74,17 @@ def test_library_and_torch_exchange_hold_the_same_words(hip):
 
 
 @pytest.mark.gpu
-def test_one_rank_collective_equals_the_device_copy(hip, monkeypatch):
-    """ITM_EXCHANGE_DEVICE_COPY=1 (debug) replaces the one-rank ncclAllGather by a memcpy: same table."""
+def test_one_rank_collective_equals_the_device_copy(hip):
+    """Debug key 24 (ITM_DEBUG_EXCHANGE_DEVICE_COPY) replaces the one-rank ncclAllGather by a memcpy: same table."""
     sc = T.Scenario(name="ex3", w=160, h=120, voxelSize=0.01, frames=4)
     tables = []
-    for key in ("0", "1"):
-        monkeypatch.setenv("ITM_EXCHANGE_DEVICE_COPY", key)
+    for key in (0, 1):
+        hip.check(hip.fn["debug_set"](24, key), "debug_set")
         ses = T.Session(hip, sc)
-        ex = NativeExchange(hip, 1, 0, max_ids=512, batch=2)
+        try:
+            ex = NativeExchange(hip, 1, 0, max_ids=512, batch=2)
+        finally:
+            hip.check(hip.fn["debug_set"](24, 0), "debug_set")
         try:
             for k in range(sc.frames):
                 v = ses.frame(k, fused=True)
@@ -94,6 +98,7 @@ def test_one_rank_collective_equals_the_device_copy(hip, monkeypatch):
 
 @pytest.mark.gpu
 def test_every_collective_is_self_checked_and_corruption_is_loud(hip, monkeypatch):
+    # (the corrupted word is a test hook of the library: debug key 25, read when an exchange is created)
     """Behind each collective the rank's own block of the gathered table is compared with what it sent (on the side stream): a healthy
     run counts the checks and no mismatch; a word corrupted on the way (test hook) makes the next step and the table read fail."""
     sc = T.Scenario(name="ex_check", w=160, h=120, voxelSize=0.01, frames=9)
@@ -107,8 +112,11 @@ def test_every_collective_is_self_checked_and_corruption_is_loud(hip, monkeypatc
         ex.table()
     finally:
         ex.close()
-    monkeypatch.setenv("ITM_EXCHANGE_SELF_CHECK_CORRUPT", "40")
-    ex = NativeExchange(hip, 1, 0, max_ids=512, batch=3)
+    hip.check(hip.fn["debug_set"](25, 40), "debug_set")
+    try:
+        ex = NativeExchange(hip, 1, 0, max_ids=512, batch=3)
+    finally:
+        hip.check(hip.fn["debug_set"](25, -1), "debug_set")
     try:
         with pytest.raises(capi.ItmError, match="self-check"):
             for k in range(sc.frames):
@@ -120,13 +128,71 @@ def test_every_collective_is_self_checked_and_corruption_is_loud(hip, monkeypatc
             ex.table()
     finally:
         ex.close()
-    monkeypatch.delenv("ITM_EXCHANGE_SELF_CHECK_CORRUPT")
     monkeypatch.setenv("ITM_EXCHANGE_SELF_CHECK", "0")
     ex = NativeExchange(hip, 1, 0, max_ids=512, batch=3)
     try:
         assert ex.self_check() == (-1, 0)
     finally:
         ex.close()
+        ses.close()
+
+
+def expected_checksum(table_words: np.ndarray, rounds: int) -> int:
+    """What itm_debug_checksum computes over a table (exchange.hip: position-weighted sum of the words as unsigned, `rounds` passes)."""
+    w = table_words.reshape(-1).view(np.uint32).astype(np.uint64)
+    i = np.arange(len(w), dtype=np.uint64) % np.uint64(1021) + np.uint64(1)
+    return int((int((w * i).sum(dtype=np.uint64)) * rounds) & 0xFFFFFFFFFFFFFFFF)
+
+
+@pytest.mark.gpu
+def test_a_device_side_consumer_reads_a_table_no_later_collective_touches(hip):
+    """itm_exchange_acquire / _release (the per-GPU global visibility table a merger's kernel reads).  A slow consumer kernel
+    (one workgroup, 400 passes over the table) is put on its own stream behind an acquire, then 20 further batches -- more than the ring
+    of eight slots -- are stepped and collected while it runs: its checksum must be that of the batch it acquired, word for word.  With
+    ONE gathered table for all batches in flight (round 4) the kernel would read a table that later collectives rewrite."""
+    sc = T.Scenario(name="ex_acq", w=160, h=120, voxelSize=0.01, frames=3)
+    ses = T.Session(hip, sc)
+    MAX_IDS, BATCH, ROUNDS = 2048, 2, 400
+    ex = NativeExchange(hip, 1, 0, max_ids=MAX_IDS, batch=BATCH)
+    stream = capi._P()
+    hip.check(hip.fn["stream_create"](capi.C.byref(stream)), "stream_create")
+    sums = capi.DevBuffer(hip, 64 * 8, np.uint64, (64,))
+    try:
+        assert ex.acquire(stream.value) == (0, -1)                       # nothing gathered yet
+        for k in range(sc.frames):
+            v = ses.frame(k, fused="four")
+        nv = ses.scene.counters(ses.rs)["noVisibleEntries"]
+        ids = np.full(MAX_IDS, -1, np.int32)
+        got = ses.scene.download(capi.BUF_VISIBLE_IDS, ses.rs)[:min(nv, MAX_IDS)]
+        ids[:len(got)] = got
+
+        def record(frame_no):
+            M = np.asarray(v.M_d, np.float32).reshape(16).copy()
+            M[0] = np.float32(frame_no)                                   # (the pose travels as the caller gives it: a frame stamp)
+            return M
+
+        frame_no, expected, taken = 0, {}, []
+        for rnd in range(6):
+            for _ in range(BATCH * (1 if rnd == 0 else 4)):               # one batch, then four batches per round: 21 batches, the ring wraps
+                ex.step(ses.rs.h, record(frame_no), None)
+                frame_no += 1
+            table, first = ex.acquire(stream.value)
+            assert table != 0 and first == frame_no - BATCH, (table, first, frame_no)
+            hip.check(hip.fn["debug_checksum"](capi._P(table), BATCH * (17 + MAX_IDS), ROUNDS, capi._P(sums.ptr + 8 * rnd), stream), "debug_checksum")
+            words = np.empty((BATCH, 17 + MAX_IDS), np.int32)
+            for j in range(BATCH):
+                words[j, :16] = record(first + j).view(np.int32); words[j, 16] = nv; words[j, 17:] = ids
+            expected[rnd] = expected_checksum(words, ROUNDS)
+            taken.append(first)
+        ex.release(stream.value)
+        hip.check(hip.fn["stream_synchronize"](stream), "stream_synchronize")
+        got_sums = sums.numpy()
+        for rnd, first in enumerate(taken):
+            assert int(got_sums[rnd]) == expected[rnd], "the consumer of the batch at frame %d read a table that was not that batch's" % first
+        assert ex.self_check() == (21, 0)
+    finally:
+        ex.close()
+        hip.check(hip.fn["stream_destroy"](stream), "stream_destroy")
         ses.close()
 
 
@@ -187,6 +253,9 @@ def test_library_exchange_with_several_ranks_on_one_gpu(hip, tmp_path, world, pa
     for d, meta in res:
         assert meta["error"] is None, meta
         assert meta["self_check"] == [14, 0], meta                      # 3 + 11 batches, each collective checked, no word differed
+        # the device-side consumer of every rank (itm_exchange_acquire + a slow checksum kernel while 11 further batches were collected):
+        # it read the table of the batch it acquired, and that table was the same on every rank
+        assert meta["consumer_first_frame"] == 4 and meta["consumer_checksum"] == res[0][1]["consumer_checksum"], meta
     t0, at = res[0][0]["tables"], res[0][0]["at"]
     assert t0.shape == (4, world, 2, 17 + 1024) and list(at) == [1, 3, 5, 27]
     for d, _ in res[1:]:
@@ -200,6 +269,8 @@ def test_library_exchange_with_several_ranks_on_one_gpu(hip, tmp_path, world, pa
                 assert rec[16] == d["own_n"][k] and d["own_n"][k] > 100
                 assert np.array_equal(rec[17:], d["own_ids"][k])
     assert not np.array_equal(res[0][0]["own_ids"][5], res[1][0]["own_ids"][5])          # the streams differ: the comparison above says something
+    # ... and the consumer's checksum is that of the gathered table of batch 2 (frames 4 and 5), which the host copy taken at frame 5 holds
+    assert res[0][1]["consumer_checksum"] == expected_checksum(t0[2], 300)
 
 
 @pytest.mark.gpu
