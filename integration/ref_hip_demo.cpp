@@ -225,7 +225,47 @@ static bool run_bench(int frames) {
     views.push_back(new ITMView(&calib, Vector2i(W, H), Vector2i(W, H), false));
     make_depth(views.back()->depth->GetData(MEMORYDEVICE_CPU), 0.004f * (float)tri(k), 0.002f * (float)tri(2 * k));
   }
-  double fps[3] = {0, 0, 0};
+  double fps[4] = {0, 0, 0, 0};
+  {
+    // the same frames as the sensor delivers them: raw 16-bit depth through the reference's ITMViewBuilder interface (UpdateView: 614 KB
+    // upload + conversion in HBM, straight into the view's device stage), then the four calls -- ITMMainEngine::ProcessFrame without the tracker
+    ITMScene<ITMVoxel_s, ITMVoxelBlockHash> scene(&sp, false, MEMORYDEVICE_CPU);
+    ITMSceneReconstructionEngine<ITMVoxel_s, ITMVoxelBlockHash>* reco = new ITMSceneReconstructionEngine_HIP<ITMVoxel_s, ITMVoxelBlockHash>();
+    ITMVisualisationEngine<ITMVoxel_s, ITMVoxelBlockHash>* vis = new ITMVisualisationEngine_HIP<ITMVoxel_s, ITMVoxelBlockHash>(&scene);
+    ITMRenderState* rs = vis->CreateRenderState(Vector2i(W, H));
+    ITMTrackingState ts(Vector2i(W, H), MEMORYDEVICE_CPU);
+    calib.disparityCalib.type = ITMDisparityCalib::TRAFO_AFFINE; calib.disparityCalib.params = Vector2f(0.001f, 0.0f);
+    ITMViewBuilder* vb = new ITMViewBuilder_HIP(&calib);
+    std::vector<ITMShortImage*> raws;
+    for (int k = 0; k < 100; ++k) {
+      raws.push_back(new ITMShortImage(Vector2i(W, H), true, false));
+      const float* d = views[(size_t)k]->depth->GetData(MEMORYDEVICE_CPU);
+      short* r = raws.back()->GetData(MEMORYDEVICE_CPU);
+      for (int i = 0; i < W * H; ++i) r[i] = (short)(d[i] * 1000.0f);
+    }
+    ITMUChar4Image rgb(Vector2i(W, H), true, false);
+    ITMView* view = NULL;
+    HipSetMirrorPolicy(HIP_MIRROR_ON_DEMAND);
+    reco->ResetScene(&scene);
+    std::chrono::steady_clock::time_point t0;
+    for (int k = 0; k < 20 + frames; ++k) {
+      if (k == 20) { HipCheck(itm_stream_synchronize(0), "sync"); t0 = std::chrono::steady_clock::now(); }
+      Matrix4f M; M.setIdentity(); M.m[12] = -(0.004f * (float)tri(k)); M.m[13] = -(0.002f * (float)tri(2 * k));
+      ts.pose_d->SetM(M);
+      vb->UpdateView(&view, &rgb, raws[(size_t)k % raws.size()], false, false);
+      reco->AllocateSceneFromDepth(&scene, view, &ts, rs);
+      reco->IntegrateIntoScene(&scene, view, &ts, rs);
+      vis->CreateExpectedDepths(ts.pose_d, &view->calib->intrinsics_d, rs);
+      vis->CreateICPMaps(view, &ts, rs);
+    }
+    HipCheck(itm_stream_synchronize(0), "sync");
+    fps[3] = (double)frames / std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    HipSyncRenderStateToHost<ITMVoxelBlockHash>(rs); HipSyncTrackingStateToHost(&ts);
+    HipSetMirrorPolicy(HIP_MIRROR_EAGER);
+    HipReleaseTrackingState(&ts); HipReleaseView(view);
+    for (ITMShortImage* r : raws) delete r;
+    delete view; delete vb; delete rs; delete reco; delete vis;
+  }
   {
     ITMScene<ITMVoxel_s, ITMVoxelBlockHash> scene(&sp, false, MEMORYDEVICE_CPU);
     ITMSceneReconstructionEngine<ITMVoxel_s, ITMVoxelBlockHash>* reco = new ITMSceneReconstructionEngine_HIP<ITMVoxel_s, ITMVoxelBlockHash>();
@@ -253,8 +293,9 @@ static bool run_bench(int frames) {
   for (ITMView* v : views) { HipReleaseView(v); delete v; }
   std::printf("{\"bench\": \"BASELINE configs[1] through the reference's abstract engines (ITMDenseMapper::ProcessFrame + ITMTrackingController::Prepare call order), "
               "640x480 hash ITMVoxel_s 4 mm, pool SDF_LOCAL_BLOCK_NUM = %d blocks, one 1.2 MB float depth image uploaded from the reference's host ITMView per frame\", "
-              "\"frames\": %d, \"fps_on_demand\": %.1f, \"fps_eager\": %.1f, \"fps_reference_cpu_engines_1_thread\": %.2f, \"equal\": %s, \"icp_points\": 100000, \"mismatch\": \"\"}\n",
-              (int)SDF_LOCAL_BLOCK_NUM, frames, fps[1], fps[0], fps[2], ok ? "true" : "false");
+              "\"frames\": %d, \"fps_on_demand\": %.1f, \"fps_eager\": %.1f, \"fps_on_demand_raw_depth_through_ITMViewBuilder_HIP\": %.1f, \"fps_reference_cpu_engines_1_thread\": %.2f, "
+              "\"equal\": %s, \"icp_points\": 100000, \"mismatch\": \"\"}\n",
+              (int)SDF_LOCAL_BLOCK_NUM, frames, fps[1], fps[0], fps[3], fps[2], ok ? "true" : "false");
   return ok;
 }
 
