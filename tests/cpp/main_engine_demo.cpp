@@ -7,6 +7,9 @@
 //   main_engine_demo --bench <frames>         closed tracking + mapping loop on the 640x480 bench scene, frames/s
 //   main_engine_demo --bench-host <frames>    the same with every raw frame arriving from page-locked host memory (ProcessFrameFromHost,
 //                                             the next frame uploaded while the current one is tracked and fused)
+//   main_engine_demo --bench-map[-host] <frames>   THIS FORK'S DEFAULT pipeline: TRACKER_EXTERNAL (Utils/ITMLibSettings.cpp:44) -- the pose source
+//                                             writes pose_d before every frame (Engine/RosPoseSourceEngine.cpp:112-118), ITMMainEngine::ProcessFrame
+//                                             builds the view from the raw frame, the tracker is a no-op, mapper + Prepare fuse and ray-cast
 // sequence file: int32 {w, h, n, trackerType, useApproximateRaycast, skipPoints, hasPoses}, float intr[4], int16 raw[n*h*w],
 //                float poses[n*16] (if hasPoses), uint8 fusion[n], uint8 mainProcessing[n]
 #include <chrono>
@@ -37,7 +40,7 @@ static ITMLibSettings settings_for(int trackerType, bool approx, bool skip) {
   return st;
 }
 
-static int bench(int frames, bool fromHost) {
+static int bench(int frames, bool fromHost, bool externalPoses = false) {
   // the bench scene: sphere of radius 0.5 m at (0, 0, 1.5) in front of a wall at 2.5 m, triangle-wave trajectory
   const int W = 640, H = 480, P = W * H, distinct = 100;
   std::vector<int16_t> raw((size_t)distinct * P);
@@ -54,13 +57,18 @@ static int bench(int frames, bool fromHost) {
   }
   void* dRaw; check(itm_dev_malloc(&dRaw, raw.size() * 2), "malloc");
   check(itm_memcpy_h2d(dRaw, raw.data(), raw.size() * 2, nullptr), "h2d");
-  ITMLibSettings st = settings_for(1, false, true);
+  ITMLibSettings st = settings_for(externalPoses ? 2 : 1, false, true);
   ITMSceneParams params(0.02f, 100, 0.004f, 0.35f, 3.0f, false);
   ITMRGBDCalib calib;
   ITMMainEngine_HIP<V, I> engine(st, params, calib, Vector2i{W, H}, Vector2i{W, H}, 1, 0.001f, 0.0f, 0x40000);
   void* hRaw = nullptr;
   if (fromHost) { check(itm_host_malloc(&hRaw, raw.size() * 2), "host malloc"); memcpy(hRaw, raw.data(), raw.size() * 2); }
   auto frame = [&](int k, bool more) {
+    if (externalPoses) {      // the pose source of this fork: world -> camera for a camera at t, identity rotation
+      float M[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+      M[12] = -(0.004f * (float)tri(k)); M[13] = -(0.002f * (float)tri(2 * k));
+      engine.GetTrackingState()->pose_d.SetM(M);
+    }
     if (!fromHost) { engine.ProcessFrame(nullptr, (const int16_t*)dRaw + (size_t)(k % distinct) * P); return; }
     engine.ProcessFrameFromHost(nullptr, (const int16_t*)hRaw + (size_t)(k % distinct) * P, more ? (const int16_t*)hRaw + (size_t)((k + 1) % distinct) * P : nullptr);
   };
@@ -73,7 +81,7 @@ static int bench(int frames, bool fromHost) {
   const float* M = engine.GetTrackingState()->pose_d.GetM();
   const int last = 4 + frames;
   const float ex = -0.004f * (float)tri(last), ey = -0.002f * (float)tri(2 * last);
-  printf("{\"frames\": %d, \"raw_frames_from\": \"%s\", \"pose\": [%.9g, %.9g, %.9g], \"fps\": %.1f, \"ms_per_frame\": %.4f, \"final_translation_error_m\": %.5f}\n", frames, fromHost ? "pinned host memory (stager)" : "device memory", M[12], M[13], M[14], frames / dt, 1e3 * dt / frames,
+  printf("{\"frames\": %d, \"tracker\": \"%s\", \"raw_frames_from\": \"%s\", \"pose\": [%.9g, %.9g, %.9g], \"fps\": %.1f, \"ms_per_frame\": %.4f, \"final_translation_error_m\": %.5f}\n", frames, externalPoses ? "external poses (TRACKER_EXTERNAL, the fork's default): mapping only" : "ICP (closed loop)", fromHost ? "pinned host memory (stager)" : "device memory", M[12], M[13], M[14], frames / dt, 1e3 * dt / frames,
          std::fmax(std::fabs(M[12] - ex), std::fmax(std::fabs(M[13] - ey), std::fabs(M[14]))));
   itm_dev_free(dRaw);
   if (hRaw) itm_host_free(hRaw);
@@ -83,6 +91,8 @@ static int bench(int frames, bool fromHost) {
 int main(int argc, char** argv) {
   if (argc >= 3 && !strcmp(argv[1], "--bench")) return bench(atoi(argv[2]), false);
   if (argc >= 3 && !strcmp(argv[1], "--bench-host")) return bench(atoi(argv[2]), true);
+  if (argc >= 3 && !strcmp(argv[1], "--bench-map")) return bench(atoi(argv[2]), false, true);
+  if (argc >= 3 && !strcmp(argv[1], "--bench-map-host")) return bench(atoi(argv[2]), true, true);
   if (argc < 2) { fprintf(stderr, "usage: %s <sequence file> | --bench <frames>\n", argv[0]); return 2; }
   FILE* f = fopen(argv[1], "rb");
   if (!f) { perror(argv[1]); return 2; }
