@@ -306,7 +306,7 @@ class ITMViewBuilder_HIP {
   // DeviceSpecific/CUDA/ITMViewBuilder_CUDA.cu:53).  Here a raw frame in pinned host memory travels on the stager's copy stream;
   // Prefetch(next frame) while the current one is fused hides the transfer altogether.
   void Prefetch(const int16_t* rawDepthHost, Vector2i size) {
-    if (!stager) check(itm_depth_stager_create(size.x, size.y, 3, &stager), "depth stager");
+    if (!stager) check(itm_depth_stager_create(size.x, size.y, 4, &stager), "depth stager");
     check(itm_depth_stager_upload(stager, rawDepthHost), "Prefetch");
     prefetched = rawDepthHost;
   }

@@ -8,6 +8,7 @@
 // exp (filter weights) and acos (uncertainty), for which the device library and the host libm may differ in the last
 // place -- parity tolerance 1e-6 relative for the filtered depth, exact for everything else that does not depend on them.
 #include <atomic>
+#include <chrono>
 #include <memory>
 #include <new>
 #include <vector>
@@ -195,8 +196,11 @@ int itm_depth_stager_create(int w, int h, int slots, itm_depth_stager** out) {
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->copy, hipStreamNonBlocking);
   for (int i = 0; i < slots && e == hipSuccess; ++i) {
     e = hipMalloc((void**)&g->buf[i], (size_t)w * h * sizeof(int16_t));
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&g->uploaded[i], hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&g->consumed[i], hipEventDisableTiming);
+    // DEVICE-scope release: producer and consumer of a slot are streams of this device.  The default (system-scope) release of
+    // hipEventRecord writes back and invalidates the L2s -- recorded on the FRAME's stream once per frame (`consumed`), that made every
+    // frame's kernels start on cold caches (the exchange found the same, exchange.hip)
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&g->uploaded[i], hipEventDisableTiming | hipEventReleaseToDevice);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&g->consumed[i], hipEventDisableTiming | hipEventReleaseToDevice);
   }
   if (e != hipSuccess) { free_stager(g); return hip_fail(e, "depth stager", __FILE__, __LINE__); }
   *out = g;
@@ -213,10 +217,22 @@ int itm_depth_stager_upload(itm_depth_stager* g, const int16_t* host) {
   if (g->consumedRecorded[b].load(std::memory_order_acquire)) {
     // the work that read the slot's previous frame: with the uploads a frame or two ahead it finished long ago, and a wait the copy
     // stream need not make is worth avoiding (a copy queued behind another queue's event costs the CALL ~100 us on this runtime)
-    const hipError_t q = hipEventQuery(g->consumed[b]);
-    if (q == hipErrorNotReady) ITM_HIP(hipStreamWaitEvent(g->copy, g->consumed[b], 0));
-    else if (q != hipSuccess) return hip_fail(q, "hipEventQuery(slot consumed)", __FILE__, __LINE__);
-    else g->consumedRecorded[b].store(0, std::memory_order_relaxed);
+    // A host that submits frames faster than the device fuses them arrives here before the slot's reader has run: it WAITS here, polling
+    // (a query is a load; this is the back-pressure that keeps the host at most `slots - 1` frames ahead of the device, which never runs
+    // dry: the frames in between are queued).  Handing the wait to the copy stream instead (hipStreamWaitEvent) was what round 4 did and
+    // cost the CALL ~100 us every frame once the host ran ahead -- the whole difference between frames from host memory and frames in HBM.
+    hipError_t q = hipEventQuery(g->consumed[b]);
+    if (q == hipErrorNotReady) {
+      const auto t0 = std::chrono::steady_clock::now();
+      for (unsigned spins = 0; q == hipErrorNotReady; ++spins) {
+        if ((spins & 0xffu) == 0xffu && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) break;
+        __builtin_ia32_pause();
+        q = hipEventQuery(g->consumed[b]);
+      }
+      if (q == hipErrorNotReady) { ITM_HIP(hipStreamWaitEvent(g->copy, g->consumed[b], 0)); q = hipSuccess; }      // (a device that is 2 s behind: let the stream sort it out)
+      else if (q == hipSuccess) g->consumedRecorded[b].store(0, std::memory_order_relaxed);
+    } else if (q == hipSuccess) g->consumedRecorded[b].store(0, std::memory_order_relaxed);
+    if (q != hipSuccess) return hip_fail(q, "hipEventQuery(slot consumed)", __FILE__, __LINE__);
   }
   // Pinned host memory is mapped into the device's address space: a kernel on the copy stream reads the frame over PCIe itself.  (The
   // runtime's own asynchronous copy goes through the SDMA engine on a stream that runs nothing else -- measured on this box: ~100 us
@@ -259,7 +275,11 @@ int itm_depth_stager_acquire(itm_depth_stager* g, itm_stream stream, const int16
   const unsigned long long head = g->head.load(std::memory_order_relaxed);
   if (head == g->tail.load(std::memory_order_acquire)) return set_error(ITM_ERR_INVALID, "no uploaded frame is waiting");
   const int b = (int)(head % (unsigned long long)g->slots);
-  ITM_HIP(hipStreamWaitEvent(as_stream(stream), g->uploaded[b], 0));
+  // with the uploads a frame ahead the copy has normally finished: then the frame's stream needs no dependency on the copy stream at all
+  // (a cross-stream wait is ~3-4 us of stream time even when it is satisfied at once); a query is a host-side load
+  const hipError_t q = hipEventQuery(g->uploaded[b]);
+  if (q == hipErrorNotReady) ITM_HIP(hipStreamWaitEvent(as_stream(stream), g->uploaded[b], 0));
+  else if (q != hipSuccess) return hip_fail(q, "hipEventQuery(upload)", __FILE__, __LINE__);
   *dev = g->buf[b];
   g->held = true;
   return ITM_OK;
