@@ -101,7 +101,12 @@ struct HipRegistry {
     void* depth = nullptr; void* rgb = nullptr; size_t pixels = 0, rgbPixels = 0;
     bool tracked = false; unsigned long long generation = 0, depthStaged = ~0ull, rgbStaged = ~0ull;
     bool hostDepthStale = false;
-    void* pinnedDepth = nullptr; void* pinnedRgb = nullptr;      // host ranges page-locked for asynchronous uploads
+    void* pinnedDepth = nullptr;                // host image page-locked for the ring's uploads
+    // A tracked view's float depth travels through a ring of device slots on a copy stream of its own (the library's itm_depth_stager,
+    // sized in bytes): the upload leaves the frame's stream, the HOST image may be rewritten as soon as the staging call returns (the
+    // reference reuses ONE ITMView for every frame), and the frames still queued on the device keep reading their own slot.
+    itm_depth_stager* ring = nullptr; bool holding = false;
+    const void* cur = nullptr;                  // where the current generation's depth lies in HBM: a slot of the ring, or `depth`
   };
   std::map<const void*, Stage> views;
   // the ICP maps / point cloud of a tracking state in HBM (trackingState->pointCloud->locations / ->colours)
@@ -109,9 +114,9 @@ struct HipRegistry {
   std::map<const void*, Maps> maps;
   static HipRegistry& Get() { static HipRegistry r; return r; }
   static void Free(Stage& st) {
+    if (st.ring) { if (st.holding) itm_depth_stager_release(st.ring, 0); itm_stream_synchronize(0); itm_depth_stager_destroy(st.ring); }
     itm_dev_free(st.depth); itm_dev_free(st.rgb);
     if (st.pinnedDepth) itm_host_unregister(st.pinnedDepth);
-    if (st.pinnedRgb) itm_host_unregister(st.pinnedRgb);
     st = Stage();
   }
   static void Free(Maps& m) { itm_dev_free(m.points); itm_dev_free(m.normals); m = Maps(); }
@@ -185,7 +190,10 @@ inline HipRegistry::Stage& HipStageOf(const ITMView* view) {
   HipRegistry::Stage& st = HipRegistry::Get().views[view];
   const Vector2i ds = view->depth->noDims, cs = view->rgb->noDims;
   const size_t px = (size_t)ds.x * ds.y, cpx = (size_t)cs.x * cs.y;
-  if (st.pixels != px) { itm_dev_free(st.depth); HipCheck(itm_dev_malloc(&st.depth, px * 4), "dev_malloc"); st.pixels = px; st.depthStaged = ~0ull; }
+  if (st.pixels != px) {
+    itm_dev_free(st.depth); HipCheck(itm_dev_malloc(&st.depth, px * 4), "dev_malloc"); st.pixels = px; st.depthStaged = ~0ull; st.cur = st.depth;
+    if (st.ring) { if (st.holding) itm_depth_stager_release(st.ring, 0); itm_stream_synchronize(0); itm_depth_stager_destroy(st.ring); st.ring = nullptr; st.holding = false; }
+  }
   if (st.rgbPixels != cpx) { itm_dev_free(st.rgb); HipCheck(itm_dev_malloc(&st.rgb, cpx * 4), "dev_malloc"); st.rgbPixels = cpx; st.rgbStaged = ~0ull; }
   return st;
 }
@@ -214,22 +222,36 @@ inline void HipPin(void*& pinned, const void* host, size_t bytes) {
 // stages the host images of a view in HBM -- once per generation for a tracked view -- and fills the POD view of the C-ABI
 inline itm_view HipStageView(const ITMView* view, const ITMPose* pose_d, bool withRgb) {
   HipRegistry::Stage& st = HipStageOf(view);
-  if (!st.tracked || st.depthStaged != st.generation) {
-    const void* host = view->depth->GetData(MEMORYDEVICE_CPU);
-    if (st.tracked) HipPin(st.pinnedDepth, host, st.pixels * 4);
-    HipCheck(itm_memcpy_h2d(st.depth, host, st.pixels * 4, 0), "memcpy_h2d");
+  const Vector2i ds = view->depth->noDims, cs = view->rgb->noDims;
+  if (!st.tracked) {
+    // nobody ever said when this view changes: staged on every call, from pageable memory (the runtime copies the host image before the
+    // call returns: whatever the host does to it afterwards is harmless)
+    HipCheck(itm_memcpy_h2d(st.depth, view->depth->GetData(MEMORYDEVICE_CPU), st.pixels * 4, 0), "memcpy_h2d");
+    st.cur = st.depth;
+  } else if (st.depthStaged != st.generation) {
+    // a new generation: through the ring.  The slot of the previous generation is released behind everything the frame's stream has
+    // been given so far (the calls of the previous frame, launched by its CreateICPMaps); the upload runs on the ring's copy stream; the
+    // host waits until the copy has READ the host image -- ~25-50 us, the one wait of a frame, and it overlaps the device's work on the
+    // frames before -- so that the caller may rewrite the image; the frame's stream needs no dependency on the copy (it has finished).
+    void* host = view->depth->GetData(MEMORYDEVICE_CPU);
+    if (!st.ring) HipCheck(itm_depth_stager_create(2 * ds.x, ds.y, 4, &st.ring), "depth ring");      // (slots of 2w x h shorts = w x h floats)
+    if (st.holding) { HipCheck(itm_depth_stager_release(st.ring, 0), "depth ring release"); st.holding = false; }
+    HipPin(st.pinnedDepth, host, st.pixels * 4);
+    HipCheck(itm_depth_stager_upload(st.ring, (const int16_t*)host), "depth ring upload");
+    for (int busy = 1; busy;) HipCheck(itm_depth_stager_pending(st.ring, nullptr, &busy), "depth ring pending");
+    const int16_t* slot = nullptr;
+    HipCheck(itm_depth_stager_acquire(st.ring, 0, &slot), "depth ring acquire");
+    st.holding = true; st.cur = slot;
     st.depthStaged = st.generation;
   }
   if (withRgb && (!st.tracked || st.rgbStaged != st.generation)) {
-    const void* host = view->rgb->GetData(MEMORYDEVICE_CPU);
-    if (st.tracked) HipPin(st.pinnedRgb, host, st.rgbPixels * 4);
-    HipCheck(itm_memcpy_h2d(st.rgb, host, st.rgbPixels * 4, 0), "memcpy_h2d");
+    // (colour images stay on the frame's stream and in pageable memory: staged by the runtime before the call returns)
+    HipCheck(itm_memcpy_h2d(st.rgb, view->rgb->GetData(MEMORYDEVICE_CPU), st.rgbPixels * 4, 0), "memcpy_h2d");
     st.rgbStaged = st.generation;
   }
-  const Vector2i ds = view->depth->noDims, cs = view->rgb->noDims;
   itm_view v; std::memset(&v, 0, sizeof v);
   // (the rgb pointer is handed over whether or not this call uploaded it: the calls of one frame must name the same view)
-  v.depth = (const float*)st.depth; v.rgb = (const uint8_t*)st.rgb;
+  v.depth = (const float*)st.cur; v.rgb = (const uint8_t*)st.rgb;
   v.w = ds.x; v.h = ds.y; v.w_rgb = cs.x; v.h_rgb = cs.y;
   std::memcpy(v.M_d, pose_d->GetM().m, 64);
   std::memcpy(v.intr_d, &view->calib->intrinsics_d.projectionParamsSimple.all, 16);
@@ -292,7 +314,7 @@ inline void HipSyncTrackingStateToHost(ITMTrackingState* ts) {
 inline void HipSyncViewToHost(ITMView* view) {
   HipRegistry::Stage& st = HipStageOf(view);
   if (!st.hostDepthStale) return;
-  HipCheck(HipDownload(view->depth->GetData(MEMORYDEVICE_CPU), st.depth, st.pixels * 4, 0), "memcpy_d2h");
+  HipCheck(HipDownload(view->depth->GetData(MEMORYDEVICE_CPU), st.cur ? st.cur : st.depth, st.pixels * 4, 0), "memcpy_d2h");
   st.hostDepthStale = false;
 }
 

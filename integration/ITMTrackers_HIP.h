@@ -77,8 +77,9 @@ class ITMDepthTracker_HIP : public ITMDepthTracker {
       : ITMDepthTracker(imgSize, trackingRegime, noHierarchyLevels, noICPRunTillLevel, distThresh, terminationThreshold, lowLevelEngine, MEMORYDEVICE_CPU) {}
   ~ITMDepthTracker_HIP() { itm_dev_free(devPoints); itm_dev_free(devNormals); itm_dev_free(devDepth); }
 
-  // the reference's own TrackCamera builds its depth pyramid on the HOST from view->depth: under HIP_MIRROR_ON_DEMAND a view whose
-  // float depth was produced in HBM comes back first
+  // the reference's own TrackCamera builds the depth pyramid on the HOST (ITMDepthTracker::PrepareForEvaluation, ITMDepthTracker.cpp:62-75,
+  // from view->depth): under HIP_MIRROR_ON_DEMAND a float depth that ITMViewBuilder_HIP produced in HBM comes back first.  The ICP maps
+  // are only ever read at level 0 (SetEvaluationParams, ITMDepthTracker.cpp:81) and only by ComputeGandH: they stay in HBM.
   void TrackCamera(ITMTrackingState* trackingState, const ITMView* view) {
     HipSyncViewToHost(const_cast<ITMView*>(view));
     ITMDepthTracker::TrackCamera(trackingState, view);
@@ -88,6 +89,7 @@ class ITMDepthTracker_HIP : public ITMDepthTracker {
 class ITMViewBuilder_HIP : public ITMViewBuilder {
   void* devRaw = nullptr; void* devA = nullptr; void* devB = nullptr; void* devN = nullptr; void* devS = nullptr;
   void* pinnedRaw = nullptr;
+  itm_depth_stager* rawRing = nullptr; int ringW = 0, ringH = 0;
   size_t pixels = 0;
   void Ensure(size_t px) {
     if (px == pixels) return;
@@ -99,7 +101,7 @@ class ITMViewBuilder_HIP : public ITMViewBuilder {
 
  public:
   explicit ITMViewBuilder_HIP(const ITMRGBDCalib* calib) : ITMViewBuilder(calib) {}
-  ~ITMViewBuilder_HIP() { if (pinnedRaw) itm_host_unregister(pinnedRaw); itm_dev_free(devRaw); itm_dev_free(devA); itm_dev_free(devB); itm_dev_free(devN); itm_dev_free(devS); }
+  ~ITMViewBuilder_HIP() { if (rawRing) { itm_stream_synchronize(0); itm_depth_stager_destroy(rawRing); } if (pinnedRaw) itm_host_unregister(pinnedRaw); itm_dev_free(devRaw); itm_dev_free(devA); itm_dev_free(devB); itm_dev_free(devN); itm_dev_free(devS); }
 
   void ConvertDisparityToDepth(ITMFloatImage* depth_out, const ITMShortImage* disp_in, const ITMIntrinsics* depthIntrinsics, Vector2f disparityCalibParams) {
     const size_t px = (size_t)disp_in->noDims.x * disp_in->noDims.y; Ensure(px);
@@ -144,8 +146,19 @@ class ITMViewBuilder_HIP : public ITMViewBuilder {
     view->rgb->SetFrom(rgbImage, ORUtils::MemoryBlock<Vector4u>::CPU_TO_CPU);
     const int w = rawDepthImage->noDims.x, h = rawDepthImage->noDims.y;
     const size_t px = (size_t)w * h; Ensure(px);
-    HipPin(pinnedRaw, rawDepthImage->GetData(MEMORYDEVICE_CPU), px * 2);      // (the source engines reuse one raw image for every frame)
-    HipCheck(itm_memcpy_h2d(devRaw, rawDepthImage->GetData(MEMORYDEVICE_CPU), px * 2, 0), "memcpy_h2d");
+    // the raw frame goes through a ring of device slots on a copy stream of its own (itm_depth_stager): the upload leaves the frame's
+    // stream, and the host waits only until the copy has READ the image source's buffer -- which the source reuses for the next frame
+    // (the reference's CUDA view builder copies synchronously here, ITMViewBuilder_CUDA.cu:53)
+    int16_t* rawHost = rawDepthImage->GetData(MEMORYDEVICE_CPU);
+    if (!rawRing || ringW != w || ringH != h) {
+      if (rawRing) { itm_stream_synchronize(0); itm_depth_stager_destroy(rawRing); }
+      HipCheck(itm_depth_stager_create(w, h, 4, &rawRing), "raw ring"); ringW = w; ringH = h;
+    }
+    HipPin(pinnedRaw, rawHost, px * 2);
+    HipCheck(itm_depth_stager_upload(rawRing, rawHost), "raw ring upload");
+    for (int busy = 1; busy;) HipCheck(itm_depth_stager_pending(rawRing, nullptr, &busy), "raw ring pending");
+    const int16_t* rawDev = nullptr;
+    HipCheck(itm_depth_stager_acquire(rawRing, 0, &rawDev), "raw ring acquire");
     if (modelSensorNoise) {
       HipCheck(itm_memcpy_h2d(devN, view->depthNormal->GetData(MEMORYDEVICE_CPU), px * 16, 0), "memcpy_h2d");
       HipCheck(itm_memcpy_h2d(devS, view->depthUncertainty->GetData(MEMORYDEVICE_CPU), px * 4, 0), "memcpy_h2d");
@@ -154,11 +167,13 @@ class ITMViewBuilder_HIP : public ITMViewBuilder {
     // the float depth is written straight into the view's device stage: the engine calls of this frame find it there (no float
     // image crosses PCIe towards the device), the host image follows now or on request (HipSyncViewToHost)
     HipRegistry::Stage& st = HipStageOf(view);
-    HipCheck(itm_update_view((const int16_t*)devRaw, w, h, dc.type == ITMDisparityCalib::TRAFO_KINECT ? 0 : 1, dc.params.x, dc.params.y,
+    if (st.holding) { HipCheck(itm_depth_stager_release(st.ring, 0), "depth ring release"); st.holding = false; }      // (a view that used to be staged from the host)
+    HipCheck(itm_update_view(rawDev, w, h, dc.type == ITMDisparityCalib::TRAFO_KINECT ? 0 : 1, dc.params.x, dc.params.y,
                              &view->calib->intrinsics_d.projectionParamsSimple.all.x, useBilateralFilter ? 1 : 0, modelSensorNoise ? 1 : 0,
                              (float*)st.depth, (float*)devB, (float*)devN, (float*)devS, 0), "UpdateView");
+    HipCheck(itm_depth_stager_release(rawRing, 0), "raw ring release");      // the conversion is what read the slot
     HipMarkViewUpdated(view);
-    st.depthStaged = st.generation; st.hostDepthStale = true;
+    st.depthStaged = st.generation; st.hostDepthStale = true; st.cur = st.depth;
     if (HipEager()) HipSyncViewToHost(view);
     if (modelSensorNoise) {
       HipCheck(HipDownload(view->depthNormal->GetData(MEMORYDEVICE_CPU), devN, px * 16, 0), "memcpy_d2h");

@@ -39,8 +39,8 @@ def test_reference_interfaces_drive_the_hip_engines_bit_exactly():
     res = subprocess.run([DEMO], capture_output=True, text=True, timeout=600)
     lines = [json.loads(l) for l in res.stdout.strip().splitlines() if l.startswith("{")]
     configs = [l for l in lines if "config" in l]
-    # hash / colour hash / dense under both mirror policies of the adapter, the view builder, the tracker
-    assert len(configs) == 8, res.stdout + res.stderr
+    # hash / colour hash / dense under both mirror policies of the adapter, the view builder, the tracker, the closed loop of the whole HIP stack, one view rewritten every frame
+    assert len(configs) == 10, res.stdout + res.stderr
     for c in configs:
         assert c["equal"], c
         assert c["icp_points"] > 3000
