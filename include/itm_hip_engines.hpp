@@ -330,6 +330,14 @@ class ITMViewBuilder_HIP {
     UpdateView(view, raw, depth, scratch, useBilateralFilter, modelSensorNoise, depthNormal, depthUncertainty);
     check(itm_depth_stager_release(stager, stream), "UpdateView (release)");
   }
+  // true once the copy stream has READ every host frame handed to Prefetch / UpdateViewFromHost so far: from then on the image source
+  // may rewrite those buffers (the uploads are asynchronous; a source that reuses ONE raw buffer asks -- or waits -- before it refills it)
+  bool HostFramesRead() const {
+    int busy = 0;
+    if (stager) check(itm_depth_stager_pending(stager, nullptr, &busy), "HostFramesRead");
+    return busy == 0;
+  }
+  void WaitHostFramesRead() const { while (!HostFramesRead()) {} }
   ~ITMViewBuilder_HIP() { if (stager) itm_depth_stager_destroy(stager); }
   ITMViewBuilder_HIP(const ITMViewBuilder_HIP&) = delete;
   ITMViewBuilder_HIP& operator=(const ITMViewBuilder_HIP&) = delete;
@@ -496,6 +504,7 @@ class ITMMainEngine_HIP {
   ITMScene<TVoxel, TIndex>* GetScene() { return &scene; }
   ITMRenderState* GetRenderState() { return renderState_live; }
   const ITMVisualisationEngine_HIP<TVoxel, TIndex>* GetVisualisationEngine() const { return &visualisationEngine; }
+  const ITMViewBuilder_HIP* GetViewBuilder() const { return viewBuilder; }
 
   // rgbImage: device uchar4 (may be null without colour), rawDepthImage: device short
   void ProcessFrame(const uint8_t* rgbImage, const int16_t* rawDepthImage) {
@@ -507,6 +516,9 @@ class ITMMainEngine_HIP {
   }
   // The reference's own signature takes the raw frame in HOST memory (Engine/ITMMainEngine.cpp:111): rawDepthHost in page-locked memory
   // (itm_host_malloc); nextRawDepthHost, when the image source already has it, is uploaded while this frame is tracked and fused.
+  // The uploads are asynchronous: a buffer handed over here may be REWRITTEN only once GetViewBuilder()->HostFramesRead() says so
+  // (WaitHostFramesRead() waits; ~25 us after the call for a frame that was not announced).  The reference's CUDA build blocks in the
+  // copy instead (ITMViewBuilder_CUDA.cu:53); an image source with two buffers never has to wait here.
   void ProcessFrameFromHost(const uint8_t* rgbImage, const int16_t* rawDepthHost, const int16_t* nextRawDepthHost = nullptr) {
     view.rgb = rgbImage;
     viewBuilder->UpdateViewFromHost(&view, rawDepthHost, (float*)depthBuf, (float*)scratchBuf, settings.useBilateralFilter, settings.modelSensorNoise,

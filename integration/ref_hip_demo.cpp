@@ -196,7 +196,7 @@ static double time_frames(ITMScene<ITMVoxel_s, ITMVoxelBlockHash>* scene, ITMSce
                           ITMVisualisationEngine<ITMVoxel_s, ITMVoxelBlockHash>* vis, std::vector<ITMView*>& views, ITMTrackingState* ts, ITMRenderState* rs,
                           int frames, bool hip) {
   reco->ResetScene(scene);
-  const int warm = hip ? 20 : 1;
+  const int warm = hip ? (int)views.size() : 1;      // (every view once: its device stage and staging ring are created on first use)
   std::chrono::steady_clock::time_point t0;
   for (int k = 0; k < warm + frames; ++k) {
     if (k == warm) { if (hip) HipCheck(itm_stream_synchronize(0), "sync"); t0 = std::chrono::steady_clock::now(); }
