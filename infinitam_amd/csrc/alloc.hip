@@ -209,6 +209,27 @@ __device__ inline bool block_in_frustum(int bx, int by, int bz, const Mat4& M, f
   return false;
 }
 
+// The same walk as a LOOP, for the visible-list launch: that kernel re-tests up to sixteen slots per lane, and with the walk unrolled at
+// every one of them it was 16 000 instructions (~100 KB of code for a 64 KB instruction cache shared by two compute units); rolled it
+// holds the corner arithmetic twice.  Steps are 6-bit codes (x+ x- y+ y- z+ z-), uniform: scalar branches.
+__device__ inline bool block_in_frustum_rolled(int bx, int by, int bz, const Mat4& M, float fx, float fy, float cx, float cy, float voxelSize, int W, int H) {
+  const float f = (float)kBlockSide * voxelSize;
+  float x = (float)bx * f, y = (float)by * f, z = (float)bz * f;
+  constexpr unsigned long long kSteps = (16ull << 6) | (4ull << 12) | (1ull << 18) | (32ull << 24) | (8ull << 30) | (6ull << 36) | (25ull << 42);
+#pragma unroll 1
+  for (int i = 0; i < 8; ++i) {
+    const uint32_t op = (uint32_t)(kSteps >> (6 * i)) & 63u;
+    if (op & 1u) x += f;
+    if (op & 2u) x -= f;
+    if (op & 4u) y += f;
+    if (op & 8u) y -= f;
+    if (op & 16u) z += f;
+    if (op & 32u) z -= f;
+    if (corner_in_image(M, fx, fy, cx, cy, W, H, x, y, z)) return true;
+  }
+  return false;
+}
+
 // checkBlockVisibility<true> (DeviceAgnostic/ITMSceneReconstructionEngine.h:243-342): a corner outside the image but inside the image
 // enlarged by an eighth on every side makes the block "visible enlarged"; the walk ends at the first corner inside the image proper
 __device__ inline bool block_in_frustum_enlarged(int bx, int by, int bz, const Mat4& M, float fx, float fy, float cx, float cy, float voxelSize, int W, int H) {
@@ -337,6 +358,7 @@ struct SweepArgs {
   uint32_t* allocKey; int2* chunkReqNext; const int32_t* excessList; const int32_t* allocList; uint32_t* headBits;
   int32_t* dirPtr; int32_t* dirSlot; void* sdfMirror; const float* depth; int lazy;
   uint32_t* sweepDone;     // per chunk: the epoch of the launch whose sweep has placed the chunk's excess allocations
+  unsigned long long* keptGran;      // per 32 slots of the excess region: {epoch, "kept" bits} of the shared re-tests
   int32_t* fatalDev;       // the scene's host-visible status word (alloc_device.h: raise_fatal)
   int forceStuck;          // test hook (debug key 20): chunk whose wait is treated as expired, or -1
 };
@@ -389,6 +411,55 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
   ITM_LS(0)
   int before = 0;
   bool stuck = SWEEP && chunk == sw.forceStuck;
+  if constexpr (SWEEP && LAZY) {
+    if (excessRegion) {
+      // THE EXCESS REGION'S RE-TESTS, SPREAD.  Excess entries are handed out from the top of the region downwards, so the ones in use
+      // lie side by side in its LAST chunk (BASELINE configs[1]: 1 732 entries, 1 518 of them in the visible list), and whenever the
+      // camera turns away from the pixels that request them that one workgroup walks the corners of eight blocks per lane, one after
+      // the other -- 16 us of a launch whose other 575 workgroups are through after 7 (tools/list_timeline.py; the 20-24 us launches
+      // of profiles/r5_counters.md; BASELINE configs[4]: 36 us every frame).  The candidates of a frame are known before the launch
+      // starts (previously visible, no request this frame: nothing in this launch changes that -- a sweep only fills empty slots), so
+      // the excess-region workgroups -- 63 of 64 idle -- share them before anything else: group G of 64 consecutive slots is re-tested
+      // by wave (G / E) % 4 of workgroup G % E in its round G / (4 E), ONE block per lane, and the 64 verdicts of a group travel to the
+      // chunk that owns the slots as two tagged granules {epoch, 32 "kept" bits}: one indivisible 8-byte store each, nothing to wait
+      // for behind them (the look-back's idiom).  The owner's count picks its lanes' bytes out of them instead of walking (below).
+      // Plain loads: a type byte that another workgroup rewrites meanwhile is one of a slot that was empty when the launch began.
+      const int firstEx = p.bucketNum / kSweepChunk, E = numChunks - firstEx, e = chunk - firstEx;
+      const int regionSlots = p.noTotalEntries - p.bucketNum;
+      int sl[kSlotsPerThread];
+      uint32_t cand = 0;
+#pragma unroll
+      for (int r = 0; r < kSlotsPerThread; ++r) {
+        const int rs = ((r * 4 + (tid >> 6)) * E + e) * kWave + (tid & (kWave - 1));
+        sl[r] = p.bucketNum + (rs < regionSlots ? rs : 0);
+        const uint32_t t = visT[sl[r]];
+        if (rs < regionSlots && t != 0u && !(t & 0x80u)) cand |= 1u << r;
+      }
+      // (the entries are asked for with the types, not behind them: one memory round trip instead of two; most go unused)
+      uint4 ent[kSlotsPerThread];
+#pragma unroll
+      for (int r = 0; r < kSlotsPerThread; ++r) ent[r] = hash[sl[r]];
+#pragma unroll 1
+      for (int r = 0; r < kSlotsPerThread; ++r) {
+        bool kept = false;
+        if (__ballot((cand >> r) & 1u) != 0ull) {                    // (uniform; most rounds of most waves have nothing to test)
+          uint4 er = ent[0];
+#pragma unroll
+          for (int j = 1; j < kSlotsPerThread; ++j) if (r == j) er = ent[j];      // r is uniform: selects, no indexed registers
+          if ((cand >> r) & 1u) {
+            const HashEntry he = unpack_entry(er);
+            kept = block_in_frustum_rolled(he.px, he.py, he.pz, p.M, p.fx, p.fy, p.cx, p.cy, p.voxelSize, p.W, p.H);
+          }
+        }
+        const unsigned long long mask = __ballot(kept);
+        if ((tid & (kWave - 1)) < 2) {
+          const int G = (r * 4 + (tid >> 6)) * E + e;
+          const uint32_t half = (tid & 1) ? (uint32_t)(mask >> 32) : (uint32_t)mask;
+          __hip_atomic_store(&sw.keptGran[2 * G + (tid & 1)], ((unsigned long long)epoch << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+  }
   // sums the granules of the chunks before this one, waiting for each to carry this launch's epoch
   auto look_back = [&]() {
     for (int j = tid; j < chunk; j += 256) {
@@ -442,8 +513,11 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
   uint32_t w[2] = {0u, 0u};
   if (slot0 < p.noTotalEntries) {  // noTotalEntries is a multiple of 8 (checked on the host)
     uint2 raw;
+    unsigned long long keptEarly = 0;
     if (excessRegion) {
       const unsigned long long q = __hip_atomic_load((const unsigned long long*)(visT + slot0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (the verdicts on this lane's slots, asked for beside the types: by now they have usually been published)
+      if constexpr (SWEEP && LAZY) keptEarly = __hip_atomic_load(&sw.keptGran[(slot0 - p.bucketNum) >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       raw = make_uint2((uint32_t)q, (uint32_t)(q >> 32));
     } else if (early) {
       raw = rawEarly;
@@ -461,13 +535,43 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
         const uint32_t t = (w[k >> 2] >> ((k & 3) * 8)) & 0xffu;
         if (!(LAZY && (t & 0x80u)) && (LAZY ? (t != 0u) : (t == 3u))) retest |= 1u << k;
       }
+      constexpr bool kShared = SWEEP && LAZY;      // the excess region's re-tests were shared out at the top of the kernel
       uint4 entry[kSlotsPerThread];
-      if (early) {
-#pragma unroll
-        for (int k = 0; k < kSlotsPerThread; ++k) entry[k] = entryEarly[k];
+      uint32_t kept8 = 0;
+      if (kShared && excessRegion) {
+        if (retest) {
+          // this lane's eight verdicts: one byte of the granule pair of the 64-slot group its slots lie in
+          const int rel = slot0 - p.bucketNum;
+          const unsigned long long* gp = &sw.keptGran[rel >> 5];
+          unsigned long long g = keptEarly;
+          for (int spin = 0; (uint32_t)(g >> 32) != epoch; ++spin) {
+            if (spin > (1 << 22)) { stuck = true; break; }
+            __builtin_amdgcn_s_sleep(kListSpinSleep);
+            g = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          kept8 = ((uint32_t)g >> (rel & 31)) & 0xffu;
+        }
       } else {
+        if (early) {
 #pragma unroll
-        for (int k = 0; k < kSlotsPerThread; ++k) entry[k] = hash[slot0 + ((retest >> k) & 1u ? k : 0)];
+          for (int k = 0; k < kSlotsPerThread; ++k) entry[k] = entryEarly[k];
+        } else {
+#pragma unroll
+          for (int k = 0; k < kSlotsPerThread; ++k) entry[k] = hash[slot0 + ((retest >> k) & 1u ? k : 0)];
+        }
+        // visible in the previous frame and not seen again: kept only if still in the frustum (one copy of the walk: a loop over the
+        // lane's slots around a loop over the corners)
+        if (retest) {
+#pragma unroll 1
+          for (int k = 0; k < kSlotsPerThread; ++k) {
+            if (!((retest >> k) & 1u)) continue;
+            uint4 ek = entry[0];
+#pragma unroll
+            for (int j = 1; j < kSlotsPerThread; ++j) if (k == j) ek = entry[j];
+            const HashEntry he = unpack_entry(ek);
+            if (block_in_frustum_rolled(he.px, he.py, he.pz, p.M, p.fx, p.fy, p.cx, p.cy, p.voxelSize, p.W, p.H)) kept8 |= 1u << k;
+          }
+        }
       }
 #pragma unroll
       for (int k = 0; k < kSlotsPerThread; ++k) {
@@ -476,9 +580,7 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
         if (LAZY && (t & 0x80u)) {
           t &= 0x7fu;                         // touched this frame: type 1 / 2
         } else if (LAZY ? (t != 0u) : (t == 3u)) {
-          // visible in the previous frame and not seen again: keep only if still in the frustum
-          HashEntry he = unpack_entry(entry[k]);
-          t = block_in_frustum(he.px, he.py, he.pz, p.M, p.fx, p.fy, p.cx, p.cy, p.voxelSize, p.W, p.H) ? 3u : 0u;
+          t = ((kept8 >> k) & 1u) ? 3u : 0u;
         }
         if (t != t0) { w[k >> 2] = (w[k >> 2] & ~(0xffu << ((k & 3) * 8))) | (t << ((k & 3) * 8)); changed = true; }
         n += (t > 0u);
@@ -703,7 +805,7 @@ int launch_sweep_stage(itm_scene* s, const itm_view* v, itm_render_state* rs, bo
   KernelTimer tv(s, ITM_TK_VISIBLE_LIST, st);
   if (onePass) {
     const uint32_t epoch = ++s->listEpoch;
-    const SweepArgs sw{s->allocKey, reqNext, s->excessList, s->allocList, s->headBits, s->dirPtr, s->dirSlot, s->sdfMirror, v->depth, lazy ? 1 : 0, s->chunkSweepDone,
+    const SweepArgs sw{s->allocKey, reqNext, s->excessList, s->allocList, s->headBits, s->dirPtr, s->dirSlot, s->sdfMirror, v->depth, lazy ? 1 : 0, s->chunkSweepDone, s->chunkKeptGran,
                        s->fatalDev, fusedSweep ? g_debug_force_list_stuck - 1 : -1};
 #define ITM_VL(CM, LZ, SW) visible_list_kernel<CM, LZ, SW><<<nChunks, 256, 0, st>>>(rs->visibleType, s->hash, s->chunkGran, epoch, reqCur, nChunks, s->counters, rs->visibleIds, rs->capIds, rs->counters, p, sw)
     if (onlyVisible) { if (lazy) ITM_VL(false, true, false); else ITM_VL(false, false, false); }

@@ -71,6 +71,7 @@ struct itm_scene {
   int32_t* chunkVis = nullptr;    // int[numChunks]: visible slots per sweep chunk (two-pass path, FindVisibleBlocks)
   unsigned long long* chunkGran = nullptr;  // u64[numChunks]: {epoch, visible count} granules of the one-pass visible list
   uint32_t* chunkSweepDone = nullptr;        // u32[numChunks]: epoch stamps of chunks whose excess allocations are in place (fused sweep)
+  unsigned long long* chunkKeptGran = nullptr;      // u64 per 32 slots: {epoch, kept bits} of the excess region's shared frustum re-tests (alloc.hip)
   uint32_t listEpoch = 0;
   // occupancy bitmap of the ordered part of the table: bit b set <=> hash[b].ptr >= -1 (an entry lives there: allocated, or swapped
   // out with its chain possibly still resident).  A clear bit

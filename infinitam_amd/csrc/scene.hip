@@ -406,7 +406,7 @@ static void free_scene(itm_scene* s) {
   free_swap_state(s);
   if (s->prof) { s->prof->flush(); for (hipEvent_t e : s->prof->pool) (void)hipEventDestroy(e); delete s->prof; }
   (void)hipFree(s->hash); (void)hipFree(s->excessList); (void)hipFree(s->vba); (void)hipFree(s->allocList);
-  (void)hipFree(s->counters); (void)hipFree(s->headBits); (void)hipFree(s->allocKey); (void)hipFree(s->chunkReq); (void)hipFree(s->chunkVis); (void)hipFree(s->chunkGran); (void)hipFree(s->chunkSweepDone);
+  (void)hipFree(s->counters); (void)hipFree(s->headBits); (void)hipFree(s->allocKey); (void)hipFree(s->chunkReq); (void)hipFree(s->chunkVis); (void)hipFree(s->chunkGran); (void)hipFree(s->chunkSweepDone); (void)hipFree(s->chunkKeptGran);
   (void)hipFree(s->dirPtr); (void)hipFree(s->dirSlot); (void)hipFree(s->sdfMirror); (void)hipFree(s->org.mTable); (void)hipFree(s->org.mPages); (void)hipFree(s->depthTiles);
   delete s;
 }
@@ -537,6 +537,7 @@ int itm_scene_create(const itm_scene_config* cfg_in, const itm_scene_params* prm
     alloc((void**)&s->chunkVis, (size_t)s->numChunks * 4);
     alloc((void**)&s->chunkGran, (size_t)s->numChunks * 8);
     alloc((void**)&s->chunkSweepDone, (size_t)s->numChunks * 4);
+    alloc((void**)&s->chunkKeptGran, (size_t)s->numChunks * (kSweepChunk / 32) * 8);
   } else {
     s->numVoxels = (size_t)cfg.denseSize[0] * cfg.denseSize[1] * cfg.denseSize[2];
     alloc((void**)&s->allocList, 4);
@@ -591,6 +592,7 @@ int itm_scene_create(const itm_scene_config* cfg_in, const itm_scene_params* prm
   if (e == hipSuccess && s->chunkReq) e = hipMemset(s->chunkReq, 0, (size_t)s->numChunks * 16);
   if (e == hipSuccess && s->chunkGran) e = hipMemset(s->chunkGran, 0, (size_t)s->numChunks * 8);
   if (e == hipSuccess && s->chunkSweepDone) e = hipMemset(s->chunkSweepDone, 0, (size_t)s->numChunks * 4);
+  if (e == hipSuccess && s->chunkKeptGran) e = hipMemset(s->chunkKeptGran, 0, (size_t)s->numChunks * (kSweepChunk / 32) * 8);
   if (e == hipSuccess && s->dirPtr) e = hipMemset(s->dirPtr, 0xff, kDirCells * 4);
   if (e == hipSuccess && s->dirSlot) e = hipMemset(s->dirSlot, 0xff, kDirCells * 4);
   if (e != hipSuccess) { free_scene(s); return hip_fail(e, "hipMemset(scene)", __FILE__, __LINE__); }

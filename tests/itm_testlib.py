@@ -107,6 +107,7 @@ class Scenario:
     noise_seed: Optional[int] = None
     origin: tuple = (0.0, 0.0, 0.0)   # metres added to every camera position: the scene and its trajectory far from the world origin (same depth images)
     frame_stride: int = 1             # frame k of the scenario is position k * frame_stride of its trajectory (bench.py's config 5 keeps every 4th pose)
+    yaw_rate: float = 0.02            # "yaw": radians per frame
 
     def params(self):
         return default_params(self.voxelSize, self.mu, self.maxW, 0.35, 3.0, self.stopIntegratingAtMaxW)
@@ -125,7 +126,7 @@ class Scenario:
         if any(self.origin):
             t = tuple(np.float32(a) + np.float32(b) for a, b in zip(t, self.origin))
         if self.trajectory == "yaw":
-            return synth.pose_matrix_yaw(t, 0.02 * k)
+            return synth.pose_matrix_yaw(t, self.yaw_rate * k)
         return synth.pose_matrix(t)
 
     def depth(self, k):

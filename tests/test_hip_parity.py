@@ -196,6 +196,35 @@ def test_sweep_inside_the_visible_list_launch_and_as_its_own_launch(hip, oracle,
     T.compare_results(a, b, sc, what=sc.name + "/separate sweep")
 
 
+@pytest.mark.parametrize("sc", [Scenario(name="turning_away_tiny_table", frames=7, bucketNum=0x1000, excessNum=0x2000, w=320, h=240, voxelSize=0.01, trajectory="yaw", yaw_rate=0.12),
+                                Scenario(name="turning_away_one_excess_chunk", frames=6, bucketNum=0x800, excessNum=0x800, w=320, h=240, voxelSize=0.01, trajectory="yaw", yaw_rate=-0.15),
+                                Scenario(name="turning_away_ragged_excess", frames=6, bucketNum=0x1000, excessNum=0x1238, w=320, h=240, voxelSize=0.01, trajectory="yaw", yaw_rate=0.15)],
+                         ids=lambda s: s.name)
+def test_excess_region_re_tests_are_shared_among_its_workgroups(hip, oracle, sc):
+    """Visible blocks that no pixel requests any more are re-tested against the frustum; the ones that live in the excess region lie
+    side by side (the excess list is handed out from one end), so the visible-list launch deals them out -- 64 slots to a wave, a block
+    to a lane -- to all workgroups of the region, and the owners of the slots pick the verdicts up as tagged granules (alloc.hip).  A
+    camera that turns 7-9 degrees per frame over tables small enough that most blocks are excess blocks: hundreds of them leave the
+    frustum or stay unrequested every frame.  Counters every frame, full state at the end, list launch with and without the sweep inside."""
+    b = T.run_scenario(oracle, sc)
+    vis = [x["noVisibleEntries"] for x in b.counters]
+    free = [x["lastFreeBlockId"] for x in b.counters]
+    # blocks that left the list = blocks allocated (all of them visible) minus the list's growth, frame by frame
+    dropped = sum((free[k - 1] - free[k]) - (vis[k] - vis[k - 1]) for k in range(1, len(vis)))
+    assert dropped > 300, (vis, free)
+    ex = b.hash["ptr"][sc.bucketNum:] >= 0
+    assert ex.sum() > 300, ex.sum()                                             # and the excess region is where they live
+    a = T.run_scenario(hip, sc, fused=True)
+    T.compare_results(a, b, sc, what=sc.name)
+    assert a.counters[-1]["statusFlags"] == 0
+    hip.check(hip.fn["debug_set"](13, 1), "debug_set")                          # the sweep as its own launch: the owners walk their own slots
+    try:
+        a = T.run_scenario(hip, sc, fused=True)
+    finally:
+        hip.check(hip.fn["debug_set"](13, 0), "debug_set")
+    T.compare_results(a, b, sc, what=sc.name + "/separate sweep")
+
+
 def test_explicit_mark_previous_path(hip, oracle):
     """The allocation normally folds "mark last frame's list as type 3" into the type encoding; the explicit
     launch (used after FindVisibleBlocks / uploads on the same render state) must give the same scene."""

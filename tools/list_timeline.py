@@ -15,7 +15,8 @@ scene.reco.ResetScene()
 rs = scene.vis.CreateRenderState((W, H))
 intr = synth.intrinsics_for(W, H)
 pts = capi.DevBuffer(be, W * H * 16); nrm = capi.DevBuffer(be, W * H * 16)
-for k in range(30):
+FRAMES = int(sys.argv[3]) if len(sys.argv) > 3 else 30
+for k in range(FRAMES):
     t = synth.bench_position(k)
     d = be.to_backend(synth.depth_frame(W, H, t, intr))
     v = capi.View(d, W, H, M_d=synth.pose_matrix(t), intr_d=intr, rgb=(be.to_backend(synth.rgb_frame(W, H)) if C5 else None), w_rgb=W, h_rgb=H, intr_rgb=intr)
@@ -42,3 +43,19 @@ print("look-back duration    ", pc(us[:, 3] - us[:, 2]))
 ex = np.arange(n) >= n - 64
 print("all done (stamp 5)    ", pc((raw[:, 5].astype(np.float64) - float(t0)) / 100.0))
 print("ordered chunks end    ", pc(us[~ex, 4]), " excess-region chunks end", pc(us[ex, 4]))
+# the slowest chunks, and how many slots of each were visible before / after this frame (the re-test candidates are the
+# previously visible slots no pixel asked for)
+if len(sys.argv) > 4:
+    order = np.argsort(-(us[:, 2] - us[:, 1]))[:6]
+    types = scene.download(capi.BUF_VISIBLE_TYPE, rs)
+    per = (types.reshape(-1, 2048) != 0).sum(axis=1)
+    hashv = scene.download(capi.BUF_HASH_ENTRIES)
+    alloc = (hashv["ptr"].reshape(-1, 2048) >= 0).sum(axis=1)
+    for c in order:
+        print("chunk %4d: count phase %.2f us, published at %.2f, visible slots now %d, allocated slots %d" % (c, us[c, 2] - us[c, 1], us[c, 2], per[c], alloc[c]))
+    print("visible slots per chunk: ordered max %d mean %.1f; excess region %s" % (per[:512].max(), per[:512].mean(), per[512:].tolist()))
+if len(sys.argv) > 4:
+    exi = np.where(ex)[0]
+    late = exi[np.argsort(-us[exi, 1])[:8]]
+    for c in late:
+        print("excess chunk %4d (e = %2d): start %.2f  after worker phase + sweep %.2f  published %.2f  after look-back %.2f  end %.2f" % (c, c - exi[0], us[c, 0], us[c, 1], us[c, 2], us[c, 3], us[c, 4]))
