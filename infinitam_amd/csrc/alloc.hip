@@ -177,15 +177,6 @@ __device__ inline void sweep_chunk(const int chunk, int* lds, uint32_t* __restri
   }
 }
 
-__global__ void __launch_bounds__(256) allocate_sweep_kernel(uint32_t* __restrict__ allocKey, const int2* __restrict__ chunkReq,
-                                                             int2* __restrict__ chunkReqNext, int numChunks, uint4* __restrict__ hash,
-                                                             const int32_t* __restrict__ excessList, const int32_t* __restrict__ allocList,
-                                                             uint8_t* __restrict__ visT, const SceneCounters* __restrict__ counters,
-                                                             uint32_t* __restrict__ headBits, int32_t* __restrict__ dirPtr, int32_t* __restrict__ dirSlot, void* __restrict__ sdfMirror,
-                                                             const float* __restrict__ depth, int lazy, AllocParams p) {
-  __shared__ int lds[8];
-  sweep_chunk<false>((int)blockIdx.x, lds, allocKey, chunkReq, chunkReqNext, numChunks, hash, excessList, allocList, visT, counters, headBits, dirPtr, dirSlot, sdfMirror, depth, lazy, p);
-}
 
 // checkBlockVisibility<false>: corners are reached by incremental +-f updates in a fixed order.
 __device__ inline bool corner_in_image(const Mat4& M, float fx, float fy, float cx, float cy, int W, int H, float x, float y, float z) {
@@ -228,6 +219,74 @@ __device__ inline bool block_in_frustum_rolled(int bx, int by, int bz, const Mat
     if (corner_in_image(M, fx, fy, cx, cy, W, H, x, y, z)) return true;
   }
   return false;
+}
+
+// The frustum re-tests of the excess region, dealt out to the region's workgroups (visible_list_kernel explains why): group G of 64
+// consecutive slots is re-tested by wave (G / E) % 4 of workgroup G % E in its round G / (4 E), one block per lane.  The verdicts go
+// to the owners of the slots either as tagged granules (GRANULES: the launch that also counts -- two 8-byte stores per group) or into
+// the type bytes themselves (the sweep as its own launch, read by the NEXT launch: "kept" under the touched mark, 0x83, which the
+// count turns into 3 -- what its own walk would have produced -- or 0).  Lazy form of the types only; called by whole workgroups.
+template <bool GRANULES>
+__device__ inline void share_excess_retests(int chunk, int numChunks, uint8_t* __restrict__ visT, const uint4* __restrict__ hash, const AllocParams& p,
+                                            unsigned long long* __restrict__ keptGran, uint32_t epoch) {
+  const int tid = threadIdx.x;
+  const int firstEx = p.bucketNum / kSweepChunk, E = numChunks - firstEx, e = chunk - firstEx;
+  const int regionSlots = p.noTotalEntries - p.bucketNum;
+  int sl[kSlotsPerThread];
+  uint32_t cand = 0;
+#pragma unroll
+  for (int r = 0; r < kSlotsPerThread; ++r) {
+    const int rs = ((r * 4 + (tid >> 6)) * E + e) * kWave + (tid & (kWave - 1));
+    sl[r] = p.bucketNum + (rs < regionSlots ? rs : 0);
+    // (plain loads: a type byte that another workgroup rewrites meanwhile is one of a slot that was empty when the launch began)
+    const uint32_t t = visT[sl[r]];
+    if (rs < regionSlots && t != 0u && !(t & 0x80u)) cand |= 1u << r;
+  }
+  // (the entries are asked for with the types, not behind them: one memory round trip instead of two; most go unused)
+  uint4 ent[kSlotsPerThread];
+#pragma unroll
+  for (int r = 0; r < kSlotsPerThread; ++r) ent[r] = hash[sl[r]];
+#pragma unroll 1
+  for (int r = 0; r < kSlotsPerThread; ++r) {
+    bool kept = false;
+    if (__ballot((cand >> r) & 1u) != 0ull) {                    // (uniform; most rounds of most waves have nothing to test)
+      uint4 er = ent[0];
+#pragma unroll
+      for (int j = 1; j < kSlotsPerThread; ++j) if (r == j) er = ent[j];      // r is uniform: selects, no indexed registers
+      if ((cand >> r) & 1u) {
+        const HashEntry he = unpack_entry(er);
+        kept = block_in_frustum_rolled(he.px, he.py, he.pz, p.M, p.fx, p.fy, p.cx, p.cy, p.voxelSize, p.W, p.H);
+        if (!GRANULES) {
+          int slr = sl[0];
+#pragma unroll
+          for (int j = 1; j < kSlotsPerThread; ++j) if (r == j) slr = sl[j];
+          visT[slr] = kept ? 0x83 : 0;
+        }
+      }
+    }
+    if (GRANULES) {
+      const unsigned long long mask = __ballot(kept);
+      if ((tid & (kWave - 1)) < 2) {
+        const int G = (r * 4 + (tid >> 6)) * E + e;
+        const uint32_t half = (tid & 1) ? (uint32_t)(mask >> 32) : (uint32_t)mask;
+        __hip_atomic_store(&keptGran[2 * G + (tid & 1)], ((unsigned long long)epoch << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) allocate_sweep_kernel(uint32_t* __restrict__ allocKey, const int2* __restrict__ chunkReq,
+                                                             int2* __restrict__ chunkReqNext, int numChunks, uint4* __restrict__ hash,
+                                                             const int32_t* __restrict__ excessList, const int32_t* __restrict__ allocList,
+                                                             uint8_t* __restrict__ visT, const SceneCounters* __restrict__ counters,
+                                                             uint32_t* __restrict__ headBits, int32_t* __restrict__ dirPtr, int32_t* __restrict__ dirSlot, void* __restrict__ sdfMirror,
+                                                             const float* __restrict__ depth, int lazy, AllocParams p) {
+  __shared__ int lds[8];
+  // (the sweep as its own launch: the count that follows is a launch of its own too, so the excess region's shared re-tests leave
+  // their verdicts in the type bytes -- share_excess_retests; the swapping build re-tests against the enlarged frustum: not shared)
+  if (lazy && !p.useSwapping && (p.bucketNum % kSweepChunk) == 0 && (int)blockIdx.x * kSweepChunk >= p.bucketNum)
+    share_excess_retests<false>((int)blockIdx.x, numChunks, visT, hash, p, nullptr, 0u);
+  sweep_chunk<false>((int)blockIdx.x, lds, allocKey, chunkReq, chunkReqNext, numChunks, hash, excessList, allocList, visT, counters, headBits, dirPtr, dirSlot, sdfMirror, depth, lazy, p);
 }
 
 // checkBlockVisibility<true> (DeviceAgnostic/ITMSceneReconstructionEngine.h:243-342): a corner outside the image but inside the image
@@ -413,51 +472,16 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
   bool stuck = SWEEP && chunk == sw.forceStuck;
   if constexpr (SWEEP && LAZY) {
     if (excessRegion) {
-      // THE EXCESS REGION'S RE-TESTS, SPREAD.  Excess entries are handed out from the top of the region downwards, so the ones in use
+      // THE EXCESS REGION'S RE-TESTS, SHARED.  Excess entries are handed out from the top of the region downwards, so the ones in use
       // lie side by side in its LAST chunk (BASELINE configs[1]: 1 732 entries, 1 518 of them in the visible list), and whenever the
-      // camera turns away from the pixels that request them that one workgroup walks the corners of eight blocks per lane, one after
+      // camera turns away from the pixels that request them that one workgroup walked the corners of eight blocks per lane, one after
       // the other -- 16 us of a launch whose other 575 workgroups are through after 7 (tools/list_timeline.py; the 20-24 us launches
       // of profiles/r5_counters.md; BASELINE configs[4]: 36 us every frame).  The candidates of a frame are known before the launch
       // starts (previously visible, no request this frame: nothing in this launch changes that -- a sweep only fills empty slots), so
-      // the excess-region workgroups -- 63 of 64 idle -- share them before anything else: group G of 64 consecutive slots is re-tested
-      // by wave (G / E) % 4 of workgroup G % E in its round G / (4 E), ONE block per lane, and the 64 verdicts of a group travel to the
+      // the excess-region workgroups -- 63 of 64 idle -- share them before anything else, and the 64 verdicts of a group travel to the
       // chunk that owns the slots as two tagged granules {epoch, 32 "kept" bits}: one indivisible 8-byte store each, nothing to wait
       // for behind them (the look-back's idiom).  The owner's count picks its lanes' bytes out of them instead of walking (below).
-      // Plain loads: a type byte that another workgroup rewrites meanwhile is one of a slot that was empty when the launch began.
-      const int firstEx = p.bucketNum / kSweepChunk, E = numChunks - firstEx, e = chunk - firstEx;
-      const int regionSlots = p.noTotalEntries - p.bucketNum;
-      int sl[kSlotsPerThread];
-      uint32_t cand = 0;
-#pragma unroll
-      for (int r = 0; r < kSlotsPerThread; ++r) {
-        const int rs = ((r * 4 + (tid >> 6)) * E + e) * kWave + (tid & (kWave - 1));
-        sl[r] = p.bucketNum + (rs < regionSlots ? rs : 0);
-        const uint32_t t = visT[sl[r]];
-        if (rs < regionSlots && t != 0u && !(t & 0x80u)) cand |= 1u << r;
-      }
-      // (the entries are asked for with the types, not behind them: one memory round trip instead of two; most go unused)
-      uint4 ent[kSlotsPerThread];
-#pragma unroll
-      for (int r = 0; r < kSlotsPerThread; ++r) ent[r] = hash[sl[r]];
-#pragma unroll 1
-      for (int r = 0; r < kSlotsPerThread; ++r) {
-        bool kept = false;
-        if (__ballot((cand >> r) & 1u) != 0ull) {                    // (uniform; most rounds of most waves have nothing to test)
-          uint4 er = ent[0];
-#pragma unroll
-          for (int j = 1; j < kSlotsPerThread; ++j) if (r == j) er = ent[j];      // r is uniform: selects, no indexed registers
-          if ((cand >> r) & 1u) {
-            const HashEntry he = unpack_entry(er);
-            kept = block_in_frustum_rolled(he.px, he.py, he.pz, p.M, p.fx, p.fy, p.cx, p.cy, p.voxelSize, p.W, p.H);
-          }
-        }
-        const unsigned long long mask = __ballot(kept);
-        if ((tid & (kWave - 1)) < 2) {
-          const int G = (r * 4 + (tid >> 6)) * E + e;
-          const uint32_t half = (tid & 1) ? (uint32_t)(mask >> 32) : (uint32_t)mask;
-          __hip_atomic_store(&sw.keptGran[2 * G + (tid & 1)], ((unsigned long long)epoch << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
+      share_excess_retests<true>(chunk, numChunks, visT, hash, p, sw.keptGran, epoch);
     }
   }
   // sums the granules of the chunks before this one, waiting for each to carry this launch's epoch
