@@ -223,10 +223,10 @@ __device__ inline bool block_in_frustum_rolled(int bx, int by, int bz, const Mat
 
 // The frustum re-tests of the excess region, dealt out to the region's workgroups (visible_list_kernel explains why): group G of 64
 // consecutive slots is re-tested by wave (G / E) % 4 of workgroup G % E in its round G / (4 E), one block per lane.  The verdicts go
-// to the owners of the slots either as tagged granules (GRANULES: the launch that also counts -- two 8-byte stores per group) or into
-// the type bytes themselves (the sweep as its own launch, read by the NEXT launch: "kept" under the touched mark, 0x83, which the
-// count turns into 3 -- what its own walk would have produced -- or 0).  Lazy form of the types only; called by whole workgroups.
-template <bool GRANULES>
+// to the owners of the slots as tagged granules -- two 8-byte stores per group.  A verdict is a function of what the slot held when
+// the launch began; the OWNER decides whether it applies: a slot that a sweep of this launch has filled meanwhile carries the touched
+// mark by the time the owner reads it (stale types of a render state that outlived a ResetScene sit on empty slots), and its verdict
+// -- possibly computed from a half-written entry -- is ignored.  Lazy form of the types only; called by whole workgroups.
 __device__ inline void share_excess_retests(int chunk, int numChunks, uint8_t* __restrict__ visT, const uint4* __restrict__ hash, const AllocParams& p,
                                             unsigned long long* __restrict__ keptGran, uint32_t epoch) {
   const int tid = threadIdx.x;
@@ -256,21 +256,13 @@ __device__ inline void share_excess_retests(int chunk, int numChunks, uint8_t* _
       if ((cand >> r) & 1u) {
         const HashEntry he = unpack_entry(er);
         kept = block_in_frustum_rolled(he.px, he.py, he.pz, p.M, p.fx, p.fy, p.cx, p.cy, p.voxelSize, p.W, p.H);
-        if (!GRANULES) {
-          int slr = sl[0];
-#pragma unroll
-          for (int j = 1; j < kSlotsPerThread; ++j) if (r == j) slr = sl[j];
-          visT[slr] = kept ? 0x83 : 0;
-        }
       }
     }
-    if (GRANULES) {
-      const unsigned long long mask = __ballot(kept);
-      if ((tid & (kWave - 1)) < 2) {
-        const int G = (r * 4 + (tid >> 6)) * E + e;
-        const uint32_t half = (tid & 1) ? (uint32_t)(mask >> 32) : (uint32_t)mask;
-        __hip_atomic_store(&keptGran[2 * G + (tid & 1)], ((unsigned long long)epoch << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+    const unsigned long long mask = __ballot(kept);
+    if ((tid & (kWave - 1)) < 2) {
+      const int G = (r * 4 + (tid >> 6)) * E + e;
+      const uint32_t half = (tid & 1) ? (uint32_t)(mask >> 32) : (uint32_t)mask;
+      __hip_atomic_store(&keptGran[2 * G + (tid & 1)], ((unsigned long long)epoch << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -282,10 +274,10 @@ __global__ void __launch_bounds__(256) allocate_sweep_kernel(uint32_t* __restric
                                                              uint32_t* __restrict__ headBits, int32_t* __restrict__ dirPtr, int32_t* __restrict__ dirSlot, void* __restrict__ sdfMirror,
                                                              const float* __restrict__ depth, int lazy, AllocParams p) {
   __shared__ int lds[8];
-  // (the sweep as its own launch: the count that follows is a launch of its own too, so the excess region's shared re-tests leave
-  // their verdicts in the type bytes -- share_excess_retests; the swapping build re-tests against the enlarged frustum: not shared)
-  if (lazy && !p.useSwapping && (p.bucketNum % kSweepChunk) == 0 && (int)blockIdx.x * kSweepChunk >= p.bucketNum)
-    share_excess_retests<false>((int)blockIdx.x, numChunks, visT, hash, p, nullptr, 0u);
+  // (The excess region's re-tests are NOT shared here although the idle workgroups are the same: with the count in a later launch the
+  // verdicts would have to travel in the type bytes, and after ResetScene the render state's stale types sit on EMPTY slots -- slots
+  // that this very launch may fill and mark "new", racing with the verdict's store.  Built, measured at +1 % for two or three scenes
+  // per process, and caught by the second-life test one run in twelve; removed.)
   sweep_chunk<false>((int)blockIdx.x, lds, allocKey, chunkReq, chunkReqNext, numChunks, hash, excessList, allocList, visT, counters, headBits, dirPtr, dirSlot, sdfMirror, depth, lazy, p);
 }
 
@@ -481,7 +473,7 @@ __global__ void __launch_bounds__(256) visible_list_kernel(uint8_t* __restrict__
       // the excess-region workgroups -- 63 of 64 idle -- share them before anything else, and the 64 verdicts of a group travel to the
       // chunk that owns the slots as two tagged granules {epoch, 32 "kept" bits}: one indivisible 8-byte store each, nothing to wait
       // for behind them (the look-back's idiom).  The owner's count picks its lanes' bytes out of them instead of walking (below).
-      share_excess_retests<true>(chunk, numChunks, visT, hash, p, sw.keptGran, epoch);
+      share_excess_retests(chunk, numChunks, visT, hash, p, sw.keptGran, epoch);
     }
   }
   // sums the granules of the chunks before this one, waiting for each to carry this launch's epoch

@@ -276,7 +276,10 @@ def compare_results(a: RunResult, b: RunResult, sc: Scenario, exact=True, what="
         assert np.array_equal(a.excess, b.excess), tag + "excess list"
         nv = a.counters[-1]["noVisibleEntries"]
         assert np.array_equal(a.visible_ids[:nv], b.visible_ids[:nv]), tag + "visible ids"
-        assert np.array_equal(a.visible_type, b.visible_type), tag + "visible types"
+        if not np.array_equal(a.visible_type, b.visible_type):
+            d = np.nonzero(a.visible_type != b.visible_type)[0]
+            raise AssertionError(f"{tag}visible types: {len(d)} differ, slots {d[:8].tolist()} have {a.visible_type[d[:8]].tolist()} vs {b.visible_type[d[:8]].tolist()}; "
+                                 f"entries there {a.hash[d[:4]].tolist()} vs {b.hash[d[:4]].tolist()}")
     assert np.array_equal(a.alloc_list, b.alloc_list), tag + "allocation list"
     if a.voxels is not None and b.voxels is not None:
         assert_fields_equal(a.voxels, b.voxels, tag + "voxels")

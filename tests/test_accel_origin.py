@@ -156,3 +156,40 @@ def test_uploaded_table_places_the_cubes_around_its_blocks(hip, oracle):
     assert np.array_equal(ra[..., 3], rb[..., 3]) and np.array_equal(ra[ra[..., 3] > 0], rb[rb[..., 3] > 0])
     assert np.count_nonzero(ra[..., 3] > 0) > 3000
     src.close(); dst.close(); ref.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["one launch", "sweep as its own launch", "count and compaction launches"])
+def test_stale_types_on_slots_that_the_second_life_fills_again(hip, oracle, form):
+    """A render state outlives ResetScene with its visible types (the reference's does): they now sit on EMPTY slots, and in tables this
+    small the second life's sweeps fill the very same excess slots again -- in the launch that also re-tests "previously visible" slots
+    against the frustum.  The new entry's type must win (the reference allocates before it re-tests); a verdict on the slot's old
+    content must not.  (A build whose shared re-tests wrote their verdicts into the type bytes lost this race one run in twelve.)"""
+    sc1 = T.Scenario(name="life1_tiny", w=320, h=240, voxelSize=0.01, frames=3, bucketNum=0x800, excessNum=0x1800, trajectory="yaw", yaw_rate=0.1)
+    sc2 = T.Scenario(name="life2_tiny", w=320, h=240, voxelSize=0.01, frames=3, bucketNum=0x800, excessNum=0x1800, trajectory="yaw", yaw_rate=-0.1, origin=(0.05, 0.02, -0.1))
+    key = {"one launch": None, "sweep as its own launch": 13, "count and compaction launches": 7}[form]
+
+    def lives(be):
+        ses = T.Session(be, sc1)
+        for k in range(sc1.frames):
+            ses.frame(k, fused=True)
+        ses.scene.reco.ResetScene()
+        ses.sc = sc2
+        for k in range(sc2.frames):
+            ses.frame(k, fused=True)
+        r = ses.snapshot()
+        r.counters = [ses.scene.counters(ses.rs)]
+        ses.close()
+        return r
+
+    b = lives(oracle)
+    assert (b.hash["ptr"][sc2.bucketNum:] >= 0).sum() > 500          # most blocks of the second life are excess blocks
+    if key is not None:
+        hip.check(hip.fn["debug_set"](key, 1), "debug_set")
+    try:
+        for rep in range(4):
+            T.compare_results(lives(hip), b, sc2, what=f"second life in a tiny table, {form}, run {rep}")
+    finally:
+        if key is not None:
+            hip.check(hip.fn["debug_set"](key, 0), "debug_set")
+
