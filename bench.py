@@ -207,11 +207,17 @@ class Stream:
         self.raw_dev = torch.empty((2, h, w), dtype=torch.int16, device=self.device)      # two upload slots (CPU shims; --raw-serial)
         # the product uploads through the library's stager: a copy stream of its own, one frame ahead of the frame being fused
         self.stager, self.staged = None, -1
+        self.converting, self.holding = False, False
         if self.device != "cpu" and "depth_stager_create" in self.be.fn and self.be.prefix == "itm_":
             g = C.c_void_p()
             self.ahead = max(1, int(os.environ.get("ITM_BENCH_RAW_AHEAD", "1")))
-            self.be.check(self.be.fn["depth_stager_create"](w, h, self.ahead + 2, C.byref(g)), "depth_stager_create")
-            self.stager = g
+            self.be.check(self.be.fn["depth_stager_create"](w, h, self.ahead + 3, C.byref(g)), "depth_stager_create")
+            # the copy converts as well (convertDepthAffineToFloat: the view has neither bilateral filter nor noise model): the slot's
+            # float image IS the view's depth, no conversion launch on the frame's stream; held until the next frame has been submitted
+            self.converting = "depth_stager_set_conversion" in self.be.fn
+            if self.converting:
+                self.be.check(self.be.fn["depth_stager_set_conversion"](g, 1, 0.001, 0.0, float(self.intr[0])), "depth_stager_set_conversion")
+            self.stager, self.holding = g, False
         self.depth_conv = torch.empty((h, w), dtype=torch.float32, device=self.device)
         self.scratch = torch.empty((h, w), dtype=torch.float32, device=self.device)
         self.raw_views = [self.capi.View(self.depth_conv.data_ptr(), w, h, M_d=self.poses[i], intr_d=self.intr,
@@ -372,13 +378,22 @@ def worker(args) -> int:
                 def upload(step):
                     be.check(be.fn["depth_stager_upload"](s.stager, C.c_void_p(s.raw_ptrs[step % s.nd])), "depth_stager_upload")
                     s.staged = step
+                if s.holding:                       # the previous frame's slot: everything that read its depth has been submitted
+                    be.check(be.fn["depth_stager_release"](s.stager, s.sp), "depth_stager_release")
+                    s.holding = False
                 if s.staged < k or s.staged > k + s.ahead:
                     s.staged = k - 1                # first frame of a leg (nothing of it is in flight)
                 while s.staged < k + (0 if last else s.ahead):
                     upload(s.staged + 1)            # the next frames travel while this one is fused
                 dev = C.c_void_p()
-                be.check(be.fn["depth_stager_acquire"](s.stager, s.sp, C.byref(dev)), "depth_stager_acquire")
-                raw_ptr = dev
+                if s.converting:
+                    depth_dev = C.c_void_p()
+                    be.check(be.fn["depth_stager_acquire_depth"](s.stager, s.sp, None, C.byref(depth_dev)), "depth_stager_acquire_depth")
+                    s.raw_views[i].depth = depth_dev.value
+                    s.holding = True
+                else:
+                    be.check(be.fn["depth_stager_acquire"](s.stager, s.sp, C.byref(dev)), "depth_stager_acquire")
+                    raw_ptr = dev
             else:
                 slot = s.raw_dev[k & 1]
                 if on_gpu:
@@ -387,13 +402,19 @@ def worker(args) -> int:
                 else:
                     slot.copy_(s.raw_host[i])
                 raw_ptr = C.c_void_p(slot.data_ptr())
-            rc = fn_view(raw_ptr, s.w, s.h, 1, 0.001, 0.0, s.intr_c, 0, 0, C.c_void_p(s.depth_conv.data_ptr()),
-                         C.c_void_p(s.scratch.data_ptr()), None, None, s.sp)
-            if rc:
-                be.check(rc, "update_view")
-            if s.stager is not None and not args.raw_serial:
-                be.check(be.fn["depth_stager_release"](s.stager, s.sp), "depth_stager_release")      # (the conversion is what read the slot)
-            rc = issue(s, C.byref(s.raw_views[i]), s.raw_views[i], None)       # (the converted image is ONE buffer: no frame can be announced ahead)
+            converted = s.stager is not None and not args.raw_serial and s.converting
+            if not converted:
+                s.raw_views[i].depth = s.depth_conv.data_ptr()
+                rc = fn_view(raw_ptr, s.w, s.h, 1, 0.001, 0.0, s.intr_c, 0, 0, C.c_void_p(s.depth_conv.data_ptr()),
+                             C.c_void_p(s.scratch.data_ptr()), None, None, s.sp)
+                if rc:
+                    be.check(rc, "update_view")
+                if s.stager is not None and not args.raw_serial:
+                    be.check(be.fn["depth_stager_release"](s.stager, s.sp), "depth_stager_release")      # (the conversion is what read the slot)
+            rc = issue(s, C.byref(s.raw_views[i]), s.raw_views[i], None)       # (no frame can be announced ahead: its depth image does not exist yet)
+            if converted and last and not rc:          # the leg ends here: nothing stays held across legs
+                be.check(be.fn["depth_stager_release"](s.stager, s.sp), "depth_stager_release")
+                s.holding = False
         else:
             # the last frame of a run() names no successor: the next leg may start anywhere
             rc = issue(s, C.byref(s.views[i]), s.views[i], (None if last else s.views[(k + 1) % s.nd]))
@@ -584,7 +605,7 @@ def worker(args) -> int:
         dt = time.perf_counter() - t1
         mode["raw"] = False
         extra["with_h2d_raw_depth"] = {"value": round(n2 / dt, 2), "unit": "frames/s", "steps": n2,
-                                       "what": f"per frame {wl['w'] * wl['h'] * 2} bytes of raw short depth from pinned host memory over PCIe (itm_depth_stager: a copy stream, one frame ahead) + itm_update_view (affine conversion) + the same fused frame"}
+                                       "what": f"per frame {wl['w'] * wl['h'] * 2} bytes of raw short depth from pinned host memory over PCIe (itm_depth_stager: a copy stream, one frame ahead; the copy kernel also does convertDepthAffineToFloat -- itm_update_view's work for a view without filter and noise model -- so the slot's float image is the view's depth) + the same fused frame"}
         # (2) the same roofline kernel when the acceleration structures (block directory, sdf mirror) do not answer -- blocks whose
         #     cells are owned by other blocks, or a device without room for them -- i.e. on the reference's own table walk
         if wl["index"] == "hash":

@@ -344,6 +344,14 @@ int ITM_FN(depth_stager_acquire)(itm_depth_stager* g, itm_stream stream, const i
  * synchronised.  *waiting = uploaded frames not acquired yet.  Either pointer may be NULL. */
 int ITM_FN(depth_stager_pending)(itm_depth_stager* g, int* waiting, int* busy);
 int ITM_FN(depth_stager_release)(itm_depth_stager* g, itm_stream stream);
+/* The copy may also CONVERT: after itm_depth_stager_set_conversion (calibType, c0, c1 and fx = intr_d[0] as in itm_update_view; call it
+ * while no frame waits in the ring) every uploaded frame is also turned into the float depth image of itm_update_view's first step
+ * (convertDisparityToDepth / convertDepthAffineToFloat, DeviceAgnostic/ITMViewBuilder.h:7-28) by the copy itself, and
+ * itm_depth_stager_acquire_depth hands out that image (and, if asked, the raw one) instead of itm_depth_stager_acquire.  For a view
+ * without bilateral filter and noise model it IS view->depth -- no conversion launch on the frame's stream --; it stays valid until
+ * the release, which therefore comes after the LAST launch that reads the frame's depth. */
+int ITM_FN(depth_stager_set_conversion)(itm_depth_stager* g, int calibType, float c0, float c1, float fx);
+int ITM_FN(depth_stager_acquire_depth)(itm_depth_stager* g, itm_stream stream, const int16_t** raw_image, const float** depth_image);
 
 /* ---- on-disk input formats of the view builder's sources (host memory, no device work) -------------------------
  * Depth: PGM "P5" (or ASCII "P2") with maxval > 256: 16-bit samples stored BIG-endian, swapped on load

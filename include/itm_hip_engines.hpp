@@ -312,9 +312,12 @@ class ITMViewBuilder_HIP {
   }
   void UpdateViewFromHost(ITMView* view, const int16_t* rawDepthHost, float* depth, float* scratch, bool useBilateralFilter,
                           bool modelSensorNoise = false, float* depthNormal = nullptr, float* depthUncertainty = nullptr) {
-    if (stager && prefetched != rawDepthHost) {
-      // frames uploaded ahead that are not the one asked for (the image source changed its mind): taken off the ring unread, else the
-      // stager -- strictly first in, first out -- would hand the stale frame to this call and stay one frame behind from then on
+    // the slot of the PREVIOUS frame: everything that read its depth has been submitted to the stream by now
+    if (holding) { check(itm_depth_stager_release(stager, stream), "UpdateView (release)"); holding = false; }
+    // without filter and noise model the float depth is the conversion alone: the stager's copy does it (itm_depth_stager_set_conversion)
+    // and the view's depth is the slot's image -- no conversion launch on the frame's stream
+    const bool plain = !useBilateralFilter && !modelSensorNoise;
+    auto discard_waiting = [&]() {
       int waiting = 0;
       check(itm_depth_stager_pending(stager, &waiting, nullptr), "UpdateView (pending)");
       for (; waiting > 0; --waiting) {
@@ -322,9 +325,25 @@ class ITMViewBuilder_HIP {
         check(itm_depth_stager_acquire(stager, stream, &stale), "UpdateView (discard)");
         check(itm_depth_stager_release(stager, stream), "UpdateView (discard)");
       }
+      prefetched = nullptr;
+    };
+    if (!stager) check(itm_depth_stager_create(view->depthSize.x, view->depthSize.y, 4, &stager), "depth stager");
+    // frames uploaded ahead that are not the one asked for (the image source changed its mind), or uploaded in the other form: taken off
+    // the ring unread, else the stager -- strictly first in, first out -- would hand the stale frame to this call and stay one frame behind
+    if (prefetched != rawDepthHost || plain != converting) discard_waiting();
+    if (plain != converting) {
+      if (plain) check(itm_depth_stager_set_conversion(stager, calibType, c0, c1, calib->intrinsics_d.all[0]), "depth stager (conversion)");
+      converting = plain;
     }
     if (prefetched != rawDepthHost) Prefetch(rawDepthHost, view->depthSize);
     prefetched = nullptr;
+    if (plain) {
+      const float* converted = nullptr;
+      check(itm_depth_stager_acquire_depth(stager, stream, nullptr, &converted), "UpdateView (acquire)");
+      view->depth = converted;
+      holding = true;           // released by the next call: the frame's launches read it
+      return;
+    }
     const int16_t* raw = nullptr;
     check(itm_depth_stager_acquire(stager, stream, &raw), "UpdateView (acquire)");
     UpdateView(view, raw, depth, scratch, useBilateralFilter, modelSensorNoise, depthNormal, depthUncertainty);
@@ -345,6 +364,7 @@ class ITMViewBuilder_HIP {
  private:
   itm_depth_stager* stager = nullptr;
   const int16_t* prefetched = nullptr;
+  bool converting = false, holding = false;
 };
 
 // ITMDepthTracker (Engine/ITMDepthTracker.h): TrackCamera refines trackingState->pose_d against the ICP maps

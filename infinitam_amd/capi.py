@@ -248,6 +248,8 @@ _HOST_IO_SIGS = {
     "depth_stager_upload": (C.c_int, [_P, _P]),
     "depth_stager_acquire": (C.c_int, [_P, _P, C.POINTER(_P)]),
     "depth_stager_release": (C.c_int, [_P, _P]),
+    "depth_stager_set_conversion": (C.c_int, [_P, C.c_int, C.c_float, C.c_float, C.c_float]),
+    "depth_stager_acquire_depth": (C.c_int, [_P, _P, C.POINTER(_P), C.POINTER(_P)]),
     "depth_stager_pending": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "stream_create": (C.c_int, [C.POINTER(_P)]),
     "stream_destroy": (C.c_int, [_P]),

@@ -150,9 +150,44 @@ int itm_update_view(const int16_t* raw, int w, int h, int calibType, float c0, f
 
 }  // extern "C"
 namespace itm {
-__global__ void __launch_bounds__(256) stage_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) dst[i] = src[i];
+// The copy of a raw frame from mapped page-locked host memory, by a kernel on the stager's copy stream.  SIXTEEN workgroups with eight
+// 16-byte loads in flight per lane, not a lane per 16 bytes: 150 workgroups' worth of PCIe reads issued at once slowed the frame they
+// run beside -- the ray cast's latency-bound tail, 36 -> 47 us while the copy was in flight (rocprofv3 trace of main_engine_demo
+// --bench-map-host) -- frames from host memory 9.94 k -> 10.6-11.1 k frames/s with 8-24 workgroups (4: the copy itself becomes the bound).
+constexpr int kStageWorkgroups = 16;
+// convertDepthAffineToFloat / convertDisparityToDepth (DeviceAgnostic/ITMViewBuilder.h:7-28): the operations of depth_affine_kernel /
+// depth_disparity_kernel (scene.hip)
+__device__ inline float stage_convert(int16_t raw, int calibType, float c0, float c1, float fx) {
+  if (calibType == 1) return ((raw <= 0) || (raw > 32000)) ? -1.0f : (float)raw * c0 + c1;
+  const float t = c0 - (float)raw;
+  float depth;
+  if (t == 0) depth = 0.0f; else depth = 8.0f * c1 * fx / t;
+  return (depth > 0) ? depth : -1.0f;
+}
+// CONVERT: the float depth image of itm_update_view's first step is written beside the raw copy (8 shorts -> 8 floats per 16 bytes read)
+template <bool CONVERT>
+__global__ void __launch_bounds__(256) stage_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n, float4* __restrict__ depth,
+                                                         int calibType, float c0, float c1, float fx) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += 8 * stride) {
+    uint4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const size_t i = i0 + k * stride; v[k] = src[i < n ? i : i0]; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const size_t i = i0 + k * stride;
+      if (i >= n) continue;
+      dst[i] = v[k];
+      if constexpr (CONVERT) {
+        const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = stage_convert((int16_t)((w[j >> 1] >> ((j & 1) * 16)) & 0xffffu), calibType, c0, c1, fx);
+        depth[2 * i] = make_float4(f[0], f[1], f[2], f[3]);
+        depth[2 * i + 1] = make_float4(f[4], f[5], f[6], f[7]);
+      }
+    }
+  }
 }
 }  // namespace itm
 extern "C" {
@@ -167,6 +202,8 @@ struct itm_depth_stager {
   int device = 0;
   hipStream_t copy = nullptr;
   std::vector<int16_t*> buf;
+  std::vector<float*> depth;                  // per slot, once a conversion has been set: the float depth image of the slot's frame
+  int calibType = -1; float c0 = 0, c1 = 0, fx = 0;
   std::vector<hipEvent_t> uploaded, consumed;
   // one thread may upload while another acquires / releases (a producer beside the frame loop): the counters both sides read are atomic
   std::unique_ptr<std::atomic<char>[]> consumedRecorded;
@@ -180,6 +217,7 @@ static void free_stager(itm_depth_stager* g) {
   for (auto e : g->uploaded) if (e) (void)hipEventDestroy(e);
   for (auto e : g->consumed) if (e) (void)hipEventDestroy(e);
   for (auto b : g->buf) if (b) (void)hipFree(b);
+  for (auto b : g->depth) if (b) (void)hipFree(b);
   delete g;
 }
 
@@ -241,11 +279,17 @@ int itm_depth_stager_upload(itm_depth_stager* g, const int16_t* host) {
   void* mapped = nullptr;
   if (hipHostGetDevicePointer(&mapped, (void*)host, 0) == hipSuccess && mapped && (bytes % 16) == 0 && ((uintptr_t)mapped % 16) == 0) {
     const size_t n = bytes / 16;
-    stage_copy_kernel<<<(unsigned)((n + 255) / 256), 256, 0, g->copy>>>((const uint4*)mapped, (uint4*)g->buf[b], n);
+    if (g->calibType >= 0) stage_copy_kernel<true><<<kStageWorkgroups, 256, 0, g->copy>>>((const uint4*)mapped, (uint4*)g->buf[b], n, (float4*)g->depth[b], g->calibType, g->c0, g->c1, g->fx);
+    else stage_copy_kernel<false><<<kStageWorkgroups, 256, 0, g->copy>>>((const uint4*)mapped, (uint4*)g->buf[b], n, nullptr, 0, 0.0f, 0.0f, 0.0f);
     ITM_LAUNCH_CHECK();
   } else {
     (void)hipGetLastError();                  // pageable memory: the runtime's staged copy
     ITM_HIP(hipMemcpyAsync(g->buf[b], host, bytes, hipMemcpyHostToDevice, g->copy));
+    if (g->calibType >= 0) {
+      const int rc = g->calibType == 0 ? itm_convert_disparity(g->buf[b], g->depth[b], g->w, g->h, g->c0, g->c1, g->fx, (itm_stream)g->copy)
+                                       : itm_convert_depth_affine(g->buf[b], g->depth[b], g->w, g->h, g->c0, g->c1, (itm_stream)g->copy);
+      if (rc) return rc;
+    }
   }
   ITM_HIP(hipEventRecord(g->uploaded[b], g->copy));
   g->tail.store(tail + 1, std::memory_order_release);
@@ -269,18 +313,65 @@ int itm_depth_stager_pending(itm_depth_stager* g, int* waiting, int* busy) {
   return ITM_OK;
 }
 
+// From the next upload on the copy also CONVERTS: every slot gets a float image, written by the copy kernel itself with the operations of
+// itm_update_view's first step (calibType 0: disparity, c0 / c1 / fx; 1: affine, c0 * raw + c1).  For a view without bilateral filter and
+// noise model that image IS the view's depth: no conversion launch on the frame's stream.  Call before the first upload (or with the ring
+// empty): frames already uploaded have no float image.
+int itm_depth_stager_set_conversion(itm_depth_stager* g, int calibType, float c0, float c1, float fx) {
+  if (!g || (calibType != 0 && calibType != 1)) return set_error(ITM_ERR_INVALID, "bad argument");
+  if (g->tail.load(std::memory_order_acquire) != g->head.load(std::memory_order_acquire)) return set_error(ITM_ERR_INVALID, "frames are waiting in the ring");
+  if (g->depth.empty()) {
+    g->depth.assign(g->slots, nullptr);
+    for (int i = 0; i < g->slots; ++i) ITM_HIP(hipMalloc((void**)&g->depth[i], (size_t)g->w * g->h * sizeof(float)));
+  }
+  g->calibType = calibType; g->c0 = c0; g->c1 = c1; g->fx = fx;
+  return ITM_OK;
+}
+
+static int acquire_slot(itm_depth_stager* g, itm_stream stream, int* slot);
+int itm_depth_stager_acquire_depth(itm_depth_stager* g, itm_stream stream, const int16_t** raw, const float** depth) {
+  if (!g || !depth) return set_error(ITM_ERR_INVALID, "null argument");
+  if (g->calibType < 0) return set_error(ITM_ERR_INVALID, "no conversion has been set (itm_depth_stager_set_conversion)");
+  int b = 0;
+  const int rc = acquire_slot(g, stream, &b);
+  if (rc) return rc;
+  if (raw) *raw = g->buf[b];
+  *depth = g->depth[b];
+  return ITM_OK;
+}
+
 int itm_depth_stager_acquire(itm_depth_stager* g, itm_stream stream, const int16_t** dev) {
   if (!g || !dev) return set_error(ITM_ERR_INVALID, "null argument");
+  int b = 0;
+  const int rc = acquire_slot(g, stream, &b);
+  if (rc) return rc;
+  *dev = g->buf[b];
+  return ITM_OK;
+}
+
+static int acquire_slot(itm_depth_stager* g, itm_stream stream, int* slot) {
   if (g->held) return set_error(ITM_ERR_INVALID, "the previous frame has not been released");
   const unsigned long long head = g->head.load(std::memory_order_relaxed);
   if (head == g->tail.load(std::memory_order_acquire)) return set_error(ITM_ERR_INVALID, "no uploaded frame is waiting");
   const int b = (int)(head % (unsigned long long)g->slots);
   // with the uploads a frame ahead the copy has normally finished: then the frame's stream needs no dependency on the copy stream at all
   // (a cross-stream wait is ~3-4 us of stream time even when it is satisfied at once); a query is a host-side load
-  const hipError_t q = hipEventQuery(g->uploaded[b]);
-  if (q == hipErrorNotReady) ITM_HIP(hipStreamWaitEvent(as_stream(stream), g->uploaded[b], 0));
-  else if (q != hipSuccess) return hip_fail(q, "hipEventQuery(upload)", __FILE__, __LINE__);
-  *dev = g->buf[b];
+  // A host that runs ahead of the device gets here while the copy is still in flight (it was launched one submission ago and takes
+  // ~25 us): it polls for a moment -- the device has frames queued, the host's wait costs it nothing -- rather than put a wait packet
+  // on the frame's stream (5-6 us between icp_maps and the next frame's first kernel in rocprofv3's trace).  A copy that takes longer
+  // than that (its slot's previous reader has not run yet) is left to the stream.
+  hipError_t q = hipEventQuery(g->uploaded[b]);
+  if (q == hipErrorNotReady) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0; q == hipErrorNotReady; ++spins) {
+      if ((spins & 0x3fu) == 0x3fu && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 150e-6) break;
+      __builtin_ia32_pause();
+      q = hipEventQuery(g->uploaded[b]);
+    }
+    if (q == hipErrorNotReady) { ITM_HIP(hipStreamWaitEvent(as_stream(stream), g->uploaded[b], 0)); q = hipSuccess; }
+  }
+  if (q != hipSuccess) return hip_fail(q, "hipEventQuery(upload)", __FILE__, __LINE__);
+  *slot = b;
   g->held = true;
   return ITM_OK;
 }
@@ -290,6 +381,13 @@ int itm_depth_stager_release(itm_depth_stager* g, itm_stream stream) {
   if (!g->held) return set_error(ITM_ERR_INVALID, "no frame is held");
   const unsigned long long head = g->head.load(std::memory_order_relaxed);
   const int b = (int)(head % (unsigned long long)g->slots);
+  // "everything submitted so far read it": engine calls that were only RECORDED with this slot's image as their view's depth (pending.hip:
+  // a frame whose CreateICPMaps has not come) are launched first, so that the event below lies behind them
+  {
+    int rc = flush_overlapping(g->buf[b], (size_t)g->w * g->h * sizeof(int16_t), as_stream(stream));
+    if (!rc && !g->depth.empty()) rc = flush_overlapping(g->depth[b], (size_t)g->w * g->h * sizeof(float), as_stream(stream));
+    if (rc) return rc;
+  }
   ITM_HIP(hipEventRecord(g->consumed[b], as_stream(stream)));
   g->consumedRecorded[b].store(1, std::memory_order_release);
   g->held = false;

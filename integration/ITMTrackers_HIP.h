@@ -90,6 +90,7 @@ class ITMViewBuilder_HIP : public ITMViewBuilder {
   void* devRaw = nullptr; void* devA = nullptr; void* devB = nullptr; void* devN = nullptr; void* devS = nullptr;
   void* pinnedRaw = nullptr;
   itm_depth_stager* rawRing = nullptr; int ringW = 0, ringH = 0;
+  bool ringPlain = false, rawHeld = false; int ringCalib = -1; float ringC0 = 0, ringC1 = 0, ringFx = 0;
   size_t pixels = 0;
   void Ensure(size_t px) {
     if (px == pixels) return;
@@ -150,25 +151,46 @@ class ITMViewBuilder_HIP : public ITMViewBuilder {
     // stream, and the host waits only until the copy has READ the image source's buffer -- which the source reuses for the next frame
     // (the reference's CUDA view builder copies synchronously here, ITMViewBuilder_CUDA.cu:53)
     int16_t* rawHost = rawDepthImage->GetData(MEMORYDEVICE_CPU);
-    if (!rawRing || ringW != w || ringH != h) {
+    const ITMDisparityCalib& dc = view->calib->disparityCalib;
+    const int calibType = dc.type == ITMDisparityCalib::TRAFO_KINECT ? 0 : 1;
+    const float fx = view->calib->intrinsics_d.projectionParamsSimple.all.x;
+    // without filter and noise model the float depth is the conversion alone: the ring's copy does it too (itm_depth_stager_set_conversion)
+    // and the slot's float image becomes the view's device stage -- no conversion launch on the frame's stream
+    const bool plain = !useBilateralFilter && !modelSensorNoise;
+    if (rawHeld) { HipCheck(itm_depth_stager_release(rawRing, 0), "raw ring release"); rawHeld = false; }      // the previous frame's slot: its readers have been submitted
+    if (!rawRing || ringW != w || ringH != h || ringPlain != plain || (plain && (ringCalib != calibType || ringC0 != dc.params.x || ringC1 != dc.params.y || ringFx != fx))) {
       if (rawRing) { itm_stream_synchronize(0); itm_depth_stager_destroy(rawRing); }
-      HipCheck(itm_depth_stager_create(w, h, 4, &rawRing), "raw ring"); ringW = w; ringH = h;
+      HipCheck(itm_depth_stager_create(w, h, 4, &rawRing), "raw ring"); ringW = w; ringH = h; ringPlain = plain;
+      if (plain) {
+        HipCheck(itm_depth_stager_set_conversion(rawRing, calibType, dc.params.x, dc.params.y, fx), "raw ring conversion");
+        ringCalib = calibType; ringC0 = dc.params.x; ringC1 = dc.params.y; ringFx = fx;
+      }
     }
     HipPin(pinnedRaw, rawHost, px * 2);
     HipCheck(itm_depth_stager_upload(rawRing, rawHost), "raw ring upload");
     for (int busy = 1; busy;) HipCheck(itm_depth_stager_pending(rawRing, nullptr, &busy), "raw ring pending");
+    if (plain) {
+      const float* converted = nullptr;
+      HipCheck(itm_depth_stager_acquire_depth(rawRing, 0, nullptr, &converted), "raw ring acquire");
+      rawHeld = true;
+      HipRegistry::Stage& st = HipStageOf(view);
+      if (st.holding) { HipCheck(itm_depth_stager_release(st.ring, 0), "depth ring release"); st.holding = false; }      // (a view that used to be staged from the host)
+      HipMarkViewUpdated(view);
+      st.depthStaged = st.generation; st.hostDepthStale = true; st.cur = converted;
+      if (HipEager()) HipSyncViewToHost(view);
+      return;
+    }
     const int16_t* rawDev = nullptr;
     HipCheck(itm_depth_stager_acquire(rawRing, 0, &rawDev), "raw ring acquire");
     if (modelSensorNoise) {
       HipCheck(itm_memcpy_h2d(devN, view->depthNormal->GetData(MEMORYDEVICE_CPU), px * 16, 0), "memcpy_h2d");
       HipCheck(itm_memcpy_h2d(devS, view->depthUncertainty->GetData(MEMORYDEVICE_CPU), px * 4, 0), "memcpy_h2d");
     }
-    const ITMDisparityCalib& dc = view->calib->disparityCalib;
     // the float depth is written straight into the view's device stage: the engine calls of this frame find it there (no float
     // image crosses PCIe towards the device), the host image follows now or on request (HipSyncViewToHost)
     HipRegistry::Stage& st = HipStageOf(view);
     if (st.holding) { HipCheck(itm_depth_stager_release(st.ring, 0), "depth ring release"); st.holding = false; }      // (a view that used to be staged from the host)
-    HipCheck(itm_update_view(rawDev, w, h, dc.type == ITMDisparityCalib::TRAFO_KINECT ? 0 : 1, dc.params.x, dc.params.y,
+    HipCheck(itm_update_view(rawDev, w, h, calibType, dc.params.x, dc.params.y,
                              &view->calib->intrinsics_d.projectionParamsSimple.all.x, useBilateralFilter ? 1 : 0, modelSensorNoise ? 1 : 0,
                              (float*)st.depth, (float*)devB, (float*)devN, (float*)devS, 0), "UpdateView");
     HipCheck(itm_depth_stager_release(rawRing, 0), "raw ring release");      // the conversion is what read the slot
