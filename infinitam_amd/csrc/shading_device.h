@@ -40,12 +40,13 @@ __device__ inline uchar4 grey_pixel(float angle) {  // drawPixelGrey
   return make_uchar4(g, g, g, g);
 }
 
-// computeNormalAndAngle<useSmoothing = true> (DeviceAgnostic/ITMVisualisationEngine.h:191-254)
-__device__ inline bool normal_from_hits(const float4* __restrict__ rays, int x, int y, int W, int H, float voxelSize,
-                                        float lx, float ly, float lz, float& nx, float& ny, float& nz, float& angle) {
+// computeNormalAndAngle<useSmoothing = true> (DeviceAgnostic/ITMVisualisationEngine.h:191-254); `at(x, y)` returns the ray-cast result of a pixel
+template <class AT>
+__device__ inline bool normal_from_hits_at(AT&& at, int x, int y, int W, int H, float voxelSize,
+                                           float lx, float ly, float lz, float& nx, float& ny, float& nz, float& angle) {
   if (y <= 2 || y >= H - 3 || x <= 2 || x >= W - 3) return false;
-  float4 xp = rays[(x + 2) + y * W], yp = rays[x + (y + 2) * W];
-  float4 xm = rays[(x - 2) + y * W], ym = rays[x + (y - 2) * W];
+  float4 xp = at(x + 2, y), yp = at(x, y + 2);
+  float4 xm = at(x - 2, y), ym = at(x, y - 2);
   float dxx = 0, dxy = 0, dxz = 0, dyx = 0, dyy = 0, dyz = 0;
   bool plus1 = false;
   if (xp.w <= 0 || yp.w <= 0 || xm.w <= 0 || ym.w <= 0) plus1 = true;
@@ -57,8 +58,8 @@ __device__ inline bool normal_from_hits(const float4* __restrict__ rays, int x, 
     if (l * voxelSize * voxelSize > (0.15f * 0.15f)) plus1 = true;
   }
   if (plus1) {
-    xp = rays[(x + 1) + y * W]; yp = rays[x + (y + 1) * W];
-    xm = rays[(x - 1) + y * W]; ym = rays[x + (y - 1) * W];
+    xp = at(x + 1, y); yp = at(x, y + 1);
+    xm = at(x - 1, y); ym = at(x, y - 1);
     dxx = xp.x - xm.x; dxy = xp.y - xm.y; dxz = xp.z - xm.z;
     dyx = yp.x - ym.x; dyy = yp.y - ym.y; dyz = yp.z - ym.z;
     if (xp.w <= 0 || yp.w <= 0 || xm.w <= 0 || ym.w <= 0) return false;
@@ -70,6 +71,10 @@ __device__ inline bool normal_from_hits(const float4* __restrict__ rays, int x, 
   nx *= sc; ny *= sc; nz *= sc;
   angle = nx * lx + ny * ly + nz * lz;
   return angle > 0.0f;
+}
+__device__ inline bool normal_from_hits(const float4* __restrict__ rays, int x, int y, int W, int H, float voxelSize,
+                                        float lx, float ly, float lz, float& nx, float& ny, float& nz, float& angle) {
+  return normal_from_hits_at([&](int qx, int qy) { return rays[qx + qy * W]; }, x, y, W, H, voxelSize, lx, ly, lz, nx, ny, nz, angle);
 }
 
 template <class VX, bool DENSE>

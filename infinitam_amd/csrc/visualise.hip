@@ -473,17 +473,33 @@ int launch_raycast(const itm_scene* s, const float* invM, const float* intr, itm
 __device__ inline void nt_store(float4* p, float4 v) { __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y); __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w); }
 __device__ inline void nt_store(uchar4* p, uchar4 v) { __builtin_nontemporal_store(*(unsigned int*)&v, (unsigned int*)p); }
 
+// A workgroup = one 16x16 tile (wave = 16x4 pixels, as the ray tiles).  The normal of a pixel is made of hits one or two pixels away in
+// x and y: the tile and its plus-shaped halo (16x16 + 4 strips of 2x16) are staged in LDS with one round of coalesced loads, instead of
+// a centre load followed by four (and often four more) dependent gathers per lane.
 __global__ void __launch_bounds__(256) icp_maps_kernel(const float4* __restrict__ rays, float4* __restrict__ points,
                                                        float4* __restrict__ normals, uchar4* __restrict__ image, RayParams p) {
+  __shared__ float4 hits[20][20];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int x = blockIdx.x * 16 + (lane & 15);
-  const int y = blockIdx.y * 16 + wave * 4 + (lane >> 4);
-  if (x >= p.W || y >= p.H) return;
+  const int lx = lane & 15, ly = wave * 4 + (lane >> 4);
+  const int x = blockIdx.x * 16 + lx, y = blockIdx.y * 16 + ly;
+  const bool inside = x < p.W && y < p.H;
+  if (inside) hits[2 + ly][2 + lx] = rays[x + y * p.W];
+  if (threadIdx.x < 128) {
+    const int strip = threadIdx.x >> 5, k = threadIdx.x & 31;      // 0 left, 1 right, 2 above, 3 below; 2 x 16 pixels each
+    int hx, hy;
+    if (strip < 2) { hx = strip == 0 ? (k & 1) : 18 + (k & 1); hy = 2 + (k >> 1); }
+    else { hy = strip == 2 ? (k & 1) : 18 + (k & 1); hx = 2 + (k >> 1); }
+    const int gx = (int)blockIdx.x * 16 + hx - 2, gy = (int)blockIdx.y * 16 + hy - 2;
+    if (gx >= 0 && gx < p.W && gy >= 0 && gy < p.H) hits[hy][hx] = rays[gx + gy * p.W];
+  }
+  __syncthreads();
+  if (!inside) return;
   const int loc = x + y * p.W;
-  const float4 r = rays[loc];
+  const float4 r = hits[2 + ly][2 + lx];
   bool found = r.w > 0.0f;
   float nx = 0, ny = 0, nz = 0, angle = 0;
-  if (found) found = normal_from_hits(rays, x, y, p.W, p.H, p.voxelSize, p.lx, p.ly, p.lz, nx, ny, nz, angle);
+  const int ox = (int)blockIdx.x * 16 - 2, oy = (int)blockIdx.y * 16 - 2;
+  if (found) found = normal_from_hits_at([&](int qx, int qy) { return hits[qy - oy][qx - ox]; }, x, y, p.W, p.H, p.voxelSize, p.lx, p.ly, p.lz, nx, ny, nz, angle);
   if (found) {
     nt_store(&image[loc], grey_pixel(angle));
     nt_store(&points[loc], make_float4(r.x * p.voxelSize, r.y * p.voxelSize, r.z * p.voxelSize, 1.0f));
