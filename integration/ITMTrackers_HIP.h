@@ -156,7 +156,8 @@ class ITMViewBuilder_HIP : public ITMViewBuilder {
     const float fx = view->calib->intrinsics_d.projectionParamsSimple.all.x;
     // without filter and noise model the float depth is the conversion alone: the ring's copy does it too (itm_depth_stager_set_conversion)
     // and the slot's float image becomes the view's device stage -- no conversion launch on the frame's stream.  (The stage then lives
-    // in this builder's ring: HipReleaseView / the last use of the view come before the builder is deleted, as in ITMMainEngine's destructor.)
+    // in this builder's ring: no engine call may use the view after its builder has been deleted.  ITMMainEngine's destructor -- builder,
+    // then view, Engine/ITMMainEngine.cpp:86-89 -- is fine: nothing reads the stage in between, HipReleaseView only frees what it owns.)
     const bool plain = !useBilateralFilter && !modelSensorNoise;
     if (rawHeld) { HipCheck(itm_depth_stager_release(rawRing, 0), "raw ring release"); rawHeld = false; }      // the previous frame's slot: its readers have been submitted
     if (!rawRing || ringW != w || ringH != h || ringPlain != plain || (plain && (ringCalib != calibType || ringC0 != dc.params.x || ringC1 != dc.params.y || ringFx != fx))) {
