@@ -126,6 +126,21 @@ __device__ inline float fuse_depth(typename VX::Reg& r, float mx, float my, floa
   return fuse_depth_update<VX>(r, depth[pix], pcz, p, touched);
 }
 
+// The colour update's condition, !(eta > mu || fabs(eta / mu) > 0.25) (DeviceAgnostic/ITMSceneReconstructionEngine.h:127-131), without the
+// IEEE division macro on the common path: for eta < -mu the correctly rounded quotient is <= -1 (division is monotone), so the voxel
+// is outside the band whatever eta is (-inf included); for eta in [-mu, mu] the Markstein quotient is the correctly rounded one
+// whenever it is a normal number, and both are far below 0.25 when it is not; a NaN eta passes every comparison as it does in the
+// reference.  (Round 6: ~10 vector instructions less per voxel of the colour kernels.)
+__device__ inline bool in_colour_band(float eta, const FuseParams& p) {
+  if (eta < -p.mu || eta > p.mu) return false;
+#if ITM_FAST_DIVISIONS
+  const float q = p.muFast ? div_markstein(eta, p.mu, p.rcpMu) : eta / p.mu;
+#else
+  const float q = eta / p.mu;
+#endif
+  return !(fabsf(q) > 0.25f);
+}
+
 __device__ inline float round_half_away(float x) { return (x < 0) ? (x - 0.5f) : (x + 0.5f); }
 
 template <class VX>
@@ -149,12 +164,12 @@ __device__ inline void fuse_colour(typename VX::Reg& r, float mx, float my, floa
   if ((u < 1) || (u > p.Wc - 2) || (v < 1) || (v > p.Hc - 2)) return;
   const int px = (int)floorf(u), py = (int)floorf(v);
   const float dx = u - (float)px, dy = v - (float)py;
-  const uchar4 zero = make_uchar4(0, 0, 0, 0);
-  const uchar4 A = rgb[px + py * p.Wc];
-  uchar4 B = zero, C = zero, D = zero;
-  if (dx != 0) B = rgb[(px + 1) + py * p.Wc];
-  if (dy != 0) C = rgb[px + (py + 1) * p.Wc];
-  if (dx != 0 && dy != 0) D = rgb[(px + 1) + (py + 1) * p.Wc];
+  // interpolateBilinear (DeviceAgnostic/ITMPixelUtils.h:11-39) fetches b, c, d only when their weight is not zero and uses 0 otherwise.
+  // All four taps are inside the image here (1 <= u <= Wc - 2, 1 <= v <= Hc - 2), and a finite channel value times a zero weight is
+  // the same +0 the reference adds: fetching the four unconditionally is bit-identical and ONE round trip instead of three
+  // dependent ones (until round 6 each conditional tap sat in its own branch behind a wait of its own).
+  const uchar4* __restrict__ row = rgb + (size_t)py * p.Wc + px;
+  const uchar4 A = row[0], B = row[1], C = row[p.Wc], D = row[p.Wc + 1];
   const float a4[3] = {(float)A.x, (float)A.y, (float)A.z}, b4[3] = {(float)B.x, (float)B.y, (float)B.z};
   const float c4[3] = {(float)C.x, (float)C.y, (float)C.z}, d4[3] = {(float)D.x, (float)D.y, (float)D.z};
   float newW = oldW + 1.0f;
@@ -193,7 +208,7 @@ __device__ inline bool fuse_voxel(typename VX::Reg& r, float mx, float my, float
   bool touched = false;
   const float eta = fuse_depth<VX>(r, mx, my, mz, depth, p, touched);
   if constexpr (VX::kColor) {
-    if (!((eta > p.mu) || (fabsf(eta / p.mu) > 0.25f))) {
+    if (in_colour_band(eta, p)) {
       fuse_colour<VX>(r, mx, my, mz, rgb, p);
       touched = true;
     }
@@ -251,26 +266,32 @@ __device__ inline void integrate_item(const HashEntry& he, int z0, int lane, typ
   if constexpr (VX::kShort || ITM_MIRROR_FLOAT_TYPES) {
     if (sdfMirror && mirror_block_base<false>(p.org, he.px, he.py, he.pz, mbase)) mirror = (typename MC::T*)sdfMirror;
   }
-  // stage 1: project every slice's voxel; stage 2: all depth pixels together; stage 3: update (+ colour), store what changed
+  // stage 1: project every slice's voxel; stage 2: all depth pixels together; stage 3: update (+ colour), store what changed.
+  // Stages 1 and 2 do not look at the voxels: the item's runs (requested by the caller) are still on their way while the wave projects
+  // and gathers, and the first wait for them stands in front of stage 3.  (Until round 6 the stopIntegratingAtMaxW test -- which reads
+  // the voxel's weight -- stood in front of the projection: the compiler's s_waitcnt for run k preceded the projection of slice k, so a
+  // wave idled through the voxels' round trip and then through the depth pixels' instead of through the longer of the two.)
   int pix[kSlices];
   float pcz[kSlices], mz[kSlices];
 #pragma unroll
   for (int k = 0; k < kSlices; ++k) {
     mz[k] = (float)(he.pz * kBlockSide + z0 + k) * p.voxelSize;
-    pix[k] = -2;                                                            // -2: voxel skipped altogether (no block / stopIntegratingAtMaxW)
-    if (!present || (p.stopAtMax && VX::w_depth(r[k]) == p.maxW)) continue;
-    pix[k] = fuse_depth_project(mx, my, mz[k], p, pcz[k]);
+    pix[k] = present ? fuse_depth_project(mx, my, mz[k], p, pcz[k]) : -2;     // -2: no block
   }
   float dm[kSlices];
 #pragma unroll
   for (int k = 0; k < kSlices; ++k) dm[k] = depth[pix[k] >= 0 ? pix[k] : 0];
+  // every gather is issued HERE, before the first look at a voxel (left alone the compiler sinks the gather of a slice into that slice's
+  // conditional update, behind the wait for the slice's voxels)
+#pragma unroll
+  for (int k = 0; k < kSlices; ++k) asm volatile("" : "+v"(dm[k]));
 #pragma unroll
   for (int k = 0; k < kSlices; ++k) {
-    if (pix[k] == -2) continue;
+    if (pix[k] == -2 || (p.stopAtMax && VX::w_depth(r[k]) == p.maxW)) continue;      // (a saturated voxel is skipped altogether, colour included)
     bool touched = false;
     const float eta = (pix[k] >= 0) ? fuse_depth_update<VX>(r[k], dm[k], pcz[k], p, touched) : -1.0f;
     if constexpr (VX::kColor) {
-      if (!((eta > p.mu) || (fabsf(eta / p.mu) > 0.25f))) {
+      if (in_colour_band(eta, p)) {
         fuse_colour<VX>(r[k], mx, my, mz[k], rgb, p);
         touched = true;
       }
@@ -310,8 +331,16 @@ __device__ inline void integrate_hash_body(int wgIdx, int wgCount, const int32_t
   }
 }
 
+#ifndef ITM_INTEGRATE_BLOCK
+#define ITM_INTEGRATE_BLOCK 256          // lanes per workgroup of the stand-alone launch: at 72 registers a SIMD holds 7 waves, which 8-wave workgroups cannot fill (6); measured 134.5 -> 120.9 us on BASELINE configs[4]
+#endif
+#ifdef ITM_INTEGRATE_WAVES_PER_EU
+#define ITM_INTEGRATE_OCC __attribute__((amdgpu_waves_per_eu(ITM_INTEGRATE_WAVES_PER_EU, ITM_INTEGRATE_WAVES_PER_EU)))
+#else
+#define ITM_INTEGRATE_OCC
+#endif
 template <class VX>
-__global__ void __launch_bounds__(512) integrate_hash_kernel(const int32_t* __restrict__ visibleIds, RenderCounters* __restrict__ rc,
+__global__ void __launch_bounds__(512) ITM_INTEGRATE_OCC integrate_hash_kernel(const int32_t* __restrict__ visibleIds, RenderCounters* __restrict__ rc,
                                                              const uint4* __restrict__ hash, void* __restrict__ vba, void* __restrict__ sdfMirror,
                                                              const float* __restrict__ depth, const uchar4* __restrict__ rgb, FuseParams p) {
   integrate_hash_body<VX>(blockIdx.x, gridDim.x, visibleIds, rc, hash, vba, sdfMirror, depth, rgb, p);
@@ -940,7 +969,7 @@ int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipS
       if (fuseProjection)
         integrate_project_kernel<VX><<<grid, 512, (size_t)RW * RH * sizeof(uint2), st>>>(rs->visibleIds, rs->counters, s->hash, s->vba, s->sdfMirror, v->depth, rgb, p,
                                                                                          rs->range, rs->projBuf, rs->rangePartials, pp, RW, RH);
-      else integrate_hash_kernel<VX><<<grid, 512, 0, st>>>(rs->visibleIds, rs->counters, s->hash, s->vba, s->sdfMirror, v->depth, rgb, p);
+      else integrate_hash_kernel<VX><<<grid * (512 / ITM_INTEGRATE_BLOCK), ITM_INTEGRATE_BLOCK, 0, st>>>(rs->visibleIds, rs->counters, s->hash, s->vba, s->sdfMirror, v->depth, rgb, p);
       return ITM_OK;
     });
     if (rc) return rc;

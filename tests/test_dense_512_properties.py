@@ -146,3 +146,21 @@ def test_dense_512_every_classified_patch_agrees_with_its_voxels(hip):
     free, shadow, mixed, violations = list(out)
     assert violations == 0, list(out)
     assert free > 5_000_000 and shadow > 5_000_000 and mixed > 1_000_000, list(out)
+
+
+def test_dense_512_raycast_matches_oracle_at_full_size(hip, oracle):
+    """BASELINE configs[2] at FULL size through the ray cast as well (castRay over a plain voxel array, reference
+    DeviceAgnostic/ITMVisualisationEngine.h:92-158 with readFromSDF_* of ITMRepresentationAccess.h:129-142): frames 0, 17, 34 of
+    bench.py --config 3's trajectory through the four engine calls on the whole 512^3 volume, on both sides.  Voxels, the constant
+    range image, raycast_result (the position of a ray that found nothing is unspecified in the reference: masked, its w is compared),
+    ICP points / normals and the grey image are compared bit for bit -- what bench.py --config 3's parity_check does, inside the suite."""
+    sc = T.Scenario(name="dense512_full", w=640, h=480, voxelType=capi.VOXEL_S, indexType=capi.INDEX_DENSE, voxelSize=0.004, mu=0.02,
+                    stopIntegratingAtMaxW=True, trajectory="bench", frames=3, frame_stride=17)
+    a = T.run_scenario(hip, sc, fused="four")
+    b = T.run_scenario(oracle, sc)
+    for r in (a, b):
+        r.raycast = r.raycast.copy()
+        r.raycast[r.raycast[..., 3] <= 0, :3] = 0
+    hits = int((a.raycast[..., 3] > 0).sum())
+    assert hits > 50_000, hits
+    T.compare_results(a, b, sc, what="dense 512^3, full size, HIP vs oracle")
