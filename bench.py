@@ -95,6 +95,8 @@ def parse():
     ap.add_argument("--origin-offset", default="0,0,0",
                     help="X,Y,Z metres added to every camera position (scene and trajectory translated together: same depth images, "
                          "block coordinates far from the world origin)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the child runs of BASELINE configs[2] (dense 512^3) and configs[4] (1280x960 colour) that the default single-GPU run appends as `other_configs`")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the secondary measurements of the default run (PCIe-inclusive rate, table-walk ray cast, stream-copy peak)")
     ap.add_argument("--lib", default=None, help="alternative shared library exporting the same C-ABI (tests: a host-memory backend)")
@@ -110,6 +112,52 @@ def _free_port() -> int:
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
+
+
+def _parse_cpulist(text: str):
+    out = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.update(range(int(a), int(b or a) + 1))
+    return out
+
+
+def rank_cpu_set(local_rank: int, local_world: int):
+    """The host cores of one rank: a DISJOINT share of the cores this process may run on -- of the NUMA node of the rank's GPU where sysfs
+    names one (/sys/class/drm/renderD<128 + i>/device/numa_node, the node's cores split among the ranks whose GPUs sit on it), of the
+    whole set otherwise.  The per-frame path is host-issued (four C-ABI calls + the exchange's issuer thread per rank): eight ranks
+    that wander over all cores migrate between NUMA nodes and share cores with each other's issuer threads.  Reads sysfs only --
+    nothing here touches a GPU.  Returns None when there is nothing to restrict (one rank, or fewer cores than ranks)."""
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return None
+    if local_world <= 1 or len(avail) < local_world:
+        return None
+
+    def node_of(i):
+        try:
+            with open(f"/sys/class/drm/renderD{128 + i}/device/numa_node") as f:
+                n = int(f.read().strip())
+            return n if n >= 0 else None
+        except (OSError, ValueError):
+            return None
+    nodes = [node_of(i) for i in range(local_world)]
+    mine = nodes[local_rank]
+    if mine is not None:
+        try:
+            with open(f"/sys/devices/system/node/node{mine}/cpulist") as f:
+                cores = sorted(_parse_cpulist(f.read()) & set(avail))
+        except (OSError, ValueError):
+            cores = []
+        peers = [i for i in range(local_world) if nodes[i] == mine]
+        if len(cores) >= len(peers):
+            k, per = peers.index(local_rank), len(cores) // len(peers)
+            return set(cores[k * per:(k + 1) * per])
+    per = len(avail) // local_world
+    return set(avail[local_rank * per:(local_rank + 1) * per])
 
 
 def launch_ranks(args) -> int:
@@ -233,6 +281,17 @@ def worker(args) -> int:
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with matching values", file=sys.stderr)
         return 2
+    # host cores of this rank, before anything touches the GPU (under torchrun as well as under bench.py's own launcher)
+    cpus = None
+    if world > 1 and os.environ.get("ITM_BENCH_NO_AFFINITY") != "1":
+        cpus = rank_cpu_set(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+        if cpus:
+            try:
+                os.sched_setaffinity(0, cpus)
+                os.environ.setdefault("OMP_NUM_THREADS", str(len(cpus)))
+            except OSError as e:
+                print(f"bench.py: rank {rank}: sched_setaffinity failed ({e})", file=sys.stderr)
+                cpus = None
     # stdout carries ONE line, the JSON of rank 0.  RCCL prints a version banner through C stdio when a communicator is created:
     # from here on file descriptor 1 is stderr for everything (C libraries and Python alike), the JSON goes to the saved descriptor.
     sys.stdout.flush()
@@ -542,7 +601,7 @@ def worker(args) -> int:
 
     # what the exchange costs THIS run: the same frames once more without it (every rank, no collective involved)
     exchange_cost = None
-    if exchange and on_gpu:
+    if exchange and (on_gpu or world > 1):
         n3 = min(args.steps, 200)
         was, exchange = exchange, False
         run(0, min(args.warmup, 20)); sync()
@@ -553,8 +612,33 @@ def worker(args) -> int:
         with_ = k_streams * args.steps / elapsed_local
         exchange_cost = {"frames_per_collective": max(1, args.exchange_batch), "rank0_fps_with_exchange": round(with_, 1),
                          "rank0_fps_without_exchange": round(without, 1), "cost_percent": round(100.0 * (1.0 - with_ / without), 1),
+                         "north_star_says": "per-frame all-gather; the default batches 8 frames per collective (same records, same table, delivered up to 7 frames later)",
                          "why_not_every_frame": "one collective per frame was measured at 8.6 percent of the frame rate issued from a C loop and 28 percent from "
                                                 "this harness on one MI355X (DESIGN.md section 6); --exchange-batch 1 selects it"}
+
+    # what the exchange delivered: rank 0 decodes the newest gathered table -- one block per rank: pose + visible ids
+    exchange_table = None
+    if exchange and exs:
+        drain()
+        try:
+            tab = exs[0].table()
+            exchange_table = {"blocks": len(tab), "blocks_with_ids": sum(1 for _, ids in tab if len(ids) > 0),
+                              "visible_counts": [int(len(ids)) for _, ids in tab],
+                              "camera_y_m": [round(-float(M[13]), 4) for M, _ in tab],
+                              "what": "newest gathered table decoded on rank 0 (infinitam_amd.streams.decode_table): stream g's camera is offset 0.05 g m in y"}
+        except Exception as e:      # noqa: BLE001 -- a missing figure, not a failed run
+            exchange_table = {"error": str(e)[:200]}
+    # host cores: every rank's share (count, first core), gathered with one all-reduce
+    host_cores = None
+    if world > 1:
+        hc = torch.zeros(world * 2, dtype=torch.int32, device=ctl_device)
+        if cpus:
+            hc[2 * rank], hc[2 * rank + 1] = len(cpus), min(cpus)
+        dist.all_reduce(hc)
+        hc = hc.cpu().tolist()
+        host_cores = {"per_rank_count": hc[0::2], "per_rank_first_core": hc[1::2],
+                      "what": "os.sched_setaffinity per rank before anything touches the GPU: a disjoint share of the cores of the GPU's NUMA node (sysfs), "
+                              "or of all cores where sysfs names none; count 0 = not restricted"}
 
     counters = streams[0].scene.counters(streams[0].rs)
     roofline = None
@@ -658,12 +742,35 @@ def worker(args) -> int:
                                      "what": "the sdf mirror as 4 MB pages from a 768 MB pool behind a 16 KB table instead of the dense 17 GB cube of the headline scene"}
             streams[0] = keep
             streams.pop()
+    # (4) an EXPLORING camera: the headline trajectory is 100-periodic, so from frame 100 on nothing is allocated; here the camera of the
+    #     parity trajectory (1 cm per frame along x, never turning back) starts on a reset scene -- every frame requests and allocates
+    #     blocks, the allocation sweep of _CPU.cpp:175-227 and the visible-list re-tests have work in every frame
+    if (rank == 0 and world == 1 and product and k_streams == 1 and on_gpu and not exchange and not args.no_extra_legs and not args.raw_depth
+            and args.config == 2 and mode["call"] == "four"):
+        extra["exploring"] = run_exploring(streams[0], be, capi, synth, torch, wl, issue, sync, timed_set=("request", "visible_list", "integrate", "raycast"))
     if rank == 0 and world == 1 and product and on_gpu and roofline is not None and not args.no_extra_legs:
         roofline["peak_measured"] = measured_stream_peak()
+        pm = roofline["peak_measured"] or {}
+        if pm.get("copy_GBs"):
+            # the same achieved rate against what THIS box's memory system delivers to a streaming read+write kernel (the integration
+            # kernels read and write every voxel of every visible block), beside the fraction of the 8 TB/s vendor peak
+            roofline["frac_of_measured_copy_peak"] = round(roofline["achieved"] / pm["copy_GBs"], 4)
+            for o in (roofline.get("other_kernels") or {}).values():
+                o["frac_of_measured_copy_peak"] = round(o["achieved"] / pm["copy_GBs"], 4)
 
     cpu_baseline, parity_check = None, None
     if rank == 0 and world == 1 and product and k_streams == 1 and not args.no_cpu_baseline:
         cpu_baseline, parity_check = run_cpu_baseline(args.config, wl, args.cpu_frames, on_gpu)
+        if "exploring" in extra and on_gpu:
+            extra["exploring"].update(run_exploring_check(wl))
+
+    # the other single-GPU configurations of BASELINE.json, each as its own bench.py process (its own scene, its own parity check and
+    # CPU sample), after everything of this run has been measured: the driver's ONE line then carries all three
+    other_configs = None
+    if (rank == 0 and world == 1 and product and k_streams == 1 and on_gpu and not args.no_extra_legs and not args.no_other_configs
+            and not args.raw_depth and args.config == 2 and not args.debug_keys):
+        sync()
+        other_configs = {f"config{c}": run_other_config(c, args) for c in (3, 5)}
 
     out = None
     if rank == 0:
@@ -683,6 +790,9 @@ def worker(args) -> int:
                                     + (("issued by the library over the STAND-IN transport of the shared-GPU self-test (not RCCL)" if standin else "issued by the library (RCCL from C++)") if native else "issued through torch.distributed")
                                     if exchange else "none"),
                        "exchange_cost_measured": exchange_cost,
+                       "exchange_frames_per_collective": (max(1, args.exchange_batch) if exchange else None),
+                       "exchange_table": exchange_table,
+                       "host_cores": host_cores,
                        "per_rank_fps_min_max": fps_minmax,
                        "visible_blocks_last_frame": counters["noVisibleEntries"],
                        **({"acceleration_structures": streams[0].scene.accel_info()} if (product and wl["index"] == "hash") else {}),
@@ -697,6 +807,7 @@ def worker(args) -> int:
                        **({"debug_keys": args.debug_keys} if args.debug_keys else {}),
                        "backend": be.version()},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity_check": parity_check,
+            **({"other_configs": other_configs} if other_configs is not None else {}),
             **extra,
         }
     for ex in exs:                     # communicators of the library exchange go before the process group they were bootstrapped over
@@ -710,10 +821,137 @@ def worker(args) -> int:
         sys.stdout.flush()
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
-        if parity_check is not None and not parity_check["equal"]:
-            print(f"bench.py: PARITY CHECK FAILED: {parity_check}", file=sys.stderr)
+        failed = [("parity_check", parity_check)] if (parity_check is not None and not parity_check["equal"]) else []
+        ex_par = (out.get("exploring") or {}).get("parity_check")
+        if ex_par is not None and not ex_par["equal"]:
+            failed.append(("exploring.parity_check", ex_par))
+        for name, oc in (other_configs or {}).items():
+            if (oc.get("parity_check") or {}).get("equal") is False:
+                failed.append((name + ".parity_check", oc["parity_check"]))
+        if failed:
+            print(f"bench.py: PARITY CHECK FAILED: {failed}", file=sys.stderr)
             return 4
     return 0
+
+
+# -------------------------------------------------------------------------------------------------------------
+# secondary legs of the default single-GPU run
+# -------------------------------------------------------------------------------------------------------------
+EXPLORING_FRAMES = 200
+
+
+def run_exploring(s0, be, capi, synth, torch, wl, issue, sync, timed_set):
+    """BASELINE configs[1]'s scene under a camera that EXPLORES: frames 0..199 of the parity trajectory (camera k at x = 0.01 k m)
+    from a reset scene, through the same four engine calls as the timed region.  Three passes over the same frames, each from a reset
+    scene: (A) timed between two synchronisations -> frames/s; (B) an event pair around every launch of the request, visible-list (the
+    allocation sweep runs inside it), integration and ray-cast kernels -> their mean durations; (C) counters read back after every frame
+    -> blocks allocated per frame."""
+    import numpy as np
+    w, h, n = s0.w, s0.h, EXPLORING_FRAMES
+    intr = s0.intr
+    pos = [synth.parity_position(k) for k in range(n)]
+    depth = torch.from_numpy(np.stack([synth.depth_frame(w, h, t, intr) for t in pos])).to(s0.device)
+    views = [capi.View(depth[k].data_ptr(), w, h, M_d=synth.pose_matrix(pos[k]), intr_d=intr, rgb=None, w_rgb=w, h_rgb=h, intr_rgb=intr).struct() for k in range(n)]
+    stream = s0.hip_stream.cuda_stream if s0.hip_stream is not None else None
+
+    def reset():
+        s0.scene.reco.ResetScene(stream=stream)
+
+    def frames(per_frame=None):
+        for k in range(n):
+            rc = issue(s0, C.byref(views[k]), views[k], None)
+            if rc:
+                be.check(rc, "frame (exploring)")
+            if per_frame:
+                per_frame(k)
+    # (A)
+    reset(); sync()
+    t0 = time.perf_counter()
+    frames(); sync()
+    dt = time.perf_counter() - t0
+    end = s0.scene.counters(s0.rs)
+    # (B)
+    reset(); sync()
+    s0.scene.profile_read(reset=True)
+    s0.scene.profile_enable(sum(1 << TK[t] for t in timed_set))
+    s0.scene.profile_sample(1)
+    frames(); sync()
+    s0.scene.profile_calibrate(64, stream); sync()
+    prof = s0.scene.profile_read(reset=True)
+    s0.scene.profile_enable(0)
+    half_pair = 0.5 * prof["empty"]["total_ms"] / max(1, prof["empty"]["calls"])
+    kernels = {t: round((prof[t]["total_ms"] / max(1, prof[t]["calls"]) - half_pair) * 1e3, 2) for t in timed_set}
+    # (C)
+    reset(); sync()
+    free, vis = [wl["blocks"] - 1], []
+
+    def after(k):
+        c = s0.scene.counters(s0.rs)
+        free.append(c["lastFreeBlockId"]); vis.append(c["noVisibleEntries"])
+    frames(after)
+    alloc = [a - b for a, b in zip(free[:-1], free[1:])]
+    steady = alloc[20:]
+    del depth
+    return {"value": round(n / dt, 2), "unit": "frames/s", "steps": n, "ms_per_step": round(1e3 * dt / n, 4),
+            "what": f"frames 0..{n - 1} of the parity trajectory (camera k at x = 0.01 k m: 1 cm per frame, never turning back) on a RESET scene, the reference's four engine "
+                    "calls per frame, depth resident in HBM: every frame requests, allocates (sweep of ITMSceneReconstructionEngine_CPU.cpp:175-227 inside the visible-list launch) "
+                    "and re-tests blocks, unlike the periodic headline trajectory",
+            "blocks_allocated_per_frame": {"first_frame": alloc[0], "mean_frames_1_19": round(sum(alloc[1:20]) / 19.0, 1),
+                                           "mean_frames_20_on": round(sum(steady) / max(1, len(steady)), 1), "min_frames_20_on": min(steady), "max_frames_20_on": max(steady)},
+            "blocks_allocated_total": (wl["blocks"] - 1) - end["lastFreeBlockId"],
+            "excess_entries_in_use_at_end": (0x20000 - 1) - end["lastFreeExcessListId"],
+            "visible_blocks": {"mean": round(sum(vis) / len(vis), 1), "last": vis[-1]},
+            "kernel_us": kernels,
+            "kernel_note": "mean over the 200 launches of each, an event pair around every launch in a separate pass (half an empty pair subtracted); "
+                           "visible_list includes the allocation sweep",
+            "statusFlags": end.get("statusFlags", 0)}
+
+
+def run_exploring_check(wl):
+    """The exploring leg's own certificate: its first frames on a fresh product scene against the CPU oracle on the same frames (SHA-256
+    of every buffer), and the oracle's rate on them as the CPU figure for an allocating workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import itm_testlib as T
+    from infinitam_amd import capi
+    nframes = 30
+    sc = T.Scenario(name="exploring", w=wl["w"], h=wl["h"], voxelType=capi.VOXEL_S, indexType=capi.INDEX_HASH, voxelSize=wl["voxelSize"], mu=wl["mu"],
+                    trajectory="parity", frames=nframes, localBlockNum=wl["blocks"])
+    one, dig = _time_cpu(T.oracle_backend(), sc, nframes, T, digests=True)
+    par = run_parity_check(sc, nframes, dig, T)
+    return {"parity_check": par,
+            "cpu_baseline": {"value": round(one, 3), "unit": "frames/s", "cores": 1, "kind": "port", "sample": f"first {nframes} frames of the exploring trajectory, oracle/libitm_oracle.so single thread"}}
+
+
+def run_other_config(c, args):
+    """`bench.py --config c` as a child process (this process's GPU work is done and synchronised; the child is started, never exec'd
+    into): the same measurement the flag gives on its own -- timed region, kernel brackets, parity check against the oracle, CPU sample --
+    reduced to the figures a reader of the driver's line needs."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--config", str(c), "--gpus", "1", "--steps", "100", "--warmup", "20", "--no-extra-legs", "--no-other-configs"]
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "ITM_BENCH_SPAWNED")}
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+        if not lines:
+            return {"error": f"exit code {r.returncode}, no JSON line", "stderr_tail": r.stderr[-400:]}
+        d = json.loads(lines[-1])
+    except Exception as e:      # noqa: BLE001 -- a missing figure, reported as such
+        return {"error": str(e)[:300]}
+    rf = d.get("roofline") or {}
+    cb = d.get("cpu_baseline") or {}
+    out = {"workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"],
+           "repetitions": (d.get("repetitions") or {}).get("count"), "dtype": d["dtype"], "exit_code": r.returncode,
+           "roofline": {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_traffic", "algorithmic_bytes_per_launch",
+                                               "avg_kernel_us", "launches_timed")},
+           "other_kernels_us": {k: v.get("avg_kernel_us") for k, v in (rf.get("other_kernels") or {}).items()},
+           "parity_check": d.get("parity_check"),
+           "cpu_baseline": ({k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample")} | ({"all_cores": cb["all_cores"]} if "all_cores" in cb else {})) if cb else None,
+           "visible_blocks_last_frame": d["config"].get("visible_blocks_last_frame"),
+           "child_wall_s": round(time.perf_counter() - t0, 1),
+           "how": "python bench.py --config %d --steps 100 --warmup 20 --no-extra-legs, run as a child of this process after its own measurements" % c}
+    return out
 
 
 # -------------------------------------------------------------------------------------------------------------

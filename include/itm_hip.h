@@ -170,7 +170,10 @@ int ITM_FN(host_malloc)(void** ptr, size_t bytes);
 int ITM_FN(host_free)(void* ptr);
 /* Page-locks host memory the HOST owns (hipHostRegister): an image buffer of the reference (ORUtils::MemoryBlock allocates with `new`)
  * becomes a source / target of asynchronous copies at PCIe speed -- from pageable memory itm_memcpy_h2d is staged through the runtime's
- * bounce buffer and blocks the calling thread.  Registering a range twice is not an error.  Unregister before the memory is freed. */
+ * bounce buffer and blocks the calling thread.  Registering a range that is registered already is not an error but is TOLD: the call
+ * returns ITM_ALREADY_REGISTERED (> 0) and the caller does not own that registration -- it must not unregister it (someone else did the
+ * registering, possibly for a different length).  Unregister what you registered before the memory is freed. */
+#define ITM_ALREADY_REGISTERED 1
 int ITM_FN(host_register)(void* ptr, size_t bytes);
 int ITM_FN(host_unregister)(void* ptr);
 int ITM_FN(memcpy_h2d)(void* dst_dev, const void* src_host, size_t bytes, itm_stream stream);
@@ -497,7 +500,8 @@ int ITM_FN(exchange_info)(const itm_exchange* exchange, int* world, int* rank, i
  * first record; NULL / -1 before the first collective).  The table belongs to the consumer until itm_exchange_release -- or the next
  * itm_exchange_acquire, which releases first -- both given the stream the consumer's reads were put on: the ring skips a held slot,
  * and the collective that next writes a released slot waits (on the exchange's side stream) behind those reads.  One holder at a time.
- * Frames and collectives go on meanwhile; nothing here blocks the host. */
+ * Frames and collectives go on meanwhile; nothing here blocks the host.  Threads: the slot is chosen and marked as held under one lock,
+ * so a consumer thread other than the one calling itm_exchange_step is safe; two consumer threads are not (one holder at a time). */
 int ITM_FN(exchange_acquire)(itm_exchange* exchange, itm_stream consumer_stream, const int32_t** table, long long* first_frame);
 int ITM_FN(exchange_release)(itm_exchange* exchange, itm_stream consumer_stream);
 /* host copy of the gathered table, world x batch records of (17 + max_ids) int32 words, rank-major; synchronises the side stream */

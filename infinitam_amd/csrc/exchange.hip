@@ -311,6 +311,7 @@ int itm_exchange_destroy(itm_exchange* x) { free_exchange(x); return ITM_OK; }
 
 int itm_exchange_step(itm_exchange* x, const itm_render_state* rs, const float M_d[16], itm_stream frame_stream) {
   if (!x || !rs || !M_d) return set_error(ITM_ERR_INVALID, "null argument");
+  if (!rs->scene) return set_error(ITM_ERR_INVALID, "the render state's scene has been destroyed");
   { const int rc = enter_scene(rs->scene, rs); if (rc) return rc; }       // engine calls recorded on the render state are launched first (pending.hip)
   hipStream_t fs = as_stream(frame_stream);
   const int slot = (int)(x->frame % x->batch);
@@ -352,10 +353,14 @@ int itm_exchange_step(itm_exchange* x, const itm_render_state* rs, const float M
   return ITM_OK;
 }
 
-// the newest slot whose collective is on the side stream (all queued collectives issued first); -1 if none yet
-static int newest_issued(itm_exchange* x) {
+// waits until every collective queued so far has been put on the side stream
+static void wait_issued(itm_exchange* x) {
   for (int b = 0; b < itm_exchange::kRing; ++b)
     while (x->state[b].load(std::memory_order_acquire) == itm_exchange::kQueued) std::this_thread::yield();
+}
+// the newest slot whose collective is on the side stream (all queued collectives issued first); -1 if none yet
+static int newest_issued(itm_exchange* x) {
+  wait_issued(x);
   std::lock_guard<std::mutex> g(x->m);
   return x->newest;
 }
@@ -372,8 +377,12 @@ int itm_exchange_acquire(itm_exchange* x, itm_stream consumer_stream, const int3
   if (!x || !table) return set_error(ITM_ERR_INVALID, "null argument");
   if (x->issuerFailed.load(std::memory_order_acquire)) return set_error(ITM_ERR_DEVICE, x->issuerMessage);
   if (x->check && ((volatile SelfCheck*)x->check)->mismatchedWords) return self_check_error(x);
-  const int b = newest_issued(x);
+  // The slot is chosen and marked as held under ONE lock: chosen outside it, a frame thread that advanced the ring by seven
+  // batches in between could re-use that slot before `held` names it, and the next collective would overwrite a table the consumer
+  // is still reading.  (acquire / release belong to the thread that calls itm_exchange_step, or to a consumer the host serialises with it.)
+  wait_issued(x);
   std::lock_guard<std::mutex> g(x->m);
+  const int b = x->newest;
   { const int rc = release_locked(x, as_stream(consumer_stream)); if (rc) return rc; }       // "release on the next acquire"
   if (b < 0) { *table = nullptr; if (first_frame) *first_frame = -1; return ITM_OK; }        // no collective has been issued yet
   ITM_HIP(hipStreamWaitEvent(as_stream(consumer_stream), x->released[b], 0));                // the table is complete (and self-checked) behind this event

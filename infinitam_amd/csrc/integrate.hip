@@ -44,10 +44,15 @@ struct FuseParams {
   int W, H, Wc, Hc;
   int stopAtMax;
   AccelOrigin org;  // where the sdf mirror cube lies (hash scenes)
+  int idsCap;       // capacity of the visible list (ids), for the speculative first fetch of integrate_hash_body
 };
 
 // Depth part, stage 1: project the voxel; returns the index of the depth pixel it falls on, or -1 when the voxel
 // cannot be touched (behind the camera / outside the image).  Operation order as SURVEY.md Appendix A.5.
+// EARLY_OUT: the conservative frustum test in front of the divisions.  It pays where most voxels leave through it (a dense volume: ~70 %
+// of the voxels are outside the image) and costs four products and four comparisons per voxel where hardly any does (the blocks of a
+// visible list: the hash kernels run without it -- round 6, ~10 % of their vector instructions).
+template <bool EARLY_OUT = true>
 __device__ inline int fuse_depth_project(float mx, float my, float mz, const FuseParams& p, float& pcz) {
   Vec3 pc = transform_point(p.M_d, mx, my, mz);
   pcz = pc.z;
@@ -57,8 +62,10 @@ __device__ inline int fuse_depth_project(float mx, float my, float mz, const Fus
   // Conservative early-out before the two divisions: the voxel is rejected below when
   // u = tx/z + cx is outside [1, W-2]; half a pixel of margin dwarfs every rounding error, so this
   // never rejects a voxel the exact test would keep (most voxels of a dense volume leave here).
-  if (tx < (0.5f - p.cx) * pc.z || tx > ((float)(p.W - 2) + 0.5f - p.cx) * pc.z ||
-      ty < (0.5f - p.cy) * pc.z || ty > ((float)(p.H - 2) + 0.5f - p.cy) * pc.z) return -1;
+  if constexpr (EARLY_OUT) {
+    if (tx < (0.5f - p.cx) * pc.z || tx > ((float)(p.W - 2) + 0.5f - p.cx) * pc.z ||
+        ty < (0.5f - p.cy) * pc.z || ty > ((float)(p.H - 2) + 0.5f - p.cy) * pc.z) return -1;
+  }
   float u, v;
   if (pc.z >= 1e-4f && pc.z <= 1e4f) {       // normal range: shared refined reciprocal, exact quotients
     const float rz = refined_rcp(pc.z);
@@ -73,7 +80,9 @@ __device__ inline int fuse_depth_project(float mx, float my, float mz, const Fus
   const float v = ty / pc.z + p.cy;
 #endif
   if ((u < 1) || (u > p.W - 2) || (v < 1) || (v > p.H - 2)) return -1;
-  return (int)(u + 0.5f) + (int)(v + 0.5f) * p.W;
+  // (both factors are below 2^23 -- images have fewer than 2^24 pixels, scene.hip -- so the 24-bit multiply-add is exact and one
+  // full-rate instruction where the 32-bit form is a quarter-rate 64-bit mad)
+  return __mul24((int)(v + 0.5f), p.W) + (int)(u + 0.5f);
 }
 
 // The running average of computeUpdatedVoxelDepthInfo (DeviceAgnostic/ITMSceneReconstructionEngine.h:45-55) with the clamped
@@ -276,7 +285,7 @@ __device__ inline void integrate_item(const HashEntry& he, int z0, int lane, typ
 #pragma unroll
   for (int k = 0; k < kSlices; ++k) {
     mz[k] = (float)(he.pz * kBlockSide + z0 + k) * p.voxelSize;
-    pix[k] = present ? fuse_depth_project(mx, my, mz[k], p, pcz[k]) : -2;     // -2: no block
+    pix[k] = present ? fuse_depth_project<false>(mx, my, mz[k], p, pcz[k]) : -2;     // -2: no block
   }
   float dm[kSlices];
 #pragma unroll
@@ -309,25 +318,44 @@ __device__ inline void integrate_hash_body(int wgIdx, int wgCount, const int32_t
                                            const float* __restrict__ depth, const uchar4* __restrict__ rgb, const FuseParams& p) {
   constexpr int kSlices = slices_of<VX>();
   constexpr int kItemsPerBlock = kBlockSide / kSlices;
-  if (rc->listInvalid) return;                        // the list of this frame is not the reference's: fuse nothing (alloc.hip, statusFlags bit 1)
-  const int nItems = rc->noVisibleEntries * kItemsPerBlock;
   const int lane = threadIdx.x & 63;
   const int waves = wgCount * (int)(blockDim.x >> 6);
   int i = __builtin_amdgcn_readfirstlane(wgIdx * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6));
+  // What a wave needs before it can ask for its first voxels is a chain of scalar round trips to memory the previous launch has just
+  // written: the list's state, the id at the wave's position, the table entry behind the id.  The first two do not depend on each other --
+  // the id is fetched speculatively (the position is clamped to the list's capacity; the value is only used once the count says it is
+  // one) -- so they travel together: three round trips to the first voxel request instead of five (until round 6: listInvalid, then the
+  // count, then the id, then the entry).
+  const int idsLast = p.idsCap - 1;
+  const int at0 = i / kItemsPerBlock;
+  int idCur = visibleIds[at0 < idsLast ? at0 : idsLast];
+  int invalid = rc->listInvalid, nv = rc->noVisibleEntries;
+  asm volatile("" : "+s"(idCur), "+s"(invalid), "+s"(nv));      // all three requested above this line, looked at below it
+  if (invalid) return;                                // the list of this frame is not the reference's: fuse nothing (alloc.hip, statusFlags bit 1)
+  const int nItems = nv * kItemsPerBlock;
   if (i >= nItems) return;
-  HashEntry cur = unpack_entry(hash[visibleIds[i / kItemsPerBlock]]);
+  // the id of the NEXT item travels with the first entry; inside the loop the entry one item ahead and the id two items ahead are requested
+  // at the top of an item and looked at behind it (positions clamped to the list's end: a wave without a next item re-reads its last)
+  int nxt = i + waves;
+  int idNext = visibleIds[(nxt < nItems ? nxt : nItems - 1) / kItemsPerBlock];
+  HashEntry cur = unpack_entry(hash[idCur]);
   typename VX::Reg r[kSlices];
   load_item<VX>(cur, (i % kItemsPerBlock) * kSlices, lane, vba, r);
+  // (the next item's VOXELS in a second register set, so that the launch could have no more waves than the device holds -- every item in
+  // flight from the first microsecond -- was built and measured in round 6 on BASELINE configs[1]: 768 workgroups 21.9-22.3 us, 1 024:
+  // 20.5, against 19.0-19.4 for 2 048 workgroups without it.  The launch is bound by vector-instruction issue, not by the chain: a wave
+  // with two items takes twice as long as a wave with one, whatever is prefetched.)
   for (;;) {
-    const int nxt = i + waves;
     const bool more = nxt < nItems;
-    HashEntry ahead = cur;
-    if (more) ahead = unpack_entry(hash[visibleIds[nxt / kItemsPerBlock]]);
-    const int zn = (nxt % kItemsPerBlock) * kSlices;
+    uint4 rawAhead = hash[idNext];
+    const int after = nxt + waves;
+    int idAfter = visibleIds[(after < nItems ? after : nItems - 1) / kItemsPerBlock];
     integrate_item<VX>(cur, (i % kItemsPerBlock) * kSlices, lane, r, vba, sdfMirror, depth, rgb, p);
+    asm volatile("" : "+s"(rawAhead.x), "+s"(rawAhead.y), "+s"(rawAhead.z), "+s"(rawAhead.w), "+s"(idAfter));
     if (!more) break;
-    load_item<VX>(ahead, zn, lane, vba, r);
-    cur = ahead; i = nxt;
+    cur = unpack_entry(rawAhead);
+    load_item<VX>(cur, (nxt % kItemsPerBlock) * kSlices, lane, vba, r);
+    i = nxt; nxt = after; idNext = idAfter;
   }
 }
 
@@ -941,6 +969,7 @@ int launch_integrate(itm_scene* s, const itm_view* v, itm_render_state* rs, hipS
   p.W = v->w; p.H = v->h; p.Wc = v->w_rgb; p.Hc = v->h_rgb;
   p.stopAtMax = s->prm.stopIntegratingAtMaxW;
   p.org = s->org;
+  p.idsCap = rs->capIds > 0 ? rs->capIds : 1;
   const uchar4* rgb = (const uchar4*)v->rgb;
   { const int rc = validate_integrate(s, v); if (rc) return rc; }
 

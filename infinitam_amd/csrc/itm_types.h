@@ -220,8 +220,9 @@ constexpr size_t kDirCells = (size_t)kDirSide * kDirSide * kDirSide;
 struct AccelOrigin {
   int32_t dx, dy, dz;
   int32_t mx, my, mz;
-  // the sdf mirror (below).  mMaxPages > 0: PAGED -- the page table, the pool's page counter and size; mMaxPages < 0: DENSE -- the whole
-  // cube is stored, no table (mTable / mPages are nullptr); 0: the scene has no mirror
+  // the sdf mirror (below).  mMaxPages > 0: PAGED -- the page table, the pool's page counter and size; mMaxPages < 0: DENSE -- a whole
+  // cube of 2^(-mMaxPages) blocks per side is stored (-8: 256^3 blocks, -7: 128^3; mirror_dense_bits), no table (mTable / mPages are
+  // nullptr); 0: the scene has no mirror
   int32_t* mTable;
   int32_t* mPages;
   int32_t mMaxPages;
@@ -301,6 +302,12 @@ template <> struct MirrorCodec<false> {
   __device__ static T of(float rawSdf) { return __float_as_uint(rawSdf); }
 };
 __host__ __device__ inline bool mirror_covers(uint32_t ux, uint32_t uy, uint32_t uz) { return ((ux | uy | uz) >> kMirrorBits) == 0u; }
+// The DENSE form's cube is sized at run time from the scene's view frustum (scene.hip: the smallest power of two of blocks that holds
+// the frustum with room to move -- 128^3 blocks = 2.1 GB of int16 sdf for a 3 m frustum at 4 mm voxels, where rounds 2-5 always stored
+// 256^3 = 17 GB): log2 of its side in blocks, and the same tests / cell order for that side.  (A wave-uniform shift count: scalar.)
+__host__ __device__ inline int mirror_dense_bits(const AccelOrigin& org) { return -org.mMaxPages; }
+__host__ __device__ inline bool mirror_dense_covers(uint32_t ux, uint32_t uy, uint32_t uz, int bits) { return ((ux | uy | uz) >> bits) == 0u; }
+__host__ __device__ inline uint32_t mirror_dense_cell(uint32_t ux, uint32_t uy, uint32_t uz, int bits) { return (uz << (2 * bits)) | (uy << bits) | ux; }
 // the cells of the cube in plain x-fastest order (the near bits, one byte per cell)
 __host__ __device__ inline uint32_t mirror_cell(uint32_t ux, uint32_t uy, uint32_t uz) { return (uz << (2 * kMirrorBits)) | (uy << kMirrorBits) | ux; }
 // page-table entry of the page that holds cube-relative block (ux, uy, uz), and the block's place inside its page
@@ -348,16 +355,30 @@ __device__ inline int mirror_claim_page(const AccelOrigin& org, uint32_t tIdx) {
   }
   return v;
 }
+// Plain read of a table entry by a reader whose block is the same for every lane of the wave (the integration: one block per wave) --
+// through the scalar cache.  As a vector load the compiler waits for it with s_waitcnt vmcnt(0), i.e. for every voxel run the wave has
+// in flight at that point; the table is not written by any launch that reads it this way.
+__device__ inline int mirror_table_entry(const AccelOrigin& org, uint32_t tIdx) {
+  const int32_t* q = org.mTable + tIdx;
+  int v;
+  asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(q) : "memory");
+  return v;
+}
 // Pool index of voxel (0, 0, 0) of block (bx, by, bz) -- voxel (x, y, z) of the block lies mirror_block_voxel(x, y, z) further --; false
 // when the block has no place in the mirror (outside the cube, page not mapped).
 // CLAIM: map the page if it is not (allocation paths); otherwise a plain read of the table.
 template <bool CLAIM>
 __device__ inline bool mirror_block_base(const AccelOrigin& org, int bx, int by, int bz, size_t& base) {
   const uint32_t ux = (uint32_t)(bx - org.mx), uy = (uint32_t)(by - org.my), uz = (uint32_t)(bz - org.mz);
+  if (org.mMaxPages < 0) {      // dense: the cube's blocks x-fastest, a kilobyte each
+    const int bits = mirror_dense_bits(org);
+    if (!mirror_dense_covers(ux, uy, uz, bits)) return false;
+    base = (size_t)mirror_dense_cell(ux, uy, uz, bits) << 9;
+    return true;
+  }
   if (org.mMaxPages == 0 || !mirror_covers(ux, uy, uz)) return false;
-  if (org.mMaxPages < 0) { base = (size_t)mirror_cell(ux, uy, uz) << 9; return true; }      // dense: the cube's blocks x-fastest, a kilobyte each
   const uint32_t tIdx = mirror_table_index(ux, uy, uz);
-  const int page = CLAIM ? mirror_claim_page(org, tIdx) : org.mTable[tIdx];
+  const int page = CLAIM ? mirror_claim_page(org, tIdx) : mirror_table_entry(org, tIdx);
   if (page < 0) return false;
   base = mirror_element(page, mirror_in_page(ux << 3, uy << 3, uz << 3));
   return true;

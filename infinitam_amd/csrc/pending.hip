@@ -55,6 +55,7 @@ int flush_deferred(itm_render_state* rs) {
   rs->deferred.stage = 0;
   unregister(rs);
   itm_scene* s = const_cast<itm_scene*>(rs->scene);
+  if (!s) return set_error(ITM_ERR_INVALID, "the render state's scene has been destroyed");      // (free_scene forgets what was recorded: belt and braces)
   const itm_view* v = &rs->deferred.view;
   hipStream_t st = rs->deferred.st;
   int rc = launch_allocate(s, v, rs, false, false, st);

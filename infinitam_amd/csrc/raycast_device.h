@@ -155,8 +155,9 @@ __device__ inline float read_raw_sdf(const VOL& vol, int px, int py, int pz, boo
       // DENSE cube (itm_types.h): the load is unconditional (cell 0 for a lane outside the cube) and the general path below is skipped by
       // a UNIFORM branch when every lane was served: no exec-mask bracket around the common case (ray cast 42.1 -> 41.7 us)
       const uint32_t ux = (uint32_t)((px >> 3) - vol.org.mx), uy = (uint32_t)((py >> 3) - vol.org.my), uz = (uint32_t)((pz >> 3) - vol.org.mz);
-      const bool covered = mirror_covers(ux, uy, uz);
-      const size_t mi = ((size_t)mirror_cell(ux, uy, uz) << 9) | (size_t)((px & 7) + ((py & 7) << 3) + ((pz & 7) << 6));
+      const int mbits = mirror_dense_bits(vol.org);
+      const bool covered = mirror_dense_covers(ux, uy, uz, mbits);
+      const size_t mi = ((size_t)mirror_dense_cell(ux, uy, uz, mbits) << 9) | (size_t)((px & 7) + ((py & 7) << 3) + ((pz & 7) << 6));
       const typename MC::T v = ((const typename MC::T*)vol.sdfMirror)[covered ? mi : (size_t)0];
       const bool present = covered && !MC::absent(v);
       const float value = present ? MC::raw(v) : (VX::kShort ? 32767.0f : 1.0f);
@@ -253,12 +254,13 @@ struct Corners {
           // neighbourhood needs at the cube's upper faces, where the general path gives the same values.)  ~35 vector instructions for
           // the eight addresses instead of ~140 -- half of what a trilinear read issued.
           const uint32_t mx = (uint32_t)((ix >> 3) - vol.org.mx), my = (uint32_t)((iy >> 3) - vol.org.my), mz = (uint32_t)((iz >> 3) - vol.org.mz);
-          const bool all = mirror_covers(mx, my, mz) && mirror_covers(mx + 1u, my + 1u, mz + 1u);
+          const int mbits = mirror_dense_bits(vol.org);
+          const bool all = mirror_dense_covers(mx, my, mz, mbits) && mirror_dense_covers(mx + 1u, my + 1u, mz + 1u, mbits);
           const int kx = ix & 7, ky = iy & 7, kz = iz & 7;
-          const size_t base = ((size_t)mirror_cell(mx, my, mz) << 9) + (size_t)(kx + (ky << 3) + (kz << 6));
+          const size_t base = ((size_t)mirror_dense_cell(mx, my, mz, mbits) << 9) + (size_t)(kx + (ky << 3) + (kz << 6));
           const uint32_t ox = (kx == 7) ? 512u - 7u : 1u;
-          const uint32_t oy = (ky == 7) ? (512u << kMirrorBits) - 56u : 8u;
-          const uint32_t oz = (kz == 7) ? (512u << (2 * kMirrorBits)) - 448u : 64u;
+          const uint32_t oy = (ky == 7) ? (512u << mbits) - 56u : 8u;
+          const uint32_t oz = (kz == 7) ? (512u << (2 * mbits)) - 448u : 64u;
           if (__all(all)) {
             typename MC::T m[8];
 #pragma unroll

@@ -184,9 +184,12 @@ __global__ void __launch_bounds__(256) mirror_fill_kernel(const uint4* __restric
 #define ITM_MIRROR_FLOAT_TYPES 0
 #endif
 static bool mirror_is_float(const itm_scene* s) { return s->cfg.voxelType == ITM_VOXEL_F || s->cfg.voxelType == ITM_VOXEL_F_RGB; }
+// side of the mirror's cube in blocks, and half of it: the DENSE form's is chosen per scene (itm_types.h, mirror_dense_bits)
+static int mirror_side(const itm_scene* s) { return s->org.mMaxPages < 0 ? (1 << mirror_dense_bits(s->org)) : kMirrorSide; }
+static size_t mirror_dense_cells(int bits) { return (size_t)1 << (3 * bits); }
 // every voxel of every page of the pool "no block here" (-32768 per short, all ones per float), no page handed out (scene creation only)
 static hipError_t mirror_clear(itm_scene* s, hipStream_t st) {
-  const size_t voxels = s->org.mMaxPages < 0 ? kMirrorCells * 512 : (size_t)s->mirrorPages * kPageBlocks * 512;
+  const size_t voxels = s->org.mMaxPages < 0 ? mirror_dense_cells(mirror_dense_bits(s->org)) * 512 : (size_t)s->mirrorPages * kPageBlocks * 512;
   hipError_t e = mirror_is_float(s) ? hipMemsetAsync(s->sdfMirror, 0xff, voxels * 4, st) : hipMemsetD16Async((unsigned short*)s->sdfMirror, (unsigned short)0x8000, voxels, st);
   if (e == hipSuccess && s->org.mTable) e = hipMemsetAsync(s->org.mTable, 0xff, kMirrorTableCells * 4, st);
   if (e == hipSuccess && s->org.mPages) e = hipMemsetAsync(s->org.mPages, 0, 4, st);
@@ -266,12 +269,13 @@ int accel_place(itm_scene* s, const float* invM, hipStream_t st) {
   AccelOrigin o = s->org;
   const int dOrg[3] = {o.dx, o.dy, o.dz}, mOrg[3] = {o.mx, o.my, o.mz};
   const bool moveDir = !s->orgPlaced || !cube_keeps(dOrg, kDirHalf, m, rho);
-  const bool moveMir = !s->orgPlaced || !cube_keeps(mOrg, kMirrorHalf, m, rho);
+  const int mHalf = mirror_side(s) / 2;
+  const bool moveMir = !s->orgPlaced || !cube_keeps(mOrg, mHalf, m, rho);
   if (!moveDir && !moveMir) return ITM_OK;
   // a cube smaller than the view is centred further towards the camera (the near part of the frustum holds most rays' steps)
   auto centre = [&](int half, int k) { const double ahead = fmin(reach * 0.5, (double)half * 0.5); return round4(cb[k] + dir[k] / len * ahead); };
   if (moveDir) { o.dx = centre(kDirHalf, 0) - kDirHalf; o.dy = centre(kDirHalf, 1) - kDirHalf; o.dz = centre(kDirHalf, 2) - kDirHalf; }
-  if (moveMir) { o.mx = centre(kMirrorHalf, 0) - kMirrorHalf; o.my = centre(kMirrorHalf, 1) - kMirrorHalf; o.mz = centre(kMirrorHalf, 2) - kMirrorHalf; }
+  if (moveMir) { o.mx = centre(mHalf, 0) - mHalf; o.my = centre(mHalf, 1) - mHalf; o.mz = centre(mHalf, 2) - mHalf; }
   const bool first = !s->orgPlaced;
   s->orgPlaced = true;
   if (first) { s->org = o; return ITM_OK; }       // nothing allocated yet: the cubes are empty wherever they lie
@@ -299,7 +303,7 @@ static void accel_place_for_table(itm_scene* s, const HashEntry* entries, size_t
   if (!any) { s->orgPlaced = false; return; }
   const int c[3] = {round4((lo[0] + hi[0]) * 0.5), round4((lo[1] + hi[1]) * 0.5), round4((lo[2] + hi[2]) * 0.5)};
   s->org.dx = c[0] - kDirHalf; s->org.dy = c[1] - kDirHalf; s->org.dz = c[2] - kDirHalf;
-  s->org.mx = c[0] - kMirrorHalf; s->org.my = c[1] - kMirrorHalf; s->org.mz = c[2] - kMirrorHalf;
+  { const int mHalf = mirror_side(s) / 2; s->org.mx = c[0] - mHalf; s->org.my = c[1] - mHalf; s->org.mz = c[2] - mHalf; }
   s->orgPlaced = true;
 }
 
@@ -373,7 +377,7 @@ static void* buffer_of(const itm_scene* s, const itm_render_state* rs, int which
   size_t P = (size_t)rs->w * rs->h;
   switch (which) {
     case ITM_BUF_VISIBLE_IDS: if (rs->hash) { *bytes = (size_t)rs->capIds * 4; return rs->visibleIds; } break;
-    case ITM_BUF_VISIBLE_TYPE: if (rs->hash) { *bytes = (size_t)rs->scene->noTotalEntries; return rs->visibleType; } break;
+    case ITM_BUF_VISIBLE_TYPE: if (rs->hash && rs->scene) { *bytes = (size_t)rs->scene->noTotalEntries; return rs->visibleType; } break;      // (an orphaned render state -- its scene was destroyed first -- no longer knows the table's size)
     case ITM_BUF_RANGE_IMAGE: *bytes = P * 8; return rs->range;
     case ITM_BUF_RAYCAST_RESULT: *bytes = P * 16; return rs->raycast;
     case ITM_BUF_RAYCAST_IMAGE: *bytes = P * 4; return rs->image;
@@ -415,14 +419,20 @@ static void free_rs(itm_render_state* r) {
   // r->scene is null when the scene was destroyed first (free_scene above): then nothing is recorded on r any more and there is no
   // scene to tell.  Otherwise calls recorded on it still happen (pending.hip: the host made them, the reference would have executed
   // them; the recorded view's images must still be valid -- see itm_scene_set_deferred_fusion in the header).
-  if (r->scene) {
-    (void)flush_deferred(r);
+  // (r->scene is read under the registry's lock: free_scene clears it under the same lock, possibly on another thread)
+  bool haveScene;
+  { std::lock_guard<std::mutex> lock(g_rsRegistryMutex); haveScene = r->scene != nullptr; }
+  if (haveScene) (void)flush_deferred(r);
+  {
     std::lock_guard<std::mutex> lock(g_rsRegistryMutex);
     itm_scene* s = const_cast<itm_scene*>(r->scene);
-    if (s->aheadRs == r) s->aheadRs = nullptr;
-    for (size_t i = 0; i < s->renderStates.size(); ++i)
-      if (s->renderStates[i] == r) { s->renderStates[i] = s->renderStates.back(); s->renderStates.pop_back(); break; }
-  } else forget_deferred(r);
+    if (s) {
+      if (s->aheadRs == r) s->aheadRs = nullptr;
+      for (size_t i = 0; i < s->renderStates.size(); ++i)
+        if (s->renderStates[i] == r) { s->renderStates[i] = s->renderStates.back(); s->renderStates.pop_back(); break; }
+    }
+  }
+  forget_deferred(r);
   (void)hipFree(r->range); (void)hipFree(r->raycast); (void)hipFree(r->fwdProj); (void)hipFree(r->missing);
   (void)hipFree(r->image); (void)hipFree(r->visibleIds); (void)hipFree(r->visibleType); (void)hipFree(r->counters);
   (void)hipFree(r->projBuf); (void)hipFree(r->rangePartials); (void)hipFree(r->pixScratch); (void)hipFree(r->pixChunk); (void)hipFree(r->viewFlags); (void)hipFree(r->viewChunkVis);
@@ -467,7 +477,7 @@ int itm_host_free(void* p) { ITM_HIP(hipHostFree(p)); return ITM_OK; }
 int itm_host_register(void* p, size_t n) {
   if (!p || !n) return set_error(ITM_ERR_INVALID, "null pointer / empty range");
   const hipError_t e = hipHostRegister(p, n, hipHostRegisterDefault);
-  if (e == hipErrorHostMemoryAlreadyRegistered) { (void)hipGetLastError(); return ITM_OK; }
+  if (e == hipErrorHostMemoryAlreadyRegistered) { (void)hipGetLastError(); return ITM_ALREADY_REGISTERED; }      // usable, but not the caller's to unregister
   if (e != hipSuccess) return hip_fail(e, "hipHostRegister", __FILE__, __LINE__);
   return ITM_OK;
 }
@@ -561,7 +571,18 @@ int itm_scene_create(const itm_scene_config* cfg_in, const itm_scene_params* prm
   if (cfg.indexType == ITM_INDEX_HASH && s->dirPtr && !g_debug_no_sdf_mirror && (ITM_MIRROR_FLOAT_TYPES || !mirror_is_float(s))) {
     const char* mode = getenv("ITM_MIRROR");
     const size_t voxBytes = mirror_is_float(s) ? 4 : 2;
-    const size_t pageBytes = (size_t)kPageBlocks * 512 * voxBytes, denseBytes = kMirrorCells * 512 * voxBytes;
+    // the dense cube's side: the smallest power of two of blocks that is at least 1.25 x the view's reach (viewFrustum_max in blocks + 2:
+    // accel_place keeps the frustum's ball inside, or the cube's centre within a quarter of its side of the ball's) -- 128 for the
+    // reference's 3 m frustum at 4 mm voxels (2.1 GB), 256 at 2 mm (17 GB); ITM_MIRROR_BITS = 6 .. 8 overrides (measurements)
+    int denseBits = kMirrorBits;
+    {
+      const double bs = (double)s->prm.voxelSize * kBlockSide;
+      const double reach = bs > 0.0 ? (double)s->prm.viewFrustum_max / bs + 2.0 : 1e9;
+      denseBits = 6;
+      while (denseBits < kMirrorBits && (double)(1 << denseBits) < 1.25 * reach) ++denseBits;
+      if (const char* e = getenv("ITM_MIRROR_BITS")) { const int v = atoi(e); if (v >= 5 && v <= kMirrorBits) denseBits = v; }
+    }
+    const size_t pageBytes = (size_t)kPageBlocks * 512 * voxBytes, denseBytes = mirror_dense_cells(denseBits) * 512 * voxBytes;
     int pages = (int)(((size_t)768 << 20) / pageBytes);
     if (const char* e = getenv("ITM_MIRROR_PAGES")) { const int v = atoi(e); if (v > 0) pages = v; }
     size_t freeB = 0, totalB = 0;
@@ -575,7 +596,8 @@ int itm_scene_create(const itm_scene_config* cfg_in, const itm_scene_params* prm
       s->sdfMirror = nullptr; s->org.mTable = nullptr; s->org.mPages = nullptr; s->org.mMaxPages = 0; s->mirrorPages = 0;
     };
     if (dense) {
-      s->org.mMaxPages = -1;
+      s->org.mMaxPages = -denseBits;
+      { const int half = 1 << (denseBits - 1); s->org.mx = -half; s->org.my = -half; s->org.mz = -half + half / 2; }      // (until the first view places it)
       if (hipMalloc(&s->sdfMirror, denseBytes) != hipSuccess || mirror_clear(s, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) drop();
     } else if (paged) {
       s->mirrorPages = pages;
@@ -633,7 +655,7 @@ int itm_scene_accel_info(const itm_scene* s, itm_accel_info* out) {
   memset(out, 0, sizeof *out);
   out->directory_bytes = s->dirPtr ? (int64_t)(kDirCells * 4) : 0;
   out->slot_directory_bytes = s->dirSlot ? (int64_t)(kDirCells * 4) : 0;
-  out->mirror_bytes = !s->sdfMirror ? 0 : s->org.mMaxPages < 0 ? (int64_t)(kMirrorCells * 512 * (mirror_is_float(s) ? 4 : 2))
+  out->mirror_bytes = !s->sdfMirror ? 0 : s->org.mMaxPages < 0 ? (int64_t)(mirror_dense_cells(mirror_dense_bits(s->org)) * 512 * (mirror_is_float(s) ? 4 : 2))
                                                                   : (int64_t)((size_t)s->mirrorPages * kPageBlocks * 512 * (mirror_is_float(s) ? 4 : 2) + kMirrorTableCells * 4);
   out->mirror_pages = s->mirrorPages;          // 0 for the dense form
   out->mirror_pages_mapped = 0;
@@ -889,6 +911,7 @@ int itm_upload(itm_scene* s, itm_render_state* rs, int which, const void* src, s
 
 int itm_export_visible_record(const itm_render_state* rs, const float M_d[16], int max_ids, void* dst, itm_stream stream) {
   if (!rs || !rs->hash || !dst || !M_d || max_ids < 0) return set_error(ITM_ERR_INVALID, "bad argument");
+  if (!rs->scene) return set_error(ITM_ERR_INVALID, "the render state's scene has been destroyed");
   { const int rc = enter_scene(rs->scene, rs); if (rc) return rc; }
   Mat4 M; memcpy(M.m, M_d, 64);
   int n = (max_ids > 17 ? max_ids : 17);

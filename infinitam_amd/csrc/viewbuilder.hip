@@ -321,8 +321,16 @@ int itm_depth_stager_set_conversion(itm_depth_stager* g, int calibType, float c0
   if (!g || (calibType != 0 && calibType != 1)) return set_error(ITM_ERR_INVALID, "bad argument");
   if (g->tail.load(std::memory_order_acquire) != g->head.load(std::memory_order_acquire)) return set_error(ITM_ERR_INVALID, "frames are waiting in the ring");
   if (g->depth.empty()) {
-    g->depth.assign(g->slots, nullptr);
-    for (int i = 0; i < g->slots; ++i) ITM_HIP(hipMalloc((void**)&g->depth[i], (size_t)g->w * g->h * sizeof(float)));
+    // all slots or none: a partly filled vector would pass for "allocated" on a retry, and the converting copy would write through a null slot
+    std::vector<float*> imgs((size_t)g->slots, nullptr);
+    for (int i = 0; i < g->slots; ++i) {
+      const hipError_t e = hipMalloc((void**)&imgs[i], (size_t)g->w * g->h * sizeof(float));
+      if (e != hipSuccess) {
+        for (float* q : imgs) if (q) (void)hipFree(q);
+        return hip_fail(e, "hipMalloc(stager float images)", __FILE__, __LINE__);
+      }
+    }
+    g->depth = imgs;
   }
   g->calibType = calibType; g->c0 = c0; g->c1 = c1; g->fx = fx;
   return ITM_OK;

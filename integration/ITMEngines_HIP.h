@@ -110,7 +110,9 @@ struct HipRegistry {
   };
   std::map<const void*, Stage> views;
   // the ICP maps / point cloud of a tracking state in HBM (trackingState->pointCloud->locations / ->colours)
-  struct Maps { void* points = nullptr; void* normals = nullptr; size_t pixels = 0, count = 0; bool hostStale = false; const void* locationsImage = nullptr; };      // count: elements the last call wrote
+  // count: elements the last call wrote; icpMaps: what lies in HBM are the maps of the last CreateICPMaps and nothing has replaced them
+  // since (CreatePointCloud writes a point list into the same buffers; HipMarkTrackingStateHostWritten: the host rewrote its image)
+  struct Maps { void* points = nullptr; void* normals = nullptr; size_t pixels = 0, count = 0; bool hostStale = false, icpMaps = false; const void* locationsImage = nullptr; };
   std::map<const void*, Maps> maps;
   static HipRegistry& Get() { static HipRegistry r; return r; }
   static void Free(Stage& st) {
@@ -205,7 +207,7 @@ inline HipRegistry::Maps& HipMapsOf(const ITMTrackingState* ts) {
   if (m.pixels != px) {
     itm_dev_free(m.points); itm_dev_free(m.normals);
     HipCheck(itm_dev_malloc(&m.points, px * 16), "dev_malloc"); HipCheck(itm_dev_malloc(&m.normals, px * 16), "dev_malloc");
-    m.pixels = px; m.hostStale = false; m.count = 0;
+    m.pixels = px; m.hostStale = false; m.icpMaps = false; m.count = 0;
   }
   m.locationsImage = ts->pointCloud->locations;
   return m;
@@ -216,6 +218,7 @@ inline HipRegistry::Maps& HipMapsOf(const ITMTrackingState* ts) {
 inline void HipPin(void*& pinned, const void* host, size_t bytes) {
   if (pinned == host) return;
   if (pinned) itm_host_unregister(pinned);
+  // only a registration made HERE is recorded (and later undone): ITM_ALREADY_REGISTERED means the range is someone else's
   pinned = (itm_host_register(const_cast<void*>(host), bytes) == ITM_OK) ? const_cast<void*>(host) : nullptr;
 }
 
@@ -309,6 +312,12 @@ inline void HipSyncTrackingStateToHost(ITMTrackingState* ts) {
   HipCheck(itm_memcpy_d2h(ts->pointCloud->locations->GetData(MEMORYDEVICE_CPU), m.points, n, 0), "memcpy_d2h");
   HipCheck(HipDownload(ts->pointCloud->colours->GetData(MEMORYDEVICE_CPU), m.normals, n, 0), "memcpy_d2h");
   m.hostStale = false;
+}
+// "The host wrote this tracking state's point cloud images itself" (a CPU visualisation engine, a file): the copies in HBM no longer
+// say what the images say -- the depth tracker uploads the host images again instead of taking the maps in HBM.
+inline void HipMarkTrackingStateHostWritten(const ITMTrackingState* ts) {
+  auto it = HipRegistry::Get().maps.find(ts);
+  if (it != HipRegistry::Get().maps.end()) { it->second.hostStale = false; it->second.icpMaps = false; }
 }
 // ... of a view whose float depth was produced in HBM (ITMViewBuilder_HIP)
 inline void HipSyncViewToHost(ITMView* view) {
@@ -426,7 +435,7 @@ class ITMVisualisationEngine_HIP : public ITMVisualisationEngine<TVoxel, TIndex>
     HipCheck(itm_create_point_cloud(Dev(), &v, HipRenderStateOf(renderState), skipPoints ? 1 : 0, (float*)m.points, (float*)m.normals, 0), "CreatePointCloud");
     itm_counters c; HipCheck(itm_get_counters(Dev(), HipRenderStateOf(renderState), &c, 0), "get_counters");
     trackingState->pointCloud->noTotalPoints = c.noTotalPoints;
-    m.count = (size_t)c.noTotalPoints; m.hostStale = true;
+    m.count = (size_t)c.noTotalPoints; m.hostStale = true; m.icpMaps = false;
     if (HipEager()) HipSyncTrackingStateToHost(trackingState);
     trackingState->pose_pointCloud->SetFrom(trackingState->pose_d);
     Mirror(renderState, false, true, false);
@@ -435,7 +444,7 @@ class ITMVisualisationEngine_HIP : public ITMVisualisationEngine<TVoxel, TIndex>
     itm_view v = HipStageView(view, trackingState->pose_d, Colour());
     HipRegistry::Maps& m = HipMapsOf(trackingState);
     HipCheck(itm_create_icp_maps(Dev(), &v, HipRenderStateOf(renderState), (float*)m.points, (float*)m.normals, 0), "CreateICPMaps");
-    m.count = m.pixels; m.hostStale = true;
+    m.count = m.pixels; m.hostStale = true; m.icpMaps = true;
     if (HipEager()) HipSyncTrackingStateToHost(trackingState);
     trackingState->pose_pointCloud->SetFrom(trackingState->pose_d);   // ITMVisualisationEngine_CPU.cpp CreateICPMaps
     Mirror(renderState, false, true, true);

@@ -36,8 +36,14 @@ class ITMDepthTracker_HIP : public ITMDepthTracker {
     if (levelId > lastLevel) {
       mapPoints = devPoints; mapNormals = devNormals;
       const HipRegistry::Maps* fresh = nullptr;
-      for (auto& kv : HipRegistry::Get().maps)
-        if (kv.second.locationsImage == (const void*)sceneHierarchyLevel->pointsMap && kv.second.pixels == mp && kv.second.count == mp) fresh = &kv.second;
+      for (auto& kv : HipRegistry::Get().maps) {
+        if (kv.second.locationsImage != (const void*)sceneHierarchyLevel->pointsMap) continue;
+        // the maps in HBM only while they ARE the last CreateICPMaps' (icpMaps: not a point list of CreatePointCloud, not superseded by
+        // a host-side write, HipMarkTrackingStateHostWritten); otherwise the host image is uploaded -- after bringing it up to date when
+        // the newest content still lies in HBM only (HIP_MIRROR_ON_DEMAND)
+        if (kv.second.icpMaps && kv.second.pixels == mp && kv.second.count == mp) fresh = &kv.second;
+        else if (kv.second.hostStale) HipSyncTrackingStateToHost((ITMTrackingState*)kv.first);
+      }
       if (fresh) { mapPoints = fresh->points; mapNormals = fresh->normals; }
       else {
         HipCheck(itm_memcpy_h2d(devPoints, sceneHierarchyLevel->pointsMap->GetData(MEMORYDEVICE_CPU), mp * 16, 0), "memcpy_h2d");

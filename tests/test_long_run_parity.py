@@ -40,10 +40,22 @@ class _CachedDepth:
         return self.cache[key]
 
 
-def lockstep(hip, oracle, sc, checkpoints, golden=None):
+class _EachDepth:
+    """A trajectory without a period: frame k is synthesised when first asked for and handed to both sessions."""
+
+    def __init__(self, sc):
+        self.sc, self.k, self.frame = sc, -1, None
+
+    def __call__(self, k):
+        if k != self.k:
+            self.k, self.frame = k, Scenario.depth(self.sc, k)
+        return self.frame
+
+
+def lockstep(hip, oracle, sc, checkpoints, golden=None, periodic=True):
     """Both backends frame by frame.  golden = (frame index, scenario, full): the HIP state after that frame against the committed
-    reference vectors of that scenario."""
-    depth = _CachedDepth(sc)
+    reference vectors of that scenario.  periodic=False: a trajectory that does not repeat (every frame synthesised, once for both)."""
+    depth = _CachedDepth(sc) if periodic else _EachDepth(sc)
     sc.__dict__["depth"] = depth            # instance attribute shadows the method: both sessions read the same cached frames
     a, b = T.Session(hip, sc), T.Session(oracle, sc)
     try:
@@ -83,6 +95,23 @@ def test_config2_220_frames_through_the_four_calls(hip, oracle):
     # the state the test is about: weights at maxW, an allocation with nothing left to allocate
     assert saturated > 1_000_000, saturated
     assert counters[-1]["lastFreeBlockId"] == counters[119]["lastFreeBlockId"], "blocks were still being allocated in the third period"
+
+
+CFG2_EXPLORING = Scenario(name="config2_exploring_160_frames", voxelSize=0.004, frames=160, trajectory="parity", localBlockNum=0x40000)
+
+
+@pytest.mark.gpu
+def test_config2_exploring_camera_through_the_four_calls(hip, oracle):
+    """The state bench.py's `exploring` leg times: config 2 at full size under a camera that never turns back (1 cm per frame along x).
+    Unlike the periodic trajectory nearly EVERY frame requests and allocates blocks (allocation sweep, reference
+    DeviceSpecific/CPU/ITMSceneReconstructionEngine_CPU.cpp:175-227), the excess list is drawn from in nearly every frame, blocks
+    leave the frustum and are re-tested and dropped (:229-269).  Lock-step with the oracle through the recorded four calls: counters,
+    visible ids and the shaded image after every frame, the whole state after frames 80 and 160."""
+    counters, _ = lockstep(hip, oracle, CFG2_EXPLORING, checkpoints={80, 160}, periodic=False)
+    alloc = [a["lastFreeBlockId"] - b["lastFreeBlockId"] for a, b in zip(counters[:-1], counters[1:])]
+    assert sum(1 for a in alloc if a > 0) >= 0.9 * len(alloc) and sum(alloc) > 8000, "the exploring camera should allocate in nearly every frame: %s" % alloc
+    used_excess = (0x20000 - 1) - counters[-1]["lastFreeExcessListId"]
+    assert used_excess > 1000, used_excess
 
 
 @pytest.mark.gpu
