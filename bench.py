@@ -1030,7 +1030,7 @@ def read_roofline(config, wl, prof, counters, scene):
     alg = algorithmic_bytes(config, wl, counters)
     achieved = alg / avg_s / 1e9
     traffic_all = {}
-    for tname in ("traffic_r05.json", "traffic_r04.json", "traffic_r03.json", "traffic_r02.json"):        # the newest PMC collection that has this config
+    for tname in ("traffic_r06.json", "traffic_r05.json", "traffic_r04.json", "traffic_r03.json", "traffic_r02.json"):        # the newest PMC collection that has this config
         tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath):
             with open(tpath) as f:

@@ -343,8 +343,11 @@ __device__ inline void integrate_hash_body(int wgIdx, int wgCount, const int32_t
   load_item<VX>(cur, (i % kItemsPerBlock) * kSlices, lane, vba, r);
   // (the next item's VOXELS in a second register set, so that the launch could have no more waves than the device holds -- every item in
   // flight from the first microsecond -- was built and measured in round 6 on BASELINE configs[1]: 768 workgroups 21.9-22.3 us, 1 024:
-  // 20.5, against 19.0-19.4 for 2 048 workgroups without it.  The launch is bound by vector-instruction issue, not by the chain: a wave
-  // with two items takes twice as long as a wave with one, whatever is prefetched.)
+  // 20.5, against 19.0-19.4 for 2 048 workgroups without it; and so was a wave that owns TWO blocks and works on them together -- sixteen
+  // runs, sixteen projections, sixteen gathers, one wait, 80 registers, every block of the frame in flight from the first microsecond on
+  // 768 resident workgroups: 20.5-21.0 us, the workgroups then last 9-18 us each.  A wave with two blocks takes twice as long as a wave
+  // with one, whatever is prefetched or interleaved: the launch is bound by what the blocks cost to work through, not by the chain
+  // (profiles/r6_notes.md).)
   for (;;) {
     const bool more = nxt < nItems;
     uint4 rawAhead = hash[idNext];

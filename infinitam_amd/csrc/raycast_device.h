@@ -144,6 +144,31 @@ __device__ inline long long locate_voxel(const VolumeView& vol, int px, int py, 
   }
 }
 
+// Dense volumes on the ray-march path: the same index as locate_voxel<true> in 32 bits, 0xffffffff = no voxel there (a dense scene holds
+// fewer than 2^32 - 1 voxels: checked at creation, scene.hip).  The 64-bit form cost the issue-bound dense ray cast two quarter-rate 64-bit
+// multiply-adds in an exec-masked branch, two 64-bit comparisons and a pair of selects per voxel read (found in the ISA, round 6); here
+// the products are 24-bit multiply-adds when the slice fits (sx * sy < 2^24 and every side < 2^24, a wave-uniform test).
+// (qx, qy, qz): the point relative to the volume's first voxel, as unsigned (0 <= q < size in one comparison per axis).  Returns the
+// linear index, 0 for a point without a voxel (always a valid address); `in` says which.
+__device__ inline uint32_t dense_lin(const VolumeView& vol, uint32_t qx, uint32_t qy, uint32_t qz, bool& in, bool use = true) {
+  in = use & (qx < (uint32_t)vol.sx) & (qy < (uint32_t)vol.sy) & (qz < (uint32_t)vol.sz);
+  const uint32_t sx = (uint32_t)vol.sx, sxy = (uint32_t)(vol.sx * vol.sy);
+  uint32_t lin;
+  if ((((uint32_t)vol.sx | (uint32_t)vol.sy | (uint32_t)vol.sz | sxy) >> 24) == 0u) {      // (uniform)
+    // two full-rate 24-bit multiply-adds (written out: from __umul24 with a scalar factor the compiler makes a mask and the quarter-rate
+    // v_mul_lo_u32).  A lane outside the volume may have q >= 2^24: its product is not used.
+    uint32_t t;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(t) : "v"(qy), "s"(sx), "v"(qx));
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(lin) : "v"(qz), "s"(sxy), "v"(t));
+  } else lin = qx + qy * sx + qz * sxy;
+  uint32_t r = in ? lin : 0u;
+  asm("" : "+v"(r));      // (the select stays in front of the 64-bit address arithmetic: behind it, it is two selects on a shifted pair)
+  return r;
+}
+__device__ inline uint32_t dense_lin(const VolumeView& vol, int px, int py, int pz, bool& in) {
+  return dense_lin(vol, (uint32_t)(px - vol.ox), (uint32_t)(py - vol.oy), (uint32_t)(pz - vol.oz), in);
+}
+
 // raw (unconverted) sdf of the voxel at an integer point; the default voxel when absent
 template <class VX, bool DENSE, class VOL = VolumeView>
 __device__ inline float read_raw_sdf(const VOL& vol, int px, int py, int pz, bool& found, BlockCache& cache) {
@@ -183,15 +208,17 @@ __device__ inline float read_raw_sdf(const VOL& vol, int px, int py, int pz, boo
       if (covered) { found = present; return value; }
     }
   }
-  const long long a = locate_voxel<DENSE>(vol, px, py, pz, cache);
-  found = a >= 0;
   if constexpr (DENSE) {
     // the load is unconditional (voxel 0 for a position outside the volume): inside an exec-masked branch the compiler waits for it there
-    const float v = VX::load_raw_sdf(vol.vba, found ? (size_t)a : (size_t)0);
+    const uint32_t a = dense_lin(vol, px, py, pz, found);
+    const float v = VX::load_raw_sdf(vol.vba, (size_t)a);
     return found ? v : (VX::kShort ? 32767.0f : 1.0f);
+  } else {
+    const long long a = locate_voxel<DENSE>(vol, px, py, pz, cache);
+    found = a >= 0;
+    if (!found) return VX::kShort ? 32767.0f : 1.0f;
+    return VX::load_raw_sdf(vol.vba, (size_t)a);
   }
-  if (!found) return VX::kShort ? 32767.0f : 1.0f;
-  return VX::load_raw_sdf(vol.vba, (size_t)a);
 }
 
 template <class VX, bool DENSE, class VOL = VolumeView>
@@ -238,9 +265,7 @@ struct Corners {
     if (DENSE) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        const long long a = locate_voxel<true>(vol, ix + (c & 1), iy + ((c >> 1) & 1), iz + (c >> 2), cache);
-        present[c] = a >= 0;
-        addr[c] = present[c] ? (size_t)a : (size_t)0;
+        addr[c] = (size_t)dense_lin(vol, ix + (c & 1), iy + ((c >> 1) & 1), iz + (c >> 2), present[c]);
       }
     } else {
       {
@@ -486,21 +511,20 @@ __device__ inline int far_run(const VolumeView& vol, bool runner, float& px, flo
   {
     float qx = px, qy = py, qz = pz;
     uint32_t at[K];
+    bool in[K];
     float raw[K];
     // (all addresses first, then all loads: interleaved, the register allocator reused a load's destination inside the next address's
     // 64-bit multiply-add and the wave waited for the load there)
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-      const uint32_t ix = (uint32_t)((int)round_ref(qx) - vol.ox), iy = (uint32_t)((int)round_ref(qy) - vol.oy), iz = (uint32_t)((int)round_ref(qz) - vol.oz);
-      const bool use = runner & (ix < (uint32_t)vol.sx) & (iy < (uint32_t)vol.sy) & (iz < (uint32_t)vol.sz);      // (unsigned: 0 <= i < size in one comparison)
-      at[j] = use ? (ix + iy * (uint32_t)vol.sx + iz * (uint32_t)(vol.sx * vol.sy)) : 0xffffffffu;
+      at[j] = dense_lin(vol, (uint32_t)((int)round_ref(qx) - vol.ox), (uint32_t)((int)round_ref(qy) - vol.oy), (uint32_t)((int)round_ref(qz) - vol.oz), in[j], runner);
       qx += sx; qy += sy; qz += sz;
     }
     asm volatile("" ::: "memory");
 #pragma unroll
-    for (int j = 0; j < K; ++j) raw[j] = VX::load_raw_sdf(vol.vba, at[j] != 0xffffffffu ? (size_t)at[j] : (size_t)0);   // voxel 0 / no use for the others
+    for (int j = 0; j < K; ++j) raw[j] = VX::load_raw_sdf(vol.vba, (size_t)at[j]);   // voxel 0 / no use for the others
 #pragma unroll
-    for (int j = 0; j < K; ++j) stop |= (((raw[j] != farRaw) | (at[j] == 0xffffffffu)) ? 1u : 0u) << j;      // outside the volume / no runner: stops the run
+    for (int j = 0; j < K; ++j) stop |= (((raw[j] != farRaw) | !in[j]) ? 1u : 0u) << j;      // outside the volume / no runner: stops the run
   }
   const int n = runner ? __builtin_ctz(stop | (1u << K)) : 0;      // positions that read exactly 1, counted from the first
   int taken = 0;

@@ -525,6 +525,9 @@ int itm_scene_create(const itm_scene_config* cfg_in, const itm_scene_params* prm
     if ((cfg.bucketNum + cfg.excessNum) % 8 != 0) return set_error(ITM_ERR_INVALID, "bucketNum + excessNum must be a multiple of 8");
   } else {
     if (cfg.denseSize[0] <= 0 || cfg.denseSize[1] <= 0 || cfg.denseSize[2] <= 0) return set_error(ITM_ERR_INVALID, "dense size must be positive");
+    // (the ray march indexes a dense volume with 32 bits, 0xffffffff = "no voxel": raycast_device.h dense_lin)
+    if ((unsigned long long)cfg.denseSize[0] * (unsigned long long)cfg.denseSize[1] * (unsigned long long)cfg.denseSize[2] >= 0xffffffffull)
+      return set_error(ITM_ERR_INVALID, "dense volume too large (2^32 - 1 voxels or more)");
   }
   if (prm->voxelSize <= 0 || prm->mu <= 0 || prm->maxW <= 0 || prm->maxW > 255) return set_error(ITM_ERR_INVALID, "bad scene parameters");
 

@@ -410,6 +410,8 @@ __global__ void __launch_bounds__(256) raycast_kernel(VolumeView volIn, const fl
     __syncthreads();
     // ---- phase 2: the parked rays, re-packed from lane 0 upwards ----
     const int n = parkCount;
+    // (the parked rays dealt out to the four waves in turn instead of 64 per wave -- fewer rays, fewer distinct states per wave -- was
+    // measured in round 6: BASELINE configs[1] 35.5 -> 37.9 us, configs[4] 112 -> 122.5 us; profiles/r6_notes.md)
     if ((int)threadIdx.x < n) {
       const float4 q = parkState[threadIdx.x];
       const int src = parkSource[threadIdx.x];
