@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 6 final measurements: GPU suite (+ the hash tests under the paged mirror), smoke, the default bench line (other_configs, exploring, parity
 # checks, CPU samples), the driver's 20-step form, secondary legs, rocprofv3 kernel stats of each configuration, HBM traffic (FETCH_SIZE /
-# WRITE_SIZE, separate passes, every kernel of the frame) and the SQ counters of the integration kernels  (-> profiles/r6_*, traffic_r06.json)
+# WRITE_SIZE, separate passes, every kernel of the frame)  (-> profiles/r6_*, traffic_r06.json; SQ / TA / TCP counters: r6_counters.sh)
 cd "$(dirname "$0")/../.."
 R=$PWD; O=gpurun_out/r6final; rm -rf $O; mkdir -p $O
 if [ -z "$SKIP_TESTS" ]; then
@@ -38,16 +38,6 @@ for c in 2 3 5; do
     timeout 900 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $R/$O/pmc_c${c}_$ctr -o p -- python3 $R/bench.py --config $c --steps 20 --warmup 5 --min-measured-s 0 --no-cpu-baseline --no-extra-legs --timer-frames 1 > $R/$O/pmc_c${c}_$ctr.log 2>&1
   done
 done
-# SQ counters of the integration kernels
-P1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD"
-P3="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INST_CYCLES_VMEM"
-for job in "2 integrate_project_kernel c2int" "5 integrate_hash_kernel c5int"; do
-  set -- $job; c=$1; rx=$2; tag=$3
-  for pass in a c; do
-    case $pass in a) P="$P1";; c) P="$P3";; esac
-    timeout 900 rocprofv3 --kernel-trace --pmc $P --kernel-include-regex "$rx" --output-format csv -d $R/$O/sq_${tag}_$pass -o p -- python3 $R/bench.py --config $c --steps 20 --warmup 5 --min-measured-s 0 --no-cpu-baseline --no-extra-legs --timer-frames 1 > $R/$O/sq_${tag}_$pass.log 2>&1
-  done
-done
 cd $R
 python3 - <<'PY'
 import csv, glob, json, collections
@@ -69,17 +59,6 @@ for c in (2, 3, 5):
     traffic[f"config{c}"] = per
 json.dump(traffic, open(f"{O}/traffic_raw.json", "w"), indent=1)
 print(json.dumps(traffic, indent=1)[:6000])
-sq = {}
-for d in sorted(glob.glob(O + "/sq_*_*")):
-    if d.endswith(".log"): continue
-    files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
-    if not files: continue
-    acc = collections.defaultdict(float); n = collections.defaultdict(int)
-    for row in csv.DictReader(open(files[0])):
-        acc[row["Counter_Name"]] += float(row["Counter_Value"]); n[row["Counter_Name"]] += 1
-    tag = d.split("sq_")[1].rsplit("_", 1)[0]
-    e = sq.setdefault(tag, {}); e.update({k: round(acc[k] / max(1, n[k]), 1) for k in acc}); e["launches"] = max(n.values()) if n else 0
-json.dump(sq, open(f"{O}/sq_counters.json", "w"), indent=1); print(json.dumps(sq, indent=1))
 PY
 find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info*" -delete; find $O -name "*counter_collection.csv" -delete
 for c in 2 3 5; do echo "== config $c"; cut -c1-110 $O/stats_c$c/*kernel_stats.csv | head -8; done
