@@ -14,7 +14,7 @@ for job in "${JL[@]}"; do
   set -- $job; c=$1; rx=$2; tag=$3
   for pass in 1 2 3 4 5; do
     eval P=\$S$pass
-    timeout 600 rocprofv3 --kernel-trace --pmc $P --kernel-include-regex "$rx" --output-format csv -d $R/$O/pmc_${tag}_$pass -o p -- python3 $R/bench.py --config $c --steps 20 --warmup 5 --min-measured-s 0 --no-cpu-baseline --no-extra-legs --timer-frames 1 > $R/$O/pmc_${tag}_$pass.log 2>&1 || echo "pass $pass of $tag failed: $(tail -2 $R/$O/pmc_${tag}_$pass.log | cut -c1-200)"
+    timeout 120 rocprofv3 --kernel-trace --pmc $P --kernel-include-regex "$rx" --output-format csv -d $R/$O/pmc_${tag}_$pass -o p -- python3 $R/bench.py --config $c --steps 20 --warmup 5 --min-measured-s 0 --no-cpu-baseline --no-extra-legs --timer-frames 1 > $R/$O/pmc_${tag}_$pass.log 2>&1 || echo "pass $pass of $tag failed: $(tail -2 $R/$O/pmc_${tag}_$pass.log | cut -c1-200)"
   done
 done
 cd $R
